@@ -1,0 +1,211 @@
+"""Independent numpy re-derivation of the forward path, used ONLY to cross-check oracle/ (the C restatement).
+
+Written from the public format definitions (AutoAWQ GEMM packing, AutoGPTQ v1, GGML block layouts, HF Llama),
+deliberately sharing no code with oracle/*.c: dequantises whole matrices with vectorised numpy and runs plain
+matmuls, so an indexing or nibble-order mistake in either implementation shows up as a mismatch.
+"""
+import numpy as np
+
+AWQ_ORDER = [0, 4, 1, 5, 2, 6, 3, 7]  # nibble position of column j inside a word: shift = 4*AWQ_ORDER[j]
+# (/root/reference/src/loader/safetensors/awq.rs:29-32: shifts [0,16,4,20,8,24,12,28])
+
+
+def round_act(x, act):
+    x = np.asarray(x, dtype=np.float32)
+    if act == "f16":
+        return x.astype(np.float16).astype(np.float32)
+    if act == "bf16":
+        u = x.view(np.uint32).astype(np.uint64)
+        return (((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint32) << 16).view(np.float32).reshape(x.shape)
+    return x
+
+
+def awq_dequant(spec):
+    K, N, gs = spec["K"], spec["N"], spec["group_size"]
+    shifts = np.array([4 * p for p in AWQ_ORDER], dtype=np.uint32)
+    qw = spec["qweight"].astype(np.uint32)
+    q = ((qw[:, :, None] >> shifts[None, None, :]) & 0xF).reshape(K, N).astype(np.float32)
+    z = ((spec["qzeros"].astype(np.uint32)[:, :, None] >> shifts[None, None, :]) & 0xF).reshape(K // gs, N)
+    s = spec["scales"].astype(np.float32)
+    g = np.arange(K) // gs
+    return ((q - z[g].astype(np.float32)) * s[g]).T.copy()  # [N, K]
+
+
+def gptq_dequant(spec):
+    K, N, gs = spec["K"], spec["N"], spec["group_size"]
+    sh = (4 * np.arange(8, dtype=np.uint32))
+    qw = spec["qweight"].astype(np.uint32)  # [K/8, N]
+    q = ((qw[:, None, :] >> sh[None, :, None]) & 0xF).reshape(K, N).astype(np.float32)
+    z = ((spec["qzeros"].astype(np.uint32)[:, :, None] >> sh[None, None, :]) & 0xF).reshape(K // gs, N) + 1
+    s = spec["scales"].astype(np.float32)
+    g = spec["g_idx"] if spec.get("g_idx") is not None else np.arange(K) // gs
+    return ((q - z[g].astype(np.float32)) * s[g]).T.copy()
+
+
+def _f16(b):
+    return np.ascontiguousarray(b).view(np.float16).astype(np.float32)
+
+
+def q8_0_dequant(blocks, N, K):
+    b = blocks.reshape(N, K // 32, 34)
+    d = _f16(b[:, :, 0:2]).reshape(N, K // 32, 1)
+    q = b[:, :, 2:].view(np.int8).astype(np.float32)
+    return (d * q).reshape(N, K)
+
+
+def q4_k_dequant(blocks, N, K):
+    nb = K // 256
+    b = blocks.reshape(N, nb, 144)
+    d = _f16(b[:, :, 0:2]).reshape(N, nb, 1)
+    dmin = _f16(b[:, :, 2:4]).reshape(N, nb, 1)
+    sc = b[:, :, 4:16].astype(np.uint32)
+    scales = np.zeros((N, nb, 8), dtype=np.uint32)
+    mins = np.zeros((N, nb, 8), dtype=np.uint32)
+    for j in range(8):
+        if j < 4:
+            scales[:, :, j] = sc[:, :, j] & 63
+            mins[:, :, j] = sc[:, :, j + 4] & 63
+        else:
+            scales[:, :, j] = (sc[:, :, j + 4] & 0xF) | ((sc[:, :, j - 4] >> 6) << 4)
+            mins[:, :, j] = (sc[:, :, j + 4] >> 4) | ((sc[:, :, j] >> 6) << 4)
+    qs = b[:, :, 16:].reshape(N, nb, 4, 32)
+    lo = (qs & 0xF).astype(np.float32)
+    hi = (qs >> 4).astype(np.float32)
+    q = np.stack([lo, hi], axis=3).reshape(N, nb, 8, 32)  # sub-block 2i = low nibbles, 2i+1 = high nibbles
+    w = (d * scales.astype(np.float32))[..., None] * q - (dmin * mins.astype(np.float32))[..., None]
+    return w.reshape(N, K)
+
+
+def q6_k_dequant(blocks, N, K):
+    nb = K // 256
+    b = blocks.reshape(N, nb, 210)
+    ql = b[:, :, 0:128].reshape(N, nb, 2, 64).astype(np.int32)
+    qh = b[:, :, 128:192].reshape(N, nb, 2, 32).astype(np.int32)
+    sc = b[:, :, 192:208].view(np.int8).reshape(N, nb, 2, 8).astype(np.float32)
+    d = _f16(b[:, :, 208:210]).reshape(N, nb, 1, 1)
+    out = np.zeros((N, nb, 2, 128), dtype=np.float32)
+    l = np.arange(32)
+    isx = l // 16
+    q1 = ((ql[..., 0:32] & 0xF) | (((qh >> 0) & 3) << 4)) - 32
+    q2 = ((ql[..., 32:64] & 0xF) | (((qh >> 2) & 3) << 4)) - 32
+    q3 = ((ql[..., 0:32] >> 4) | (((qh >> 4) & 3) << 4)) - 32
+    q4 = ((ql[..., 32:64] >> 4) | (((qh >> 6) & 3) << 4)) - 32
+    out[..., 0:32] = d * sc[..., isx + 0] * q1
+    out[..., 32:64] = d * sc[..., isx + 2] * q2
+    out[..., 64:96] = d * sc[..., isx + 4] * q3
+    out[..., 96:128] = d * sc[..., isx + 6] * q4
+    return out.reshape(N, K)
+
+
+def dequant(spec):
+    k = spec["kind"]
+    if k == "awq":
+        return awq_dequant(spec)
+    if k == "gptq":
+        return gptq_dequant(spec)
+    if k == "gguf":
+        f = {8: q8_0_dequant, 12: q4_k_dequant, 14: q6_k_dequant}[spec["ggml_type"]]
+        return f(spec["blocks"], spec["N"], spec["K"])
+    w = spec["weight"]
+    if w.dtype == np.uint16:
+        return (w.astype(np.uint32) << 16).view(np.float32)
+    return w.astype(np.float32)
+
+
+def linear(spec, x):
+    y = x.astype(np.float32) @ dequant(spec).T
+    if spec.get("bias") is not None:
+        y = y + spec["bias"].astype(np.float32)
+    return y.astype(np.float32)
+
+
+def rope_tables(cfg):
+    hd, P = cfg["head_dim"], cfg["max_seq_len"]
+    inv = 1.0 / (np.float64(cfg["rope_theta"]) ** (np.arange(0, hd, 2, dtype=np.float64) / hd))
+    rs = cfg.get("rope_scaling")
+    if rs and rs["type"] == "linear":
+        inv = inv / rs["factor"]
+    elif rs and rs["type"] == "llama3":
+        f, lo, hi, old = rs["factor"], rs["low_freq_factor"], rs["high_freq_factor"], rs["original_max_position_embeddings"]
+        wl = 2 * np.pi / inv
+        smooth = (old / wl - lo) / (hi - lo)
+        mid = (1 - smooth) * inv / f + smooth * inv
+        inv = np.where(wl > old / lo, inv / f, np.where(wl < old / hi, inv, mid))
+    ang = np.arange(P, dtype=np.float32)[:, None] * inv.astype(np.float32)[None, :]
+    return np.cos(ang.astype(np.float64)).astype(np.float32), np.sin(ang.astype(np.float64)).astype(np.float32)
+
+
+def rope(v, c, s, interleaved):
+    half = v.shape[-1] // 2
+    out = np.empty_like(v)
+    if interleaved:
+        x0, x1 = v[..., 0::2], v[..., 1::2]
+        out[..., 0::2] = x0 * c - x1 * s
+        out[..., 1::2] = x1 * c + x0 * s
+    else:
+        x0, x1 = v[..., :half], v[..., half:]
+        out[..., :half] = x0 * c - x1 * s
+        out[..., half:] = x1 * c + x0 * s
+    return out
+
+
+def rms_norm(x, w, eps, act):
+    rs = 1.0 / np.sqrt(np.mean(x.astype(np.float32) ** 2, axis=-1, keepdims=True, dtype=np.float32) + np.float32(eps))
+    return round_act(w * round_act(x * rs.astype(np.float32), act), act)
+
+
+class NpLlama:
+    """Token-at-a-time numpy forward with a python-list KV cache (small models only)."""
+
+    def __init__(self, model):
+        self.m = model
+        self.cfg = model["config"]
+        self.cos, self.sin = rope_tables(self.cfg)
+        self.W = [{k: dequant(lay[k]) for k in ("q", "k", "v", "o", "gate", "up", "down")} for lay in model["layers"]]
+        self.B = [{k: lay[k].get("bias") for k in ("q", "k", "v", "o", "gate", "up", "down")} for lay in model["layers"]]
+        self.lm = dequant(model["lm_head"])
+        self.emb = dequant(dict(kind="dense", weight=model["embed"]))
+        self.K = [[] for _ in model["layers"]]
+        self.V = [[] for _ in model["layers"]]
+
+    def _lin(self, l, name, x):
+        y = x @ self.W[l][name].T
+        b = self.B[l][name]
+        return (y + b.astype(np.float32)) if b is not None else y
+
+    def step(self, token, pos):
+        c = self.cfg
+        act = c["act_dtype"]
+        R = lambda a: round_act(a, act)
+        nq, nkv, hd = c["n_heads"], c["n_kv_heads"], c["head_dim"]
+        h = R(self.emb[token])
+        prev = None
+        for l, lay in enumerate(self.m["layers"]):
+            if prev is not None:
+                h = R(h + prev)
+            xn = rms_norm(h, lay["attn_norm"], c["rms_eps"], act)
+            q = R(self._lin(l, "q", xn)).reshape(nq, hd)
+            k = R(self._lin(l, "k", xn)).reshape(nkv, hd)
+            v = R(self._lin(l, "v", xn)).reshape(nkv, hd)
+            q = R(rope(q, self.cos[pos], self.sin[pos], c["rope_interleaved"]))
+            k = R(rope(k, self.cos[pos], self.sin[pos], c["rope_interleaved"]))
+            self.K[l].append(k)
+            self.V[l].append(v)
+            Kc = np.stack(self.K[l], axis=1)  # [nkv, T, hd]
+            Vc = np.stack(self.V[l], axis=1)
+            rep = nq // nkv
+            o = np.empty((nq, hd), dtype=np.float32)
+            for hh in range(nq):
+                s = (Kc[hh // rep] @ q[hh]) * np.float32(1.0 / np.sqrt(hd))
+                p = np.exp(s - s.max())
+                o[hh] = (p / p.sum()) @ Vc[hh // rep]
+            o = R(o.reshape(-1))
+            h = R(h + R(self._lin(l, "o", o)))
+            xn = rms_norm(h, lay["ffn_norm"], c["rms_eps"], act)
+            g = R(self._lin(l, "gate", xn))
+            u = R(self._lin(l, "up", xn))
+            a = R(R(g / (1.0 + np.exp(-g))) * u)
+            prev = R(self._lin(l, "down", a))
+        h = R(h + prev)
+        xn = rms_norm(h, self.m["final_norm"], c["rms_eps"], act)
+        return R(xn @ self.lm.T)
