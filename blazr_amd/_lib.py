@@ -1,0 +1,144 @@
+"""ctypes loader for libblazr_hip.so (the C-ABI in include/blazr_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a compute call is made without a
+gfx950 device, it raises.  Nothing here imports oracle/.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libblazr_hip.so")
+_LIB = None
+
+OK, E_INVALID, E_NODEVICE, E_HIP, E_UNSUPPORTED, E_NOTFOUND, E_OOM = 0, -1, -2, -3, -4, -5, -6
+F32, F16, BF16, I64, I32, U32, U8 = range(7)
+ABI_VERSION = 1
+FWD_ALL_LOGITS = 1
+ROPE_NONE, ROPE_LINEAR, ROPE_LLAMA3 = 0, 1, 2
+ARCH_LLAMA = 0
+
+
+class BlazrHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libblazr_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class ModelConfig(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("arch", C.c_int32), ("hidden", C.c_int32), ("n_layers", C.c_int32),
+                ("n_heads", C.c_int32), ("n_kv_heads", C.c_int32), ("head_dim", C.c_int32), ("inter", C.c_int32),
+                ("vocab", C.c_int32), ("max_seq_len", C.c_int32), ("rms_eps", C.c_float), ("act_dtype", C.c_int32),
+                ("tie_embeddings", C.c_int32), ("rope_theta", C.c_float), ("rope_interleaved", C.c_int32),
+                ("rope_scaling", C.c_int32), ("rope_factor", C.c_float), ("rope_low_freq_factor", C.c_float),
+                ("rope_high_freq_factor", C.c_float), ("rope_original_max_pos", C.c_int32), ("reserved", C.c_int32 * 16)]
+
+
+class GenConfig(C.Structure):
+    _fields_ = [("max_tokens", C.c_int32), ("temperature", C.c_float), ("repeat_penalty", C.c_float),
+                ("repeat_last_n", C.c_int32), ("frequency_penalty", C.c_float), ("presence_penalty", C.c_float),
+                ("top_k", C.c_int32), ("top_p", C.c_float), ("min_p", C.c_float), ("seed", C.c_uint64),
+                ("eos_id", C.c_int64), ("use_graph", C.c_int32), ("paged", C.c_int32), ("block_size", C.c_int32),
+                ("reserved", C.c_int32 * 8)]
+
+
+class GenStats(C.Structure):
+    _fields_ = [("prefill_ms", C.c_double), ("decode_ms", C.c_double), ("n_generated", C.c_int32),
+                ("finish_reason", C.c_int32)]
+
+
+# name -> (restype, argtypes); every symbol include/blazr_hip.h declares
+P = C.c_void_p
+SYMBOLS = {
+    "bz_last_error": (C.c_char_p, []),
+    "bz_abi_version": (C.c_int, []),
+    "bz_device_open": (C.c_int, [C.c_int, C.POINTER(P)]),
+    "bz_device_close": (C.c_int, [P]),
+    "bz_device_synchronize": (C.c_int, [P]),
+    "bz_device_memory_info": (C.c_int, [P, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "bz_device_name": (C.c_int, [P, C.c_char_p, C.c_size_t]),
+    "bz_device_stream": (P, [P]),
+    "bz_tensor_from_host": (C.c_int, [P, C.c_int, C.POINTER(C.c_int64), C.c_int, P, C.POINTER(P)]),
+    "bz_tensor_zeros": (C.c_int, [P, C.c_int, C.POINTER(C.c_int64), C.c_int, C.POINTER(P)]),
+    "bz_tensor_free": (C.c_int, [P]),
+    "bz_tensor_to_host": (C.c_int, [P, P, C.c_size_t]),
+    "bz_tensor_nbytes": (C.c_int, [P, C.POINTER(C.c_size_t)]),
+    "bz_tensor_copy_from_host": (C.c_int, [P, P, C.c_size_t]),
+    "bz_event_record": (C.c_int, [P, C.POINTER(C.c_uint64)]),
+    "bz_event_sync": (C.c_int, [P, C.c_uint64]),
+    "bz_tensor_to_host_pipelined": (C.c_int, [P, C.c_uint64, P, C.c_size_t]),
+    "bz_model_create": (C.c_int, [P, C.POINTER(ModelConfig), C.POINTER(P)]),
+    "bz_model_free": (C.c_int, [P]),
+    "bz_model_add_dense": (C.c_int, [P, C.c_char_p, C.c_int, C.POINTER(C.c_int64), C.c_int, P]),
+    "bz_model_add_awq": (C.c_int, [P, C.c_char_p, C.c_int64, C.c_int64, P, P, P, C.c_int]),
+    "bz_model_add_gptq": (C.c_int, [P, C.c_char_p, C.c_int64, C.c_int64, P, P, P, P, P, C.c_int]),
+    "bz_model_add_gguf": (C.c_int, [P, C.c_char_p, C.c_int, C.c_int64, C.c_int64, P]),
+    "bz_model_finalize": (C.c_int, [P]),
+    "bz_model_get_config": (C.c_int, [P, C.POINTER(ModelConfig)]),
+    "bz_model_weight_bytes": (C.c_int, [P, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "bz_kv_create": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(P)]),
+    "bz_kv_free": (C.c_int, [P]),
+    "bz_kv_reset": (C.c_int, [P]),
+    "bz_kv_seq_len": (C.c_int, [P]),
+    "bz_kv_read": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, P]),
+    "bz_paged_kv_create": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(P)]),
+    "bz_paged_kv_free": (C.c_int, [P]),
+    "bz_paged_kv_set_seq_len": (C.c_int, [P, C.c_int]),
+    "bz_paged_kv_seq_len": (C.c_int, [P]),
+    "bz_forward_kv": (C.c_int, [P, P, C.c_int, P, C.c_int, P, C.c_uint32]),
+    "bz_forward_paged": (C.c_int, [P, P, C.c_int, P, P, P, C.c_int, C.c_int, C.c_int, P, C.c_uint32]),
+    "bz_forward_embed": (C.c_int, [P, P, C.c_int, P]),
+    "bz_forward_layers_range": (C.c_int, [P, P, P, C.POINTER(C.c_int), C.c_int, P, C.c_int, C.c_int, C.c_int]),
+    "bz_forward_head": (C.c_int, [P, P, P, C.c_int, C.c_int, P, C.c_uint32]),
+    "bz_logits_to_token": (C.c_int, [P, P, C.c_int64, C.c_int64, P, P, C.c_int, C.c_float, C.c_float, C.c_float,
+                                     C.c_float, C.c_int, C.c_float, C.c_float, C.c_uint64, P]),
+    "bz_argmax_to_buf": (C.c_int, [P, P, C.c_int64, C.c_int64, P]),
+    "bz_decode_graph_capture": (C.c_int, [P, P, C.POINTER(P)]),
+    "bz_decode_graph_capture_paged": (C.c_int, [P, P, C.c_int, C.POINTER(P)]),
+    "bz_decode_graph_seed": (C.c_int, [P, C.c_int64, C.c_int]),
+    "bz_decode_graph_set_block_table": (C.c_int, [P, P, C.c_int]),
+    "bz_decode_graph_replay": (C.c_int, [P]),
+    "bz_decode_graph_read_token": (C.c_int, [P, C.c_int64, C.POINTER(C.c_int64)]),
+    "bz_decode_graph_read_logits": (C.c_int, [P, P, C.c_size_t]),
+    "bz_decode_graph_free": (C.c_int, [P]),
+    "bz_generate": (C.c_int, [P, P, C.c_int, C.POINTER(GenConfig), P, C.POINTER(GenStats)]),
+    "bz_quant_matmul": (C.c_int, [P, C.c_char_p, P, C.c_int, P]),
+    "bz_dequant": (C.c_int, [P, C.c_char_p, P]),
+    "bz_rms_norm": (C.c_int, [P, P, P, P, C.c_int, C.c_int, C.c_float, C.c_int, P, P]),
+    "bz_rope": (C.c_int, [P, P, C.c_int, C.c_int, C.c_int]),
+    "bz_silu_mul": (C.c_int, [P, P, P, C.c_int64, C.c_int, P]),
+    "bz_attn_decode": (C.c_int, [P, P, P, C.c_int, C.c_int, P]),
+    "bz_paged_attn_decode": (C.c_int, [P, P, P, C.c_int, P, C.c_int, P]),
+    "bz_kv_insert": (C.c_int, [P, P, C.c_int, C.c_int, P, P]),
+    "bz_rope_caches": (C.c_int, [P, P, P]),
+}
+
+
+def build(force=False):
+    """Compile blazr_amd/csrc for gfx950 with hipcc (cross-compiles without a GPU)."""
+    args = ["make", "-s", "-C", os.path.join(_HERE, "csrc")]
+    if force:
+        subprocess.run(args + ["clean"], check=True)
+    subprocess.run(args, check=True)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise BlazrHipError(E_NODEVICE, "%s not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                            "(there is no CPU fallback)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)   # AttributeError here == a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        if L.bz_abi_version() != ABI_VERSION:
+            raise BlazrHipError(E_INVALID, "ABI version mismatch")
+        _LIB = L
+    return _LIB
+
+
+def check(rc):
+    if rc != OK:
+        raise BlazrHipError(rc, lib().bz_last_error().decode("utf-8", "replace"))

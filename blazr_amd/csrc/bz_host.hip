@@ -1,0 +1,1404 @@
+// bz_host.hip -- host side of libblazr_hip.so: device/tensor handles, model construction + repack,
+// the Llama-family decode step built from the fused kernels, hipGraph capture, and the decode loop.
+// C-ABI entry points are declared in include/blazr_hip.h (each cites the reference interface it replaces).
+#include "bz_internal.h"
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+#include <algorithm>
+#include <chrono>
+#include <numeric>
+
+// ---------------------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+void bz_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* bz_last_error(void) { return g_err; }
+extern "C" int bz_abi_version(void) { return BZ_ABI_VERSION; }
+
+size_t bz_dtype_size(int dt) {
+  switch (dt) {
+    case BZ_F32: case BZ_I32: case BZ_U32: return 4;
+    case BZ_F16: case BZ_BF16: return 2;
+    case BZ_I64: return 8;
+    case BZ_U8: return 1;
+    default: return 0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// device
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int bz_device_open(int id, bz_device** out) {
+  if (!out) BZ_FAIL(BZ_E_INVALID, "bz_device_open: out is null");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) BZ_FAIL(BZ_E_NODEVICE, "no HIP device available (%s); libblazr_hip has no CPU fallback", hipGetErrorString(e));
+  if (id < 0 || id >= n) BZ_FAIL(BZ_E_INVALID, "device id %d out of range [0,%d)", id, n);
+  BZ_HIP(hipSetDevice(id));
+  bz_device* d = new bz_device();
+  d->id = id;
+  BZ_HIP(hipGetDeviceProperties(&d->prop, id));
+  if (strncmp(d->prop.gcnArchName, "gfx950", 6) != 0) {
+    std::string arch = d->prop.gcnArchName;
+    delete d;
+    BZ_FAIL(BZ_E_NODEVICE, "device %d is %s; this library is built for gfx950 (MI355X) only", id, arch.c_str());
+  }
+  BZ_HIP(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+  BZ_HIP(hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking));
+  d->pinned_bytes = 1 << 20;
+  BZ_HIP(hipHostMalloc(&d->pinned, d->pinned_bytes, hipHostMallocDefault));
+  BZ_HIP(hipMalloc((void**)&d->scratch, 4096));
+  *out = d;
+  return BZ_OK;
+}
+extern "C" int bz_device_close(bz_device* d) {
+  if (!d) return BZ_OK;
+  hipSetDevice(d->id);
+  hipStreamSynchronize(d->stream);
+  for (auto ev : d->events) hipEventDestroy(ev);
+  if (d->pinned) hipHostFree(d->pinned);
+  if (d->scratch) hipFree(d->scratch);
+  hipStreamDestroy(d->stream);
+  hipStreamDestroy(d->copy_stream);
+  delete d;
+  return BZ_OK;
+}
+extern "C" int bz_device_synchronize(bz_device* d) {
+  if (!d) BZ_FAIL(BZ_E_INVALID, "null device");
+  BZ_HIP(hipStreamSynchronize(d->stream));
+  BZ_HIP(hipStreamSynchronize(d->copy_stream));
+  return BZ_OK;
+}
+extern "C" int bz_device_memory_info(bz_device* d, size_t* f, size_t* t) {
+  if (!d) BZ_FAIL(BZ_E_INVALID, "null device");
+  BZ_HIP(hipSetDevice(d->id));
+  BZ_HIP(hipMemGetInfo(f, t));
+  return BZ_OK;
+}
+extern "C" int bz_device_name(bz_device* d, char* buf, size_t n) {
+  if (!d || !buf) BZ_FAIL(BZ_E_INVALID, "null argument");
+  snprintf(buf, n, "%s (%s, %d CUs)", d->prop.name, d->prop.gcnArchName, d->prop.multiProcessorCount);
+  return BZ_OK;
+}
+extern "C" void* bz_device_stream(bz_device* d) { return d ? (void*)d->stream : nullptr; }
+
+// pinned staging: returns a host pointer valid until ~pinned_bytes more have been requested
+static void* pinned_slot(bz_device* d, size_t bytes) {
+  bytes = (bytes + 63) & ~(size_t)63;
+  if (d->pinned_off + bytes > d->pinned_bytes) d->pinned_off = 0;
+  void* p = (char*)d->pinned + d->pinned_off;
+  d->pinned_off += bytes;
+  return p;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// tensors
+// ---------------------------------------------------------------------------------------------------------
+static int tensor_alloc(bz_device* dev, int dtype, const int64_t* shape, int ndim, bz_tensor** out) {
+  if (!dev || !out || ndim < 0 || ndim > 8) BZ_FAIL(BZ_E_INVALID, "tensor: bad arguments");
+  size_t es = bz_dtype_size(dtype);
+  if (!es) BZ_FAIL(BZ_E_INVALID, "tensor: bad dtype %d", dtype);
+  size_t n = 1;
+  for (int i = 0; i < ndim; i++) { if (shape[i] < 0) BZ_FAIL(BZ_E_INVALID, "tensor: negative dim"); n *= (size_t)shape[i]; }
+  bz_tensor* t = new bz_tensor();
+  t->dev = dev; t->dtype = dtype; t->shape.assign(shape, shape + ndim); t->nbytes = n * es;
+  BZ_HIP(hipSetDevice(dev->id));
+  hipError_t e = hipMalloc(&t->ptr, std::max<size_t>(t->nbytes, 16));
+  if (e != hipSuccess) { delete t; BZ_FAIL(BZ_E_OOM, "hipMalloc(%zu) failed: %s", n * es, hipGetErrorString(e)); }
+  *out = t;
+  return BZ_OK;
+}
+extern "C" int bz_tensor_from_host(bz_device* dev, int dtype, const int64_t* shape, int ndim, const void* host, bz_tensor** out) {
+  BZ_TRY(tensor_alloc(dev, dtype, shape, ndim, out));
+  if ((*out)->nbytes && host) {
+    BZ_HIP(hipMemcpyAsync((*out)->ptr, host, (*out)->nbytes, hipMemcpyHostToDevice, dev->stream));
+    BZ_HIP(hipStreamSynchronize(dev->stream));
+  }
+  return BZ_OK;
+}
+extern "C" int bz_tensor_zeros(bz_device* dev, int dtype, const int64_t* shape, int ndim, bz_tensor** out) {
+  BZ_TRY(tensor_alloc(dev, dtype, shape, ndim, out));
+  if ((*out)->nbytes) BZ_HIP(hipMemsetAsync((*out)->ptr, 0, (*out)->nbytes, dev->stream));
+  return BZ_OK;
+}
+extern "C" int bz_tensor_free(bz_tensor* t) {
+  if (!t) return BZ_OK;
+  if (t->owned && t->ptr) { hipStreamSynchronize(t->dev->stream); hipFree(t->ptr); }
+  delete t;
+  return BZ_OK;
+}
+extern "C" int bz_tensor_nbytes(const bz_tensor* t, size_t* out) {
+  if (!t || !out) BZ_FAIL(BZ_E_INVALID, "null argument");
+  *out = t->nbytes;
+  return BZ_OK;
+}
+extern "C" int bz_tensor_to_host(const bz_tensor* t, void* host, size_t bytes) {
+  if (!t || !host) BZ_FAIL(BZ_E_INVALID, "null argument");
+  if (bytes > t->nbytes) BZ_FAIL(BZ_E_INVALID, "to_host: %zu bytes requested, tensor holds %zu", bytes, t->nbytes);
+  BZ_HIP(hipMemcpyAsync(host, t->ptr, bytes, hipMemcpyDeviceToHost, t->dev->stream));
+  BZ_HIP(hipStreamSynchronize(t->dev->stream));
+  return BZ_OK;
+}
+extern "C" int bz_tensor_copy_from_host(bz_tensor* t, const void* host, size_t bytes) {
+  if (!t || !host) BZ_FAIL(BZ_E_INVALID, "null argument");
+  if (bytes > t->nbytes) BZ_FAIL(BZ_E_INVALID, "copy_from_host: %zu bytes given, tensor holds %zu", bytes, t->nbytes);
+  BZ_HIP(hipMemcpyAsync(t->ptr, host, bytes, hipMemcpyHostToDevice, t->dev->stream));
+  BZ_HIP(hipStreamSynchronize(t->dev->stream));
+  return BZ_OK;
+}
+extern "C" int bz_event_record(bz_device* d, uint64_t* out) {
+  if (!d || !out) BZ_FAIL(BZ_E_INVALID, "null argument");
+  // small ring of reusable events
+  const size_t RING = 64;
+  if (d->events.size() < RING) {
+    hipEvent_t ev;
+    BZ_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    d->events.push_back(ev);
+  }
+  const uint64_t id = d->event_counter++ % d->events.size();
+  BZ_HIP(hipEventRecord(d->events[id], d->stream));
+  *out = id;
+  return BZ_OK;
+}
+extern "C" int bz_event_sync(bz_device* d, uint64_t ev) {
+  if (!d || ev >= d->events.size()) BZ_FAIL(BZ_E_INVALID, "bad event");
+  BZ_HIP(hipEventSynchronize(d->events[ev]));
+  return BZ_OK;
+}
+extern "C" int bz_tensor_to_host_pipelined(const bz_tensor* t, uint64_t ev, void* host, size_t bytes) {
+  if (!t || !host || ev >= t->dev->events.size()) BZ_FAIL(BZ_E_INVALID, "bad argument");
+  if (bytes > t->nbytes) BZ_FAIL(BZ_E_INVALID, "to_host_pipelined: size");
+  bz_device* d = t->dev;
+  // the copy waits only for `ev`, on the copy stream: the compute stream keeps running forward(t+1)
+  BZ_HIP(hipStreamWaitEvent(d->copy_stream, d->events[ev], 0));
+  BZ_HIP(hipMemcpyAsync(host, t->ptr, bytes, hipMemcpyDeviceToHost, d->copy_stream));
+  BZ_HIP(hipStreamSynchronize(d->copy_stream));
+  return BZ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// model
+// ---------------------------------------------------------------------------------------------------------
+struct RawTensor {
+  int kind = 0;  // 0 dense, 1 awq, 2 gptq, 3 gguf
+  int dtype = BZ_F32;
+  std::vector<int64_t> shape;
+  int64_t N = 0, K = 0; int gs = 0; int ggml_type = 0;
+  void* d0 = nullptr; void* d1 = nullptr; void* d2 = nullptr;  // dense data | qweight,scales,zeros/qzeros | blocks
+  float* d_bias = nullptr;
+  std::vector<int32_t> g_idx;
+  size_t bytes = 0;
+  bool consumed = false;
+};
+
+struct FusedLinear {
+  std::vector<LinearDev> parts;
+  std::vector<int> n_off;
+  int N = 0, K = 0;
+  bool fix_out = true;  // parts accumulate into fixed point (else direct f32 store)
+};
+
+struct LayerDev {
+  float* attn_norm = nullptr; float* ffn_norm = nullptr;
+  FusedLinear qkv, o, gateup, down;
+};
+
+struct bz_model {
+  bz_device* dev = nullptr;
+  bz_model_config cfg;
+  bool finalized = false;
+  std::unordered_map<std::string, RawTensor> raw;
+  std::vector<LayerDev> layers;
+  void* embed = nullptr; int embed_dt = BZ_F16;
+  float* final_norm = nullptr;
+  FusedLinear lm_head;
+  std::unordered_map<std::string, LinearDev> named;  // views for the op-level API
+  std::vector<void*> owned;                           // device allocations to free
+  float* cos_t = nullptr; float* sin_t = nullptr;
+  // workspace
+  float* hbuf[2] = {nullptr, nullptr};
+  long long* ring[3] = {nullptr, nullptr, nullptr};
+  float* dring[3] = {nullptr, nullptr, nullptr};   // direct-output twins of the ring (ROWS kernels)
+  int ring_n = 0;
+  float* attn_out = nullptr;
+  float* logits = nullptr;
+  float* pval = nullptr; int* pidx = nullptr; int nparts = 0;
+  float* scratch = nullptr;
+  long long* tok_tmp = nullptr;
+  int* pos_tmp = nullptr;
+  size_t resident = 0, per_token = 0;
+};
+
+static int dev_alloc(bz_model* m, void** p, size_t bytes) {
+  hipError_t e = hipMalloc(p, std::max<size_t>(bytes, 16));
+  if (e != hipSuccess) BZ_FAIL(BZ_E_OOM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+  m->owned.push_back(*p);
+  return BZ_OK;
+}
+static int upload(bz_device* d, void** out, const void* host, size_t bytes) {
+  hipError_t e = hipMalloc(out, std::max<size_t>(bytes, 16));
+  if (e != hipSuccess) BZ_FAIL(BZ_E_OOM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+  if (bytes) BZ_HIP(hipMemcpy(*out, host, bytes, hipMemcpyHostToDevice));
+  (void)d;
+  return BZ_OK;
+}
+
+extern "C" int bz_model_create(bz_device* dev, const bz_model_config* cfg, bz_model** out) {
+  if (!dev || !cfg || !out) BZ_FAIL(BZ_E_INVALID, "bz_model_create: null argument");
+  if (cfg->abi_version != BZ_ABI_VERSION) BZ_FAIL(BZ_E_INVALID, "config abi_version %d != %d", cfg->abi_version, BZ_ABI_VERSION);
+  if (cfg->arch != BZ_ARCH_LLAMA) BZ_FAIL(BZ_E_UNSUPPORTED, "arch %d not implemented in this build (llama family only)", cfg->arch);
+  if (cfg->hidden <= 0 || cfg->n_layers <= 0 || cfg->n_heads <= 0 || cfg->n_kv_heads <= 0 || cfg->head_dim <= 0 || cfg->inter <= 0 ||
+      cfg->vocab <= 0 || cfg->max_seq_len <= 0)
+    BZ_FAIL(BZ_E_INVALID, "config: non-positive dimension");
+  if (cfg->n_heads % cfg->n_kv_heads) BZ_FAIL(BZ_E_INVALID, "config: n_heads %% n_kv_heads != 0");
+  if (cfg->hidden % 8 || cfg->head_dim % 8 || cfg->inter % 8) BZ_FAIL(BZ_E_UNSUPPORTED, "config: hidden/head_dim/inter must be multiples of 8");
+  if (cfg->act_dtype != BZ_F32 && cfg->act_dtype != BZ_F16 && cfg->act_dtype != BZ_BF16) BZ_FAIL(BZ_E_INVALID, "config: bad act_dtype");
+  bz_model* m = new bz_model();
+  m->dev = dev; m->cfg = *cfg;
+  *out = m;
+  return BZ_OK;
+}
+
+static void raw_free(RawTensor& r) {
+  if (r.d0) hipFree(r.d0);
+  if (r.d1) hipFree(r.d1);
+  if (r.d2) hipFree(r.d2);
+  if (r.d_bias) hipFree(r.d_bias);
+  r.d0 = r.d1 = r.d2 = nullptr; r.d_bias = nullptr;
+}
+
+extern "C" int bz_model_free(bz_model* m) {
+  if (!m) return BZ_OK;
+  hipSetDevice(m->dev->id);
+  hipStreamSynchronize(m->dev->stream);
+  for (auto& kv : m->raw) raw_free(kv.second);
+  for (void* p : m->owned) hipFree(p);
+  delete m;
+  return BZ_OK;
+}
+
+static int check_add(bz_model* m, const char* name) {
+  if (!m || !name) BZ_FAIL(BZ_E_INVALID, "model add: null argument");
+  if (m->finalized) BZ_FAIL(BZ_E_INVALID, "model add: model already finalized");
+  if (m->raw.count(name)) BZ_FAIL(BZ_E_INVALID, "model add: duplicate tensor '%s'", name);
+  BZ_HIP(hipSetDevice(m->dev->id));
+  return BZ_OK;
+}
+
+extern "C" int bz_model_add_dense(bz_model* m, const char* name, int dtype, const int64_t* shape, int ndim, const void* host) {
+  BZ_TRY(check_add(m, name));
+  if (!host || ndim < 1 || ndim > 2) BZ_FAIL(BZ_E_INVALID, "add_dense '%s': need 1-D or 2-D host data", name);
+  if (dtype != BZ_F32 && dtype != BZ_F16 && dtype != BZ_BF16) BZ_FAIL(BZ_E_INVALID, "add_dense '%s': dtype %d", name, dtype);
+  RawTensor r; r.kind = 0; r.dtype = dtype; r.shape.assign(shape, shape + ndim);
+  r.N = shape[0]; r.K = ndim == 2 ? shape[1] : 1;
+  r.bytes = (size_t)r.N * r.K * bz_dtype_size(dtype);
+  BZ_TRY(upload(m->dev, &r.d0, host, r.bytes));
+  m->raw[name] = r;
+  return BZ_OK;
+}
+
+extern "C" int bz_model_add_awq(bz_model* m, const char* name, int64_t N, int64_t K, const uint32_t* qweight, const float* scales,
+                                const float* zeros, int gs) {
+  BZ_TRY(check_add(m, name));
+  if (!qweight || !scales || !zeros) BZ_FAIL(BZ_E_INVALID, "add_awq '%s': null data", name);
+  if (gs != 128) BZ_FAIL(BZ_E_UNSUPPORTED, "add_awq '%s': group_size %d (only 128 is implemented)", name, gs);
+  if (N % 64 || K % 128) BZ_FAIL(BZ_E_UNSUPPORTED, "add_awq '%s': N=%lld must be a multiple of 64 and K=%lld of 128", name, (long long)N, (long long)K);
+  RawTensor r; r.kind = 1; r.N = N; r.K = K; r.gs = gs;
+  const size_t G = (size_t)K / gs;
+  // the reference hands f32 scales/zeros that originate from f16 / 4-bit values (awq.rs:202-213): verify so that
+  // storing them as f16 / u8 in HBM is exact
+  for (size_t i = 0; i < G * (size_t)N; i++) {
+    float s = scales[i];
+    if (__half2float(__float2half(s)) != s) BZ_FAIL(BZ_E_UNSUPPORTED, "add_awq '%s': scale[%zu]=%g is not f16-representable", name, i, s);
+    float z = zeros[i];
+    if (!(z >= 0.f && z <= 15.f && z == floorf(z))) BZ_FAIL(BZ_E_INVALID, "add_awq '%s': zero[%zu]=%g is not an integer in [0,15]", name, i, z);
+  }
+  BZ_TRY(upload(m->dev, &r.d0, qweight, (size_t)K * (N / 8) * 4));
+  BZ_TRY(upload(m->dev, &r.d1, scales, G * N * 4));
+  BZ_TRY(upload(m->dev, &r.d2, zeros, G * N * 4));
+  m->raw[name] = r;
+  return BZ_OK;
+}
+
+extern "C" int bz_model_add_gptq(bz_model* m, const char* name, int64_t N, int64_t K, const uint32_t* qweight, const float* scales,
+                                 const uint32_t* qzeros, const int32_t* g_idx, const float* bias, int gs) {
+  BZ_TRY(check_add(m, name));
+  if (!qweight || !scales || !qzeros) BZ_FAIL(BZ_E_INVALID, "add_gptq '%s': null data", name);
+  if (gs != 128) BZ_FAIL(BZ_E_UNSUPPORTED, "add_gptq '%s': group_size %d (only 128 is implemented)", name, gs);
+  if (N % 64 || K % 128) BZ_FAIL(BZ_E_UNSUPPORTED, "add_gptq '%s': N must be a multiple of 64 and K of 128", name);
+  RawTensor r; r.kind = 2; r.N = N; r.K = K; r.gs = gs;
+  const size_t G = (size_t)K / gs;
+  for (size_t i = 0; i < G * (size_t)N; i++)
+    if (__half2float(__float2half(scales[i])) != scales[i]) BZ_FAIL(BZ_E_UNSUPPORTED, "add_gptq '%s': scale[%zu] is not f16-representable", name, i);
+  if (g_idx) {
+    r.g_idx.assign(g_idx, g_idx + K);
+    std::vector<int> cnt(G, 0);
+    for (int64_t k = 0; k < K; k++) {
+      if (g_idx[k] < 0 || (size_t)g_idx[k] >= G) BZ_FAIL(BZ_E_INVALID, "add_gptq '%s': g_idx[%lld]=%d out of range", name, (long long)k, g_idx[k]);
+      cnt[g_idx[k]]++;
+    }
+    for (size_t g = 0; g < G; g++) if (cnt[g] != gs) BZ_FAIL(BZ_E_UNSUPPORTED, "add_gptq '%s': group %zu has %d members (expected %d)", name, g, cnt[g], gs);
+  }
+  BZ_TRY(upload(m->dev, &r.d0, qweight, (size_t)(K / 8) * N * 4));
+  BZ_TRY(upload(m->dev, &r.d1, scales, G * N * 4));
+  BZ_TRY(upload(m->dev, &r.d2, qzeros, G * (N / 8) * 4));
+  if (bias) { void* b; BZ_TRY(upload(m->dev, &b, bias, (size_t)N * 4)); r.d_bias = (float*)b; }
+  m->raw[name] = r;
+  return BZ_OK;
+}
+
+extern "C" int bz_model_add_gguf(bz_model* m, const char* name, int ggml_type, int64_t N, int64_t K, const void* blocks) {
+  BZ_TRY(check_add(m, name));
+  if (!blocks) BZ_FAIL(BZ_E_INVALID, "add_gguf '%s': null data", name);
+  if (ggml_type == BZ_GGML_F32 || ggml_type == BZ_GGML_F16 || ggml_type == BZ_GGML_BF16) {
+    int64_t shape[2] = {N, K};
+    int dt = ggml_type == BZ_GGML_F32 ? BZ_F32 : (ggml_type == BZ_GGML_F16 ? BZ_F16 : BZ_BF16);
+    return bz_model_add_dense(m, name, dt, shape, K > 1 ? 2 : 1, blocks);
+  }
+  BZ_FAIL(BZ_E_UNSUPPORTED, "add_gguf '%s': ggml type %d block-dequant GEMV is not implemented in this build yet", name, ggml_type);
+}
+
+// --- finalize helpers ---------------------------------------------------------------------------------------
+static int choose_gw(int N, int K, int target) {
+  const int G = K / 128, nst = (N + 255) / 256;
+  int best = 1; double bestc = 1e30;
+  for (int gw = 1; gw <= std::min(G, 16); gw++) {
+    if (G % gw) continue;
+    const double wgs = (double)nst * (G / gw);
+    double c = fabs(log(wgs / (double)target));
+    if (wgs < 256) c += 1.0;  // never fewer workgroups than CUs
+    if (c < bestc) { bestc = c; best = gw; }
+  }
+  return best;
+}
+
+static int gemv_target_wgs() {
+  const char* e = getenv("BZ_GEMV_TARGET_WGS");
+  int t = e ? atoi(e) : 0;
+  return t > 0 ? t : 1024;
+}
+
+// Build one LinearDev (kernel layout) from several raw tensors concatenated along N (same K, same kind).
+static int build_q4g(bz_model* m, const std::vector<RawTensor*>& rs, LinearDev* L) {
+  const int K = (int)rs[0]->K, gs = rs[0]->gs;
+  int N = 0;
+  for (auto* r : rs) N += (int)r->N;
+  const size_t G = (size_t)K / gs;
+  const size_t wbytes = (size_t)N * K / 2, sbytes = (size_t)N * G * 2, zbytes = (size_t)N * G;
+  void *w, *s, *z;
+  BZ_TRY(dev_alloc(m, &w, wbytes));
+  BZ_TRY(dev_alloc(m, &s, sbytes));
+  BZ_TRY(dev_alloc(m, &z, zbytes));
+  hipStream_t st = m->dev->stream;
+  size_t n0 = 0;
+  int* d_perm = nullptr; int* d_gidx = nullptr;
+  for (auto* r : rs) {
+    char* wo = (char*)w + n0 * K / 2;
+    char* so = (char*)s + n0 * G * 2;
+    char* zo = (char*)z + n0 * G;
+    if (r->kind == 1) {
+      BZ_TRY(bzk_repack_awq(st, (const uint32_t*)r->d0, (const float*)r->d1, (const float*)r->d2, (int)r->N, K, gs, wo, so, zo));
+    } else {
+      if (!r->g_idx.empty() && !d_perm) {
+        // act-order: sort k by group (stable) so that every group is contiguous; x is gathered through perm in the prologue
+        std::vector<int> perm(K);
+        std::iota(perm.begin(), perm.end(), 0);
+        std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return r->g_idx[a] < r->g_idx[b]; });
+        bool ident = true;
+        for (int k = 0; k < K; k++) if (perm[k] != k) { ident = false; break; }
+        if (!ident) {
+          void* p; BZ_TRY(dev_alloc(m, &p, (size_t)K * 4));
+          BZ_HIP(hipMemcpy(p, perm.data(), (size_t)K * 4, hipMemcpyHostToDevice));
+          d_perm = (int*)p;
+          void* gi; BZ_TRY(dev_alloc(m, &gi, (size_t)K * 4));
+          BZ_HIP(hipMemcpy(gi, r->g_idx.data(), (size_t)K * 4, hipMemcpyHostToDevice));
+          d_gidx = (int*)gi;
+        }
+      }
+      BZ_TRY(bzk_repack_gptq(st, (const uint32_t*)r->d0, (const float*)r->d1, (const uint32_t*)r->d2, d_perm, d_gidx, (int)r->N, K, gs, wo, so, zo));
+    }
+    n0 += (size_t)r->N;
+  }
+  // bias (GPTQ): concatenated, zero where absent
+  bool any_bias = false;
+  for (auto* r : rs) any_bias |= r->d_bias != nullptr;
+  float* bias = nullptr;
+  if (any_bias) {
+    void* b; BZ_TRY(dev_alloc(m, &b, (size_t)N * 4));
+    BZ_HIP(hipMemsetAsync(b, 0, (size_t)N * 4, st));
+    size_t o = 0;
+    for (auto* r : rs) { if (r->d_bias) BZ_HIP(hipMemcpyAsync((float*)b + o, r->d_bias, (size_t)r->N * 4, hipMemcpyDeviceToDevice, st)); o += (size_t)r->N; }
+    bias = (float*)b;
+  }
+  BZ_HIP(hipStreamSynchronize(st));
+  L->kind = LK_Q4G; L->N = N; L->K = K; L->gs = gs; L->w = w; L->scales = s; L->zeros = z; L->perm = d_perm; L->bias = bias;
+  L->gw = choose_gw(N, K, gemv_target_wgs());
+  L->bytes = wbytes + sbytes + zbytes;
+  L->algo_bytes = wbytes + sbytes + (size_t)N * G / 2;
+  return BZ_OK;
+}
+
+static int build_rows(bz_model* m, const std::vector<RawTensor*>& rs, LinearDev* L) {
+  const int K = (int)rs[0]->K, dt = rs[0]->dtype;
+  int N = 0;
+  for (auto* r : rs) { N += (int)r->N; if (r->dtype != dt || r->K != K) BZ_FAIL(BZ_E_UNSUPPORTED, "fused dense parts differ in dtype/K"); }
+  const size_t es = bz_dtype_size(dt);
+  void* w;
+  if (rs.size() == 1) {
+    w = rs[0]->d0; rs[0]->d0 = nullptr; m->owned.push_back(w);  // take ownership, no copy
+  } else {
+    BZ_TRY(dev_alloc(m, &w, (size_t)N * K * es));
+    size_t o = 0;
+    for (auto* r : rs) { BZ_HIP(hipMemcpy((char*)w + o, r->d0, (size_t)r->N * K * es, hipMemcpyDeviceToDevice)); o += (size_t)r->N * K * es; }
+  }
+  L->kind = LK_ROWS; L->N = N; L->K = K; L->wdt = dt; L->w = w;
+  L->bytes = (size_t)N * K * es; L->algo_bytes = L->bytes;
+  return BZ_OK;
+}
+
+static bool same_perm(const RawTensor* a, const RawTensor* b) { return a->g_idx == b->g_idx; }
+
+// names: HF tensor names (without ".weight"); fuses along N when layouts allow, otherwise keeps separate parts
+static int build_fused(bz_model* m, const std::vector<std::string>& names, FusedLinear* F) {
+  std::vector<RawTensor*> rs;
+  for (auto& nm : names) {
+    auto it = m->raw.find(nm + ".weight");
+    if (it == m->raw.end()) BZ_FAIL(BZ_E_NOTFOUND, "finalize: tensor '%s.weight' was not added", nm.c_str());
+    // optional dense bias "<name>.bias" for dense/awq layers is not part of the Llama family; GPTQ carries its own
+    rs.push_back(&it->second);
+  }
+  F->K = (int)rs[0]->K; F->N = 0;
+  for (auto* r : rs) { if (r->K != F->K) BZ_FAIL(BZ_E_INVALID, "finalize: fused parts disagree on K"); F->N += (int)r->N; }
+  bool fusable = true;
+  for (auto* r : rs) {
+    if (r->kind != rs[0]->kind) fusable = false;
+    if (r->kind == 2 && !same_perm(r, rs[0])) fusable = false;
+    if (r->kind == 0 && r->dtype != rs[0]->dtype) fusable = false;
+  }
+  std::vector<std::vector<RawTensor*>> groups;
+  if (fusable) groups.push_back(rs);
+  else for (auto* r : rs) groups.push_back({r});
+  int noff = 0; size_t ri = 0;
+  for (auto& g : groups) {
+    LinearDev L;
+    if (g[0]->kind == 1 || g[0]->kind == 2) BZ_TRY(build_q4g(m, g, &L));
+    else if (g[0]->kind == 0) { if (g[0]->shape.size() != 2) BZ_FAIL(BZ_E_INVALID, "finalize: linear weight must be 2-D"); BZ_TRY(build_rows(m, g, &L)); }
+    else BZ_FAIL(BZ_E_UNSUPPORTED, "finalize: tensor kind %d", g[0]->kind);
+    F->parts.push_back(L); F->n_off.push_back(noff);
+    // per-name views for the op-level API
+    int sub = 0;
+    for (auto* r : g) {
+      LinearDev V = L; V.owned = false; V.N = (int)r->N;
+      if (L.kind == LK_Q4G) {
+        const size_t G = (size_t)L.K / 128;
+        V.w = (char*)L.w + (size_t)sub * L.K / 2; V.scales = (char*)L.scales + (size_t)sub * G * 2; V.zeros = (char*)L.zeros + (size_t)sub * G;
+        V.bias = L.bias ? L.bias + sub : nullptr;
+        V.gw = choose_gw(V.N, V.K, gemv_target_wgs());
+      } else {
+        V.w = (char*)L.w + (size_t)sub * L.K * bz_dtype_size(L.wdt);
+      }
+      m->named[names[ri] + ".weight"] = V;
+      sub += (int)r->N; ri++;
+    }
+    noff += L.N;
+  }
+  F->fix_out = F->parts[0].kind != LK_ROWS;
+  for (auto& p : F->parts) if ((p.kind != LK_ROWS) != F->fix_out) BZ_FAIL(BZ_E_UNSUPPORTED, "finalize: mixed quantised/dense parts in one fused linear");
+  for (auto* r : rs) { raw_free(*r); r->consumed = true; }
+  return BZ_OK;
+}
+
+static int take_vector_f32(bz_model* m, const std::string& name, int n, float** out) {
+  auto it = m->raw.find(name);
+  if (it == m->raw.end()) BZ_FAIL(BZ_E_NOTFOUND, "finalize: tensor '%s' was not added", name.c_str());
+  RawTensor& r = it->second;
+  if ((int64_t)r.N * r.K != n) BZ_FAIL(BZ_E_INVALID, "finalize: '%s' has %lld elements, expected %d", name.c_str(), (long long)(r.N * r.K), n);
+  // norms are kept as f32 holding values rounded to the activation dtype (awq.rs:93-103 casts BF16 -> F16)
+  std::vector<char> host(r.bytes);
+  BZ_HIP(hipMemcpy(host.data(), r.d0, r.bytes, hipMemcpyDeviceToHost));
+  std::vector<float> f(n);
+  for (int i = 0; i < n; i++) {
+    float v;
+    if (r.dtype == BZ_F32) v = ((float*)host.data())[i];
+    else if (r.dtype == BZ_F16) v = __half2float(((__half*)host.data())[i]);
+    else { uint32_t u = (uint32_t)((uint16_t*)host.data())[i] << 16; memcpy(&v, &u, 4); }
+    if (m->cfg.act_dtype == BZ_F16) v = __half2float(__float2half(v));
+    else if (m->cfg.act_dtype == BZ_BF16) { uint32_t u; memcpy(&u, &v, 4); u += 0x7fffu + ((u >> 16) & 1u); u &= 0xffff0000u; memcpy(&v, &u, 4); }
+    f[i] = v;
+  }
+  void* d; BZ_TRY(dev_alloc(m, &d, (size_t)n * 4));
+  BZ_HIP(hipMemcpy(d, f.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+  *out = (float*)d;
+  raw_free(r); r.consumed = true;
+  return BZ_OK;
+}
+
+// RoPE tables: same formula as oracle/orc_ops.c (restated, not shared): HF inv_freq with linear / llama3 scaling
+// (/root/reference/src/loader/safetensors/config.rs:83-95), angle = (float)pos * (float)inv_freq, cos/sin via double libm.
+static void rope_tables_host(const bz_model_config& c, std::vector<float>& cs, std::vector<float>& sn) {
+  const int half = c.head_dim / 2;
+  cs.resize((size_t)c.max_seq_len * half); sn.resize((size_t)c.max_seq_len * half);
+  const double PI2 = 6.283185307179586476925286766559;
+  for (int i = 0; i < half; i++) {
+    double inv = 1.0 / pow((double)c.rope_theta, (double)(2 * i) / (double)c.head_dim);
+    if (c.rope_scaling == BZ_ROPE_LINEAR) inv /= (double)c.rope_factor;
+    else if (c.rope_scaling == BZ_ROPE_LLAMA3) {
+      double low_wl = (double)c.rope_original_max_pos / (double)c.rope_low_freq_factor;
+      double high_wl = (double)c.rope_original_max_pos / (double)c.rope_high_freq_factor;
+      double wl = PI2 / inv;
+      if (wl > low_wl) inv = inv / (double)c.rope_factor;
+      else if (wl >= high_wl) {
+        double smooth = ((double)c.rope_original_max_pos / wl - (double)c.rope_low_freq_factor) /
+                        ((double)c.rope_high_freq_factor - (double)c.rope_low_freq_factor);
+        inv = (1.0 - smooth) * inv / (double)c.rope_factor + smooth * inv;
+      }
+    }
+    const float invf = (float)inv;
+    for (int p = 0; p < c.max_seq_len; p++) {
+      float ang = (float)p * invf;
+      cs[(size_t)p * half + i] = (float)cos((double)ang);
+      sn[(size_t)p * half + i] = (float)sin((double)ang);
+    }
+  }
+}
+
+extern "C" int bz_model_finalize(bz_model* m) {
+  if (!m) BZ_FAIL(BZ_E_INVALID, "null model");
+  if (m->finalized) BZ_FAIL(BZ_E_INVALID, "model already finalized");
+  BZ_HIP(hipSetDevice(m->dev->id));
+  const bz_model_config& c = m->cfg;
+  const int H = c.hidden, nq = c.n_heads, nkv = c.n_kv_heads, hd = c.head_dim, I = c.inter, V = c.vocab;
+  char nm[256];
+  m->layers.resize(c.n_layers);
+  for (int l = 0; l < c.n_layers; l++) {
+    LayerDev& Ld = m->layers[l];
+    snprintf(nm, sizeof nm, "model.layers.%d.", l);
+    std::string p = nm;
+    BZ_TRY(take_vector_f32(m, p + "input_layernorm.weight", H, &Ld.attn_norm));
+    BZ_TRY(take_vector_f32(m, p + "post_attention_layernorm.weight", H, &Ld.ffn_norm));
+    BZ_TRY(build_fused(m, {p + "self_attn.q_proj", p + "self_attn.k_proj", p + "self_attn.v_proj"}, &Ld.qkv));
+    BZ_TRY(build_fused(m, {p + "self_attn.o_proj"}, &Ld.o));
+    BZ_TRY(build_fused(m, {p + "mlp.gate_proj", p + "mlp.up_proj"}, &Ld.gateup));
+    BZ_TRY(build_fused(m, {p + "mlp.down_proj"}, &Ld.down));
+    if (Ld.qkv.N != (nq + 2 * nkv) * hd || Ld.qkv.K != H) BZ_FAIL(BZ_E_INVALID, "layer %d: q/k/v shapes do not match the config", l);
+    if (Ld.o.N != H || Ld.o.K != nq * hd) BZ_FAIL(BZ_E_INVALID, "layer %d: o_proj shape does not match the config", l);
+    if (Ld.gateup.N != 2 * I || Ld.gateup.K != H) BZ_FAIL(BZ_E_INVALID, "layer %d: gate/up shapes do not match the config", l);
+    if (Ld.down.N != H || Ld.down.K != I) BZ_FAIL(BZ_E_INVALID, "layer %d: down_proj shape does not match the config", l);
+  }
+  BZ_TRY(take_vector_f32(m, "model.norm.weight", H, &m->final_norm));
+  // embeddings stay in their storage dtype (rows are gathered); tied lm_head reads the same buffer
+  {
+    auto it = m->raw.find("model.embed_tokens.weight");
+    if (it == m->raw.end()) BZ_FAIL(BZ_E_NOTFOUND, "finalize: 'model.embed_tokens.weight' was not added");
+    RawTensor& r = it->second;
+    if (r.kind != 0 || r.N != V || r.K != H) BZ_FAIL(BZ_E_INVALID, "finalize: embed_tokens must be dense [vocab, hidden]");
+    m->embed = r.d0; m->embed_dt = r.dtype; r.d0 = nullptr; m->owned.push_back(m->embed); r.consumed = true;
+    m->resident += r.bytes;
+    if (c.tie_embeddings || !m->raw.count("lm_head.weight")) {
+      LinearDev L; L.kind = LK_ROWS; L.N = V; L.K = H; L.wdt = m->embed_dt; L.w = m->embed; L.owned = false;
+      L.bytes = 0; L.algo_bytes = r.bytes;
+      m->lm_head.parts.push_back(L); m->lm_head.n_off.push_back(0); m->lm_head.N = V; m->lm_head.K = H; m->lm_head.fix_out = false;
+      m->named["lm_head.weight"] = L;
+    } else {
+      BZ_TRY(build_fused(m, {"lm_head"}, &m->lm_head));
+      if (m->lm_head.N != V || m->lm_head.K != H) BZ_FAIL(BZ_E_INVALID, "finalize: lm_head shape does not match the config");
+    }
+  }
+  if (m->lm_head.fix_out || m->lm_head.parts.size() != 1)
+    BZ_FAIL(BZ_E_UNSUPPORTED, "finalize: quantised lm_head is not implemented in this build (dense f16/bf16/f32 only)");
+  for (auto& kv : m->raw) if (!kv.second.consumed) BZ_FAIL(BZ_E_INVALID, "finalize: tensor '%s' is not used by this architecture", kv.first.c_str());
+  m->raw.clear();
+
+  // rope caches
+  std::vector<float> cs, sn;
+  rope_tables_host(c, cs, sn);
+  void* p;
+  BZ_TRY(dev_alloc(m, &p, cs.size() * 4)); m->cos_t = (float*)p; BZ_HIP(hipMemcpy(p, cs.data(), cs.size() * 4, hipMemcpyHostToDevice));
+  BZ_TRY(dev_alloc(m, &p, sn.size() * 4)); m->sin_t = (float*)p; BZ_HIP(hipMemcpy(p, sn.data(), sn.size() * 4, hipMemcpyHostToDevice));
+
+  // workspace
+  m->ring_n = std::max(std::max((nq + 2 * nkv) * hd, 2 * I), std::max(H, nq * hd));
+  for (int i = 0; i < 3; i++) {
+    BZ_TRY(dev_alloc(m, &p, (size_t)m->ring_n * 8)); m->ring[i] = (long long*)p; BZ_HIP(hipMemset(p, 0, (size_t)m->ring_n * 8));
+    BZ_TRY(dev_alloc(m, &p, (size_t)m->ring_n * 4)); m->dring[i] = (float*)p; BZ_HIP(hipMemset(p, 0, (size_t)m->ring_n * 4));
+  }
+  for (int i = 0; i < 2; i++) { BZ_TRY(dev_alloc(m, &p, (size_t)H * 4)); m->hbuf[i] = (float*)p; }
+  BZ_TRY(dev_alloc(m, &p, (size_t)nq * hd * 4)); m->attn_out = (float*)p;
+  BZ_TRY(dev_alloc(m, &p, (size_t)V * 4)); m->logits = (float*)p;
+  m->nparts = bzk_gemv_rows_blocks(m->lm_head.parts[0]);
+  BZ_TRY(dev_alloc(m, &p, (size_t)m->nparts * 4)); m->pval = (float*)p;
+  BZ_TRY(dev_alloc(m, &p, (size_t)m->nparts * 4)); m->pidx = (int*)p;
+  BZ_TRY(dev_alloc(m, &p, 4096)); m->scratch = (float*)p;
+  BZ_TRY(dev_alloc(m, &p, 64)); m->tok_tmp = (long long*)p;
+  BZ_TRY(dev_alloc(m, &p, 64)); m->pos_tmp = (int*)p;
+
+  // accounting
+  size_t act_b = bz_dtype_size(c.act_dtype);
+  m->per_token = (size_t)(2 * c.n_layers + 1) * H * act_b + (size_t)H * bz_dtype_size(m->embed_dt);
+  for (auto& Ld : m->layers)
+    for (FusedLinear* F : {&Ld.qkv, &Ld.o, &Ld.gateup, &Ld.down})
+      for (auto& L : F->parts) { m->resident += L.bytes; m->per_token += L.algo_bytes; }
+  for (auto& L : m->lm_head.parts) { m->resident += L.bytes; m->per_token += L.algo_bytes; }
+  m->finalized = true;
+  return BZ_OK;
+}
+
+extern "C" int bz_model_get_config(const bz_model* m, bz_model_config* out) {
+  if (!m || !out) BZ_FAIL(BZ_E_INVALID, "null argument");
+  *out = m->cfg;
+  return BZ_OK;
+}
+extern "C" int bz_model_weight_bytes(const bz_model* m, size_t* resident, size_t* per_token) {
+  if (!m || !m->finalized) BZ_FAIL(BZ_E_INVALID, "model not finalized");
+  if (resident) *resident = m->resident;
+  if (per_token) *per_token = m->per_token;
+  return BZ_OK;
+}
+extern "C" int bz_rope_caches(bz_model* m, float* c, float* s) {
+  if (!m || !m->finalized) BZ_FAIL(BZ_E_INVALID, "model not finalized");
+  size_t n = (size_t)m->cfg.max_seq_len * (m->cfg.head_dim / 2) * 4;
+  if (c) BZ_HIP(hipMemcpy(c, m->cos_t, n, hipMemcpyDeviceToHost));
+  if (s) BZ_HIP(hipMemcpy(s, m->sin_t, n, hipMemcpyDeviceToHost));
+  return BZ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// KV caches
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int bz_kv_create(bz_device* dev, int layers, int batch, int n_kv, int init_cap, int max_len, int hd, int dtype, bz_kv** out) {
+  if (!dev || !out) BZ_FAIL(BZ_E_INVALID, "null argument");
+  if (batch != 1) BZ_FAIL(BZ_E_UNSUPPORTED, "kv cache: batch %d (single-stream decode only)", batch);
+  if (layers <= 0 || n_kv <= 0 || init_cap <= 0 || max_len < init_cap || hd <= 0) BZ_FAIL(BZ_E_INVALID, "kv cache: bad dimensions");
+  if (dtype != BZ_F16 && dtype != BZ_BF16 && dtype != BZ_F32) BZ_FAIL(BZ_E_INVALID, "kv cache: dtype %d", dtype);
+  BZ_HIP(hipSetDevice(dev->id));
+  bz_kv* kv = new bz_kv();
+  kv->dev = dev; kv->layers = layers; kv->n_kv = n_kv; kv->cap = init_cap; kv->max_len = max_len; kv->hd = hd; kv->dtype = dtype;
+  size_t bytes = (size_t)layers * n_kv * init_cap * hd * bz_dtype_size(dtype);
+  if (hipMalloc(&kv->k, bytes) != hipSuccess || hipMalloc(&kv->v, bytes) != hipSuccess) { delete kv; BZ_FAIL(BZ_E_OOM, "kv cache: hipMalloc(%zu) failed", bytes); }
+  BZ_HIP(hipMemsetAsync(kv->k, 0, bytes, dev->stream));
+  BZ_HIP(hipMemsetAsync(kv->v, 0, bytes, dev->stream));
+  *out = kv;
+  return BZ_OK;
+}
+extern "C" int bz_kv_free(bz_kv* kv) {
+  if (!kv) return BZ_OK;
+  hipStreamSynchronize(kv->dev->stream);
+  hipFree(kv->k); hipFree(kv->v);
+  delete kv;
+  return BZ_OK;
+}
+extern "C" int bz_kv_reset(bz_kv* kv) { if (!kv) BZ_FAIL(BZ_E_INVALID, "null kv"); kv->seq_len = 0; return BZ_OK; }
+extern "C" int bz_kv_seq_len(const bz_kv* kv) { return kv ? kv->seq_len : -1; }
+
+static int kv_grow(bz_kv* kv, int need) {
+  if (need <= kv->cap) return BZ_OK;
+  if (need > kv->max_len) BZ_FAIL(BZ_E_INVALID, "kv cache: %d positions needed, max_seq_len is %d", need, kv->max_len);
+  int ncap = std::min(kv->max_len, std::max(need, kv->cap * 2));
+  const size_t es = bz_dtype_size(kv->dtype);
+  const size_t rows = (size_t)kv->layers * kv->n_kv;
+  void *nk, *nv;
+  size_t bytes = rows * ncap * kv->hd * es;
+  if (hipMalloc(&nk, bytes) != hipSuccess || hipMalloc(&nv, bytes) != hipSuccess) BZ_FAIL(BZ_E_OOM, "kv cache grow: hipMalloc(%zu) failed", bytes);
+  hipStream_t st = kv->dev->stream;
+  BZ_HIP(hipMemsetAsync(nk, 0, bytes, st));
+  BZ_HIP(hipMemsetAsync(nv, 0, bytes, st));
+  const size_t oldp = (size_t)kv->cap * kv->hd * es, newp = (size_t)ncap * kv->hd * es;
+  BZ_HIP(hipMemcpy2DAsync(nk, newp, kv->k, oldp, oldp, rows, hipMemcpyDeviceToDevice, st));
+  BZ_HIP(hipMemcpy2DAsync(nv, newp, kv->v, oldp, oldp, rows, hipMemcpyDeviceToDevice, st));
+  BZ_HIP(hipStreamSynchronize(st));
+  hipFree(kv->k); hipFree(kv->v);
+  kv->k = nk; kv->v = nv; kv->cap = ncap;
+  return BZ_OK;
+}
+
+static KvView view_of(const bz_kv* kv) {
+  KvView v{};
+  v.k = kv->k; v.v = kv->v; v.dtype = kv->dtype; v.hd = kv->hd; v.n_kv = kv->n_kv; v.paged = 0;
+  v.layer_stride = (long long)kv->n_kv * kv->cap * kv->hd; v.cap = kv->cap; v.bs = 1; v.block_table = nullptr; v.slot = nullptr;
+  return v;
+}
+static KvView view_of(const bz_paged_kv* kv, const int* block_table, const int* slot) {
+  KvView v{};
+  v.k = kv->k; v.v = kv->v; v.dtype = kv->dtype; v.hd = kv->hd; v.n_kv = kv->n_kv; v.paged = 1;
+  v.layer_stride = (long long)kv->num_blocks * kv->n_kv * kv->block_size * kv->hd; v.cap = 0; v.bs = kv->block_size;
+  v.block_table = block_table; v.slot = slot;
+  return v;
+}
+
+extern "C" int bz_kv_read(const bz_kv* kv, int layer, int kvh, int which, int len, float* host) {
+  if (!kv || !host || layer < 0 || layer >= kv->layers || kvh < 0 || kvh >= kv->n_kv || len < 0 || len > kv->cap) BZ_FAIL(BZ_E_INVALID, "kv_read: bad argument");
+  float* d;
+  BZ_HIP(hipMalloc(&d, std::max<size_t>((size_t)len * kv->hd * 4, 16)));
+  int rc = bzk_kv_read(kv->dev->stream, view_of(kv), layer, kvh, which, len, d);
+  if (rc == BZ_OK) { hipMemcpyAsync(host, d, (size_t)len * kv->hd * 4, hipMemcpyDeviceToHost, kv->dev->stream); hipStreamSynchronize(kv->dev->stream); }
+  hipFree(d);
+  return rc;
+}
+
+extern "C" int bz_paged_kv_create(bz_device* dev, int layers, int num_blocks, int block_size, int n_kv, int hd, int dtype, bz_paged_kv** out) {
+  if (!dev || !out) BZ_FAIL(BZ_E_INVALID, "null argument");
+  if (layers <= 0 || num_blocks <= 0 || block_size <= 0 || n_kv <= 0 || hd <= 0) BZ_FAIL(BZ_E_INVALID, "paged kv: bad dimensions");
+  if (dtype != BZ_F16 && dtype != BZ_BF16 && dtype != BZ_F32) BZ_FAIL(BZ_E_INVALID, "paged kv: dtype %d", dtype);
+  BZ_HIP(hipSetDevice(dev->id));
+  bz_paged_kv* kv = new bz_paged_kv();
+  kv->dev = dev; kv->layers = layers; kv->num_blocks = num_blocks; kv->block_size = block_size; kv->n_kv = n_kv; kv->hd = hd; kv->dtype = dtype;
+  size_t bytes = (size_t)layers * num_blocks * n_kv * block_size * hd * bz_dtype_size(dtype);
+  if (hipMalloc(&kv->k, bytes) != hipSuccess || hipMalloc(&kv->v, bytes) != hipSuccess) { delete kv; BZ_FAIL(BZ_E_OOM, "paged kv: hipMalloc(%zu) failed", bytes); }
+  BZ_HIP(hipMemsetAsync(kv->k, 0, bytes, dev->stream));
+  BZ_HIP(hipMemsetAsync(kv->v, 0, bytes, dev->stream));
+  *out = kv;
+  return BZ_OK;
+}
+extern "C" int bz_paged_kv_free(bz_paged_kv* kv) {
+  if (!kv) return BZ_OK;
+  hipStreamSynchronize(kv->dev->stream);
+  hipFree(kv->k); hipFree(kv->v);
+  delete kv;
+  return BZ_OK;
+}
+extern "C" int bz_paged_kv_set_seq_len(bz_paged_kv* kv, int n) { if (!kv || n < 0) BZ_FAIL(BZ_E_INVALID, "bad argument"); kv->seq_len = n; return BZ_OK; }
+extern "C" int bz_paged_kv_seq_len(const bz_paged_kv* kv) { return kv ? kv->seq_len : -1; }
+
+// ---------------------------------------------------------------------------------------------------------
+// the decode step (one token through all layers), built from the fused kernels
+// ---------------------------------------------------------------------------------------------------------
+__global__ void k_set_int(int* p, int v) { p[0] = v; }
+
+struct StepIO {
+  KvView kv;
+  const long long* d_tok;   // token id (device)
+  const int* d_pos;         // position (device)
+  // pieces API: when set, the step starts from a given hidden row (+ optional prev) instead of the embedding
+  const float* hidden_in = nullptr; const float* prev_in = nullptr;
+  int layer_start = 0, layer_end = -1;
+  bool do_embed = true, do_head = true;
+  float* hidden_out = nullptr; float* prev_out = nullptr;   // pieces API outputs (f32 rows)
+  FinalArgs* final_args = nullptr;                          // graph mode: fused argmax + bookkeeping
+};
+
+// Fixed-point accumulator ring.  Launch j accumulates into ring[j % 3] (which must be zero), reads the output of
+// launch j-1 and zeroes ring[(j+1) % 3] -- last written by launch j-2 and last read by launch j-1, both complete by
+// stream order.  `dirty[i]` = number of non-zero entries ring[i] may hold.
+struct RingState { int ri = 0; int dirty[3] = {0, 0, 0}; };
+
+// Launch every part of a fused linear.  Returns the VSrc describing its output.
+static int run_fused(bz_model* m, const FusedLinear& F, Pro pro, RingState& rs, VSrc* out) {
+  hipStream_t st = m->dev->stream;
+  const int act = m->cfg.act_dtype;
+  const int ri = rs.ri, rz = (rs.ri + 1) % 3;
+  long long* acc = m->ring[ri];
+  float* direct = m->dring[ri];
+  for (size_t i = 0; i < F.parts.size(); i++) {
+    const LinearDev& L = F.parts[i];
+    Pro p = pro; p.perm = L.perm;
+    GemvOut o{};
+    o.acc = acc + F.n_off[i]; o.direct = direct + F.n_off[i];
+    o.zero_buf = (i == 0 && rs.dirty[rz] > 0) ? m->ring[rz] : nullptr; o.zero_n = rs.dirty[rz];
+    BZ_TRY(bzk_gemv(st, L, p, o, act));
+  }
+  rs.dirty[rz] = 0;
+  rs.dirty[ri] = F.fix_out ? F.N : 0;
+  rs.ri = rz;
+  out->fix = F.fix_out ? 1 : 0;
+  out->p = F.fix_out ? (const void*)acc : (const void*)direct;
+  return BZ_OK;
+}
+
+static int llama_step(bz_model* m, const StepIO& io) {
+  const bz_model_config& c = m->cfg;
+  hipStream_t st = m->dev->stream;
+  const int H = c.hidden, I = c.inter, act = c.act_dtype;
+  const int lend = io.layer_end < 0 ? c.n_layers : io.layer_end;
+  int cur = 0;
+  RingState rs;
+  VSrc prev{nullptr, 0};
+  if (io.do_embed) {
+    BZ_TRY(bzk_embed(st, m->embed, m->embed_dt, io.d_tok, H, act, m->hbuf[cur]));
+  } else {
+    BZ_HIP(hipMemcpyAsync(m->hbuf[cur], io.hidden_in, (size_t)H * 4, hipMemcpyDeviceToDevice, st));
+    if (io.prev_in) { prev.p = io.prev_in; prev.fix = 0; }
+  }
+  for (int l = io.layer_start; l < lend; l++) {
+    const LayerDev& Ld = m->layers[l];
+    Pro pn{}; pn.mode = PRO_NORM; pn.src = prev; pn.h_in = m->hbuf[cur]; pn.h_out = m->hbuf[cur ^ 1]; pn.norm_w = Ld.attn_norm;
+    pn.eps = c.rms_eps; pn.H = H; pn.act = act;
+    VSrc qkv;
+    BZ_TRY(run_fused(m, Ld.qkv, pn, rs, &qkv));
+    cur ^= 1;
+
+    AttnArgs aa{};
+    aa.qkv = qkv; aa.cos_t = m->cos_t; aa.sin_t = m->sin_t; aa.interleaved = c.rope_interleaved; aa.pos = io.d_pos;
+    aa.nq = c.n_heads; aa.nkv = c.n_kv_heads; aa.hd = c.head_dim; aa.act = act; aa.kv = io.kv; aa.layer = l; aa.out = m->attn_out;
+    aa.zero_buf = nullptr; aa.zero_n = 0; aa.q_only = 0;
+    BZ_TRY(bzk_attn_decode(st, aa));
+
+    Pro pp{}; pp.mode = PRO_PLAIN; pp.src = VSrc{m->attn_out, 0}; pp.act = act; pp.H = 0;
+    VSrc ov;
+    BZ_TRY(run_fused(m, Ld.o, pp, rs, &ov));
+
+    Pro pf{}; pf.mode = PRO_NORM; pf.src = ov; pf.h_in = m->hbuf[cur]; pf.h_out = m->hbuf[cur ^ 1]; pf.norm_w = Ld.ffn_norm;
+    pf.eps = c.rms_eps; pf.H = H; pf.act = act;
+    VSrc gu;
+    BZ_TRY(run_fused(m, Ld.gateup, pf, rs, &gu));
+    cur ^= 1;
+
+    Pro ps{}; ps.mode = PRO_SILU; ps.src = gu; ps.H = I; ps.act = act;
+    VSrc dn;
+    BZ_TRY(run_fused(m, Ld.down, ps, rs, &dn));
+    prev = dn;
+  }
+  if (io.hidden_out) {
+    BZ_HIP(hipMemcpyAsync(io.hidden_out, m->hbuf[cur], (size_t)H * 4, hipMemcpyDeviceToDevice, st));
+    if (io.prev_out && prev.p) {
+      if (prev.fix) BZ_TRY(bzk_fix_to_f32(st, (const long long*)prev.p, H, act, io.prev_out));
+      else BZ_HIP(hipMemcpyAsync(io.prev_out, prev.p, (size_t)H * 4, hipMemcpyDeviceToDevice, st));
+    }
+  }
+  // ring indices at this point: rs.ri is clean; (rs.ri+2)%3 holds `prev` (still needed by the head), (rs.ri+1)%3 is stale
+  const int ra = (rs.ri + 2) % 3, rb = (rs.ri + 1) % 3;
+  if (io.do_head) {
+    Pro ph{}; ph.mode = PRO_NORM; ph.src = prev; ph.h_in = m->hbuf[cur]; ph.h_out = nullptr; ph.norm_w = m->final_norm;
+    ph.eps = c.rms_eps; ph.H = H; ph.act = act;
+    GemvOut o{};
+    o.direct = m->logits; o.amax_val = m->pval; o.amax_idx = m->pidx;
+    o.zero_buf = rs.dirty[rb] > 0 ? m->ring[rb] : nullptr; o.zero_n = rs.dirty[rb];
+    BZ_TRY(bzk_gemv(st, m->lm_head.parts[0], ph, o, act));
+    rs.dirty[rb] = 0;
+    if (io.final_args) {
+      FinalArgs fa = *io.final_args;
+      fa.pval = m->pval; fa.pidx = m->pidx; fa.nparts = m->nparts;
+      fa.zero_buf = rs.dirty[ra] > 0 ? m->ring[ra] : nullptr; fa.zero_n = rs.dirty[ra];
+      BZ_TRY(bzk_argmax_final(st, fa));
+      rs.dirty[ra] = 0;
+    }
+  }
+  // every ring buffer must be zero again when the step ends
+  for (int i = 0; i < 3; i++) if (rs.dirty[i] > 0) BZ_TRY(bzk_zero64(st, m->ring[i], rs.dirty[i]));
+  return BZ_OK;
+}
+
+static int check_fwd(bz_model* m, const bz_tensor* tokens, int S) {
+  if (!m || !m->finalized) BZ_FAIL(BZ_E_INVALID, "forward: model not finalized");
+  if (!tokens || tokens->dtype != BZ_I64 || tokens->nbytes < (size_t)S * 8 || S <= 0) BZ_FAIL(BZ_E_INVALID, "forward: tokens must be an I64 tensor with >= S elements");
+  BZ_HIP(hipSetDevice(m->dev->id));
+  return BZ_OK;
+}
+
+static int emit_logits(bz_model* m, bz_tensor* logits_out, int row) {
+  const size_t vb = (size_t)m->cfg.vocab * 4;
+  if (!logits_out || logits_out->dtype != BZ_F32 || logits_out->nbytes < (size_t)(row + 1) * vb) BZ_FAIL(BZ_E_INVALID, "forward: logits_out too small");
+  BZ_HIP(hipMemcpyAsync((char*)logits_out->ptr + (size_t)row * vb, m->logits, vb, hipMemcpyDeviceToDevice, m->dev->stream));
+  return BZ_OK;
+}
+
+extern "C" int bz_forward_kv(bz_model* m, const bz_tensor* tokens, int S, bz_kv* kv, int position, bz_tensor* logits_out, uint32_t flags) {
+  BZ_TRY(check_fwd(m, tokens, S));
+  if (!kv || kv->layers != m->cfg.n_layers || kv->n_kv != m->cfg.n_kv_heads || kv->hd != m->cfg.head_dim) BZ_FAIL(BZ_E_INVALID, "forward_kv: cache does not match the model");
+  if (position < 0 || position + S > m->cfg.max_seq_len) BZ_FAIL(BZ_E_INVALID, "forward_kv: position %d + S %d exceeds max_seq_len %d", position, S, m->cfg.max_seq_len);
+  BZ_TRY(kv_grow(kv, position + S));
+  const bool all = flags & BZ_FWD_ALL_LOGITS;
+  for (int s = 0; s < S; s++) {
+    hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, m->dev->stream, m->pos_tmp, position + s);
+    StepIO io{};
+    io.kv = view_of(kv); io.d_tok = (const long long*)tokens->ptr + s; io.d_pos = m->pos_tmp;
+    io.do_head = all || s == S - 1;
+    BZ_TRY(llama_step(m, io));
+    if (io.do_head) BZ_TRY(emit_logits(m, logits_out, all ? s : 0));
+  }
+  kv->seq_len = position + S;
+  return BZ_OK;
+}
+
+extern "C" int bz_forward_paged(bz_model* m, const bz_tensor* tokens, int S, bz_paged_kv* kv, const bz_tensor* slot_mapping,
+                                const bz_tensor* block_table, int n_table, int seq_len_k, int start_pos, bz_tensor* logits_out, uint32_t flags) {
+  BZ_TRY(check_fwd(m, tokens, S));
+  if (!kv || kv->layers != m->cfg.n_layers || kv->n_kv != m->cfg.n_kv_heads || kv->hd != m->cfg.head_dim) BZ_FAIL(BZ_E_INVALID, "forward_paged: cache does not match the model");
+  if (!slot_mapping || slot_mapping->dtype != BZ_I32 || slot_mapping->nbytes < (size_t)S * 4) BZ_FAIL(BZ_E_INVALID, "forward_paged: slot_mapping must be I32[S]");
+  if (!block_table || block_table->dtype != BZ_I32 || block_table->nbytes < (size_t)n_table * 4) BZ_FAIL(BZ_E_INVALID, "forward_paged: block_table must be I32[n_table]");
+  if (start_pos < 0 || start_pos + S != seq_len_k) BZ_FAIL(BZ_E_INVALID, "forward_paged: start_pos + S must equal seq_len_k");
+  if ((seq_len_k + kv->block_size - 1) / kv->block_size > n_table) BZ_FAIL(BZ_E_INVALID, "forward_paged: block_table too short for seq_len_k");
+  if (seq_len_k > m->cfg.max_seq_len) BZ_FAIL(BZ_E_INVALID, "forward_paged: seq_len_k exceeds max_seq_len");
+  const bool all = flags & BZ_FWD_ALL_LOGITS;
+  for (int s = 0; s < S; s++) {
+    hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, m->dev->stream, m->pos_tmp, start_pos + s);
+    StepIO io{};
+    io.kv = view_of(kv, (const int*)block_table->ptr, (const int*)slot_mapping->ptr + s);
+    io.d_tok = (const long long*)tokens->ptr + s; io.d_pos = m->pos_tmp;
+    io.do_head = all || s == S - 1;
+    BZ_TRY(llama_step(m, io));
+    if (io.do_head) BZ_TRY(emit_logits(m, logits_out, all ? s : 0));
+  }
+  kv->seq_len = seq_len_k;
+  return BZ_OK;
+}
+
+extern "C" int bz_forward_embed(bz_model* m, const bz_tensor* tokens, int S, bz_tensor* hidden_out) {
+  BZ_TRY(check_fwd(m, tokens, S));
+  const int H = m->cfg.hidden;
+  if (!hidden_out || hidden_out->dtype != BZ_F32 || hidden_out->nbytes < (size_t)S * H * 4) BZ_FAIL(BZ_E_INVALID, "forward_embed: hidden_out must be F32 [S,hidden]");
+  for (int s = 0; s < S; s++)
+    BZ_TRY(bzk_embed(m->dev->stream, m->embed, m->embed_dt, (const long long*)tokens->ptr + s, H, m->cfg.act_dtype, (float*)hidden_out->ptr + (size_t)s * H));
+  return BZ_OK;
+}
+
+extern "C" int bz_forward_layers_range(bz_model* m, bz_tensor* hidden, bz_tensor* prev_mlp, int* has_prev, int S, bz_kv* kv, int start, int end, int position) {
+  if (!m || !m->finalized) BZ_FAIL(BZ_E_INVALID, "model not finalized");
+  const int H = m->cfg.hidden;
+  if (!hidden || hidden->dtype != BZ_F32 || hidden->nbytes < (size_t)S * H * 4 || !prev_mlp || prev_mlp->dtype != BZ_F32 || prev_mlp->nbytes < (size_t)S * H * 4 || !has_prev)
+    BZ_FAIL(BZ_E_INVALID, "layers_range: hidden / prev_mlp must be F32 [S,hidden]");
+  if (start < 0 || end > m->cfg.n_layers || start > end) BZ_FAIL(BZ_E_INVALID, "layers_range: bad layer range [%d,%d)", start, end);
+  if (!kv || position < 0 || position + S > m->cfg.max_seq_len) BZ_FAIL(BZ_E_INVALID, "layers_range: bad cache / position");
+  BZ_HIP(hipSetDevice(m->dev->id));
+  BZ_TRY(kv_grow(kv, position + S));
+  if (start == end) return BZ_OK;
+  for (int s = 0; s < S; s++) {
+    hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, m->dev->stream, m->pos_tmp, position + s);
+    StepIO io{};
+    io.kv = view_of(kv); io.d_tok = nullptr; io.d_pos = m->pos_tmp;
+    io.do_embed = false; io.do_head = false; io.layer_start = start; io.layer_end = end;
+    io.hidden_in = (float*)hidden->ptr + (size_t)s * H;
+    io.prev_in = *has_prev ? (float*)prev_mlp->ptr + (size_t)s * H : nullptr;
+    io.hidden_out = (float*)hidden->ptr + (size_t)s * H;
+    io.prev_out = (float*)prev_mlp->ptr + (size_t)s * H;
+    BZ_TRY(llama_step(m, io));
+  }
+  *has_prev = 1;
+  if (end == m->cfg.n_layers) kv->seq_len = position + S;
+  return BZ_OK;
+}
+
+extern "C" int bz_forward_head(bz_model* m, const bz_tensor* hidden, const bz_tensor* prev_mlp, int has_prev, int S, bz_tensor* logits_out, uint32_t flags) {
+  if (!m || !m->finalized) BZ_FAIL(BZ_E_INVALID, "model not finalized");
+  const int H = m->cfg.hidden;
+  if (!hidden || hidden->dtype != BZ_F32 || hidden->nbytes < (size_t)S * H * 4) BZ_FAIL(BZ_E_INVALID, "forward_head: hidden must be F32 [S,hidden]");
+  if (has_prev && (!prev_mlp || prev_mlp->nbytes < (size_t)S * H * 4)) BZ_FAIL(BZ_E_INVALID, "forward_head: prev_mlp must be F32 [S,hidden]");
+  BZ_HIP(hipSetDevice(m->dev->id));
+  const bool all = flags & BZ_FWD_ALL_LOGITS;
+  for (int s = all ? 0 : S - 1; s < S; s++) {
+    StepIO io{};
+    io.do_embed = false; io.do_head = true; io.layer_start = 0; io.layer_end = 0;
+    io.hidden_in = (const float*)hidden->ptr + (size_t)s * H;
+    io.prev_in = has_prev ? (const float*)prev_mlp->ptr + (size_t)s * H : nullptr;
+    BZ_TRY(llama_step(m, io));
+    BZ_TRY(emit_logits(m, logits_out, all ? s : 0));
+  }
+  return BZ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// sampling
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int bz_logits_to_token(bz_device* dev, const bz_tensor* logits, int64_t rows, int64_t vocab, const bz_tensor* ids, const bz_tensor* cnts,
+                                  int n, float rp, float fp, float pp, float temperature, int top_k, float top_p, float min_p, uint64_t seed,
+                                  bz_tensor* token_out) {
+  if (!dev || !logits || !token_out || rows <= 0 || vocab <= 0) BZ_FAIL(BZ_E_INVALID, "logits_to_token: bad argument");
+  if (logits->dtype != BZ_F32 || logits->nbytes < (size_t)rows * vocab * 4) BZ_FAIL(BZ_E_INVALID, "logits_to_token: logits must be F32 [rows,vocab]");
+  if (token_out->dtype != BZ_I64 || token_out->nbytes < 8) BZ_FAIL(BZ_E_INVALID, "logits_to_token: token_out must be I64[1]");
+  if (n > 0 && (!ids || !cnts || ids->dtype != BZ_I64 || cnts->dtype != BZ_I32 || ids->nbytes < (size_t)n * 8 || cnts->nbytes < (size_t)n * 4))
+    BZ_FAIL(BZ_E_INVALID, "logits_to_token: ids I64[n] / cnts I32[n] required");
+  BZ_HIP(hipSetDevice(dev->id));
+  float* scratch = dev->scratch;
+  int rc = bzk_logits_to_token(dev->stream, (const float*)logits->ptr + (size_t)(rows - 1) * vocab, vocab, n ? (const long long*)ids->ptr : nullptr,
+                               n ? (const int*)cnts->ptr : nullptr, n, rp, fp, pp, temperature, top_k, top_p, min_p, seed, scratch,
+                               (long long*)token_out->ptr);
+  return rc;
+}
+extern "C" int bz_argmax_to_buf(bz_device* dev, const bz_tensor* logits, int64_t rows, int64_t vocab, bz_tensor* token_out) {
+  return bz_logits_to_token(dev, logits, rows, vocab, nullptr, nullptr, 0, 1.0f, 0.f, 0.f, 0.f, 0, 1.f, 0.f, 0, token_out);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// whole-step hipGraph
+// ---------------------------------------------------------------------------------------------------------
+struct bz_decode_graph {
+  bz_model* m = nullptr;
+  hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+  long long* tok_buf = nullptr;     // device: input token of the next replay
+  int* pos = nullptr;               // device: position of the next replay
+  int* step = nullptr;              // device: replay counter
+  long long* tok_log = nullptr;     // pinned host, written by the final kernel: log[step % LOGCAP]
+  int* block_table = nullptr; int max_blocks = 0;
+  bz_kv* kv = nullptr; bz_paged_kv* pkv = nullptr;
+  std::vector<hipEvent_t> evs;
+  long long replays = 0;
+  static const int LOGCAP = 4096;
+};
+
+static int graph_capture_common(bz_decode_graph* g, const KvView& view) {
+  bz_model* m = g->m;
+  hipStream_t st = m->dev->stream;
+  BZ_HIP(hipMalloc(&g->tok_buf, 64));
+  BZ_HIP(hipMalloc(&g->pos, 64));
+  BZ_HIP(hipMalloc(&g->step, 64));
+  BZ_HIP(hipMemset(g->tok_buf, 0, 64)); BZ_HIP(hipMemset(g->pos, 0, 64)); BZ_HIP(hipMemset(g->step, 0, 64));
+  BZ_HIP(hipHostMalloc(&g->tok_log, sizeof(long long) * bz_decode_graph::LOGCAP, hipHostMallocDefault));
+  memset(g->tok_log, 0xff, sizeof(long long) * bz_decode_graph::LOGCAP);
+  BZ_HIP(hipStreamSynchronize(st));
+  FinalArgs fa{};
+  fa.tok_out = g->tok_buf; fa.tok_log = g->tok_log; fa.step = g->step; fa.logcap = bz_decode_graph::LOGCAP; fa.pos = g->pos;
+  StepIO io{};
+  io.kv = view; io.d_tok = g->tok_buf; io.d_pos = g->pos; io.final_args = &fa;
+  BZ_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+  int rc = llama_step(m, io);
+  hipGraph_t graph = nullptr;
+  hipError_t e = hipStreamEndCapture(st, &graph);
+  if (rc != BZ_OK) { if (graph) hipGraphDestroy(graph); return rc; }
+  if (e != hipSuccess) BZ_FAIL(BZ_E_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+  g->graph = graph;
+  BZ_HIP(hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0));
+  for (int i = 0; i < 8; i++) { hipEvent_t ev; BZ_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); g->evs.push_back(ev); }
+  return BZ_OK;
+}
+
+extern "C" int bz_decode_graph_capture(bz_model* m, bz_kv* kv, bz_decode_graph** out) {
+  if (!m || !m->finalized || !kv || !out) BZ_FAIL(BZ_E_INVALID, "graph capture: bad argument");
+  BZ_HIP(hipSetDevice(m->dev->id));
+  // stable addresses: the cache must sit at full capacity (cuda_graphs.rs:70)
+  BZ_TRY(kv_grow(kv, kv->max_len));
+  bz_decode_graph* g = new bz_decode_graph();
+  g->m = m; g->kv = kv;
+  int rc = graph_capture_common(g, view_of(kv));
+  if (rc != BZ_OK) { bz_decode_graph_free(g); return rc; }
+  *out = g;
+  return BZ_OK;
+}
+extern "C" int bz_decode_graph_capture_paged(bz_model* m, bz_paged_kv* kv, int max_blocks, bz_decode_graph** out) {
+  if (!m || !m->finalized || !kv || !out || max_blocks <= 0) BZ_FAIL(BZ_E_INVALID, "graph capture: bad argument");
+  BZ_HIP(hipSetDevice(m->dev->id));
+  bz_decode_graph* g = new bz_decode_graph();
+  g->m = m; g->pkv = kv; g->max_blocks = max_blocks;
+  BZ_HIP(hipMalloc(&g->block_table, (size_t)max_blocks * 4));
+  BZ_HIP(hipMemset(g->block_table, 0, (size_t)max_blocks * 4));
+  int rc = graph_capture_common(g, view_of(kv, g->block_table, nullptr));
+  if (rc != BZ_OK) { bz_decode_graph_free(g); return rc; }
+  *out = g;
+  return BZ_OK;
+}
+extern "C" int bz_decode_graph_set_block_table(bz_decode_graph* g, const int32_t* bt, int n) {
+  if (!g || !g->block_table || !bt || n < 0 || n > g->max_blocks) BZ_FAIL(BZ_E_INVALID, "set_block_table: bad argument");
+  BZ_HIP(hipMemcpyAsync(g->block_table, bt, (size_t)n * 4, hipMemcpyHostToDevice, g->m->dev->stream));
+  BZ_HIP(hipStreamSynchronize(g->m->dev->stream));
+  return BZ_OK;
+}
+extern "C" int bz_decode_graph_seed(bz_decode_graph* g, int64_t token, int position) {
+  if (!g) BZ_FAIL(BZ_E_INVALID, "null graph");
+  if (position < 0 || position >= g->m->cfg.max_seq_len) BZ_FAIL(BZ_E_INVALID, "graph seed: position %d out of range", position);
+  hipStream_t st = g->m->dev->stream;
+  long long t = token; int p = position, z = 0;
+  BZ_HIP(hipMemcpyAsync(g->tok_buf, &t, 8, hipMemcpyHostToDevice, st));
+  BZ_HIP(hipMemcpyAsync(g->pos, &p, 4, hipMemcpyHostToDevice, st));
+  BZ_HIP(hipMemcpyAsync(g->step, &z, 4, hipMemcpyHostToDevice, st));
+  BZ_HIP(hipStreamSynchronize(st));
+  g->replays = 0;
+  return BZ_OK;
+}
+extern "C" int bz_decode_graph_replay(bz_decode_graph* g) {
+  if (!g || !g->exec) BZ_FAIL(BZ_E_INVALID, "null graph");
+  hipStream_t st = g->m->dev->stream;
+  BZ_HIP(hipGraphLaunch(g->exec, st));
+  BZ_HIP(hipEventRecord(g->evs[g->replays % g->evs.size()], st));
+  g->replays++;
+  if (g->kv) g->kv->seq_len++;
+  if (g->pkv) g->pkv->seq_len++;
+  return BZ_OK;
+}
+extern "C" int bz_decode_graph_read_token(bz_decode_graph* g, int64_t step, int64_t* out) {
+  if (!g || !out || step < 0 || step >= g->replays) BZ_FAIL(BZ_E_INVALID, "read_token: step %lld of %lld", (long long)step, g ? g->replays : 0);
+  if (g->replays - step > (long long)g->evs.size()) BZ_HIP(hipStreamSynchronize(g->m->dev->stream));
+  else BZ_HIP(hipEventSynchronize(g->evs[step % g->evs.size()]));
+  if (g->replays - step > bz_decode_graph::LOGCAP) BZ_FAIL(BZ_E_INVALID, "read_token: step %lld fell out of the token log", (long long)step);
+  *out = ((volatile long long*)g->tok_log)[step % bz_decode_graph::LOGCAP];
+  return BZ_OK;
+}
+extern "C" int bz_decode_graph_read_logits(bz_decode_graph* g, float* host, size_t n) {
+  if (!g || !host || n > (size_t)g->m->cfg.vocab) BZ_FAIL(BZ_E_INVALID, "read_logits: bad argument");
+  BZ_HIP(hipMemcpyAsync(host, g->m->logits, n * 4, hipMemcpyDeviceToHost, g->m->dev->stream));
+  BZ_HIP(hipStreamSynchronize(g->m->dev->stream));
+  return BZ_OK;
+}
+extern "C" int bz_decode_graph_free(bz_decode_graph* g) {
+  if (!g) return BZ_OK;
+  hipStreamSynchronize(g->m->dev->stream);
+  for (auto ev : g->evs) hipEventDestroy(ev);
+  if (g->exec) hipGraphExecDestroy(g->exec);
+  if (g->graph) hipGraphDestroy(g->graph);
+  if (g->tok_buf) hipFree(g->tok_buf);
+  if (g->pos) hipFree(g->pos);
+  if (g->step) hipFree(g->step);
+  if (g->block_table) hipFree(g->block_table);
+  if (g->tok_log) hipHostFree(g->tok_log);
+  delete g;
+  return BZ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host decode loop: restates Executor::generate (/root/reference/src/engine/executor_generate.rs:341-410, contiguous
+// branch; :182-340 paged branch) and generate_with_graphs (/root/reference/src/engine/cuda_graphs.rs:34-190)
+// ---------------------------------------------------------------------------------------------------------
+// sampling.rs:169-191 penalty_window
+static int penalty_window(const std::vector<uint32_t>& hist, int last_n, std::vector<int64_t>& ids, std::vector<int32_t>& cnts) {
+  size_t b = 0;
+  if (last_n > 0 && (size_t)last_n < hist.size()) b = hist.size() - last_n;
+  ids.clear(); cnts.clear();
+  for (size_t i = b; i < hist.size(); i++) {
+    size_t j = 0;
+    for (; j < ids.size(); j++) if (ids[j] == (int64_t)hist[i]) { cnts[j]++; break; }
+    if (j == ids.size()) { ids.push_back(hist[i]); cnts.push_back(1); }
+  }
+  return (int)ids.size();
+}
+
+extern "C" int bz_generate(bz_model* m, const int64_t* prompt, int n_prompt, const bz_gen_config* gc, int64_t* out_tokens, bz_gen_stats* stats) {
+  if (!m || !m->finalized || !prompt || !gc || !out_tokens) BZ_FAIL(BZ_E_INVALID, "generate: bad argument");
+  if (n_prompt <= 0) { if (stats) memset(stats, 0, sizeof(*stats)); return BZ_OK; }  // executor_generate.rs:75-77
+  const bz_model_config& c = m->cfg;
+  bz_device* dev = m->dev;
+  BZ_HIP(hipSetDevice(dev->id));
+  for (int i = 0; i < n_prompt; i++) if (prompt[i] < 0 || prompt[i] >= c.vocab) BZ_FAIL(BZ_E_INVALID, "generate: prompt token %lld out of vocab", (long long)prompt[i]);
+  int max_tokens = std::min(gc->max_tokens, std::max(0, c.max_seq_len - n_prompt));  // :79-82
+  const bool greedy = gc->temperature == 0.0f;
+  if (gc->use_graph && !greedy) BZ_FAIL(BZ_E_INVALID, "generate: graph mode is greedy-only (cli/run.rs:144-157)");
+  const int kv_dt = c.act_dtype;
+  int rc = BZ_OK;
+  bz_tensor *t_prompt = nullptr, *t_logits = nullptr, *t_tok = nullptr, *t_ids = nullptr, *t_cnts = nullptr, *t_slot = nullptr, *t_bt = nullptr;
+  bz_kv* kv = nullptr; bz_paged_kv* pkv = nullptr; bz_decode_graph* graph = nullptr;
+  std::vector<uint32_t> history(prompt, prompt + n_prompt);
+  std::vector<int32_t> bt;
+  int n_out = 0, finish = 0;
+  auto T0 = std::chrono::steady_clock::now();
+  auto T1 = T0;
+  int64_t sh1[1] = {1}, shp[1] = {n_prompt}, shv[2] = {1, c.vocab}, sh64[1] = {4096};
+#define GEN_TRY(x) do { rc = (x); if (rc != BZ_OK) goto done; } while (0)
+  GEN_TRY(bz_tensor_from_host(dev, BZ_I64, shp, 1, prompt, &t_prompt));
+  GEN_TRY(bz_tensor_zeros(dev, BZ_F32, shv, 2, &t_logits));
+  GEN_TRY(bz_tensor_zeros(dev, BZ_I64, sh1, 1, &t_tok));
+  GEN_TRY(bz_tensor_zeros(dev, BZ_I64, sh64, 1, &t_ids));
+  GEN_TRY(bz_tensor_zeros(dev, BZ_I32, sh64, 1, &t_cnts));
+  if (gc->paged) {
+    const int bs = gc->block_size > 0 ? gc->block_size : 16;
+    const int total = n_prompt + max_tokens;
+    const int nblocks = (total + bs - 1) / bs + 4;  // executor_generate.rs:191-196
+    GEN_TRY(bz_paged_kv_create(dev, c.n_layers, nblocks, bs, c.n_kv_heads, c.head_dim, kv_dt, &pkv));
+    // CpuBlockAllocator hands out blocks in order; a private allocator gives 0,1,2,...
+    bt.resize(nblocks);
+    for (int i = 0; i < nblocks; i++) bt[i] = i;
+    int64_t shb[1] = {nblocks}, shs[1] = {n_prompt};
+    GEN_TRY(bz_tensor_from_host(dev, BZ_I32, shb, 1, bt.data(), &t_bt));
+    std::vector<int32_t> slots(n_prompt);
+    for (int i = 0; i < n_prompt; i++) slots[i] = bt[i / bs] * bs + i % bs;  // compute_slot_mapping (batch_decode.rs:81-88)
+    GEN_TRY(bz_tensor_from_host(dev, BZ_I32, shs, 1, slots.data(), &t_slot));
+    GEN_TRY(bz_forward_paged(m, t_prompt, n_prompt, pkv, t_slot, t_bt, nblocks, n_prompt, 0, t_logits, 0));
+  } else {
+    const int cap = std::min(n_prompt + max_tokens, c.max_seq_len);  // :346
+    GEN_TRY(bz_kv_create(dev, c.n_layers, 1, c.n_kv_heads, std::max(cap, 1), c.max_seq_len, c.head_dim, kv_dt, &kv));
+    GEN_TRY(bz_forward_kv(m, t_prompt, n_prompt, kv, 0, t_logits, 0));
+  }
+  GEN_TRY(bz_device_synchronize(dev));
+  T1 = std::chrono::steady_clock::now();
+
+  if (gc->use_graph) {
+    // cuda_graphs.rs:149-189: first token from the prefill logits, then one graph launch per token
+    int64_t tok;
+    GEN_TRY(bz_argmax_to_buf(dev, t_logits, 1, c.vocab, t_tok));
+    GEN_TRY(bz_tensor_to_host(t_tok, &tok, 8));
+    if (gc->paged) { GEN_TRY(bz_decode_graph_capture_paged(m, pkv, (int)bt.size(), &graph)); GEN_TRY(bz_decode_graph_set_block_table(graph, bt.data(), (int)bt.size())); }
+    else GEN_TRY(bz_decode_graph_capture(m, kv, &graph));
+    GEN_TRY(bz_decode_graph_seed(graph, tok, n_prompt));
+    for (int i = 0; i < max_tokens; i++) {
+      out_tokens[n_out++] = tok; history.push_back((uint32_t)tok);
+      if (tok == gc->eos_id) { finish = 1; break; }
+      if (i + 1 == max_tokens) break;
+      GEN_TRY(bz_decode_graph_replay(graph));
+      GEN_TRY(bz_decode_graph_read_token(graph, i, &tok));
+    }
+  } else {
+    std::vector<int64_t> ids; std::vector<int32_t> cnts;
+    const bool has_pen = gc->repeat_penalty != 1.0f || gc->frequency_penalty != 0.f || gc->presence_penalty != 0.f;
+    for (int i = 0; i < max_tokens; i++) {
+      int n = has_pen ? penalty_window(history, gc->repeat_last_n, ids, cnts) : 0;  // sampling.rs:431
+      if (n > 4096) { n = 4096; }
+      if (n) { GEN_TRY(bz_tensor_copy_from_host(t_ids, ids.data(), (size_t)n * 8)); GEN_TRY(bz_tensor_copy_from_host(t_cnts, cnts.data(), (size_t)n * 4)); }
+      GEN_TRY(bz_logits_to_token(dev, t_logits, 1, c.vocab, t_ids, t_cnts, n, gc->repeat_penalty, gc->frequency_penalty, gc->presence_penalty,
+                                 greedy ? 0.0f : gc->temperature, gc->top_k, gc->top_p, gc->min_p, gc->seed + (uint64_t)i, t_tok));
+      uint64_t ev;
+      GEN_TRY(bz_event_record(dev, &ev));                                           // :367 record_event
+      const bool last = i + 1 == max_tokens;
+      // :372 the next forward is launched BEFORE the token is read back (token stays on device)
+      if (!last) {
+        if (gc->paged) {
+          const int bs = pkv->block_size, cur = pkv->seq_len;
+          int32_t slot = bt[cur / bs] * bs + cur % bs;
+          GEN_TRY(bz_tensor_copy_from_host(t_slot, &slot, 4));
+          GEN_TRY(bz_forward_paged(m, t_tok, 1, pkv, t_slot, t_bt, (int)bt.size(), cur + 1, cur, t_logits, 0));
+        } else {
+          GEN_TRY(bz_forward_kv(m, t_tok, 1, kv, kv->seq_len, t_logits, 0));
+        }
+      }
+      int64_t tok;
+      GEN_TRY(bz_tensor_to_host_pipelined(t_tok, ev, &tok, 8));                      // :378 read_token_id
+      out_tokens[n_out++] = tok; history.push_back((uint32_t)tok);
+      if (tok == gc->eos_id) { finish = 1; break; }
+    }
+  }
+  GEN_TRY(bz_device_synchronize(dev));
+done:
+  {
+    auto T2 = std::chrono::steady_clock::now();
+    if (stats) {
+      stats->prefill_ms = std::chrono::duration<double, std::milli>(T1 - T0).count();
+      stats->decode_ms = std::chrono::duration<double, std::milli>(T2 - T1).count();
+      stats->n_generated = n_out; stats->finish_reason = finish;
+    }
+  }
+  bz_decode_graph_free(graph);
+  bz_tensor_free(t_prompt); bz_tensor_free(t_logits); bz_tensor_free(t_tok); bz_tensor_free(t_ids); bz_tensor_free(t_cnts);
+  bz_tensor_free(t_slot); bz_tensor_free(t_bt);
+  bz_kv_free(kv); bz_paged_kv_free(pkv);
+  return rc;
+#undef GEN_TRY
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// op-level entry points
+// ---------------------------------------------------------------------------------------------------------
+static int find_linear(bz_model* m, const char* name, LinearDev* out) {
+  if (!m || !m->finalized || !name) BZ_FAIL(BZ_E_INVALID, "model not finalized");
+  auto it = m->named.find(name);
+  if (it == m->named.end()) BZ_FAIL(BZ_E_NOTFOUND, "no linear weight named '%s'", name);
+  *out = it->second;
+  return BZ_OK;
+}
+
+extern "C" int bz_quant_matmul(bz_model* m, const char* name, const bz_tensor* x, int S, bz_tensor* y) {
+  LinearDev L;
+  BZ_TRY(find_linear(m, name, &L));
+  if (!x || !y || x->dtype != BZ_F32 || y->dtype != BZ_F32 || S <= 0 || x->nbytes < (size_t)S * L.K * 4 || y->nbytes < (size_t)S * L.N * 4)
+    BZ_FAIL(BZ_E_INVALID, "quant_matmul: x must be F32 [S,%d], y F32 [S,%d]", L.K, L.N);
+  BZ_HIP(hipSetDevice(m->dev->id));
+  hipStream_t st = m->dev->stream;
+  // op-level results are NOT rounded to the activation dtype: the caller sees the f32 accumulator
+  long long* acc = nullptr;
+  if (L.kind != LK_ROWS) BZ_HIP(hipMalloc(&acc, (size_t)L.N * 8));
+  int rc = BZ_OK;
+  for (int s = 0; s < S && rc == BZ_OK; s++) {
+    Pro p{}; p.mode = PRO_PLAIN; p.src = VSrc{(const float*)x->ptr + (size_t)s * L.K, 0}; p.act = BZ_F32; p.perm = L.perm;
+    GemvOut o{};
+    if (L.kind == LK_ROWS) { o.direct = (float*)y->ptr + (size_t)s * L.N; rc = bzk_gemv(st, L, p, o, BZ_F32); }
+    else {
+      rc = bzk_zero64(st, acc, L.N);
+      o.acc = acc;
+      if (rc == BZ_OK) rc = bzk_gemv(st, L, p, o, BZ_F32);
+      if (rc == BZ_OK) rc = bzk_fix_to_f32(st, acc, L.N, BZ_F32, (float*)y->ptr + (size_t)s * L.N);
+    }
+  }
+  hipStreamSynchronize(st);
+  if (acc) hipFree(acc);
+  return rc;
+}
+
+extern "C" int bz_dequant(bz_model* m, const char* name, float* host) {
+  LinearDev L;
+  BZ_TRY(find_linear(m, name, &L));
+  if (!host) BZ_FAIL(BZ_E_INVALID, "dequant: null output");
+  BZ_HIP(hipSetDevice(m->dev->id));
+  const size_t n = (size_t)L.N * L.K;
+  float* d;
+  BZ_HIP(hipMalloc(&d, n * 4));
+  int rc = L.kind == LK_Q4G ? bzk_dequant_q4g(m->dev->stream, L, d) : (L.kind == LK_ROWS ? bzk_dequant_rows(m->dev->stream, L, d) : BZ_E_UNSUPPORTED);
+  std::vector<float> tmp;
+  if (rc == BZ_OK) {
+    if (L.perm) {
+      // kernel order k' -> original k = perm[k']
+      tmp.resize(n);
+      hipMemcpy(tmp.data(), d, n * 4, hipMemcpyDeviceToHost);
+      std::vector<int> perm(L.K);
+      hipMemcpy(perm.data(), L.perm, (size_t)L.K * 4, hipMemcpyDeviceToHost);
+      for (int r = 0; r < L.N; r++) for (int k = 0; k < L.K; k++) host[(size_t)r * L.K + perm[k]] = tmp[(size_t)r * L.K + k];
+    } else {
+      hipMemcpy(host, d, n * 4, hipMemcpyDeviceToHost);
+    }
+  }
+  hipFree(d);
+  return rc;
+}
+
+extern "C" int bz_rms_norm(bz_device* dev, const bz_tensor* x, const bz_tensor* prev, const bz_tensor* w, int rows, int n, float eps, int act,
+                           bz_tensor* y, bz_tensor* h_out) {
+  if (!dev || !x || !w || !y || rows <= 0 || n <= 0) BZ_FAIL(BZ_E_INVALID, "rms_norm: bad argument");
+  const size_t need = (size_t)rows * n * 4;
+  if (x->dtype != BZ_F32 || y->dtype != BZ_F32 || w->dtype != BZ_F32 || x->nbytes < need || y->nbytes < need || w->nbytes < (size_t)n * 4 ||
+      (prev && prev->nbytes < need) || (h_out && h_out->nbytes < need))
+    BZ_FAIL(BZ_E_INVALID, "rms_norm: F32 tensors of [rows,n] / [n] required");
+  BZ_HIP(hipSetDevice(dev->id));
+  BZ_TRY(bzk_rms_norm(dev->stream, (const float*)x->ptr, prev ? (const float*)prev->ptr : nullptr, (const float*)w->ptr, rows, n, eps, act,
+                      (float*)y->ptr, h_out ? (float*)h_out->ptr : nullptr));
+  BZ_HIP(hipStreamSynchronize(dev->stream));
+  return BZ_OK;
+}
+
+extern "C" int bz_rope(bz_model* m, bz_tensor* x, int S, int n_heads, int position) {
+  if (!m || !m->finalized || !x || x->dtype != BZ_F32 || S <= 0 || n_heads <= 0) BZ_FAIL(BZ_E_INVALID, "rope: bad argument");
+  if (x->nbytes < (size_t)S * n_heads * m->cfg.head_dim * 4) BZ_FAIL(BZ_E_INVALID, "rope: x must be F32 [S,n_heads,head_dim]");
+  if (position < 0 || position + S > m->cfg.max_seq_len) BZ_FAIL(BZ_E_INVALID, "rope: positions out of range");
+  BZ_HIP(hipSetDevice(m->dev->id));
+  BZ_TRY(bzk_rope(m->dev->stream, (float*)x->ptr, S, n_heads, m->cfg.head_dim, position, m->cos_t, m->sin_t, m->cfg.rope_interleaved, m->cfg.act_dtype));
+  BZ_HIP(hipStreamSynchronize(m->dev->stream));
+  return BZ_OK;
+}
+
+extern "C" int bz_silu_mul(bz_device* dev, const bz_tensor* g, const bz_tensor* u, int64_t n, int act, bz_tensor* y) {
+  if (!dev || !g || !u || !y || n <= 0 || g->nbytes < (size_t)n * 4 || u->nbytes < (size_t)n * 4 || y->nbytes < (size_t)n * 4) BZ_FAIL(BZ_E_INVALID, "silu_mul: bad argument");
+  BZ_HIP(hipSetDevice(dev->id));
+  BZ_TRY(bzk_silu_mul(dev->stream, (const float*)g->ptr, (const float*)u->ptr, n, act, (float*)y->ptr));
+  BZ_HIP(hipStreamSynchronize(dev->stream));
+  return BZ_OK;
+}
+
+static int attn_common(bz_model* m, const bz_tensor* q, const KvView& view, int layer, int len, bz_tensor* out) {
+  const bz_model_config& c = m->cfg;
+  const size_t need = (size_t)c.n_heads * c.head_dim * 4;
+  if (!q || !out || q->dtype != BZ_F32 || out->dtype != BZ_F32 || q->nbytes < need || out->nbytes < need) BZ_FAIL(BZ_E_INVALID, "attn_decode: q/out must be F32 [n_heads,head_dim]");
+  if (layer < 0 || layer >= c.n_layers || len <= 0) BZ_FAIL(BZ_E_INVALID, "attn_decode: bad layer/len");
+  hipStream_t st = m->dev->stream;
+  hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, m->pos_tmp, len);
+  AttnArgs aa{};
+  aa.qkv = VSrc{q->ptr, 0}; aa.cos_t = m->cos_t; aa.sin_t = m->sin_t; aa.interleaved = c.rope_interleaved; aa.pos = m->pos_tmp;
+  aa.nq = c.n_heads; aa.nkv = c.n_kv_heads; aa.hd = c.head_dim; aa.act = c.act_dtype; aa.kv = view; aa.layer = layer; aa.out = (float*)out->ptr;
+  aa.q_only = 1;
+  BZ_TRY(bzk_attn_decode(st, aa));
+  BZ_HIP(hipStreamSynchronize(st));
+  return BZ_OK;
+}
+extern "C" int bz_attn_decode(bz_model* m, const bz_tensor* q, bz_kv* kv, int layer, int len, bz_tensor* out) {
+  if (!m || !m->finalized || !kv || len > kv->cap) BZ_FAIL(BZ_E_INVALID, "attn_decode: bad argument");
+  BZ_HIP(hipSetDevice(m->dev->id));
+  return attn_common(m, q, view_of(kv), layer, len, out);
+}
+extern "C" int bz_paged_attn_decode(bz_model* m, const bz_tensor* q, bz_paged_kv* kv, int layer, const bz_tensor* block_table, int len, bz_tensor* out) {
+  if (!m || !m->finalized || !kv || !block_table || block_table->dtype != BZ_I32) BZ_FAIL(BZ_E_INVALID, "paged_attn_decode: bad argument");
+  if ((size_t)((len + kv->block_size - 1) / kv->block_size) * 4 > block_table->nbytes) BZ_FAIL(BZ_E_INVALID, "paged_attn_decode: block_table too short");
+  BZ_HIP(hipSetDevice(m->dev->id));
+  return attn_common(m, q, view_of(kv, (const int*)block_table->ptr, nullptr), layer, len, out);
+}
+extern "C" int bz_kv_insert(bz_model* m, bz_kv* kv, int layer, int position, const bz_tensor* k, const bz_tensor* v) {
+  if (!m || !m->finalized || !kv || !k || !v) BZ_FAIL(BZ_E_INVALID, "kv_insert: bad argument");
+  const size_t need = (size_t)kv->n_kv * kv->hd * 4;
+  if (k->dtype != BZ_F32 || v->dtype != BZ_F32 || k->nbytes < need || v->nbytes < need) BZ_FAIL(BZ_E_INVALID, "kv_insert: k/v must be F32 [n_kv_heads,head_dim]");
+  if (layer < 0 || layer >= kv->layers || position < 0 || position >= kv->max_len) BZ_FAIL(BZ_E_INVALID, "kv_insert: bad layer/position");
+  BZ_HIP(hipSetDevice(m->dev->id));
+  BZ_TRY(kv_grow(kv, position + 1));
+  hipStream_t st = m->dev->stream;
+  hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, m->pos_tmp, position);
+  BZ_TRY(bzk_kv_insert(st, view_of(kv), layer, (const float*)k->ptr, (const float*)v->ptr, m->pos_tmp, kv->n_kv, kv->hd));
+  BZ_HIP(hipStreamSynchronize(st));
+  if (position + 1 > kv->seq_len) kv->seq_len = position + 1;
+  return BZ_OK;
+}

@@ -1,0 +1,167 @@
+// bz_internal.h -- internal types of libblazr_hip.so (host + device). Not part of the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include <unordered_map>
+#include <memory>
+#include "../../include/blazr_hip.h"
+
+// ---------------------------------------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------------------------------------
+void bz_set_error(const char* fmt, ...);
+#define BZ_FAIL(code, ...) do { bz_set_error(__VA_ARGS__); return (code); } while (0)
+#define BZ_HIP(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { \
+  bz_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); return BZ_E_HIP; } } while (0)
+#define BZ_TRY(expr) do { int rc__ = (expr); if (rc__ != BZ_OK) return rc__; } while (0)
+
+// ---------------------------------------------------------------------------------------------------------
+// device-visible PODs
+// ---------------------------------------------------------------------------------------------------------
+// A vector another kernel produced: plain f32 (already rounded to the activation dtype) or 64-bit fixed point
+// (2^-32 units) accumulated by split-K GEMV blocks with integer atomics (exactly associative => deterministic).
+struct VSrc { const void* p; int fix; };
+
+enum { PRO_PLAIN = 0, PRO_NORM = 1, PRO_SILU = 2 };
+// How a GEMV block builds its activation slice x[k0, k0+KR):
+struct Pro {
+  int mode;
+  VSrc src;            // PLAIN: x[K]; NORM: deferred residual prev[H] (p == nullptr: none); SILU: gate at [0,I), up at [I,2I)
+  const float* h_in;   // NORM: residual stream
+  float* h_out;        // NORM: h' = R(h + prev), written by block 0 (nullptr: skip)
+  const float* norm_w; // NORM
+  float eps;
+  int H;               // NORM: == K ; SILU: I
+  int act;             // activation dtype for rounding (BZ_F32/F16/BF16)
+  const int* perm;     // optional: x'[k] = x[perm[k]] (GPTQ act-order)
+};
+
+enum { LK_NONE = 0, LK_Q4G = 1, LK_ROWS = 2, LK_Q4K = 3, LK_Q6K = 4, LK_Q80 = 5 };
+
+// Device-resident linear layer in kernel layout.
+struct LinearDev {
+  int kind = LK_NONE;
+  int N = 0, K = 0, gs = 0;
+  int wdt = BZ_F16;         // ROWS: weight dtype
+  void* w = nullptr;        // Q4G: [N/64][K/32][64 lanes][16 B]; ROWS: [N][K]; K-quants: see kernels
+  void* scales = nullptr;   // Q4G: f16 [N/64][G][64]
+  void* zeros = nullptr;    // Q4G: u8  [N/64][G][64]  (AWQ z, GPTQ z+1)
+  void* hdr = nullptr;      // K-quants: per-superblock headers
+  int* perm = nullptr;      // GPTQ act-order
+  float* bias = nullptr;
+  int gw = 1;               // groups (of gs) per workgroup (split-K granularity)
+  size_t bytes = 0;         // resident bytes
+  size_t algo_bytes = 0;    // minimal on-disk bytes (SURVEY 8d accounting)
+  bool owned = true;
+};
+
+struct bz_device {
+  int id = 0;
+  hipStream_t stream = nullptr;
+  hipStream_t copy_stream = nullptr;
+  hipDeviceProp_t prop;
+  std::vector<hipEvent_t> events;
+  void* pinned = nullptr; size_t pinned_bytes = 0; // small pinned staging ring
+  size_t pinned_off = 0;
+  uint64_t event_counter = 0;
+  float* scratch = nullptr;   // 4 KiB device scratch (sampling partials)
+};
+
+struct bz_tensor {
+  bz_device* dev = nullptr;
+  void* ptr = nullptr;
+  int dtype = BZ_F32;
+  std::vector<int64_t> shape;
+  size_t nbytes = 0;
+  bool owned = true;
+};
+
+struct bz_kv {
+  bz_device* dev = nullptr;
+  int layers = 0, batch = 1, n_kv = 0, cap = 0, max_len = 0, hd = 0, dtype = BZ_F16;
+  int seq_len = 0;
+  void* k = nullptr; void* v = nullptr;   // [layer][kv_head][cap][hd]
+};
+
+struct bz_paged_kv {
+  bz_device* dev = nullptr;
+  int layers = 0, num_blocks = 0, block_size = 16, n_kv = 0, hd = 0, dtype = BZ_F16;
+  int seq_len = 0;
+  void* k = nullptr; void* v = nullptr;   // [layer][block][kv_head][block_size][hd]
+};
+
+// how the attention kernel finds K/V rows
+struct KvView {
+  void* k; void* v;
+  int dtype, hd, n_kv;
+  int paged;
+  long long layer_stride;   // elements between layers
+  // contiguous: row(p) = base + ((kvh*cap + p) * hd)
+  int cap;
+  // paged: row(p) = base + (((block_table[p/bs] * n_kv + kvh) * bs + p%bs) * hd)
+  int bs;
+  const int* block_table;
+  const int* slot;          // paged: write slot for the new token (nullptr: derive from pos via block_table)
+};
+
+size_t bz_dtype_size(int dtype);
+
+// ---------------------------------------------------------------------------------------------------------
+// kernel launchers (bz_kernels.hip)
+// ---------------------------------------------------------------------------------------------------------
+struct GemvOut {
+  long long* acc;        // Q4G/K-quants: fixed-point accumulator [N] (must be zero on entry)
+  float* direct;         // ROWS: direct store [N] (rounded to act)
+  long long* zero_buf;   // buffer this launch zeroes for the NEXT accumulate launch (nullptr: none)
+  int zero_n;
+  float* amax_val; int* amax_idx; // ROWS argmax partials per block (nullptr: off)
+};
+
+int bzk_gemv(hipStream_t s, const LinearDev& L, const Pro& pro, const GemvOut& out, int act);
+int bzk_gemv_rows_blocks(const LinearDev& L);   // number of workgroups the ROWS kernel uses (argmax partial count)
+int bzk_repack_awq(hipStream_t s, const uint32_t* d_qweight, const float* d_scales, const float* d_zeros, int N, int K, int gs,
+                   void* w_out, void* s_out, void* z_out);
+int bzk_repack_gptq(hipStream_t s, const uint32_t* d_qweight, const float* d_scales, const uint32_t* d_qzeros, const int* d_perm,
+                    const int* d_gidx, int N, int K, int gs, void* w_out, void* s_out, void* z_out);
+int bzk_dequant_q4g(hipStream_t s, const LinearDev& L, float* out /*[N][K] device*/);
+int bzk_dequant_rows(hipStream_t s, const LinearDev& L, float* out);
+int bzk_embed(hipStream_t s, const void* table, int tdt, const long long* tok, int H, int act, float* h_out);
+int bzk_fix_to_f32(hipStream_t s, const long long* acc, int n, int act, float* out);
+int bzk_zero64(hipStream_t s, long long* p, int n);
+
+struct AttnArgs {
+  VSrc qkv;                 // [nq*hd | nkv*hd | nkv*hd]
+  const float* cos_t; const float* sin_t; // [max_pos][hd/2]
+  int interleaved;
+  const int* pos;           // device scalar: position of the new token
+  int nq, nkv, hd, act;
+  KvView kv; int layer;
+  float* out;               // [nq*hd] f32 rounded
+  long long* zero_buf; int zero_n;
+  int q_only;               // op-level test: q given roped in qkv (plain), no insert, len = *pos
+};
+int bzk_attn_decode(hipStream_t s, const AttnArgs& a);
+int bzk_kv_insert(hipStream_t s, const KvView& kv, int layer, const float* k, const float* v, const int* pos, int nkv, int hd);
+int bzk_kv_read(hipStream_t s, const KvView& kv, int layer, int kvh, int which, int len, float* out);
+
+// final argmax over partials (or full logits) -> token; optionally advance position and publish token
+struct FinalArgs {
+  const float* pval; const int* pidx; int nparts;   // partials from ROWS kernel
+  long long* tok_out;       // next-token buffer (also the embed input of the next step)
+  long long* tok_log; int* step; // optional token ring log[*step % logcap] = tok; ++*step
+  int logcap;
+  int* pos;                 // optional: ++*pos
+  long long* zero_buf; int zero_n;
+};
+int bzk_argmax_final(hipStream_t s, const FinalArgs& a);
+int bzk_logits_to_token(hipStream_t s, const float* logits, long long V, const long long* ids, const int* cnts, int n, float rp,
+                        float fp, float pp, float temperature, int top_k, float top_p, float min_p, unsigned long long seed,
+                        float* scratch /*[V]*/, long long* tok_out);
+int bzk_rms_norm(hipStream_t s, const float* x, const float* prev, const float* w, int rows, int n, float eps, int act, float* y,
+                 float* h_out);
+int bzk_rope(hipStream_t s, float* x, int S, int nh, int hd, int position, const float* cos_t, const float* sin_t, int interleaved,
+             int act);
+int bzk_silu_mul(hipStream_t s, const float* g, const float* u, long long n, int act, float* y);

@@ -1,0 +1,1059 @@
+// bz_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the decode hot path.
+//
+// Design (DESIGN.md has the full story):
+//   * Every linear layer at batch 1 is an HBM-bound GEMV.  INT4 group-quantised weights (AWQ/GPTQ) are repacked
+//     once at load into [N/64 tiles][K/32 chunks][64 lanes][16 B] so that one wave-wide `global_load_dwordx4`
+//     reads 1 KiB contiguous = 32 k-values for 64 output columns; lane == output column, so there is no
+//     cross-lane reduction, and the activation slice is wave-uniform (broadcast reads from LDS).
+//   * The dot products run on V_DOT4_I32_I8: the f16 activation slice is split, per group of 128, into two
+//     int8 planes (x ~= sx * (256*hi + lo)), i.e. 16-bit fixed point relative to the group maximum -- error
+//     <= 2^-16 of the group max, far below the f16 rounding of the outputs.  Low nibbles are used as stored
+//     (q, 0..15), high nibbles are stored as (q-8) in two's complement so that `w & 0xF0F0F0F0` IS the signed
+//     byte 16*(q-8): one V_AND per 4 weights, no shifts.  All group arithmetic is exact in int32.
+//   * Split-K partial sums are added with 64-bit INTEGER atomics in 2^-32 fixed point: integer addition is
+//     associative, so the result is bit-reproducible regardless of block scheduling.  The consumer kernel
+//     converts and rounds in its prologue -- there are no separate reduce / norm / activation launches.
+//   * Each GEMV's prologue rebuilds its activation slice from the previous kernel's output (residual add,
+//     RMSNorm, SiLU*up, rounding to the activation dtype), issues its first weight loads BEFORE doing so, and
+//     stages the group scales/zeros for its tile in LDS.
+#include "bz_internal.h"
+#include <math.h>
+
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+// streamed-once weights: non-temporal loads (guide: nt on weights that one CU reads once)
+__device__ __forceinline__ uint4 ldnt(const uint4* p) {
+  const u32x4_t v = __builtin_nontemporal_load((const u32x4_t*)p);
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float4 ldnt(const float4* p) {
+  const f32x4_t v = __builtin_nontemporal_load((const f32x4_t*)p);
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// scalar helpers
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bf16_round(float x) {
+  unsigned u = __float_as_uint(x);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return x;  // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return __uint_as_float(u & 0xffff0000u);
+}
+__device__ __forceinline__ float round_act(float x, int act) {
+  if (act == BZ_F16) return __half2float(__float2half_rn(x));
+  if (act == BZ_BF16) return bf16_round(x);
+  return x;
+}
+// 2^-32 fixed point
+__device__ __forceinline__ float fix2f(long long a) {
+  int hi = (int)(a >> 32);
+  unsigned lo = (unsigned)(a & 0xffffffffll);
+  return (float)hi + (float)lo * 2.3283064365386963e-10f;
+}
+__device__ __forceinline__ long long f2fix(float p) { return __float2ll_rn(p * 4294967296.0f); }
+__device__ __forceinline__ float vsrc_get(const VSrc& s, int i, int act) {
+  if (s.fix) return round_act(fix2f(((const long long*)s.p)[i]), act);
+  return ((const float*)s.p)[i];
+}
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+  return v;
+}
+// deterministic block sum over 256 threads; red: LDS float[4]
+__device__ __forceinline__ float block_sum256(float v, float* red) {
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = (red[0] + red[1]) + (red[2] + red[3]);
+  __syncthreads();
+  return t;
+}
+
+__device__ __forceinline__ void zero_duty(long long* zb, int zn) {
+  if (zb)
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < zn; i += gridDim.x * blockDim.x) zb[i] = 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// prologue: build the activation slice x[k0, k0+KR) as f32 in LDS
+// ---------------------------------------------------------------------------------------------------------
+// Simple form (loads inside): used by the ROWS kernels, whose slice is all of K.
+// pos(i): LDS position of slice element i (identity, or the ROWS swizzle).
+template <bool SWZ>
+__device__ __forceinline__ int xs_pos(int i) {
+  if (!SWZ) return i;
+  return (i & ~511) + ((i & 4) << 6) + ((i & 511) >> 3 << 2) + (i & 3);
+}
+
+template <bool SWZ>
+__device__ void build_x_simple(const Pro& p, int k0, int KR, float* xs, float* red, bool writer) {
+  const int tid = threadIdx.x;
+  if (p.mode == PRO_NORM) {
+    const bool hasprev = p.src.p != nullptr;
+    float ss = 0.f;
+    for (int base = 0; base < p.H; base += 4096) {
+      float4 hv[4];
+      float pv[4][4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        int i = base + j * 1024 + tid * 4;
+        hv[j] = (i < p.H) ? *(const float4*)(p.h_in + i) : make_float4(0, 0, 0, 0);
+        if (hasprev) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) pv[j][e] = (i < p.H) ? vsrc_get(p.src, i + e, p.act) : 0.f;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        int i = base + j * 1024 + tid * 4;
+        float v[4] = {hv[j].x, hv[j].y, hv[j].z, hv[j].w};
+        if (hasprev) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] = round_act(v[e] + pv[j][e], p.act);
+        }
+        if (i < p.H) {
+          ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+          if (writer && p.h_out) *(float4*)(p.h_out + i) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      }
+    }
+    ss = block_sum256(ss, red);
+    const float rs = 1.0f / sqrtf(ss / (float)p.H + p.eps);
+    for (int base = 0; base < KR; base += 2048) {
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        int i = base + e * 256 + tid;
+        if (i < KR) {
+          int kk = p.perm ? p.perm[k0 + i] : (k0 + i);
+          float v = p.h_in[kk];
+          if (hasprev) v = round_act(v + vsrc_get(p.src, kk, p.act), p.act);
+          xs[xs_pos<SWZ>(i)] = round_act(p.norm_w[kk] * round_act(v * rs, p.act), p.act);
+        }
+      }
+    }
+  } else {
+    for (int base = 0; base < KR; base += 2048) {
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        int i = base + e * 256 + tid;
+        if (i < KR) {
+          int kk = p.perm ? p.perm[k0 + i] : (k0 + i);
+          float v;
+          if (p.mode == PRO_SILU) {
+            float g = vsrc_get(p.src, kk, p.act), u = vsrc_get(p.src, p.H + kk, p.act);
+            v = round_act(round_act(silu_f(g), p.act) * u, p.act);
+          } else {
+            v = vsrc_get(p.src, kk, p.act);
+          }
+          xs[xs_pos<SWZ>(i)] = v;
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// Split form for the int4 GEMV: `xload` only ISSUES the prologue's global loads into registers, then the caller
+// issues its first weight loads, then `xfinish` computes.  vmcnt is in-order, so this order lets the HBM weight
+// loads fly while the (L2-resident) prologue data is consumed.  MODE / FIX are compile-time so that every array
+// below is statically indexed and stays in registers.
+template <int FIX>
+__device__ __forceinline__ float vget(const void* p, int i, int act) {
+  if (FIX) return round_act(fix2f(((const long long*)p)[i]), act);
+  return ((const float*)p)[i];
+}
+
+template <int MODE, int MAXJ, int E>
+struct XRegs {
+  float4 h[MODE == PRO_NORM ? MAXJ : 1];     // NORM: full-H pass, element i = j*1024 + tid*4
+  float pf[MODE == PRO_NORM ? MAXJ : 1][4];  // NORM: prev as f32 (converted at load)
+  float sa[E];                               // slice element e: NORM h / PLAIN x / SILU gate
+  float sb[MODE == PRO_PLAIN ? 1 : E];       // NORM prev / SILU up
+  float sw[MODE == PRO_NORM ? E : 1];        // NORM weight
+};
+
+template <int MODE, int FIX, int MAXJ, int E>
+__device__ __forceinline__ void xload(const Pro& p, int k0, int KR, XRegs<MODE, MAXJ, E>& r) {
+  const int tid = threadIdx.x;
+  const bool hasprev = p.src.p != nullptr;
+  if (MODE == PRO_NORM) {
+#pragma unroll
+    for (int j = 0; j < MAXJ; j++) {
+      const int i = j * 1024 + tid * 4;
+      const bool on = i < p.H;
+      r.h[j] = on ? *(const float4*)(p.h_in + i) : make_float4(0, 0, 0, 0);
+#pragma unroll
+      for (int e = 0; e < 4; e++) r.pf[j][e] = (on && hasprev) ? vget<FIX>(p.src.p, i + e, p.act) : 0.f;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < E; e++) {
+    const int i = e * 256 + tid;
+    const bool on = i < KR;
+    const int kk = on ? (p.perm ? p.perm[k0 + i] : (k0 + i)) : 0;
+    if (MODE == PRO_NORM) {
+      r.sa[e] = on ? p.h_in[kk] : 0.f;
+      r.sb[e] = (on && hasprev) ? vget<FIX>(p.src.p, kk, p.act) : 0.f;
+      r.sw[e] = on ? p.norm_w[kk] : 0.f;
+    } else if (MODE == PRO_SILU) {
+      r.sa[e] = on ? vget<FIX>(p.src.p, kk, p.act) : 0.f;
+      r.sb[e] = on ? vget<FIX>(p.src.p, p.H + kk, p.act) : 0.f;
+    } else {
+      r.sa[e] = on ? vget<FIX>(p.src.p, kk, p.act) : 0.f;
+    }
+  }
+}
+
+template <int MODE, int MAXJ, int E>
+__device__ __forceinline__ void xfinish(const Pro& p, int KR, const XRegs<MODE, MAXJ, E>& r, float* xs, float* red, bool writer) {
+  const int tid = threadIdx.x;
+  const bool hasprev = p.src.p != nullptr;
+  if (MODE == PRO_NORM) {
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXJ; j++) {
+      const int i = j * 1024 + tid * 4;
+      float v[4] = {r.h[j].x, r.h[j].y, r.h[j].z, r.h[j].w};
+      if (hasprev) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[e] = round_act(v[e] + r.pf[j][e], p.act);
+      }
+      if (i < p.H) {
+        ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+        if (writer && p.h_out) *(float4*)(p.h_out + i) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+    ss = block_sum256(ss, red);
+    const float rs = 1.0f / sqrtf(ss / (float)p.H + p.eps);
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      const int i = e * 256 + tid;
+      float v = r.sa[e];
+      if (hasprev) v = round_act(v + r.sb[e], p.act);
+      v = round_act(r.sw[e] * round_act(v * rs, p.act), p.act);
+      if (i < KR) xs[i] = v;
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      const int i = e * 256 + tid;
+      float v = r.sa[e];
+      if (MODE == PRO_SILU) v = round_act(round_act(silu_f(v), p.act) * r.sb[e], p.act);
+      if (i < KR) xs[i] = v;
+    }
+  }
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// activation slice -> two int8 planes + per-group parameters   (QG = 128 k per group, 16 lanes x 8 each)
+//   gpar[g] = { sx/16 (as float bits), 128*sum_{k%8>=4} xi, 16*sum xi, 0 }
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void quant_x128(const float* xs, int KR, unsigned* xh, unsigned* xl, int4* gpar) {
+  for (int base = 0; base < KR; base += 2048) {
+    const int e0 = base + threadIdx.x * 8;
+    const bool on = e0 < KR;
+    float v[8];
+    if (on) {
+      float4 a = *(const float4*)(xs + e0), b = *(const float4*)(xs + e0 + 4);
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; i++) v[i] = 0.f;
+    }
+    float am = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) am = fmaxf(am, fabsf(v[i]));
+#pragma unroll
+    for (int m = 1; m <= 8; m <<= 1) am = fmaxf(am, __shfl_xor(am, m, 64));
+    const float inv = am > 0.f ? 32512.0f / am : 0.f;
+    int xi[8];
+    unsigned wh[2] = {0, 0}, wl[2] = {0, 0};
+    int sall = 0, sb = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      xi[i] = (int)rintf(v[i] * inv);
+      int hi = (xi[i] + 128) >> 8;
+      int lo = xi[i] - (hi << 8);
+      wh[i >> 2] |= ((unsigned)hi & 255u) << (8 * (i & 3));
+      wl[i >> 2] |= ((unsigned)lo & 255u) << (8 * (i & 3));
+      sall += xi[i];
+      if (i >= 4) sb += xi[i];
+    }
+#pragma unroll
+    for (int m = 1; m <= 8; m <<= 1) { sall += __shfl_xor(sall, m, 64); sb += __shfl_xor(sb, m, 64); }
+    if (on) {
+      *(uint2*)(xh + e0 / 4) = make_uint2(wh[0], wh[1]);
+      *(uint2*)(xl + e0 / 4) = make_uint2(wl[0], wl[1]);
+      if ((threadIdx.x & 15) == 0) gpar[e0 >> 7] = make_int4(__float_as_int(am * (1.0f / (32512.0f * 16.0f))), 128 * sb, 16 * sall, 0);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// INT4 group-quantised GEMV (AWQ / GPTQ after repack).  grid = nst * (G/GW) blocks of 256 threads.
+// ---------------------------------------------------------------------------------------------------------
+#define Q4G_E 8  // slice elements per thread (KR <= 2048)
+
+__device__ __forceinline__ void q4g_consume(const uint4 (&w)[4], int g, const uint4* xh4, const uint4* xl4, const int4* gpar,
+                                            float s, int z, float& y) {
+  int Ahi = 0, Alo = 0, Bhi = 0, Blo = 0;
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    const uint4 h0 = xh4[g * 8 + c * 2], h1 = xh4[g * 8 + c * 2 + 1];
+    const uint4 l0 = xl4[g * 8 + c * 2], l1 = xl4[g * 8 + c * 2 + 1];
+    const unsigned Xh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+    const unsigned Xl[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+    const unsigned W[4] = {w[c].x, w[c].y, w[c].z, w[c].w};
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int a = (int)(W[j] & 0x0F0F0F0Fu), b = (int)(W[j] & 0xF0F0F0F0u);
+      Ahi = __builtin_amdgcn_sdot4(a, (int)Xh[2 * j], Ahi, false);
+      Alo = __builtin_amdgcn_sdot4(a, (int)Xl[2 * j], Alo, false);
+      Bhi = __builtin_amdgcn_sdot4(b, (int)Xh[2 * j + 1], Bhi, false);
+      Blo = __builtin_amdgcn_sdot4(b, (int)Xl[2 * j + 1], Blo, false);
+    }
+  }
+  const int4 gp = gpar[g];
+  // 16 * sum_k (q_k - z) * xi_k, exact in two's complement (see file header)
+  const unsigned U = ((((unsigned)Ahi << 4) + (unsigned)Bhi) << 8) + (((unsigned)Alo << 4) + (unsigned)Blo) + (unsigned)gp.y -
+                     (unsigned)z * (unsigned)gp.z;
+  y += (s * __int_as_float(gp.x)) * (float)(int)U;
+}
+
+template <int MODE, int FIX, int MAXJ>
+__global__ __launch_bounds__(256) void k_gemv_q4g(const uint4* __restrict__ W, const __half* __restrict__ S,
+                                                  const unsigned char* __restrict__ Z, const float* __restrict__ bias, int N, int K,
+                                                  int GW, int nst, Pro pro, long long* acc, long long* zero_buf, int zero_n) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int KR = GW * 128;
+  float* xs = (float*)smem;                               // [KR]
+  unsigned* xh = (unsigned*)(xs + KR);                    // [KR/4]
+  unsigned* xl = xh + KR / 4;                             // [KR/4]
+  int4* gpar = (int4*)(xl + KR / 4);                      // [GW]
+  __half* sS = (__half*)(gpar + GW);                      // [4][GW][64]
+  unsigned char* sZ = (unsigned char*)(sS + 4 * GW * 64); // [4][GW][64]
+  float* red = (float*)(sZ + 4 * GW * 64);                // [4]
+
+  const int st = blockIdx.x % nst, ks = blockIdx.x / nst;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int nt = st * 4 + wave;
+  const bool wave_on = nt * 64 < N;
+  const int G = K >> 7;
+  const int k0 = ks * KR, g0 = ks * GW;
+
+  zero_duty(zero_buf, zero_n);
+
+  // (1) issue the prologue's loads (L2-resident data)
+  XRegs<MODE, MAXJ, Q4G_E> xr;
+  xload<MODE, FIX, MAXJ, Q4G_E>(pro, k0, KR, xr);
+
+  // (2) issue the first weight loads and the scale/zero staging loads (HBM)
+  const uint4* wp = W + ((size_t)nt * (K >> 5) + (k0 >> 5)) * 64 + lane;
+  uint4 A[4], B[4];
+#pragma unroll
+  for (int c = 0; c < 4; c++) { A[c] = make_uint4(0, 0, 0, 0); B[c] = make_uint4(0, 0, 0, 0); }
+  if (wave_on) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) A[c] = ldnt(wp + c * 64);
+    if (GW > 1) {
+#pragma unroll
+      for (int c = 0; c < 4; c++) B[c] = ldnt(wp + (4 + c) * 64);
+    }
+    for (int g = 0; g < GW; g++) {
+      sS[(wave * GW + g) * 64 + lane] = S[((size_t)nt * G + g0 + g) * 64 + lane];
+      sZ[(wave * GW + g) * 64 + lane] = Z[((size_t)nt * G + g0 + g) * 64 + lane];
+    }
+  }
+
+  // (3) finish the prologue while the weights are in flight
+  xfinish<MODE, MAXJ, Q4G_E>(pro, KR, xr, xs, red, blockIdx.x == 0);
+  quant_x128(xs, KR, xh, xl, gpar);
+  __syncthreads();
+  if (!wave_on) return;
+
+  // (4) stream the k-range: two groups (8 KiB per wave) in flight
+  const uint4* xh4 = (const uint4*)xh;
+  const uint4* xl4 = (const uint4*)xl;
+  float y = 0.f;
+  for (int g = 0; g < GW; g += 2) {
+    {
+      const float s = __half2float(sS[(wave * GW + g) * 64 + lane]);
+      const int z = sZ[(wave * GW + g) * 64 + lane];
+      q4g_consume(A, g, xh4, xl4, gpar, s, z, y);
+      if (g + 2 < GW) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) A[c] = ldnt(wp + ((g + 2) * 4 + c) * 64);
+      }
+    }
+    if (g + 1 < GW) {
+      const float s = __half2float(sS[(wave * GW + g + 1) * 64 + lane]);
+      const int z = sZ[(wave * GW + g + 1) * 64 + lane];
+      q4g_consume(B, g + 1, xh4, xl4, gpar, s, z, y);
+      if (g + 3 < GW) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) B[c] = ldnt(wp + ((g + 3) * 4 + c) * 64);
+      }
+    }
+  }
+  const int n = nt * 64 + lane;
+  if (bias != nullptr && ks == 0) y += bias[n];
+  atomicAdd((unsigned long long*)(acc + n), (unsigned long long)f2fix(y));
+}
+
+static size_t q4g_smem(int GW) {
+  size_t KR = (size_t)GW * 128;
+  return KR * 4 + KR / 4 * 4 * 2 + (size_t)GW * 16 + (size_t)4 * GW * 64 * 2 + (size_t)4 * GW * 64 + 16;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// dense row-major GEMV  W[N][K] (f16 / bf16 / f32), one wave per 4 rows at a time, x in LDS.
+// Direct store of the rounded result (+ optional fused argmax partials for lm_head).
+// ---------------------------------------------------------------------------------------------------------
+template <int WDT>
+__device__ __forceinline__ void load8(const void* W, size_t elem_off, bool on, float (&w)[8]) {
+  if (WDT == BZ_F32) {
+    float4 a = make_float4(0, 0, 0, 0), b = a;
+    if (on) { a = ldnt((const float4*)((const float*)W + elem_off)); b = ldnt((const float4*)((const float*)W + elem_off + 4)); }
+    w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+  } else {
+    uint4 r = make_uint4(0, 0, 0, 0);
+    if (on) r = ldnt((const uint4*)((const unsigned short*)W + elem_off));
+    const unsigned u[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      if (WDT == BZ_F16) {
+        w[2 * i] = __half2float(__ushort_as_half((unsigned short)(u[i] & 0xffffu)));
+        w[2 * i + 1] = __half2float(__ushort_as_half((unsigned short)(u[i] >> 16)));
+      } else {
+        w[2 * i] = __uint_as_float(u[i] << 16);
+        w[2 * i + 1] = __uint_as_float(u[i] & 0xffff0000u);
+      }
+    }
+  }
+}
+
+template <int WDT>
+__global__ __launch_bounds__(256) void k_gemv_rows(const void* __restrict__ W, const float* __restrict__ bias, int N, int K,
+                                                   int rows_per_wg, Pro pro, float* out, int act, float* pval, int* pidx,
+                                                   long long* zero_buf, int zero_n) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int KP = (K + 511) & ~511;
+  float* xs = (float*)smem;     // [KP] swizzled
+  float* red = xs + KP;         // [4] + argmax scratch [4] + [4]
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  zero_duty(zero_buf, zero_n);
+  for (int i = K + threadIdx.x; i < KP; i += 256) xs[xs_pos<true>(i)] = 0.f;
+  build_x_simple<true>(pro, 0, K, xs, red, blockIdx.x == 0);
+
+  const int rpw = rows_per_wg >> 2;
+  const int rbeg = blockIdx.x * rows_per_wg + wave * rpw;
+  const int rend = min(rbeg + rpw, N);
+  const int KC = KP >> 9;
+  const float4* xs4 = (const float4*)xs;
+  float bestv = -INFINITY; int besti = 0x7fffffff;
+  for (int r = rbeg; r < rend; r += 4) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+    for (int kc = 0; kc < KC; kc++) {
+      const int k = kc * 512 + lane * 8;
+      const bool kon = k < K;
+      float w[4][8];
+#pragma unroll
+      for (int rr = 0; rr < 4; rr++) load8<WDT>(W, (size_t)(r + rr) * K + k, kon && (r + rr < rend), w[rr]);
+      const float4 xa = xs4[kc * 128 + lane], xb = xs4[kc * 128 + 64 + lane];
+#pragma unroll
+      for (int rr = 0; rr < 4; rr++) {
+        acc[rr] += w[rr][0] * xa.x + w[rr][1] * xa.y + w[rr][2] * xa.z + w[rr][3] * xa.w + w[rr][4] * xb.x + w[rr][5] * xb.y +
+                   w[rr][6] * xb.z + w[rr][7] * xb.w;
+      }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) {
+      float v = wave_sum(acc[rr]);
+      if (r + rr < rend) {
+        if (bias) v += bias[r + rr];
+        v = round_act(v, act);
+        if (lane == 0) out[r + rr] = v;
+        if (v > bestv) { bestv = v; besti = r + rr; }
+      }
+    }
+  }
+  if (pval) {
+    float* bv = red + 4; int* bi = (int*)(red + 8);
+    if (lane == 0) { bv[wave] = bestv; bi[wave] = besti; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float v = bv[0]; int ix = bi[0];
+      for (int w2 = 1; w2 < 4; w2++) if (bv[w2] > v) { v = bv[w2]; ix = bi[w2]; }
+      pval[blockIdx.x] = v; pidx[blockIdx.x] = ix;
+    }
+  }
+}
+
+static int rows_per_wg_for(int N) {
+  // ~1000 workgroups when N is large, at least 16 rows (4 per wave) per workgroup
+  int r = 16;
+  while (r < 256 && (N + r - 1) / r > 1024) r <<= 1;
+  return r;
+}
+int bzk_gemv_rows_blocks(const LinearDev& L) { int r = rows_per_wg_for(L.N); return (L.N + r - 1) / r; }
+
+int bzk_gemv(hipStream_t s, const LinearDev& L, const Pro& pro, const GemvOut& out, int act) {
+  if (L.kind == LK_Q4G) {
+    if (!out.acc) BZ_FAIL(BZ_E_INVALID, "q4g gemv needs a fixed-point accumulator");
+    const int G = L.K / 128, GW = L.gw;
+    const int nst = (L.N + 255) / 256;
+    const int grid = nst * (G / GW);
+    const size_t smem = q4g_smem(GW);
+    const int maxj = pro.mode == PRO_NORM ? (pro.H + 1023) / 1024 : 1;
+    if (GW > 16) BZ_FAIL(BZ_E_INVALID, "q4g gemv: %d groups per workgroup (max 16)", GW);
+#define LAUNCH_Q4G(MODE, FIX, MJ) hipLaunchKernelGGL((k_gemv_q4g<MODE, FIX, MJ>), dim3(grid), dim3(256), smem, s, (const uint4*)L.w, \
+    (const __half*)L.scales, (const unsigned char*)L.zeros, L.bias, L.N, L.K, GW, nst, pro, out.acc, out.zero_buf, out.zero_n)
+#define LAUNCH_Q4G_F(MODE, MJ) do { if (pro.src.fix) LAUNCH_Q4G(MODE, 1, MJ); else LAUNCH_Q4G(MODE, 0, MJ); } while (0)
+    if (pro.mode == PRO_PLAIN) LAUNCH_Q4G_F(PRO_PLAIN, 1);
+    else if (pro.mode == PRO_SILU) LAUNCH_Q4G_F(PRO_SILU, 1);
+    else if (maxj <= 1) LAUNCH_Q4G_F(PRO_NORM, 1);
+    else if (maxj <= 2) LAUNCH_Q4G_F(PRO_NORM, 2);
+    else if (maxj <= 4) LAUNCH_Q4G_F(PRO_NORM, 4);
+    else if (maxj <= 8) LAUNCH_Q4G_F(PRO_NORM, 8);
+    else BZ_FAIL(BZ_E_UNSUPPORTED, "hidden size %d too large for the fused norm prologue", pro.H);
+#undef LAUNCH_Q4G_F
+#undef LAUNCH_Q4G
+    BZ_HIP(hipGetLastError());
+    return BZ_OK;
+  }
+  if (L.kind == LK_ROWS) {
+    if (!out.direct) BZ_FAIL(BZ_E_INVALID, "rows gemv needs a direct output");
+    const int rpw = rows_per_wg_for(L.N);
+    const int grid = (L.N + rpw - 1) / rpw;
+    const int KP = (L.K + 511) & ~511;
+    const size_t smem = (size_t)KP * 4 + 64;
+    if (smem > 160 * 1024) BZ_FAIL(BZ_E_UNSUPPORTED, "K=%d too large for the rows GEMV", L.K);
+#define LAUNCH_ROWS(DT) hipLaunchKernelGGL((k_gemv_rows<DT>), dim3(grid), dim3(256), smem, s, (const void*)L.w, L.bias, L.N, L.K, rpw, \
+    pro, out.direct, act, out.amax_val, out.amax_idx, out.zero_buf, out.zero_n)
+    if (L.wdt == BZ_F16) LAUNCH_ROWS(BZ_F16); else if (L.wdt == BZ_BF16) LAUNCH_ROWS(BZ_BF16); else LAUNCH_ROWS(BZ_F32);
+#undef LAUNCH_ROWS
+    BZ_HIP(hipGetLastError());
+    return BZ_OK;
+  }
+  BZ_FAIL(BZ_E_UNSUPPORTED, "gemv: linear kind %d not implemented", L.kind);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// load-time repack (runs once, on the GPU)
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned awq_nib(const uint32_t* qw, int N, int k, int n) {
+  // /root/reference/src/loader/safetensors/awq.rs:29-32 : column j of a word sits at shift [0,16,4,20,8,24,12,28][j]
+  const unsigned sh = ((n & 1) << 4) | ((n & 7) >> 1 << 2);
+  return (qw[(size_t)k * (N >> 3) + (n >> 3)] >> sh) & 15u;
+}
+
+__global__ void k_repack_awq(const uint32_t* qw, const float* sc, const float* zf, int N, int K, int gs, uint32_t* wout, __half* sout,
+                             unsigned char* zout) {
+  const size_t total = (size_t)N * (K >> 3);  // output words
+  const int G = K / gs;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int j = idx & 3;
+    const int lane = (idx >> 2) & 63;
+    const size_t t = idx >> 8;
+    const int kc = (int)(t % (size_t)(K >> 5));
+    const int nt = (int)(t / (size_t)(K >> 5));
+    const int n = nt * 64 + lane;
+    unsigned word = 0;
+#pragma unroll
+    for (int bb = 0; bb < 4; bb++) {
+      const int k1 = kc * 32 + j * 8 + bb;
+      const unsigned q1 = awq_nib(qw, N, k1, n), q2 = awq_nib(qw, N, k1 + 4, n);
+      word |= (q1 | ((q2 ^ 8u) << 4)) << (8 * bb);
+    }
+    wout[idx] = word;
+  }
+  const size_t gt = (size_t)N * G;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < gt; idx += (size_t)gridDim.x * blockDim.x) {
+    const int lane = idx & 63;
+    const size_t t = idx >> 6;
+    const int g = (int)(t % (size_t)G);
+    const int nt = (int)(t / (size_t)G);
+    const int n = nt * 64 + lane;
+    sout[idx] = __float2half_rn(sc[(size_t)g * N + n]);
+    zout[idx] = (unsigned char)(int)zf[(size_t)g * N + n];
+  }
+}
+
+__global__ void k_repack_gptq(const uint32_t* qw, const float* sc, const uint32_t* qz, const int* perm, const int* gidx, int N, int K,
+                              int gs, uint32_t* wout, __half* sout, unsigned char* zout) {
+  // /root/reference/src/loader/safetensors/gptq.rs:3-8 : qweight [K/8][N] sequential nibbles, qzeros [G][N/8] packed
+  const size_t total = (size_t)N * (K >> 3);
+  const int G = K / gs;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int j = idx & 3;
+    const int lane = (idx >> 2) & 63;
+    const size_t t = idx >> 8;
+    const int kc = (int)(t % (size_t)(K >> 5));
+    const int nt = (int)(t / (size_t)(K >> 5));
+    const int n = nt * 64 + lane;
+    unsigned word = 0;
+#pragma unroll
+    for (int bb = 0; bb < 4; bb++) {
+      int k1 = kc * 32 + j * 8 + bb, k2 = k1 + 4;
+      if (perm) { k1 = perm[k1]; k2 = perm[k2]; }
+      const unsigned q1 = (qw[(size_t)(k1 >> 3) * N + n] >> (4 * (k1 & 7))) & 15u;
+      const unsigned q2 = (qw[(size_t)(k2 >> 3) * N + n] >> (4 * (k2 & 7))) & 15u;
+      word |= (q1 | ((q2 ^ 8u) << 4)) << (8 * bb);
+    }
+    wout[idx] = word;
+  }
+  const size_t gt = (size_t)N * G;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < gt; idx += (size_t)gridDim.x * blockDim.x) {
+    const int lane = idx & 63;
+    const size_t t = idx >> 6;
+    const int gp = (int)(t % (size_t)G);      // group index in the (sorted) kernel order
+    const int nt = (int)(t / (size_t)G);
+    const int n = nt * 64 + lane;
+    // original group id of the sorted group: g_idx of its first member (all members share it)
+    const int g = (perm && gidx) ? gidx[perm[gp * gs]] : gp;
+    sout[idx] = __float2half_rn(sc[(size_t)g * N + n]);
+    zout[idx] = (unsigned char)(((qz[(size_t)g * (N >> 3) + (n >> 3)] >> (4 * (n & 7))) & 15u) + 1u);  // ASSUMPTION: AutoGPTQ v1 (+1)
+  }
+}
+
+int bzk_repack_awq(hipStream_t s, const uint32_t* q, const float* sc, const float* z, int N, int K, int gs, void* w, void* so, void* zo) {
+  hipLaunchKernelGGL(k_repack_awq, dim3(2048), dim3(256), 0, s, q, sc, z, N, K, gs, (uint32_t*)w, (__half*)so, (unsigned char*)zo);
+  BZ_HIP(hipGetLastError());
+  return BZ_OK;
+}
+int bzk_repack_gptq(hipStream_t s, const uint32_t* q, const float* sc, const uint32_t* qz, const int* perm, const int* gidx, int N, int K,
+                    int gs, void* w, void* so, void* zo) {
+  hipLaunchKernelGGL(k_repack_gptq, dim3(2048), dim3(256), 0, s, q, sc, qz, perm, gidx, N, K, gs, (uint32_t*)w, (__half*)so,
+                     (unsigned char*)zo);
+  BZ_HIP(hipGetLastError());
+  return BZ_OK;
+}
+
+// dequantise the REPACKED layout back to f32 [N][K'] (K' in kernel order, i.e. perm applied) -- validates the repack
+__global__ void k_dequant_q4g(const uint32_t* W, const __half* S, const unsigned char* Z, int N, int K, float* out) {
+  const size_t total = (size_t)N * K;
+  const int G = K >> 7;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int k = (int)(idx % (size_t)K);
+    const int n = (int)(idx / (size_t)K);
+    const int nt = n >> 6, lane = n & 63, kc = k >> 5, j = (k & 31) >> 3, r = k & 7;
+    const unsigned word = W[(((size_t)nt * (K >> 5) + kc) * 64 + lane) * 4 + j];
+    const unsigned byte = (word >> (8 * (r & 3))) & 255u;
+    const float q = (r < 4) ? (float)(byte & 15u) : (float)((byte >> 4) ^ 8u);
+    const size_t gi = ((size_t)nt * G + (k >> 7)) * 64 + lane;
+    out[idx] = (q - (float)Z[gi]) * __half2float(S[gi]);
+  }
+}
+int bzk_dequant_q4g(hipStream_t s, const LinearDev& L, float* out) {
+  hipLaunchKernelGGL(k_dequant_q4g, dim3(2048), dim3(256), 0, s, (const uint32_t*)L.w, (const __half*)L.scales,
+                     (const unsigned char*)L.zeros, L.N, L.K, out);
+  BZ_HIP(hipGetLastError());
+  return BZ_OK;
+}
+__global__ void k_dequant_rows(const void* W, int wdt, size_t total, float* out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    float v;
+    if (wdt == BZ_F32) v = ((const float*)W)[i];
+    else if (wdt == BZ_F16) v = __half2float(((const __half*)W)[i]);
+    else v = __uint_as_float((unsigned)((const unsigned short*)W)[i] << 16);
+    out[i] = v;
+  }
+}
+int bzk_dequant_rows(hipStream_t s, const LinearDev& L, float* out) {
+  hipLaunchKernelGGL(k_dequant_rows, dim3(2048), dim3(256), 0, s, (const void*)L.w, L.wdt, (size_t)L.N * L.K, out);
+  BZ_HIP(hipGetLastError());
+  return BZ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// small kernels
+// ---------------------------------------------------------------------------------------------------------
+__global__ void k_embed(const void* table, int tdt, const long long* tok, int H, int act, float* h) {
+  const long long t = tok[0];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < H; i += gridDim.x * blockDim.x) {
+    const size_t idx = (size_t)t * H + i;
+    float v;
+    if (tdt == BZ_F32) v = ((const float*)table)[idx];
+    else if (tdt == BZ_F16) v = __half2float(((const __half*)table)[idx]);
+    else v = __uint_as_float((unsigned)((const unsigned short*)table)[idx] << 16);
+    h[i] = round_act(v, act);
+  }
+}
+int bzk_embed(hipStream_t s, const void* table, int tdt, const long long* tok, int H, int act, float* h) {
+  hipLaunchKernelGGL(k_embed, dim3((H + 255) / 256), dim3(256), 0, s, table, tdt, tok, H, act, h);
+  BZ_HIP(hipGetLastError());
+  return BZ_OK;
+}
+
+__global__ void k_fix_to_f32(const long long* acc, int n, int act, float* out) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = round_act(fix2f(acc[i]), act);
+}
+int bzk_fix_to_f32(hipStream_t s, const long long* acc, int n, int act, float* out) {
+  hipLaunchKernelGGL(k_fix_to_f32, dim3((n + 255) / 256), dim3(256), 0, s, acc, n, act, out);
+  BZ_HIP(hipGetLastError());
+  return BZ_OK;
+}
+__global__ void k_zero64(long long* p, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0;
+}
+int bzk_zero64(hipStream_t s, long long* p, int n) {
+  hipLaunchKernelGGL(k_zero64, dim3((n + 255) / 256), dim3(256), 0, s, p, n);
+  BZ_HIP(hipGetLastError());
+  return BZ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// KV cache access
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ size_t kv_row_off(const KvView& kv, int layer, int kvh, int p) {
+  if (kv.paged) {
+    const int blk = kv.block_table[p / kv.bs];
+    return (size_t)layer * kv.layer_stride + (((size_t)blk * kv.n_kv + kvh) * kv.bs + (p % kv.bs)) * kv.hd;
+  }
+  return (size_t)layer * kv.layer_stride + ((size_t)kvh * kv.cap + p) * kv.hd;
+}
+__device__ __forceinline__ size_t kv_slot_off(const KvView& kv, int layer, int kvh, int slot) {
+  const int blk = slot / kv.bs, o = slot % kv.bs;
+  return (size_t)layer * kv.layer_stride + (((size_t)blk * kv.n_kv + kvh) * kv.bs + o) * kv.hd;
+}
+__device__ __forceinline__ float kv_ld(const void* base, size_t off, int dt) {
+  if (dt == BZ_F16) return __half2float(((const __half*)base)[off]);
+  if (dt == BZ_BF16) return __uint_as_float((unsigned)((const unsigned short*)base)[off] << 16);
+  return ((const float*)base)[off];
+}
+__device__ __forceinline__ void kv_st(void* base, size_t off, int dt, float v) {
+  if (dt == BZ_F16) ((__half*)base)[off] = __float2half_rn(v);
+  else if (dt == BZ_BF16) ((unsigned short*)base)[off] = (unsigned short)(__float_as_uint(bf16_round(v)) >> 16);
+  else ((float*)base)[off] = v;
+}
+// 8 consecutive elements of a row -> f32
+__device__ __forceinline__ void kv_ld8(const void* base, size_t off, int dt, float (&o)[8]) {
+  if (dt == BZ_F32) {
+    const float4 a = *(const float4*)((const float*)base + off), b = *(const float4*)((const float*)base + off + 4);
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+  } else {
+    const uint4 r = *(const uint4*)((const unsigned short*)base + off);
+    const unsigned u[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      if (dt == BZ_F16) {
+        o[2 * i] = __half2float(__ushort_as_half((unsigned short)(u[i] & 0xffffu)));
+        o[2 * i + 1] = __half2float(__ushort_as_half((unsigned short)(u[i] >> 16)));
+      } else {
+        o[2 * i] = __uint_as_float(u[i] << 16);
+        o[2 * i + 1] = __uint_as_float(u[i] & 0xffff0000u);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// attention decode: one workgroup per kv head; fuses q/k/v finishing (fixed-point -> f32, rounding), RoPE,
+// KV append and the single-query attention of the `rep` query heads that share the kv head.
+// ---------------------------------------------------------------------------------------------------------
+#define ATT_CH 256  // positions per wave per chunk
+#define ATT_MAXHD 256
+
+__global__ __launch_bounds__(256) void k_attn_decode(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int hd = a.hd, half = hd >> 1, rep = a.nq / a.nkv;
+  float* qs = (float*)smem;               // [rep][hd]
+  float* knew = qs + rep * hd;            // [hd]
+  float* vnew = knew + hd;                // [hd]
+  float* sc = vnew + hd;                  // [4][ATT_CH]
+  const int kvh = blockIdx.x;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int pos = a.pos[0];
+  const int len = a.q_only ? pos : pos + 1;
+  const KvView& kv = a.kv;
+  zero_duty(a.zero_buf, a.zero_n);
+
+  if (!a.q_only) {
+    const float* cr = a.cos_t + (size_t)pos * half;
+    const float* sr = a.sin_t + (size_t)pos * half;
+    for (int idx = tid; idx < (rep + 1) * half; idx += 256) {
+      const int hh = idx / half, i = idx % half;
+      const int base = hh < rep ? (kvh * rep + hh) * hd : a.nq * hd + kvh * hd;
+      const int ia = a.interleaved ? 2 * i : i, ib = a.interleaved ? 2 * i + 1 : i + half;
+      const float x0 = vsrc_get(a.qkv, base + ia, a.act), x1 = vsrc_get(a.qkv, base + ib, a.act);
+      const float c = cr[i], s = sr[i];
+      const float y0 = round_act(x0 * c - x1 * s, a.act), y1 = round_act(x1 * c + x0 * s, a.act);
+      if (hh < rep) { qs[hh * hd + ia] = y0; qs[hh * hd + ib] = y1; }
+      else { knew[ia] = y0; knew[ib] = y1; }
+    }
+    for (int i = tid; i < hd; i += 256) vnew[i] = vsrc_get(a.qkv, a.nq * hd + a.nkv * hd + kvh * hd + i, a.act);
+    __syncthreads();
+    // KV append (kv_insert)
+    size_t woff;
+    if (kv.paged) woff = kv_slot_off(kv, a.layer, kvh, kv.slot ? kv.slot[0] : (kv.block_table[pos / kv.bs] * kv.bs + pos % kv.bs));
+    else woff = kv_row_off(kv, a.layer, kvh, pos);
+    for (int i = tid; i < hd; i += 256) { kv_st(kv.k, woff + i, kv.dtype, knew[i]); kv_st(kv.v, woff + i, kv.dtype, vnew[i]); }
+  } else {
+    for (int i = tid; i < rep * hd; i += 256) qs[i] = ((const float*)a.qkv.p)[kvh * rep * hd + i];
+    __syncthreads();
+  }
+
+  const float scale = 1.0f / sqrtf((float)hd);
+  float* scw = sc + wave * ATT_CH;
+  const int nround = (rep + 3) >> 2;
+  for (int rd = 0; rd < nround; rd++) {
+    const int hq = rd * 4 + wave;
+    const bool active = hq < rep;
+    const float* q = qs + (active ? hq : 0) * hd;
+    float m = -INFINITY, l = 0.f;
+    float oacc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c0 = 0; c0 < len; c0 += ATT_CH) {
+      float sv[4];
+      float cm = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int p = c0 + j * 64 + lane;
+        float s = -INFINITY;
+        if (active && p < len) {
+          float d = 0.f;
+          if (!a.q_only && p == pos) {
+            for (int i = 0; i < hd; i++) d += q[i] * knew[i];
+          } else {
+            const size_t ro = kv_row_off(kv, a.layer, kvh, p);
+            for (int i = 0; i < hd; i += 8) {
+              float kk[8];
+              kv_ld8(kv.k, ro + i, kv.dtype, kk);
+              const float4 qa = *(const float4*)(q + i), qb = *(const float4*)(q + i + 4);
+              d += kk[0] * qa.x + kk[1] * qa.y + kk[2] * qa.z + kk[3] * qa.w + kk[4] * qb.x + kk[5] * qb.y + kk[6] * qb.z + kk[7] * qb.w;
+            }
+          }
+          s = d * scale;
+        }
+        sv[j] = s;
+        cm = fmaxf(cm, s);
+      }
+      cm = wave_max(cm);
+      const float mn = fmaxf(m, cm);
+      const float alpha = (m == -INFINITY) ? 0.f : expf(m - mn);
+      float ls = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const float e = (sv[j] == -INFINITY) ? 0.f : expf(sv[j] - mn);
+        scw[j * 64 + lane] = e;
+        ls += e;
+      }
+      l = l * alpha + wave_sum(ls);
+      m = mn;
+#pragma unroll
+      for (int t = 0; t < 4; t++) oacc[t] *= alpha;
+      __syncthreads();
+      const int cn = min(ATT_CH, len - c0);
+      if (active) {
+        for (int pp = 0; pp < cn; pp++) {
+          const float e = scw[pp];
+          const int p = c0 + pp;
+          if (!a.q_only && p == pos) {
+#pragma unroll
+            for (int t = 0; t < 4; t++) { const int d = lane + 64 * t; if (d < hd) oacc[t] += e * vnew[d]; }
+          } else {
+            const size_t ro = kv_row_off(kv, a.layer, kvh, p);
+#pragma unroll
+            for (int t = 0; t < 4; t++) { const int d = lane + 64 * t; if (d < hd) oacc[t] += e * kv_ld(kv.v, ro + d, kv.dtype); }
+          }
+        }
+      }
+      __syncthreads();
+    }
+    if (active) {
+      const float inv = 1.0f / l;
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        const int d = lane + 64 * t;
+        if (d < hd) a.out[(size_t)(kvh * rep + hq) * hd + d] = round_act(oacc[t] * inv, a.act);
+      }
+    }
+  }
+}
+
+int bzk_attn_decode(hipStream_t s, const AttnArgs& a) {
+  if (a.hd > ATT_MAXHD || (a.hd & 7)) BZ_FAIL(BZ_E_UNSUPPORTED, "head_dim %d unsupported", a.hd);
+  const int rep = a.nq / a.nkv;
+  const size_t smem = (size_t)(rep * a.hd + 2 * a.hd + 4 * ATT_CH) * 4;
+  hipLaunchKernelGGL(k_attn_decode, dim3(a.nkv), dim3(256), smem, s, a);
+  BZ_HIP(hipGetLastError());
+  return BZ_OK;
+}
+
+__global__ void k_kv_insert(KvView kv, int layer, const float* k, const float* v, const int* pos, int nkv, int hd) {
+  const int p = pos[0];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nkv * hd; i += gridDim.x * blockDim.x) {
+    const int h = i / hd, d = i % hd;
+    const size_t off = kv.paged ? kv_slot_off(kv, layer, h, kv.slot ? kv.slot[0] : (kv.block_table[p / kv.bs] * kv.bs + p % kv.bs))
+                                : kv_row_off(kv, layer, h, p);
+    kv_st(kv.k, off + d, kv.dtype, k[i]);
+    kv_st(kv.v, off + d, kv.dtype, v[i]);
+  }
+}
+int bzk_kv_insert(hipStream_t s, const KvView& kv, int layer, const float* k, const float* v, const int* pos, int nkv, int hd) {
+  hipLaunchKernelGGL(k_kv_insert, dim3((nkv * hd + 255) / 256), dim3(256), 0, s, kv, layer, k, v, pos, nkv, hd);
+  BZ_HIP(hipGetLastError());
+  return BZ_OK;
+}
+__global__ void k_kv_read(KvView kv, int layer, int kvh, int which, int len, float* out) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < len * kv.hd; i += gridDim.x * blockDim.x) {
+    const int p = i / kv.hd, d = i % kv.hd;
+    out[i] = kv_ld(which ? kv.v : kv.k, kv_row_off(kv, layer, kvh, p) + d, kv.dtype);
+  }
+}
+int bzk_kv_read(hipStream_t s, const KvView& kv, int layer, int kvh, int which, int len, float* out) {
+  hipLaunchKernelGGL(k_kv_read, dim3((len * kv.hd + 255) / 256), dim3(256), 0, s, kv, layer, kvh, which, len, out);
+  BZ_HIP(hipGetLastError());
+  return BZ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// sampling
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool better(float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); }
+
+__global__ __launch_bounds__(256) void k_argmax_final(FinalArgs a) {
+  __shared__ float sv[256];
+  __shared__ int si[256];
+  float bv = -INFINITY; int bi = 0x7fffffff;
+  for (int i = threadIdx.x; i < a.nparts; i += 256) {
+    const float v = a.pval[i]; const int ix = a.pidx[i];
+    if (better(v, ix, bv, bi)) { bv = v; bi = ix; }
+  }
+  sv[threadIdx.x] = bv; si[threadIdx.x] = bi;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s && better(sv[threadIdx.x + s], si[threadIdx.x + s], sv[threadIdx.x], si[threadIdx.x])) {
+      sv[threadIdx.x] = sv[threadIdx.x + s]; si[threadIdx.x] = si[threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const long long tok = si[0];
+    a.tok_out[0] = tok;
+    if (a.tok_log) { const int st = a.step[0]; a.tok_log[st % a.logcap] = tok; a.step[0] = st + 1; }
+    if (a.pos) a.pos[0] = a.pos[0] + 1;
+  }
+  if (a.zero_buf) for (int i = threadIdx.x; i < a.zero_n; i += 256) a.zero_buf[i] = 0;
+}
+int bzk_argmax_final(hipStream_t s, const FinalArgs& a) {
+  hipLaunchKernelGGL(k_argmax_final, dim3(1), dim3(256), 0, s, a);
+  BZ_HIP(hipGetLastError());
+  return BZ_OK;
+}
+
+// SamplingOps::logits_to_token (/root/reference/src/engine/sampling.rs:445-460): penalties over <= a few hundred
+// ids, then argmax (temperature == 0).  Two launches: per-block partial argmax over penalised logits, then final.
+__global__ __launch_bounds__(256) void k_penalised_argmax(const float* logits, long long V, const long long* ids, const int* cnts, int n,
+                                                          float rp, float fp, float pp, float* pval, int* pidx) {
+  __shared__ float sv[256];
+  __shared__ int si[256];
+  float bv = -INFINITY; int bi = 0x7fffffff;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < V; i += (long long)gridDim.x * 256) {
+    float x = logits[i];
+    for (int j = 0; j < n; j++) {
+      if (ids[j] == i) {
+        if (rp != 1.0f) x = (x > 0.f) ? x / rp : x * rp;  // ASSUMPTION: llama.cpp sign rule (oracle/orc_ops.c)
+        x -= fp * (float)cnts[j] + pp;
+      }
+    }
+    if (better(x, (int)i, bv, bi)) { bv = x; bi = (int)i; }
+  }
+  sv[threadIdx.x] = bv; si[threadIdx.x] = bi;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s && better(sv[threadIdx.x + s], si[threadIdx.x + s], sv[threadIdx.x], si[threadIdx.x])) {
+      sv[threadIdx.x] = sv[threadIdx.x + s]; si[threadIdx.x] = si[threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { pval[blockIdx.x] = sv[0]; pidx[blockIdx.x] = si[0]; }
+}
+
+int bzk_logits_to_token(hipStream_t s, const float* logits, long long V, const long long* ids, const int* cnts, int n, float rp, float fp,
+                        float pp, float temperature, int top_k, float top_p, float min_p, unsigned long long seed, float* scratch,
+                        long long* tok_out) {
+  (void)top_k; (void)top_p; (void)min_p; (void)seed;
+  if (temperature != 0.0f)
+    BZ_FAIL(BZ_E_UNSUPPORTED, "logits_to_token: temperature > 0 sampling is not implemented yet (greedy + penalties only)");
+  const int nb = 64;
+  float* pval = scratch; int* pidx = (int*)(scratch + nb);
+  hipLaunchKernelGGL(k_penalised_argmax, dim3(nb), dim3(256), 0, s, logits, V, ids, cnts, n, rp, fp, pp, pval, pidx);
+  BZ_HIP(hipGetLastError());
+  FinalArgs fa{};
+  fa.pval = pval; fa.pidx = pidx; fa.nparts = nb; fa.tok_out = tok_out;
+  return bzk_argmax_final(s, fa);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// op-level kernels (tests; the forward path uses the fused forms above)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_rms_norm(const float* x, const float* prev, const float* w, int n, float eps, int act, float* y,
+                                                  float* h_out) {
+  __shared__ float red[4];
+  const float* xr = x + (size_t)blockIdx.x * n;
+  const float* pr = prev ? prev + (size_t)blockIdx.x * n : nullptr;
+  float ss = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    float v = xr[i];
+    if (pr) v = round_act(v + pr[i], act);
+    ss += v * v;
+  }
+  ss = block_sum256(ss, red);
+  const float rs = 1.0f / sqrtf(ss / (float)n + eps);
+  for (int i = threadIdx.x; i < n; i += 256) {
+    float v = xr[i];
+    if (pr) v = round_act(v + pr[i], act);
+    if (h_out) h_out[(size_t)blockIdx.x * n + i] = v;
+    y[(size_t)blockIdx.x * n + i] = round_act(w[i] * round_act(v * rs, act), act);
+  }
+}
+int bzk_rms_norm(hipStream_t s, const float* x, const float* prev, const float* w, int rows, int n, float eps, int act, float* y,
+                 float* h_out) {
+  hipLaunchKernelGGL(k_rms_norm, dim3(rows), dim3(256), 0, s, x, prev, w, n, eps, act, y, h_out);
+  BZ_HIP(hipGetLastError());
+  return BZ_OK;
+}
+
+__global__ void k_rope(float* x, int S, int nh, int hd, int position, const float* cos_t, const float* sin_t, int interleaved, int act) {
+  const int half = hd >> 1;
+  const size_t total = (size_t)S * nh * half;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int i = (int)(idx % half);
+    const size_t hv = idx / half;
+    const int sidx = (int)(hv / nh);
+    float* v = x + hv * hd;
+    const int ia = interleaved ? 2 * i : i, ib = interleaved ? 2 * i + 1 : i + half;
+    const float c = cos_t[(size_t)(position + sidx) * half + i], sn = sin_t[(size_t)(position + sidx) * half + i];
+    const float x0 = v[ia], x1 = v[ib];
+    v[ia] = round_act(x0 * c - x1 * sn, act);
+    v[ib] = round_act(x1 * c + x0 * sn, act);
+  }
+}
+int bzk_rope(hipStream_t s, float* x, int S, int nh, int hd, int position, const float* cos_t, const float* sin_t, int interleaved,
+             int act) {
+  const size_t total = (size_t)S * nh * (hd / 2);
+  hipLaunchKernelGGL(k_rope, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, S, nh, hd, position, cos_t, sin_t, interleaved, act);
+  BZ_HIP(hipGetLastError());
+  return BZ_OK;
+}
+
+__global__ void k_silu_mul(const float* g, const float* u, long long n, int act, float* y) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    y[i] = round_act(round_act(silu_f(g[i]), act) * u[i], act);
+}
+int bzk_silu_mul(hipStream_t s, const float* g, const float* u, long long n, int act, float* y) {
+  hipLaunchKernelGGL(k_silu_mul, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g, u, n, act, y);
+  BZ_HIP(hipGetLastError());
+  return BZ_OK;
+}

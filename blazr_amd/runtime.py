@@ -1,0 +1,476 @@
+"""Host-side mirror of the boostr surface blazr's engine calls, over the C-ABI.
+
+Names and argument meaning follow the reference so that parity tests read like the reference's call sites:
+
+* ``LoadedModel.forward_with_kv_cache(input, kv, position)``      /root/reference/src/engine/executor_generate.rs:357,372
+* ``LoadedModel.forward_with_paged_kv_cache(input, cache, slot_mapping, block_table, seq_len_k, start_pos)``  :259-262
+* ``LoadedModel.forward_embed / forward_layers_range / forward_head``  /root/reference/src/cli/swarm_forward.rs:205,239-263
+* ``LayeredKvCache.new_positional(...)``, ``LayeredPagedKvCache(...)``  executor_generate.rs:350-353, :208-210
+* ``logits_to_token(...)``  /root/reference/src/engine/sampling.rs:445-460
+* ``Executor.generate``  executor_generate.rs:341-410 (the loop itself runs in C++: ``bz_generate``)
+
+All compute happens in libblazr_hip.so on the GPU; numpy arrays are only the host view of inputs/outputs.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+_NP2BZ = {np.dtype(np.float32): L.F32, np.dtype(np.float16): L.F16, np.dtype(np.int64): L.I64, np.dtype(np.int32): L.I32,
+          np.dtype(np.uint32): L.U32, np.dtype(np.uint8): L.U8}
+_BZ2NP = {L.F32: np.float32, L.F16: np.float16, L.BF16: np.uint16, L.I64: np.int64, L.I32: np.int32, L.U32: np.uint32, L.U8: np.uint8}
+_DT = {"f32": L.F32, "f16": L.F16, "bf16": L.BF16}
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Device:
+    """boostr::CudaDevice::new(id) + CudaClient (cli/run.rs:70-81)."""
+
+    def __init__(self, device_id=0):
+        h = C.c_void_p()
+        L.check(L.lib().bz_device_open(device_id, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            L.lib().bz_device_close(self.h)
+            self.h = None
+
+    def synchronize(self):
+        L.check(L.lib().bz_device_synchronize(self.h))
+
+    def memory_info(self):
+        f, t = C.c_size_t(), C.c_size_t()
+        L.check(L.lib().bz_device_memory_info(self.h, C.byref(f), C.byref(t)))
+        return f.value, t.value
+
+    def name(self):
+        b = C.create_string_buffer(256)
+        L.check(L.lib().bz_device_name(self.h, b, 256))
+        return b.value.decode()
+
+    def stream(self):
+        return L.lib().bz_device_stream(self.h)
+
+    # Tensor::from_slice / zeros
+    def tensor(self, array, dtype=None):
+        a = np.ascontiguousarray(array)
+        dt = dtype if dtype is not None else _NP2BZ[a.dtype]
+        shape = (C.c_int64 * max(a.ndim, 1))(*(a.shape if a.ndim else (1,)))
+        h = C.c_void_p()
+        L.check(L.lib().bz_tensor_from_host(self.h, dt, shape, max(a.ndim, 1), _ptr(a), C.byref(h)))
+        return Tensor(self, h, dt, tuple(a.shape) if a.ndim else (1,))
+
+    def zeros(self, shape, dtype=L.F32):
+        shape = tuple(int(s) for s in shape)
+        sh = (C.c_int64 * len(shape))(*shape)
+        h = C.c_void_p()
+        L.check(L.lib().bz_tensor_zeros(self.h, dtype, sh, len(shape), C.byref(h)))
+        return Tensor(self, h, dtype, shape)
+
+    def record_event(self):
+        ev = C.c_uint64()
+        L.check(L.lib().bz_event_record(self.h, C.byref(ev)))
+        return ev.value
+
+
+class Tensor:
+    def __init__(self, dev, h, dtype, shape):
+        self.dev, self.h, self.dtype, self.shape = dev, h, dtype, shape
+
+    def __del__(self):
+        try:
+            if self.h:
+                L.lib().bz_tensor_free(self.h)
+        except Exception:
+            pass
+
+    def to_numpy(self):
+        out = np.empty(self.shape, dtype=_BZ2NP[self.dtype])
+        L.check(L.lib().bz_tensor_to_host(self.h, _ptr(out), out.nbytes))
+        return out
+
+    to_vec = to_numpy
+
+    def copy_from(self, array):
+        a = np.ascontiguousarray(array, dtype=_BZ2NP[self.dtype])
+        L.check(L.lib().bz_tensor_copy_from_host(self.h, _ptr(a), a.nbytes))
+
+    def to_vec_pipelined(self, event):
+        out = np.empty(self.shape, dtype=_BZ2NP[self.dtype])
+        L.check(L.lib().bz_tensor_to_host_pipelined(self.h, event, _ptr(out), out.nbytes))
+        return out
+
+
+def make_config(cfg):
+    """synth/HF-style config dict -> bz_model_config POD."""
+    c = L.ModelConfig()
+    c.abi_version = L.ABI_VERSION
+    c.arch = L.ARCH_LLAMA
+    for k in ("hidden", "n_layers", "n_heads", "n_kv_heads", "head_dim", "inter", "vocab", "max_seq_len"):
+        setattr(c, k, int(cfg[k]))
+    c.rms_eps = cfg["rms_eps"]
+    c.act_dtype = _DT[cfg["act_dtype"]]
+    c.tie_embeddings = int(bool(cfg.get("tie_embeddings")))
+    c.rope_theta = cfg["rope_theta"]
+    c.rope_interleaved = int(cfg.get("rope_interleaved", 0))
+    rs = cfg.get("rope_scaling") or {}
+    c.rope_scaling = {"none": L.ROPE_NONE, "linear": L.ROPE_LINEAR, "llama3": L.ROPE_LLAMA3}[rs.get("type", "none")]
+    c.rope_factor = rs.get("factor", 1.0)
+    c.rope_low_freq_factor = rs.get("low_freq_factor", 1.0)
+    c.rope_high_freq_factor = rs.get("high_freq_factor", 4.0)
+    c.rope_original_max_pos = rs.get("original_max_position_embeddings", 8192)
+    return c
+
+
+_AWQ_SHIFTS = np.array([0, 16, 4, 20, 8, 24, 12, 28], dtype=np.uint32)  # awq.rs:32
+
+
+def unpack_awq_zeros(qzeros, N):
+    """awq.rs:239-263: packed [G, N/8] -> f32 [G, N] (what DecomposedQuantTensor carries)."""
+    qz = np.ascontiguousarray(qzeros, dtype=np.uint32)
+    return ((qz[:, :, None] >> _AWQ_SHIFTS[None, None, :]) & 0xF).reshape(qz.shape[0], N).astype(np.float32)
+
+
+class LoadedModel:
+    """boostr::model::LoadedModel<R> behind the C-ABI."""
+
+    def __init__(self, dev, cfg):
+        self.dev = dev
+        self.cfg = dict(cfg)
+        self.c = make_config(cfg)
+        h = C.c_void_p()
+        L.check(L.lib().bz_model_create(dev.h, C.byref(self.c), C.byref(h)))
+        self.h = h
+        self.finalized = False
+        self._shapes = {}
+
+    def __del__(self):
+        try:
+            if self.h:
+                L.lib().bz_model_free(self.h)
+        except Exception:
+            pass
+
+    # --- VarMap::insert / insert_decomposed_quant ---------------------------------------------------------
+    def add_dense(self, name, array):
+        a = np.ascontiguousarray(array)
+        dt = L.BF16 if a.dtype == np.uint16 else _NP2BZ[a.dtype]
+        shape = (C.c_int64 * a.ndim)(*a.shape)
+        L.check(L.lib().bz_model_add_dense(self.h, name.encode(), dt, shape, a.ndim, _ptr(a)))
+
+    def add_linear(self, base, spec):
+        """`spec` in the loader formats of blazr_amd.synth (== what awq.rs / gptq.rs / regular.rs produce)."""
+        name = (base + ".weight").encode()
+        kind = spec["kind"]
+        self._shapes[base + ".weight"] = (int(spec["N"]), int(spec["K"]))
+        if kind == "dense":
+            self.add_dense(base + ".weight", spec["weight"])
+        elif kind == "awq":
+            qw = np.ascontiguousarray(spec["qweight"], dtype=np.uint32)
+            sc = np.ascontiguousarray(spec["scales"]).astype(np.float32)            # awq.rs:202-206 f16 -> f32
+            zf = unpack_awq_zeros(spec["qzeros"], spec["N"])                        # awq.rs:208-213
+            L.check(L.lib().bz_model_add_awq(self.h, name, spec["N"], spec["K"], _ptr(qw), _ptr(sc), _ptr(zf), spec["group_size"]))
+        elif kind == "gptq":
+            qw = np.ascontiguousarray(spec["qweight"], dtype=np.uint32)
+            sc = np.ascontiguousarray(spec["scales"]).astype(np.float32)
+            qz = np.ascontiguousarray(spec["qzeros"], dtype=np.uint32)              # kept packed (gptq.rs:209-219)
+            gi = None if spec.get("g_idx") is None else np.ascontiguousarray(spec["g_idx"], dtype=np.int32)
+            bi = None if spec.get("bias") is None else np.ascontiguousarray(spec["bias"]).astype(np.float32)
+            L.check(L.lib().bz_model_add_gptq(self.h, name, spec["N"], spec["K"], _ptr(qw), _ptr(sc), _ptr(qz),
+                                              None if gi is None else _ptr(gi), None if bi is None else _ptr(bi), spec["group_size"]))
+        elif kind == "gguf":
+            b = np.ascontiguousarray(spec["blocks"], dtype=np.uint8)
+            L.check(L.lib().bz_model_add_gguf(self.h, name, spec["ggml_type"], spec["N"], spec["K"], _ptr(b)))
+        else:
+            raise ValueError(kind)
+
+    def add_llama_layer(self, i, lay):
+        p = "model.layers.%d." % i
+        self.add_dense(p + "input_layernorm.weight", np.asarray(lay["attn_norm"], dtype=np.float32))
+        self.add_dense(p + "post_attention_layernorm.weight", np.asarray(lay["ffn_norm"], dtype=np.float32))
+        for short, hf in (("q", "self_attn.q_proj"), ("k", "self_attn.k_proj"), ("v", "self_attn.v_proj"), ("o", "self_attn.o_proj"),
+                          ("gate", "mlp.gate_proj"), ("up", "mlp.up_proj"), ("down", "mlp.down_proj")):
+            self.add_linear(p + hf, lay[short])
+
+    def add_llama_head(self, embed, final_norm, lm_head):
+        self.add_dense("model.embed_tokens.weight", embed)
+        self.add_dense("model.norm.weight", np.asarray(final_norm, dtype=np.float32))
+        if not self.cfg.get("tie_embeddings"):
+            self.add_linear("lm_head", lm_head)
+
+    @classmethod
+    def from_synth(cls, dev, model):
+        """Whole in-memory model dict (blazr_amd.synth.make_llama)."""
+        m = cls(dev, model["config"])
+        for i, lay in enumerate(model["layers"]):
+            m.add_llama_layer(i, lay)
+        m.add_llama_head(model["embed"], model["final_norm"], model["lm_head"])
+        m.finalize()
+        return m
+
+    @classmethod
+    def from_synth_streamed(cls, dev, cfg, seed=None):
+        """Generate + upload layer by layer (bounded host memory) -- used for the 8B bench shape."""
+        from . import synth
+        kw = {} if seed is None else {"seed": seed}
+        m = cls(dev, cfg)
+        for i in range(cfg["n_layers"]):
+            m.add_llama_layer(i, synth.llama_layer(cfg, i, **kw))
+        emb, fn, lm = synth.llama_head(cfg, **kw)
+        m.add_llama_head(emb, fn, lm)
+        m.finalize()
+        return m
+
+    def finalize(self):
+        L.check(L.lib().bz_model_finalize(self.h))
+        self.finalized = True
+
+    # --- accessors (LoadedModel::num_layers etc.) ---------------------------------------------------------
+    def num_layers(self):
+        return self.c.n_layers
+
+    def num_kv_heads(self):
+        return self.c.n_kv_heads
+
+    def head_dim(self):
+        return self.c.head_dim
+
+    def hidden_size(self):
+        return self.c.hidden
+
+    def vocab_size(self):
+        return self.c.vocab
+
+    def needs_kv_cache(self):
+        return True
+
+    def needs_ssm_state(self):
+        return False
+
+    def weight_bytes(self):
+        a, b = C.c_size_t(), C.c_size_t()
+        L.check(L.lib().bz_model_weight_bytes(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def rope_caches(self):
+        n = self.c.max_seq_len * (self.c.head_dim // 2)
+        c, s = np.empty(n, np.float32), np.empty(n, np.float32)
+        L.check(L.lib().bz_rope_caches(self.h, _ptr(c), _ptr(s)))
+        return c.reshape(self.c.max_seq_len, -1), s.reshape(self.c.max_seq_len, -1)
+
+    # --- forward --------------------------------------------------------------------------------------------
+    def _tokens(self, tokens):
+        if isinstance(tokens, Tensor):
+            return tokens, int(np.prod(tokens.shape))
+        t = np.ascontiguousarray(tokens, dtype=np.int64).reshape(-1)
+        return self.dev.tensor(t), len(t)
+
+    def forward_with_kv_cache(self, tokens, kv, position, all_logits=False):
+        t, S = self._tokens(tokens)
+        out = self.dev.zeros((S if all_logits else 1, self.c.vocab), L.F32)
+        L.check(L.lib().bz_forward_kv(self.h, t.h, S, kv.h, position, out.h, L.FWD_ALL_LOGITS if all_logits else 0))
+        return out
+
+    def forward_with_paged_kv_cache(self, tokens, cache, slot_mapping, block_table, seq_len_k, start_pos, all_logits=False):
+        t, S = self._tokens(tokens)
+        sm = slot_mapping if isinstance(slot_mapping, Tensor) else self.dev.tensor(np.asarray(slot_mapping, dtype=np.int32))
+        bt = block_table if isinstance(block_table, Tensor) else self.dev.tensor(np.asarray(block_table, dtype=np.int32).reshape(-1))
+        out = self.dev.zeros((S if all_logits else 1, self.c.vocab), L.F32)
+        L.check(L.lib().bz_forward_paged(self.h, t.h, S, cache.h, sm.h, bt.h, int(np.prod(bt.shape)), seq_len_k, start_pos, out.h,
+                                         L.FWD_ALL_LOGITS if all_logits else 0))
+        return out
+
+    def forward_embed(self, tokens):
+        t, S = self._tokens(tokens)
+        out = self.dev.zeros((S, self.c.hidden), L.F32)
+        L.check(L.lib().bz_forward_embed(self.h, t.h, S, out.h))
+        return out
+
+    def forward_layers_range(self, hidden, prev_mlp, kv, start, end, position):
+        S = hidden.shape[0]
+        has = C.c_int(0 if prev_mlp is None else 1)
+        pm = prev_mlp if prev_mlp is not None else self.dev.zeros((S, self.c.hidden), L.F32)
+        L.check(L.lib().bz_forward_layers_range(self.h, hidden.h, pm.h, C.byref(has), S, kv.h, start, end, position))
+        return hidden, (pm if has.value else None)
+
+    def forward_head(self, hidden, prev_mlp, all_logits=False):
+        S = hidden.shape[0]
+        out = self.dev.zeros((S if all_logits else 1, self.c.vocab), L.F32)
+        L.check(L.lib().bz_forward_head(self.h, hidden.h, None if prev_mlp is None else prev_mlp.h, int(prev_mlp is not None), S, out.h,
+                                        L.FWD_ALL_LOGITS if all_logits else 0))
+        return out
+
+    # --- op-level ----------------------------------------------------------------------------------------------
+    def quant_matmul(self, name, x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        S = 1 if x.ndim == 1 else x.shape[0]
+        xt = self.dev.tensor(x.reshape(S, -1))
+        N = self.linear_shape(name)[0]
+        y = self.dev.zeros((S, N), L.F32)
+        L.check(L.lib().bz_quant_matmul(self.h, name.encode(), xt.h, S, y.h))
+        return y.to_numpy()
+
+    def linear_shape(self, name):
+        return self._shapes[name]
+
+    def dequant(self, name):
+        N, K = self._shapes[name]
+        out = np.empty((N, K), dtype=np.float32)
+        L.check(L.lib().bz_dequant(self.h, name.encode(), _ptr(out)))
+        return out
+
+
+class LayeredKvCache:
+    """boostr::inference::LayeredKvCache::new_positional (executor_generate.rs:350-353)."""
+
+    def __init__(self, dev, layers, batch, n_kv_heads, initial_capacity, max_seq_len, head_dim, dtype):
+        h = C.c_void_p()
+        L.check(L.lib().bz_kv_create(dev.h, layers, batch, n_kv_heads, initial_capacity, max_seq_len, head_dim, dtype, C.byref(h)))
+        self.h, self.dev, self.head_dim = h, dev, head_dim
+
+    new_positional = classmethod(lambda cls, *a: cls(*a))
+
+    def __del__(self):
+        try:
+            if self.h:
+                L.lib().bz_kv_free(self.h)
+        except Exception:
+            pass
+
+    def seq_len(self):
+        return L.lib().bz_kv_seq_len(self.h)
+
+    def reset(self):
+        L.check(L.lib().bz_kv_reset(self.h))
+
+    def read(self, layer, kv_head, which, length):
+        out = np.empty((length, self.head_dim), dtype=np.float32)
+        L.check(L.lib().bz_kv_read(self.h, layer, kv_head, which, length, _ptr(out)))
+        return out
+
+
+class LayeredPagedKvCache:
+    """boostr::inference::kv_cache::LayeredPagedKvCache::new (executor_generate.rs:208-210) + a private block list
+    (CpuBlockAllocator hands out blocks in order)."""
+
+    def __init__(self, dev, layers, num_blocks, block_size, n_kv_heads, head_dim, dtype):
+        h = C.c_void_p()
+        L.check(L.lib().bz_paged_kv_create(dev.h, layers, num_blocks, block_size, n_kv_heads, head_dim, dtype, C.byref(h)))
+        self.h, self.dev = h, dev
+        self.block_size, self.num_blocks = block_size, num_blocks
+        self.blocks = []
+
+    def __del__(self):
+        try:
+            if self.h:
+                L.lib().bz_paged_kv_free(self.h)
+        except Exception:
+            pass
+
+    def set_blocks(self, blocks):
+        self.blocks = list(blocks)
+
+    def seq_len(self):
+        return L.lib().bz_paged_kv_seq_len(self.h)
+
+    def set_seq_len(self, n):
+        L.check(L.lib().bz_paged_kv_set_seq_len(self.h, n))
+
+    def compute_slot_mapping(self, start, length):
+        """slot = block_id * block_size + offset (batch_decode.rs:81-88)."""
+        bs = self.block_size
+        return [self.blocks[p // bs] * bs + p % bs for p in range(start, start + length)]
+
+    def block_table_device_format(self):
+        return list(self.blocks)
+
+
+def penalty_window(recent_tokens, repeat_last_n):
+    """sampling.rs:169-191: unique ids + counts over the last `repeat_last_n` tokens."""
+    w = recent_tokens[-repeat_last_n:] if 0 < repeat_last_n < len(recent_tokens) else recent_tokens
+    ids, cnts = [], []
+    for t in w:
+        if t in ids:
+            cnts[ids.index(t)] += 1
+        else:
+            ids.append(int(t))
+            cnts.append(1)
+    return np.asarray(ids, dtype=np.int64), np.asarray(cnts, dtype=np.int32)
+
+
+def logits_to_token(dev, logits, ids, cnts, repeat_penalty=1.0, frequency_penalty=0.0, presence_penalty=0.0, temperature=0.0,
+                    top_k=0, top_p=1.0, min_p=0.0, seed=0):
+    """SamplingOps::logits_to_token (sampling.rs:445-460) -> I64[1] device tensor."""
+    rows, vocab = logits.shape
+    n = len(ids)
+    tid = dev.tensor(np.asarray(ids, dtype=np.int64)) if n else None
+    tcn = dev.tensor(np.asarray(cnts, dtype=np.int32)) if n else None
+    out = dev.zeros((1,), L.I64)
+    L.check(L.lib().bz_logits_to_token(dev.h, logits.h, rows, vocab, tid.h if n else None, tcn.h if n else None, n, repeat_penalty,
+                                       frequency_penalty, presence_penalty, temperature, top_k, top_p, min_p, seed, out.h))
+    return out
+
+
+class DecodeGraph:
+    """inference::decode_graph::DecodeGraph (cuda_graphs.rs:97-189) as a hipGraph."""
+
+    def __init__(self, model, kv, max_blocks=0):
+        h = C.c_void_p()
+        if isinstance(kv, LayeredPagedKvCache):
+            L.check(L.lib().bz_decode_graph_capture_paged(model.h, kv.h, max_blocks or kv.num_blocks, C.byref(h)))
+        else:
+            L.check(L.lib().bz_decode_graph_capture(model.h, kv.h, C.byref(h)))
+        self.h, self.model, self.kv = h, model, kv
+
+    def __del__(self):
+        try:
+            if self.h:
+                L.lib().bz_decode_graph_free(self.h)
+        except Exception:
+            pass
+
+    def seed_next_token(self, token, position):
+        L.check(L.lib().bz_decode_graph_seed(self.h, int(token), int(position)))
+
+    def set_block_table(self, blocks):
+        b = np.asarray(blocks, dtype=np.int32)
+        L.check(L.lib().bz_decode_graph_set_block_table(self.h, _ptr(b), len(b)))
+
+    def replay(self):
+        L.check(L.lib().bz_decode_graph_replay(self.h))
+
+    def read_token(self, step):
+        t = C.c_int64()
+        L.check(L.lib().bz_decode_graph_read_token(self.h, step, C.byref(t)))
+        return t.value
+
+    def read_logits(self):
+        out = np.empty(self.model.c.vocab, dtype=np.float32)
+        L.check(L.lib().bz_decode_graph_read_logits(self.h, _ptr(out), len(out)))
+        return out
+
+
+class Executor:
+    """engine::Executor<R> restricted to token ids in -> token ids out (tokenizer is out of scope)."""
+
+    def __init__(self, model):
+        self.model = model
+
+    def generate(self, prompt_tokens, max_tokens, temperature=0.0, repeat_penalty=1.0, repeat_last_n=64, frequency_penalty=0.0,
+                 presence_penalty=0.0, eos_id=-1, use_graph=False, paged=False, block_size=16, seed=0):
+        g = L.GenConfig()
+        g.max_tokens, g.temperature, g.repeat_penalty, g.repeat_last_n = max_tokens, temperature, repeat_penalty, repeat_last_n
+        g.frequency_penalty, g.presence_penalty = frequency_penalty, presence_penalty
+        g.top_k, g.top_p, g.min_p, g.seed = 0, 1.0, 0.0, seed
+        g.eos_id, g.use_graph, g.paged, g.block_size = eos_id, int(use_graph), int(paged), block_size
+        p = np.ascontiguousarray(prompt_tokens, dtype=np.int64)
+        out = np.zeros(max(max_tokens, 1), dtype=np.int64)
+        st = L.GenStats()
+        L.check(L.lib().bz_generate(self.model.h, _ptr(p), len(p), C.byref(g), _ptr(out), C.byref(st)))
+        self.last_stats = dict(prefill_ms=st.prefill_ms, decode_ms=st.decode_ms, n_generated=st.n_generated, finish_reason=st.finish_reason)
+        return out[:st.n_generated]

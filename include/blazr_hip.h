@@ -1,0 +1,225 @@
+/*
+ * blazr_hip.h -- C ABI of libblazr_hip.so: the MI355X (gfx950) forward path that sits where blazr's
+ * `boostr` dependency sits today.
+ *
+ * blazr is generic over `R: boostr::Runtime` (/root/reference/src/engine/executor.rs:67-80).  A Rust
+ * `HipRuntime` whose client methods forward to the functions below is the drop-in; the extern "C" block a
+ * maintainer would add is shown in INTEGRATION.md.  Every entry point cites the reference interface it
+ * replaces (file:line under /root/reference).
+ *
+ * Conventions
+ *   - every function returns BZ_OK (0) or a negative BZ_E* code; bz_last_error() gives the message of the
+ *     calling thread's last failure (boostr returns Result<_, E: Display>, stringified by blazr with
+ *     anyhow!("...: {}", e), e.g. executor_generate.rs:138).  No C++ exception crosses the boundary.
+ *   - handles are opaque; all device work is enqueued on the device handle's HIP stream; a cache / state
+ *     object must not be used from two host threads at once (blazr owns one per request,
+ *     executor_generate.rs:131,208,350).
+ *   - plain pointers and sizes only.  "host" pointers are ordinary host memory; device memory is only
+ *     reachable through bz_tensor handles.
+ *   - there is NO CPU fallback: without a HIP device every compute entry point fails with BZ_E_NODEVICE.
+ */
+#ifndef BLAZR_HIP_H
+#define BLAZR_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BZ_ABI_VERSION 1
+
+enum {
+  BZ_OK = 0,
+  BZ_E_INVALID = -1,    /* bad argument / shape / state */
+  BZ_E_NODEVICE = -2,   /* no usable HIP device */
+  BZ_E_HIP = -3,        /* HIP runtime error (message has hipGetErrorString) */
+  BZ_E_UNSUPPORTED = -4,/* valid request this build does not implement */
+  BZ_E_NOTFOUND = -5,   /* tensor name not registered */
+  BZ_E_OOM = -6
+};
+
+/* boostr::DType::{F32,F16,BF16,I64,I32,U32} (executor_cache.rs:178, awq.rs:194, gptq.rs:222) + U8 for raw blocks */
+enum { BZ_F32 = 0, BZ_F16 = 1, BZ_BF16 = 2, BZ_I64 = 3, BZ_I32 = 4, BZ_U32 = 5, BZ_U8 = 6 };
+
+/* ggml type ids accepted by bz_model_add_gguf (format::Gguf tensor_info().ggml_type, loader/gguf.rs:33) */
+enum { BZ_GGML_F32 = 0, BZ_GGML_F16 = 1, BZ_GGML_Q8_0 = 8, BZ_GGML_Q4_K = 12, BZ_GGML_Q6_K = 14, BZ_GGML_BF16 = 30 };
+
+enum { BZ_ARCH_LLAMA = 0, BZ_ARCH_MAMBA2 = 1, BZ_ARCH_DEEPSEEK2 = 2 };
+enum { BZ_ROPE_NONE = 0, BZ_ROPE_LINEAR = 1, BZ_ROPE_LLAMA3 = 2 };
+
+typedef struct bz_device bz_device;
+typedef struct bz_tensor bz_tensor;
+typedef struct bz_model bz_model;
+typedef struct bz_kv bz_kv;
+typedef struct bz_paged_kv bz_paged_kv;
+typedef struct bz_decode_graph bz_decode_graph;
+
+/* POD mirror of the fields of boostr::model::UniversalConfig that the forward path reads
+ * (loader/safetensors/config.rs:31-95, loader/gguf.rs:101-306, config/blazr.rs:35-52). */
+typedef struct {
+  int32_t abi_version;     /* BZ_ABI_VERSION */
+  int32_t arch;            /* BZ_ARCH_* */
+  int32_t hidden, n_layers, n_heads, n_kv_heads, head_dim, inter, vocab;
+  int32_t max_seq_len;
+  float   rms_eps;         /* default 1e-5, gguf.rs:157-160 */
+  int32_t act_dtype;       /* inference dtype: BZ_F16 for AWQ/GPTQ (awq.rs:69-71), BZ_F32 for GGUF (gguf.rs:305) */
+  int32_t tie_embeddings;  /* lm_head aliases model.embed_tokens.weight */
+  float   rope_theta;
+  int32_t rope_interleaved;/* 0: HF half-split pairs, 1: GGML NORM pairs (2i,2i+1) */
+  int32_t rope_scaling;    /* BZ_ROPE_* ; fields below per loader/safetensors/config.rs:83-95 */
+  float   rope_factor, rope_low_freq_factor, rope_high_freq_factor;
+  int32_t rope_original_max_pos;
+  int32_t reserved[16];
+} bz_model_config;
+
+/* ---- errors / device ------------------------------------------------------------------------------- */
+const char* bz_last_error(void);
+int bz_abi_version(void);
+/* boostr::CudaDevice::new(id) + CudaClient::new(device) (cli/run.rs:70-81) */
+int bz_device_open(int device_id, bz_device** out);
+int bz_device_close(bz_device* dev);
+int bz_device_synchronize(bz_device* dev);
+/* CudaDevice::memory_info() (cli/serve.rs:61) */
+int bz_device_memory_info(bz_device* dev, size_t* free_bytes, size_t* total_bytes);
+int bz_device_name(bz_device* dev, char* buf, size_t n);
+/* raw hipStream_t of the handle (for callers that time with HIP events on the launch stream) */
+void* bz_device_stream(bz_device* dev);
+
+/* ---- tensors (Tensor<R>::from_slice / zeros / to_vec / record_event / to_vec_pipelined) --------------- */
+int bz_tensor_from_host(bz_device* dev, int dtype, const int64_t* shape, int ndim, const void* host, bz_tensor** out);
+int bz_tensor_zeros(bz_device* dev, int dtype, const int64_t* shape, int ndim, bz_tensor** out);
+int bz_tensor_free(bz_tensor* t);
+int bz_tensor_to_host(const bz_tensor* t, void* host, size_t bytes);           /* Tensor::to_vec (sampling.rs:49) */
+int bz_tensor_nbytes(const bz_tensor* t, size_t* out);
+int bz_tensor_copy_from_host(bz_tensor* t, const void* host, size_t bytes);
+/* record_event() -> u64 ; to_vec_pipelined(event) (executor_cache.rs:199-204): event-synchronised D2H on a copy stream */
+int bz_event_record(bz_device* dev, uint64_t* event_out);
+int bz_event_sync(bz_device* dev, uint64_t event);
+int bz_tensor_to_host_pipelined(const bz_tensor* t, uint64_t event, void* host, size_t bytes);
+
+/* ---- model construction (VarMap::insert / insert_decomposed_quant / from_gguf -> LoadedModel::load) --- */
+int bz_model_create(bz_device* dev, const bz_model_config* cfg, bz_model** out);
+int bz_model_free(bz_model* m);
+/* VarMap::insert(name, tensor) (awq.rs:104, regular.rs:89-117). HF tensor names; shape [N,K] or [N]. dtype F32/F16/BF16. */
+int bz_model_add_dense(bz_model* m, const char* name, int dtype, const int64_t* shape, int ndim, const void* host);
+/* DecomposedQuantTensor::new(qweight u32[K,N/8], scales f32[K/gs,N], qzeros f32[K/gs,N], None, Awq{gs}, [N,K]) (awq.rs:190-225) */
+int bz_model_add_awq(bz_model* m, const char* name, int64_t N, int64_t K, const uint32_t* qweight, const float* scales,
+                     const float* zeros, int group_size);
+/* DecomposedQuantTensor::new(qweight u32[K/8,N], scales f32[G,N], qzeros u32[G,N/8], g_idx i32[K]?, Gptq{gs}, [N,K]) + bias f32[N]? (gptq.rs:198-259) */
+int bz_model_add_gptq(bz_model* m, const char* name, int64_t N, int64_t K, const uint32_t* qweight, const float* scales,
+                      const uint32_t* qzeros, const int32_t* g_idx, const float* bias, int group_size);
+/* VarMap::from_gguf (gguf.rs:33): raw ggml blocks of one tensor, N rows of K weights */
+int bz_model_add_gguf(bz_model* m, const char* name, int ggml_type, int64_t N, int64_t K, const void* raw_blocks);
+/* LoadedModel::load(&config.model, &mut vb) (awq.rs:133-136): validates names/shapes, repacks weights into the
+ * kernels' HBM layout, builds RoPE tables and workspaces.  Host copies passed to add_* may be freed afterwards. */
+int bz_model_finalize(bz_model* m);
+/* LoadedModel::{num_layers, num_kv_heads, head_dim, hidden_size, vocab_size, needs_kv_cache, needs_ssm_state} */
+int bz_model_get_config(const bz_model* m, bz_model_config* out);
+/* bytes of weights resident in HBM after repack, and the algorithmic bytes one decoded token streams */
+int bz_model_weight_bytes(const bz_model* m, size_t* resident, size_t* per_token_stream);
+
+/* ---- inference state ---------------------------------------------------------------------------------- */
+/* LayeredKvCache::new_positional(layers,batch,kv_heads,initial_capacity,max_seq_len,head_dim,dtype,device) (executor_generate.rs:350-353) */
+int bz_kv_create(bz_device* dev, int layers, int batch, int n_kv_heads, int initial_capacity, int max_seq_len, int head_dim,
+                 int dtype, bz_kv** out);
+int bz_kv_free(bz_kv* kv);
+int bz_kv_reset(bz_kv* kv);
+int bz_kv_seq_len(const bz_kv* kv);                    /* LayeredKvCache::seq_len() (executor_generate.rs:371) */
+/* debug/test: copy K or V rows [0,len) of (layer, kv_head) to host as f32 [len][head_dim] */
+int bz_kv_read(const bz_kv* kv, int layer, int kv_head, int which /*0=K,1=V*/, int len, float* host);
+/* LayeredPagedKvCache::new(layers,num_blocks,block_size,kv_heads,head_dim,dtype,device) (executor_generate.rs:208-210) */
+int bz_paged_kv_create(bz_device* dev, int layers, int num_blocks, int block_size, int n_kv_heads, int head_dim, int dtype,
+                       bz_paged_kv** out);
+int bz_paged_kv_free(bz_paged_kv* kv);
+int bz_paged_kv_set_seq_len(bz_paged_kv* kv, int seq_len);  /* set_seq_len (executor_generate.rs:242,286) */
+int bz_paged_kv_seq_len(const bz_paged_kv* kv);
+
+/* ---- forward ------------------------------------------------------------------------------------------ */
+#define BZ_FWD_ALL_LOGITS 1u  /* logits for all S positions ([S,V]); default: last position only ([1,V]) */
+/* LoadedModel::forward_with_kv_cache(&input,&mut kv,position) (executor_generate.rs:357,372).
+ * tokens: I64 [1,S] device tensor; logits_out: F32 [S or 1, vocab] device tensor (values rounded to act dtype). */
+int bz_forward_kv(bz_model* m, const bz_tensor* tokens, int S, bz_kv* kv, int position, bz_tensor* logits_out, uint32_t flags);
+/* LoadedModel::forward_with_paged_kv_cache(input,cache,slot_mapping,block_table,seq_len_k,start_pos) (executor_generate.rs:259-262,289-292).
+ * slot_mapping I32 [S], block_table I32 [1,n_table] device tensors. */
+int bz_forward_paged(bz_model* m, const bz_tensor* tokens, int S, bz_paged_kv* kv, const bz_tensor* slot_mapping,
+                     const bz_tensor* block_table, int n_table, int seq_len_k, int start_pos, bz_tensor* logits_out, uint32_t flags);
+/* forward_embed / forward_layers_range(hidden, prev_mlp, kv, start, end, position) / forward_head(hidden, prev_mlp)
+ * (cli/swarm_forward.rs:205,239-263; executor_multimodal.rs:263-268).  hidden/prev_mlp: F32 [S,hidden] device tensors;
+ * has_prev: in/out flag (prev_mlp = Option<Tensor>).  head(layers(embed(x))) == forward_kv(x) bit-for-bit. */
+int bz_forward_embed(bz_model* m, const bz_tensor* tokens, int S, bz_tensor* hidden_out);
+int bz_forward_layers_range(bz_model* m, bz_tensor* hidden, bz_tensor* prev_mlp, int* has_prev, int S, bz_kv* kv, int start,
+                            int end, int position);
+int bz_forward_head(bz_model* m, const bz_tensor* hidden, const bz_tensor* prev_mlp, int has_prev, int S, bz_tensor* logits_out,
+                    uint32_t flags);
+
+/* ---- sampling ----------------------------------------------------------------------------------------- */
+/* SamplingOps::logits_to_token(logits, ids, cnts, n, repeat, freq, presence, temperature, top_k, top_p, min_p, seed)
+ * -> I64[1] on device (engine/sampling.rs:445-460).  logits F32 [rows,vocab]: the LAST row is used (narrow).
+ * ids I64[n], cnts I32[n] device tensors (may be NULL when n == 0). */
+int bz_logits_to_token(bz_device* dev, const bz_tensor* logits, int64_t rows, int64_t vocab, const bz_tensor* ids,
+                       const bz_tensor* cnts, int n, float repeat_penalty, float freq_penalty, float presence_penalty,
+                       float temperature, int top_k, float top_p, float min_p, uint64_t seed, bz_tensor* token_out);
+/* decode_graph::argmax_to_buf(client, logits, next_token_buf) (cuda_graphs.rs:107,128); argmax_on_gpu (executor_cache.rs:189-196) */
+int bz_argmax_to_buf(bz_device* dev, const bz_tensor* logits, int64_t rows, int64_t vocab, bz_tensor* token_out);
+
+/* ---- whole-step graph (Runtime::capture_graph + DecodeGraph, cuda_graphs.rs:97-189) --------------------- */
+/* Captures one greedy decode step {embed(token_buf) -> layers -> head -> argmax -> token_buf, ++position} as a hipGraph
+ * over stable buffers with a device-resident position.  The cache must already hold the prefill. */
+int bz_decode_graph_capture(bz_model* m, bz_kv* kv, bz_decode_graph** out);
+int bz_decode_graph_capture_paged(bz_model* m, bz_paged_kv* kv, int max_blocks, bz_decode_graph** out);
+/* DecodeGraph::seed_next_token (cuda_graphs.rs:149-163): first input token + its position */
+int bz_decode_graph_seed(bz_decode_graph* g, int64_t token, int position);
+/* paged only: block table for the sequence (host i32[n]) -- slot_mapping is derived on device from position */
+int bz_decode_graph_set_block_table(bz_decode_graph* g, const int32_t* block_table, int n);
+/* DecodeGraph::pre_replay_and_launch (cuda_graphs.rs:166-170): one graph launch = one token */
+int bz_decode_graph_replay(bz_decode_graph* g);
+/* event-pipelined read of the token produced by replay number `step` (0-based since seed) */
+int bz_decode_graph_read_token(bz_decode_graph* g, int64_t step, int64_t* token_out);
+/* last logits of the most recent replay (F32 [vocab]) copied to host */
+int bz_decode_graph_read_logits(bz_decode_graph* g, float* host, size_t n);
+int bz_decode_graph_free(bz_decode_graph* g);
+
+/* ---- host decode loop (Executor::generate contiguous branch, executor_generate.rs:341-410) ---------------- */
+typedef struct {
+  int32_t max_tokens;
+  float   temperature;       /* 0 => greedy (generation.rs:262-264) */
+  float   repeat_penalty;    /* reference default 1.1 (generation.rs:164-166); 1.0 disables */
+  int32_t repeat_last_n;     /* 64 (commands.rs:40) */
+  float   frequency_penalty, presence_penalty;
+  int32_t top_k; float top_p, min_p; uint64_t seed;
+  int64_t eos_id;            /* -1: none */
+  int32_t use_graph;         /* --graphs (cli/run.rs:144-157): greedy only, penalties ignored as in the reference */
+  int32_t paged;             /* --paged-attention */
+  int32_t block_size;        /* 16 (inference.rs:189-191) */
+  int32_t reserved[8];
+} bz_gen_config;
+typedef struct { double prefill_ms, decode_ms; int32_t n_generated; int32_t finish_reason; /* 0 length, 1 eos */ } bz_gen_stats;
+/* prompt: host i64[n_prompt]; out_tokens: host i64[max_tokens] */
+int bz_generate(bz_model* m, const int64_t* prompt, int n_prompt, const bz_gen_config* gc, int64_t* out_tokens, bz_gen_stats* stats);
+
+/* ---- op-level entry points (parity tests; each is the kernel the forward path uses) ------------------------ */
+/* QuantMatmulOps / dense matmul on a registered weight `name` ("….weight"): y[S,N] = x[S,K] W^T (+bias); x,y F32 device tensors */
+int bz_quant_matmul(bz_model* m, const char* name, const bz_tensor* x, int S, bz_tensor* y);
+/* DequantOps: whole weight -> F32 [N,K] on host (from the REPACKED device layout: validates the repack) */
+int bz_dequant(bz_model* m, const char* name, float* host_out);
+/* NormalizationOps::rms_norm with optional fused residual: h' = round(h + prev) ; y = w * round(h' * rsqrt(mean(h'^2)+eps)) */
+int bz_rms_norm(bz_device* dev, const bz_tensor* x, const bz_tensor* prev /*nullable*/, const bz_tensor* weight, int rows, int n,
+                float eps, int act_dtype, bz_tensor* y, bz_tensor* h_out /*nullable*/);
+/* RoPE on [S, n_heads, head_dim] F32 in place, positions position..position+S-1, using the model's cos/sin caches (rope_caches()) */
+int bz_rope(bz_model* m, bz_tensor* x, int S, int n_heads, int position);
+/* ActivationOps/BinaryOps: y = round(round(silu(gate)) * up) */
+int bz_silu_mul(bz_device* dev, const bz_tensor* gate, const bz_tensor* up, int64_t n, int act_dtype, bz_tensor* y);
+/* single-token attention of q F32 [n_heads, head_dim] over layer `layer` of the cache, first `len` positions */
+int bz_attn_decode(bz_model* m, const bz_tensor* q, bz_kv* kv, int layer, int len, bz_tensor* out);
+int bz_paged_attn_decode(bz_model* m, const bz_tensor* q, bz_paged_kv* kv, int layer, const bz_tensor* block_table, int len,
+                         bz_tensor* out);
+/* kv_insert kernel (cuda_graphs.rs:5): write k,v F32 [n_kv_heads, head_dim] at `position` (contiguous) */
+int bz_kv_insert(bz_model* m, bz_kv* kv, int layer, int position, const bz_tensor* k, const bz_tensor* v);
+/* rope_caches() -> (cos, sin) F32 [max_pos, head_dim/2] copied to host */
+int bz_rope_caches(bz_model* m, float* cos_host, float* sin_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

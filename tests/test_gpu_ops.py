@@ -1,0 +1,195 @@
+"""GPU parity, op level: every kernel of the hot path against the CPU oracle, through the C-ABI.
+
+Bars: bit-exact for integer/byte work (repack -> dequant round trip, KV insert/read, argmax ids);
+fp tolerances are written at each assert.  The oracle is the checker only (see oracle/orc.h).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from blazr_amd import _lib as L
+from blazr_amd import runtime, synth
+from oracle import orc_py
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tiny_awq(device):
+    model = synth.make_llama("tiny-awq")
+    return model, runtime.LoadedModel.from_synth(device, model), orc_py.OrcLlama(model)
+
+
+@pytest.fixture(scope="module")
+def tiny_gptq(device):
+    model = synth.make_llama("tiny-gptq", act_order=True, bias=True)
+    return model, runtime.LoadedModel.from_synth(device, model), orc_py.OrcLlama(model)
+
+
+def _names(i=0):
+    p = "model.layers.%d." % i
+    return {"q": p + "self_attn.q_proj.weight", "k": p + "self_attn.k_proj.weight", "v": p + "self_attn.v_proj.weight",
+            "o": p + "self_attn.o_proj.weight", "gate": p + "mlp.gate_proj.weight", "up": p + "mlp.up_proj.weight",
+            "down": p + "mlp.down_proj.weight"}
+
+
+@pytest.mark.parametrize("fix", ["tiny_awq", "tiny_gptq"])
+def test_repack_dequant_bit_exact(fix, request):
+    """load-time repack (AWQ nibble order awq.rs:29-32 / GPTQ sequential + act-order) is lossless: dequantising the
+    REPACKED HBM layout reproduces the oracle's dequant of the original tensors bit for bit."""
+    model, lm, _ = request.getfixturevalue(fix)
+    for short, name in _names(1).items():
+        want = orc_py.OrcLinear(model["layers"][1][short]).dequant()
+        got = lm.dequant(name)
+        assert np.array_equal(got, want), (fix, short, np.abs(got - want).max())
+
+
+@pytest.mark.parametrize("fix", ["tiny_awq", "tiny_gptq"])
+@pytest.mark.parametrize("short", ["q", "k", "o", "gate", "down"])
+def test_quant_matmul_vs_oracle(fix, short, request):
+    model, lm, _ = request.getfixturevalue(fix)
+    spec = model["layers"][0][short]
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((3, spec["K"])).astype(np.float16).astype(np.float32)
+    x[1] *= 37.0          # large dynamic range
+    x[2, ::7] = 0.0
+    want = orc_py.OrcLinear(spec).forward(x)
+    got = lm.quant_matmul(_names(0)[short], x)
+    # int8x2 activation split: |err| <= 2^-16 * group max per term; f32 accumulation order differs from the oracle
+    tol = 2e-5 * np.abs(want).max() + 1e-6
+    assert np.abs(got - want).max() <= tol, (np.abs(got - want).max(), tol)
+
+
+def test_quant_matmul_edge_inputs(tiny_awq):
+    model, lm, _ = tiny_awq
+    spec = model["layers"][0]["gate"]
+    name = _names(0)["gate"]
+    K = spec["K"]
+    ol = orc_py.OrcLinear(spec)
+    for x in (np.zeros(K, np.float32), np.full(K, 65504.0, np.float32), np.full(K, -6.1e-5, np.float32),
+              np.eye(1, K, 5, dtype=np.float32)[0] * 3.0):
+        want = ol.forward(x)[0]
+        got = lm.quant_matmul(name, x)[0]
+        assert np.abs(got - want).max() <= 2e-5 * max(np.abs(want).max(), 1e-30) + 1e-12
+
+
+def test_rms_norm(device):
+    rng = np.random.default_rng(1)
+    for act, adt in (("f16", L.F16), ("bf16", L.BF16), ("f32", L.F32)):
+        n = 384
+        x = orc_py.round_act(rng.standard_normal((2, n)).astype(np.float32) * 3, act)
+        p = orc_py.round_act(rng.standard_normal((2, n)).astype(np.float32), act)
+        w = orc_py.round_act(1 + 0.1 * rng.standard_normal(n).astype(np.float32), act)
+        y, ho = device.zeros((2, n)), device.zeros((2, n))
+        L.check(L.lib().bz_rms_norm(device.h, device.tensor(x).h, device.tensor(p).h, device.tensor(w).h, 2, n, 1e-5, adt, y.h, ho.h))
+        h = orc_py.round_act(x + p, act)
+        want = np.empty_like(h)
+        for r in range(2):
+            orc_py.lib().orc_rms_norm(h[r].ctypes.data_as(C.c_void_p), w.ctypes.data_as(C.c_void_p), n, 1e-5, orc_py._DT[act],
+                                      want[r].ctypes.data_as(C.c_void_p))
+        assert np.array_equal(ho.to_numpy(), h)
+        ulp = {"f16": 2 ** -10, "bf16": 2 ** -7, "f32": 1e-6}[act]
+        assert np.abs(y.to_numpy() - want).max() <= ulp * np.abs(want).max()
+
+
+def test_rope_tables_and_apply(tiny_awq, device):
+    model, lm, om = tiny_awq
+    cfg = model["config"]
+    cos, sin = lm.rope_caches()
+    rc = orc_py.RopeCfg()
+    rc.head_dim, rc.max_pos, rc.theta, rc.scaling_type = cfg["head_dim"], cfg["max_seq_len"], cfg["rope_theta"], 0
+    rc.factor, rc.low_freq_factor, rc.high_freq_factor, rc.original_max_pos = 1.0, 1.0, 4.0, 8192
+    wc = np.empty_like(cos)
+    ws = np.empty_like(sin)
+    orc_py.lib().orc_rope_tables(C.byref(rc), wc.ctypes.data_as(C.c_void_p), ws.ctypes.data_as(C.c_void_p))
+    assert np.array_equal(cos, wc) and np.array_equal(sin, ws)
+    rng = np.random.default_rng(2)
+    S, nh, hd = 3, cfg["n_heads"], cfg["head_dim"]
+    x = rng.standard_normal((S, nh, hd)).astype(np.float16).astype(np.float32)
+    t = device.tensor(x)
+    L.check(L.lib().bz_rope(lm.h, t.h, S, nh, 11))
+    want = x.copy()
+    for s in range(S):
+        for h in range(nh):
+            v = want[s, h]
+            orc_py.lib().orc_rope_apply(v.ctypes.data_as(C.c_void_p), hd, hd, wc[11 + s].ctypes.data_as(C.c_void_p),
+                                        ws[11 + s].ctypes.data_as(C.c_void_p), 0)
+    want = orc_py.round_act(want, "f16")
+    assert np.abs(t.to_numpy() - want).max() <= 2 ** -10 * np.abs(want).max()
+
+
+def test_silu_mul(device):
+    rng = np.random.default_rng(3)
+    g = (rng.standard_normal(1000) * 4).astype(np.float16).astype(np.float32)
+    u = rng.standard_normal(1000).astype(np.float16).astype(np.float32)
+    y = device.zeros((1000,))
+    L.check(L.lib().bz_silu_mul(device.h, device.tensor(g).h, device.tensor(u).h, 1000, L.F16, y.h))
+    want = orc_py.round_act(orc_py.round_act(g / (1 + np.exp(-g)), "f16") * u, "f16")
+    assert np.abs(y.to_numpy() - want).max() <= 2 ** -9 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("length", [1, 2, 63, 64, 65, 200])
+def test_kv_insert_and_attention(tiny_awq, device, length):
+    model, lm, _ = tiny_awq
+    cfg = model["config"]
+    nq, nkv, hd = cfg["n_heads"], cfg["n_kv_heads"], cfg["head_dim"]
+    rng = np.random.default_rng(length)
+    kv = runtime.LayeredKvCache(device, cfg["n_layers"], 1, nkv, 8, cfg["max_seq_len"], hd, L.F16)  # grows on demand
+    K = rng.standard_normal((length, nkv, hd)).astype(np.float16).astype(np.float32)
+    V = rng.standard_normal((length, nkv, hd)).astype(np.float16).astype(np.float32)
+    for p in range(length):
+        L.check(L.lib().bz_kv_insert(lm.h, kv.h, 1, p, device.tensor(K[p]).h, device.tensor(V[p]).h))
+    for h in range(nkv):   # byte-exact round trip through the f16 cache
+        assert np.array_equal(kv.read(1, h, 0, length), K[:, h])
+        assert np.array_equal(kv.read(1, h, 1, length), V[:, h])
+    q = rng.standard_normal((nq, hd)).astype(np.float16).astype(np.float32)
+    out = device.zeros((nq, hd))
+    L.check(L.lib().bz_attn_decode(lm.h, device.tensor(q).h, kv.h, 1, length, out.h))
+    rep = nq // nkv
+    want = np.empty((nq, hd), np.float32)
+    for h in range(nkv):
+        kc = np.ascontiguousarray(K[:, h])
+        vc = np.ascontiguousarray(V[:, h])
+        qq = np.ascontiguousarray(q[h * rep:(h + 1) * rep])
+        o = np.empty((rep, hd), np.float32)
+        orc_py.lib().orc_attn_decode(qq.ctypes.data_as(C.c_void_p), rep, hd, kc.ctypes.data_as(C.c_void_p), vc.ctypes.data_as(C.c_void_p),
+                                     hd, length, 1.0 / np.sqrt(hd), o.ctypes.data_as(C.c_void_p))
+        want[h * rep:(h + 1) * rep] = o
+    want = orc_py.round_act(want, "f16")
+    assert np.abs(out.to_numpy() - want).max() <= 2 ** -9 * max(np.abs(want).max(), 1e-3)
+
+
+def test_logits_to_token_greedy_and_penalties(device):
+    rng = np.random.default_rng(9)
+    V = 5000
+    logits = rng.standard_normal((2, V)).astype(np.float32)
+    logits[1, 100] = logits[1, 4000] = logits[1].max() + 1.0      # exact tie: lowest index wins
+    t = device.tensor(logits)
+    tok = runtime.logits_to_token(device, t, [], []).to_numpy()[0]
+    assert tok == 100
+    # penalties (llama.cpp sign rule; unpinned in the reference, see oracle/orc_ops.c)
+    hist = [100, 100, 4000, 7, 7, 7]
+    ids, cnts = runtime.penalty_window(hist, 64)
+    got = runtime.logits_to_token(device, t, ids, cnts, repeat_penalty=1.3, frequency_penalty=0.2, presence_penalty=0.1).to_numpy()[0]
+    want = orc_py.lib().orc_logits_to_token(np.ascontiguousarray(logits[1]).ctypes.data_as(C.c_void_p), V, ids.ctypes.data_as(C.c_void_p),
+                                            cnts.ctypes.data_as(C.c_void_p), len(ids), 1.3, 0.2, 0.1, 0.0, 0, 1.0, 0.0, 0)
+    assert got == want
+    with pytest.raises(L.BlazrHipError):
+        runtime.logits_to_token(device, t, [], [], temperature=0.7)   # sampling is a "next" row: loud, not silent
+
+
+def test_error_paths(device, tiny_awq):
+    model, lm, _ = tiny_awq
+    with pytest.raises(L.BlazrHipError) as e:
+        lm.quant_matmul("model.layers.0.self_attn.q_proj.weight", np.zeros((1, 8), np.float32))
+    assert e.value.code == L.E_INVALID
+    with pytest.raises(L.BlazrHipError) as e:
+        L.check(L.lib().bz_quant_matmul(lm.h, b"nope.weight", device.zeros((1, 256)).h, 1, device.zeros((1, 256)).h))
+    assert e.value.code == L.E_NOTFOUND
+    bad = runtime.LoadedModel(device, model["config"])
+    with pytest.raises(L.BlazrHipError):
+        bad.finalize()    # nothing added
+    kv = runtime.LayeredKvCache(device, 2, 1, 2, 4, 16, 64, L.F16)
+    with pytest.raises(L.BlazrHipError):
+        lm.forward_with_kv_cache([1, 2, 3], kv, 15)   # position + S > max_seq_len of the cache
