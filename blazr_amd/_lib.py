@@ -3,6 +3,7 @@
 The product path has NO fallback: if the shared library is missing or a compute call is made without a
 gfx950 device, it raises.  Nothing here imports oracle/.
 """
+import atexit
 import ctypes as C
 import os
 import subprocess
@@ -10,6 +11,15 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libblazr_hip.so")
 _LIB = None
+alive = True   # cleared at interpreter exit: handle destructors must not call into a torn-down HIP runtime
+
+
+def _at_exit():
+    global alive
+    alive = False
+
+
+atexit.register(_at_exit)
 
 OK, E_INVALID, E_NODEVICE, E_HIP, E_UNSUPPORTED, E_NOTFOUND, E_OOM = 0, -1, -2, -3, -4, -5, -6
 F32, F16, BF16, I64, I32, U32, U8 = range(7)

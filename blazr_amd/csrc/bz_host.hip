@@ -14,6 +14,8 @@
 // errors
 // ---------------------------------------------------------------------------------------------------------
 static thread_local char g_err[1024] = "";
+static bool bz_trace_on() { static int t = -1; if (t < 0) t = getenv("BZ_TRACE") ? 1 : 0; return t == 1; }
+#define BZ_TRACE(...) do { if (bz_trace_on()) { fprintf(stderr, "[bz] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
 void bz_set_error(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -59,8 +61,11 @@ extern "C" int bz_device_open(int id, bz_device** out) {
   *out = d;
   return BZ_OK;
 }
-extern "C" int bz_device_close(bz_device* d) {
-  if (!d) return BZ_OK;
+// The device handle is reference counted: children (tensors, models, caches, graphs) keep it alive, so that a host
+// language whose destructors run in arbitrary order (GC) cannot free a child against a destroyed stream.
+void bz_dev_retain(bz_device* d) { __atomic_add_fetch(&d->refs, 1, __ATOMIC_RELAXED); }
+void bz_dev_release(bz_device* d) {
+  if (__atomic_sub_fetch(&d->refs, 1, __ATOMIC_ACQ_REL) > 0) return;
   hipSetDevice(d->id);
   hipStreamSynchronize(d->stream);
   for (auto ev : d->events) hipEventDestroy(ev);
@@ -69,6 +74,12 @@ extern "C" int bz_device_close(bz_device* d) {
   hipStreamDestroy(d->stream);
   hipStreamDestroy(d->copy_stream);
   delete d;
+}
+extern "C" int bz_device_close(bz_device* d) {
+  if (!d) return BZ_OK;
+  hipSetDevice(d->id);
+  hipStreamSynchronize(d->stream);
+  bz_dev_release(d);
   return BZ_OK;
 }
 extern "C" int bz_device_synchronize(bz_device* d) {
@@ -113,6 +124,7 @@ static int tensor_alloc(bz_device* dev, int dtype, const int64_t* shape, int ndi
   BZ_HIP(hipSetDevice(dev->id));
   hipError_t e = hipMalloc(&t->ptr, std::max<size_t>(t->nbytes, 16));
   if (e != hipSuccess) { delete t; BZ_FAIL(BZ_E_OOM, "hipMalloc(%zu) failed: %s", n * es, hipGetErrorString(e)); }
+  bz_dev_retain(dev);
   *out = t;
   return BZ_OK;
 }
@@ -132,6 +144,7 @@ extern "C" int bz_tensor_zeros(bz_device* dev, int dtype, const int64_t* shape, 
 extern "C" int bz_tensor_free(bz_tensor* t) {
   if (!t) return BZ_OK;
   if (t->owned && t->ptr) { hipStreamSynchronize(t->dev->stream); hipFree(t->ptr); }
+  bz_dev_release(t->dev);
   delete t;
   return BZ_OK;
 }
@@ -263,6 +276,7 @@ extern "C" int bz_model_create(bz_device* dev, const bz_model_config* cfg, bz_mo
   if (cfg->act_dtype != BZ_F32 && cfg->act_dtype != BZ_F16 && cfg->act_dtype != BZ_BF16) BZ_FAIL(BZ_E_INVALID, "config: bad act_dtype");
   bz_model* m = new bz_model();
   m->dev = dev; m->cfg = *cfg;
+  bz_dev_retain(dev);
   *out = m;
   return BZ_OK;
 }
@@ -281,6 +295,7 @@ extern "C" int bz_model_free(bz_model* m) {
   hipStreamSynchronize(m->dev->stream);
   for (auto& kv : m->raw) raw_free(kv.second);
   for (void* p : m->owned) hipFree(p);
+  bz_dev_release(m->dev);
   delete m;
   return BZ_OK;
 }
@@ -647,6 +662,7 @@ extern "C" int bz_model_finalize(bz_model* m) {
     for (FusedLinear* F : {&Ld.qkv, &Ld.o, &Ld.gateup, &Ld.down})
       for (auto& L : F->parts) { m->resident += L.bytes; m->per_token += L.algo_bytes; }
   for (auto& L : m->lm_head.parts) { m->resident += L.bytes; m->per_token += L.algo_bytes; }
+  BZ_HIP(hipDeviceSynchronize());   // null-stream memsets above vs. the non-blocking compute stream
   m->finalized = true;
   return BZ_OK;
 }
@@ -685,6 +701,7 @@ extern "C" int bz_kv_create(bz_device* dev, int layers, int batch, int n_kv, int
   if (hipMalloc(&kv->k, bytes) != hipSuccess || hipMalloc(&kv->v, bytes) != hipSuccess) { delete kv; BZ_FAIL(BZ_E_OOM, "kv cache: hipMalloc(%zu) failed", bytes); }
   BZ_HIP(hipMemsetAsync(kv->k, 0, bytes, dev->stream));
   BZ_HIP(hipMemsetAsync(kv->v, 0, bytes, dev->stream));
+  bz_dev_retain(dev);
   *out = kv;
   return BZ_OK;
 }
@@ -692,6 +709,7 @@ extern "C" int bz_kv_free(bz_kv* kv) {
   if (!kv) return BZ_OK;
   hipStreamSynchronize(kv->dev->stream);
   hipFree(kv->k); hipFree(kv->v);
+  bz_dev_release(kv->dev);
   delete kv;
   return BZ_OK;
 }
@@ -754,6 +772,7 @@ extern "C" int bz_paged_kv_create(bz_device* dev, int layers, int num_blocks, in
   if (hipMalloc(&kv->k, bytes) != hipSuccess || hipMalloc(&kv->v, bytes) != hipSuccess) { delete kv; BZ_FAIL(BZ_E_OOM, "paged kv: hipMalloc(%zu) failed", bytes); }
   BZ_HIP(hipMemsetAsync(kv->k, 0, bytes, dev->stream));
   BZ_HIP(hipMemsetAsync(kv->v, 0, bytes, dev->stream));
+  bz_dev_retain(dev);
   *out = kv;
   return BZ_OK;
 }
@@ -761,6 +780,7 @@ extern "C" int bz_paged_kv_free(bz_paged_kv* kv) {
   if (!kv) return BZ_OK;
   hipStreamSynchronize(kv->dev->stream);
   hipFree(kv->k); hipFree(kv->v);
+  bz_dev_release(kv->dev);
   delete kv;
   return BZ_OK;
 }
@@ -901,6 +921,7 @@ static int emit_logits(bz_model* m, bz_tensor* logits_out, int row) {
 
 extern "C" int bz_forward_kv(bz_model* m, const bz_tensor* tokens, int S, bz_kv* kv, int position, bz_tensor* logits_out, uint32_t flags) {
   BZ_TRY(check_fwd(m, tokens, S));
+  BZ_TRACE("forward_kv: S=%d position=%d", S, position);
   if (!kv || kv->layers != m->cfg.n_layers || kv->n_kv != m->cfg.n_kv_heads || kv->hd != m->cfg.head_dim) BZ_FAIL(BZ_E_INVALID, "forward_kv: cache does not match the model");
   if (position < 0 || position + S > m->cfg.max_seq_len) BZ_FAIL(BZ_E_INVALID, "forward_kv: position %d + S %d exceeds max_seq_len %d", position, S, m->cfg.max_seq_len);
   BZ_TRY(kv_grow(kv, position + S));
@@ -1020,6 +1041,7 @@ extern "C" int bz_argmax_to_buf(bz_device* dev, const bz_tensor* logits, int64_t
 // ---------------------------------------------------------------------------------------------------------
 struct bz_decode_graph {
   bz_model* m = nullptr;
+  bz_device* dev = nullptr;
   hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
   long long* tok_buf = nullptr;     // device: input token of the next replay
   int* pos = nullptr;               // device: position of the next replay
@@ -1041,19 +1063,22 @@ static int graph_capture_common(bz_decode_graph* g, const KvView& view) {
   BZ_HIP(hipMemset(g->tok_buf, 0, 64)); BZ_HIP(hipMemset(g->pos, 0, 64)); BZ_HIP(hipMemset(g->step, 0, 64));
   BZ_HIP(hipHostMalloc(&g->tok_log, sizeof(long long) * bz_decode_graph::LOGCAP, hipHostMallocDefault));
   memset(g->tok_log, 0xff, sizeof(long long) * bz_decode_graph::LOGCAP);
-  BZ_HIP(hipStreamSynchronize(st));
+  BZ_HIP(hipDeviceSynchronize());
   FinalArgs fa{};
   fa.tok_out = g->tok_buf; fa.tok_log = g->tok_log; fa.step = g->step; fa.logcap = bz_decode_graph::LOGCAP; fa.pos = g->pos;
   StepIO io{};
   io.kv = view; io.d_tok = g->tok_buf; io.d_pos = g->pos; io.final_args = &fa;
+  BZ_TRACE("graph: begin capture");
   BZ_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
   int rc = llama_step(m, io);
   hipGraph_t graph = nullptr;
   hipError_t e = hipStreamEndCapture(st, &graph);
+  BZ_TRACE("graph: end capture rc=%d hip=%d", rc, (int)e);
   if (rc != BZ_OK) { if (graph) hipGraphDestroy(graph); return rc; }
   if (e != hipSuccess) BZ_FAIL(BZ_E_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
   g->graph = graph;
   BZ_HIP(hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0));
+  BZ_TRACE("graph: instantiated");
   for (int i = 0; i < 8; i++) { hipEvent_t ev; BZ_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); g->evs.push_back(ev); }
   return BZ_OK;
 }
@@ -1064,6 +1089,7 @@ extern "C" int bz_decode_graph_capture(bz_model* m, bz_kv* kv, bz_decode_graph**
   // stable addresses: the cache must sit at full capacity (cuda_graphs.rs:70)
   BZ_TRY(kv_grow(kv, kv->max_len));
   bz_decode_graph* g = new bz_decode_graph();
+  bz_dev_retain(m->dev); g->dev = m->dev;
   g->m = m; g->kv = kv;
   int rc = graph_capture_common(g, view_of(kv));
   if (rc != BZ_OK) { bz_decode_graph_free(g); return rc; }
@@ -1074,6 +1100,7 @@ extern "C" int bz_decode_graph_capture_paged(bz_model* m, bz_paged_kv* kv, int m
   if (!m || !m->finalized || !kv || !out || max_blocks <= 0) BZ_FAIL(BZ_E_INVALID, "graph capture: bad argument");
   BZ_HIP(hipSetDevice(m->dev->id));
   bz_decode_graph* g = new bz_decode_graph();
+  bz_dev_retain(m->dev); g->dev = m->dev;
   g->m = m; g->pkv = kv; g->max_blocks = max_blocks;
   BZ_HIP(hipMalloc(&g->block_table, (size_t)max_blocks * 4));
   BZ_HIP(hipMemset(g->block_table, 0, (size_t)max_blocks * 4));
@@ -1126,7 +1153,7 @@ extern "C" int bz_decode_graph_read_logits(bz_decode_graph* g, float* host, size
 }
 extern "C" int bz_decode_graph_free(bz_decode_graph* g) {
   if (!g) return BZ_OK;
-  hipStreamSynchronize(g->m->dev->stream);
+  hipStreamSynchronize(g->dev->stream);
   for (auto ev : g->evs) hipEventDestroy(ev);
   if (g->exec) hipGraphExecDestroy(g->exec);
   if (g->graph) hipGraphDestroy(g->graph);
@@ -1135,6 +1162,7 @@ extern "C" int bz_decode_graph_free(bz_decode_graph* g) {
   if (g->step) hipFree(g->step);
   if (g->block_table) hipFree(g->block_table);
   if (g->tok_log) hipHostFree(g->tok_log);
+  bz_dev_release(g->dev);
   delete g;
   return BZ_OK;
 }
@@ -1203,6 +1231,7 @@ extern "C" int bz_generate(bz_model* m, const int64_t* prompt, int n_prompt, con
   }
   GEN_TRY(bz_device_synchronize(dev));
   T1 = std::chrono::steady_clock::now();
+  BZ_TRACE("generate: prefill of %d tokens done (graph=%d paged=%d)", n_prompt, gc->use_graph, gc->paged);
 
   if (gc->use_graph) {
     // cuda_graphs.rs:149-189: first token from the prefill logits, then one graph launch per token
@@ -1212,12 +1241,14 @@ extern "C" int bz_generate(bz_model* m, const int64_t* prompt, int n_prompt, con
     if (gc->paged) { GEN_TRY(bz_decode_graph_capture_paged(m, pkv, (int)bt.size(), &graph)); GEN_TRY(bz_decode_graph_set_block_table(graph, bt.data(), (int)bt.size())); }
     else GEN_TRY(bz_decode_graph_capture(m, kv, &graph));
     GEN_TRY(bz_decode_graph_seed(graph, tok, n_prompt));
+    BZ_TRACE("generate: graph captured and seeded with token %lld at position %d", (long long)tok, n_prompt);
     for (int i = 0; i < max_tokens; i++) {
       out_tokens[n_out++] = tok; history.push_back((uint32_t)tok);
       if (tok == gc->eos_id) { finish = 1; break; }
       if (i + 1 == max_tokens) break;
       GEN_TRY(bz_decode_graph_replay(graph));
       GEN_TRY(bz_decode_graph_read_token(graph, i, &tok));
+      BZ_TRACE("generate: replay %d -> token %lld", i, (long long)tok);
     }
   } else {
     std::vector<int64_t> ids; std::vector<int32_t> cnts;
@@ -1244,6 +1275,7 @@ extern "C" int bz_generate(bz_model* m, const int64_t* prompt, int n_prompt, con
       }
       int64_t tok;
       GEN_TRY(bz_tensor_to_host_pipelined(t_tok, ev, &tok, 8));                      // :378 read_token_id
+      BZ_TRACE("generate: step %d -> token %lld", i, (long long)tok);
       out_tokens[n_out++] = tok; history.push_back((uint32_t)tok);
       if (tok == gc->eos_id) { finish = 1; break; }
     }
@@ -1314,6 +1346,7 @@ extern "C" int bz_dequant(bz_model* m, const char* name, float* host) {
   BZ_HIP(hipMalloc(&d, n * 4));
   int rc = L.kind == LK_Q4G ? bzk_dequant_q4g(m->dev->stream, L, d) : (L.kind == LK_ROWS ? bzk_dequant_rows(m->dev->stream, L, d) : BZ_E_UNSUPPORTED);
   std::vector<float> tmp;
+  if (rc == BZ_OK) rc = hipStreamSynchronize(m->dev->stream) == hipSuccess ? BZ_OK : BZ_E_HIP;  // the stream is non-blocking
   if (rc == BZ_OK) {
     if (L.perm) {
       // kernel order k' -> original k = perm[k']

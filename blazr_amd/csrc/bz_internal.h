@@ -68,7 +68,10 @@ struct bz_device {
   size_t pinned_off = 0;
   uint64_t event_counter = 0;
   float* scratch = nullptr;   // 4 KiB device scratch (sampling partials)
+  int refs = 1;               // the handle itself + every live child object (tensor/model/cache/graph)
 };
+void bz_dev_retain(bz_device* d);
+void bz_dev_release(bz_device* d);
 
 struct bz_tensor {
   bz_device* dev = nullptr;

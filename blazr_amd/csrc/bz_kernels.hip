@@ -5,9 +5,9 @@
 //     once at load into [N/64 tiles][K/32 chunks][64 lanes][16 B] so that one wave-wide `global_load_dwordx4`
 //     reads 1 KiB contiguous = 32 k-values for 64 output columns; lane == output column, so there is no
 //     cross-lane reduction, and the activation slice is wave-uniform (broadcast reads from LDS).
-//   * The dot products run on V_DOT4_I32_I8: the f16 activation slice is split, per group of 128, into two
-//     int8 planes (x ~= sx * (256*hi + lo)), i.e. 16-bit fixed point relative to the group maximum -- error
-//     <= 2^-16 of the group max, far below the f16 rounding of the outputs.  Low nibbles are used as stored
+//   * The dot products run on V_DOT4_I32_I8: the f16 activation slice is split, per group of 128, into three
+//     int8 planes (x ~= sx * (65536*hi + 256*mid + lo)), i.e. 24-bit fixed point relative to the group maximum --
+//     the integer path reproduces f32 arithmetic on f16/bf16 activations.  Low nibbles are used as stored
 //     (q, 0..15), high nibbles are stored as (q-8) in two's complement so that `w & 0xF0F0F0F0` IS the signed
 //     byte 16*(q-8): one V_AND per 4 weights, no shifts.  All group arithmetic is exact in int32.
 //   * Split-K partial sums are added with 64-bit INTEGER atomics in 2^-32 fixed point: integer addition is
@@ -47,9 +47,11 @@ __device__ __forceinline__ float round_act(float x, int act) {
 }
 // 2^-32 fixed point
 __device__ __forceinline__ float fix2f(long long a) {
-  int hi = (int)(a >> 32);
-  unsigned lo = (unsigned)(a & 0xffffffffll);
-  return (float)hi + (float)lo * 2.3283064365386963e-10f;
+  // sign-magnitude: (float)hi + (float)lo*2^-32 on the two's-complement halves cancels catastrophically for small
+  // negative values (hi = -1, lo ~ 2^32)
+  const unsigned long long m = a < 0 ? (unsigned long long)(-a) : (unsigned long long)a;
+  const float r = (float)(unsigned)(m >> 32) + (float)(unsigned)(m & 0xffffffffull) * 2.3283064365386963e-10f;
+  return a < 0 ? -r : r;
 }
 __device__ __forceinline__ long long f2fix(float p) { return __float2ll_rn(p * 4294967296.0f); }
 __device__ __forceinline__ float vsrc_get(const VSrc& s, int i, int act) {
@@ -255,10 +257,15 @@ __device__ __forceinline__ void xfinish(const Pro& p, int KR, const XRegs<MODE, 
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// activation slice -> two int8 planes + per-group parameters   (QG = 128 k per group, 16 lanes x 8 each)
-//   gpar[g] = { sx/16 (as float bits), 128*sum_{k%8>=4} xi, 16*sum xi, 0 }
+// activation slice -> three int8 planes + per-group parameters   (QG = 128 k per group, 16 lanes x 8 each)
+//   x ~= sx * xi,  xi = 65536*hi + 256*mid + lo  (24-bit fixed point relative to the group maximum: exact for f16/bf16
+//   activations down to 2^-13 of the group max, i.e. the int path reproduces f32 arithmetic)
+//   gpar[2g]   = { sx/16 (float bits), 128*SB_hi, 128*SB_mid, 128*SB_lo }   SB = sum over the k with (k%8) >= 4
+//   gpar[2g+1] = { 16*S_hi, 16*S_mid, 16*S_lo, 0 }                          S  = sum over the whole group
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void quant_x128(const float* xs, int KR, unsigned* xh, unsigned* xl, int4* gpar) {
+#define XQ_MAX 8355000.0f  // < 127*65536 + 127*256 + 127
+
+__device__ __forceinline__ void quant_x128(const float* xs, int KR, unsigned* xh, unsigned* xm, unsigned* xl, int4* gpar) {
   for (int base = 0; base < KR; base += 2048) {
     const int e0 = base + threadIdx.x * 8;
     const bool on = e0 < KR;
@@ -275,26 +282,35 @@ __device__ __forceinline__ void quant_x128(const float* xs, int KR, unsigned* xh
     for (int i = 0; i < 8; i++) am = fmaxf(am, fabsf(v[i]));
 #pragma unroll
     for (int m = 1; m <= 8; m <<= 1) am = fmaxf(am, __shfl_xor(am, m, 64));
-    const float inv = am > 0.f ? 32512.0f / am : 0.f;
-    int xi[8];
-    unsigned wh[2] = {0, 0}, wl[2] = {0, 0};
-    int sall = 0, sb = 0;
+    const float inv = am > 0.f ? XQ_MAX / am : 0.f;
+    unsigned wh[2] = {0, 0}, wm[2] = {0, 0}, wl[2] = {0, 0};
+    int s_hi = 0, s_mid = 0, s_lo = 0, b_hi = 0, b_mid = 0, b_lo = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-      xi[i] = (int)rintf(v[i] * inv);
-      int hi = (xi[i] + 128) >> 8;
-      int lo = xi[i] - (hi << 8);
+      const int xi = (int)rintf(v[i] * inv);
+      const int lo = ((xi + 128) & 255) - 128;
+      const int r1 = (xi - lo) >> 8;
+      const int mid = ((r1 + 128) & 255) - 128;
+      const int hi = (r1 - mid) >> 8;
       wh[i >> 2] |= ((unsigned)hi & 255u) << (8 * (i & 3));
+      wm[i >> 2] |= ((unsigned)mid & 255u) << (8 * (i & 3));
       wl[i >> 2] |= ((unsigned)lo & 255u) << (8 * (i & 3));
-      sall += xi[i];
-      if (i >= 4) sb += xi[i];
+      s_hi += hi; s_mid += mid; s_lo += lo;
+      if (i >= 4) { b_hi += hi; b_mid += mid; b_lo += lo; }
     }
 #pragma unroll
-    for (int m = 1; m <= 8; m <<= 1) { sall += __shfl_xor(sall, m, 64); sb += __shfl_xor(sb, m, 64); }
+    for (int m = 1; m <= 8; m <<= 1) {
+      s_hi += __shfl_xor(s_hi, m, 64); s_mid += __shfl_xor(s_mid, m, 64); s_lo += __shfl_xor(s_lo, m, 64);
+      b_hi += __shfl_xor(b_hi, m, 64); b_mid += __shfl_xor(b_mid, m, 64); b_lo += __shfl_xor(b_lo, m, 64);
+    }
     if (on) {
       *(uint2*)(xh + e0 / 4) = make_uint2(wh[0], wh[1]);
+      *(uint2*)(xm + e0 / 4) = make_uint2(wm[0], wm[1]);
       *(uint2*)(xl + e0 / 4) = make_uint2(wl[0], wl[1]);
-      if ((threadIdx.x & 15) == 0) gpar[e0 >> 7] = make_int4(__float_as_int(am * (1.0f / (32512.0f * 16.0f))), 128 * sb, 16 * sall, 0);
+      if ((threadIdx.x & 15) == 0) {
+        gpar[2 * (e0 >> 7)] = make_int4(__float_as_int(am * (1.0f / (XQ_MAX * 16.0f))), 128 * b_hi, 128 * b_mid, 128 * b_lo);
+        gpar[2 * (e0 >> 7) + 1] = make_int4(16 * s_hi, 16 * s_mid, 16 * s_lo, 0);
+      }
     }
   }
 }
@@ -304,30 +320,36 @@ __device__ __forceinline__ void quant_x128(const float* xs, int KR, unsigned* xh
 // ---------------------------------------------------------------------------------------------------------
 #define Q4G_E 8  // slice elements per thread (KR <= 2048)
 
-__device__ __forceinline__ void q4g_consume(const uint4 (&w)[4], int g, const uint4* xh4, const uint4* xl4, const int4* gpar,
-                                            float s, int z, float& y) {
-  int Ahi = 0, Alo = 0, Bhi = 0, Blo = 0;
+__device__ __forceinline__ void q4g_consume(const uint4 (&w)[4], int g, const uint4* xh4, const uint4* xm4, const uint4* xl4,
+                                            const int4* gpar, float s, int z, float& y) {
+  int Ah = 0, Am = 0, Al = 0, Bh = 0, Bm = 0, Bl = 0;
 #pragma unroll
   for (int c = 0; c < 4; c++) {
     const uint4 h0 = xh4[g * 8 + c * 2], h1 = xh4[g * 8 + c * 2 + 1];
+    const uint4 m0 = xm4[g * 8 + c * 2], m1 = xm4[g * 8 + c * 2 + 1];
     const uint4 l0 = xl4[g * 8 + c * 2], l1 = xl4[g * 8 + c * 2 + 1];
     const unsigned Xh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+    const unsigned Xm[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
     const unsigned Xl[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
     const unsigned W[4] = {w[c].x, w[c].y, w[c].z, w[c].w};
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       const int a = (int)(W[j] & 0x0F0F0F0Fu), b = (int)(W[j] & 0xF0F0F0F0u);
-      Ahi = __builtin_amdgcn_sdot4(a, (int)Xh[2 * j], Ahi, false);
-      Alo = __builtin_amdgcn_sdot4(a, (int)Xl[2 * j], Alo, false);
-      Bhi = __builtin_amdgcn_sdot4(b, (int)Xh[2 * j + 1], Bhi, false);
-      Blo = __builtin_amdgcn_sdot4(b, (int)Xl[2 * j + 1], Blo, false);
+      Ah = __builtin_amdgcn_sdot4(a, (int)Xh[2 * j], Ah, false);
+      Am = __builtin_amdgcn_sdot4(a, (int)Xm[2 * j], Am, false);
+      Al = __builtin_amdgcn_sdot4(a, (int)Xl[2 * j], Al, false);
+      Bh = __builtin_amdgcn_sdot4(b, (int)Xh[2 * j + 1], Bh, false);
+      Bm = __builtin_amdgcn_sdot4(b, (int)Xm[2 * j + 1], Bm, false);
+      Bl = __builtin_amdgcn_sdot4(b, (int)Xl[2 * j + 1], Bl, false);
     }
   }
-  const int4 gp = gpar[g];
-  // 16 * sum_k (q_k - z) * xi_k, exact in two's complement (see file header)
-  const unsigned U = ((((unsigned)Ahi << 4) + (unsigned)Bhi) << 8) + (((unsigned)Alo << 4) + (unsigned)Blo) + (unsigned)gp.y -
-                     (unsigned)z * (unsigned)gp.z;
-  y += (s * __int_as_float(gp.x)) * (float)(int)U;
+  const int4 g1 = gpar[2 * g], g2 = gpar[2 * g + 1];
+  // per plane: 16 * sum_k (q_k - z) * plane_k, exact in int32 (|.| < 2^23)
+  const int Uh = (Ah << 4) + Bh + g1.y - z * g2.x;
+  const int Um = (Am << 4) + Bm + g1.z - z * g2.y;
+  const int Ul = (Al << 4) + Bl + g1.w - z * g2.z;
+  const float f = fmaf((float)Uh, 65536.0f, fmaf((float)Um, 256.0f, (float)Ul));
+  y += (s * __int_as_float(g1.x)) * f;
 }
 
 template <int MODE, int FIX, int MAXJ>
@@ -338,9 +360,10 @@ __global__ __launch_bounds__(256) void k_gemv_q4g(const uint4* __restrict__ W, c
   const int KR = GW * 128;
   float* xs = (float*)smem;                               // [KR]
   unsigned* xh = (unsigned*)(xs + KR);                    // [KR/4]
-  unsigned* xl = xh + KR / 4;                             // [KR/4]
-  int4* gpar = (int4*)(xl + KR / 4);                      // [GW]
-  __half* sS = (__half*)(gpar + GW);                      // [4][GW][64]
+  unsigned* xm = xh + KR / 4;                             // [KR/4]
+  unsigned* xl = xm + KR / 4;                             // [KR/4]
+  int4* gpar = (int4*)(xl + KR / 4);                      // [2*GW]
+  __half* sS = (__half*)(gpar + 2 * GW);                  // [4][GW][64]
   unsigned char* sZ = (unsigned char*)(sS + 4 * GW * 64); // [4][GW][64]
   float* red = (float*)(sZ + 4 * GW * 64);                // [4]
 
@@ -377,19 +400,20 @@ __global__ __launch_bounds__(256) void k_gemv_q4g(const uint4* __restrict__ W, c
 
   // (3) finish the prologue while the weights are in flight
   xfinish<MODE, MAXJ, Q4G_E>(pro, KR, xr, xs, red, blockIdx.x == 0);
-  quant_x128(xs, KR, xh, xl, gpar);
+  quant_x128(xs, KR, xh, xm, xl, gpar);
   __syncthreads();
   if (!wave_on) return;
 
   // (4) stream the k-range: two groups (8 KiB per wave) in flight
   const uint4* xh4 = (const uint4*)xh;
+  const uint4* xm4 = (const uint4*)xm;
   const uint4* xl4 = (const uint4*)xl;
   float y = 0.f;
   for (int g = 0; g < GW; g += 2) {
     {
       const float s = __half2float(sS[(wave * GW + g) * 64 + lane]);
       const int z = sZ[(wave * GW + g) * 64 + lane];
-      q4g_consume(A, g, xh4, xl4, gpar, s, z, y);
+      q4g_consume(A, g, xh4, xm4, xl4, gpar, s, z, y);
       if (g + 2 < GW) {
 #pragma unroll
         for (int c = 0; c < 4; c++) A[c] = ldnt(wp + ((g + 2) * 4 + c) * 64);
@@ -398,7 +422,7 @@ __global__ __launch_bounds__(256) void k_gemv_q4g(const uint4* __restrict__ W, c
     if (g + 1 < GW) {
       const float s = __half2float(sS[(wave * GW + g + 1) * 64 + lane]);
       const int z = sZ[(wave * GW + g + 1) * 64 + lane];
-      q4g_consume(B, g + 1, xh4, xl4, gpar, s, z, y);
+      q4g_consume(B, g + 1, xh4, xm4, xl4, gpar, s, z, y);
       if (g + 3 < GW) {
 #pragma unroll
         for (int c = 0; c < 4; c++) B[c] = ldnt(wp + ((g + 3) * 4 + c) * 64);
@@ -412,7 +436,7 @@ __global__ __launch_bounds__(256) void k_gemv_q4g(const uint4* __restrict__ W, c
 
 static size_t q4g_smem(int GW) {
   size_t KR = (size_t)GW * 128;
-  return KR * 4 + KR / 4 * 4 * 2 + (size_t)GW * 16 + (size_t)4 * GW * 64 * 2 + (size_t)4 * GW * 64 + 16;
+  return KR * 4 + KR / 4 * 4 * 3 + (size_t)GW * 32 + (size_t)4 * GW * 64 * 2 + (size_t)4 * GW * 64 + 16;
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -84,7 +84,7 @@ class Tensor:
 
     def __del__(self):
         try:
-            if self.h:
+            if self.h and L.alive:
                 L.lib().bz_tensor_free(self.h)
         except Exception:
             pass
@@ -151,7 +151,7 @@ class LoadedModel:
 
     def __del__(self):
         try:
-            if self.h:
+            if self.h and L.alive:
                 L.lib().bz_model_free(self.h)
         except Exception:
             pass
@@ -337,7 +337,7 @@ class LayeredKvCache:
 
     def __del__(self):
         try:
-            if self.h:
+            if self.h and L.alive:
                 L.lib().bz_kv_free(self.h)
         except Exception:
             pass
@@ -367,7 +367,7 @@ class LayeredPagedKvCache:
 
     def __del__(self):
         try:
-            if self.h:
+            if self.h and L.alive:
                 L.lib().bz_paged_kv_free(self.h)
         except Exception:
             pass
@@ -429,7 +429,7 @@ class DecodeGraph:
 
     def __del__(self):
         try:
-            if self.h:
+            if self.h and L.alive:
                 L.lib().bz_decode_graph_free(self.h)
         except Exception:
             pass

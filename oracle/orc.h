@@ -169,6 +169,7 @@ int orc_llama_generate(const orc_llama* m, const int64_t* prompt, int n_prompt, 
                        int64_t* out_tokens, float* logits_trace /* optional [max_tokens][vocab] */);
 
 int orc_num_threads(void);
+void orc_set_num_threads(int n);
 
 #ifdef __cplusplus
 }

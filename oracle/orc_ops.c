@@ -15,8 +15,9 @@
 
 /* HF LlamaRMSNorm: y = w * round(x * rsqrt(mean(x^2) + eps)); both products rounded to the activation dtype */
 void orc_rms_norm(const float* x, const float* w, int n, float eps, int act, float* out) {
-  float ss = 0.0f;
-  for (int i = 0; i < n; i++) ss += x[i] * x[i];
+  double ssd = 0.0;   /* exact-ish sum of squares, one rounding */
+  for (int i = 0; i < n; i++) ssd += (double)(x[i] * x[i]);
+  float ss = (float)ssd;
   float rs = 1.0f / sqrtf(ss / (float)n + eps);
   for (int i = 0; i < n; i++) out[i] = orc_round(w[i] * orc_round(x[i] * rs, act), act);
 }

@@ -66,7 +66,13 @@ def lib():
         path = os.path.join(_HERE, "liborc.so")
         if not os.path.exists(path):
             build()
+        # the GPU box exposes many more cores than its CPU share (16 for one GPU): cap the OpenMP team and never spin
+        ncpu = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
+        os.environ.setdefault("OMP_NUM_THREADS", str(ncpu))
+        os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
         L = C.CDLL(path)
+        L.orc_set_num_threads.argtypes = [C.c_int]
+        L.orc_set_num_threads(int(os.environ["OMP_NUM_THREADS"]))
         L.orc_f16_to_f32.restype = C.c_float
         L.orc_f16_to_f32.argtypes = [C.c_uint16]
         L.orc_f32_to_f16.restype = C.c_uint16

@@ -16,6 +16,14 @@
 #include <omp.h>
 #endif
 
+void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 int orc_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();
@@ -234,30 +242,39 @@ void orc_linear_dequant(const orc_linear* L, float* out) {
 }
 
 /* ---------------------------------------------------------------- y = x W^T (+bias) */
-/* Summation order (the oracle's definition; the HIP path is compared at fp tolerance):
- *   AWQ / GPTQ : for each output n, sequential over k = 0..K-1, f32:  acc += x[k] * ((q - z) * s)
- *   DENSE/GGUF : 8 strided partial sums (k mod 8), combined ((0+4)+(2+6))+((1+5)+(3+7)), f32            */
+/* Summation order (the oracle's definition; the HIP path is compared at fp tolerance).  Blocked summation: f32
+ * products and f32 partial sums inside a block of 128 k, blocks added in double, one rounding to f32 at the end --
+ * i.e. the oracle is the (nearly) exactly-rounded dot product, so a comparison measures the HIP path's error only.
+ *   AWQ / GPTQ : block = quantisation group; within it sequential over k:  acc += x[k] * ((q - z) * s)
+ *   DENSE/GGUF : block = 128 k; within it 8 strided partial sums combined ((0+4)+(2+6))+((1+5)+(3+7))        */
+#define BLK 128
 static inline float dot8(const float* a, const float* b, int K) {
-  float p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  int k = 0;
-  for (; k + 8 <= K; k += 8)
-    for (int j = 0; j < 8; j++) p[j] += a[k + j] * b[k + j];
-  for (int j = 0; k < K; k++, j++) p[j] += a[k] * b[k];
-  return ((p[0] + p[4]) + (p[2] + p[6])) + ((p[1] + p[5]) + (p[3] + p[7]));
+  double tot = 0.0;
+  for (int k0 = 0; k0 < K; k0 += BLK) {
+    const int ke = (k0 + BLK < K) ? k0 + BLK : K;
+    float p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int k = k0;
+    for (; k + 8 <= ke; k += 8)
+      for (int j = 0; j < 8; j++) p[j] += a[k + j] * b[k + j];
+    for (int j = 0; k < ke; k++, j++) p[j] += a[k] * b[k];
+    tot += (double)(((p[0] + p[4]) + (p[2] + p[6])) + ((p[1] + p[5]) + (p[3] + p[7])));
+  }
+  return (float)tot;
 }
 
 #define NB 64 /* columns per work item */
+#define PAR_MIN ((size_t)1 << 21) /* weights below which a GEMV stays on one thread */
 
 static void awq_forward(const orc_linear* L, const float* x, int S, float* y) {
   const int N = L->N, K = L->K, gs = L->group_size, n8 = N / 8;
   const uint32_t* qw = (const uint32_t*)L->w;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if ((size_t)N * K >= PAR_MIN)
   for (int nb = 0; nb < N / NB; nb++) {
-    float acc[8][NB]; float wrow[NB];
+    float acc[8][NB]; float wrow[NB]; double tot[8][NB];
     const int n0 = nb * NB;
     for (int s0 = 0; s0 < S; s0 += 8) {
       const int sc = (S - s0) < 8 ? (S - s0) : 8;
-      memset(acc, 0, sizeof(acc));
+      memset(acc, 0, sizeof(acc)); memset(tot, 0, sizeof(tot));
       for (int k = 0; k < K; k++) {
         const float* srow = L->scales + (size_t)(k / gs) * N + n0;
         const float* zrow = L->zeros_f + (size_t)(k / gs) * N + n0;
@@ -273,9 +290,12 @@ static void awq_forward(const orc_linear* L, const float* x, int S, float* y) {
           const float xv = x[(size_t)(s0 + s) * K + k];
           for (int c = 0; c < NB; c++) acc[s][c] += xv * wrow[c];
         }
+        if ((k + 1) % gs == 0)
+          for (int s = 0; s < sc; s++)
+            for (int c = 0; c < NB; c++) { tot[s][c] += (double)acc[s][c]; acc[s][c] = 0.0f; }
       }
       for (int s = 0; s < sc; s++)
-        for (int c = 0; c < NB; c++) y[(size_t)(s0 + s) * N + n0 + c] = acc[s][c] + (L->bias ? L->bias[n0 + c] : 0.0f);
+        for (int c = 0; c < NB; c++) y[(size_t)(s0 + s) * N + n0 + c] = (float)tot[s][c] + (L->bias ? L->bias[n0 + c] : 0.0f);
     }
   }
 }
@@ -283,13 +303,13 @@ static void awq_forward(const orc_linear* L, const float* x, int S, float* y) {
 static void gptq_forward(const orc_linear* L, const float* x, int S, float* y) {
   const int N = L->N, K = L->K;
   const uint32_t* qw = (const uint32_t*)L->w;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if ((size_t)N * K >= PAR_MIN)
   for (int nb = 0; nb < N / NB; nb++) {
-    float acc[8][NB]; float wrow[NB];
+    float acc[8][NB]; float wrow[NB]; double tot[8][NB];
     const int n0 = nb * NB;
     for (int s0 = 0; s0 < S; s0 += 8) {
       const int sc = (S - s0) < 8 ? (S - s0) : 8;
-      memset(acc, 0, sizeof(acc));
+      memset(acc, 0, sizeof(acc)); memset(tot, 0, sizeof(tot));
       for (int k = 0; k < K; k++) {
         const int g = gptq_group(L, k);
         const float* srow = L->scales + (size_t)g * N + n0;
@@ -305,9 +325,12 @@ static void gptq_forward(const orc_linear* L, const float* x, int S, float* y) {
           const float xv = x[(size_t)(s0 + s) * K + k];
           for (int c = 0; c < NB; c++) acc[s][c] += xv * wrow[c];
         }
+        if ((k + 1) % L->group_size == 0)   /* with act-order a block is 128 consecutive k, not one group */
+          for (int s = 0; s < sc; s++)
+            for (int c = 0; c < NB; c++) { tot[s][c] += (double)acc[s][c]; acc[s][c] = 0.0f; }
       }
       for (int s = 0; s < sc; s++)
-        for (int c = 0; c < NB; c++) y[(size_t)(s0 + s) * N + n0 + c] = acc[s][c] + (L->bias ? L->bias[n0 + c] : 0.0f);
+        for (int c = 0; c < NB; c++) y[(size_t)(s0 + s) * N + n0 + c] = (float)tot[s][c] + (L->bias ? L->bias[n0 + c] : 0.0f);
     }
   }
 }
@@ -315,7 +338,7 @@ static void gptq_forward(const orc_linear* L, const float* x, int S, float* y) {
 static void rows_forward(const orc_linear* L, const float* x, int S, float* y) {
   const int N = L->N, K = L->K;
   const size_t rb = (L->kind == ORC_LIN_GGUF) ? orc_ggml_row_bytes(L->ggml_type, (size_t)K) : 0;
-#pragma omp parallel
+#pragma omp parallel if ((size_t)N * K >= PAR_MIN)
   {
     float* wrow = (float*)malloc(sizeof(float) * (size_t)K);
 #pragma omp for schedule(static)
@@ -337,9 +360,12 @@ void orc_linear_forward(const orc_linear* L, const float* x, int S, float* y) {
   else { /* ragged N: slow generic path, same summation order as the blocked one */
     for (int s = 0; s < S; s++)
       for (int n = 0; n < L->N; n++) {
-        float acc = 0.0f;
-        for (int k = 0; k < L->K; k++) acc += x[(size_t)s * L->K + k] * (L->kind == ORC_LIN_AWQ ? awq_w(L, k, n) : gptq_w(L, k, n));
-        y[(size_t)s * L->N + n] = acc + (L->bias ? L->bias[n] : 0.0f);
+        float acc = 0.0f; double tot = 0.0;
+        for (int k = 0; k < L->K; k++) {
+          acc += x[(size_t)s * L->K + k] * (L->kind == ORC_LIN_AWQ ? awq_w(L, k, n) : gptq_w(L, k, n));
+          if ((k + 1) % L->group_size == 0) { tot += (double)acc; acc = 0.0f; }
+        }
+        y[(size_t)s * L->N + n] = (float)(tot + (double)acc) + (L->bias ? L->bias[n] : 0.0f);
       }
   }
 }

@@ -1,3 +1,4 @@
+import faulthandler
 import os
 import sys
 
@@ -20,3 +21,17 @@ def device():
     d = runtime.Device(0)
     yield d
     d.close()
+
+
+@pytest.fixture(autouse=True)
+def _watchdog(request):
+    """A GPU call that never returns would otherwise sit in C until the box's limit: dump the Python stack and exit after
+    150 s in one test (faulthandler's watchdog thread works while the main thread is blocked inside ctypes)."""
+    if request.node.get_closest_marker("gpu") is None:
+        yield
+        return
+    faulthandler.dump_traceback_later(int(os.environ.get("BZ_TEST_WATCHDOG_S", "150")), exit=True)
+    try:
+        yield
+    finally:
+        faulthandler.cancel_dump_traceback_later()

@@ -56,8 +56,8 @@ def test_quant_matmul_vs_oracle(fix, short, request):
     x[2, ::7] = 0.0
     want = orc_py.OrcLinear(spec).forward(x)
     got = lm.quant_matmul(_names(0)[short], x)
-    # int8x2 activation split: |err| <= 2^-16 * group max per term; f32 accumulation order differs from the oracle
-    tol = 2e-5 * np.abs(want).max() + 1e-6
+    # int8x3 activation split is 24-bit fixed point (f32-exact products); f32 accumulation order differs from the oracle
+    tol = 2e-6 * np.abs(want).max() + 1e-7
     assert np.abs(got - want).max() <= tol, (np.abs(got - want).max(), tol)
 
 
@@ -71,7 +71,7 @@ def test_quant_matmul_edge_inputs(tiny_awq):
               np.eye(1, K, 5, dtype=np.float32)[0] * 3.0):
         want = ol.forward(x)[0]
         got = lm.quant_matmul(name, x)[0]
-        assert np.abs(got - want).max() <= 2e-5 * max(np.abs(want).max(), 1e-30) + 1e-12
+        assert np.abs(got - want).max() <= 2e-6 * max(np.abs(want).max(), 1e-30) + 1e-12
 
 
 def test_rms_norm(device):
@@ -82,7 +82,8 @@ def test_rms_norm(device):
         p = orc_py.round_act(rng.standard_normal((2, n)).astype(np.float32), act)
         w = orc_py.round_act(1 + 0.1 * rng.standard_normal(n).astype(np.float32), act)
         y, ho = device.zeros((2, n)), device.zeros((2, n))
-        L.check(L.lib().bz_rms_norm(device.h, device.tensor(x).h, device.tensor(p).h, device.tensor(w).h, 2, n, 1e-5, adt, y.h, ho.h))
+        tx, tp, tw = device.tensor(x), device.tensor(p), device.tensor(w)   # keep the handles alive across the call
+        L.check(L.lib().bz_rms_norm(device.h, tx.h, tp.h, tw.h, 2, n, 1e-5, adt, y.h, ho.h))
         h = orc_py.round_act(x + p, act)
         want = np.empty_like(h)
         for r in range(2):
@@ -124,7 +125,8 @@ def test_silu_mul(device):
     g = (rng.standard_normal(1000) * 4).astype(np.float16).astype(np.float32)
     u = rng.standard_normal(1000).astype(np.float16).astype(np.float32)
     y = device.zeros((1000,))
-    L.check(L.lib().bz_silu_mul(device.h, device.tensor(g).h, device.tensor(u).h, 1000, L.F16, y.h))
+    tg, tu = device.tensor(g), device.tensor(u)
+    L.check(L.lib().bz_silu_mul(device.h, tg.h, tu.h, 1000, L.F16, y.h))
     want = orc_py.round_act(orc_py.round_act(g / (1 + np.exp(-g)), "f16") * u, "f16")
     assert np.abs(y.to_numpy() - want).max() <= 2 ** -9 * np.abs(want).max()
 
@@ -139,13 +141,15 @@ def test_kv_insert_and_attention(tiny_awq, device, length):
     K = rng.standard_normal((length, nkv, hd)).astype(np.float16).astype(np.float32)
     V = rng.standard_normal((length, nkv, hd)).astype(np.float16).astype(np.float32)
     for p in range(length):
-        L.check(L.lib().bz_kv_insert(lm.h, kv.h, 1, p, device.tensor(K[p]).h, device.tensor(V[p]).h))
+        tk, tv = device.tensor(K[p]), device.tensor(V[p])
+        L.check(L.lib().bz_kv_insert(lm.h, kv.h, 1, p, tk.h, tv.h))
     for h in range(nkv):   # byte-exact round trip through the f16 cache
         assert np.array_equal(kv.read(1, h, 0, length), K[:, h])
         assert np.array_equal(kv.read(1, h, 1, length), V[:, h])
     q = rng.standard_normal((nq, hd)).astype(np.float16).astype(np.float32)
     out = device.zeros((nq, hd))
-    L.check(L.lib().bz_attn_decode(lm.h, device.tensor(q).h, kv.h, 1, length, out.h))
+    tq = device.tensor(q)
+    L.check(L.lib().bz_attn_decode(lm.h, tq.h, kv.h, 1, length, out.h))
     rep = nq // nkv
     want = np.empty((nq, hd), np.float32)
     for h in range(nkv):
@@ -184,8 +188,9 @@ def test_error_paths(device, tiny_awq):
     with pytest.raises(L.BlazrHipError) as e:
         lm.quant_matmul("model.layers.0.self_attn.q_proj.weight", np.zeros((1, 8), np.float32))
     assert e.value.code == L.E_INVALID
+    za, zb = device.zeros((1, 256)), device.zeros((1, 256))
     with pytest.raises(L.BlazrHipError) as e:
-        L.check(L.lib().bz_quant_matmul(lm.h, b"nope.weight", device.zeros((1, 256)).h, 1, device.zeros((1, 256)).h))
+        L.check(L.lib().bz_quant_matmul(lm.h, b"nope.weight", za.h, 1, zb.h))
     assert e.value.code == L.E_NOTFOUND
     bad = runtime.LoadedModel(device, model["config"])
     with pytest.raises(L.BlazrHipError):
