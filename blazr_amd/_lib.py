@@ -52,6 +52,10 @@ class GenConfig(C.Structure):
                 ("reserved", C.c_int32 * 8)]
 
 
+class KernelTime(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_int32), ("total_ms", C.c_double), ("algo_bytes", C.c_double)]
+
+
 class GenStats(C.Structure):
     _fields_ = [("prefill_ms", C.c_double), ("decode_ms", C.c_double), ("n_generated", C.c_int32),
                 ("finish_reason", C.c_int32)]
@@ -112,6 +116,8 @@ SYMBOLS = {
     "bz_decode_graph_read_logits": (C.c_int, [P, P, C.c_size_t]),
     "bz_decode_graph_free": (C.c_int, [P]),
     "bz_generate": (C.c_int, [P, P, C.c_int, C.POINTER(GenConfig), P, C.POINTER(GenStats)]),
+    "bz_profile_step": (C.c_int, [P, P, C.c_int64, C.c_int, C.c_int, C.POINTER(KernelTime), C.c_int, C.POINTER(C.c_int)]),
+    "bz_tune_gemv": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "bz_quant_matmul": (C.c_int, [P, C.c_char_p, P, C.c_int, P]),
     "bz_dequant": (C.c_int, [P, C.c_char_p, P]),
     "bz_rms_norm": (C.c_int, [P, P, P, P, C.c_int, C.c_int, C.c_float, C.c_int, P, P]),

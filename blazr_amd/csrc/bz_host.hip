@@ -398,7 +398,7 @@ static int choose_gw(int N, int K, int target) {
 static int gemv_target_wgs() {
   const char* e = getenv("BZ_GEMV_TARGET_WGS");
   int t = e ? atoi(e) : 0;
-  return t > 0 ? t : 1024;
+  return t > 0 ? t : 600;
 }
 
 // Build one LinearDev (kernel layout) from several raw tensors concatenated along N (same K, same kind).
@@ -1012,6 +1012,104 @@ extern "C" int bz_forward_head(bz_model* m, const bz_tensor* hidden, const bz_te
     BZ_TRY(emit_logits(m, logits_out, all ? s : 0));
   }
   return BZ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// measurement: per-kernel dispatch times of real decode steps (rocprof-comparable kernel durations
+// taken with HIP events on the launch stream)
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int bz_profile_step(bz_model* m, bz_kv* kv, int64_t token, int position, int iters, bz_kernel_time* out, int max_out, int* n_out) {
+  if (!m || !m->finalized || !kv || !out || !n_out || iters <= 0 || max_out <= 0) BZ_FAIL(BZ_E_INVALID, "profile_step: bad argument");
+  if (token < 0 || token >= m->cfg.vocab || position < 0 || position + iters > m->cfg.max_seq_len) BZ_FAIL(BZ_E_INVALID, "profile_step: token/position out of range");
+  BZ_HIP(hipSetDevice(m->dev->id));
+  BZ_TRY(kv_grow(kv, position + iters));
+  hipStream_t st = m->dev->stream;
+  long long t = token;
+  BZ_HIP(hipMemcpyAsync(m->tok_tmp, &t, 8, hipMemcpyHostToDevice, st));
+  BZ_HIP(hipStreamSynchronize(st));
+  BzTimingSink sink;
+  int rc = BZ_OK;
+  for (int i = 0; i < iters && rc == BZ_OK; i++) {
+    hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, m->pos_tmp, position + i);
+    FinalArgs fa{};
+    fa.tok_out = m->tok_tmp + 1;   // scratch: do not feed the sampled token back (same input every iteration)
+    StepIO io{};
+    io.kv = view_of(kv); io.d_tok = m->tok_tmp; io.d_pos = m->pos_tmp; io.final_args = &fa;
+    bzk_set_timing_sink(&sink);
+    rc = llama_step(m, io);
+    bzk_set_timing_sink(nullptr);
+  }
+  hipStreamSynchronize(st);
+  int n = 0;
+  for (auto& r : sink.recs) {
+    float ms = 0.f;
+    if (rc == BZ_OK && hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+      int j = 0;
+      for (; j < n; j++) if (strcmp(out[j].name, r.label) == 0) break;
+      if (j == n && n < max_out) { memset(&out[n], 0, sizeof(out[n])); strncpy(out[n].name, r.label, sizeof(out[n].name) - 1); n++; }
+      if (j < n) { out[j].launches++; out[j].total_ms += ms; out[j].algo_bytes += r.bytes; }
+    }
+    hipEventDestroy(r.e0); hipEventDestroy(r.e1);
+  }
+  *n_out = n;
+  if (kv->seq_len < position + iters) kv->seq_len = position + iters;
+  return rc;
+}
+
+__global__ void k_fill_u32(uint32_t* p, size_t n, uint32_t seed) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    uint32_t x = (uint32_t)i * 2654435761u + seed; x ^= x >> 15; x *= 2246822519u; x ^= x >> 13;
+    p[i] = x;
+  }
+}
+
+// Kernel tuning aid: times the int4 GEMV kernel alone on synthetic weights ([N,K], gs 128) rotated over `nbuf` buffers
+// (so that every launch streams from HBM, not from the 256 MiB Infinity Cache).  mode: 0 plain f32 x, 1 fused
+// residual+RMSNorm prologue (fixed-point prev), 2 SiLU*up prologue (fixed-point gate/up).  Returns the mean dispatch time.
+extern "C" int bz_tune_gemv(bz_device* dev, int N, int K, int gw, int mode, int nbuf, int iters, int flags, double* avg_us) {
+  if (!dev || !avg_us || N % 64 || K % 128 || gw <= 0 || (K / 128) % gw || gw > 16 || nbuf <= 0 || iters <= 0 || mode < 0 || mode > 2) BZ_FAIL(BZ_E_INVALID, "tune_gemv: bad argument");
+  BZ_HIP(hipSetDevice(dev->id));
+  hipStream_t st = dev->stream;
+  const size_t G = (size_t)K / 128, wb = (size_t)N * K / 2, sb = (size_t)N * G * 2, zb = (size_t)N * G;
+  std::vector<void*> bufs;
+  int rc = BZ_OK;
+  auto alloc = [&](size_t bytes, void** p) { if (hipMalloc(p, bytes) != hipSuccess) { rc = BZ_E_OOM; *p = nullptr; } else bufs.push_back(*p); };
+  std::vector<LinearDev> Ls(nbuf);
+  for (int b = 0; b < nbuf && rc == BZ_OK; b++) {
+    void *w, *s2, *z;
+    alloc(wb, &w); alloc(sb, &s2); alloc(zb, &z);
+    if (rc != BZ_OK) break;
+    hipLaunchKernelGGL(k_fill_u32, dim3(2048), dim3(256), 0, st, (uint32_t*)w, wb / 4, 17u * b + 1u);
+    hipMemsetAsync(s2, 0x1c, sb, st);   // f16 0x1c1c ~ 0.004
+    hipMemsetAsync(z, 8, zb, st);
+    LinearDev& L = Ls[b];
+    L.kind = LK_Q4G; L.N = N; L.K = K; L.gs = 128; L.w = w; L.scales = s2; L.zeros = z; L.gw = gw; L.npf = (flags & 8) ? 4 : 2; L.algo_bytes = wb + sb + zb / 2;
+  }
+  const int KX = mode == 2 ? 2 * K : K;
+  void *xs, *acc, *hin, *hout, *nw, *src;
+  alloc((size_t)KX * 8, &src); alloc((size_t)N * 8, &acc); alloc((size_t)K * 4, &hin); alloc((size_t)K * 4, &hout); alloc((size_t)K * 4, &nw); alloc((size_t)KX * 4, &xs);
+  if (rc != BZ_OK) { for (void* p : bufs) hipFree(p); BZ_FAIL(BZ_E_OOM, "tune_gemv: out of memory"); }
+  hipLaunchKernelGGL(k_fill_u32, dim3(64), dim3(256), 0, st, (uint32_t*)src, (size_t)KX * 2, 5u);
+  hipMemsetAsync(xs, 0x3c, (size_t)KX * 4, st); hipMemsetAsync(hin, 0x3c, (size_t)K * 4, st); hipMemsetAsync(nw, 0x3c, (size_t)K * 4, st);
+  hipMemsetAsync(acc, 0, (size_t)N * 8, st);
+  Pro p{};
+  p.act = BZ_F16; p.dbg = flags; p.eps = 1e-5f;
+  if (mode == 0) { p.mode = PRO_PLAIN; p.src = VSrc{xs, 0}; }
+  else if (mode == 1) { p.mode = PRO_NORM; p.src = VSrc{src, 1}; p.h_in = (float*)hin; p.h_out = (float*)hout; p.norm_w = (float*)nw; p.H = K; }
+  else { p.mode = PRO_SILU; p.src = VSrc{src, 1}; p.H = K; }
+  BzTimingSink sink;
+  for (int i = 0; i < iters + 2 && rc == BZ_OK; i++) {
+    GemvOut o{}; o.acc = (long long*)acc;
+    if (i == 2) bzk_set_timing_sink(&sink);
+    rc = bzk_gemv(st, Ls[i % nbuf], p, o, BZ_F16);
+  }
+  bzk_set_timing_sink(nullptr);
+  hipStreamSynchronize(st);
+  double tot = 0; int n = 0;
+  for (auto& r : sink.recs) { float ms = 0.f; if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) { tot += ms; n++; } hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+  *avg_us = n ? 1e3 * tot / n : 0.0;
+  for (void* q : bufs) hipFree(q);
+  return rc;
 }
 
 // ---------------------------------------------------------------------------------------------------------

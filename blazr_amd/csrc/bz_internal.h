@@ -37,6 +37,7 @@ struct Pro {
   int H;               // NORM: == K ; SILU: I
   int act;             // activation dtype for rounding (BZ_F32/F16/BF16)
   const int* perm;     // optional: x'[k] = x[perm[k]] (GPTQ act-order)
+  int dbg;             // tuning only (bz_tune_gemv): 1 = store instead of atomics, 2 = skip the dot4 work, 4 = skip quantisation
 };
 
 enum { LK_NONE = 0, LK_Q4G = 1, LK_ROWS = 2, LK_Q4K = 3, LK_Q6K = 4, LK_Q80 = 5 };
@@ -53,6 +54,7 @@ struct LinearDev {
   int* perm = nullptr;      // GPTQ act-order
   float* bias = nullptr;
   int gw = 1;               // groups (of gs) per workgroup (split-K granularity)
+  int npf = 2;              // groups of weight loads kept in flight per wave (2 or 4)
   size_t bytes = 0;         // resident bytes
   size_t algo_bytes = 0;    // minimal on-disk bytes (SURVEY 8d accounting)
   bool owned = true;
@@ -111,6 +113,11 @@ struct KvView {
 };
 
 size_t bz_dtype_size(int dtype);
+
+// per-launch timing records (bz_profile_step)
+struct BzTimingRec { const char* label; double bytes; hipEvent_t e0, e1; };
+struct BzTimingSink { std::vector<BzTimingRec> recs; };
+void bzk_set_timing_sink(BzTimingSink* s);
 
 // ---------------------------------------------------------------------------------------------------------
 // kernel launchers (bz_kernels.hip)

@@ -19,6 +19,28 @@
 #include "bz_internal.h"
 #include <math.h>
 
+#include <hip/hip_ext.h>
+
+// ---------------------------------------------------------------------------------------------------------
+// launch helper: plain launch, or -- while a profile is being taken -- hipExtLaunchKernelGGL with start/stop events
+// bound to the dispatch itself (pure kernel time on the launch stream, no inter-kernel gap)
+// ---------------------------------------------------------------------------------------------------------
+static thread_local BzTimingSink* g_sink = nullptr;
+void bzk_set_timing_sink(BzTimingSink* s) { g_sink = s; }
+
+#define BZ_LAUNCH(label, bytes, kernel, grid, block, smem, stream, ...)                                              \
+  do {                                                                                                               \
+    if (g_sink) {                                                                                                    \
+      hipEvent_t e0__, e1__;                                                                                         \
+      BZ_HIP(hipEventCreate(&e0__));                                                                                 \
+      BZ_HIP(hipEventCreate(&e1__));                                                                                 \
+      hipExtLaunchKernelGGL(kernel, grid, block, smem, stream, e0__, e1__, 0, __VA_ARGS__);                          \
+      g_sink->recs.push_back(BzTimingRec{label, (double)(bytes), e0__, e1__});                                       \
+    } else {                                                                                                         \
+      hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__);                                            \
+    }                                                                                                                \
+  } while (0)
+
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 // streamed-once weights: non-temporal loads (guide: nt on weights that one CU reads once)
@@ -352,7 +374,7 @@ __device__ __forceinline__ void q4g_consume(const uint4 (&w)[4], int g, const ui
   y += (s * __int_as_float(g1.x)) * f;
 }
 
-template <int MODE, int FIX, int MAXJ>
+template <int MODE, int FIX, int MAXJ, int NPF>
 __global__ __launch_bounds__(256) void k_gemv_q4g(const uint4* __restrict__ W, const __half* __restrict__ S,
                                                   const unsigned char* __restrict__ Z, const float* __restrict__ bias, int N, int K,
                                                   int GW, int nst, Pro pro, long long* acc, long long* zero_buf, int zero_n) {
@@ -376,62 +398,69 @@ __global__ __launch_bounds__(256) void k_gemv_q4g(const uint4* __restrict__ W, c
 
   zero_duty(zero_buf, zero_n);
 
-  // (1) issue the prologue's loads (L2-resident data)
+  // (1) group scales / zero points of this wave's tile: GW*128 B + GW*64 B, contiguous -> wide loads now, LDS later
+  unsigned sreg[8], zreg[4];
+  {
+    const unsigned* Sg = (const unsigned*)(S + ((size_t)nt * G + g0) * 64);
+    const unsigned* Zg = (const unsigned*)(Z + ((size_t)nt * G + g0) * 64);
+#pragma unroll
+    for (int j = 0; j < 8; j++) sreg[j] = (wave_on && lane + 64 * j < GW * 32) ? Sg[lane + 64 * j] : 0u;
+#pragma unroll
+    for (int j = 0; j < 4; j++) zreg[j] = (wave_on && lane + 64 * j < GW * 16) ? Zg[lane + 64 * j] : 0u;
+  }
+
+  // (2) issue the prologue's loads (L2-resident data)
   XRegs<MODE, MAXJ, Q4G_E> xr;
   xload<MODE, FIX, MAXJ, Q4G_E>(pro, k0, KR, xr);
 
-  // (2) issue the first weight loads and the scale/zero staging loads (HBM)
+  // (3) issue the first NPF groups of weight loads (HBM): they fly while the prologue computes
   const uint4* wp = W + ((size_t)nt * (K >> 5) + (k0 >> 5)) * 64 + lane;
-  uint4 A[4], B[4];
+  uint4 Wb[NPF][4];
 #pragma unroll
-  for (int c = 0; c < 4; c++) { A[c] = make_uint4(0, 0, 0, 0); B[c] = make_uint4(0, 0, 0, 0); }
-  if (wave_on) {
+  for (int b = 0; b < NPF; b++) {
 #pragma unroll
-    for (int c = 0; c < 4; c++) A[c] = ldnt(wp + c * 64);
-    if (GW > 1) {
-#pragma unroll
-      for (int c = 0; c < 4; c++) B[c] = ldnt(wp + (4 + c) * 64);
-    }
-    for (int g = 0; g < GW; g++) {
-      sS[(wave * GW + g) * 64 + lane] = S[((size_t)nt * G + g0 + g) * 64 + lane];
-      sZ[(wave * GW + g) * 64 + lane] = Z[((size_t)nt * G + g0 + g) * 64 + lane];
-    }
+    for (int c = 0; c < 4; c++) Wb[b][c] = (wave_on && b < GW) ? ldnt(wp + (b * 4 + c) * 64) : make_uint4(0, 0, 0, 0);
   }
 
-  // (3) finish the prologue while the weights are in flight
+  // (4) finish the prologue
   xfinish<MODE, MAXJ, Q4G_E>(pro, KR, xr, xs, red, blockIdx.x == 0);
-  quant_x128(xs, KR, xh, xm, xl, gpar);
+  {
+    unsigned* sSw = (unsigned*)(sS + wave * GW * 64);
+    unsigned* sZw = (unsigned*)(sZ + wave * GW * 64);
+#pragma unroll
+    for (int j = 0; j < 8; j++) if (lane + 64 * j < GW * 32) sSw[lane + 64 * j] = sreg[j];
+#pragma unroll
+    for (int j = 0; j < 4; j++) if (lane + 64 * j < GW * 16) sZw[lane + 64 * j] = zreg[j];
+  }
+  if (!(pro.dbg & 4)) quant_x128(xs, KR, xh, xm, xl, gpar);
   __syncthreads();
   if (!wave_on) return;
 
-  // (4) stream the k-range: two groups (8 KiB per wave) in flight
+  // (5) stream the k-range with NPF groups (NPF * 4 KiB per wave) in flight
   const uint4* xh4 = (const uint4*)xh;
   const uint4* xm4 = (const uint4*)xm;
   const uint4* xl4 = (const uint4*)xl;
   float y = 0.f;
-  for (int g = 0; g < GW; g += 2) {
-    {
-      const float s = __half2float(sS[(wave * GW + g) * 64 + lane]);
-      const int z = sZ[(wave * GW + g) * 64 + lane];
-      q4g_consume(A, g, xh4, xm4, xl4, gpar, s, z, y);
-      if (g + 2 < GW) {
+  for (int gb = 0; gb < GW; gb += NPF) {
 #pragma unroll
-        for (int c = 0; c < 4; c++) A[c] = ldnt(wp + ((g + 2) * 4 + c) * 64);
-      }
-    }
-    if (g + 1 < GW) {
-      const float s = __half2float(sS[(wave * GW + g + 1) * 64 + lane]);
-      const int z = sZ[(wave * GW + g + 1) * 64 + lane];
-      q4g_consume(B, g + 1, xh4, xm4, xl4, gpar, s, z, y);
-      if (g + 3 < GW) {
+    for (int b = 0; b < NPF; b++) {
+      const int g = gb + b;
+      if (g < GW) {
+        const float s = __half2float(sS[(wave * GW + g) * 64 + lane]);
+        const int z = sZ[(wave * GW + g) * 64 + lane];
+        if (pro.dbg & 2) y += __uint_as_float((Wb[b][0].x ^ Wb[b][1].y ^ Wb[b][2].z ^ Wb[b][3].w) & 0x007fffffu);
+        else q4g_consume(Wb[b], g, xh4, xm4, xl4, gpar, s, z, y);
+        if (g + NPF < GW) {
 #pragma unroll
-        for (int c = 0; c < 4; c++) B[c] = ldnt(wp + ((g + 3) * 4 + c) * 64);
+          for (int c = 0; c < 4; c++) Wb[b][c] = ldnt(wp + ((g + NPF) * 4 + c) * 64);
+        }
       }
     }
   }
   const int n = nt * 64 + lane;
   if (bias != nullptr && ks == 0) y += bias[n];
-  atomicAdd((unsigned long long*)(acc + n), (unsigned long long)f2fix(y));
+  if (pro.dbg & 1) acc[n] = f2fix(y);
+  else atomicAdd((unsigned long long*)(acc + n), (unsigned long long)f2fix(y));
 }
 
 static size_t q4g_smem(int GW) {
@@ -541,9 +570,11 @@ int bzk_gemv(hipStream_t s, const LinearDev& L, const Pro& pro, const GemvOut& o
     const size_t smem = q4g_smem(GW);
     const int maxj = pro.mode == PRO_NORM ? (pro.H + 1023) / 1024 : 1;
     if (GW > 16) BZ_FAIL(BZ_E_INVALID, "q4g gemv: %d groups per workgroup (max 16)", GW);
-#define LAUNCH_Q4G(MODE, FIX, MJ) hipLaunchKernelGGL((k_gemv_q4g<MODE, FIX, MJ>), dim3(grid), dim3(256), smem, s, (const uint4*)L.w, \
+#define LAUNCH_Q4G(MODE, FIX, MJ, NPF) BZ_LAUNCH(MODE == PRO_NORM ? "gemv_q4g<norm>" : (MODE == PRO_SILU ? "gemv_q4g<silu>" : "gemv_q4g<plain>"), \
+    L.algo_bytes, (k_gemv_q4g<MODE, FIX, MJ, NPF>), dim3(grid), dim3(256), smem, s, (const uint4*)L.w,                      \
     (const __half*)L.scales, (const unsigned char*)L.zeros, L.bias, L.N, L.K, GW, nst, pro, out.acc, out.zero_buf, out.zero_n)
-#define LAUNCH_Q4G_F(MODE, MJ) do { if (pro.src.fix) LAUNCH_Q4G(MODE, 1, MJ); else LAUNCH_Q4G(MODE, 0, MJ); } while (0)
+#define LAUNCH_Q4G_N(MODE, FIX, MJ) do { if (L.npf >= 4) LAUNCH_Q4G(MODE, FIX, MJ, 4); else LAUNCH_Q4G(MODE, FIX, MJ, 2); } while (0)
+#define LAUNCH_Q4G_F(MODE, MJ) do { if (pro.src.fix) LAUNCH_Q4G_N(MODE, 1, MJ); else LAUNCH_Q4G_N(MODE, 0, MJ); } while (0)
     if (pro.mode == PRO_PLAIN) LAUNCH_Q4G_F(PRO_PLAIN, 1);
     else if (pro.mode == PRO_SILU) LAUNCH_Q4G_F(PRO_SILU, 1);
     else if (maxj <= 1) LAUNCH_Q4G_F(PRO_NORM, 1);
@@ -551,6 +582,7 @@ int bzk_gemv(hipStream_t s, const LinearDev& L, const Pro& pro, const GemvOut& o
     else if (maxj <= 4) LAUNCH_Q4G_F(PRO_NORM, 4);
     else if (maxj <= 8) LAUNCH_Q4G_F(PRO_NORM, 8);
     else BZ_FAIL(BZ_E_UNSUPPORTED, "hidden size %d too large for the fused norm prologue", pro.H);
+#undef LAUNCH_Q4G_N
 #undef LAUNCH_Q4G_F
 #undef LAUNCH_Q4G
     BZ_HIP(hipGetLastError());
@@ -563,8 +595,8 @@ int bzk_gemv(hipStream_t s, const LinearDev& L, const Pro& pro, const GemvOut& o
     const int KP = (L.K + 511) & ~511;
     const size_t smem = (size_t)KP * 4 + 64;
     if (smem > 160 * 1024) BZ_FAIL(BZ_E_UNSUPPORTED, "K=%d too large for the rows GEMV", L.K);
-#define LAUNCH_ROWS(DT) hipLaunchKernelGGL((k_gemv_rows<DT>), dim3(grid), dim3(256), smem, s, (const void*)L.w, L.bias, L.N, L.K, rpw, \
-    pro, out.direct, act, out.amax_val, out.amax_idx, out.zero_buf, out.zero_n)
+#define LAUNCH_ROWS(DT) BZ_LAUNCH(out.amax_val ? "gemv_rows<lm_head+argmax>" : "gemv_rows", L.algo_bytes, (k_gemv_rows<DT>), dim3(grid), \
+    dim3(256), smem, s, (const void*)L.w, L.bias, L.N, L.K, rpw, pro, out.direct, act, out.amax_val, out.amax_idx, out.zero_buf, out.zero_n)
     if (L.wdt == BZ_F16) LAUNCH_ROWS(BZ_F16); else if (L.wdt == BZ_BF16) LAUNCH_ROWS(BZ_BF16); else LAUNCH_ROWS(BZ_F32);
 #undef LAUNCH_ROWS
     BZ_HIP(hipGetLastError());
@@ -715,7 +747,7 @@ __global__ void k_embed(const void* table, int tdt, const long long* tok, int H,
   }
 }
 int bzk_embed(hipStream_t s, const void* table, int tdt, const long long* tok, int H, int act, float* h) {
-  hipLaunchKernelGGL(k_embed, dim3((H + 255) / 256), dim3(256), 0, s, table, tdt, tok, H, act, h);
+  BZ_LAUNCH("embed", (double)H * (tdt == BZ_F32 ? 4 : 2), k_embed, dim3((H + 255) / 256), dim3(256), 0, s, table, tdt, tok, H, act, h);
   BZ_HIP(hipGetLastError());
   return BZ_OK;
 }
@@ -783,133 +815,180 @@ __device__ __forceinline__ void kv_ld8(const void* base, size_t off, int dt, flo
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// attention decode: one workgroup per kv head; fuses q/k/v finishing (fixed-point -> f32, rounding), RoPE,
-// KV append and the single-query attention of the `rep` query heads that share the kv head.
+// attention decode: one workgroup per kv head; fuses q/k/v finishing (fixed-point -> f32, rounding), RoPE, KV append
+// and the single-query attention of the `rep` query heads that share the kv head.
+//
+// Wave w serves query head w (+4, +8 ...).  LANE == POSITION: lane l walks positions l, l+64, ... as its own online-
+// softmax stream (m, l, o[HD] in registers; K/V rows straight to VGPRs, all loads of a row issued together), so there
+// is no per-position cross-lane traffic; the 64 streams are merged once at the end (log-sum-exp weights, o reduced
+// through LDS in 32-column rounds).
 // ---------------------------------------------------------------------------------------------------------
-#define ATT_CH 256  // positions per wave per chunk
 #define ATT_MAXHD 256
 
+// one cache row as raw 16-byte pieces (kept packed in registers; converted at use)
+template <int HD, int KVDT>
+struct KvRow {
+  static constexpr int NV = (KVDT == BZ_F32) ? HD / 4 : HD / 8;
+  uint4 raw[NV];
+  __device__ __forceinline__ void load(const void* base, size_t off) {
+    const uint4* p = (KVDT == BZ_F32) ? (const uint4*)((const float*)base + off) : (const uint4*)((const unsigned short*)base + off);
+#pragma unroll
+    for (int i = 0; i < NV; i++) raw[i] = p[i];
+  }
+  __device__ __forceinline__ void from_f32(const float* src) {   // LDS row (the token being appended)
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+      if (KVDT == BZ_F32) {
+        const float4 v = *(const float4*)(src + i * 4);
+        raw[i] = make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w));
+      } else {
+        unsigned u[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const float x0 = src[i * 8 + 2 * j], x1 = src[i * 8 + 2 * j + 1];
+          if (KVDT == BZ_F16) u[j] = (unsigned)__half_as_ushort(__float2half_rn(x0)) | ((unsigned)__half_as_ushort(__float2half_rn(x1)) << 16);
+          else u[j] = (__float_as_uint(bf16_round(x0)) >> 16) | (__float_as_uint(bf16_round(x1)) & 0xffff0000u);
+        }
+        raw[i] = make_uint4(u[0], u[1], u[2], u[3]);
+      }
+    }
+  }
+  // element e of the row as f32 (e is a compile-time constant after unrolling)
+  __device__ __forceinline__ float get(int e) const {
+    if (KVDT == BZ_F32) {
+      const uint4 v = raw[e >> 2];
+      const unsigned u = (e & 3) == 0 ? v.x : ((e & 3) == 1 ? v.y : ((e & 3) == 2 ? v.z : v.w));
+      return __uint_as_float(u);
+    }
+    const uint4 v = raw[e >> 3];
+    const int w = (e >> 1) & 3;
+    const unsigned u = w == 0 ? v.x : (w == 1 ? v.y : (w == 2 ? v.z : v.w));
+    if (KVDT == BZ_F16) return __half2float(__ushort_as_half((unsigned short)((e & 1) ? (u >> 16) : (u & 0xffffu))));
+    return __uint_as_float((e & 1) ? (u & 0xffff0000u) : (u << 16));
+  }
+};
+
+template <int HD, int KVDT>
 __global__ __launch_bounds__(256) void k_attn_decode(AttnArgs a) {
+  // grid = nq query heads.  All 256 lanes of the workgroup are position streams of ONE query head (position p -> lane
+  // p % 256), merged once through LDS.  Workgroups of one GQA group recompute the (tiny) k/v finishing redundantly; the
+  // first head of the group appends the new row to the cache.
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int hd = a.hd, half = hd >> 1, rep = a.nq / a.nkv;
-  float* qs = (float*)smem;               // [rep][hd]
-  float* knew = qs + rep * hd;            // [hd]
-  float* vnew = knew + hd;                // [hd]
-  float* sc = vnew + hd;                  // [4][ATT_CH]
-  const int kvh = blockIdx.x;
+  constexpr int half = HD / 2;
+  constexpr int LDR = HD + 4;             // padded row: 16-B aligned, conflict-free column walks
+  const int rep = a.nq / a.nkv;
+  float* qs = (float*)smem;               // [HD]
+  float* knew = qs + HD;                  // [HD]
+  float* vnew = knew + HD;                // [HD]
+  float* wred = vnew + HD;                // [8]: per-wave max / sum
+  float* ored = wred + 8;                 // [256][LDR]
+  const int hq = blockIdx.x, kvh = hq / rep;
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int pos = a.pos[0];
   const int len = a.q_only ? pos : pos + 1;
+  const int ncache = pos;                 // positions [0, ncache) come from the cache; `pos` itself (if any) from LDS
   const KvView& kv = a.kv;
   zero_duty(a.zero_buf, a.zero_n);
 
   if (!a.q_only) {
     const float* cr = a.cos_t + (size_t)pos * half;
     const float* sr = a.sin_t + (size_t)pos * half;
-    for (int idx = tid; idx < (rep + 1) * half; idx += 256) {
-      const int hh = idx / half, i = idx % half;
-      const int base = hh < rep ? (kvh * rep + hh) * hd : a.nq * hd + kvh * hd;
+    for (int idx = tid; idx < 2 * half; idx += 256) {
+      const int hh = idx / half, i = idx % half;       // hh 0: this query head, 1: the kv head's new key
+      const int base = hh == 0 ? hq * HD : a.nq * HD + kvh * HD;
       const int ia = a.interleaved ? 2 * i : i, ib = a.interleaved ? 2 * i + 1 : i + half;
       const float x0 = vsrc_get(a.qkv, base + ia, a.act), x1 = vsrc_get(a.qkv, base + ib, a.act);
       const float c = cr[i], s = sr[i];
       const float y0 = round_act(x0 * c - x1 * s, a.act), y1 = round_act(x1 * c + x0 * s, a.act);
-      if (hh < rep) { qs[hh * hd + ia] = y0; qs[hh * hd + ib] = y1; }
+      if (hh == 0) { qs[ia] = y0; qs[ib] = y1; }
       else { knew[ia] = y0; knew[ib] = y1; }
     }
-    for (int i = tid; i < hd; i += 256) vnew[i] = vsrc_get(a.qkv, a.nq * hd + a.nkv * hd + kvh * hd + i, a.act);
+    for (int i = tid; i < HD; i += 256) vnew[i] = vsrc_get(a.qkv, a.nq * HD + a.nkv * HD + kvh * HD + i, a.act);
     __syncthreads();
-    // KV append (kv_insert)
-    size_t woff;
-    if (kv.paged) woff = kv_slot_off(kv, a.layer, kvh, kv.slot ? kv.slot[0] : (kv.block_table[pos / kv.bs] * kv.bs + pos % kv.bs));
-    else woff = kv_row_off(kv, a.layer, kvh, pos);
-    for (int i = tid; i < hd; i += 256) { kv_st(kv.k, woff + i, kv.dtype, knew[i]); kv_st(kv.v, woff + i, kv.dtype, vnew[i]); }
+    if (hq % rep == 0) {   // KV append (kv_insert), once per kv head
+      size_t woff;
+      if (kv.paged) woff = kv_slot_off(kv, a.layer, kvh, kv.slot ? kv.slot[0] : (kv.block_table[pos / kv.bs] * kv.bs + pos % kv.bs));
+      else woff = kv_row_off(kv, a.layer, kvh, pos);
+      for (int i = tid; i < HD; i += 256) { kv_st(kv.k, woff + i, kv.dtype, knew[i]); kv_st(kv.v, woff + i, kv.dtype, vnew[i]); }
+    }
   } else {
-    for (int i = tid; i < rep * hd; i += 256) qs[i] = ((const float*)a.qkv.p)[kvh * rep * hd + i];
+    for (int i = tid; i < HD; i += 256) qs[i] = ((const float*)a.qkv.p)[hq * HD + i];
     __syncthreads();
   }
 
-  const float scale = 1.0f / sqrtf((float)hd);
-  float* scw = sc + wave * ATT_CH;
-  const int nround = (rep + 3) >> 2;
-  for (int rd = 0; rd < nround; rd++) {
-    const int hq = rd * 4 + wave;
-    const bool active = hq < rep;
-    const float* q = qs + (active ? hq : 0) * hd;
-    float m = -INFINITY, l = 0.f;
-    float oacc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int c0 = 0; c0 < len; c0 += ATT_CH) {
-      float sv[4];
-      float cm = -INFINITY;
+  const float scale = 1.0f / sqrtf((float)HD);
+  float m = -INFINITY, l = 0.f;
+  float o[HD];
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const int p = c0 + j * 64 + lane;
-        float s = -INFINITY;
-        if (active && p < len) {
-          float d = 0.f;
-          if (!a.q_only && p == pos) {
-            for (int i = 0; i < hd; i++) d += q[i] * knew[i];
-          } else {
-            const size_t ro = kv_row_off(kv, a.layer, kvh, p);
-            for (int i = 0; i < hd; i += 8) {
-              float kk[8];
-              kv_ld8(kv.k, ro + i, kv.dtype, kk);
-              const float4 qa = *(const float4*)(q + i), qb = *(const float4*)(q + i + 4);
-              d += kk[0] * qa.x + kk[1] * qa.y + kk[2] * qa.z + kk[3] * qa.w + kk[4] * qb.x + kk[5] * qb.y + kk[6] * qb.z + kk[7] * qb.w;
-            }
-          }
-          s = d * scale;
-        }
-        sv[j] = s;
-        cm = fmaxf(cm, s);
-      }
-      cm = wave_max(cm);
-      const float mn = fmaxf(m, cm);
-      const float alpha = (m == -INFINITY) ? 0.f : expf(m - mn);
-      float ls = 0.f;
+  for (int i = 0; i < HD; i++) o[i] = 0.f;
+  for (int p = tid; p < len; p += 256) {
+    KvRow<HD, KVDT> kr, vr;
+    const size_t ro = p < ncache ? kv_row_off(kv, a.layer, kvh, p) : 0;
+    if (p < ncache) kr.load(kv.k, ro); else kr.from_f32(knew);
+    // 16-bit caches: K and V rows in flight together (128 VGPRs); f32 cache: V after the dot (register budget)
+    if (KVDT != BZ_F32) { if (p < ncache) vr.load(kv.v, ro); else vr.from_f32(vnew); }
+    float d = 0.f;
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const float e = (sv[j] == -INFINITY) ? 0.f : expf(sv[j] - mn);
-        scw[j * 64 + lane] = e;
-        ls += e;
-      }
-      l = l * alpha + wave_sum(ls);
+    for (int i = 0; i < HD; i += 4) {
+      const float4 qa = *(const float4*)(qs + i);
+      d += kr.get(i) * qa.x + kr.get(i + 1) * qa.y + kr.get(i + 2) * qa.z + kr.get(i + 3) * qa.w;
+    }
+    if (KVDT == BZ_F32) { if (p < ncache) vr.load(kv.v, ro); else vr.from_f32(vnew); }
+    const float s = d * scale;
+    if (m == -INFINITY) {          // first position of this stream: e = exp(0) = 1
+      m = s; l = 1.f;
+#pragma unroll
+      for (int i = 0; i < HD; i++) o[i] = vr.get(i);
+    } else {
+      const float mn = fmaxf(m, s);
+      const float alpha = expf(m - mn), e = expf(s - mn);
+      l = l * alpha + e;
       m = mn;
 #pragma unroll
-      for (int t = 0; t < 4; t++) oacc[t] *= alpha;
-      __syncthreads();
-      const int cn = min(ATT_CH, len - c0);
-      if (active) {
-        for (int pp = 0; pp < cn; pp++) {
-          const float e = scw[pp];
-          const int p = c0 + pp;
-          if (!a.q_only && p == pos) {
-#pragma unroll
-            for (int t = 0; t < 4; t++) { const int d = lane + 64 * t; if (d < hd) oacc[t] += e * vnew[d]; }
-          } else {
-            const size_t ro = kv_row_off(kv, a.layer, kvh, p);
-#pragma unroll
-            for (int t = 0; t < 4; t++) { const int d = lane + 64 * t; if (d < hd) oacc[t] += e * kv_ld(kv.v, ro + d, kv.dtype); }
-          }
-        }
-      }
-      __syncthreads();
+      for (int i = 0; i < HD; i++) o[i] = o[i] * alpha + e * vr.get(i);
     }
-    if (active) {
-      const float inv = 1.0f / l;
+  }
+  // merge the (up to) 256 streams: global max / sum through LDS, o through a padded [rows][HD] image
+  const float wm = wave_max(m);
+  if (lane == 0) wred[wave] = wm;
+  __syncthreads();
+  const float M = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
+  const float w = (m == -INFINITY) ? 0.f : expf(m - M);
+  const float ws = wave_sum(l * w);
+  if (lane == 0) wred[4 + wave] = ws;
+  const int nrows = min(len, 256);
+  if (tid < nrows) {
 #pragma unroll
-      for (int t = 0; t < 4; t++) {
-        const int d = lane + 64 * t;
-        if (d < hd) a.out[(size_t)(kvh * rep + hq) * hd + d] = round_act(oacc[t] * inv, a.act);
-      }
-    }
+    for (int i = 0; i < HD; i += 4) *(float4*)(ored + tid * LDR + i) = make_float4(o[i] * w, o[i + 1] * w, o[i + 2] * w, o[i + 3] * w);
+  }
+  __syncthreads();
+  const float inv = 1.0f / ((wred[4] + wred[5]) + (wred[6] + wred[7]));
+  // thread t: column t % HD, rows t / HD, t / HD + 256 / HD, ...   (256 / HD row-phases)
+  constexpr int PH = 256 / HD;            // 2 for HD 128, 4 for HD 64
+  const int col = tid % HD, ph = tid / HD;
+  float acc = 0.f;
+  for (int r = ph; r < nrows; r += PH) acc += ored[r * LDR + col];
+  __syncthreads();
+  ored[ph * LDR + col] = acc;             // reuse the first PH rows for the phase partials
+  __syncthreads();
+  if (tid < HD) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < PH; q++) t += ored[q * LDR + tid];
+    a.out[(size_t)hq * HD + tid] = round_act(t * inv, a.act);
   }
 }
 
 int bzk_attn_decode(hipStream_t s, const AttnArgs& a) {
-  if (a.hd > ATT_MAXHD || (a.hd & 7)) BZ_FAIL(BZ_E_UNSUPPORTED, "head_dim %d unsupported", a.hd);
-  const int rep = a.nq / a.nkv;
-  const size_t smem = (size_t)(rep * a.hd + 2 * a.hd + 4 * ATT_CH) * 4;
-  hipLaunchKernelGGL(k_attn_decode, dim3(a.nkv), dim3(256), smem, s, a);
+  const size_t smem = (size_t)(3 * a.hd + 8 + 256 * (a.hd + 4)) * 4;
+#define LAUNCH_ATT(HD, DT) BZ_LAUNCH("attn_decode", 0.0, (k_attn_decode<HD, DT>), dim3(a.nq), dim3(256), smem, s, a)
+#define LAUNCH_ATT_DT(HD) do { if (a.kv.dtype == BZ_F16) LAUNCH_ATT(HD, BZ_F16); else if (a.kv.dtype == BZ_BF16) LAUNCH_ATT(HD, BZ_BF16); \
+                               else LAUNCH_ATT(HD, BZ_F32); } while (0)
+  if (a.hd == 64) LAUNCH_ATT_DT(64);
+  else if (a.hd == 128) LAUNCH_ATT_DT(128);
+  else BZ_FAIL(BZ_E_UNSUPPORTED, "head_dim %d unsupported (64 and 128 are built)", a.hd);
+#undef LAUNCH_ATT_DT
+#undef LAUNCH_ATT
   BZ_HIP(hipGetLastError());
   return BZ_OK;
 }
@@ -971,7 +1050,7 @@ __global__ __launch_bounds__(256) void k_argmax_final(FinalArgs a) {
   if (a.zero_buf) for (int i = threadIdx.x; i < a.zero_n; i += 256) a.zero_buf[i] = 0;
 }
 int bzk_argmax_final(hipStream_t s, const FinalArgs& a) {
-  hipLaunchKernelGGL(k_argmax_final, dim3(1), dim3(256), 0, s, a);
+  BZ_LAUNCH("argmax_final", 0.0, k_argmax_final, dim3(1), dim3(256), 0, s, a);
   BZ_HIP(hipGetLastError());
   return BZ_OK;
 }

@@ -305,6 +305,14 @@ class LoadedModel:
                                         L.FWD_ALL_LOGITS if all_logits else 0))
         return out
 
+    def profile_step(self, kv, token, position, iters=4):
+        """per-kernel dispatch times of `iters` real decode steps (bz_profile_step)"""
+        buf = (L.KernelTime * 32)()
+        n = C.c_int()
+        L.check(L.lib().bz_profile_step(self.h, kv.h, int(token), int(position), iters, buf, 32, C.byref(n)))
+        return [dict(name=buf[i].name.decode(), launches=buf[i].launches, total_ms=buf[i].total_ms, algo_bytes=buf[i].algo_bytes)
+                for i in range(n.value)]
+
     # --- op-level ----------------------------------------------------------------------------------------------
     def quant_matmul(self, name, x):
         x = np.ascontiguousarray(x, dtype=np.float32)

@@ -198,6 +198,17 @@ typedef struct { double prefill_ms, decode_ms; int32_t n_generated; int32_t fini
 /* prompt: host i64[n_prompt]; out_tokens: host i64[max_tokens] */
 int bz_generate(bz_model* m, const int64_t* prompt, int n_prompt, const bz_gen_config* gc, int64_t* out_tokens, bz_gen_stats* stats);
 
+/* ---- measurement (methodology of /root/reference/src/cli/bench.rs:24-33,299-306) ----------------------- */
+typedef struct { char name[48]; int32_t launches; double total_ms; double algo_bytes; } bz_kernel_time;
+/* Runs `iters` eager decode steps (token at position, position+1, ...) with every kernel launched through
+ * hipExtLaunchKernelGGL start/stop events on the compute stream and returns, per kernel, launches / summed dispatch time /
+ * summed algorithmic bytes.  Durations are pure kernel times (comparable with rocprofv3 --kernel-trace). */
+int bz_profile_step(bz_model* m, bz_kv* kv, int64_t token, int position, int iters, bz_kernel_time* out, int max_out, int* n_out);
+
+/* Kernel tuning aid: mean dispatch time of the int4 GEMV kernel alone on synthetic [N,K] gs-128 weights rotated over `nbuf`
+ * HBM buffers.  mode 0 plain x / 1 fused residual+RMSNorm prologue / 2 SiLU*up prologue; flags are debugging knobs (0). */
+int bz_tune_gemv(bz_device* dev, int N, int K, int groups_per_wg, int mode, int nbuf, int iters, int flags, double* avg_us);
+
 /* ---- op-level entry points (parity tests; each is the kernel the forward path uses) ------------------------ */
 /* QuantMatmulOps / dense matmul on a registered weight `name` ("….weight"): y[S,N] = x[S,K] W^T (+bias); x,y F32 device tensors */
 int bz_quant_matmul(bz_model* m, const char* name, const bz_tensor* x, int S, bz_tensor* y);
