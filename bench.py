@@ -123,16 +123,11 @@ def main():
     gpu_ms = timer.ms()
     dev.synchronize()
     host_ms = (time.perf_counter() - t_host0) * 1e3
+    from blazr_amd import replicas
     if dist is not None:
-        import torch
-        t = torch.tensor([max(gpu_ms, host_ms)], device="cuda")
         dist.barrier()
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall_ms = float(t.item())
-    else:
-        wall_ms = max(gpu_ms, host_ms)
+    tok_s, wall_ms = replicas.aggregate_tokens_per_s(max(gpu_ms, host_ms), args.steps, dist, "cuda" if dist is not None else None)
     tokens = [first] + [graph.read_token(i) for i in range(args.warmup + args.steps)]
-    tok_s = n_gpus * args.steps / (wall_ms / 1e3)
 
     # per-kernel dispatch times of real decode steps (pure kernel time, hipExtLaunchKernelGGL start/stop events)
     pos = args.prompt_len + args.warmup + args.steps
