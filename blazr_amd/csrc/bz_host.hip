@@ -858,21 +858,52 @@ static int llama_step(bz_model* m, const StepIO& io) {
     aa.qkv = qkv; aa.cos_t = m->cos_t; aa.sin_t = m->sin_t; aa.interleaved = c.rope_interleaved; aa.pos = io.d_pos;
     aa.nq = c.n_heads; aa.nkv = c.n_kv_heads; aa.hd = c.head_dim; aa.act = act; aa.kv = io.kv; aa.layer = l; aa.out = m->attn_out;
     aa.zero_buf = nullptr; aa.zero_n = 0; aa.q_only = 0;
-    BZ_TRY(bzk_attn_decode(st, aa));
-
-    Pro pp{}; pp.mode = PRO_PLAIN; pp.src = VSrc{m->attn_out, 0}; pp.act = act; pp.H = 0;
+    static long long* attn_stamps = nullptr;
+    if (getenv("BZ_ATTN_STAMPS")) {
+      if (!attn_stamps) { hipMalloc(&attn_stamps, 256); hipMemset(attn_stamps, 0, 256); }
+      if (l == 1) {
+        if (getenv("BZ_ATTN_STAMPS_PRINT")) {
+          long long hst[16]; hipStreamSynchronize(st); hipMemcpy(hst, attn_stamps, 128, hipMemcpyDeviceToHost);
+          fprintf(stderr, "[bz] attn stamps (us since entry):");
+          for (int q = 1; q <= 8; q++) fprintf(stderr, " %d:%.2f", q, (hst[q] - hst[0]) / 100.0);
+          fprintf(stderr, "\n");
+        }
+      }
+      aa.stamps = l == 0 ? attn_stamps : nullptr;
+    }
     VSrc ov;
-    BZ_TRY(run_fused(m, Ld.o, pp, rs, &ov));
+    static const bool no_fuse = getenv("BZ_NO_ATTN_FUSION") != nullptr;
+    if (!no_fuse && Ld.o.parts.size() == 1 && Ld.o.fix_out && bzk_attn_oproj_slices(aa, Ld.o.parts[0]) > 0) {
+      // attention + o_proj in one launch: same ring protocol as a GEMV launch
+      const int rz = (rs.ri + 1) % 3;
+      aa.zero_buf = rs.dirty[rz] > 0 ? m->ring[rz] : nullptr; aa.zero_n = rs.dirty[rz];
+      BZ_TRY(bzk_attn_oproj(st, aa, Ld.o.parts[0], m->ring[rs.ri]));
+      ov = VSrc{m->ring[rs.ri], 1};
+      rs.dirty[rz] = 0; rs.dirty[rs.ri] = Ld.o.N; rs.ri = rz;
+    } else {
+      BZ_TRY(bzk_attn_decode(st, aa));
+      Pro pp{}; pp.mode = PRO_PLAIN; pp.src = VSrc{m->attn_out, 0}; pp.act = act; pp.H = 0;
+      BZ_TRY(run_fused(m, Ld.o, pp, rs, &ov));
+    }
 
     Pro pf{}; pf.mode = PRO_NORM; pf.src = ov; pf.h_in = m->hbuf[cur]; pf.h_out = m->hbuf[cur ^ 1]; pf.norm_w = Ld.ffn_norm;
     pf.eps = c.rms_eps; pf.H = H; pf.act = act;
-    VSrc gu;
-    BZ_TRY(run_fused(m, Ld.gateup, pf, rs, &gu));
-    cur ^= 1;
-
-    Pro ps{}; ps.mode = PRO_SILU; ps.src = gu; ps.H = I; ps.act = act;
     VSrc dn;
-    BZ_TRY(run_fused(m, Ld.down, ps, rs, &dn));
+    static const bool no_mlp_fuse = getenv("BZ_NO_MLP_FUSION") != nullptr;
+    if (!no_mlp_fuse && Ld.gateup.parts.size() == 1 && Ld.down.parts.size() == 1 && bzk_mlp_fusable(Ld.gateup.parts[0], Ld.down.parts[0], H, I)) {
+      // norm + gate/up + SiLU*up + down in one launch (same ring protocol as one GEMV launch)
+      const int rz = (rs.ri + 1) % 3;
+      BZ_TRY(bzk_mlp_q4g(st, Ld.gateup.parts[0], Ld.down.parts[0], H, I, pf, m->ring[rs.ri], rs.dirty[rz] > 0 ? m->ring[rz] : nullptr, rs.dirty[rz]));
+      dn = VSrc{m->ring[rs.ri], 1};
+      rs.dirty[rz] = 0; rs.dirty[rs.ri] = H; rs.ri = rz;
+      cur ^= 1;
+    } else {
+      VSrc gu;
+      BZ_TRY(run_fused(m, Ld.gateup, pf, rs, &gu));
+      cur ^= 1;
+      Pro ps{}; ps.mode = PRO_SILU; ps.src = gu; ps.H = I; ps.act = act;
+      BZ_TRY(run_fused(m, Ld.down, ps, rs, &dn));
+    }
     prev = dn;
   }
   if (io.hidden_out) {

@@ -131,7 +131,9 @@ struct GemvOut {
 };
 
 int bzk_gemv(hipStream_t s, const LinearDev& L, const Pro& pro, const GemvOut& out, int act);
-int bzk_gemv_rows_blocks(const LinearDev& L);   // number of workgroups the ROWS kernel uses (argmax partial count)
+int bzk_gemv_rows_blocks(const LinearDev& L);
+bool bzk_mlp_fusable(const LinearDev& gu, const LinearDev& dn, int H, int I);
+int bzk_mlp_q4g(hipStream_t s, const LinearDev& gu, const LinearDev& dn, int H, int I, const Pro& pro, long long* acc, long long* zero_buf, int zero_n);   // number of workgroups the ROWS kernel uses (argmax partial count)
 int bzk_repack_awq(hipStream_t s, const uint32_t* d_qweight, const float* d_scales, const float* d_zeros, int N, int K, int gs,
                    void* w_out, void* s_out, void* z_out);
 int bzk_repack_gptq(hipStream_t s, const uint32_t* d_qweight, const float* d_scales, const uint32_t* d_qzeros, const int* d_perm,
@@ -152,8 +154,11 @@ struct AttnArgs {
   float* out;               // [nq*hd] f32 rounded
   long long* zero_buf; int zero_n;
   int q_only;               // op-level test: q given roped in qkv (plain), no insert, len = *pos
+  long long* stamps;        // diagnostic build only (BZ_ATTN_STAMPS): s_memrealtime at phase boundaries of block 0
 };
 int bzk_attn_decode(hipStream_t s, const AttnArgs& a);
+int bzk_attn_oproj_slices(const AttnArgs& a, const LinearDev& L);   // 0: fused form not applicable
+int bzk_attn_oproj(hipStream_t s, const AttnArgs& a, const LinearDev& L, long long* acc);
 int bzk_kv_insert(hipStream_t s, const KvView& kv, int layer, const float* k, const float* v, const int* pos, int nkv, int hd);
 int bzk_kv_read(hipStream_t s, const KvView& kv, int layer, int kvh, int which, int len, float* out);
 

@@ -288,7 +288,7 @@ __device__ __forceinline__ void xfinish(const Pro& p, int KR, const XRegs<MODE, 
 #define XQ_MAX 8355000.0f  // < 127*65536 + 127*256 + 127
 
 __device__ __forceinline__ void quant_x128(const float* xs, int KR, unsigned* xh, unsigned* xm, unsigned* xl, int4* gpar) {
-  for (int base = 0; base < KR; base += 2048) {
+  for (int base = 0; base < KR; base += (int)blockDim.x * 8) {
     const int e0 = base + threadIdx.x * 8;
     const bool on = e0 < KR;
     float v[8];
@@ -372,6 +372,252 @@ __device__ __forceinline__ void q4g_consume(const uint4 (&w)[4], int g, const ui
   const int Ul = (Al << 4) + Bl + g1.w - z * g2.z;
   const float f = fmaf((float)Uh, 65536.0f, fmaf((float)Um, 256.0f, (float)Ul));
   y += (s * __int_as_float(g1.x)) * f;
+}
+
+// same arithmetic over NCH 32-k chunks whose x planes start at uint4 index xo; group parameters at gpar[gp], gpar[gp+1]
+template <int NCH>
+__device__ __forceinline__ void q4g_consume_n(const uint4 (&w)[NCH], int xo, int gp, const uint4* xh4, const uint4* xm4, const uint4* xl4,
+                                              const int4* gpar, float s, int z, float& y) {
+  int Ah = 0, Am = 0, Al = 0, Bh = 0, Bm = 0, Bl = 0;
+#pragma unroll
+  for (int c = 0; c < NCH; c++) {
+    const uint4 h0 = xh4[xo + c * 2], h1 = xh4[xo + c * 2 + 1];
+    const uint4 m0 = xm4[xo + c * 2], m1 = xm4[xo + c * 2 + 1];
+    const uint4 l0 = xl4[xo + c * 2], l1 = xl4[xo + c * 2 + 1];
+    const unsigned Xh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+    const unsigned Xm[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+    const unsigned Xl[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+    const unsigned W[4] = {w[c].x, w[c].y, w[c].z, w[c].w};
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int a = (int)(W[j] & 0x0F0F0F0Fu), b = (int)(W[j] & 0xF0F0F0F0u);
+      Ah = __builtin_amdgcn_sdot4(a, (int)Xh[2 * j], Ah, false);
+      Am = __builtin_amdgcn_sdot4(a, (int)Xm[2 * j], Am, false);
+      Al = __builtin_amdgcn_sdot4(a, (int)Xl[2 * j], Al, false);
+      Bh = __builtin_amdgcn_sdot4(b, (int)Xh[2 * j + 1], Bh, false);
+      Bm = __builtin_amdgcn_sdot4(b, (int)Xm[2 * j + 1], Bm, false);
+      Bl = __builtin_amdgcn_sdot4(b, (int)Xl[2 * j + 1], Bl, false);
+    }
+  }
+  const int4 g1 = gpar[gp], g2 = gpar[gp + 1];
+  const int Uh = (Ah << 4) + Bh + g1.y - z * g2.x;
+  const int Um = (Am << 4) + Bm + g1.z - z * g2.y;
+  const int Ul = (Al << 4) + Bl + g1.w - z * g2.z;
+  const float f = fmaf((float)Uh, 65536.0f, fmaf((float)Um, 256.0f, (float)Ul));
+  y += (s * __int_as_float(g1.x)) * f;
+}
+
+// 64 values -> three int8 planes + parameters (one 64-k half group; threads 0..7 of the block, 8 values each)
+__device__ __forceinline__ void quant_x64(const float* a, unsigned* xh, unsigned* xm, unsigned* xl, int4* gpar) {
+  const int t = threadIdx.x;
+  if (t >= 64) return;                       // first wave only (shuffles below stay inside it)
+  const bool on = t < 8;
+  float v[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) v[i] = on ? a[t * 8 + i] : 0.f;
+  float am = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; i++) am = fmaxf(am, fabsf(v[i]));
+#pragma unroll
+  for (int m = 1; m <= 4; m <<= 1) am = fmaxf(am, __shfl_xor(am, m, 64));
+  const float inv = am > 0.f ? XQ_MAX / am : 0.f;
+  unsigned wh[2] = {0, 0}, wm[2] = {0, 0}, wl[2] = {0, 0};
+  int s_hi = 0, s_mid = 0, s_lo = 0, b_hi = 0, b_mid = 0, b_lo = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const int xi = (int)rintf(v[i] * inv);
+    const int lo = ((xi + 128) & 255) - 128;
+    const int r1 = (xi - lo) >> 8;
+    const int mid = ((r1 + 128) & 255) - 128;
+    const int hi = (r1 - mid) >> 8;
+    wh[i >> 2] |= ((unsigned)hi & 255u) << (8 * (i & 3));
+    wm[i >> 2] |= ((unsigned)mid & 255u) << (8 * (i & 3));
+    wl[i >> 2] |= ((unsigned)lo & 255u) << (8 * (i & 3));
+    s_hi += hi; s_mid += mid; s_lo += lo;
+    if (i >= 4) { b_hi += hi; b_mid += mid; b_lo += lo; }
+  }
+#pragma unroll
+  for (int m = 1; m <= 4; m <<= 1) {
+    s_hi += __shfl_xor(s_hi, m, 64); s_mid += __shfl_xor(s_mid, m, 64); s_lo += __shfl_xor(s_lo, m, 64);
+    b_hi += __shfl_xor(b_hi, m, 64); b_mid += __shfl_xor(b_mid, m, 64); b_lo += __shfl_xor(b_lo, m, 64);
+  }
+  if (on) {
+    *(uint2*)(xh + t * 2) = make_uint2(wh[0], wh[1]);
+    *(uint2*)(xm + t * 2) = make_uint2(wm[0], wm[1]);
+    *(uint2*)(xl + t * 2) = make_uint2(wl[0], wl[1]);
+    if (t == 0) {
+      gpar[0] = make_int4(__float_as_int(am * (1.0f / (XQ_MAX * 16.0f))), 128 * b_hi, 128 * b_mid, 128 * b_lo);
+      gpar[1] = make_int4(16 * s_hi, 16 * s_mid, 16 * s_lo, 0);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Fused MLP (INT4):  acc_down += Wd[:, slice] . R(R(silu(R(Wg[slice] x))) * R(Wu[slice] x)),  x = RMSNorm(R(h + prev))
+// grid = I/64 blocks of 512 threads.  A block owns 64 intermediate columns: gate and up over the FULL K (8 waves split K,
+// no split-K across blocks, so SiLU*up is final inside the block) and then its 64-k slab of down_proj for all outputs.
+// down_proj is a sum over the intermediate dimension, so the slabs combine through the fixed-point accumulator.
+// One launch streams 81 % of a layer's bytes with one fused-norm prologue per block.
+// ---------------------------------------------------------------------------------------------------------
+template <int FIX, int GPW, int TPW>   // GPW k-groups per wave (gate/up), TPW output tiles per wave (down)
+__global__ __launch_bounds__(512) void k_mlp_q4g(const uint4* __restrict__ Wgu, const __half* __restrict__ Sgu, const unsigned char* __restrict__ Zgu,
+                                                 const float* __restrict__ bgu, const uint4* __restrict__ Wd, const __half* __restrict__ Sd,
+                                                 const unsigned char* __restrict__ Zd, const float* __restrict__ bd, int H, int I, Pro pro,
+                                                 long long* acc, long long* zero_buf, int zero_n) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* xs = (float*)smem;                   // [H]
+  unsigned* xh = (unsigned*)(xs + H);         // [H/4] x3
+  unsigned* xm = xh + H / 4;
+  unsigned* xl = xm + H / 4;
+  const int G = H >> 7;
+  int4* gpar = (int4*)(xl + H / 4);           // [2G]
+  float* part = (float*)(gpar + 2 * G);       // [8][128]
+  float* av = part + 8 * 128;                 // [64]
+  unsigned* ah = (unsigned*)(av + 64);        // [16] x3
+  unsigned* am_ = ah + 16;
+  unsigned* al = am_ + 16;
+  int4* apar = (int4*)(al + 16);              // [2]
+  float* red = (float*)(apar + 2);            // [8]
+
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int sl = blockIdx.x;                  // intermediate slice: columns [64 sl, 64 sl + 64)
+  const int NTI = I >> 6;                     // gate tile = sl, up tile = NTI + sl
+  const int gbeg = wave * GPW;                // G == 8 * GPW
+  const int tbeg = wave * TPW;                // H / 64 == 8 * TPW
+  const int GD = I >> 7, gd = sl >> 1;        // down's quantisation group of these 64 k
+  zero_duty(zero_buf, zero_n);
+
+  // (1) prologue loads: full-H pass, 4 contiguous elements per thread per 2048
+  const bool hasprev = pro.src.p != nullptr;
+  float hv[GPW / 2 > 0 ? GPW / 2 : 1][4];     // H == 1024 * GPW == 2048 * (GPW / 2)
+#pragma unroll
+  for (int j = 0; j < (GPW / 2 > 0 ? GPW / 2 : 1); j++) {
+    const int i = j * 2048 + tid * 4;
+    const bool on = i < H;
+    const float4 h4 = on ? *(const float4*)(pro.h_in + i) : make_float4(0, 0, 0, 0);
+    hv[j][0] = h4.x; hv[j][1] = h4.y; hv[j][2] = h4.z; hv[j][3] = h4.w;
+    if (hasprev) {
+#pragma unroll
+      for (int e = 0; e < 4; e++) { const float pv = on ? vget<FIX>(pro.src.p, i + e, pro.act) : 0.f; hv[j][e] = round_act(hv[j][e] + pv, pro.act); }
+    }
+  }
+  // (2) all gate + up loads of this wave's k-range up front: 256 KB per block in flight while the norm prologue computes
+  const uint4* wg = Wgu + ((size_t)sl * (H >> 5) + gbeg * 4) * 64 + lane;
+  const uint4* wu = Wgu + ((size_t)(NTI + sl) * (H >> 5) + gbeg * 4) * 64 + lane;
+  uint4 Ag[GPW][4], Au[GPW][4];
+#pragma unroll
+  for (int b = 0; b < GPW; b++) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) { Ag[b][c] = ldnt(wg + (b * 4 + c) * 64); Au[b][c] = ldnt(wu + (b * 4 + c) * 64); }
+  }
+  float sg[GPW], su[GPW]; int zg[GPW], zu[GPW];
+#pragma unroll
+  for (int b = 0; b < GPW; b++) {
+    const size_t ig = ((size_t)sl * G + gbeg + b) * 64 + lane, iu = ((size_t)(NTI + sl) * G + gbeg + b) * 64 + lane;
+    sg[b] = __half2float(Sgu[ig]); zg[b] = Zgu[ig]; su[b] = __half2float(Sgu[iu]); zu[b] = Zgu[iu];
+  }
+  // (3) finish the norm
+  float ss = 0.f;
+#pragma unroll
+  for (int j = 0; j < (GPW / 2 > 0 ? GPW / 2 : 1); j++) {
+    const int i = j * 2048 + tid * 4;
+    if (i < H) {
+      ss += hv[j][0] * hv[j][0] + hv[j][1] * hv[j][1] + hv[j][2] * hv[j][2] + hv[j][3] * hv[j][3];
+      if (blockIdx.x == 0 && pro.h_out) *(float4*)(pro.h_out + i) = make_float4(hv[j][0], hv[j][1], hv[j][2], hv[j][3]);
+    }
+  }
+  ss = wave_sum(ss);
+  if (lane == 0) red[wave] = ss;
+  __syncthreads();
+  ss = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
+  const float rs = 1.0f / sqrtf(ss / (float)H + pro.eps);
+#pragma unroll
+  for (int j = 0; j < (GPW / 2 > 0 ? GPW / 2 : 1); j++) {
+    const int i = j * 2048 + tid * 4;
+    if (i < H) {
+      const float4 w4 = *(const float4*)(pro.norm_w + i);
+      *(float4*)(xs + i) = make_float4(round_act(w4.x * round_act(hv[j][0] * rs, pro.act), pro.act), round_act(w4.y * round_act(hv[j][1] * rs, pro.act), pro.act),
+                                       round_act(w4.z * round_act(hv[j][2] * rs, pro.act), pro.act), round_act(w4.w * round_act(hv[j][3] * rs, pro.act), pro.act));
+    }
+  }
+  __syncthreads();
+  quant_x128(xs, H, xh, xm, xl, gpar);
+  __syncthreads();
+
+  // (4) gate / up partial dot products over this wave's k-groups
+  const uint4* xh4 = (const uint4*)xh;
+  const uint4* xm4 = (const uint4*)xm;
+  const uint4* xl4 = (const uint4*)xl;
+  float yg = 0.f, yu = 0.f;
+#pragma unroll
+  for (int b = 0; b < (GPW + 1) / 2; b++) {
+    q4g_consume(Ag[b], gbeg + b, xh4, xm4, xl4, gpar, sg[b], zg[b], yg);
+    q4g_consume(Au[b], gbeg + b, xh4, xm4, xl4, gpar, su[b], zu[b], yu);
+  }
+  // half of the gate/up registers are free: issue this wave's down slab now; it flies during the remaining dot products,
+  // the reduction, SiLU and the quantisation
+  uint4 D[TPW][2];
+  float sd[TPW]; int zd[TPW];
+#pragma unroll
+  for (int q = 0; q < TPW; q++) {
+    const uint4* wp = Wd + ((size_t)(tbeg + q) * (I >> 5) + 2 * sl) * 64 + lane;
+    D[q][0] = ldnt(wp); D[q][1] = ldnt(wp + 64);
+    const size_t si = ((size_t)(tbeg + q) * GD + gd) * 64 + lane;
+    sd[q] = __half2float(Sd[si]); zd[q] = Zd[si];
+  }
+#pragma unroll
+  for (int b = (GPW + 1) / 2; b < GPW; b++) {
+    q4g_consume(Ag[b], gbeg + b, xh4, xm4, xl4, gpar, sg[b], zg[b], yg);
+    q4g_consume(Au[b], gbeg + b, xh4, xm4, xl4, gpar, su[b], zu[b], yu);
+  }
+  part[wave * 128 + lane] = yg;
+  part[wave * 128 + 64 + lane] = yu;
+  __syncthreads();
+  if (tid < 128) {
+    float t = 0.f;
+#pragma unroll
+    for (int w2 = 0; w2 < 8; w2++) t += part[w2 * 128 + tid];
+    if (bgu) t += bgu[tid < 64 ? sl * 64 + tid : I + sl * 64 + (tid - 64)];
+    part[tid] = round_act(t, pro.act);
+  }
+  __syncthreads();
+  if (tid < 64) av[tid] = round_act(round_act(silu_f(part[tid]), pro.act) * part[64 + tid], pro.act);
+  __syncthreads();
+  quant_x64(av, ah, am_, al, apar);
+  __syncthreads();
+  // (5) this wave's down slab
+  const uint4* ah4 = (const uint4*)ah;
+  const uint4* am4 = (const uint4*)am_;
+  const uint4* al4 = (const uint4*)al;
+#pragma unroll
+  for (int q = 0; q < TPW; q++) {
+    float y = 0.f;
+    q4g_consume_n<2>(D[q], 0, 0, ah4, am4, al4, apar, sd[q], zd[q], y);
+    const int n = (tbeg + q) * 64 + lane;
+    if (bd != nullptr && sl == 0) y += bd[n];
+    atomicAdd((unsigned long long*)(acc + n), (unsigned long long)f2fix(y));
+  }
+}
+
+static size_t mlp_smem(int H) { return (size_t)H * 4 + (size_t)H * 3 + (size_t)(H >> 7) * 32 + 8 * 128 * 4 + 64 * 4 + 48 * 4 + 32 + 32 + 64; }
+
+bool bzk_mlp_fusable(const LinearDev& gu, const LinearDev& dn, int H, int I) {
+  return gu.kind == LK_Q4G && dn.kind == LK_Q4G && !gu.perm && !dn.perm && gu.N == 2 * I && gu.K == H && dn.N == H && dn.K == I &&
+         (H == 2048 || H == 4096) && I % 128 == 0 && mlp_smem(H) <= 64 * 1024;
+}
+
+int bzk_mlp_q4g(hipStream_t s, const LinearDev& gu, const LinearDev& dn, int H, int I, const Pro& pro, long long* acc, long long* zero_buf, int zero_n) {
+  if (!bzk_mlp_fusable(gu, dn, H, I)) BZ_FAIL(BZ_E_INVALID, "fused MLP does not apply to this shape");
+  const size_t smem = mlp_smem(H);
+  const double bytes = (double)gu.algo_bytes + (double)dn.algo_bytes;
+#define LAUNCH_MLP(FIX, GP, TP) BZ_LAUNCH("mlp_q4g<norm+gate/up+silu+down>", bytes, (k_mlp_q4g<FIX, GP, TP>), dim3(I / 64), dim3(512), smem, s, \
+    (const uint4*)gu.w, (const __half*)gu.scales, (const unsigned char*)gu.zeros, gu.bias, (const uint4*)dn.w, (const __half*)dn.scales,            \
+    (const unsigned char*)dn.zeros, dn.bias, H, I, pro, acc, zero_buf, zero_n)
+  if (H == 4096) { if (pro.src.fix) LAUNCH_MLP(1, 4, 8); else LAUNCH_MLP(0, 4, 8); }
+  else { if (pro.src.fix) LAUNCH_MLP(1, 2, 4); else LAUNCH_MLP(0, 2, 4); }
+#undef LAUNCH_MLP
+  BZ_HIP(hipGetLastError());
+  return BZ_OK;
 }
 
 template <int MODE, int FIX, int MAXJ, int NPF>
@@ -979,12 +1225,416 @@ __global__ __launch_bounds__(256) void k_attn_decode(AttnArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// attention decode FUSED with o_proj (INT4): grid = nq heads x CS column slices.  o_proj is a sum over heads,
+// out[n] = sum_h Wo[n, h*HD:(h+1)*HD] . attn_h, so block (h, cs) computes head h's attention (redundantly in each of the
+// CS slices -- the K/V rows are L2 hits) and multiplies it by its [N/CS columns x HD] slab of Wo, accumulating into the
+// fixed-point o accumulator.  The slab's weight loads and the K/V row loads are issued first, so HBM latency hides
+// behind the q/k/v finishing and the softmax; one launch (and its ramp/tail) per layer disappears.
+// HD == 128 == the quantisation group, so a head is exactly one k-group of Wo.
+// ---------------------------------------------------------------------------------------------------------
+template <int KVDT, int TPW>   // TPW = 64-column tiles per wave
+__global__ __launch_bounds__(256) void k_attn_oproj(AttnArgs a, const uint4* __restrict__ W, const __half* __restrict__ S,
+                                                    const unsigned char* __restrict__ Z, const float* __restrict__ bias, int N, int CS,
+                                                    long long* acc) {
+  constexpr int HD = 128, half = 64, LDR = HD + 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int rep = a.nq / a.nkv;
+  float* qs = (float*)smem;               // [HD]
+  float* knew = qs + HD;                  // [HD]
+  float* vnew = knew + HD;                // [HD]
+  float* wred = vnew + HD;                // [8]
+  float* outh = wred + 8;                 // [HD] head output (rounded), then its int8 planes
+  unsigned* xh = (unsigned*)(outh + HD);  // [32] [32] [32]
+  unsigned* xm = xh + 32;
+  unsigned* xl = xm + 32;
+  int4* gpar = (int4*)(xl + 32);          // [2]
+  float* ored = (float*)(gpar + 2);       // [256][LDR]
+  const int hq = blockIdx.x / CS, cs = blockIdx.x % CS, kvh = hq / rep;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int pos = a.pos[0];
+  const int len = pos + 1, ncache = pos;
+  const KvView& kv = a.kv;
+  const int K = a.nq * HD, G = K >> 7;
+  zero_duty(a.zero_buf, a.zero_n);
+
+  const int t0 = (cs * 4 + wave) * TPW;   // o_proj slab: tiles t0 .. t0+TPW-1 of this wave, k-group == this head
+  // (1) this lane's K/V rows (position p = tid; longer contexts loop below)
+  KvRow<HD, KVDT> kr, vr;
+  const bool own = tid < ncache;
+  if (own) { const size_t ro = kv_row_off(kv, a.layer, kvh, tid); kr.load(kv.k, ro); vr.load(kv.v, ro); }
+
+  // (3) q/k/v finishing (fixed point -> f32, rounding, RoPE), KV append
+  {
+    const float* cr = a.cos_t + (size_t)pos * half;
+    const float* sr = a.sin_t + (size_t)pos * half;
+    if (tid < 2 * half) {
+      const int hh = tid / half, i = tid % half;
+      const int base = hh == 0 ? hq * HD : a.nq * HD + kvh * HD;
+      const int ia = a.interleaved ? 2 * i : i, ib = a.interleaved ? 2 * i + 1 : i + half;
+      const float x0 = vsrc_get(a.qkv, base + ia, a.act), x1 = vsrc_get(a.qkv, base + ib, a.act);
+      const float c = cr[i], s = sr[i];
+      const float y0 = round_act(x0 * c - x1 * s, a.act), y1 = round_act(x1 * c + x0 * s, a.act);
+      if (hh == 0) { qs[ia] = y0; qs[ib] = y1; }
+      else { knew[ia] = y0; knew[ib] = y1; }
+    } else {
+      const int i = tid - 2 * half;
+      vnew[i] = vsrc_get(a.qkv, a.nq * HD + a.nkv * HD + kvh * HD + i, a.act);
+    }
+    __syncthreads();
+    if (hq % rep == 0 && cs == 0) {
+      size_t woff;
+      if (kv.paged) woff = kv_slot_off(kv, a.layer, kvh, kv.slot ? kv.slot[0] : (kv.block_table[pos / kv.bs] * kv.bs + pos % kv.bs));
+      else woff = kv_row_off(kv, a.layer, kvh, pos);
+      if (tid < HD) { kv_st(kv.k, woff + tid, kv.dtype, knew[tid]); kv_st(kv.v, woff + tid, kv.dtype, vnew[tid]); }
+    }
+  }
+
+  // (4) attention: lane == position stream
+  const float scale = 1.0f / sqrtf((float)HD);
+  float m = -INFINITY, l = 0.f;
+  float o[HD];
+#pragma unroll
+  for (int i = 0; i < HD; i++) o[i] = 0.f;
+  for (int p = tid; p < len; p += 256) {
+    if (p != tid || !own) {   // rows not preloaded: later positions of this stream, or the token being appended
+      if (p < ncache) { const size_t ro = kv_row_off(kv, a.layer, kvh, p); kr.load(kv.k, ro); vr.load(kv.v, ro); }
+      else { kr.from_f32(knew); vr.from_f32(vnew); }
+    }
+    float d = 0.f;
+#pragma unroll
+    for (int i = 0; i < HD; i += 4) {
+      const float4 qa = *(const float4*)(qs + i);
+      d += kr.get(i) * qa.x + kr.get(i + 1) * qa.y + kr.get(i + 2) * qa.z + kr.get(i + 3) * qa.w;
+    }
+    const float s = d * scale;
+    if (m == -INFINITY) {
+      m = s; l = 1.f;
+#pragma unroll
+      for (int i = 0; i < HD; i++) o[i] = vr.get(i);
+    } else {
+      const float mn = fmaxf(m, s);
+      const float alpha = expf(m - mn), e = expf(s - mn);
+      l = l * alpha + e;
+      m = mn;
+#pragma unroll
+      for (int i = 0; i < HD; i++) o[i] = o[i] * alpha + e * vr.get(i);
+    }
+  }
+  // (2) the K/V row registers are dead: issue the o_proj slab loads now; they fly during the merge and the quantisation
+  uint4 Wb[TPW][4];
+  float sc[TPW]; int zp[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; t++) {
+    const uint4* wp = W + ((size_t)(t0 + t) * (K >> 5) + hq * 4) * 64 + lane;
+#pragma unroll
+    for (int c = 0; c < 4; c++) Wb[t][c] = ldnt(wp + c * 64);
+    sc[t] = __half2float(S[((size_t)(t0 + t) * G + hq) * 64 + lane]);
+    zp[t] = Z[((size_t)(t0 + t) * G + hq) * 64 + lane];
+  }
+  const float wm = wave_max(m);
+  if (lane == 0) wred[wave] = wm;
+  __syncthreads();
+  const float M = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
+  const float w = (m == -INFINITY) ? 0.f : expf(m - M);
+  const float ws = wave_sum(l * w);
+  if (lane == 0) wred[4 + wave] = ws;
+  const int nrows = min(len, 256);
+  if (tid < nrows) {
+#pragma unroll
+    for (int i = 0; i < HD; i += 4) *(float4*)(ored + tid * LDR + i) = make_float4(o[i] * w, o[i + 1] * w, o[i + 2] * w, o[i + 3] * w);
+  }
+  __syncthreads();
+  const float inv = 1.0f / ((wred[4] + wred[5]) + (wred[6] + wred[7]));
+  {
+    const int col = tid % HD, ph = tid / HD;   // 2 row phases
+    float accv = 0.f;
+    for (int r = ph; r < nrows; r += 2) accv += ored[r * LDR + col];
+    __syncthreads();
+    ored[ph * LDR + col] = accv;
+    __syncthreads();
+    if (tid < HD) outh[tid] = round_act((ored[tid] + ored[LDR + tid]) * inv, a.act);
+  }
+  __syncthreads();
+
+  // (5) head output -> three int8 planes (one group of 128), then the slab GEMV
+  quant_x128(outh, HD, xh, xm, xl, gpar);
+  __syncthreads();
+  const uint4* xh4 = (const uint4*)xh;
+  const uint4* xm4 = (const uint4*)xm;
+  const uint4* xl4 = (const uint4*)xl;
+#pragma unroll
+  for (int t = 0; t < TPW; t++) {
+    float y = 0.f;
+    q4g_consume(Wb[t], 0, xh4, xm4, xl4, gpar, sc[t], zp[t], y);
+    const int n = (t0 + t) * 64 + lane;
+    if (bias != nullptr && hq == 0) y += bias[n];
+    atomicAdd((unsigned long long*)(acc + n), (unsigned long long)f2fix(y));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// attention decode v2 (head_dim 128, 16-bit cache), optionally fused with o_proj.
+//   scores : lane == position; K row stays packed, q is packed f16/bf16 pairs in LDS, V_DOT2_F32_{F16,BF16}: no converts
+//   PV     : the packed V rows go through an LDS image [row][272 B] (conflict-free b128 writes); thread t sums
+//            d-pair (t & 63) over rows = (t >> 6) mod 4 with the softmax weights broadcast from LDS
+//   chunks of 256 positions are merged online (running max / sum / output in the 128 output threads)
+// FUSE: block (head, column slice) multiplies the head output by its slab of Wo (see k_attn_oproj) -- slab loads are
+// issued at kernel entry and stay in flight through the whole attention.
+// ---------------------------------------------------------------------------------------------------------
+typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 b2_t __attribute__((ext_vector_type(2)));
+template <int KVDT>
+__device__ __forceinline__ float dot2acc(unsigned a, unsigned b, float c) {
+  if (KVDT == BZ_F16) return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2_t, a), __builtin_bit_cast(h2_t, b), c, false);
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b2_t, a), __builtin_bit_cast(b2_t, b), c, false);
+}
+template <int KVDT>
+__device__ __forceinline__ unsigned pack2(float x0, float x1) {
+  if (KVDT == BZ_F16) return (unsigned)__half_as_ushort(__float2half_rn(x0)) | ((unsigned)__half_as_ushort(__float2half_rn(x1)) << 16);
+  return (__float_as_uint(bf16_round(x0)) >> 16) | (__float_as_uint(bf16_round(x1)) & 0xffff0000u);
+}
+template <int KVDT>
+__device__ __forceinline__ void unpack2(unsigned u, float& x0, float& x1) {
+  if (KVDT == BZ_F16) { x0 = __half2float(__ushort_as_half((unsigned short)(u & 0xffffu))); x1 = __half2float(__ushort_as_half((unsigned short)(u >> 16))); }
+  else { x0 = __uint_as_float(u << 16); x1 = __uint_as_float(u & 0xffff0000u); }
+}
+
+template <int KVDT, int FUSE, int TPW>
+__global__ __launch_bounds__(256) void k_attn2(AttnArgs a, const uint4* __restrict__ W, const __half* __restrict__ S,
+                                               const unsigned char* __restrict__ Z, const float* __restrict__ bias, int CS, long long* acc) {
+  // Mapping: a chunk is 256 positions, wave w owns positions c0 + 64 w .. +63.  One wave-wide 16-byte load fetches 4 whole
+  // rows (1 KiB contiguous in the contiguous cache): lane l holds piece (l & 15) = elements 8*(l&15)..+7 of row 4 i + (l >> 4)
+  // for load i = 0..15.  A row's score is a 4-DOT2 partial per lane reduced over its 16 lanes -- and lands exactly in the
+  // lanes that hold that row's V pieces, so P.V accumulates in registers (8 outputs per lane) with no LDS image.
+  constexpr int HD = 128, half = 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned* q2 = (unsigned*)smem;             // [64] packed q pairs
+  unsigned* k2 = q2 + 64;                     // [64] packed new key
+  unsigned* v2 = k2 + 64;                     // [64] packed new value
+  float* wred = (float*)(v2 + 64);            // [8]
+  float* pout = wred + 8;                     // [4][128] PV partials of the 4 waves
+  float* outh = pout + 512;                   // [128] head output (FUSE)
+  unsigned* xh = (unsigned*)(outh + 128);     // [32] x3
+  unsigned* xm = xh + 32;
+  unsigned* xl = xm + 32;
+  int4* gpar = (int4*)(xl + 32);              // [2]
+  const int rep = a.nq / a.nkv;
+  const int hq = FUSE ? blockIdx.x / CS : blockIdx.x, cs = FUSE ? blockIdx.x % CS : 0, kvh = hq / rep;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int piece = lane & 15, rsub = lane >> 4;
+#define STAMP(i) do { if (a.stamps && blockIdx.x == 0 && tid == 0) a.stamps[i] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+  STAMP(0);
+  const int pos = a.pos[0];
+  const int len = a.q_only ? pos : pos + 1, ncache = pos;
+  const KvView& kv = a.kv;
+  zero_duty(a.zero_buf, a.zero_n);
+
+  // (1) first chunk's K/V rows: 32 coalesced loads per wave, issued before anything else
+  uint4 kr[16], vr[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    const int p = wave * 64 + 4 * i + rsub;
+    kr[i] = make_uint4(0, 0, 0, 0); vr[i] = make_uint4(0, 0, 0, 0);
+    if (p < ncache) {
+      const size_t ro = kv_row_off(kv, a.layer, kvh, p) + piece * 8;
+      kr[i] = *(const uint4*)((const unsigned short*)kv.k + ro);
+      vr[i] = *(const uint4*)((const unsigned short*)kv.v + ro);
+    }
+  }
+  // (0) o_proj slab of this wave (FUSE): in flight through the whole attention
+  uint4 Wb[FUSE ? TPW : 1][4];
+  const int t0 = (cs * 4 + wave) * TPW;
+  if (FUSE) {
+    const int K = a.nq * HD;
+#pragma unroll
+    for (int t = 0; t < TPW; t++) {
+      const uint4* wp = W + ((size_t)(t0 + t) * (K >> 5) + hq * 4) * 64 + lane;
+#pragma unroll
+      for (int c = 0; c < 4; c++) Wb[t][c] = ldnt(wp + c * 64);
+    }
+  }
+  STAMP(1);
+  // (2) q/k/v finishing: fixed point -> f32, rounding, RoPE; packed q / new key / new value to LDS; KV append
+  if (!a.q_only) {
+    const float* cr = a.cos_t + (size_t)pos * half;
+    const float* sr = a.sin_t + (size_t)pos * half;
+    if (tid < 2 * half) {
+      const int hh = tid / half, i = tid % half;
+      const int base = hh == 0 ? hq * HD : a.nq * HD + kvh * HD;
+      const int ia = a.interleaved ? 2 * i : i, ib = a.interleaved ? 2 * i + 1 : i + half;
+      const float x0 = vsrc_get(a.qkv, base + ia, a.act), x1 = vsrc_get(a.qkv, base + ib, a.act);
+      const float c = cr[i], s = sr[i];
+      const float y0 = round_act(x0 * c - x1 * s, a.act), y1 = round_act(x1 * c + x0 * s, a.act);
+      unsigned short* dst = (unsigned short*)(hh == 0 ? q2 : k2);
+      const unsigned p0 = pack2<KVDT>(y0, y1);
+      dst[ia] = (unsigned short)(p0 & 0xffffu);
+      dst[ib] = (unsigned short)(p0 >> 16);
+    } else if (tid < 2 * half + 64) {
+      const int j = tid - 2 * half;
+      const int vb = a.nq * HD + a.nkv * HD + kvh * HD;
+      v2[j] = pack2<KVDT>(vsrc_get(a.qkv, vb + 2 * j, a.act), vsrc_get(a.qkv, vb + 2 * j + 1, a.act));
+    }
+    __syncthreads();
+    if (hq % rep == 0 && cs == 0 && tid < 64) {   // KV append, once per kv head: 64 threads x 4-byte pairs
+      size_t woff;
+      if (kv.paged) woff = kv_slot_off(kv, a.layer, kvh, kv.slot ? kv.slot[0] : (kv.block_table[pos / kv.bs] * kv.bs + pos % kv.bs));
+      else woff = kv_row_off(kv, a.layer, kvh, pos);
+      ((unsigned*)((unsigned short*)kv.k + woff))[tid] = k2[tid];
+      ((unsigned*)((unsigned short*)kv.v + woff))[tid] = v2[tid];
+    }
+  } else {
+    if (tid < 64) q2[tid] = pack2<KVDT>(((const float*)a.qkv.p)[hq * HD + 2 * tid], ((const float*)a.qkv.p)[hq * HD + 2 * tid + 1]);
+    __syncthreads();
+  }
+  STAMP(2);
+
+  const float scale = 1.0f / sqrtf((float)HD);
+  const uint4 qq = ((const uint4*)q2)[piece];
+  float Mrun = -INFINITY, Lrun = 0.f, Orun = 0.f;   // running state (threads < 128 own output d = tid)
+  for (int c0 = 0; c0 < len; c0 += 256) {
+    if (c0 > 0) {
+      __syncthreads();   // the previous chunk's pout / wred reads are done
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const int p = c0 + wave * 64 + 4 * i + rsub;
+        kr[i] = make_uint4(0, 0, 0, 0); vr[i] = make_uint4(0, 0, 0, 0);
+        if (p < ncache) {
+          const size_t ro = kv_row_off(kv, a.layer, kvh, p) + piece * 8;
+          kr[i] = *(const uint4*)((const unsigned short*)kv.k + ro);
+          vr[i] = *(const uint4*)((const unsigned short*)kv.v + ro);
+        }
+      }
+    }
+    // the token being appended (position pos == ncache) comes from LDS
+    float sc_[16];
+    float mloc = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int p = c0 + wave * 64 + 4 * i + rsub;
+      uint4 kk = kr[i];
+      if (!a.q_only && p == pos) { kk = ((const uint4*)k2)[piece]; vr[i] = ((const uint4*)v2)[piece]; }
+      float d = dot2acc<KVDT>(kk.x, qq.x, 0.f);
+      d = dot2acc<KVDT>(kk.y, qq.y, d); d = dot2acc<KVDT>(kk.z, qq.z, d); d = dot2acc<KVDT>(kk.w, qq.w, d);
+      d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64); d += __shfl_xor(d, 8, 64);
+      sc_[i] = (p < len) ? d * scale : -INFINITY;
+      mloc = fmaxf(mloc, sc_[i]);
+    }
+    STAMP(3);
+    const float wm = wave_max(mloc);
+    if (lane == 0) wred[wave] = wm;
+    __syncthreads();
+    const float Mc = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
+    float accv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float lsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const float e = (sc_[i] == -INFINITY) ? 0.f : expf(sc_[i] - Mc);
+      lsum += e;
+      float v[8];
+      unpack2<KVDT>(vr[i].x, v[0], v[1]); unpack2<KVDT>(vr[i].y, v[2], v[3]);
+      unpack2<KVDT>(vr[i].z, v[4], v[5]); unpack2<KVDT>(vr[i].w, v[6], v[7]);
+#pragma unroll
+      for (int q = 0; q < 8; q++) accv[q] = fmaf(e, v[q], accv[q]);
+    }
+    // rows of the wave: the 4 lane groups hold different rows -> reduce over xor 16, 32 (the 16 lanes of a group are replicas for lsum)
+    lsum += __shfl_xor(lsum, 16, 64); lsum += __shfl_xor(lsum, 32, 64);
+#pragma unroll
+    for (int q = 0; q < 8; q++) { accv[q] += __shfl_xor(accv[q], 16, 64); accv[q] += __shfl_xor(accv[q], 32, 64); }
+    STAMP(4);
+    if (lane < 16) {
+      *(float4*)(pout + wave * 128 + piece * 8) = make_float4(accv[0], accv[1], accv[2], accv[3]);
+      *(float4*)(pout + wave * 128 + piece * 8 + 4) = make_float4(accv[4], accv[5], accv[6], accv[7]);
+    }
+    if (lane == 0) wred[4 + wave] = lsum;
+    __syncthreads();
+    STAMP(5);
+    if (tid < 128) {
+      const float oc = (pout[tid] + pout[128 + tid]) + (pout[256 + tid] + pout[384 + tid]);
+      const float Lc = (wred[4] + wred[5]) + (wred[6] + wred[7]);
+      const float Mn = fmaxf(Mrun, Mc);
+      const float fa = (Mrun == -INFINITY) ? 0.f : expf(Mrun - Mn), fb = expf(Mc - Mn);
+      Orun = Orun * fa + oc * fb;
+      Lrun = Lrun * fa + Lc * fb;
+      Mrun = Mn;
+    }
+  }
+  if (!FUSE) {
+    if (tid < 128) a.out[(size_t)hq * HD + tid] = round_act(Orun / Lrun, a.act);
+    return;
+  }
+  if (tid < 128) outh[tid] = round_act(Orun / Lrun, a.act);
+  // slab scales / zero points (L2-resident, tiny): fetched now, used after the quantisation
+  float sc[FUSE ? TPW : 1]; int zp[FUSE ? TPW : 1];
+  {
+    const int G = (a.nq * HD) >> 7;
+#pragma unroll
+    for (int t = 0; t < (FUSE ? TPW : 1); t++) {
+      sc[t] = __half2float(S[((size_t)(t0 + t) * G + hq) * 64 + lane]);
+      zp[t] = Z[((size_t)(t0 + t) * G + hq) * 64 + lane];
+    }
+  }
+  __syncthreads();
+  STAMP(6);
+  quant_x128(outh, HD, xh, xm, xl, gpar);
+  __syncthreads();
+  STAMP(7);
+  const uint4* xh4 = (const uint4*)xh;
+  const uint4* xm4 = (const uint4*)xm;
+  const uint4* xl4 = (const uint4*)xl;
+#pragma unroll
+  for (int t = 0; t < (FUSE ? TPW : 1); t++) {
+    float y = 0.f;
+    q4g_consume(Wb[t], 0, xh4, xm4, xl4, gpar, sc[t], zp[t], y);
+    const int n = (t0 + t) * 64 + lane;
+    if (bias != nullptr && hq == 0) y += bias[n];
+    atomicAdd((unsigned long long*)(acc + n), (unsigned long long)f2fix(y));
+  }
+  STAMP(8);
+#undef STAMP
+}
+
+static size_t attn2_smem() { return (size_t)(64 * 3 + 8 + 512 + 128 + 96 + 8) * 4; }
+
+// picks the column-slice count so that nq * CS ~ 256 workgroups; returns 0 when the fused form does not apply
+int bzk_attn_oproj_slices(const AttnArgs& a, const LinearDev& L) {
+  if (a.hd != 128 || L.kind != LK_Q4G || L.perm != nullptr || L.K != a.nq * 128 || a.q_only) return 0;
+  const int NT = L.N / 64;
+  for (int cs = 8; cs >= 1; cs >>= 1) {
+    if (NT % (cs * 4) == 0 && NT / (cs * 4) <= 2 && a.nq * cs <= 1024) return cs;
+  }
+  return 0;
+}
+
+int bzk_attn_oproj(hipStream_t s, const AttnArgs& a, const LinearDev& L, long long* acc) {
+  const int CS = bzk_attn_oproj_slices(a, L);
+  if (CS <= 0) BZ_FAIL(BZ_E_INVALID, "attn+o_proj fusion does not apply to this shape");
+  const int TPW = (L.N / 64) / (CS * 4);
+  const size_t smem = (size_t)(3 * 128 + 8 + 128 + 96 + 8 + 256 * 132) * 4;
+#define LAUNCH_AO(DT, T) BZ_LAUNCH("attn+o_proj", L.algo_bytes, (k_attn2<DT, 1, T>), dim3(a.nq * CS), dim3(256), attn2_smem(), s, a, (const uint4*)L.w, \
+    (const __half*)L.scales, (const unsigned char*)L.zeros, L.bias, CS, acc)
+#define LAUNCH_AO_T(DT) do { if (TPW == 1) LAUNCH_AO(DT, 1); else LAUNCH_AO(DT, 2); } while (0)
+  if (a.kv.dtype == BZ_F16) LAUNCH_AO_T(BZ_F16);
+  else if (a.kv.dtype == BZ_BF16) LAUNCH_AO_T(BZ_BF16);
+  else BZ_FAIL(BZ_E_UNSUPPORTED, "attn+o_proj fusion: f32 KV cache not built");
+#undef LAUNCH_AO_T
+#undef LAUNCH_AO
+  BZ_HIP(hipGetLastError());
+  return BZ_OK;
+}
+
 int bzk_attn_decode(hipStream_t s, const AttnArgs& a) {
   const size_t smem = (size_t)(3 * a.hd + 8 + 256 * (a.hd + 4)) * 4;
 #define LAUNCH_ATT(HD, DT) BZ_LAUNCH("attn_decode", 0.0, (k_attn_decode<HD, DT>), dim3(a.nq), dim3(256), smem, s, a)
 #define LAUNCH_ATT_DT(HD) do { if (a.kv.dtype == BZ_F16) LAUNCH_ATT(HD, BZ_F16); else if (a.kv.dtype == BZ_BF16) LAUNCH_ATT(HD, BZ_BF16); \
                                else LAUNCH_ATT(HD, BZ_F32); } while (0)
-  if (a.hd == 64) LAUNCH_ATT_DT(64);
+  if (a.hd == 128 && a.kv.dtype != BZ_F32) {
+    if (a.kv.dtype == BZ_F16) BZ_LAUNCH("attn_decode", 0.0, (k_attn2<BZ_F16, 0, 1>), dim3(a.nq), dim3(256), attn2_smem(), s, a, (const uint4*)nullptr,
+                                        (const __half*)nullptr, (const unsigned char*)nullptr, (const float*)nullptr, 1, (long long*)nullptr);
+    else BZ_LAUNCH("attn_decode", 0.0, (k_attn2<BZ_BF16, 0, 1>), dim3(a.nq), dim3(256), attn2_smem(), s, a, (const uint4*)nullptr,
+                   (const __half*)nullptr, (const unsigned char*)nullptr, (const float*)nullptr, 1, (long long*)nullptr);
+  }
+  else if (a.hd == 64) LAUNCH_ATT_DT(64);
   else if (a.hd == 128) LAUNCH_ATT_DT(128);
   else BZ_FAIL(BZ_E_UNSUPPORTED, "head_dim %d unsupported (64 and 128 are built)", a.hd);
 #undef LAUNCH_ATT_DT
