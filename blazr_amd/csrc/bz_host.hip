@@ -888,6 +888,17 @@ static int llama_step(bz_model* m, const StepIO& io) {
 
     Pro pf{}; pf.mode = PRO_NORM; pf.src = ov; pf.h_in = m->hbuf[cur]; pf.h_out = m->hbuf[cur ^ 1]; pf.norm_w = Ld.ffn_norm;
     pf.eps = c.rms_eps; pf.H = H; pf.act = act;
+    static long long* mlp_stamps = nullptr;
+    if (getenv("BZ_MLP_STAMPS")) {
+      if (!mlp_stamps) { hipMalloc(&mlp_stamps, 256); hipMemset(mlp_stamps, 0, 256); }
+      if (l == 1) {
+        long long hst[16]; hipStreamSynchronize(st); hipMemcpy(hst, mlp_stamps, 128, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[bz] mlp stamps (us since entry):");
+        for (int q = 1; q <= 6; q++) fprintf(stderr, " %d:%.2f", q, (hst[q] - hst[0]) / 100.0);
+        fprintf(stderr, "\n");
+      }
+      pf.stamps = l == 0 ? mlp_stamps : nullptr;
+    }
     VSrc dn;
     static const bool no_mlp_fuse = getenv("BZ_NO_MLP_FUSION") != nullptr;
     if (!no_mlp_fuse && Ld.gateup.parts.size() == 1 && Ld.down.parts.size() == 1 && bzk_mlp_fusable(Ld.gateup.parts[0], Ld.down.parts[0], H, I)) {

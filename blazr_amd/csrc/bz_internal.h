@@ -37,6 +37,7 @@ struct Pro {
   int H;               // NORM: == K ; SILU: I
   int act;             // activation dtype for rounding (BZ_F32/F16/BF16)
   const int* perm;     // optional: x'[k] = x[perm[k]] (GPTQ act-order)
+  long long* stamps;   // diagnostic only (BZ_MLP_STAMPS): s_memrealtime at phase boundaries of block 0
   int dbg;             // tuning only (bz_tune_gemv): 1 = store instead of atomics, 2 = skip the dot4 work, 4 = skip quantisation
 };
 

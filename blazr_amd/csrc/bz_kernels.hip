@@ -196,49 +196,69 @@ __device__ __forceinline__ float vget(const void* p, int i, int act) {
   return ((const float*)p)[i];
 }
 
-template <int MODE, int MAXJ, int E>
+// raw value as loaded (f32, or the 64-bit fixed-point accumulator); converted only in xfinish so that the loads of the
+// whole prologue are issued back to back (a conversion right after its load makes hipcc wait vmcnt(0) per element)
+template <int FIX> struct RawT { typedef float T; };
+template <> struct RawT<1> { typedef long long T; };
+template <int FIX>
+__device__ __forceinline__ typename RawT<FIX>::T vraw(const void* p, int i) {
+  if (FIX) return (typename RawT<FIX>::T)((const long long*)p)[i];
+  return (typename RawT<FIX>::T)((const float*)p)[i];
+}
+template <int FIX>
+__device__ __forceinline__ float vcvt(typename RawT<FIX>::T r, int act) {
+  if (FIX) return round_act(fix2f((long long)r), act);
+  return (float)r;
+}
+
+template <int MODE, int FIX, int MAXJ, int E>
 struct XRegs {
+  typedef typename RawT<FIX>::T R;
   float4 h[MODE == PRO_NORM ? MAXJ : 1];     // NORM: full-H pass, element i = j*1024 + tid*4
-  float pf[MODE == PRO_NORM ? MAXJ : 1][4];  // NORM: prev as f32 (converted at load)
-  float sa[E];                               // slice element e: NORM h / PLAIN x / SILU gate
-  float sb[MODE == PRO_PLAIN ? 1 : E];       // NORM prev / SILU up
+  R pf[MODE == PRO_NORM ? MAXJ : 1][4];      // NORM: deferred residual (raw)
+  float sa_f[MODE == PRO_NORM ? E : 1];      // NORM: h of the slice
+  R sa[MODE == PRO_NORM ? 1 : E];            // PLAIN x / SILU gate (raw)
+  R sb[MODE == PRO_PLAIN ? 1 : E];           // NORM prev / SILU up (raw)
   float sw[MODE == PRO_NORM ? E : 1];        // NORM weight
 };
 
 template <int MODE, int FIX, int MAXJ, int E>
-__device__ __forceinline__ void xload(const Pro& p, int k0, int KR, XRegs<MODE, MAXJ, E>& r) {
+__device__ __forceinline__ void xload(const Pro& p, int k0, int KR, XRegs<MODE, FIX, MAXJ, E>& r) {
+  // NOTE: every load is unconditional at a clamped (always valid) index.  `cond ? load : 0` makes hipcc branch around
+  // the load and wait vmcnt(0) after it, which serialises the whole prologue (and everything issued before it).
   const int tid = threadIdx.x;
   const bool hasprev = p.src.p != nullptr;
+  const void* prevp = hasprev ? p.src.p : (const void*)p.h_in;   // any valid address when there is no residual
   if (MODE == PRO_NORM) {
 #pragma unroll
     for (int j = 0; j < MAXJ; j++) {
-      const int i = j * 1024 + tid * 4;
-      const bool on = i < p.H;
-      r.h[j] = on ? *(const float4*)(p.h_in + i) : make_float4(0, 0, 0, 0);
+      int i = j * 1024 + tid * 4;
+      i = i < p.H ? i : 0;
+      r.h[j] = *(const float4*)(p.h_in + i);
 #pragma unroll
-      for (int e = 0; e < 4; e++) r.pf[j][e] = (on && hasprev) ? vget<FIX>(p.src.p, i + e, p.act) : 0.f;
+      for (int e = 0; e < 4; e++) r.pf[j][e] = vraw<FIX>(prevp, (FIX || hasprev) ? i + e : 0);
     }
   }
 #pragma unroll
   for (int e = 0; e < E; e++) {
-    const int i = e * 256 + tid;
-    const bool on = i < KR;
-    const int kk = on ? (p.perm ? p.perm[k0 + i] : (k0 + i)) : 0;
+    int i = e * 256 + tid;
+    i = i < KR ? i : 0;
+    const int kk = p.perm ? p.perm[k0 + i] : (k0 + i);
     if (MODE == PRO_NORM) {
-      r.sa[e] = on ? p.h_in[kk] : 0.f;
-      r.sb[e] = (on && hasprev) ? vget<FIX>(p.src.p, kk, p.act) : 0.f;
-      r.sw[e] = on ? p.norm_w[kk] : 0.f;
+      r.sa_f[e] = p.h_in[kk];
+      r.sb[e] = vraw<FIX>(prevp, kk);
+      r.sw[e] = p.norm_w[kk];
     } else if (MODE == PRO_SILU) {
-      r.sa[e] = on ? vget<FIX>(p.src.p, kk, p.act) : 0.f;
-      r.sb[e] = on ? vget<FIX>(p.src.p, p.H + kk, p.act) : 0.f;
+      r.sa[e] = vraw<FIX>(p.src.p, kk);
+      r.sb[e] = vraw<FIX>(p.src.p, p.H + kk);
     } else {
-      r.sa[e] = on ? vget<FIX>(p.src.p, kk, p.act) : 0.f;
+      r.sa[e] = vraw<FIX>(p.src.p, kk);
     }
   }
 }
 
-template <int MODE, int MAXJ, int E>
-__device__ __forceinline__ void xfinish(const Pro& p, int KR, const XRegs<MODE, MAXJ, E>& r, float* xs, float* red, bool writer) {
+template <int MODE, int FIX, int MAXJ, int E>
+__device__ __forceinline__ void xfinish(const Pro& p, int KR, const XRegs<MODE, FIX, MAXJ, E>& r, float* xs, float* red, bool writer) {
   const int tid = threadIdx.x;
   const bool hasprev = p.src.p != nullptr;
   if (MODE == PRO_NORM) {
@@ -249,7 +269,7 @@ __device__ __forceinline__ void xfinish(const Pro& p, int KR, const XRegs<MODE, 
       float v[4] = {r.h[j].x, r.h[j].y, r.h[j].z, r.h[j].w};
       if (hasprev) {
 #pragma unroll
-        for (int e = 0; e < 4; e++) v[e] = round_act(v[e] + r.pf[j][e], p.act);
+        for (int e = 0; e < 4; e++) v[e] = round_act(v[e] + vcvt<FIX>(r.pf[j][e], p.act), p.act);
       }
       if (i < p.H) {
         ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
@@ -261,8 +281,8 @@ __device__ __forceinline__ void xfinish(const Pro& p, int KR, const XRegs<MODE, 
 #pragma unroll
     for (int e = 0; e < E; e++) {
       const int i = e * 256 + tid;
-      float v = r.sa[e];
-      if (hasprev) v = round_act(v + r.sb[e], p.act);
+      float v = r.sa_f[e];
+      if (hasprev) v = round_act(v + vcvt<FIX>(r.sb[e], p.act), p.act);
       v = round_act(r.sw[e] * round_act(v * rs, p.act), p.act);
       if (i < KR) xs[i] = v;
     }
@@ -270,8 +290,8 @@ __device__ __forceinline__ void xfinish(const Pro& p, int KR, const XRegs<MODE, 
 #pragma unroll
     for (int e = 0; e < E; e++) {
       const int i = e * 256 + tid;
-      float v = r.sa[e];
-      if (MODE == PRO_SILU) v = round_act(round_act(silu_f(v), p.act) * r.sb[e], p.act);
+      float v = vcvt<FIX>(r.sa[e], p.act);
+      if (MODE == PRO_SILU) v = round_act(round_act(silu_f(v), p.act) * vcvt<FIX>(r.sb[e], p.act), p.act);
       if (i < KR) xs[i] = v;
     }
   }
@@ -487,20 +507,24 @@ __global__ __launch_bounds__(512) void k_mlp_q4g(const uint4* __restrict__ Wgu, 
   const int GD = I >> 7, gd = sl >> 1;        // down's quantisation group of these 64 k
   zero_duty(zero_buf, zero_n);
 
-  // (1) prologue loads: full-H pass, 4 contiguous elements per thread per 2048
+  // (1) prologue loads: full-H pass, 4 contiguous elements per thread per 2048 (h, deferred residual, norm weight) --
+  //     loads only, unconditional (H == 2048 * NJ), arithmetic after the weight loads have been issued
+  constexpr int NJ = GPW / 2 > 0 ? GPW / 2 : 1;
   const bool hasprev = pro.src.p != nullptr;
-  float hv[GPW / 2 > 0 ? GPW / 2 : 1][4];     // H == 1024 * GPW == 2048 * (GPW / 2)
+  const void* prevp = hasprev ? pro.src.p : (const void*)pro.h_in;
+  float hv[NJ][4];
+  typename RawT<FIX>::T pv[NJ][4];
+  float4 nw[NJ];
 #pragma unroll
-  for (int j = 0; j < (GPW / 2 > 0 ? GPW / 2 : 1); j++) {
+  for (int j = 0; j < NJ; j++) {
     const int i = j * 2048 + tid * 4;
-    const bool on = i < H;
-    const float4 h4 = on ? *(const float4*)(pro.h_in + i) : make_float4(0, 0, 0, 0);
+    const float4 h4 = *(const float4*)(pro.h_in + i);
     hv[j][0] = h4.x; hv[j][1] = h4.y; hv[j][2] = h4.z; hv[j][3] = h4.w;
-    if (hasprev) {
 #pragma unroll
-      for (int e = 0; e < 4; e++) { const float pv = on ? vget<FIX>(pro.src.p, i + e, pro.act) : 0.f; hv[j][e] = round_act(hv[j][e] + pv, pro.act); }
-    }
+    for (int e = 0; e < 4; e++) pv[j][e] = vraw<FIX>(prevp, (FIX || hasprev) ? i + e : 0);
+    nw[j] = *(const float4*)(pro.norm_w + i);
   }
+  __builtin_amdgcn_sched_barrier(0);   // keep the prologue's loads AHEAD of the weight stream (vmcnt is in-order)
   // (2) all gate + up loads of this wave's k-range up front: 256 KB per block in flight while the norm prologue computes
   const uint4* wg = Wgu + ((size_t)sl * (H >> 5) + gbeg * 4) * 64 + lane;
   const uint4* wu = Wgu + ((size_t)(NTI + sl) * (H >> 5) + gbeg * 4) * 64 + lane;
@@ -519,12 +543,14 @@ __global__ __launch_bounds__(512) void k_mlp_q4g(const uint4* __restrict__ Wgu, 
   // (3) finish the norm
   float ss = 0.f;
 #pragma unroll
-  for (int j = 0; j < (GPW / 2 > 0 ? GPW / 2 : 1); j++) {
+  for (int j = 0; j < NJ; j++) {
     const int i = j * 2048 + tid * 4;
-    if (i < H) {
-      ss += hv[j][0] * hv[j][0] + hv[j][1] * hv[j][1] + hv[j][2] * hv[j][2] + hv[j][3] * hv[j][3];
-      if (blockIdx.x == 0 && pro.h_out) *(float4*)(pro.h_out + i) = make_float4(hv[j][0], hv[j][1], hv[j][2], hv[j][3]);
+    if (hasprev) {
+#pragma unroll
+      for (int e = 0; e < 4; e++) hv[j][e] = round_act(hv[j][e] + vcvt<FIX>(pv[j][e], pro.act), pro.act);
     }
+    ss += hv[j][0] * hv[j][0] + hv[j][1] * hv[j][1] + hv[j][2] * hv[j][2] + hv[j][3] * hv[j][3];
+    if (blockIdx.x == 0 && pro.h_out) *(float4*)(pro.h_out + i) = make_float4(hv[j][0], hv[j][1], hv[j][2], hv[j][3]);
   }
   ss = wave_sum(ss);
   if (lane == 0) red[wave] = ss;
@@ -532,13 +558,10 @@ __global__ __launch_bounds__(512) void k_mlp_q4g(const uint4* __restrict__ Wgu, 
   ss = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
   const float rs = 1.0f / sqrtf(ss / (float)H + pro.eps);
 #pragma unroll
-  for (int j = 0; j < (GPW / 2 > 0 ? GPW / 2 : 1); j++) {
+  for (int j = 0; j < NJ; j++) {
     const int i = j * 2048 + tid * 4;
-    if (i < H) {
-      const float4 w4 = *(const float4*)(pro.norm_w + i);
-      *(float4*)(xs + i) = make_float4(round_act(w4.x * round_act(hv[j][0] * rs, pro.act), pro.act), round_act(w4.y * round_act(hv[j][1] * rs, pro.act), pro.act),
-                                       round_act(w4.z * round_act(hv[j][2] * rs, pro.act), pro.act), round_act(w4.w * round_act(hv[j][3] * rs, pro.act), pro.act));
-    }
+    *(float4*)(xs + i) = make_float4(round_act(nw[j].x * round_act(hv[j][0] * rs, pro.act), pro.act), round_act(nw[j].y * round_act(hv[j][1] * rs, pro.act), pro.act),
+                                     round_act(nw[j].z * round_act(hv[j][2] * rs, pro.act), pro.act), round_act(nw[j].w * round_act(hv[j][3] * rs, pro.act), pro.act));
   }
   __syncthreads();
   quant_x128(xs, H, xh, xm, xl, gpar);
@@ -645,31 +668,34 @@ __global__ __launch_bounds__(256) void k_gemv_q4g(const uint4* __restrict__ W, c
   zero_duty(zero_buf, zero_n);
 
   // (1) group scales / zero points of this wave's tile: GW*128 B + GW*64 B, contiguous -> wide loads now, LDS later
+  const int ntc = wave_on ? nt : 0;          // clamped tile for addressing: loads are unconditional (see xload)
   unsigned sreg[8], zreg[4];
   {
-    const unsigned* Sg = (const unsigned*)(S + ((size_t)nt * G + g0) * 64);
-    const unsigned* Zg = (const unsigned*)(Z + ((size_t)nt * G + g0) * 64);
+    const unsigned* Sg = (const unsigned*)(S + ((size_t)ntc * G + g0) * 64);
+    const unsigned* Zg = (const unsigned*)(Z + ((size_t)ntc * G + g0) * 64);
 #pragma unroll
-    for (int j = 0; j < 8; j++) sreg[j] = (wave_on && lane + 64 * j < GW * 32) ? Sg[lane + 64 * j] : 0u;
+    for (int j = 0; j < 8; j++) sreg[j] = Sg[min(lane + 64 * j, GW * 32 - 1)];
 #pragma unroll
-    for (int j = 0; j < 4; j++) zreg[j] = (wave_on && lane + 64 * j < GW * 16) ? Zg[lane + 64 * j] : 0u;
+    for (int j = 0; j < 4; j++) zreg[j] = Zg[min(lane + 64 * j, GW * 16 - 1)];
   }
 
   // (2) issue the prologue's loads (L2-resident data)
-  XRegs<MODE, MAXJ, Q4G_E> xr;
+  XRegs<MODE, FIX, MAXJ, Q4G_E> xr;
   xload<MODE, FIX, MAXJ, Q4G_E>(pro, k0, KR, xr);
+  __builtin_amdgcn_sched_barrier(0);   // keep the prologue's loads AHEAD of the weight stream (vmcnt is in-order)
 
   // (3) issue the first NPF groups of weight loads (HBM): they fly while the prologue computes
-  const uint4* wp = W + ((size_t)nt * (K >> 5) + (k0 >> 5)) * 64 + lane;
+  const uint4* wp = W + ((size_t)ntc * (K >> 5) + (k0 >> 5)) * 64 + lane;
   uint4 Wb[NPF][4];
 #pragma unroll
   for (int b = 0; b < NPF; b++) {
+    const int bc = min(b, GW - 1);           // NPF <= GW by construction of the launcher; clamp keeps the address valid anyway
 #pragma unroll
-    for (int c = 0; c < 4; c++) Wb[b][c] = (wave_on && b < GW) ? ldnt(wp + (b * 4 + c) * 64) : make_uint4(0, 0, 0, 0);
+    for (int c = 0; c < 4; c++) Wb[b][c] = ldnt(wp + (bc * 4 + c) * 64);
   }
 
   // (4) finish the prologue
-  xfinish<MODE, MAXJ, Q4G_E>(pro, KR, xr, xs, red, blockIdx.x == 0);
+  xfinish<MODE, FIX, MAXJ, Q4G_E>(pro, KR, xr, xs, red, blockIdx.x == 0);
   {
     unsigned* sSw = (unsigned*)(sS + wave * GW * 64);
     unsigned* sZw = (unsigned*)(sZ + wave * GW * 64);
@@ -768,7 +794,7 @@ __global__ __launch_bounds__(256) void k_gemv_rows(const void* __restrict__ W, c
       const bool kon = k < K;
       float w[4][8];
 #pragma unroll
-      for (int rr = 0; rr < 4; rr++) load8<WDT>(W, (size_t)(r + rr) * K + k, kon && (r + rr < rend), w[rr]);
+      for (int rr = 0; rr < 4; rr++) load8<WDT>(W, (size_t)min(r + rr, N - 1) * K + (kon ? k : 0), true, w[rr]);   // xs is 0 beyond K
       const float4 xa = xs4[kc * 128 + lane], xb = xs4[kc * 128 + 64 + lane];
 #pragma unroll
       for (int rr = 0; rr < 4; rr++) {
@@ -819,7 +845,8 @@ int bzk_gemv(hipStream_t s, const LinearDev& L, const Pro& pro, const GemvOut& o
 #define LAUNCH_Q4G(MODE, FIX, MJ, NPF) BZ_LAUNCH(MODE == PRO_NORM ? "gemv_q4g<norm>" : (MODE == PRO_SILU ? "gemv_q4g<silu>" : "gemv_q4g<plain>"), \
     L.algo_bytes, (k_gemv_q4g<MODE, FIX, MJ, NPF>), dim3(grid), dim3(256), smem, s, (const uint4*)L.w,                      \
     (const __half*)L.scales, (const unsigned char*)L.zeros, L.bias, L.N, L.K, GW, nst, pro, out.acc, out.zero_buf, out.zero_n)
-#define LAUNCH_Q4G_N(MODE, FIX, MJ) do { if (L.npf >= 4) LAUNCH_Q4G(MODE, FIX, MJ, 4); else LAUNCH_Q4G(MODE, FIX, MJ, 2); } while (0)
+#define LAUNCH_Q4G_N(MODE, FIX, MJ) do { if (GW == 1) LAUNCH_Q4G(MODE, FIX, MJ, 1); else if (L.npf >= 4 && GW >= 4) LAUNCH_Q4G(MODE, FIX, MJ, 4); \
+                                          else LAUNCH_Q4G(MODE, FIX, MJ, 2); } while (0)
 #define LAUNCH_Q4G_F(MODE, MJ) do { if (pro.src.fix) LAUNCH_Q4G_N(MODE, 1, MJ); else LAUNCH_Q4G_N(MODE, 0, MJ); } while (0)
     if (pro.mode == PRO_PLAIN) LAUNCH_Q4G_F(PRO_PLAIN, 1);
     else if (pro.mode == PRO_SILU) LAUNCH_Q4G_F(PRO_SILU, 1);
@@ -1430,17 +1457,34 @@ __global__ __launch_bounds__(256) void k_attn2(AttnArgs a, const uint4* __restri
   const KvView& kv = a.kv;
   zero_duty(a.zero_buf, a.zero_n);
 
-  // (1) first chunk's K/V rows: 32 coalesced loads per wave, issued before anything else
+  // (0a) the q/k/v finishing's own loads first (vmcnt is in-order: what is issued first returns first)
+  float px0 = 0.f, px1 = 0.f, pc = 0.f, ps = 0.f;
+  if (!a.q_only) {
+    if (tid < 2 * half) {
+      const int hh = tid / half, i = tid % half;
+      const int base = hh == 0 ? hq * HD : a.nq * HD + kvh * HD;
+      const int ia = a.interleaved ? 2 * i : i, ib = a.interleaved ? 2 * i + 1 : i + half;
+      px0 = vsrc_get(a.qkv, base + ia, a.act); px1 = vsrc_get(a.qkv, base + ib, a.act);
+      pc = a.cos_t[(size_t)pos * half + i]; ps = a.sin_t[(size_t)pos * half + i];
+    } else if (tid < 2 * half + 64) {
+      const int j = tid - 2 * half;
+      const int vb = a.nq * HD + a.nkv * HD + kvh * HD;
+      px0 = vsrc_get(a.qkv, vb + 2 * j, a.act); px1 = vsrc_get(a.qkv, vb + 2 * j + 1, a.act);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // (1) first chunk's K/V rows: 32 coalesced loads per wave
+  // (unconditional loads at clamped rows: rows >= len get weight 0 below; the cache is zero-initialised and only ever holds
+  //  finite values, so 0 * stale == 0)
+  const int pmax = ncache > 0 ? ncache - 1 : 0;
   uint4 kr[16], vr[16];
+  size_t ro[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) ro[i] = kv_row_off(kv, a.layer, kvh, min(wave * 64 + 4 * i + rsub, pmax)) + piece * 8;
 #pragma unroll
   for (int i = 0; i < 16; i++) {
-    const int p = wave * 64 + 4 * i + rsub;
-    kr[i] = make_uint4(0, 0, 0, 0); vr[i] = make_uint4(0, 0, 0, 0);
-    if (p < ncache) {
-      const size_t ro = kv_row_off(kv, a.layer, kvh, p) + piece * 8;
-      kr[i] = *(const uint4*)((const unsigned short*)kv.k + ro);
-      vr[i] = *(const uint4*)((const unsigned short*)kv.v + ro);
-    }
+    kr[i] = *(const uint4*)((const unsigned short*)kv.k + ro[i]);
+    vr[i] = *(const uint4*)((const unsigned short*)kv.v + ro[i]);
   }
   // (0) o_proj slab of this wave (FUSE): in flight through the whole attention
   uint4 Wb[FUSE ? TPW : 1][4];
@@ -1457,23 +1501,16 @@ __global__ __launch_bounds__(256) void k_attn2(AttnArgs a, const uint4* __restri
   STAMP(1);
   // (2) q/k/v finishing: fixed point -> f32, rounding, RoPE; packed q / new key / new value to LDS; KV append
   if (!a.q_only) {
-    const float* cr = a.cos_t + (size_t)pos * half;
-    const float* sr = a.sin_t + (size_t)pos * half;
     if (tid < 2 * half) {
       const int hh = tid / half, i = tid % half;
-      const int base = hh == 0 ? hq * HD : a.nq * HD + kvh * HD;
       const int ia = a.interleaved ? 2 * i : i, ib = a.interleaved ? 2 * i + 1 : i + half;
-      const float x0 = vsrc_get(a.qkv, base + ia, a.act), x1 = vsrc_get(a.qkv, base + ib, a.act);
-      const float c = cr[i], s = sr[i];
-      const float y0 = round_act(x0 * c - x1 * s, a.act), y1 = round_act(x1 * c + x0 * s, a.act);
+      const float y0 = round_act(px0 * pc - px1 * ps, a.act), y1 = round_act(px1 * pc + px0 * ps, a.act);
       unsigned short* dst = (unsigned short*)(hh == 0 ? q2 : k2);
       const unsigned p0 = pack2<KVDT>(y0, y1);
       dst[ia] = (unsigned short)(p0 & 0xffffu);
       dst[ib] = (unsigned short)(p0 >> 16);
     } else if (tid < 2 * half + 64) {
-      const int j = tid - 2 * half;
-      const int vb = a.nq * HD + a.nkv * HD + kvh * HD;
-      v2[j] = pack2<KVDT>(vsrc_get(a.qkv, vb + 2 * j, a.act), vsrc_get(a.qkv, vb + 2 * j + 1, a.act));
+      v2[tid - 2 * half] = pack2<KVDT>(px0, px1);
     }
     __syncthreads();
     if (hq % rep == 0 && cs == 0 && tid < 64) {   // KV append, once per kv head: 64 threads x 4-byte pairs
@@ -1496,14 +1533,11 @@ __global__ __launch_bounds__(256) void k_attn2(AttnArgs a, const uint4* __restri
     if (c0 > 0) {
       __syncthreads();   // the previous chunk's pout / wred reads are done
 #pragma unroll
+      for (int i = 0; i < 16; i++) ro[i] = kv_row_off(kv, a.layer, kvh, min(c0 + wave * 64 + 4 * i + rsub, pmax)) + piece * 8;
+#pragma unroll
       for (int i = 0; i < 16; i++) {
-        const int p = c0 + wave * 64 + 4 * i + rsub;
-        kr[i] = make_uint4(0, 0, 0, 0); vr[i] = make_uint4(0, 0, 0, 0);
-        if (p < ncache) {
-          const size_t ro = kv_row_off(kv, a.layer, kvh, p) + piece * 8;
-          kr[i] = *(const uint4*)((const unsigned short*)kv.k + ro);
-          vr[i] = *(const uint4*)((const unsigned short*)kv.v + ro);
-        }
+        kr[i] = *(const uint4*)((const unsigned short*)kv.k + ro[i]);
+        vr[i] = *(const uint4*)((const unsigned short*)kv.v + ro[i]);
       }
     }
     // the token being appended (position pos == ncache) comes from LDS

@@ -2,6 +2,7 @@ import os, sys
 sys.path.insert(0, ".")
 os.environ["BZ_ATTN_STAMPS"] = "1"
 os.environ["BZ_ATTN_STAMPS_PRINT"] = "1"
+os.environ["BZ_MLP_STAMPS"] = "1"
 from blazr_amd import runtime, synth, _lib as L
 cfg = synth.make_config("llama3-8b-awq-2l")
 dev = runtime.Device(0)
