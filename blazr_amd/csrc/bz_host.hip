@@ -378,7 +378,17 @@ extern "C" int bz_model_add_gguf(bz_model* m, const char* name, int ggml_type, i
     int dt = ggml_type == BZ_GGML_F32 ? BZ_F32 : (ggml_type == BZ_GGML_F16 ? BZ_F16 : BZ_BF16);
     return bz_model_add_dense(m, name, dt, shape, K > 1 ? 2 : 1, blocks);
   }
-  BZ_FAIL(BZ_E_UNSUPPORTED, "add_gguf '%s': ggml type %d block-dequant GEMV is not implemented in this build yet", name, ggml_type);
+  size_t rowb = 0;
+  if (ggml_type == BZ_GGML_Q8_0) rowb = (size_t)K / 32 * 34;
+  else if (ggml_type == BZ_GGML_Q4_K) rowb = (size_t)K / 256 * 144;
+  else if (ggml_type == BZ_GGML_Q6_K) rowb = (size_t)K / 256 * 210;
+  else BZ_FAIL(BZ_E_UNSUPPORTED, "add_gguf '%s': ggml type %d is not implemented (F32, F16, BF16, Q8_0, Q4_K, Q6_K are)", name, ggml_type);
+  if (N % 64 || K % 256) BZ_FAIL(BZ_E_UNSUPPORTED, "add_gguf '%s': N=%lld must be a multiple of 64 and K=%lld of 256", name, (long long)N, (long long)K);
+  RawTensor r; r.kind = 3; r.N = N; r.K = K; r.ggml_type = ggml_type; r.bytes = (size_t)N * rowb;
+  r.shape = {N, K};
+  BZ_TRY(upload(m->dev, &r.d0, blocks, r.bytes));
+  m->raw[name] = r;
+  return BZ_OK;
 }
 
 // --- finalize helpers ---------------------------------------------------------------------------------------
@@ -479,6 +489,53 @@ static int build_rows(bz_model* m, const std::vector<RawTensor*>& rs, LinearDev*
   return BZ_OK;
 }
 
+static int choose_sbw(int N, int K, int target) {
+  const int SB = K / 256, nst = (N + 255) / 256;
+  int best = 1; double bestc = 1e30;
+  for (int w = 1; w <= std::min(SB, 8); w++) {
+    if (SB % w) continue;
+    const double wgs = (double)nst * (SB / w);
+    double c = fabs(log(wgs / (double)target));
+    if (wgs < 256) c += 1.0;
+    if (c < bestc) { bestc = c; best = w; }
+  }
+  return best;
+}
+
+// GGUF block tensors of one ggml type, concatenated along N
+static int build_gq(bz_model* m, const std::vector<RawTensor*>& rs, LinearDev* L) {
+  const int K = (int)rs[0]->K, type = rs[0]->ggml_type;
+  int N = 0;
+  for (auto* r : rs) N += (int)r->N;
+  const int kind = type == BZ_GGML_Q8_0 ? LK_Q80 : (type == BZ_GGML_Q4_K ? LK_Q4K : LK_Q6K);
+  size_t wqb, whb = 0, hdb = 0, ddb;
+  if (kind == LK_Q80) { wqb = (size_t)N * K; ddb = (size_t)N * (K / 32) * 2; }
+  else if (kind == LK_Q4K) { wqb = (size_t)N * K / 2; hdb = (size_t)N * (K / 256) * 16; ddb = 0; }
+  else { wqb = (size_t)N * K / 2; whb = (size_t)N * K / 4; hdb = (size_t)N * (K / 256) * 16; ddb = (size_t)N * (K / 256) * 2; }
+  void *wq = nullptr, *wh = nullptr, *hd = nullptr, *dd = nullptr;
+  BZ_TRY(dev_alloc(m, &wq, wqb));
+  if (whb) BZ_TRY(dev_alloc(m, &wh, whb));
+  if (hdb) BZ_TRY(dev_alloc(m, &hd, hdb));
+  if (ddb) BZ_TRY(dev_alloc(m, &dd, ddb));
+  size_t n0 = 0;
+  for (auto* r : rs) {
+    // per-tile layouts: a part starting at column n0 starts at tile n0/64 of every array
+    const size_t t0 = n0 / 64;
+    char* wqo = (char*)wq + t0 * (wqb / (N / 64));
+    char* who = wh ? (char*)wh + t0 * (whb / (N / 64)) : nullptr;
+    char* hdo = hd ? (char*)hd + t0 * (hdb / (N / 64)) : nullptr;
+    char* ddo = dd ? (char*)dd + t0 * (ddb / (N / 64)) : nullptr;
+    BZ_TRY(bzk_repack_gq(m->dev->stream, kind, r->d0, (int)r->N, K, wqo, who, hdo, ddo));
+    n0 += (size_t)r->N;
+  }
+  BZ_HIP(hipStreamSynchronize(m->dev->stream));
+  L->kind = kind; L->N = N; L->K = K; L->gs = kind == LK_Q80 ? 32 : 256; L->w = wq; L->zeros = wh; L->hdr = hd; L->scales = dd;
+  L->gw = choose_sbw(N, K, gemv_target_wgs());
+  L->bytes = wqb + whb + hdb + ddb;
+  L->algo_bytes = L->bytes;     // the repack keeps the ggml bytes per weight (34/32, 144/256, 210/256)
+  return BZ_OK;
+}
+
 static bool same_perm(const RawTensor* a, const RawTensor* b) { return a->g_idx == b->g_idx; }
 
 // names: HF tensor names (without ".weight"); fuses along N when layouts allow, otherwise keeps separate parts
@@ -497,6 +554,7 @@ static int build_fused(bz_model* m, const std::vector<std::string>& names, Fused
     if (r->kind != rs[0]->kind) fusable = false;
     if (r->kind == 2 && !same_perm(r, rs[0])) fusable = false;
     if (r->kind == 0 && r->dtype != rs[0]->dtype) fusable = false;
+    if (r->kind == 3 && r->ggml_type != rs[0]->ggml_type) fusable = false;
   }
   std::vector<std::vector<RawTensor*>> groups;
   if (fusable) groups.push_back(rs);
@@ -506,6 +564,7 @@ static int build_fused(bz_model* m, const std::vector<std::string>& names, Fused
     LinearDev L;
     if (g[0]->kind == 1 || g[0]->kind == 2) BZ_TRY(build_q4g(m, g, &L));
     else if (g[0]->kind == 0) { if (g[0]->shape.size() != 2) BZ_FAIL(BZ_E_INVALID, "finalize: linear weight must be 2-D"); BZ_TRY(build_rows(m, g, &L)); }
+    else if (g[0]->kind == 3) BZ_TRY(build_gq(m, g, &L));
     else BZ_FAIL(BZ_E_UNSUPPORTED, "finalize: tensor kind %d", g[0]->kind);
     F->parts.push_back(L); F->n_off.push_back(noff);
     // per-name views for the op-level API
@@ -517,8 +576,15 @@ static int build_fused(bz_model* m, const std::vector<std::string>& names, Fused
         V.w = (char*)L.w + (size_t)sub * L.K / 2; V.scales = (char*)L.scales + (size_t)sub * G * 2; V.zeros = (char*)L.zeros + (size_t)sub * G;
         V.bias = L.bias ? L.bias + sub : nullptr;
         V.gw = choose_gw(V.N, V.K, gemv_target_wgs());
-      } else {
+      } else if (L.kind == LK_ROWS) {
         V.w = (char*)L.w + (size_t)sub * L.K * bz_dtype_size(L.wdt);
+      } else {
+        const size_t t0 = (size_t)sub / 64, K = (size_t)L.K;
+        if (L.kind == LK_Q80) { V.w = (char*)L.w + t0 * 64 * K; V.scales = (char*)L.scales + t0 * (K / 32) * 64 * 2; }
+        else if (L.kind == LK_Q4K) { V.w = (char*)L.w + t0 * 32 * K; V.hdr = (char*)L.hdr + t0 * (K / 256) * 64 * 16; }
+        else { V.w = (char*)L.w + t0 * 32 * K; V.zeros = (char*)L.zeros + t0 * 16 * K; V.hdr = (char*)L.hdr + t0 * (K / 256) * 64 * 16;
+               V.scales = (char*)L.scales + t0 * (K / 256) * 64 * 2; }
+        V.gw = choose_sbw(V.N, V.K, gemv_target_wgs());
       }
       m->named[names[ri] + ".weight"] = V;
       sub += (int)r->N; ri++;
@@ -627,8 +693,7 @@ extern "C" int bz_model_finalize(bz_model* m) {
       if (m->lm_head.N != V || m->lm_head.K != H) BZ_FAIL(BZ_E_INVALID, "finalize: lm_head shape does not match the config");
     }
   }
-  if (m->lm_head.fix_out || m->lm_head.parts.size() != 1)
-    BZ_FAIL(BZ_E_UNSUPPORTED, "finalize: quantised lm_head is not implemented in this build (dense f16/bf16/f32 only)");
+  if (m->lm_head.parts.size() != 1) BZ_FAIL(BZ_E_UNSUPPORTED, "finalize: lm_head must be a single tensor");
   for (auto& kv : m->raw) if (!kv.second.consumed) BZ_FAIL(BZ_E_INVALID, "finalize: tensor '%s' is not used by this architecture", kv.first.c_str());
   m->raw.clear();
 
@@ -641,6 +706,7 @@ extern "C" int bz_model_finalize(bz_model* m) {
 
   // workspace
   m->ring_n = std::max(std::max((nq + 2 * nkv) * hd, 2 * I), std::max(H, nq * hd));
+  if (m->lm_head.fix_out) m->ring_n = std::max(m->ring_n, V);
   for (int i = 0; i < 3; i++) {
     BZ_TRY(dev_alloc(m, &p, (size_t)m->ring_n * 8)); m->ring[i] = (long long*)p; BZ_HIP(hipMemset(p, 0, (size_t)m->ring_n * 8));
     BZ_TRY(dev_alloc(m, &p, (size_t)m->ring_n * 4)); m->dring[i] = (float*)p; BZ_HIP(hipMemset(p, 0, (size_t)m->ring_n * 4));
@@ -648,7 +714,7 @@ extern "C" int bz_model_finalize(bz_model* m) {
   for (int i = 0; i < 2; i++) { BZ_TRY(dev_alloc(m, &p, (size_t)H * 4)); m->hbuf[i] = (float*)p; }
   BZ_TRY(dev_alloc(m, &p, (size_t)nq * hd * 4)); m->attn_out = (float*)p;
   BZ_TRY(dev_alloc(m, &p, (size_t)V * 4)); m->logits = (float*)p;
-  m->nparts = bzk_gemv_rows_blocks(m->lm_head.parts[0]);
+  m->nparts = m->lm_head.fix_out ? 64 : bzk_gemv_rows_blocks(m->lm_head.parts[0]);
   BZ_TRY(dev_alloc(m, &p, (size_t)m->nparts * 4)); m->pval = (float*)p;
   BZ_TRY(dev_alloc(m, &p, (size_t)m->nparts * 4)); m->pidx = (int*)p;
   BZ_TRY(dev_alloc(m, &p, 4096)); m->scratch = (float*)p;
@@ -929,17 +995,27 @@ static int llama_step(bz_model* m, const StepIO& io) {
   if (io.do_head) {
     Pro ph{}; ph.mode = PRO_NORM; ph.src = prev; ph.h_in = m->hbuf[cur]; ph.h_out = nullptr; ph.norm_w = m->final_norm;
     ph.eps = c.rms_eps; ph.H = H; ph.act = act;
-    GemvOut o{};
-    o.direct = m->logits; o.amax_val = m->pval; o.amax_idx = m->pidx;
-    o.zero_buf = rs.dirty[rb] > 0 ? m->ring[rb] : nullptr; o.zero_n = rs.dirty[rb];
-    BZ_TRY(bzk_gemv(st, m->lm_head.parts[0], ph, o, act));
-    rs.dirty[rb] = 0;
+    int rfin = ra;   // ring buffer the final kernel zeroes
+    if (m->lm_head.fix_out) {
+      // quantised lm_head (GGUF output.weight): split-K GEMV into the ring, then convert + partial argmax
+      VSrc lv;
+      BZ_TRY(run_fused(m, m->lm_head, ph, rs, &lv));
+      BZ_TRY(bzk_fix_to_f32(st, (const long long*)lv.p, c.vocab, act, m->logits));
+      BZ_TRY(bzk_argmax_partials(st, m->logits, c.vocab, m->pval, m->pidx, m->nparts));
+      rfin = -1;
+    } else {
+      GemvOut o{};
+      o.direct = m->logits; o.amax_val = m->pval; o.amax_idx = m->pidx;
+      o.zero_buf = rs.dirty[rb] > 0 ? m->ring[rb] : nullptr; o.zero_n = rs.dirty[rb];
+      BZ_TRY(bzk_gemv(st, m->lm_head.parts[0], ph, o, act));
+      rs.dirty[rb] = 0;
+    }
     if (io.final_args) {
       FinalArgs fa = *io.final_args;
       fa.pval = m->pval; fa.pidx = m->pidx; fa.nparts = m->nparts;
-      fa.zero_buf = rs.dirty[ra] > 0 ? m->ring[ra] : nullptr; fa.zero_n = rs.dirty[ra];
+      if (rfin >= 0) { fa.zero_buf = rs.dirty[rfin] > 0 ? m->ring[rfin] : nullptr; fa.zero_n = rs.dirty[rfin]; }
       BZ_TRY(bzk_argmax_final(st, fa));
-      rs.dirty[ra] = 0;
+      if (rfin >= 0) rs.dirty[rfin] = 0;
     }
   }
   // every ring buffer must be zero again when the step ends
@@ -1484,7 +1560,7 @@ extern "C" int bz_dequant(bz_model* m, const char* name, float* host) {
   const size_t n = (size_t)L.N * L.K;
   float* d;
   BZ_HIP(hipMalloc(&d, n * 4));
-  int rc = L.kind == LK_Q4G ? bzk_dequant_q4g(m->dev->stream, L, d) : (L.kind == LK_ROWS ? bzk_dequant_rows(m->dev->stream, L, d) : BZ_E_UNSUPPORTED);
+  int rc = L.kind == LK_Q4G ? bzk_dequant_q4g(m->dev->stream, L, d) : (L.kind == LK_ROWS ? bzk_dequant_rows(m->dev->stream, L, d) : bzk_dequant_gq(m->dev->stream, L, d));
   std::vector<float> tmp;
   if (rc == BZ_OK) rc = hipStreamSynchronize(m->dev->stream) == hipSuccess ? BZ_OK : BZ_E_HIP;  // the stream is non-blocking
   if (rc == BZ_OK) {

@@ -48,7 +48,7 @@ struct LinearDev {
   int kind = LK_NONE;
   int N = 0, K = 0, gs = 0;
   int wdt = BZ_F16;         // ROWS: weight dtype
-  void* w = nullptr;        // Q4G: [N/64][K/32][64 lanes][16 B]; ROWS: [N][K]; K-quants: see kernels
+  void* w = nullptr;        // Q4G: [N/64][K/32][64 lanes][16 B]; ROWS: [N][K]; GGUF kinds: see k_gemv_gq (zeros = Q6_K highs, hdr = headers, scales = f16 d)
   void* scales = nullptr;   // Q4G: f16 [N/64][G][64]
   void* zeros = nullptr;    // Q4G: u8  [N/64][G][64]  (AWQ z, GPTQ z+1)
   void* hdr = nullptr;      // K-quants: per-superblock headers
@@ -141,6 +141,9 @@ int bzk_repack_gptq(hipStream_t s, const uint32_t* d_qweight, const float* d_sca
                     const int* d_gidx, int N, int K, int gs, void* w_out, void* s_out, void* z_out);
 int bzk_dequant_q4g(hipStream_t s, const LinearDev& L, float* out /*[N][K] device*/);
 int bzk_dequant_rows(hipStream_t s, const LinearDev& L, float* out);
+int bzk_repack_gq(hipStream_t s, int kind, const void* raw, int N, int K, void* wq, void* wh, void* hd, void* dd);
+int bzk_dequant_gq(hipStream_t s, const LinearDev& L, float* out);
+int bzk_argmax_partials(hipStream_t s, const float* v, long long n, float* pval, int* pidx, int nb);
 int bzk_embed(hipStream_t s, const void* table, int tdt, const long long* tok, int H, int act, float* h_out);
 int bzk_fix_to_f32(hipStream_t s, const long long* acc, int n, int act, float* out);
 int bzk_zero64(hipStream_t s, long long* p, int n);

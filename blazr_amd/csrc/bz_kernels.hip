@@ -735,6 +735,269 @@ __global__ __launch_bounds__(256) void k_gemv_q4g(const uint4* __restrict__ W, c
   else atomicAdd((unsigned long long*)(acc + n), (unsigned long long)f2fix(y));
 }
 
+// =========================================================================================================
+// GGUF block-quantised GEMV: Q8_0 / Q4_K / Q6_K  (formats = public GGML block layouts, gguf.rs:33 hands
+// the blocks over opaquely).  Same skeleton as k_gemv_q4g -- lane == output column, split-K over k-slices, fused
+// prologues, 3-plane int8 activations on V_DOT4_I32_I8, fixed-point atomics -- with the activation slice scaled per
+// 32-k chunk so that every format's sub-block structure (32 for Q8_0/Q4_K, 16 for Q6_K) falls on chunk boundaries.
+//
+// HBM layouts after the load-time repack (bytes per weight unchanged: 34/32, 144/256, 210/256):
+//   Q8_0 : q  [N/64][K/16][64][16 B] int8,                      d  [N/64][K/32][64] f16
+//   Q4_K : q  [N/64][K/32][64][16 B] nibbles (A/B order as Q4G), hdr [N/64][K/256][64][16 B] = {d, dmin, scales[12]} verbatim
+//   Q6_K : ql [N/64][K/32][64][16 B] low nibbles (A/B order),    qh [N/64][K/32][64][8 B] 2-bit highs,
+//          sc [N/64][K/256][64][16 B] int8 x16,                  d  [N/64][K/256][64] f16
+// per-chunk activation parameters in LDS (2 x int4 per chunk):
+//   P0 = { sx (f32 bits), Sa_h, Sa_m, Sa_l }   P1 = { Sb_h, Sb_m, Sb_l, 0 }
+//   Q4_K: Sa = sum over the chunk, Sb = sum over k%8 >= 4 (for the signed high-nibble trick);  Q6_K: Sa / Sb = sums over the
+//   first / second 16;  Q8_0: unused.
+// =========================================================================================================
+enum { GQ_Q80 = 0, GQ_Q4K = 1, GQ_Q6K = 2 };
+
+template <int FMT>
+__device__ __forceinline__ void quant_x32(const float* xs, int KR, unsigned* xh, unsigned* xm, unsigned* xl, int4* cpar) {
+  for (int base = 0; base < KR; base += (int)blockDim.x * 8) {
+    const int e0 = base + threadIdx.x * 8;
+    const bool on = e0 < KR;
+    float v[8];
+    if (on) {
+      float4 a = *(const float4*)(xs + e0), b = *(const float4*)(xs + e0 + 4);
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; i++) v[i] = 0.f;
+    }
+    float am = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) am = fmaxf(am, fabsf(v[i]));
+    am = fmaxf(am, __shfl_xor(am, 1, 64)); am = fmaxf(am, __shfl_xor(am, 2, 64));   // 4 lanes x 8 = one 32-k chunk
+    const float inv = am > 0.f ? XQ_MAX / am : 0.f;
+    unsigned wh[2] = {0, 0}, wm[2] = {0, 0}, wl[2] = {0, 0};
+    int sa[3] = {0, 0, 0}, sb[3] = {0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int xi = (int)rintf(v[i] * inv);
+      const int lo = ((xi + 128) & 255) - 128;
+      const int r1 = (xi - lo) >> 8;
+      const int mid = ((r1 + 128) & 255) - 128;
+      const int hi = (r1 - mid) >> 8;
+      wh[i >> 2] |= ((unsigned)hi & 255u) << (8 * (i & 3));
+      wm[i >> 2] |= ((unsigned)mid & 255u) << (8 * (i & 3));
+      wl[i >> 2] |= ((unsigned)lo & 255u) << (8 * (i & 3));
+      if (FMT == GQ_Q4K) { sa[0] += hi; sa[1] += mid; sa[2] += lo; if (i >= 4) { sb[0] += hi; sb[1] += mid; sb[2] += lo; } }
+      if (FMT == GQ_Q6K) { sa[0] += hi; sa[1] += mid; sa[2] += lo; }   // per-thread sum; halves are separated below
+    }
+    if (FMT == GQ_Q6K) {
+      // lanes 0,1 of the 4-lane group hold k 0..15 (first half), lanes 2,3 hold k 16..31
+      const bool second = (threadIdx.x & 2) != 0;
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        const int mine = sa[q] + __shfl_xor(sa[q], 1, 64);          // sum of my half
+        const int other = __shfl_xor(mine, 2, 64);                  // the other half
+        sa[q] = second ? other : mine;                              // Sa = first half
+        sb[q] = second ? mine : other;                              // Sb = second half
+      }
+    } else if (FMT == GQ_Q4K) {
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        sa[q] += __shfl_xor(sa[q], 1, 64); sa[q] += __shfl_xor(sa[q], 2, 64);
+        sb[q] += __shfl_xor(sb[q], 1, 64); sb[q] += __shfl_xor(sb[q], 2, 64);
+      }
+    }
+    if (on) {
+      *(uint2*)(xh + e0 / 4) = make_uint2(wh[0], wh[1]);
+      *(uint2*)(xm + e0 / 4) = make_uint2(wm[0], wm[1]);
+      *(uint2*)(xl + e0 / 4) = make_uint2(wl[0], wl[1]);
+      if ((threadIdx.x & 3) == 0) {
+        cpar[2 * (e0 >> 5)] = make_int4(__float_as_int(am * (1.0f / XQ_MAX)), sa[0], sa[1], sa[2]);
+        cpar[2 * (e0 >> 5) + 1] = make_int4(sb[0], sb[1], sb[2], 0);
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ float planes_f(int uh, int um, int ul) { return fmaf((float)uh, 65536.0f, fmaf((float)um, 256.0f, (float)ul)); }
+
+// one 32-k chunk of signed / unsigned int8 weights given as 8 words (4 weights each, k order), against the chunk's planes
+__device__ __forceinline__ void dot_chunk8(const unsigned (&w)[8], const uint4* xh4, const uint4* xm4, const uint4* xl4, int c, int (&u)[3]) {
+  const uint4 h0 = xh4[c * 2], h1 = xh4[c * 2 + 1], m0 = xm4[c * 2], m1 = xm4[c * 2 + 1], l0 = xl4[c * 2], l1 = xl4[c * 2 + 1];
+  const unsigned Xh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+  const unsigned Xm[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+  const unsigned Xl[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    u[0] = __builtin_amdgcn_sdot4((int)w[j], (int)Xh[j], u[0], false);
+    u[1] = __builtin_amdgcn_sdot4((int)w[j], (int)Xm[j], u[1], false);
+    u[2] = __builtin_amdgcn_sdot4((int)w[j], (int)Xl[j], u[2], false);
+  }
+}
+
+// Q4_K 6-bit scale / min of sub-block j from the 12 packed bytes (GGML get_scale_min_k4)
+__device__ __forceinline__ void q4k_scale_min(const unsigned (&hw)[4], int j, int& sc, int& mn) {
+  // bytes: hw[0] = d,dmin ; scales bytes s[0..11] = bytes 4..15 of the 16-byte header
+  auto sbyte = [&](int i) -> unsigned { const int bi = 4 + i; return (hw[bi >> 2] >> (8 * (bi & 3))) & 255u; };
+  if (j < 4) { sc = (int)(sbyte(j) & 63u); mn = (int)(sbyte(j + 4) & 63u); }
+  else { sc = (int)((sbyte(j + 4) & 15u) | ((sbyte(j - 4) >> 6) << 4)); mn = (int)((sbyte(j + 4) >> 4) | ((sbyte(j) >> 6) << 4)); }
+}
+
+#define GQ_E 8   // slice elements per thread (KR <= 2048)
+
+template <int FMT, int MODE, int FIX, int MAXJ>
+__global__ __launch_bounds__(256) void k_gemv_gq(const uint4* __restrict__ Wq, const uint2* __restrict__ Wh, const uint4* __restrict__ Hd,
+                                                 const __half* __restrict__ Dd, const float* __restrict__ bias, int N, int K, int SBW, int nst,
+                                                 Pro pro, long long* acc, long long* zero_buf, int zero_n) {
+  // SBW = 256-k superblocks per workgroup (k-slice of 256 * SBW)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int KR = SBW * 256;
+  float* xs = (float*)smem;                 // [KR]
+  unsigned* xh = (unsigned*)(xs + KR);      // [KR/4] x3
+  unsigned* xm = xh + KR / 4;
+  unsigned* xl = xm + KR / 4;
+  int4* cpar = (int4*)(xl + KR / 4);        // [2 * KR/32]
+  float* red = (float*)(cpar + 2 * (KR / 32));
+  const int st = blockIdx.x % nst, ks = blockIdx.x / nst;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int nt = st * 4 + wave;
+  const bool wave_on = nt * 64 < N;
+  const int ntc = wave_on ? nt : 0;
+  const int k0 = ks * KR;
+  zero_duty(zero_buf, zero_n);
+
+  XRegs<MODE, FIX, MAXJ, GQ_E> xr;
+  xload<MODE, FIX, MAXJ, GQ_E>(pro, k0, KR, xr);
+  __builtin_amdgcn_sched_barrier(0);
+  // first superblock's weights
+  const int SB = K >> 8, C32 = K >> 5;
+  const int sb0 = ks * SBW;
+  uint4 q[16];          // Q8_0: 16 x 16 B (256 int8) ; Q4_K / Q6_K: 8 x 16 B nibbles
+  uint2 qh[8];          // Q6_K highs
+  uint4 hd = make_uint4(0, 0, 0, 0);
+  __half dv[8];         // Q8_0: the 8 block scales of the superblock ; Q6_K: dv[0] = d
+  auto load_sb = [&](int sb) {
+    if (FMT == GQ_Q80) {
+      const uint4* p = Wq + ((size_t)ntc * (K >> 4) + (size_t)sb * 16) * 64 + lane;
+#pragma unroll
+      for (int i = 0; i < 16; i++) q[i] = ldnt(p + i * 64);
+#pragma unroll
+      for (int c = 0; c < 8; c++) dv[c] = Dd[((size_t)ntc * C32 + (size_t)sb * 8 + c) * 64 + lane];
+    } else {
+      const uint4* p = Wq + ((size_t)ntc * C32 + (size_t)sb * 8) * 64 + lane;
+#pragma unroll
+      for (int i = 0; i < 8; i++) q[i] = ldnt(p + i * 64);
+      hd = Hd[((size_t)ntc * SB + sb) * 64 + lane];
+      if (FMT == GQ_Q6K) {
+        const uint2* ph = Wh + ((size_t)ntc * C32 + (size_t)sb * 8) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < 8; i++) qh[i] = ph[i * 64];
+        dv[0] = Dd[((size_t)ntc * SB + sb) * 64 + lane];
+      }
+    }
+  };
+  load_sb(sb0);
+  xfinish<MODE, FIX, MAXJ, GQ_E>(pro, KR, xr, xs, red, blockIdx.x == 0);
+  quant_x32<FMT>(xs, KR, xh, xm, xl, cpar);
+  __syncthreads();
+  if (!wave_on) return;
+
+  const uint4* xh4 = (const uint4*)xh;
+  const uint4* xm4 = (const uint4*)xm;
+  const uint4* xl4 = (const uint4*)xl;
+  float y = 0.f;
+  for (int s = 0; s < SBW; s++) {
+    const int sb = sb0 + s;
+    (void)sb;
+    if (FMT == GQ_Q80) {
+#pragma unroll
+      for (int c = 0; c < 8; c++) {     // chunk = one Q8_0 block
+        const unsigned w[8] = {q[2 * c].x, q[2 * c].y, q[2 * c].z, q[2 * c].w, q[2 * c + 1].x, q[2 * c + 1].y, q[2 * c + 1].z, q[2 * c + 1].w};
+        int u[3] = {0, 0, 0};
+        dot_chunk8(w, xh4, xm4, xl4, s * 8 + c, u);
+        y += __half2float(dv[c]) * (__int_as_float(cpar[2 * (s * 8 + c)].x) * planes_f(u[0], u[1], u[2]));
+      }
+    } else if (FMT == GQ_Q4K) {
+      const unsigned hw[4] = {hd.x, hd.y, hd.z, hd.w};
+      const float d = __half2float(__ushort_as_half((unsigned short)(hw[0] & 0xffffu)));
+      const float dmin = __half2float(__ushort_as_half((unsigned short)(hw[0] >> 16)));
+#pragma unroll
+      for (int c = 0; c < 8; c++) {     // chunk = one sub-block
+        const unsigned ww[4] = {q[c].x, q[c].y, q[c].z, q[c].w};
+        // nibble trick of Q4G: low nibbles q (unsigned), high nibbles stored as (q - 8): words in k order are A0,B0,A1,B1,...
+        unsigned w[8];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { w[2 * j] = ww[j] & 0x0F0F0F0Fu; w[2 * j + 1] = ww[j] & 0xF0F0F0F0u; }
+        int ua[3] = {0, 0, 0}, ub[3] = {0, 0, 0};
+        {
+          const int cc = s * 8 + c;
+          const uint4 h0 = xh4[cc * 2], h1 = xh4[cc * 2 + 1], m0 = xm4[cc * 2], m1 = xm4[cc * 2 + 1], l0 = xl4[cc * 2], l1 = xl4[cc * 2 + 1];
+          const unsigned Xh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+          const unsigned Xm[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+          const unsigned Xl[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            ua[0] = __builtin_amdgcn_sdot4((int)w[2 * j], (int)Xh[2 * j], ua[0], false);
+            ua[1] = __builtin_amdgcn_sdot4((int)w[2 * j], (int)Xm[2 * j], ua[1], false);
+            ua[2] = __builtin_amdgcn_sdot4((int)w[2 * j], (int)Xl[2 * j], ua[2], false);
+            ub[0] = __builtin_amdgcn_sdot4((int)w[2 * j + 1], (int)Xh[2 * j + 1], ub[0], false);
+            ub[1] = __builtin_amdgcn_sdot4((int)w[2 * j + 1], (int)Xm[2 * j + 1], ub[1], false);
+            ub[2] = __builtin_amdgcn_sdot4((int)w[2 * j + 1], (int)Xl[2 * j + 1], ub[2], false);
+          }
+        }
+        const int4 p0 = cpar[2 * (s * 8 + c)], p1 = cpar[2 * (s * 8 + c) + 1];
+        // 16 * sum q x  per plane = 16 A + B' + 128 Sb   (B' = sum 16 (q - 8) x)
+        const float qx = planes_f((ua[0] << 4) + ub[0] + 128 * p1.x, (ua[1] << 4) + ub[1] + 128 * p1.y, (ua[2] << 4) + ub[2] + 128 * p1.z) * (1.0f / 16.0f);
+        const float sx_ = planes_f(p0.y, p0.z, p0.w);
+        int sc, mn;
+        q4k_scale_min(hw, c, sc, mn);
+        y += __int_as_float(p0.x) * ((d * (float)sc) * qx - (dmin * (float)mn) * sx_);
+      }
+    } else {  // Q6_K
+      const unsigned sw[4] = {hd.x, hd.y, hd.z, hd.w};   // 16 int8 scales
+      const float d = __half2float(dv[0]);
+#pragma unroll
+      for (int c = 0; c < 8; c++) {     // chunk = 32 k = two 16-blocks (words 0..3 and 4..7 in k order)
+        const unsigned ww[4] = {q[c].x, q[c].y, q[c].z, q[c].w};
+        const unsigned hh[2] = {qh[c].x, qh[c].y};
+        unsigned w[8];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const unsigned lo_a = ww[j] & 0x0F0F0F0Fu, lo_b = (ww[j] >> 4) & 0x0F0F0F0Fu;
+          const int fa = 2 * j, fb = 2 * j + 1;      // 2-bit field index (k order words A_j, B_j)
+          const unsigned hi_a = ((hh[fa >> 2] >> (2 * (fa & 3))) & 0x03030303u) << 4;
+          const unsigned hi_b = ((hh[fb >> 2] >> (2 * (fb & 3))) & 0x03030303u) << 4;
+          w[2 * j] = lo_a | hi_a;       // q in 0..63 (as positive int8); the -32 is applied through the plane sums
+          w[2 * j + 1] = lo_b | hi_b;
+        }
+        const int cc = s * 8 + c;
+        const uint4 h0 = xh4[cc * 2], h1 = xh4[cc * 2 + 1], m0 = xm4[cc * 2], m1 = xm4[cc * 2 + 1], l0 = xl4[cc * 2], l1 = xl4[cc * 2 + 1];
+        const unsigned Xh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+        const unsigned Xm[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+        const unsigned Xl[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+        int u0[3] = {0, 0, 0}, u1[3] = {0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          u0[0] = __builtin_amdgcn_sdot4((int)w[j], (int)Xh[j], u0[0], false);
+          u0[1] = __builtin_amdgcn_sdot4((int)w[j], (int)Xm[j], u0[1], false);
+          u0[2] = __builtin_amdgcn_sdot4((int)w[j], (int)Xl[j], u0[2], false);
+          u1[0] = __builtin_amdgcn_sdot4((int)w[4 + j], (int)Xh[4 + j], u1[0], false);
+          u1[1] = __builtin_amdgcn_sdot4((int)w[4 + j], (int)Xm[4 + j], u1[1], false);
+          u1[2] = __builtin_amdgcn_sdot4((int)w[4 + j], (int)Xl[4 + j], u1[2], false);
+        }
+        const int4 p0 = cpar[2 * cc], p1 = cpar[2 * cc + 1];
+        const int s0 = (int)(signed char)((sw[(2 * c) >> 2] >> (8 * ((2 * c) & 3))) & 255u);
+        const int s1 = (int)(signed char)((sw[(2 * c + 1) >> 2] >> (8 * ((2 * c + 1) & 3))) & 255u);
+        const float f0 = planes_f(u0[0] - 32 * p0.y, u0[1] - 32 * p0.z, u0[2] - 32 * p0.w);
+        const float f1 = planes_f(u1[0] - 32 * p1.x, u1[1] - 32 * p1.y, u1[2] - 32 * p1.z);
+        y += __int_as_float(p0.x) * ((d * (float)s0) * f0 + (d * (float)s1) * f1);
+      }
+    }
+    if (s + 1 < SBW) load_sb(sb + 1);
+  }
+  const int n = nt * 64 + lane;
+  if (bias != nullptr && ks == 0) y += bias[n];
+  atomicAdd((unsigned long long*)(acc + n), (unsigned long long)f2fix(y));
+}
+
+static size_t gq_smem(int SBW) { size_t KR = (size_t)SBW * 256; return KR * 4 + KR * 3 + KR + 64; }
+
 static size_t q4g_smem(int GW) {
   size_t KR = (size_t)GW * 128;
   return KR * 4 + KR / 4 * 4 * 3 + (size_t)GW * 32 + (size_t)4 * GW * 64 * 2 + (size_t)4 * GW * 64 + 16;
@@ -833,6 +1096,148 @@ static int rows_per_wg_for(int N) {
 }
 int bzk_gemv_rows_blocks(const LinearDev& L) { int r = rows_per_wg_for(L.N); return (L.N + r - 1) / r; }
 
+// ---- GGUF: load-time repack from raw row-major ggml blocks ([N][K/blk] blocks of 34 / 144 / 210 bytes) -----------
+__device__ __forceinline__ unsigned q4k_raw_nib(const unsigned char* blk, int k) {   // weight k (0..255) of a raw block_q4_K
+  const int j64 = k >> 6, l = k & 63;
+  const unsigned char b = blk[16 + j64 * 32 + (l & 31)];
+  return l < 32 ? (b & 15u) : (unsigned)(b >> 4);
+}
+__device__ __forceinline__ unsigned q6k_raw(const unsigned char* blk, int k) {       // 6-bit value (0..63) of weight k of a raw block_q6_K
+  const int n128 = k >> 7, l = k & 127, quad = l >> 5, pos = l & 31;
+  const unsigned char qlb = blk[n128 * 64 + (quad & 1) * 32 + pos];
+  const unsigned lo = quad < 2 ? (qlb & 15u) : (unsigned)(qlb >> 4);
+  const unsigned hi = (blk[128 + n128 * 32 + pos] >> (2 * quad)) & 3u;
+  return lo | (hi << 4);
+}
+
+__global__ void k_repack_gq(int fmt, const unsigned char* raw, int N, int K, uint32_t* wq, uint32_t* wh, uint32_t* hd, __half* dd) {
+  const size_t gsz = (size_t)gridDim.x * blockDim.x, gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (fmt == GQ_Q80) {
+    const size_t rb = (size_t)(K / 32) * 34;
+    const size_t total = (size_t)N * (K >> 2);                 // output words (4 int8 each)
+    for (size_t idx = gid; idx < total; idx += gsz) {
+      const int j = idx & 3, lane = (idx >> 2) & 63;
+      const size_t t = idx >> 8;
+      const int kc = (int)(t % (size_t)(K >> 4)), nt = (int)(t / (size_t)(K >> 4));
+      const int n = nt * 64 + lane, k = kc * 16 + j * 4;
+      const unsigned char* b = raw + (size_t)n * rb + (size_t)(k >> 5) * 34 + 2 + (k & 31);
+      wq[idx] = (unsigned)b[0] | ((unsigned)b[1] << 8) | ((unsigned)b[2] << 16) | ((unsigned)b[3] << 24);
+    }
+    const size_t nb = (size_t)N * (K >> 5);
+    for (size_t idx = gid; idx < nb; idx += gsz) {
+      const int lane = idx & 63;
+      const size_t t = idx >> 6;
+      const int b = (int)(t % (size_t)(K >> 5)), nt = (int)(t / (size_t)(K >> 5));
+      const unsigned char* p = raw + (size_t)(nt * 64 + lane) * rb + (size_t)b * 34;
+      dd[idx] = __ushort_as_half((unsigned short)(p[0] | (p[1] << 8)));
+    }
+    return;
+  }
+  const size_t bsz = fmt == GQ_Q4K ? 144 : 210;
+  const size_t rb = (size_t)(K / 256) * bsz;
+  const size_t total = (size_t)N * (K >> 3);                   // nibble words (8 weights each)
+  for (size_t idx = gid; idx < total; idx += gsz) {
+    const int j = idx & 3, lane = (idx >> 2) & 63;
+    const size_t t = idx >> 8;
+    const int kc = (int)(t % (size_t)(K >> 5)), nt = (int)(t / (size_t)(K >> 5));
+    const int n = nt * 64 + lane;
+    const unsigned char* blk = raw + (size_t)n * rb + (size_t)(kc >> 3) * bsz;
+    const int kb = (kc & 7) * 32 + j * 8;
+    unsigned word = 0;
+#pragma unroll
+    for (int bb = 0; bb < 4; bb++) {
+      if (fmt == GQ_Q4K) {
+        const unsigned q1 = q4k_raw_nib(blk, kb + bb), q2 = q4k_raw_nib(blk, kb + 4 + bb);
+        word |= (q1 | ((q2 ^ 8u) << 4)) << (8 * bb);
+      } else {
+        const unsigned q1 = q6k_raw(blk, kb + bb) & 15u, q2 = q6k_raw(blk, kb + 4 + bb) & 15u;
+        word |= (q1 | (q2 << 4)) << (8 * bb);
+      }
+    }
+    wq[idx] = word;
+  }
+  if (fmt == GQ_Q6K) {
+    const size_t th = (size_t)N * (K >> 5) * 2;               // two high-bit words per (chunk, lane)
+    for (size_t idx = gid; idx < th; idx += gsz) {
+      const int hw = idx & 1, lane = (idx >> 1) & 63;
+      const size_t t = idx >> 7;
+      const int kc = (int)(t % (size_t)(K >> 5)), nt = (int)(t / (size_t)(K >> 5));
+      const unsigned char* blk = raw + (size_t)(nt * 64 + lane) * rb + (size_t)(kc >> 3) * bsz;
+      unsigned word = 0;
+      for (int f = 0; f < 4; f++) {            // field F = hw*4 + f  <-> k-order word F: k = 4 F + b
+        const int F = hw * 4 + f;
+        for (int bb = 0; bb < 4; bb++) {
+          const unsigned hi = q6k_raw(blk, (kc & 7) * 32 + 4 * F + bb) >> 4;
+          word |= hi << (8 * bb + 2 * f);
+        }
+      }
+      wh[idx] = word;
+    }
+  }
+  const size_t nsb = (size_t)N * (K >> 8);
+  for (size_t idx = gid; idx < nsb * 4; idx += gsz) {          // 16-byte header per (superblock, lane)
+    const int wi = idx & 3, lane = (idx >> 2) & 63;
+    const size_t t = idx >> 8;
+    const int sb = (int)(t % (size_t)(K >> 8)), nt = (int)(t / (size_t)(K >> 8));
+    const unsigned char* blk = raw + (size_t)(nt * 64 + lane) * rb + (size_t)sb * bsz;
+    const unsigned char* src = fmt == GQ_Q4K ? blk + wi * 4 : blk + 192 + wi * 4;   // Q4_K: d,dmin,scales[12] ; Q6_K: scales[16]
+    hd[idx] = (unsigned)src[0] | ((unsigned)src[1] << 8) | ((unsigned)src[2] << 16) | ((unsigned)src[3] << 24);
+    if (fmt == GQ_Q6K && wi == 0) dd[((size_t)nt * (K >> 8) + sb) * 64 + lane] = __ushort_as_half((unsigned short)(blk[208] | (blk[209] << 8)));
+  }
+}
+int bzk_repack_gq(hipStream_t s, int kind, const void* raw, int N, int K, void* wq, void* wh, void* hd, void* dd) {
+  const int fmt = kind == LK_Q80 ? GQ_Q80 : (kind == LK_Q4K ? GQ_Q4K : GQ_Q6K);
+  hipLaunchKernelGGL(k_repack_gq, dim3(2048), dim3(256), 0, s, fmt, (const unsigned char*)raw, N, K, (uint32_t*)wq, (uint32_t*)wh, (uint32_t*)hd, (__half*)dd);
+  BZ_HIP(hipGetLastError());
+  return BZ_OK;
+}
+
+// dequantise the REPACKED layouts to f32 [N][K] (validates the repack against the oracle's ggml dequant)
+__global__ void k_dequant_gq(int fmt, const uint32_t* wq, const uint32_t* wh, const uint32_t* hd, const __half* dd, int N, int K, float* out) {
+  const size_t total = (size_t)N * K;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int k = (int)(idx % (size_t)K), n = (int)(idx / (size_t)K);
+    const int nt = n >> 6, lane = n & 63;
+    if (fmt == GQ_Q80) {
+      const unsigned word = wq[(((size_t)nt * (K >> 4) + (k >> 4)) * 64 + lane) * 4 + ((k & 15) >> 2)];
+      const int q = (int)(signed char)((word >> (8 * (k & 3))) & 255u);
+      out[idx] = __half2float(dd[((size_t)nt * (K >> 5) + (k >> 5)) * 64 + lane]) * (float)q;
+      continue;
+    }
+    const int kc = k >> 5, r = k & 31, j = r >> 3, rr = r & 7;
+    const unsigned word = wq[(((size_t)nt * (K >> 5) + kc) * 64 + lane) * 4 + j];
+    const unsigned byte = (word >> (8 * (rr & 3))) & 255u;
+    const size_t hi = (((size_t)nt * (K >> 8) + (k >> 8)) * 64 + lane) * 4;
+    const unsigned hw[4] = {hd[hi], hd[hi + 1], hd[hi + 2], hd[hi + 3]};
+    if (fmt == GQ_Q4K) {
+      const float q = rr < 4 ? (float)(byte & 15u) : (float)((byte >> 4) ^ 8u);
+      const float d = __half2float(__ushort_as_half((unsigned short)(hw[0] & 0xffffu))), dmin = __half2float(__ushort_as_half((unsigned short)(hw[0] >> 16)));
+      int sc, mn;
+      q4k_scale_min(hw, (k & 255) >> 5, sc, mn);
+      out[idx] = (d * (float)sc) * q - (dmin * (float)mn);
+    } else {
+      const unsigned lo = rr < 4 ? (byte & 15u) : (byte >> 4);
+      const int F = r >> 2;   // k-order word
+      const unsigned hword = wh[(((size_t)nt * (K >> 5) + kc) * 64 + lane) * 2 + (F >> 2)];
+      const unsigned hi2 = (hword >> (8 * (r & 3) + 2 * (F & 3))) & 3u;
+      const int q = (int)(lo | (hi2 << 4)) - 32;
+      const int si = (k & 255) >> 4;
+      const int sc = (int)(signed char)((hw[si >> 2] >> (8 * (si & 3))) & 255u);
+      out[idx] = __half2float(dd[((size_t)nt * (K >> 8) + (k >> 8)) * 64 + lane]) * (float)sc * (float)q;
+    }
+  }
+}
+int bzk_dequant_gq(hipStream_t s, const LinearDev& L, float* out) {
+  const int fmt = L.kind == LK_Q80 ? GQ_Q80 : (L.kind == LK_Q4K ? GQ_Q4K : GQ_Q6K);
+  hipLaunchKernelGGL(k_dequant_gq, dim3(2048), dim3(256), 0, s, fmt, (const uint32_t*)L.w, (const uint32_t*)L.zeros, (const uint32_t*)L.hdr,
+                     (const __half*)L.scales, L.N, L.K, out);
+  BZ_HIP(hipGetLastError());
+  return BZ_OK;
+}
+
+// partial argmax over a plain f32 vector (quantised lm_head path): nb blocks -> pval/pidx
+int bzk_argmax_partials(hipStream_t s, const float* v, long long n, float* pval, int* pidx, int nb);
+
 int bzk_gemv(hipStream_t s, const LinearDev& L, const Pro& pro, const GemvOut& out, int act) {
   if (L.kind == LK_Q4G) {
     if (!out.acc) BZ_FAIL(BZ_E_INVALID, "q4g gemv needs a fixed-point accumulator");
@@ -872,6 +1277,28 @@ int bzk_gemv(hipStream_t s, const LinearDev& L, const Pro& pro, const GemvOut& o
     dim3(256), smem, s, (const void*)L.w, L.bias, L.N, L.K, rpw, pro, out.direct, act, out.amax_val, out.amax_idx, out.zero_buf, out.zero_n)
     if (L.wdt == BZ_F16) LAUNCH_ROWS(BZ_F16); else if (L.wdt == BZ_BF16) LAUNCH_ROWS(BZ_BF16); else LAUNCH_ROWS(BZ_F32);
 #undef LAUNCH_ROWS
+    BZ_HIP(hipGetLastError());
+    return BZ_OK;
+  }
+  if (L.kind == LK_Q80 || L.kind == LK_Q4K || L.kind == LK_Q6K) {
+    if (!out.acc) BZ_FAIL(BZ_E_INVALID, "block-quant gemv needs a fixed-point accumulator");
+    const int SB = L.K / 256, SBW = L.gw;
+    if (SBW <= 0 || SB % SBW || SBW > 8) BZ_FAIL(BZ_E_INVALID, "block-quant gemv: bad k-slice %d of %d superblocks", SBW, SB);
+    const int nst = (L.N + 255) / 256;
+    const int grid = nst * (SB / SBW);
+    const size_t smem = gq_smem(SBW);
+    const int maxj = pro.mode == PRO_NORM ? (pro.H + 1023) / 1024 : 1;
+    const char* label = L.kind == LK_Q80 ? "gemv_q8_0" : (L.kind == LK_Q4K ? "gemv_q4_K" : "gemv_q6_K");
+#define LAUNCH_GQ(FMT, MODE, FIX, MJ) BZ_LAUNCH(label, L.algo_bytes, (k_gemv_gq<FMT, MODE, FIX, MJ>), dim3(grid), dim3(256), smem, s, (const uint4*)L.w, \
+    (const uint2*)L.zeros, (const uint4*)L.hdr, (const __half*)L.scales, L.bias, L.N, L.K, SBW, nst, pro, out.acc, out.zero_buf, out.zero_n)
+#define LAUNCH_GQ_F(FMT, MODE, MJ) do { if (pro.src.fix) LAUNCH_GQ(FMT, MODE, 1, MJ); else LAUNCH_GQ(FMT, MODE, 0, MJ); } while (0)
+#define LAUNCH_GQ_M(FMT) do { if (pro.mode == PRO_PLAIN) LAUNCH_GQ_F(FMT, PRO_PLAIN, 1); else if (pro.mode == PRO_SILU) LAUNCH_GQ_F(FMT, PRO_SILU, 1); \
+    else if (maxj <= 1) LAUNCH_GQ_F(FMT, PRO_NORM, 1); else if (maxj <= 2) LAUNCH_GQ_F(FMT, PRO_NORM, 2); else if (maxj <= 4) LAUNCH_GQ_F(FMT, PRO_NORM, 4); \
+    else if (maxj <= 8) LAUNCH_GQ_F(FMT, PRO_NORM, 8); else BZ_FAIL(BZ_E_UNSUPPORTED, "hidden size %d too large for the fused norm prologue", pro.H); } while (0)
+    if (L.kind == LK_Q80) LAUNCH_GQ_M(GQ_Q80); else if (L.kind == LK_Q4K) LAUNCH_GQ_M(GQ_Q4K); else LAUNCH_GQ_M(GQ_Q6K);
+#undef LAUNCH_GQ_M
+#undef LAUNCH_GQ_F
+#undef LAUNCH_GQ
     BZ_HIP(hipGetLastError());
     return BZ_OK;
   }
@@ -1765,6 +2192,12 @@ __global__ __launch_bounds__(256) void k_penalised_argmax(const float* logits, l
     __syncthreads();
   }
   if (threadIdx.x == 0) { pval[blockIdx.x] = sv[0]; pidx[blockIdx.x] = si[0]; }
+}
+
+int bzk_argmax_partials(hipStream_t s, const float* v, long long n, float* pval, int* pidx, int nb) {
+  hipLaunchKernelGGL(k_penalised_argmax, dim3(nb), dim3(256), 0, s, v, n, (const long long*)nullptr, (const int*)nullptr, 0, 1.0f, 0.f, 0.f, pval, pidx);
+  BZ_HIP(hipGetLastError());
+  return BZ_OK;
 }
 
 int bzk_logits_to_token(hipStream_t s, const float* logits, long long V, const long long* ids, const int* cnts, int n, float rp, float fp,

@@ -47,7 +47,8 @@ def _kv_dt(cfg):
     return {"f16": L.F16, "bf16": L.BF16, "f32": L.F32}[cfg["act_dtype"]]
 
 
-PRESETS = [("tiny-awq", {}), ("tiny-gptq", dict(act_order=True, bias=True)), ("tiny-gptq", {}), ("tiny-bf16", {})]
+PRESETS = [("tiny-awq", {}), ("tiny-gptq", dict(act_order=True, bias=True)), ("tiny-gptq", {}), ("tiny-bf16", {}),
+           ("tiny-q8_0", {}), ("tiny-q4km", {})]   # GGUF: f32 activations, interleaved RoPE, Q6_K lm_head (Q4_K_M)
 
 
 @pytest.fixture(scope="module", params=PRESETS, ids=lambda p: p[0] + ("+" + "+".join(p[1]) if p[1] else ""))

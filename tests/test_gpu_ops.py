@@ -27,6 +27,18 @@ def tiny_gptq(device):
     return model, runtime.LoadedModel.from_synth(device, model), orc_py.OrcLlama(model)
 
 
+@pytest.fixture(scope="module")
+def tiny_q4km(device):
+    model = synth.make_llama("tiny-q4km")
+    return model, runtime.LoadedModel.from_synth(device, model), orc_py.OrcLlama(model)
+
+
+@pytest.fixture(scope="module")
+def tiny_q80(device):
+    model = synth.make_llama("tiny-q8_0")
+    return model, runtime.LoadedModel.from_synth(device, model), orc_py.OrcLlama(model)
+
+
 def _names(i=0):
     p = "model.layers.%d." % i
     return {"q": p + "self_attn.q_proj.weight", "k": p + "self_attn.k_proj.weight", "v": p + "self_attn.v_proj.weight",
@@ -43,6 +55,42 @@ def test_repack_dequant_bit_exact(fix, request):
         want = orc_py.OrcLinear(model["layers"][1][short]).dequant()
         got = lm.dequant(name)
         assert np.array_equal(got, want), (fix, short, np.abs(got - want).max())
+
+
+@pytest.mark.parametrize("fix", ["tiny_q4km", "tiny_q80"])
+def test_gguf_repack_dequant_bit_exact(fix, request):
+    """GGML Q8_0 / Q4_K / Q6_K blocks -> kernel layout is lossless: dequantising the repacked HBM layout equals the
+    oracle's ggml dequant of the raw blocks bit for bit (layer 0 of Q4_K_M carries Q6_K attn_v / ffn_down)."""
+    model, lm, _ = request.getfixturevalue(fix)
+    seen = set()
+    for layer in (0, 1, 3):
+        if layer >= model["config"]["n_layers"]:
+            continue
+        for short, name in _names(layer).items():
+            spec = model["layers"][layer][short]
+            seen.add(spec["ggml_type"])
+            want = orc_py.OrcLinear(spec).dequant()
+            got = lm.dequant(name)
+            assert np.array_equal(got, want), (fix, layer, short, spec["ggml_type"], np.abs(got - want).max())
+    want = orc_py.OrcLinear(model["lm_head"]).dequant()
+    assert np.array_equal(lm.dequant("lm_head.weight"), want)
+    assert seen == ({8} if fix == "tiny_q80" else {12, 14})
+
+
+@pytest.mark.parametrize("fix", ["tiny_q4km", "tiny_q80"])
+@pytest.mark.parametrize("short", ["q", "v", "gate", "down"])
+def test_gguf_matmul_vs_oracle(fix, short, request):
+    model, lm, _ = request.getfixturevalue(fix)
+    spec = model["layers"][0][short]
+    rng = np.random.default_rng(6)
+    x = rng.standard_normal((3, spec["K"])).astype(np.float32)
+    x[1] *= 50.0
+    x[2, ::5] = 0.0
+    want = orc_py.OrcLinear(spec).forward(x)
+    got = lm.quant_matmul(_names(0)[short], x)
+    # f32 activations through the 24-bit (per 32-k chunk) fixed-point split: |err| <= 2^-23 * chunk max per term
+    tol = 3e-6 * np.abs(want).max() + 1e-7
+    assert np.abs(got - want).max() <= tol, (np.abs(got - want).max(), tol)
 
 
 @pytest.mark.parametrize("fix", ["tiny_awq", "tiny_gptq"])
