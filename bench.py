@@ -77,6 +77,8 @@ def main():
 
     from blazr_amd import runtime, synth
 
+    if args.preset in synth.MAMBA_PRESETS:
+        return bench_mamba2(args, rank, local_rank, world, dist)
     cfg = synth.make_config(args.preset)
     need = args.prompt_len + args.warmup + args.steps + 8
     if need > cfg["max_seq_len"]:
@@ -174,6 +176,66 @@ def main():
                                          "decode tokens (%.1f s); host has %d logical CPUs" % (args.prompt_len, t_prefill, n_cpu - 1, t_decode, os.cpu_count())}
         out["parity"] = {"greedy_ids_match": cpu_tokens == tokens[:n_cpu], "n_tokens": n_cpu, "cpu": cpu_tokens, "gpu": tokens[:n_cpu]}
 
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def bench_mamba2(args, rank, local_rank, world, dist):
+    """Secondary workload (BASELINE.json configs[3]): Mamba2 decode, state + weights streamed once per token."""
+    from blazr_amd import replicas, runtime, synth
+    cfg = synth.make_mamba_config(args.preset)
+    dev = runtime.Device(local_rank)
+    t0 = time.time()
+    lm = runtime.LoadedModel.from_synth_streamed(dev, cfg)
+    load_s = time.time() - t0
+    w_bytes, s_bytes = synth.mamba2_bytes_per_token(cfg)
+    resident, per_token = lm.weight_bytes()
+    assert per_token == w_bytes, (per_token, w_bytes)
+    prompt = synth.prompt_tokens(args.prompt_len, cfg["vocab"])
+    st = runtime.LayeredSsmState(lm)
+    logits = lm.forward_with_ssm_state(prompt, st)
+    first = int(runtime.logits_to_token(dev, logits, [], []).to_numpy()[0])
+    graph = runtime.DecodeGraph(lm, st)
+    graph.seed_next_token(first, args.prompt_len)
+    for _ in range(args.warmup):
+        graph.replay()
+    dev.synchronize()
+    timer = hip_events(C.c_void_p(dev.stream()))
+    if dist is not None:
+        dist.barrier()
+    dev.synchronize()
+    t_host0 = time.perf_counter()
+    timer.start()
+    for _ in range(args.steps):
+        graph.replay()
+    timer.stop()
+    gpu_ms = timer.ms()
+    dev.synchronize()
+    host_ms = (time.perf_counter() - t_host0) * 1e3
+    if dist is not None:
+        dist.barrier()
+    n_gpus = max(world, 1)
+    tok_s, wall_ms = replicas.aggregate_tokens_per_s(max(gpu_ms, host_ms), args.steps, dist, "cuda" if dist is not None else None)
+    tokens = [first] + [graph.read_token(i) for i in range(args.warmup + args.steps)]
+    prof = lm.profile_step_ssm(st, tokens[-1], iters=4)
+    for p in prof:
+        p["avg_us"] = 1e3 * p["total_ms"] / max(p["launches"], 1)
+        p["gbs"] = (p["algo_bytes"] / 1e9) / (p["total_ms"] / 1e3) if p["total_ms"] > 0 and p["algo_bytes"] > 0 else None
+    dom = max(prof, key=lambda p: p["total_ms"])
+    algo = w_bytes + s_bytes
+    out = {"metric": "decode tokens/sec, %s seq=1 on MI355X (and HBM-roofline fraction)" % args.preset, "value": round(tok_s, 2), "unit": "tokens/s",
+           "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(wall_ms / args.steps, 5), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": cfg["act_dtype"], "data": "synthetic",
+           "config": {"workload": "%s greedy decode, batch 1, prompt %d, whole step as one hipGraph" % (args.preset, args.prompt_len),
+                      "algorithmic_bytes_per_token": algo, "weight_bytes": w_bytes, "state_bytes_rw": s_bytes, "resident_weight_bytes": resident},
+           "roofline": {"bound": "hbm", "kernel": dom["name"], "achieved": round(dom["gbs"], 1) if dom["gbs"] else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(dom["gbs"] / HBM_PEAK_GBS, 4) if dom["gbs"] else None, "traffic": None,
+                        "whole_step_frac": round(algo * (tok_s / n_gpus) / (HBM_PEAK_GBS * 1e9), 4)},
+           "kernels": [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in p.items()} for p in prof],
+           "gpu_ms_events": round(gpu_ms, 3), "host_ms": round(host_ms, 3), "load_s": round(load_s, 1), "tokens_head": tokens[:8]}
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

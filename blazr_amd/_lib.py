@@ -27,6 +27,7 @@ ABI_VERSION = 1
 FWD_ALL_LOGITS = 1
 ROPE_NONE, ROPE_LINEAR, ROPE_LLAMA3 = 0, 1, 2
 ARCH_LLAMA = 0
+ARCH_MAMBA2 = 1
 
 
 class BlazrHipError(RuntimeError):
@@ -41,7 +42,9 @@ class ModelConfig(C.Structure):
                 ("vocab", C.c_int32), ("max_seq_len", C.c_int32), ("rms_eps", C.c_float), ("act_dtype", C.c_int32),
                 ("tie_embeddings", C.c_int32), ("rope_theta", C.c_float), ("rope_interleaved", C.c_int32),
                 ("rope_scaling", C.c_int32), ("rope_factor", C.c_float), ("rope_low_freq_factor", C.c_float),
-                ("rope_high_freq_factor", C.c_float), ("rope_original_max_pos", C.c_int32), ("reserved", C.c_int32 * 16)]
+                ("rope_high_freq_factor", C.c_float), ("rope_original_max_pos", C.c_int32),
+                ("ssm_d_inner", C.c_int32), ("ssm_n_heads", C.c_int32), ("ssm_head_dim", C.c_int32), ("ssm_d_state", C.c_int32),
+                ("ssm_n_groups", C.c_int32), ("ssm_conv_kernel", C.c_int32), ("reserved", C.c_int32 * 10)]
 
 
 class GenConfig(C.Structure):
@@ -117,6 +120,12 @@ SYMBOLS = {
     "bz_decode_graph_free": (C.c_int, [P]),
     "bz_generate": (C.c_int, [P, P, C.c_int, C.POINTER(GenConfig), P, C.POINTER(GenStats)]),
     "bz_profile_step": (C.c_int, [P, P, C.c_int64, C.c_int, C.c_int, C.POINTER(KernelTime), C.c_int, C.POINTER(C.c_int)]),
+    "bz_profile_step_ssm": (C.c_int, [P, P, C.c_int64, C.c_int, C.POINTER(KernelTime), C.c_int, C.POINTER(C.c_int)]),
+    "bz_ssm_state_create": (C.c_int, [P, C.c_int, C.c_int, C.POINTER(P)]),
+    "bz_ssm_state_free": (C.c_int, [P]),
+    "bz_ssm_state_reset": (C.c_int, [P]),
+    "bz_forward_ssm": (C.c_int, [P, P, C.c_int, P, P, C.c_uint32]),
+    "bz_decode_graph_capture_ssm": (C.c_int, [P, P, C.POINTER(P)]),
     "bz_tune_gemv": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "bz_quant_matmul": (C.c_int, [P, C.c_char_p, P, C.c_int, P]),
     "bz_dequant": (C.c_int, [P, C.c_char_p, P]),

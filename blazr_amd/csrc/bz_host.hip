@@ -224,7 +224,15 @@ struct LayerDev {
   FusedLinear qkv, o, gateup, down;
 };
 
+struct MambaLayerDev {
+  float* norm = nullptr; float* conv_w = nullptr; float* conv_b = nullptr; float* dt_bias = nullptr; float* A_log = nullptr; float* D = nullptr;
+  float* gnorm = nullptr;
+  FusedLinear in_proj, out_proj;
+};
+
 struct bz_model {
+  std::vector<MambaLayerDev> mlayers;
+  float* xbc = nullptr; float* ybuf = nullptr;   // Mamba2 workspace
   bz_device* dev = nullptr;
   bz_model_config cfg;
   bool finalized = false;
@@ -267,12 +275,20 @@ static int upload(bz_device* d, void** out, const void* host, size_t bytes) {
 extern "C" int bz_model_create(bz_device* dev, const bz_model_config* cfg, bz_model** out) {
   if (!dev || !cfg || !out) BZ_FAIL(BZ_E_INVALID, "bz_model_create: null argument");
   if (cfg->abi_version != BZ_ABI_VERSION) BZ_FAIL(BZ_E_INVALID, "config abi_version %d != %d", cfg->abi_version, BZ_ABI_VERSION);
-  if (cfg->arch != BZ_ARCH_LLAMA) BZ_FAIL(BZ_E_UNSUPPORTED, "arch %d not implemented in this build (llama family only)", cfg->arch);
+  if (cfg->arch != BZ_ARCH_LLAMA && cfg->arch != BZ_ARCH_MAMBA2) BZ_FAIL(BZ_E_UNSUPPORTED, "arch %d not implemented in this build (llama family and mamba2)", cfg->arch);
+  if (cfg->arch == BZ_ARCH_MAMBA2) {
+    if (cfg->hidden <= 0 || cfg->n_layers <= 0 || cfg->vocab <= 0 || cfg->ssm_d_inner <= 0 || cfg->ssm_n_heads <= 0 || cfg->ssm_head_dim <= 0 ||
+        cfg->ssm_d_state <= 0 || cfg->ssm_n_groups <= 0 || cfg->ssm_conv_kernel < 2)
+      BZ_FAIL(BZ_E_INVALID, "config: non-positive mamba2 dimension");
+    if (cfg->ssm_n_heads * cfg->ssm_head_dim != cfg->ssm_d_inner || cfg->ssm_n_heads % cfg->ssm_n_groups || cfg->hidden % 8 || cfg->ssm_d_inner % 8)
+      BZ_FAIL(BZ_E_INVALID, "config: inconsistent mamba2 dimensions");
+  } else {
   if (cfg->hidden <= 0 || cfg->n_layers <= 0 || cfg->n_heads <= 0 || cfg->n_kv_heads <= 0 || cfg->head_dim <= 0 || cfg->inter <= 0 ||
       cfg->vocab <= 0 || cfg->max_seq_len <= 0)
     BZ_FAIL(BZ_E_INVALID, "config: non-positive dimension");
   if (cfg->n_heads % cfg->n_kv_heads) BZ_FAIL(BZ_E_INVALID, "config: n_heads %% n_kv_heads != 0");
   if (cfg->hidden % 8 || cfg->head_dim % 8 || cfg->inter % 8) BZ_FAIL(BZ_E_UNSUPPORTED, "config: hidden/head_dim/inter must be multiples of 8");
+  }
   if (cfg->act_dtype != BZ_F32 && cfg->act_dtype != BZ_F16 && cfg->act_dtype != BZ_BF16) BZ_FAIL(BZ_E_INVALID, "config: bad act_dtype");
   bz_model* m = new bz_model();
   m->dev = dev; m->cfg = *cfg;
@@ -310,10 +326,12 @@ static int check_add(bz_model* m, const char* name) {
 
 extern "C" int bz_model_add_dense(bz_model* m, const char* name, int dtype, const int64_t* shape, int ndim, const void* host) {
   BZ_TRY(check_add(m, name));
-  if (!host || ndim < 1 || ndim > 2) BZ_FAIL(BZ_E_INVALID, "add_dense '%s': need 1-D or 2-D host data", name);
+  if (!host || ndim < 1 || ndim > 3) BZ_FAIL(BZ_E_INVALID, "add_dense '%s': need 1-D .. 3-D host data", name);
   if (dtype != BZ_F32 && dtype != BZ_F16 && dtype != BZ_BF16) BZ_FAIL(BZ_E_INVALID, "add_dense '%s': dtype %d", name, dtype);
   RawTensor r; r.kind = 0; r.dtype = dtype; r.shape.assign(shape, shape + ndim);
-  r.N = shape[0]; r.K = ndim == 2 ? shape[1] : 1;
+  r.N = shape[0]; r.K = 1;
+  for (int i = 1; i < ndim; i++) r.K *= shape[i];   // conv1d.weight [C,1,k] folds to [C,k]
+  for (int i = 0; i < ndim; i++) if (shape[i] <= 0) BZ_FAIL(BZ_E_INVALID, "add_dense '%s': non-positive dimension", name);
   r.bytes = (size_t)r.N * r.K * bz_dtype_size(dtype);
   BZ_TRY(upload(m->dev, &r.d0, host, r.bytes));
   m->raw[name] = r;
@@ -597,7 +615,7 @@ static int build_fused(bz_model* m, const std::vector<std::string>& names, Fused
   return BZ_OK;
 }
 
-static int take_vector_f32(bz_model* m, const std::string& name, int n, float** out) {
+static int take_vector_f32(bz_model* m, const std::string& name, int n, float** out, bool round_to_act = true) {
   auto it = m->raw.find(name);
   if (it == m->raw.end()) BZ_FAIL(BZ_E_NOTFOUND, "finalize: tensor '%s' was not added", name.c_str());
   RawTensor& r = it->second;
@@ -611,7 +629,8 @@ static int take_vector_f32(bz_model* m, const std::string& name, int n, float** 
     if (r.dtype == BZ_F32) v = ((float*)host.data())[i];
     else if (r.dtype == BZ_F16) v = __half2float(((__half*)host.data())[i]);
     else { uint32_t u = (uint32_t)((uint16_t*)host.data())[i] << 16; memcpy(&v, &u, 4); }
-    if (m->cfg.act_dtype == BZ_F16) v = __half2float(__float2half(v));
+    if (!round_to_act) {}
+    else if (m->cfg.act_dtype == BZ_F16) v = __half2float(__float2half(v));
     else if (m->cfg.act_dtype == BZ_BF16) { uint32_t u; memcpy(&u, &v, 4); u += 0x7fffu + ((u >> 16) & 1u); u &= 0xffff0000u; memcpy(&v, &u, 4); }
     f[i] = v;
   }
@@ -651,10 +670,13 @@ static void rope_tables_host(const bz_model_config& c, std::vector<float>& cs, s
   }
 }
 
+static int finalize_mamba2(bz_model* m);
+
 extern "C" int bz_model_finalize(bz_model* m) {
   if (!m) BZ_FAIL(BZ_E_INVALID, "null model");
   if (m->finalized) BZ_FAIL(BZ_E_INVALID, "model already finalized");
   BZ_HIP(hipSetDevice(m->dev->id));
+  if (m->cfg.arch == BZ_ARCH_MAMBA2) return finalize_mamba2(m);
   const bz_model_config& c = m->cfg;
   const int H = c.hidden, nq = c.n_heads, nkv = c.n_kv_heads, hd = c.head_dim, I = c.inter, V = c.vocab;
   char nm[256];
@@ -749,6 +771,113 @@ extern "C" int bz_rope_caches(bz_model* m, float* c, float* s) {
   size_t n = (size_t)m->cfg.max_seq_len * (m->cfg.head_dim / 2) * 4;
   if (c) BZ_HIP(hipMemcpy(c, m->cos_t, n, hipMemcpyDeviceToHost));
   if (s) BZ_HIP(hipMemcpy(s, m->sin_t, n, hipMemcpyDeviceToHost));
+  return BZ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Mamba2 (BZ_ARCH_MAMBA2): HF Mamba2 tensor names
+// ---------------------------------------------------------------------------------------------------------
+static int finalize_mamba2(bz_model* m) {
+  const bz_model_config& c = m->cfg;
+  const int D = c.hidden, DI = c.ssm_d_inner, NH = c.ssm_n_heads, NS = c.ssm_d_state, G = c.ssm_n_groups, KC = c.ssm_conv_kernel, V = c.vocab;
+  const int conv_dim = DI + 2 * G * NS, d_in = 2 * DI + 2 * G * NS + NH;
+  char nm[256];
+  m->mlayers.resize(c.n_layers);
+  for (int l = 0; l < c.n_layers; l++) {
+    MambaLayerDev& L = m->mlayers[l];
+    snprintf(nm, sizeof nm, "backbone.layers.%d.", l);
+    std::string p = nm;
+    BZ_TRY(take_vector_f32(m, p + "norm.weight", D, &L.norm));
+    BZ_TRY(take_vector_f32(m, p + "mixer.conv1d.weight", conv_dim * KC, &L.conv_w));
+    BZ_TRY(take_vector_f32(m, p + "mixer.conv1d.bias", conv_dim, &L.conv_b));
+    BZ_TRY(take_vector_f32(m, p + "mixer.dt_bias", NH, &L.dt_bias, false));   // kept as stored (f32 in HF checkpoints)
+    BZ_TRY(take_vector_f32(m, p + "mixer.A_log", NH, &L.A_log, false));   // kept as stored (f32 in HF checkpoints)
+    BZ_TRY(take_vector_f32(m, p + "mixer.D", NH, &L.D, false));   // kept as stored (f32 in HF checkpoints)
+    BZ_TRY(take_vector_f32(m, p + "mixer.norm.weight", DI, &L.gnorm));
+    BZ_TRY(build_fused(m, {p + "mixer.in_proj"}, &L.in_proj));
+    BZ_TRY(build_fused(m, {p + "mixer.out_proj"}, &L.out_proj));
+    if (L.in_proj.N != d_in || L.in_proj.K != D || L.out_proj.N != D || L.out_proj.K != DI) BZ_FAIL(BZ_E_INVALID, "layer %d: in_proj/out_proj shapes do not match the config", l);
+    if (L.in_proj.fix_out || L.out_proj.fix_out) BZ_FAIL(BZ_E_UNSUPPORTED, "mamba2: quantised projections are not implemented (dense f16/bf16/f32)");
+  }
+  BZ_TRY(take_vector_f32(m, "backbone.norm_f.weight", D, &m->final_norm));
+  {
+    auto it = m->raw.find("backbone.embeddings.weight");
+    if (it == m->raw.end()) BZ_FAIL(BZ_E_NOTFOUND, "finalize: 'backbone.embeddings.weight' was not added");
+    RawTensor& r = it->second;
+    if (r.kind != 0 || r.N != V || r.K != D) BZ_FAIL(BZ_E_INVALID, "finalize: embeddings must be dense [vocab, hidden]");
+    m->embed = r.d0; m->embed_dt = r.dtype; r.d0 = nullptr; m->owned.push_back(m->embed); r.consumed = true;
+    m->resident += r.bytes;
+    if (c.tie_embeddings || !m->raw.count("lm_head.weight")) {
+      LinearDev L; L.kind = LK_ROWS; L.N = V; L.K = D; L.wdt = m->embed_dt; L.w = m->embed; L.owned = false; L.bytes = 0; L.algo_bytes = r.bytes;
+      m->lm_head.parts.push_back(L); m->lm_head.n_off.push_back(0); m->lm_head.N = V; m->lm_head.K = D; m->lm_head.fix_out = false;
+      m->named["lm_head.weight"] = L;
+    } else {
+      BZ_TRY(build_fused(m, {"lm_head"}, &m->lm_head));
+      if (m->lm_head.fix_out) BZ_FAIL(BZ_E_UNSUPPORTED, "mamba2: quantised lm_head is not implemented");
+    }
+  }
+  for (auto& kv : m->raw) if (!kv.second.consumed) BZ_FAIL(BZ_E_INVALID, "finalize: tensor '%s' is not used by this architecture", kv.first.c_str());
+  m->raw.clear();
+  void* p;
+  m->ring_n = std::max(std::max(d_in, DI), D);
+  for (int i = 0; i < 3; i++) {
+    BZ_TRY(dev_alloc(m, &p, (size_t)m->ring_n * 8)); m->ring[i] = (long long*)p; BZ_HIP(hipMemset(p, 0, (size_t)m->ring_n * 8));
+    BZ_TRY(dev_alloc(m, &p, (size_t)m->ring_n * 4)); m->dring[i] = (float*)p; BZ_HIP(hipMemset(p, 0, (size_t)m->ring_n * 4));
+  }
+  for (int i = 0; i < 2; i++) { BZ_TRY(dev_alloc(m, &p, (size_t)D * 4)); m->hbuf[i] = (float*)p; }
+  BZ_TRY(dev_alloc(m, &p, (size_t)conv_dim * 4)); m->xbc = (float*)p;
+  BZ_TRY(dev_alloc(m, &p, (size_t)DI * 4)); m->ybuf = (float*)p;
+  BZ_TRY(dev_alloc(m, &p, (size_t)V * 4)); m->logits = (float*)p;
+  m->nparts = bzk_gemv_rows_blocks(m->lm_head.parts[0]);
+  BZ_TRY(dev_alloc(m, &p, (size_t)m->nparts * 4)); m->pval = (float*)p;
+  BZ_TRY(dev_alloc(m, &p, (size_t)m->nparts * 4)); m->pidx = (int*)p;
+  BZ_TRY(dev_alloc(m, &p, 64)); m->tok_tmp = (long long*)p;
+  BZ_TRY(dev_alloc(m, &p, 64)); m->pos_tmp = (int*)p;
+  const size_t act_b = bz_dtype_size(c.act_dtype);
+  m->per_token = (size_t)D * bz_dtype_size(m->embed_dt) + (size_t)D * act_b;
+  for (auto& L : m->mlayers) {
+    for (FusedLinear* F : {&L.in_proj, &L.out_proj}) for (auto& P : F->parts) { m->resident += P.bytes; m->per_token += P.algo_bytes; }
+    m->per_token += (size_t)(conv_dim * (KC + 1) + 3 * NH + DI + D) * act_b;
+  }
+  for (auto& L : m->lm_head.parts) { m->resident += L.bytes; m->per_token += L.algo_bytes; }
+  BZ_HIP(hipDeviceSynchronize());
+  m->finalized = true;
+  return BZ_OK;
+}
+
+extern "C" int bz_ssm_state_create(bz_model* m, int batch, int dtype, bz_ssm_state** out) {
+  if (!m || !m->finalized || m->cfg.arch != BZ_ARCH_MAMBA2 || !out) BZ_FAIL(BZ_E_INVALID, "ssm_state_create: needs a finalized mamba2 model");
+  if (batch != 1) BZ_FAIL(BZ_E_UNSUPPORTED, "ssm state: batch %d (single-stream decode only)", batch);
+  if (dtype != BZ_F32 && dtype != BZ_F16 && dtype != BZ_BF16) BZ_FAIL(BZ_E_INVALID, "ssm state: dtype %d", dtype);
+  if (dtype != m->cfg.act_dtype) BZ_FAIL(BZ_E_UNSUPPORTED, "ssm state dtype must equal the model's activation dtype");
+  BZ_HIP(hipSetDevice(m->dev->id));
+  const bz_model_config& c = m->cfg;
+  bz_ssm_state* s = new bz_ssm_state();
+  s->dev = m->dev; s->layers = c.n_layers; s->n_heads = c.ssm_n_heads; s->head_dim = c.ssm_head_dim; s->d_state = c.ssm_d_state;
+  s->conv_dim = c.ssm_d_inner + 2 * c.ssm_n_groups * c.ssm_d_state; s->kc = c.ssm_conv_kernel; s->dtype = dtype;
+  const size_t sb = (size_t)s->layers * s->n_heads * s->head_dim * s->d_state * bz_dtype_size(dtype);
+  const size_t cb = (size_t)s->layers * s->conv_dim * (s->kc - 1) * 4;
+  if (hipMalloc(&s->ssm, sb) != hipSuccess || hipMalloc((void**)&s->conv, cb) != hipSuccess) { delete s; BZ_FAIL(BZ_E_OOM, "ssm state: hipMalloc failed"); }
+  BZ_HIP(hipMemsetAsync(s->ssm, 0, sb, m->dev->stream));
+  BZ_HIP(hipMemsetAsync(s->conv, 0, cb, m->dev->stream));
+  bz_dev_retain(m->dev);
+  *out = s;
+  return BZ_OK;
+}
+extern "C" int bz_ssm_state_free(bz_ssm_state* s) {
+  if (!s) return BZ_OK;
+  hipStreamSynchronize(s->dev->stream);
+  hipFree(s->ssm); hipFree(s->conv);
+  bz_dev_release(s->dev);
+  delete s;
+  return BZ_OK;
+}
+extern "C" int bz_ssm_state_reset(bz_ssm_state* s) {
+  if (!s) BZ_FAIL(BZ_E_INVALID, "null state");
+  const size_t sb = (size_t)s->layers * s->n_heads * s->head_dim * s->d_state * bz_dtype_size(s->dtype);
+  const size_t cb = (size_t)s->layers * s->conv_dim * (s->kc - 1) * 4;
+  BZ_HIP(hipMemsetAsync(s->ssm, 0, sb, s->dev->stream));
+  BZ_HIP(hipMemsetAsync(s->conv, 0, cb, s->dev->stream));
   return BZ_OK;
 }
 
@@ -868,6 +997,7 @@ struct StepIO {
   bool do_embed = true, do_head = true;
   float* hidden_out = nullptr; float* prev_out = nullptr;   // pieces API outputs (f32 rows)
   FinalArgs* final_args = nullptr;                          // graph mode: fused argmax + bookkeeping
+  bz_ssm_state* ssm = nullptr;                              // Mamba2: recurrent state instead of a KV cache
 };
 
 // Fixed-point accumulator ring.  Launch j accumulates into ring[j % 3] (which must be zero), reads the output of
@@ -1023,6 +1153,53 @@ static int llama_step(bz_model* m, const StepIO& io) {
   return BZ_OK;
 }
 
+
+// Mamba2 decode step (forward_with_ssm_state, /root/reference/src/engine/executor_generate.rs:137,148), 4 launches per layer:
+//   in_proj GEMV (prologue: residual add + RMSNorm) -> conv1d step + SiLU -> SSM recurrence -> out_proj GEMV (prologue: gate + grouped RMSNorm)
+static int mamba_step(bz_model* m, const StepIO& io) {
+  const bz_model_config& c = m->cfg;
+  hipStream_t st = m->dev->stream;
+  const int D = c.hidden, DI = c.ssm_d_inner, NH = c.ssm_n_heads, NS = c.ssm_d_state, G = c.ssm_n_groups, KC = c.ssm_conv_kernel, act = c.act_dtype;
+  const int conv_dim = DI + 2 * G * NS;
+  bz_ssm_state* S = io.ssm;
+  int cur = 0;
+  RingState rs;
+  VSrc prev{nullptr, 0};
+  BZ_TRY(bzk_embed(st, m->embed, m->embed_dt, io.d_tok, D, act, m->hbuf[cur]));
+  for (int l = 0; l < c.n_layers; l++) {
+    const MambaLayerDev& L = m->mlayers[l];
+    Pro pn{}; pn.mode = PRO_NORM; pn.src = prev; pn.h_in = m->hbuf[cur]; pn.h_out = m->hbuf[cur ^ 1]; pn.norm_w = L.norm; pn.eps = c.rms_eps; pn.H = D; pn.act = act;
+    VSrc zx;
+    BZ_TRY(run_fused(m, L.in_proj, pn, rs, &zx));
+    cur ^= 1;
+    const float* zxp = (const float*)zx.p;
+    BZ_TRY(bzk_conv_step(st, zxp, DI, conv_dim, KC, L.conv_w, L.conv_b, S->conv + (size_t)l * conv_dim * (KC - 1), act, m->xbc));
+    SsmArgs sa{};
+    sa.xbc = m->xbc; sa.zxbcdt = zxp; sa.dt_off = DI + conv_dim; sa.dt_bias = L.dt_bias; sa.A_log = L.A_log; sa.D = L.D;
+    sa.state = (char*)S->ssm + (size_t)l * NH * c.ssm_head_dim * NS * bz_dtype_size(S->dtype); sa.sdt = S->dtype;
+    sa.n_heads = NH; sa.head_dim = c.ssm_head_dim; sa.d_state = NS; sa.n_groups = G; sa.d_inner = DI; sa.act = act; sa.y = m->ybuf;
+    BZ_TRY(bzk_ssm_step(st, sa));
+    Pro pg{}; pg.mode = PRO_GATED; pg.src = VSrc{m->ybuf, 0}; pg.h_in = zxp; pg.norm_w = L.gnorm; pg.eps = c.rms_eps; pg.H = DI; pg.act = act; pg.aux = G;
+    VSrc ov;
+    BZ_TRY(run_fused(m, L.out_proj, pg, rs, &ov));
+    prev = ov;
+  }
+  if (io.do_head) {
+    Pro ph{}; ph.mode = PRO_NORM; ph.src = prev; ph.h_in = m->hbuf[cur]; ph.h_out = nullptr; ph.norm_w = m->final_norm; ph.eps = c.rms_eps; ph.H = D; ph.act = act;
+    GemvOut o{};
+    o.direct = m->logits; o.amax_val = m->pval; o.amax_idx = m->pidx;
+    BZ_TRY(bzk_gemv(st, m->lm_head.parts[0], ph, o, act));
+    if (io.final_args) {
+      FinalArgs fa = *io.final_args;
+      fa.pval = m->pval; fa.pidx = m->pidx; fa.nparts = m->nparts;
+      BZ_TRY(bzk_argmax_final(st, fa));
+    }
+  }
+  return BZ_OK;
+}
+
+static int model_step(bz_model* m, const StepIO& io) { return m->cfg.arch == BZ_ARCH_MAMBA2 ? mamba_step(m, io) : llama_step(m, io); }
+
 static int check_fwd(bz_model* m, const bz_tensor* tokens, int S) {
   if (!m || !m->finalized) BZ_FAIL(BZ_E_INVALID, "forward: model not finalized");
   if (!tokens || tokens->dtype != BZ_I64 || tokens->nbytes < (size_t)S * 8 || S <= 0) BZ_FAIL(BZ_E_INVALID, "forward: tokens must be an I64 tensor with >= S elements");
@@ -1040,6 +1217,7 @@ static int emit_logits(bz_model* m, bz_tensor* logits_out, int row) {
 extern "C" int bz_forward_kv(bz_model* m, const bz_tensor* tokens, int S, bz_kv* kv, int position, bz_tensor* logits_out, uint32_t flags) {
   BZ_TRY(check_fwd(m, tokens, S));
   BZ_TRACE("forward_kv: S=%d position=%d", S, position);
+  if (m->cfg.arch != BZ_ARCH_LLAMA) BZ_FAIL(BZ_E_INVALID, "forward_kv: model has no KV cache (use bz_forward_ssm)");
   if (!kv || kv->layers != m->cfg.n_layers || kv->n_kv != m->cfg.n_kv_heads || kv->hd != m->cfg.head_dim) BZ_FAIL(BZ_E_INVALID, "forward_kv: cache does not match the model");
   if (position < 0 || position + S > m->cfg.max_seq_len) BZ_FAIL(BZ_E_INVALID, "forward_kv: position %d + S %d exceeds max_seq_len %d", position, S, m->cfg.max_seq_len);
   BZ_TRY(kv_grow(kv, position + S));
@@ -1059,6 +1237,7 @@ extern "C" int bz_forward_kv(bz_model* m, const bz_tensor* tokens, int S, bz_kv*
 extern "C" int bz_forward_paged(bz_model* m, const bz_tensor* tokens, int S, bz_paged_kv* kv, const bz_tensor* slot_mapping,
                                 const bz_tensor* block_table, int n_table, int seq_len_k, int start_pos, bz_tensor* logits_out, uint32_t flags) {
   BZ_TRY(check_fwd(m, tokens, S));
+  if (m->cfg.arch != BZ_ARCH_LLAMA) BZ_FAIL(BZ_E_INVALID, "forward_paged: model has no KV cache (use bz_forward_ssm)");
   if (!kv || kv->layers != m->cfg.n_layers || kv->n_kv != m->cfg.n_kv_heads || kv->hd != m->cfg.head_dim) BZ_FAIL(BZ_E_INVALID, "forward_paged: cache does not match the model");
   if (!slot_mapping || slot_mapping->dtype != BZ_I32 || slot_mapping->nbytes < (size_t)S * 4) BZ_FAIL(BZ_E_INVALID, "forward_paged: slot_mapping must be I32[S]");
   if (!block_table || block_table->dtype != BZ_I32 || block_table->nbytes < (size_t)n_table * 4) BZ_FAIL(BZ_E_INVALID, "forward_paged: block_table must be I32[n_table]");
@@ -1079,6 +1258,29 @@ extern "C" int bz_forward_paged(bz_model* m, const bz_tensor* tokens, int S, bz_
   return BZ_OK;
 }
 
+static int check_ssm(bz_model* m, bz_ssm_state* st) {
+  const bz_model_config& c = m->cfg;
+  if (c.arch != BZ_ARCH_MAMBA2) BZ_FAIL(BZ_E_INVALID, "forward_ssm: model is not a mamba2 model");
+  if (!st || st->layers != c.n_layers || st->n_heads != c.ssm_n_heads || st->head_dim != c.ssm_head_dim || st->d_state != c.ssm_d_state ||
+      st->kc != c.ssm_conv_kernel || st->conv_dim != c.ssm_d_inner + 2 * c.ssm_n_groups * c.ssm_d_state || st->dtype != c.act_dtype)
+    BZ_FAIL(BZ_E_INVALID, "forward_ssm: state does not match the model");
+  return BZ_OK;
+}
+
+extern "C" int bz_forward_ssm(bz_model* m, const bz_tensor* tokens, int S, bz_ssm_state* st, bz_tensor* logits_out, uint32_t flags) {
+  BZ_TRY(check_fwd(m, tokens, S));
+  BZ_TRY(check_ssm(m, st));
+  const bool all = flags & BZ_FWD_ALL_LOGITS;
+  for (int s = 0; s < S; s++) {
+    StepIO io{};
+    io.ssm = st; io.d_tok = (const long long*)tokens->ptr + s;
+    io.do_head = all || s == S - 1;
+    BZ_TRY(mamba_step(m, io));
+    if (io.do_head) BZ_TRY(emit_logits(m, logits_out, all ? s : 0));
+  }
+  return BZ_OK;
+}
+
 extern "C" int bz_forward_embed(bz_model* m, const bz_tensor* tokens, int S, bz_tensor* hidden_out) {
   BZ_TRY(check_fwd(m, tokens, S));
   const int H = m->cfg.hidden;
@@ -1090,6 +1292,7 @@ extern "C" int bz_forward_embed(bz_model* m, const bz_tensor* tokens, int S, bz_
 
 extern "C" int bz_forward_layers_range(bz_model* m, bz_tensor* hidden, bz_tensor* prev_mlp, int* has_prev, int S, bz_kv* kv, int start, int end, int position) {
   if (!m || !m->finalized) BZ_FAIL(BZ_E_INVALID, "model not finalized");
+  if (m->cfg.arch != BZ_ARCH_LLAMA) BZ_FAIL(BZ_E_UNSUPPORTED, "layers_range: llama family only");
   const int H = m->cfg.hidden;
   if (!hidden || hidden->dtype != BZ_F32 || hidden->nbytes < (size_t)S * H * 4 || !prev_mlp || prev_mlp->dtype != BZ_F32 || prev_mlp->nbytes < (size_t)S * H * 4 || !has_prev)
     BZ_FAIL(BZ_E_INVALID, "layers_range: hidden / prev_mlp must be F32 [S,hidden]");
@@ -1136,7 +1339,24 @@ extern "C" int bz_forward_head(bz_model* m, const bz_tensor* hidden, const bz_te
 // measurement: per-kernel dispatch times of real decode steps (rocprof-comparable kernel durations
 // taken with HIP events on the launch stream)
 // ---------------------------------------------------------------------------------------------------------
+static int profile_collect(BzTimingSink& sink, int rc, bz_kernel_time* out, int max_out, int* n_out) {
+  int n = 0;
+  for (auto& r : sink.recs) {
+    float ms = 0.f;
+    if (rc == BZ_OK && hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+      int j = 0;
+      for (; j < n; j++) if (strcmp(out[j].name, r.label) == 0) break;
+      if (j == n && n < max_out) { memset(&out[n], 0, sizeof(out[n])); strncpy(out[n].name, r.label, sizeof(out[n].name) - 1); n++; }
+      if (j < n) { out[j].launches++; out[j].total_ms += ms; out[j].algo_bytes += r.bytes; }
+    }
+    hipEventDestroy(r.e0); hipEventDestroy(r.e1);
+  }
+  *n_out = n;
+  return rc;
+}
+
 extern "C" int bz_profile_step(bz_model* m, bz_kv* kv, int64_t token, int position, int iters, bz_kernel_time* out, int max_out, int* n_out) {
+  if (m && m->finalized && m->cfg.arch != BZ_ARCH_LLAMA) BZ_FAIL(BZ_E_UNSUPPORTED, "profile_step: llama family only (use bz_profile_step_ssm)");
   if (!m || !m->finalized || !kv || !out || !n_out || iters <= 0 || max_out <= 0) BZ_FAIL(BZ_E_INVALID, "profile_step: bad argument");
   if (token < 0 || token >= m->cfg.vocab || position < 0 || position + iters > m->cfg.max_seq_len) BZ_FAIL(BZ_E_INVALID, "profile_step: token/position out of range");
   BZ_HIP(hipSetDevice(m->dev->id));
@@ -1158,20 +1378,32 @@ extern "C" int bz_profile_step(bz_model* m, bz_kv* kv, int64_t token, int positi
     bzk_set_timing_sink(nullptr);
   }
   hipStreamSynchronize(st);
-  int n = 0;
-  for (auto& r : sink.recs) {
-    float ms = 0.f;
-    if (rc == BZ_OK && hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
-      int j = 0;
-      for (; j < n; j++) if (strcmp(out[j].name, r.label) == 0) break;
-      if (j == n && n < max_out) { memset(&out[n], 0, sizeof(out[n])); strncpy(out[n].name, r.label, sizeof(out[n].name) - 1); n++; }
-      if (j < n) { out[j].launches++; out[j].total_ms += ms; out[j].algo_bytes += r.bytes; }
-    }
-    hipEventDestroy(r.e0); hipEventDestroy(r.e1);
-  }
-  *n_out = n;
   if (kv->seq_len < position + iters) kv->seq_len = position + iters;
-  return rc;
+  return profile_collect(sink, rc, out, max_out, n_out);
+}
+
+extern "C" int bz_profile_step_ssm(bz_model* m, bz_ssm_state* ssm, int64_t token, int iters, bz_kernel_time* out, int max_out, int* n_out) {
+  if (!m || !m->finalized || !out || !n_out || iters <= 0 || max_out <= 0) BZ_FAIL(BZ_E_INVALID, "profile_step_ssm: bad argument");
+  BZ_TRY(check_ssm(m, ssm));
+  if (token < 0 || token >= m->cfg.vocab) BZ_FAIL(BZ_E_INVALID, "profile_step_ssm: token out of range");
+  BZ_HIP(hipSetDevice(m->dev->id));
+  hipStream_t st = m->dev->stream;
+  long long t = token;
+  BZ_HIP(hipMemcpyAsync(m->tok_tmp, &t, 8, hipMemcpyHostToDevice, st));
+  BZ_HIP(hipStreamSynchronize(st));
+  BzTimingSink sink;
+  int rc = BZ_OK;
+  for (int i = 0; i < iters && rc == BZ_OK; i++) {
+    FinalArgs fa{};
+    fa.tok_out = m->tok_tmp + 1;
+    StepIO io{};
+    io.ssm = ssm; io.d_tok = m->tok_tmp; io.final_args = &fa;
+    bzk_set_timing_sink(&sink);
+    rc = mamba_step(m, io);
+    bzk_set_timing_sink(nullptr);
+  }
+  hipStreamSynchronize(st);
+  return profile_collect(sink, rc, out, max_out, n_out);
 }
 
 __global__ void k_fill_u32(uint32_t* p, size_t n, uint32_t seed) {
@@ -1264,7 +1496,7 @@ struct bz_decode_graph {
   int* step = nullptr;              // device: replay counter
   long long* tok_log = nullptr;     // pinned host, written by the final kernel: log[step % LOGCAP]
   int* block_table = nullptr; int max_blocks = 0;
-  bz_kv* kv = nullptr; bz_paged_kv* pkv = nullptr;
+  bz_kv* kv = nullptr; bz_paged_kv* pkv = nullptr; bz_ssm_state* ssm = nullptr;
   std::vector<hipEvent_t> evs;
   long long replays = 0;
   static const int LOGCAP = 4096;
@@ -1283,10 +1515,10 @@ static int graph_capture_common(bz_decode_graph* g, const KvView& view) {
   FinalArgs fa{};
   fa.tok_out = g->tok_buf; fa.tok_log = g->tok_log; fa.step = g->step; fa.logcap = bz_decode_graph::LOGCAP; fa.pos = g->pos;
   StepIO io{};
-  io.kv = view; io.d_tok = g->tok_buf; io.d_pos = g->pos; io.final_args = &fa;
+  io.kv = view; io.d_tok = g->tok_buf; io.d_pos = g->pos; io.final_args = &fa; io.ssm = g->ssm;
   BZ_TRACE("graph: begin capture");
   BZ_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-  int rc = llama_step(m, io);
+  int rc = model_step(m, io);
   hipGraph_t graph = nullptr;
   hipError_t e = hipStreamEndCapture(st, &graph);
   BZ_TRACE("graph: end capture rc=%d hip=%d", rc, (int)e);
@@ -1301,6 +1533,7 @@ static int graph_capture_common(bz_decode_graph* g, const KvView& view) {
 
 extern "C" int bz_decode_graph_capture(bz_model* m, bz_kv* kv, bz_decode_graph** out) {
   if (!m || !m->finalized || !kv || !out) BZ_FAIL(BZ_E_INVALID, "graph capture: bad argument");
+  if (m->cfg.arch != BZ_ARCH_LLAMA) BZ_FAIL(BZ_E_INVALID, "graph capture: model has no KV cache (use bz_decode_graph_capture_ssm)");
   BZ_HIP(hipSetDevice(m->dev->id));
   // stable addresses: the cache must sit at full capacity (cuda_graphs.rs:70)
   BZ_TRY(kv_grow(kv, kv->max_len));
@@ -1314,6 +1547,7 @@ extern "C" int bz_decode_graph_capture(bz_model* m, bz_kv* kv, bz_decode_graph**
 }
 extern "C" int bz_decode_graph_capture_paged(bz_model* m, bz_paged_kv* kv, int max_blocks, bz_decode_graph** out) {
   if (!m || !m->finalized || !kv || !out || max_blocks <= 0) BZ_FAIL(BZ_E_INVALID, "graph capture: bad argument");
+  if (m->cfg.arch != BZ_ARCH_LLAMA) BZ_FAIL(BZ_E_INVALID, "graph capture: model has no KV cache (use bz_decode_graph_capture_ssm)");
   BZ_HIP(hipSetDevice(m->dev->id));
   bz_decode_graph* g = new bz_decode_graph();
   bz_dev_retain(m->dev); g->dev = m->dev;
@@ -1321,6 +1555,18 @@ extern "C" int bz_decode_graph_capture_paged(bz_model* m, bz_paged_kv* kv, int m
   BZ_HIP(hipMalloc(&g->block_table, (size_t)max_blocks * 4));
   BZ_HIP(hipMemset(g->block_table, 0, (size_t)max_blocks * 4));
   int rc = graph_capture_common(g, view_of(kv, g->block_table, nullptr));
+  if (rc != BZ_OK) { bz_decode_graph_free(g); return rc; }
+  *out = g;
+  return BZ_OK;
+}
+extern "C" int bz_decode_graph_capture_ssm(bz_model* m, bz_ssm_state* st, bz_decode_graph** out) {
+  if (!m || !m->finalized || !out) BZ_FAIL(BZ_E_INVALID, "graph capture: bad argument");
+  BZ_TRY(check_ssm(m, st));
+  BZ_HIP(hipSetDevice(m->dev->id));
+  bz_decode_graph* g = new bz_decode_graph();
+  bz_dev_retain(m->dev); g->dev = m->dev;
+  g->m = m; g->ssm = st;
+  int rc = graph_capture_common(g, KvView{});
   if (rc != BZ_OK) { bz_decode_graph_free(g); return rc; }
   *out = g;
   return BZ_OK;
@@ -1333,7 +1579,7 @@ extern "C" int bz_decode_graph_set_block_table(bz_decode_graph* g, const int32_t
 }
 extern "C" int bz_decode_graph_seed(bz_decode_graph* g, int64_t token, int position) {
   if (!g) BZ_FAIL(BZ_E_INVALID, "null graph");
-  if (position < 0 || position >= g->m->cfg.max_seq_len) BZ_FAIL(BZ_E_INVALID, "graph seed: position %d out of range", position);
+  if (position < 0 || (!g->ssm && position >= g->m->cfg.max_seq_len)) BZ_FAIL(BZ_E_INVALID, "graph seed: position %d out of range", position);
   hipStream_t st = g->m->dev->stream;
   long long t = token; int p = position, z = 0;
   BZ_HIP(hipMemcpyAsync(g->tok_buf, &t, 8, hipMemcpyHostToDevice, st));
@@ -1413,7 +1659,8 @@ extern "C" int bz_generate(bz_model* m, const int64_t* prompt, int n_prompt, con
   const int kv_dt = c.act_dtype;
   int rc = BZ_OK;
   bz_tensor *t_prompt = nullptr, *t_logits = nullptr, *t_tok = nullptr, *t_ids = nullptr, *t_cnts = nullptr, *t_slot = nullptr, *t_bt = nullptr;
-  bz_kv* kv = nullptr; bz_paged_kv* pkv = nullptr; bz_decode_graph* graph = nullptr;
+  bz_kv* kv = nullptr; bz_paged_kv* pkv = nullptr; bz_decode_graph* graph = nullptr; bz_ssm_state* ssm = nullptr;
+  const bool mamba = c.arch == BZ_ARCH_MAMBA2;   // executor_generate.rs:123-181
   std::vector<uint32_t> history(prompt, prompt + n_prompt);
   std::vector<int32_t> bt;
   int n_out = 0, finish = 0;
@@ -1426,7 +1673,10 @@ extern "C" int bz_generate(bz_model* m, const int64_t* prompt, int n_prompt, con
   GEN_TRY(bz_tensor_zeros(dev, BZ_I64, sh1, 1, &t_tok));
   GEN_TRY(bz_tensor_zeros(dev, BZ_I64, sh64, 1, &t_ids));
   GEN_TRY(bz_tensor_zeros(dev, BZ_I32, sh64, 1, &t_cnts));
-  if (gc->paged) {
+  if (mamba) {
+    GEN_TRY(bz_ssm_state_create(m, 1, c.act_dtype, &ssm));                       // :131-133 LayeredSsmState::new
+    GEN_TRY(bz_forward_ssm(m, t_prompt, n_prompt, ssm, t_logits, 0));            // :137
+  } else if (gc->paged) {
     const int bs = gc->block_size > 0 ? gc->block_size : 16;
     const int total = n_prompt + max_tokens;
     const int nblocks = (total + bs - 1) / bs + 4;  // executor_generate.rs:191-196
@@ -1454,7 +1704,8 @@ extern "C" int bz_generate(bz_model* m, const int64_t* prompt, int n_prompt, con
     int64_t tok;
     GEN_TRY(bz_argmax_to_buf(dev, t_logits, 1, c.vocab, t_tok));
     GEN_TRY(bz_tensor_to_host(t_tok, &tok, 8));
-    if (gc->paged) { GEN_TRY(bz_decode_graph_capture_paged(m, pkv, (int)bt.size(), &graph)); GEN_TRY(bz_decode_graph_set_block_table(graph, bt.data(), (int)bt.size())); }
+    if (mamba) GEN_TRY(bz_decode_graph_capture_ssm(m, ssm, &graph));
+    else if (gc->paged) { GEN_TRY(bz_decode_graph_capture_paged(m, pkv, (int)bt.size(), &graph)); GEN_TRY(bz_decode_graph_set_block_table(graph, bt.data(), (int)bt.size())); }
     else GEN_TRY(bz_decode_graph_capture(m, kv, &graph));
     GEN_TRY(bz_decode_graph_seed(graph, tok, n_prompt));
     BZ_TRACE("generate: graph captured and seeded with token %lld at position %d", (long long)tok, n_prompt);
@@ -1480,7 +1731,9 @@ extern "C" int bz_generate(bz_model* m, const int64_t* prompt, int n_prompt, con
       const bool last = i + 1 == max_tokens;
       // :372 the next forward is launched BEFORE the token is read back (token stays on device)
       if (!last) {
-        if (gc->paged) {
+        if (mamba) {
+          GEN_TRY(bz_forward_ssm(m, t_tok, 1, ssm, t_logits, 0));                  // :148
+        } else if (gc->paged) {
           const int bs = pkv->block_size, cur = pkv->seq_len;
           int32_t slot = bt[cur / bs] * bs + cur % bs;
           GEN_TRY(bz_tensor_copy_from_host(t_slot, &slot, 4));
@@ -1509,7 +1762,7 @@ done:
   bz_decode_graph_free(graph);
   bz_tensor_free(t_prompt); bz_tensor_free(t_logits); bz_tensor_free(t_tok); bz_tensor_free(t_ids); bz_tensor_free(t_cnts);
   bz_tensor_free(t_slot); bz_tensor_free(t_bt);
-  bz_kv_free(kv); bz_paged_kv_free(pkv);
+  bz_kv_free(kv); bz_paged_kv_free(pkv); bz_ssm_state_free(ssm);
   return rc;
 #undef GEN_TRY
 }

@@ -25,7 +25,7 @@ void bz_set_error(const char* fmt, ...);
 // (2^-32 units) accumulated by split-K GEMV blocks with integer atomics (exactly associative => deterministic).
 struct VSrc { const void* p; int fix; };
 
-enum { PRO_PLAIN = 0, PRO_NORM = 1, PRO_SILU = 2 };
+enum { PRO_PLAIN = 0, PRO_NORM = 1, PRO_SILU = 2, PRO_GATED = 3 };
 // How a GEMV block builds its activation slice x[k0, k0+KR):
 struct Pro {
   int mode;
@@ -37,6 +37,7 @@ struct Pro {
   int H;               // NORM: == K ; SILU: I
   int act;             // activation dtype for rounding (BZ_F32/F16/BF16)
   const int* perm;     // optional: x'[k] = x[perm[k]] (GPTQ act-order)
+  int aux;             // GATED: number of norm groups
   long long* stamps;   // diagnostic only (BZ_MLP_STAMPS): s_memrealtime at phase boundaries of block 0
   int dbg;             // tuning only (bz_tune_gemv): 1 = store instead of atomics, 2 = skip the dot4 work, 4 = skip quantisation
 };
@@ -90,6 +91,13 @@ struct bz_kv {
   int layers = 0, batch = 1, n_kv = 0, cap = 0, max_len = 0, hd = 0, dtype = BZ_F16;
   int seq_len = 0;
   void* k = nullptr; void* v = nullptr;   // [layer][kv_head][cap][hd]
+};
+
+struct bz_ssm_state {
+  bz_device* dev = nullptr;
+  int layers = 0, n_heads = 0, head_dim = 0, d_state = 0, conv_dim = 0, kc = 0, dtype = BZ_BF16;
+  void* ssm = nullptr;      // [layers][n_heads][head_dim][d_state] in dtype
+  float* conv = nullptr;    // [layers][conv_dim][kc-1] f32 (values representable in the activation dtype)
 };
 
 struct bz_paged_kv {
@@ -184,3 +192,17 @@ int bzk_rms_norm(hipStream_t s, const float* x, const float* prev, const float* 
 int bzk_rope(hipStream_t s, float* x, int S, int nh, int hd, int position, const float* cos_t, const float* sin_t, int interleaved,
              int act);
 int bzk_silu_mul(hipStream_t s, const float* g, const float* u, long long n, int act, float* y);
+
+// Mamba2 kernels
+int bzk_conv_step(hipStream_t s, const float* zxbcdt, int x_off, int conv_dim, int kc, const float* w, const float* b, float* conv_state, int act,
+                  float* xbc_out);
+struct SsmArgs {
+  const float* xbc;      // [d_inner | G*NS (B) | G*NS (C)] after conv + silu
+  const float* zxbcdt;   // raw in_proj output (dt at dt_off)
+  int dt_off;
+  const float* dt_bias; const float* A_log; const float* D;
+  void* state; int sdt;  // this layer's [n_heads][head_dim][d_state]
+  int n_heads, head_dim, d_state, n_groups, d_inner, act;
+  float* y;              // [d_inner]
+};
+int bzk_ssm_step(hipStream_t s, const SsmArgs& a);

@@ -164,6 +164,24 @@ __device__ void build_x_simple(const Pro& p, int k0, int KR, float* xs, float* r
         }
       }
     }
+  } else if (p.mode == PRO_GATED) {
+    // Mamba2 gated RMSNorm: v = R(y * R(silu(z))) ; x = R(w * R(v * rsqrt(mean_group(v^2) + eps)))   (src = y, h_in = z, H = d_inner)
+    const int G = p.aux > 0 ? p.aux : 1, gsz = p.H / G;
+    for (int g = 0; g < G; g++) {
+      float ss = 0.f;
+      for (int i = tid; i < gsz; i += 256) {
+        const int kk = g * gsz + i;
+        const float v = round_act(vsrc_get(p.src, kk, p.act) * round_act(silu_f(p.h_in[kk]), p.act), p.act);
+        xs[xs_pos<SWZ>(kk)] = v;
+        ss += v * v;
+      }
+      ss = block_sum256(ss, red);
+      const float rs = 1.0f / sqrtf(ss / (float)gsz + p.eps);
+      for (int i = tid; i < gsz; i += 256) {
+        const int kk = g * gsz + i;
+        xs[xs_pos<SWZ>(kk)] = round_act(p.norm_w[kk] * round_act(xs[xs_pos<SWZ>(kk)] * rs, p.act), p.act);
+      }
+    }
   } else {
     for (int base = 0; base < KR; base += 2048) {
 #pragma unroll
@@ -2274,6 +2292,100 @@ __global__ void k_silu_mul(const float* g, const float* u, long long n, int act,
 }
 int bzk_silu_mul(hipStream_t s, const float* g, const float* u, long long n, int act, float* y) {
   hipLaunchKernelGGL(k_silu_mul, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g, u, n, act, y);
+  BZ_HIP(hipGetLastError());
+  return BZ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Mamba2 single-token kernels: causal conv1d step, SSM state update + readout
+// ---------------------------------------------------------------------------------------------------------
+__global__ void k_conv_step(const float* zx, int x_off, int conv_dim, int kc, const float* w, const float* b, float* cs, int act, float* out) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= conv_dim) return;
+  float* st = cs + (size_t)ch * (kc - 1);
+  const float xr = zx[x_off + ch];
+  float a = 0.f;
+  for (int j = 0; j < kc - 1; j++) a += st[j] * w[(size_t)ch * kc + j];
+  a += xr * w[(size_t)ch * kc + kc - 1];
+  a = round_act(a + b[ch], act);
+  out[ch] = round_act(silu_f(a), act);
+  for (int j = 0; j + 1 < kc - 1; j++) st[j] = st[j + 1];
+  st[kc - 2] = xr;
+}
+int bzk_conv_step(hipStream_t s, const float* zxbcdt, int x_off, int conv_dim, int kc, const float* w, const float* b, float* conv_state, int act,
+                  float* xbc_out) {
+  BZ_LAUNCH("mamba2_conv_step", (double)conv_dim * (kc * 2 + 2) * 4, k_conv_step, dim3((conv_dim + 255) / 256), dim3(256), 0, s, zxbcdt, x_off, conv_dim, kc,
+            w, b, conv_state, act, xbc_out);
+  BZ_HIP(hipGetLastError());
+  return BZ_OK;
+}
+
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+
+// grid = n_heads; 256 threads = 64 rows (p) x 4 state quarters.  h = R(h * dA + (dt x) B); y = R(sum_n h C + D x)
+template <int SDT>
+__global__ __launch_bounds__(256) void k_ssm_step(SsmArgs a) {
+  __shared__ float sB[256], sC[256];
+  const int hd = blockIdx.x, tid = threadIdx.x;
+  const int NS = a.d_state, HD = a.head_dim;
+  const int g = hd / (a.n_heads / a.n_groups);
+  for (int i = tid; i < NS; i += 256) { sB[i] = a.xbc[a.d_inner + g * NS + i]; sC[i] = a.xbc[a.d_inner + a.n_groups * NS + g * NS + i]; }
+  const float dt = round_act(softplus_f(round_act(a.zxbcdt[a.dt_off + hd] + a.dt_bias[hd], a.act)), a.act);
+  const float dA = expf(dt * -expf(a.A_log[hd]));
+  const float Dh = a.D[hd];
+  __syncthreads();
+  const int q = tid & 3, nq = NS >> 2;            // this thread's quarter of the state row
+  for (int p0 = 0; p0 < HD; p0 += 64) {
+    const int p = p0 + (tid >> 2);
+    float acc = 0.f, xv = 0.f;
+    if (p < HD) {
+      xv = a.xbc[hd * HD + p];
+      const float dtx = dt * xv;
+      const size_t off = ((size_t)hd * HD + p) * NS + q * nq;
+      const bool vec = (SDT != BZ_F32) && (nq & 7) == 0;
+      if (vec) {
+        // 16-bit state: 8 elements per 16-byte load / store
+        if constexpr (SDT != BZ_F32) for (int n = 0; n < nq; n += 8) {
+          uint4* sp = (uint4*)((unsigned short*)a.state + off + n);
+          const uint4 raw = *sp;
+          unsigned u[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            float h0, h1;
+            unpack2<SDT>(u[j], h0, h1);
+            h0 = round_act(h0 * dA + dtx * sB[q * nq + n + 2 * j], a.act);
+            h1 = round_act(h1 * dA + dtx * sB[q * nq + n + 2 * j + 1], a.act);
+            acc += h0 * sC[q * nq + n + 2 * j];
+            acc += h1 * sC[q * nq + n + 2 * j + 1];
+            u[j] = pack2<SDT>(h0, h1);
+          }
+          *sp = make_uint4(u[0], u[1], u[2], u[3]);
+        }
+      } else {
+        for (int n = 0; n < nq; n++) {
+          float hcur;
+          if (SDT == BZ_F32) hcur = ((float*)a.state)[off + n];
+          else if (SDT == BZ_F16) hcur = __half2float(((__half*)a.state)[off + n]);
+          else hcur = __uint_as_float((unsigned)((unsigned short*)a.state)[off + n] << 16);
+          const float hn = round_act(hcur * dA + dtx * sB[q * nq + n], a.act);
+          acc += hn * sC[q * nq + n];
+          if (SDT == BZ_F32) ((float*)a.state)[off + n] = hn;
+          else if (SDT == BZ_F16) ((__half*)a.state)[off + n] = __float2half_rn(hn);
+          else ((unsigned short*)a.state)[off + n] = (unsigned short)(__float_as_uint(bf16_round(hn)) >> 16);
+        }
+      }
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    if (p < HD && q == 0) a.y[hd * HD + p] = round_act(acc + Dh * xv, a.act);
+  }
+}
+int bzk_ssm_step(hipStream_t s, const SsmArgs& a) {
+  if (a.d_state > 256 || (a.d_state & 3) || a.n_heads % a.n_groups) BZ_FAIL(BZ_E_UNSUPPORTED, "ssm_step: d_state %d / groups %d unsupported", a.d_state, a.n_groups);
+  const double bytes = 2.0 * a.n_heads * a.head_dim * a.d_state * (a.sdt == BZ_F32 ? 4 : 2);
+  if (a.sdt == BZ_F32) BZ_LAUNCH("mamba2_ssm_step", bytes, (k_ssm_step<BZ_F32>), dim3(a.n_heads), dim3(256), 0, s, a);
+  else if (a.sdt == BZ_F16) BZ_LAUNCH("mamba2_ssm_step", bytes, (k_ssm_step<BZ_F16>), dim3(a.n_heads), dim3(256), 0, s, a);
+  else BZ_LAUNCH("mamba2_ssm_step", bytes, (k_ssm_step<BZ_BF16>), dim3(a.n_heads), dim3(256), 0, s, a);
   BZ_HIP(hipGetLastError());
   return BZ_OK;
 }

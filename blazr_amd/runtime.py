@@ -110,6 +110,17 @@ def make_config(cfg):
     """synth/HF-style config dict -> bz_model_config POD."""
     c = L.ModelConfig()
     c.abi_version = L.ABI_VERSION
+    if cfg.get("arch") == "mamba2":
+        # SsmConfig (loader/gguf.rs:219-262)
+        c.arch = L.ARCH_MAMBA2
+        for k in ("hidden", "n_layers", "vocab", "max_seq_len"):
+            setattr(c, k, int(cfg[k]))
+        for k in ("d_inner", "n_heads", "head_dim", "d_state", "n_groups", "conv_kernel"):
+            setattr(c, "ssm_" + k, int(cfg[k]))
+        c.rms_eps = cfg["rms_eps"]
+        c.act_dtype = _DT[cfg["act_dtype"]]
+        c.tie_embeddings = int(bool(cfg.get("tie_embeddings")))
+        return c
     c.arch = L.ARCH_LLAMA
     for k in ("hidden", "n_layers", "n_heads", "n_kv_heads", "head_dim", "inter", "vocab", "max_seq_len"):
         setattr(c, k, int(cfg[k]))
@@ -203,10 +214,37 @@ class LoadedModel:
         if not self.cfg.get("tie_embeddings"):
             self.add_linear("lm_head", lm_head)
 
+    def add_mamba2_layer(self, i, lay):
+        """HF Mamba2 tensor names (backbone.layers.{i}.mixer.*)"""
+        p = "backbone.layers.%d." % i
+        f32 = lambda a: np.asarray(a, dtype=np.float32)
+        self.add_dense(p + "norm.weight", f32(lay["norm"]))
+        self.add_linear(p + "mixer.in_proj", lay["in_proj"])
+        cw = f32(lay["conv_w"])
+        self.add_dense(p + "mixer.conv1d.weight", cw.reshape(cw.shape[0], 1, cw.shape[1]))
+        self.add_dense(p + "mixer.conv1d.bias", f32(lay["conv_b"]))
+        self.add_dense(p + "mixer.dt_bias", f32(lay["dt_bias"]))
+        self.add_dense(p + "mixer.A_log", f32(lay["A_log"]))
+        self.add_dense(p + "mixer.D", f32(lay["D"]))
+        self.add_dense(p + "mixer.norm.weight", f32(lay["gnorm"]))
+        self.add_linear(p + "mixer.out_proj", lay["out_proj"])
+
+    def add_mamba2_head(self, embed, final_norm, lm_head):
+        self.add_dense("backbone.embeddings.weight", embed)
+        self.add_dense("backbone.norm_f.weight", np.asarray(final_norm, dtype=np.float32))
+        if not self.cfg.get("tie_embeddings"):
+            self.add_linear("lm_head", lm_head)
+
     @classmethod
     def from_synth(cls, dev, model):
-        """Whole in-memory model dict (blazr_amd.synth.make_llama)."""
+        """Whole in-memory model dict (blazr_amd.synth.make_llama / make_mamba2)."""
         m = cls(dev, model["config"])
+        if model["config"].get("arch") == "mamba2":
+            for i, lay in enumerate(model["layers"]):
+                m.add_mamba2_layer(i, lay)
+            m.add_mamba2_head(model["embed"], model["final_norm"], model["lm_head"])
+            m.finalize()
+            return m
         for i, lay in enumerate(model["layers"]):
             m.add_llama_layer(i, lay)
         m.add_llama_head(model["embed"], model["final_norm"], model["lm_head"])
@@ -219,6 +257,13 @@ class LoadedModel:
         from . import synth
         kw = {} if seed is None else {"seed": seed}
         m = cls(dev, cfg)
+        if cfg.get("arch") == "mamba2":
+            for i in range(cfg["n_layers"]):
+                m.add_mamba2_layer(i, synth.mamba2_layer(cfg, i, **kw))
+            emb, fn, lm = synth.mamba2_head(cfg, **kw)
+            m.add_mamba2_head(emb, fn, lm)
+            m.finalize()
+            return m
         for i in range(cfg["n_layers"]):
             m.add_llama_layer(i, synth.llama_layer(cfg, i, **kw))
         emb, fn, lm = synth.llama_head(cfg, **kw)
@@ -247,10 +292,15 @@ class LoadedModel:
         return self.c.vocab
 
     def needs_kv_cache(self):
-        return True
+        return self.c.arch != L.ARCH_MAMBA2
 
     def needs_ssm_state(self):
-        return False
+        return self.c.arch == L.ARCH_MAMBA2
+
+    def mamba_config(self):
+        if self.c.arch != L.ARCH_MAMBA2:
+            return None
+        return {k: getattr(self.c, "ssm_" + k) for k in ("d_inner", "n_heads", "head_dim", "d_state", "n_groups", "conv_kernel")}
 
     def weight_bytes(self):
         a, b = C.c_size_t(), C.c_size_t()
@@ -285,6 +335,13 @@ class LoadedModel:
                                          L.FWD_ALL_LOGITS if all_logits else 0))
         return out
 
+    def forward_with_ssm_state(self, tokens, ssm, all_logits=False):
+        """LoadedModel::forward_with_ssm_state (executor_generate.rs:137,148)"""
+        t, S = self._tokens(tokens)
+        out = self.dev.zeros((S if all_logits else 1, self.c.vocab), L.F32)
+        L.check(L.lib().bz_forward_ssm(self.h, t.h, S, ssm.h, out.h, L.FWD_ALL_LOGITS if all_logits else 0))
+        return out
+
     def forward_embed(self, tokens):
         t, S = self._tokens(tokens)
         out = self.dev.zeros((S, self.c.hidden), L.F32)
@@ -310,6 +367,13 @@ class LoadedModel:
         buf = (L.KernelTime * 32)()
         n = C.c_int()
         L.check(L.lib().bz_profile_step(self.h, kv.h, int(token), int(position), iters, buf, 32, C.byref(n)))
+        return [dict(name=buf[i].name.decode(), launches=buf[i].launches, total_ms=buf[i].total_ms, algo_bytes=buf[i].algo_bytes)
+                for i in range(n.value)]
+
+    def profile_step_ssm(self, ssm, token, iters=4):
+        buf = (L.KernelTime * 32)()
+        n = C.c_int()
+        L.check(L.lib().bz_profile_step_ssm(self.h, ssm.h, int(token), iters, buf, 32, C.byref(n)))
         return [dict(name=buf[i].name.decode(), launches=buf[i].launches, total_ms=buf[i].total_ms, algo_bytes=buf[i].algo_bytes)
                 for i in range(n.value)]
 
@@ -360,6 +424,26 @@ class LayeredKvCache:
         out = np.empty((length, self.head_dim), dtype=np.float32)
         L.check(L.lib().bz_kv_read(self.h, layer, kv_head, which, length, _ptr(out)))
         return out
+
+
+class LayeredSsmState:
+    """boostr::inference::LayeredSsmState::new(layers, batch, mamba_config, dtype, device) (executor_generate.rs:131-133):
+    ssm [B, n_heads, head_dim, d_state] + conv [B, conv_dim, k-1] per layer (docs/architecture.md:52-54)."""
+
+    def __init__(self, model, batch=1, dtype=None):
+        h = C.c_void_p()
+        L.check(L.lib().bz_ssm_state_create(model.h, batch, model.c.act_dtype if dtype is None else dtype, C.byref(h)))
+        self.h, self.dev = h, model.dev
+
+    def __del__(self):
+        try:
+            if self.h and L.alive:
+                L.lib().bz_ssm_state_free(self.h)
+        except Exception:
+            pass
+
+    def reset(self):
+        L.check(L.lib().bz_ssm_state_reset(self.h))
 
 
 class LayeredPagedKvCache:
@@ -429,7 +513,9 @@ class DecodeGraph:
 
     def __init__(self, model, kv, max_blocks=0):
         h = C.c_void_p()
-        if isinstance(kv, LayeredPagedKvCache):
+        if isinstance(kv, LayeredSsmState):
+            L.check(L.lib().bz_decode_graph_capture_ssm(model.h, kv.h, C.byref(h)))
+        elif isinstance(kv, LayeredPagedKvCache):
             L.check(L.lib().bz_decode_graph_capture_paged(model.h, kv.h, max_blocks or kv.num_blocks, C.byref(h)))
         else:
             L.check(L.lib().bz_decode_graph_capture(model.h, kv.h, C.byref(h)))

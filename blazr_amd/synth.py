@@ -53,6 +53,16 @@ PRESETS = {
                       tie_embeddings=False, rope_interleaved=1),
 }
 
+MAMBA_PRESETS = {
+    # BASELINE.json configs[3]: Mamba2-2.7B (SURVEY.md 8d cfg 4)
+    "mamba2-2.7b": dict(arch="mamba2", hidden=2560, n_layers=64, vocab=50288, d_inner=5120, n_heads=80, head_dim=64, d_state=128,
+                        n_groups=1, conv_kernel=4, rms_eps=1e-5, act_dtype="bf16", tie_embeddings=True, max_seq_len=1 << 20),
+    "tiny-mamba2": dict(arch="mamba2", hidden=256, n_layers=3, vocab=1024, d_inner=512, n_heads=8, head_dim=64, d_state=128,
+                        n_groups=1, conv_kernel=4, rms_eps=1e-5, act_dtype="bf16", tie_embeddings=True, max_seq_len=1 << 20),
+    "tiny-mamba2-g2": dict(arch="mamba2", hidden=256, n_layers=2, vocab=1024, d_inner=512, n_heads=8, head_dim=64, d_state=64,
+                           n_groups=2, conv_kernel=4, rms_eps=1e-5, act_dtype="f32", tie_embeddings=False, max_seq_len=1 << 20),
+}
+
 GGML_Q8_0, GGML_Q4_K, GGML_Q6_K = 8, 12, 14
 BASE_SEED = 0xB1A2
 
@@ -258,3 +268,57 @@ def algorithmic_bytes_per_token(cfg):
     norms = (2 * L + 1) * H * act_b
     emb_row = H * act_b
     return wb + head + norms + emb_row
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Mamba2 (HF Mamba2 tensor names; BASELINE.json configs[3])
+# ---------------------------------------------------------------------------------------------------------
+def mamba2_layer(cfg, i, seed=BASE_SEED):
+    D, DI, NH, NS, G, KC = cfg["hidden"], cfg["d_inner"], cfg["n_heads"], cfg["d_state"], cfg["n_groups"], cfg["conv_kernel"]
+    act = cfg["act_dtype"]
+    conv_dim = DI + 2 * G * NS
+    d_in = 2 * DI + 2 * G * NS + NH
+    p = "backbone.layers.%d." % i
+    r = _rng(p + "mixer.misc", seed)
+    lay = {}
+    lay["norm"] = _repr(1.0 + _normal(_rng(p + "norm.weight", seed), (D,), 0.02), act)
+    lay["in_proj"] = dense_linear(p + "mixer.in_proj", d_in, D, act, seed=seed)
+    lay["conv_w"] = _repr(_normal(_rng(p + "mixer.conv1d.weight", seed), (conv_dim, KC), 0.3), act)
+    lay["conv_b"] = _repr(_normal(_rng(p + "mixer.conv1d.bias", seed), (conv_dim,), 0.05), act)
+    lay["dt_bias"] = _repr(r.uniform(-4.0, -1.0, NH).astype(np.float32), act)       # softplus -> dt in ~[0.02, 0.3]
+    lay["A_log"] = _repr(np.log(r.uniform(1.0, 16.0, NH)).astype(np.float32), act)
+    lay["D"] = _repr(r.uniform(0.5, 1.5, NH).astype(np.float32), act)
+    lay["gnorm"] = _repr(1.0 + _normal(_rng(p + "mixer.norm.weight", seed), (DI,), 0.02), act)
+    lay["out_proj"] = dense_linear(p + "mixer.out_proj", D, DI, act, seed=seed)
+    return lay
+
+
+def mamba2_head(cfg, seed=BASE_SEED):
+    D, V, act = cfg["hidden"], cfg["vocab"], cfg["act_dtype"]
+    embed = _store(_normal(_rng("backbone.embeddings.weight", seed), (V, D), 0.02), act)
+    final_norm = _repr(1.0 + _normal(_rng("backbone.norm_f.weight", seed), (D,), 0.02), act)
+    lm = dict(kind="dense", N=V, K=D, weight=embed) if cfg.get("tie_embeddings") else dense_linear("lm_head", V, D, act, seed=seed)
+    return embed, final_norm, lm
+
+
+def make_mamba_config(preset, **over):
+    cfg = dict(MAMBA_PRESETS[preset]) if isinstance(preset, str) else dict(preset)
+    cfg.update(over)
+    return cfg
+
+
+def make_mamba2(preset, seed=BASE_SEED, **over):
+    cfg = make_mamba_config(preset, **over)
+    embed, final_norm, lm = mamba2_head(cfg, seed)
+    return dict(config=cfg, embed=embed, final_norm=final_norm, lm_head=lm, layers=[mamba2_layer(cfg, i, seed) for i in range(cfg["n_layers"])])
+
+
+def mamba2_bytes_per_token(cfg):
+    """weights streamed + recurrent state read and written per decoded token (SURVEY.md 8d cfg 4)"""
+    D, DI, NH, HD, NS, G, KC, V, L = (cfg[k] for k in ("hidden", "d_inner", "n_heads", "head_dim", "d_state", "n_groups", "conv_kernel", "vocab", "n_layers"))
+    b = {"f16": 2, "bf16": 2, "f32": 4}[cfg["act_dtype"]]
+    conv_dim, d_in = DI + 2 * G * NS, 2 * DI + 2 * G * NS + NH
+    per_layer = (d_in * D + D * DI) * b + (conv_dim * (KC + 1) + 3 * NH + DI + D) * b
+    weights = L * per_layer + V * D * b + D * b + D * b
+    state = L * (NH * HD * NS * b * 2 + conv_dim * (KC - 1) * 4 * 2)
+    return weights, state

@@ -54,6 +54,7 @@ typedef struct bz_model bz_model;
 typedef struct bz_kv bz_kv;
 typedef struct bz_paged_kv bz_paged_kv;
 typedef struct bz_decode_graph bz_decode_graph;
+typedef struct bz_ssm_state bz_ssm_state;
 
 /* POD mirror of the fields of boostr::model::UniversalConfig that the forward path reads
  * (loader/safetensors/config.rs:31-95, loader/gguf.rs:101-306, config/blazr.rs:35-52). */
@@ -70,7 +71,9 @@ typedef struct {
   int32_t rope_scaling;    /* BZ_ROPE_* ; fields below per loader/safetensors/config.rs:83-95 */
   float   rope_factor, rope_low_freq_factor, rope_high_freq_factor;
   int32_t rope_original_max_pos;
-  int32_t reserved[16];
+  /* boostr::model::SsmConfig (loader/gguf.rs:219-262) -- BZ_ARCH_MAMBA2 only */
+  int32_t ssm_d_inner, ssm_n_heads, ssm_head_dim, ssm_d_state, ssm_n_groups, ssm_conv_kernel;
+  int32_t reserved[10];
 } bz_model_config;
 
 /* ---- errors / device ------------------------------------------------------------------------------- */
@@ -135,7 +138,15 @@ int bz_paged_kv_free(bz_paged_kv* kv);
 int bz_paged_kv_set_seq_len(bz_paged_kv* kv, int seq_len);  /* set_seq_len (executor_generate.rs:242,286) */
 int bz_paged_kv_seq_len(const bz_paged_kv* kv);
 
+/* LayeredSsmState::new(layers, batch, mamba_config, dtype, device) (executor_generate.rs:131-133): recurrent state
+ * [layers][n_heads][head_dim][d_state] in `dtype` + conv window [layers][conv_dim][k-1] (docs/architecture.md:52-54) */
+int bz_ssm_state_create(bz_model* m, int batch, int dtype, bz_ssm_state** out);
+int bz_ssm_state_free(bz_ssm_state* s);
+int bz_ssm_state_reset(bz_ssm_state* s);
+
 /* ---- forward ------------------------------------------------------------------------------------------ */
+/* LoadedModel::forward_with_ssm_state(&input, &mut ssm) (executor_generate.rs:137,148): Mamba2; tokens I64 [1,S] */
+int bz_forward_ssm(bz_model* m, const bz_tensor* tokens, int S, bz_ssm_state* state, bz_tensor* logits_out, uint32_t flags);
 #define BZ_FWD_ALL_LOGITS 1u  /* logits for all S positions ([S,V]); default: last position only ([1,V]) */
 /* LoadedModel::forward_with_kv_cache(&input,&mut kv,position) (executor_generate.rs:357,372).
  * tokens: I64 [1,S] device tensor; logits_out: F32 [S or 1, vocab] device tensor (values rounded to act dtype). */
@@ -168,6 +179,7 @@ int bz_argmax_to_buf(bz_device* dev, const bz_tensor* logits, int64_t rows, int6
  * over stable buffers with a device-resident position.  The cache must already hold the prefill. */
 int bz_decode_graph_capture(bz_model* m, bz_kv* kv, bz_decode_graph** out);
 int bz_decode_graph_capture_paged(bz_model* m, bz_paged_kv* kv, int max_blocks, bz_decode_graph** out);
+int bz_decode_graph_capture_ssm(bz_model* m, bz_ssm_state* state, bz_decode_graph** out);
 /* DecodeGraph::seed_next_token (cuda_graphs.rs:149-163): first input token + its position */
 int bz_decode_graph_seed(bz_decode_graph* g, int64_t token, int position);
 /* paged only: block table for the sequence (host i32[n]) -- slot_mapping is derived on device from position */
@@ -204,6 +216,8 @@ typedef struct { char name[48]; int32_t launches; double total_ms; double algo_b
  * hipExtLaunchKernelGGL start/stop events on the compute stream and returns, per kernel, launches / summed dispatch time /
  * summed algorithmic bytes.  Durations are pure kernel times (comparable with rocprofv3 --kernel-trace). */
 int bz_profile_step(bz_model* m, bz_kv* kv, int64_t token, int position, int iters, bz_kernel_time* out, int max_out, int* n_out);
+/* the same for a Mamba2 model (advances `state` by `iters` tokens) */
+int bz_profile_step_ssm(bz_model* m, bz_ssm_state* state, int64_t token, int iters, bz_kernel_time* out, int max_out, int* n_out);
 
 /* Kernel tuning aid: mean dispatch time of the int4 GEMV kernel alone on synthetic [N,K] gs-128 weights rotated over `nbuf`
  * HBM buffers.  mode 0 plain x / 1 fused residual+RMSNorm prologue / 2 SiLU*up prologue; flags are debugging knobs (0). */

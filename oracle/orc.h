@@ -168,6 +168,39 @@ int orc_llama_generate(const orc_llama* m, const int64_t* prompt, int n_prompt, 
                        float repeat_penalty, int repeat_last_n, int64_t eos_id,
                        int64_t* out_tokens, float* logits_trace /* optional [max_tokens][vocab] */);
 
+/* ---- Mamba2 ------------------------------------------------------------- */
+typedef struct {
+  int hidden, n_layers, vocab;
+  int d_inner, n_heads, head_dim, d_state, n_groups, conv_kernel;   /* SsmConfig (gguf.rs:219-262) */
+  float rms_eps;
+  int act_dtype;
+} orc_mamba2_cfg;
+typedef struct {
+  const float* norm;            /* [hidden] */
+  orc_linear in_proj;           /* [2 d_inner + 2 G d_state + n_heads, hidden] */
+  const float* conv_w;          /* [conv_dim][k] */
+  const float* conv_b;          /* [conv_dim] */
+  const float* dt_bias; const float* A_log; const float* D;   /* [n_heads] */
+  const float* gnorm;           /* [d_inner] gated RMSNorm weight */
+  orc_linear out_proj;          /* [hidden, d_inner] */
+} orc_mamba2_layer;
+typedef struct {
+  orc_mamba2_cfg cfg;
+  const void* embed; int embed_dtype;
+  const float* final_norm;
+  orc_linear lm_head;
+  orc_mamba2_layer* layers;
+} orc_mamba2;
+typedef struct { float* ssm; float* conv; } orc_ssm_state;   /* [L][n_heads][head_dim][d_state], [L][conv_dim][k-1] */
+orc_mamba2* orc_mamba2_new(const orc_mamba2_cfg* cfg);
+void orc_mamba2_free(orc_mamba2* m);
+orc_ssm_state* orc_ssm_state_new(const orc_mamba2_cfg* cfg);
+void orc_ssm_state_free(orc_ssm_state* s);
+/* executor_generate.rs:137,148 forward_with_ssm_state */
+int orc_mamba2_forward(const orc_mamba2* m, const int64_t* tokens, int S, orc_ssm_state* st, float* logits, int all_logits);
+int orc_mamba2_generate(const orc_mamba2* m, const int64_t* prompt, int n_prompt, int max_tokens, int64_t eos_id, int64_t* out_tokens,
+                        float* logits_trace);
+
 int orc_num_threads(void);
 void orc_set_num_threads(int n);
 

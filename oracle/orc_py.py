@@ -50,6 +50,26 @@ class Llama(C.Structure):
                 ("lm_head", Linear), ("layers", C.POINTER(LlamaLayer)), ("cos_t", C.c_void_p), ("sin_t", C.c_void_p)]
 
 
+class Mamba2Cfg(C.Structure):
+    _fields_ = [("hidden", C.c_int), ("n_layers", C.c_int), ("vocab", C.c_int), ("d_inner", C.c_int), ("n_heads", C.c_int),
+                ("head_dim", C.c_int), ("d_state", C.c_int), ("n_groups", C.c_int), ("conv_kernel", C.c_int), ("rms_eps", C.c_float),
+                ("act_dtype", C.c_int)]
+
+
+class Mamba2Layer(C.Structure):
+    _fields_ = [("norm", C.c_void_p), ("in_proj", Linear), ("conv_w", C.c_void_p), ("conv_b", C.c_void_p), ("dt_bias", C.c_void_p),
+                ("A_log", C.c_void_p), ("D", C.c_void_p), ("gnorm", C.c_void_p), ("out_proj", Linear)]
+
+
+class Mamba2(C.Structure):
+    _fields_ = [("cfg", Mamba2Cfg), ("embed", C.c_void_p), ("embed_dtype", C.c_int), ("final_norm", C.c_void_p), ("lm_head", Linear),
+                ("layers", C.POINTER(Mamba2Layer))]
+
+
+class SsmState(C.Structure):
+    _fields_ = [("ssm", C.c_void_p), ("conv", C.c_void_p)]
+
+
 class Kv(C.Structure):
     _fields_ = [("n_layers", C.c_int), ("n_kv_heads", C.c_int), ("head_dim", C.c_int), ("capacity", C.c_int),
                 ("seq_len", C.c_int), ("k", C.c_void_p), ("v", C.c_void_p)]
@@ -124,6 +144,16 @@ def lib():
         L.orc_llama_generate.restype = C.c_int
         L.orc_llama_generate.argtypes = [C.POINTER(Llama), C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int64,
                                          C.c_void_p, C.c_void_p]
+        L.orc_mamba2_new.restype = C.POINTER(Mamba2)
+        L.orc_mamba2_new.argtypes = [C.POINTER(Mamba2Cfg)]
+        L.orc_mamba2_free.argtypes = [C.POINTER(Mamba2)]
+        L.orc_ssm_state_new.restype = C.POINTER(SsmState)
+        L.orc_ssm_state_new.argtypes = [C.POINTER(Mamba2Cfg)]
+        L.orc_ssm_state_free.argtypes = [C.POINTER(SsmState)]
+        L.orc_mamba2_forward.restype = C.c_int
+        L.orc_mamba2_forward.argtypes = [C.POINTER(Mamba2), C.c_void_p, C.c_int, C.POINTER(SsmState), C.c_void_p, C.c_int]
+        L.orc_mamba2_generate.restype = C.c_int
+        L.orc_mamba2_generate.argtypes = [C.POINTER(Mamba2), C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]
         L.orc_num_threads.restype = C.c_int
         _LIB = L
     return _LIB
@@ -326,4 +356,60 @@ class OrcLlama:
                                      _p(tr))
         if n < 0:
             raise RuntimeError("orc_llama_generate failed")
+        return (out[:n], tr[:n]) if trace else out[:n]
+
+
+class OrcMamba2:
+    """Oracle Mamba2 model built from a blazr_amd.synth.make_mamba2 dict."""
+
+    def __init__(self, model):
+        cfg = model["config"]
+        c = Mamba2Cfg()
+        for k in ("hidden", "n_layers", "vocab", "d_inner", "n_heads", "head_dim", "d_state", "n_groups", "conv_kernel"):
+            setattr(c, k, cfg[k])
+        c.rms_eps = cfg["rms_eps"]
+        c.act_dtype = _DT[cfg["act_dtype"]]
+        self.cfg = c
+        self.h = lib().orc_mamba2_new(C.byref(c))
+        self.keep = []
+        m = self.h.contents
+        emb = np.ascontiguousarray(model["embed"])
+        m.embed = _p(emb)
+        m.embed_dtype = {np.dtype(np.float32): F32, np.dtype(np.float16): F16, np.dtype(np.uint16): BF16}[emb.dtype]
+        fn = np.ascontiguousarray(model["final_norm"], dtype=np.float32)
+        m.final_norm = _p(fn)
+        lm = OrcLinear(model["lm_head"])
+        m.lm_head = lm.c
+        self.keep += [emb, fn, lm]
+        for i, lay in enumerate(model["layers"]):
+            Lr = m.layers[i]
+            for name in ("norm", "conv_w", "conv_b", "dt_bias", "A_log", "D", "gnorm"):
+                a = np.ascontiguousarray(lay[name], dtype=np.float32)
+                self.keep.append(a)
+                setattr(Lr, name, _p(a))
+            for name in ("in_proj", "out_proj"):
+                ol = OrcLinear(lay[name])
+                self.keep.append(ol)
+                setattr(Lr, name, ol.c)
+
+    def __del__(self):
+        try:
+            lib().orc_mamba2_free(self.h)
+        except Exception:
+            pass
+
+    def new_state(self):
+        return lib().orc_ssm_state_new(C.byref(self.cfg))
+
+    def forward(self, tokens, state, all_logits=False):
+        t = np.ascontiguousarray(tokens, dtype=np.int64)
+        out = np.empty((len(t) if all_logits else 1, self.cfg.vocab), dtype=np.float32)
+        lib().orc_mamba2_forward(self.h, _p(t), len(t), state, _p(out), int(all_logits))
+        return out
+
+    def generate(self, prompt, max_tokens, eos_id=-1, trace=False):
+        p = np.ascontiguousarray(prompt, dtype=np.int64)
+        out = np.zeros(max_tokens, dtype=np.int64)
+        tr = np.zeros((max_tokens, self.cfg.vocab), dtype=np.float32) if trace else None
+        n = lib().orc_mamba2_generate(self.h, _p(p), len(p), max_tokens, eos_id, _p(out), _p(tr))
         return (out[:n], tr[:n]) if trace else out[:n]

@@ -209,3 +209,52 @@ class NpLlama:
         h = R(h + prev)
         xn = rms_norm(h, self.m["final_norm"], c["rms_eps"], act)
         return R(xn @ self.lm.T)
+
+
+class NpMamba2:
+    """Independent numpy Mamba2 step (vectorised over heads / state; public Mamba2 recurrence)."""
+
+    def __init__(self, model):
+        self.m, self.cfg = model, model["config"]
+        c = self.cfg
+        self.Win = [dequant(l["in_proj"]) for l in model["layers"]]
+        self.Wout = [dequant(l["out_proj"]) for l in model["layers"]]
+        self.lm = dequant(model["lm_head"])
+        self.emb = dequant(dict(kind="dense", weight=model["embed"]))
+        conv_dim = c["d_inner"] + 2 * c["n_groups"] * c["d_state"]
+        self.conv = [np.zeros((conv_dim, c["conv_kernel"] - 1), np.float32) for _ in model["layers"]]
+        self.ssm = [np.zeros((c["n_heads"], c["head_dim"], c["d_state"]), np.float32) for _ in model["layers"]]
+
+    def step(self, token):
+        c = self.cfg
+        act = c["act_dtype"]
+        R = lambda a: round_act(a, act)
+        DI, NH, HD, NS, G = c["d_inner"], c["n_heads"], c["head_dim"], c["d_state"], c["n_groups"]
+        conv_dim = DI + 2 * G * NS
+        silu = lambda a: a / (1.0 + np.exp(-a))
+        h = R(self.emb[token])
+        for l, lay in enumerate(self.m["layers"]):
+            xn = rms_norm(h, lay["norm"], c["rms_eps"], act)
+            zx = R(xn @ self.Win[l].T)
+            z, xraw, dtr = zx[:DI], zx[DI:DI + conv_dim], zx[DI + conv_dim:]
+            win = np.concatenate([self.conv[l], xraw[:, None]], axis=1)
+            a = R((win * lay["conv_w"]).sum(axis=1, dtype=np.float32) + lay["conv_b"])
+            xbc = R(silu(a))
+            self.conv[l] = win[:, 1:].copy()
+            x = xbc[:DI].reshape(NH, HD)
+            B = xbc[DI:DI + G * NS].reshape(G, NS)
+            Cm = xbc[DI + G * NS:].reshape(G, NS)
+            sp = R(dtr + lay["dt_bias"])
+            dt = R(np.where(sp > 20, sp, np.log1p(np.exp(sp))))
+            dA = np.exp(dt * -np.exp(lay["A_log"])).astype(np.float32)
+            grp = np.arange(NH) // (NH // G)
+            st = R(self.ssm[l] * dA[:, None, None] + (dt[:, None] * x)[:, :, None] * B[grp][:, None, :])
+            self.ssm[l] = st
+            y = R((st * Cm[grp][:, None, :]).sum(axis=2, dtype=np.float32) + lay["D"][:, None] * x).reshape(-1)
+            y = R(y * R(silu(z)))
+            yg = y.reshape(G, -1)
+            rs = 1.0 / np.sqrt((yg.astype(np.float64) ** 2).mean(axis=1, keepdims=True).astype(np.float32) + np.float32(c["rms_eps"]))
+            y = R(lay["gnorm"] * R(yg * rs).reshape(-1))
+            h = R(h + R(y @ self.Wout[l].T))
+        xn = rms_norm(h, self.m["final_norm"], c["rms_eps"], act)
+        return R(xn @ self.lm.T)
