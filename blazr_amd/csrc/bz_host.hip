@@ -232,7 +232,7 @@ struct MambaLayerDev {
 
 struct bz_model {
   std::vector<MambaLayerDev> mlayers;
-  float* xbc = nullptr; float* ybuf = nullptr;   // Mamba2 workspace
+  float* xbc = nullptr; float* ybuf = nullptr; float* vss = nullptr;   // Mamba2 workspace
   bz_device* dev = nullptr;
   bz_model_config cfg;
   bool finalized = false;
@@ -507,6 +507,15 @@ static int build_rows(bz_model* m, const std::vector<RawTensor*>& rs, LinearDev*
   return BZ_OK;
 }
 
+// dense linear whose consumer reads plain f32 (lm_head logits, Mamba2 in_proj): no split-K
+static void force_direct(FusedLinear* F) {
+  bool rows = true;
+  for (auto& p : F->parts) rows = rows && p.kind == LK_ROWS;
+  if (!rows) return;
+  for (auto& p : F->parts) p.sk = 1;
+  F->fix_out = false;
+}
+
 static int choose_sbw(int N, int K, int target) {
   const int SB = K / 256, nst = (N + 255) / 256;
   int best = 1; double bestc = 1e30;
@@ -595,6 +604,7 @@ static int build_fused(bz_model* m, const std::vector<std::string>& names, Fused
         V.bias = L.bias ? L.bias + sub : nullptr;
         V.gw = choose_gw(V.N, V.K, gemv_target_wgs());
       } else if (L.kind == LK_ROWS) {
+        V.sk = 1;
         V.w = (char*)L.w + (size_t)sub * L.K * bz_dtype_size(L.wdt);
       } else {
         const size_t t0 = (size_t)sub / 64, K = (size_t)L.K;
@@ -609,8 +619,11 @@ static int build_fused(bz_model* m, const std::vector<std::string>& names, Fused
     }
     noff += L.N;
   }
-  F->fix_out = F->parts[0].kind != LK_ROWS;
-  for (auto& p : F->parts) if ((p.kind != LK_ROWS) != F->fix_out) BZ_FAIL(BZ_E_UNSUPPORTED, "finalize: mixed quantised/dense parts in one fused linear");
+  static const bool no_sk = getenv("BZ_NO_ROWS_SPLITK") != nullptr;
+  for (auto& p : F->parts) if (p.kind == LK_ROWS && !no_sk) p.sk = bzk_rows_choose_sk(p.N, p.K);
+  auto is_fix = [](const LinearDev& p) { return p.kind != LK_ROWS || p.sk > 1; };
+  F->fix_out = is_fix(F->parts[0]);
+  for (auto& p : F->parts) if (is_fix(p) != F->fix_out) BZ_FAIL(BZ_E_UNSUPPORTED, "finalize: mixed fixed-point/direct parts in one fused linear");
   for (auto* r : rs) { raw_free(*r); r->consumed = true; }
   return BZ_OK;
 }
@@ -712,6 +725,7 @@ extern "C" int bz_model_finalize(bz_model* m) {
       m->named["lm_head.weight"] = L;
     } else {
       BZ_TRY(build_fused(m, {"lm_head"}, &m->lm_head));
+      force_direct(&m->lm_head);
       if (m->lm_head.N != V || m->lm_head.K != H) BZ_FAIL(BZ_E_INVALID, "finalize: lm_head shape does not match the config");
     }
   }
@@ -795,9 +809,11 @@ static int finalize_mamba2(bz_model* m) {
     BZ_TRY(take_vector_f32(m, p + "mixer.D", NH, &L.D, false));   // kept as stored (f32 in HF checkpoints)
     BZ_TRY(take_vector_f32(m, p + "mixer.norm.weight", DI, &L.gnorm));
     BZ_TRY(build_fused(m, {p + "mixer.in_proj"}, &L.in_proj));
+    force_direct(&L.in_proj);   // conv1d / SSM kernels read the projection as plain f32
     BZ_TRY(build_fused(m, {p + "mixer.out_proj"}, &L.out_proj));
     if (L.in_proj.N != d_in || L.in_proj.K != D || L.out_proj.N != D || L.out_proj.K != DI) BZ_FAIL(BZ_E_INVALID, "layer %d: in_proj/out_proj shapes do not match the config", l);
-    if (L.in_proj.fix_out || L.out_proj.fix_out) BZ_FAIL(BZ_E_UNSUPPORTED, "mamba2: quantised projections are not implemented (dense f16/bf16/f32)");
+    if (L.in_proj.fix_out || L.in_proj.parts[0].kind != LK_ROWS || L.out_proj.parts[0].kind != LK_ROWS)
+      BZ_FAIL(BZ_E_UNSUPPORTED, "mamba2: quantised projections are not implemented (dense f16/bf16/f32)");
   }
   BZ_TRY(take_vector_f32(m, "backbone.norm_f.weight", D, &m->final_norm));
   {
@@ -813,6 +829,7 @@ static int finalize_mamba2(bz_model* m) {
       m->named["lm_head.weight"] = L;
     } else {
       BZ_TRY(build_fused(m, {"lm_head"}, &m->lm_head));
+      force_direct(&m->lm_head);
       if (m->lm_head.fix_out) BZ_FAIL(BZ_E_UNSUPPORTED, "mamba2: quantised lm_head is not implemented");
     }
   }
@@ -827,6 +844,7 @@ static int finalize_mamba2(bz_model* m) {
   for (int i = 0; i < 2; i++) { BZ_TRY(dev_alloc(m, &p, (size_t)D * 4)); m->hbuf[i] = (float*)p; }
   BZ_TRY(dev_alloc(m, &p, (size_t)conv_dim * 4)); m->xbc = (float*)p;
   BZ_TRY(dev_alloc(m, &p, (size_t)DI * 4)); m->ybuf = (float*)p;
+  BZ_TRY(dev_alloc(m, &p, (size_t)NH * 4)); m->vss = (float*)p;
   BZ_TRY(dev_alloc(m, &p, (size_t)V * 4)); m->logits = (float*)p;
   m->nparts = bzk_gemv_rows_blocks(m->lm_head.parts[0]);
   BZ_TRY(dev_alloc(m, &p, (size_t)m->nparts * 4)); m->pval = (float*)p;
@@ -1177,24 +1195,31 @@ static int mamba_step(bz_model* m, const StepIO& io) {
     SsmArgs sa{};
     sa.xbc = m->xbc; sa.zxbcdt = zxp; sa.dt_off = DI + conv_dim; sa.dt_bias = L.dt_bias; sa.A_log = L.A_log; sa.D = L.D;
     sa.state = (char*)S->ssm + (size_t)l * NH * c.ssm_head_dim * NS * bz_dtype_size(S->dtype); sa.sdt = S->dtype;
-    sa.n_heads = NH; sa.head_dim = c.ssm_head_dim; sa.d_state = NS; sa.n_groups = G; sa.d_inner = DI; sa.act = act; sa.y = m->ybuf;
+    sa.n_heads = NH; sa.head_dim = c.ssm_head_dim; sa.d_state = NS; sa.n_groups = G; sa.d_inner = DI; sa.act = act; sa.y = m->ybuf; sa.z = zxp; sa.vss = m->vss;
     BZ_TRY(bzk_ssm_step(st, sa));
-    Pro pg{}; pg.mode = PRO_GATED; pg.src = VSrc{m->ybuf, 0}; pg.h_in = zxp; pg.norm_w = L.gnorm; pg.eps = c.rms_eps; pg.H = DI; pg.act = act; pg.aux = G;
+    Pro pg{}; pg.mode = PRO_GATED2; pg.src = VSrc{m->ybuf, 0}; pg.h_in = m->vss; pg.aux2 = NH; pg.norm_w = L.gnorm; pg.eps = c.rms_eps; pg.H = DI; pg.act = act; pg.aux = G;
     VSrc ov;
     BZ_TRY(run_fused(m, L.out_proj, pg, rs, &ov));
     prev = ov;
   }
+  // ring indices as in llama_step: rs.ri clean, (rs.ri+2)%3 holds `prev` when it is fixed point, (rs.ri+1)%3 stale
+  const int ra = (rs.ri + 2) % 3, rb = (rs.ri + 1) % 3;
   if (io.do_head) {
     Pro ph{}; ph.mode = PRO_NORM; ph.src = prev; ph.h_in = m->hbuf[cur]; ph.h_out = nullptr; ph.norm_w = m->final_norm; ph.eps = c.rms_eps; ph.H = D; ph.act = act;
     GemvOut o{};
     o.direct = m->logits; o.amax_val = m->pval; o.amax_idx = m->pidx;
+    o.zero_buf = rs.dirty[rb] > 0 ? m->ring[rb] : nullptr; o.zero_n = rs.dirty[rb];
     BZ_TRY(bzk_gemv(st, m->lm_head.parts[0], ph, o, act));
+    rs.dirty[rb] = 0;
     if (io.final_args) {
       FinalArgs fa = *io.final_args;
       fa.pval = m->pval; fa.pidx = m->pidx; fa.nparts = m->nparts;
+      fa.zero_buf = rs.dirty[ra] > 0 ? m->ring[ra] : nullptr; fa.zero_n = rs.dirty[ra];
       BZ_TRY(bzk_argmax_final(st, fa));
+      rs.dirty[ra] = 0;
     }
   }
+  for (int i = 0; i < 3; i++) if (rs.dirty[i] > 0) BZ_TRY(bzk_zero64(st, m->ring[i], rs.dirty[i]));
   return BZ_OK;
 }
 

@@ -25,7 +25,7 @@ void bz_set_error(const char* fmt, ...);
 // (2^-32 units) accumulated by split-K GEMV blocks with integer atomics (exactly associative => deterministic).
 struct VSrc { const void* p; int fix; };
 
-enum { PRO_PLAIN = 0, PRO_NORM = 1, PRO_SILU = 2, PRO_GATED = 3 };
+enum { PRO_PLAIN = 0, PRO_NORM = 1, PRO_SILU = 2, PRO_GATED = 3, PRO_GATED2 = 4 };
 // How a GEMV block builds its activation slice x[k0, k0+KR):
 struct Pro {
   int mode;
@@ -37,7 +37,8 @@ struct Pro {
   int H;               // NORM: == K ; SILU: I
   int act;             // activation dtype for rounding (BZ_F32/F16/BF16)
   const int* perm;     // optional: x'[k] = x[perm[k]] (GPTQ act-order)
-  int aux;             // GATED: number of norm groups
+  int aux;             // GATED / GATED2: number of norm groups
+  int aux2;            // GATED2: number of heads (h_in = per-head sums of v^2 from the SSM kernel, src = v = R(y * R(silu z)))
   long long* stamps;   // diagnostic only (BZ_MLP_STAMPS): s_memrealtime at phase boundaries of block 0
   int dbg;             // tuning only (bz_tune_gemv): 1 = store instead of atomics, 2 = skip the dot4 work, 4 = skip quantisation
 };
@@ -56,6 +57,7 @@ struct LinearDev {
   int* perm = nullptr;      // GPTQ act-order
   float* bias = nullptr;
   int gw = 1;               // groups (of gs) per workgroup (split-K granularity)
+  int sk = 1;               // ROWS: split-K count (> 1 => fixed-point accumulator output)
   int npf = 2;              // groups of weight loads kept in flight per wave (2 or 4)
   size_t bytes = 0;         // resident bytes
   size_t algo_bytes = 0;    // minimal on-disk bytes (SURVEY 8d accounting)
@@ -141,6 +143,7 @@ struct GemvOut {
 
 int bzk_gemv(hipStream_t s, const LinearDev& L, const Pro& pro, const GemvOut& out, int act);
 int bzk_gemv_rows_blocks(const LinearDev& L);
+int bzk_rows_choose_sk(int N, int K);
 bool bzk_mlp_fusable(const LinearDev& gu, const LinearDev& dn, int H, int I);
 int bzk_mlp_q4g(hipStream_t s, const LinearDev& gu, const LinearDev& dn, int H, int I, const Pro& pro, long long* acc, long long* zero_buf, int zero_n);   // number of workgroups the ROWS kernel uses (argmax partial count)
 int bzk_repack_awq(hipStream_t s, const uint32_t* d_qweight, const float* d_scales, const float* d_zeros, int N, int K, int gs,
@@ -204,5 +207,7 @@ struct SsmArgs {
   void* state; int sdt;  // this layer's [n_heads][head_dim][d_state]
   int n_heads, head_dim, d_state, n_groups, d_inner, act;
   float* y;              // [d_inner]
+  const float* z;        // optional gate input [d_inner]: y <- R(y * R(silu(z))) and vss[head] <- sum of y^2 (feeds PRO_GATED2)
+  float* vss;            // [n_heads]
 };
 int bzk_ssm_step(hipStream_t s, const SsmArgs& a);

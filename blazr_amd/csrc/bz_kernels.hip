@@ -118,54 +118,103 @@ __device__ __forceinline__ int xs_pos(int i) {
   return (i & ~511) + ((i & 4) << 6) + ((i & 511) >> 3 << 2) + (i & 3);
 }
 
-template <bool SWZ>
-__device__ void build_x_simple(const Pro& p, int k0, int KR, float* xs, float* red, bool writer) {
+// All global loads of a batch are issued first, unconditionally (clamped index), and converted afterwards: a load under
+// a condition, or a conversion right after its load, makes hipcc wait vmcnt(0) per element and serialises the batch.
+template <bool FIX> struct SrcRaw { typedef float T; };
+template <> struct SrcRaw<true> { typedef long long T; };
+template <bool FIX>
+__device__ __forceinline__ typename SrcRaw<FIX>::T src_raw(const void* p, int i) {
+  if constexpr (FIX) return ((const long long*)p)[i]; else return ((const float*)p)[i];
+}
+template <bool FIX>
+__device__ __forceinline__ float src_cvt(typename SrcRaw<FIX>::T r, int act) {
+  if constexpr (FIX) return round_act(fix2f(r), act); else return r;
+}
+
+// NORM pass 1: v = R(h + prev) for the whole row -> sum of squares; slice elements [k0, k0+KR) are parked in xs
+template <bool SWZ, bool FIX, bool PREV>
+__device__ __forceinline__ float norm_pass1(const Pro& p, int k0, int KR, float* xs, bool writer) {
   const int tid = threadIdx.x;
-  if (p.mode == PRO_NORM) {
-    const bool hasprev = p.src.p != nullptr;
-    float ss = 0.f;
-    for (int base = 0; base < p.H; base += 4096) {
-      float4 hv[4];
-      float pv[4][4];
+  float ss = 0.f;
+  for (int base = 0; base < p.H; base += 4096) {
+    float4 hv[4];
+    typename SrcRaw<FIX>::T pr[4][4];
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        int i = base + j * 1024 + tid * 4;
-        hv[j] = (i < p.H) ? *(const float4*)(p.h_in + i) : make_float4(0, 0, 0, 0);
-        if (hasprev) {
+    for (int j = 0; j < 4; j++) {
+      const int i = min(base + j * 1024 + tid * 4, p.H - 4);
+      hv[j] = *(const float4*)(p.h_in + i);
+      if (PREV) {
 #pragma unroll
-          for (int e = 0; e < 4; e++) pv[j][e] = (i < p.H) ? vsrc_get(p.src, i + e, p.act) : 0.f;
-        }
+        for (int e = 0; e < 4; e++) pr[j][e] = src_raw<FIX>(p.src.p, i + e);
       }
+    }
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        int i = base + j * 1024 + tid * 4;
-        float v[4] = {hv[j].x, hv[j].y, hv[j].z, hv[j].w};
-        if (hasprev) {
+    for (int j = 0; j < 4; j++) {
+      const int i = base + j * 1024 + tid * 4;
+      float v[4] = {hv[j].x, hv[j].y, hv[j].z, hv[j].w};
+      if (PREV) {
 #pragma unroll
-          for (int e = 0; e < 4; e++) v[e] = round_act(v[e] + pv[j][e], p.act);
-        }
-        if (i < p.H) {
-          ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
-          if (writer && p.h_out) *(float4*)(p.h_out + i) = make_float4(v[0], v[1], v[2], v[3]);
+        for (int e = 0; e < 4; e++) v[e] = round_act(v[e] + src_cvt<FIX>(pr[j][e], p.act), p.act);
+      }
+      if (i < p.H) {
+        ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+        if (writer && p.h_out) *(float4*)(p.h_out + i) = make_float4(v[0], v[1], v[2], v[3]);
+        if (i >= k0 && i < k0 + KR) {       // k0, KR and i are multiples of 4
+#pragma unroll
+          for (int e = 0; e < 4; e++) xs[xs_pos<SWZ>(i - k0 + e)] = v[e];
         }
       }
     }
-    ss = block_sum256(ss, red);
+  }
+  return ss;
+}
+
+template <bool SWZ, bool FIX, bool SILU>
+__device__ __forceinline__ void plain_fill(const Pro& p, int k0, int KR, float* xs) {
+  const int tid = threadIdx.x;
+  for (int base = 0; base < KR; base += 2048) {
+    typename SrcRaw<FIX>::T a[8], b[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const int kk = k0 + min(base + e * 256 + tid, KR - 1);
+      a[e] = src_raw<FIX>(p.src.p, kk);
+      if (SILU) b[e] = src_raw<FIX>(p.src.p, p.H + kk);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const int i = base + e * 256 + tid;
+      float v = src_cvt<FIX>(a[e], p.act);
+      if (SILU) v = round_act(round_act(silu_f(v), p.act) * src_cvt<FIX>(b[e], p.act), p.act);
+      if (i < KR) xs[xs_pos<SWZ>(i)] = v;
+    }
+  }
+}
+
+// Simple form (loads inside): used by the ROWS kernels (no act-order permutation there).  Slice [k0, k0+KR), KR > 0.
+template <bool SWZ>
+__device__ void build_x_simple(const Pro& p, int k0, int KR, float* xs, float* red, bool writer) {
+  const int tid = threadIdx.x;
+  if (KR <= 0) { __syncthreads(); return; }
+  if (p.mode == PRO_NORM) {
+    float ss;
+    if (p.src.p == nullptr) ss = norm_pass1<SWZ, false, false>(p, k0, KR, xs, writer);
+    else if (p.src.fix) ss = norm_pass1<SWZ, true, true>(p, k0, KR, xs, writer);
+    else ss = norm_pass1<SWZ, false, true>(p, k0, KR, xs, writer);
+    ss = block_sum256(ss, red);           // (also orders the xs writes of pass 1 before the reads below)
     const float rs = 1.0f / sqrtf(ss / (float)p.H + p.eps);
     for (int base = 0; base < KR; base += 2048) {
+      float ww[8];
+#pragma unroll
+      for (int e = 0; e < 8; e++) ww[e] = p.norm_w[k0 + min(base + e * 256 + tid, KR - 1)];
 #pragma unroll
       for (int e = 0; e < 8; e++) {
-        int i = base + e * 256 + tid;
-        if (i < KR) {
-          int kk = p.perm ? p.perm[k0 + i] : (k0 + i);
-          float v = p.h_in[kk];
-          if (hasprev) v = round_act(v + vsrc_get(p.src, kk, p.act), p.act);
-          xs[xs_pos<SWZ>(i)] = round_act(p.norm_w[kk] * round_act(v * rs, p.act), p.act);
-        }
+        const int i = base + e * 256 + tid;
+        if (i < KR) xs[xs_pos<SWZ>(i)] = round_act(ww[e] * round_act(xs[xs_pos<SWZ>(i)] * rs, p.act), p.act);
       }
     }
   } else if (p.mode == PRO_GATED) {
     // Mamba2 gated RMSNorm: v = R(y * R(silu(z))) ; x = R(w * R(v * rsqrt(mean_group(v^2) + eps)))   (src = y, h_in = z, H = d_inner)
+    // whole-vector form (k0 == 0, KR == H); the decode step uses GATED2, where the SSM kernel has done the gate and the sums
     const int G = p.aux > 0 ? p.aux : 1, gsz = p.H / G;
     for (int g = 0; g < G; g++) {
       float ss = 0.f;
@@ -182,24 +231,33 @@ __device__ void build_x_simple(const Pro& p, int k0, int KR, float* xs, float* r
         xs[xs_pos<SWZ>(kk)] = round_act(p.norm_w[kk] * round_act(xs[xs_pos<SWZ>(kk)] * rs, p.act), p.act);
       }
     }
-  } else {
+  } else if (p.mode == PRO_GATED2) {
+    // gated RMSNorm with the gate and the per-head sums of squares already applied / reduced by the SSM kernel
+    const int G = p.aux > 0 ? p.aux : 1, gsz = p.H / G, hpg = p.aux2 / G;
+    if (tid < G) {
+      float ss = 0.f;
+      for (int h = 0; h < hpg; h++) ss += p.h_in[tid * hpg + h];
+      red[4 + tid] = 1.0f / sqrtf(ss / (float)gsz + p.eps);
+    }
+    __syncthreads();
     for (int base = 0; base < KR; base += 2048) {
+      float vv[8], ww[8];
 #pragma unroll
       for (int e = 0; e < 8; e++) {
-        int i = base + e * 256 + tid;
-        if (i < KR) {
-          int kk = p.perm ? p.perm[k0 + i] : (k0 + i);
-          float v;
-          if (p.mode == PRO_SILU) {
-            float g = vsrc_get(p.src, kk, p.act), u = vsrc_get(p.src, p.H + kk, p.act);
-            v = round_act(round_act(silu_f(g), p.act) * u, p.act);
-          } else {
-            v = vsrc_get(p.src, kk, p.act);
-          }
-          xs[xs_pos<SWZ>(i)] = v;
-        }
+        const int kk = k0 + min(base + e * 256 + tid, KR - 1);
+        vv[e] = ((const float*)p.src.p)[kk];
+        ww[e] = p.norm_w[kk];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        const int i = base + e * 256 + tid;
+        if (i < KR) xs[xs_pos<SWZ>(i)] = round_act(ww[e] * round_act(vv[e] * red[4 + (k0 + i) / gsz], p.act), p.act);
       }
     }
+  } else if (p.mode == PRO_SILU) {
+    if (p.src.fix) plain_fill<SWZ, true, true>(p, k0, KR, xs); else plain_fill<SWZ, false, true>(p, k0, KR, xs);
+  } else {
+    if (p.src.fix) plain_fill<SWZ, true, false>(p, k0, KR, xs); else plain_fill<SWZ, false, false>(p, k0, KR, xs);
   }
   __syncthreads();
 }
@@ -1048,53 +1106,125 @@ __device__ __forceinline__ void load8(const void* W, size_t elem_off, bool on, f
   }
 }
 
+// raw 8-weight piece of one row: one 16-byte load for f16 / bf16, two for f32
+template <int WDT> struct RowPiece { uint4 a; };
+template <> struct RowPiece<BZ_F32> { uint4 a, b; };
 template <int WDT>
+__device__ __forceinline__ RowPiece<WDT> piece_load(const void* W, size_t elem_off) {
+  RowPiece<WDT> p;
+  if constexpr (WDT == BZ_F32) { p.a = ldnt((const uint4*)((const float*)W + elem_off)); p.b = ldnt((const uint4*)((const float*)W + elem_off + 4)); }
+  else p.a = ldnt((const uint4*)((const unsigned short*)W + elem_off));
+  return p;
+}
+template <int WDT>
+__device__ __forceinline__ float piece_dot(const RowPiece<WDT>& p, const float4& xa, const float4& xb) {
+  float w[8];
+  if constexpr (WDT == BZ_F32) {
+    w[0] = __uint_as_float(p.a.x); w[1] = __uint_as_float(p.a.y); w[2] = __uint_as_float(p.a.z); w[3] = __uint_as_float(p.a.w);
+    w[4] = __uint_as_float(p.b.x); w[5] = __uint_as_float(p.b.y); w[6] = __uint_as_float(p.b.z); w[7] = __uint_as_float(p.b.w);
+  } else {
+    const unsigned u[4] = {p.a.x, p.a.y, p.a.z, p.a.w};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      if constexpr (WDT == BZ_F16) {
+        w[2 * i] = __half2float(__ushort_as_half((unsigned short)(u[i] & 0xffffu)));
+        w[2 * i + 1] = __half2float(__ushort_as_half((unsigned short)(u[i] >> 16)));
+      } else {
+        w[2 * i] = __uint_as_float(u[i] << 16);
+        w[2 * i + 1] = __uint_as_float(u[i] & 0xffff0000u);
+      }
+    }
+  }
+  return w[0] * xa.x + w[1] * xa.y + w[2] * xa.z + w[3] * xa.w + w[4] * xb.x + w[5] * xb.y + w[6] * xb.z + w[7] * xb.w;
+}
+
+// A wave walks its rows four at a time, one 512-k chunk per step (row group, chunk).  Loads run two steps ahead of the
+// FMAs (three stage buffers), and the first two stages are issued before the prologue so that the weight stream is
+// already in flight while x is built.
+// SPLIT: split-K.  blockIdx = row block * SK + ks; slice ks covers KCs chunks of 512 k; partial sums go to the 64-bit
+// fixed-point accumulator `accbuf` (order-independent, hence deterministic) and are rounded by the consumer.
+template <int WDT, bool SPLIT>
 __global__ __launch_bounds__(256) void k_gemv_rows(const void* __restrict__ W, const float* __restrict__ bias, int N, int K,
                                                    int rows_per_wg, Pro pro, float* out, int act, float* pval, int* pidx,
-                                                   long long* zero_buf, int zero_n) {
+                                                   long long* zero_buf, int zero_n, int SK, long long* accbuf) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int KP = (K + 511) & ~511;
   float* xs = (float*)smem;     // [KP] swizzled
   float* red = xs + KP;         // [4] + argmax scratch [4] + [4]
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  zero_duty(zero_buf, zero_n);
-  for (int i = K + threadIdx.x; i < KP; i += 256) xs[xs_pos<true>(i)] = 0.f;
-  build_x_simple<true>(pro, 0, K, xs, red, blockIdx.x == 0);
-
   const int rpw = rows_per_wg >> 2;
-  const int rbeg = blockIdx.x * rows_per_wg + wave * rpw;
+  const int rb = SPLIT ? blockIdx.x / SK : blockIdx.x, ks = SPLIT ? blockIdx.x % SK : 0;
+  const int rbeg = rb * rows_per_wg + wave * rpw;
   const int rend = min(rbeg + rpw, N);
-  const int KC = KP >> 9;
-  const float4* xs4 = (const float4*)xs;
-  float bestv = -INFINITY; int besti = 0x7fffffff;
-  for (int r = rbeg; r < rend; r += 4) {
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-    for (int kc = 0; kc < KC; kc++) {
-      const int k = kc * 512 + lane * 8;
-      const bool kon = k < K;
-      float w[4][8];
+  const int KCall = KP >> 9, KCs = SPLIT ? (KCall + SK - 1) / SK : KCall;
+  const int kc0 = ks * KCs;
+  const int KC = max(min(KCs, KCall - kc0), 1);
+  const int kb = kc0 * 512;                                 // first k of this slice
+  const int ngroups = rend > rbeg ? (rend - rbeg + 3) >> 2 : 0;
+  const int nsteps = ngroups * KC;
+  struct Stage { RowPiece<WDT> p[4]; };
+  // issue cursor (clamped at the last step: a few redundant loads at the tail, never a branch around a load)
+  int ir = min(rbeg, N - 1), ikc = 0, ist = 0;
+  auto issue = [&](Stage& S) {
+    const int k = kb + ikc * 512 + lane * 8;
+    const int ko = k < K ? k : 0;                           // xs is 0 beyond K
 #pragma unroll
-      for (int rr = 0; rr < 4; rr++) load8<WDT>(W, (size_t)min(r + rr, N - 1) * K + (kon ? k : 0), true, w[rr]);   // xs is 0 beyond K
-      const float4 xa = xs4[kc * 128 + lane], xb = xs4[kc * 128 + 64 + lane];
+    for (int rr = 0; rr < 4; rr++) S.p[rr] = piece_load<WDT>(W, (size_t)min(ir + rr, N - 1) * K + ko);
+    if (ist + 1 < nsteps) { ist++; if (++ikc == KC) { ikc = 0; ir += 4; } }
+  };
+  Stage s0, s1, s2;
+  issue(s0);
+  issue(s1);
+  __builtin_amdgcn_sched_barrier(0);
+  zero_duty(zero_buf, zero_n);
+  const float4* xs4;
+  if (!SPLIT || pro.mode == PRO_GATED) {
+    // whole vector in LDS (the gated norm needs every element of its group anyway)
+    for (int i = K + threadIdx.x; i < KP; i += 256) xs[xs_pos<true>(i)] = 0.f;
+    build_x_simple<true>(pro, 0, K, xs, red, blockIdx.x == 0);
+    xs4 = (const float4*)(xs + kb);
+  } else {
+    const int KR = max(min(K - kb, KC * 512), 0);
+    for (int i = KR + threadIdx.x; i < KC * 512; i += 256) xs[xs_pos<true>(i)] = 0.f;
+    build_x_simple<true>(pro, kb, KR, xs, red, blockIdx.x == 0);
+    xs4 = (const float4*)xs;
+  }
+  float bestv = -INFINITY; int besti = 0x7fffffff;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  int cr = rbeg, ckc = 0, cst = 0;
+  auto consume = [&](const Stage& S) {
+    if (cst >= nsteps) return;
+    cst++;
+    const float4 xa = xs4[ckc * 128 + lane], xb = xs4[ckc * 128 + 64 + lane];
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) acc[rr] += piece_dot<WDT>(S.p[rr], xa, xb);
+    if (++ckc == KC) {
+      ckc = 0;
 #pragma unroll
       for (int rr = 0; rr < 4; rr++) {
-        acc[rr] += w[rr][0] * xa.x + w[rr][1] * xa.y + w[rr][2] * xa.z + w[rr][3] * xa.w + w[rr][4] * xb.x + w[rr][5] * xb.y +
-                   w[rr][6] * xb.z + w[rr][7] * xb.w;
+        float v = wave_sum(acc[rr]);
+        acc[rr] = 0.f;
+        if (cr + rr < rend) {
+          if (SPLIT) {
+            if (bias && ks == 0) v += bias[cr + rr];
+            if (lane == 0) atomicAdd((unsigned long long*)(accbuf + cr + rr), (unsigned long long)f2fix(v));
+          } else {
+            if (bias) v += bias[cr + rr];
+            v = round_act(v, act);
+            if (lane == 0) out[cr + rr] = v;
+            if (v > bestv) { bestv = v; besti = cr + rr; }
+          }
+        }
       }
+      cr += 4;
     }
-#pragma unroll
-    for (int rr = 0; rr < 4; rr++) {
-      float v = wave_sum(acc[rr]);
-      if (r + rr < rend) {
-        if (bias) v += bias[r + rr];
-        v = round_act(v, act);
-        if (lane == 0) out[r + rr] = v;
-        if (v > bestv) { bestv = v; besti = r + rr; }
-      }
-    }
+  };
+  for (int st = 0; st < nsteps; st += 3) {
+    issue(s2); consume(s0);
+    issue(s0); consume(s1);
+    issue(s1); consume(s2);
   }
-  if (pval) {
+  if (!SPLIT && pval) {
     float* bv = red + 4; int* bi = (int*)(red + 8);
     if (lane == 0) { bv[wave] = bestv; bi[wave] = besti; }
     __syncthreads();
@@ -1108,9 +1238,20 @@ __global__ __launch_bounds__(256) void k_gemv_rows(const void* __restrict__ W, c
 
 static int rows_per_wg_for(int N) {
   // ~1000 workgroups when N is large, at least 16 rows (4 per wave) per workgroup
+  static const int forced = getenv("BZ_ROWS_RPW") ? atoi(getenv("BZ_ROWS_RPW")) : 0;
+  if (forced > 0 && N < 40000) return forced;
   int r = 16;
   while (r < 256 && (N + r - 1) / r > 1024) r <<= 1;
   return r;
+}
+// split count for a dense [N,K] GEMV: enough (16-row x K-slice) workgroups to fill the chip when N alone is too small
+int bzk_rows_choose_sk(int N, int K) {
+  const int rbs = (N + 15) / 16, KC = (K + 511) / 512;
+  if (rbs >= 512 || KC < 8) return 1;
+  int sk = std::min((512 + rbs - 1) / rbs, KC / 4);   // a slice keeps >= 4 chunks (2048 k): below that the prologue dominates
+  const int kcs = (KC + sk - 1) / sk;
+  sk = (KC + kcs - 1) / kcs;
+  return sk;
 }
 int bzk_gemv_rows_blocks(const LinearDev& L) { int r = rows_per_wg_for(L.N); return (L.N + r - 1) / r; }
 
@@ -1285,16 +1426,22 @@ int bzk_gemv(hipStream_t s, const LinearDev& L, const Pro& pro, const GemvOut& o
     return BZ_OK;
   }
   if (L.kind == LK_ROWS) {
-    if (!out.direct) BZ_FAIL(BZ_E_INVALID, "rows gemv needs a direct output");
-    const int rpw = rows_per_wg_for(L.N);
-    const int grid = (L.N + rpw - 1) / rpw;
+    const int SK = L.sk > 1 ? L.sk : 1;
+    if (SK == 1 && !out.direct) BZ_FAIL(BZ_E_INVALID, "rows gemv needs a direct output");
+    if (SK > 1 && (!out.acc || out.amax_val)) BZ_FAIL(BZ_E_INVALID, "split-K rows gemv needs a fixed-point accumulator");
+    const int rpw = SK > 1 ? 16 : rows_per_wg_for(L.N);
+    const int grid = ((L.N + rpw - 1) / rpw) * SK;
     const int KP = (L.K + 511) & ~511;
     const size_t smem = (size_t)KP * 4 + 64;
     if (smem > 160 * 1024) BZ_FAIL(BZ_E_UNSUPPORTED, "K=%d too large for the rows GEMV", L.K);
-#define LAUNCH_ROWS(DT) BZ_LAUNCH(out.amax_val ? "gemv_rows<lm_head+argmax>" : "gemv_rows", L.algo_bytes, (k_gemv_rows<DT>), dim3(grid), \
-    dim3(256), smem, s, (const void*)L.w, L.bias, L.N, L.K, rpw, pro, out.direct, act, out.amax_val, out.amax_idx, out.zero_buf, out.zero_n)
+    const char* lbl = out.amax_val ? "gemv_rows<lm_head+argmax>" : pro.mode == PRO_NORM ? "gemv_rows<norm>" : (pro.mode == PRO_GATED || pro.mode == PRO_GATED2) ? "gemv_rows<gated>"
+                      : pro.mode == PRO_SILU ? "gemv_rows<silu>" : "gemv_rows";
+#define LAUNCH_ROWS1(DT, SP) BZ_LAUNCH(lbl, L.algo_bytes, (k_gemv_rows<DT, SP>), dim3(grid), \
+    dim3(256), smem, s, (const void*)L.w, L.bias, L.N, L.K, rpw, pro, out.direct, act, out.amax_val, out.amax_idx, out.zero_buf, out.zero_n, SK, out.acc)
+#define LAUNCH_ROWS(DT) do { if (SK > 1) LAUNCH_ROWS1(DT, true); else LAUNCH_ROWS1(DT, false); } while (0)
     if (L.wdt == BZ_F16) LAUNCH_ROWS(BZ_F16); else if (L.wdt == BZ_BF16) LAUNCH_ROWS(BZ_BF16); else LAUNCH_ROWS(BZ_F32);
 #undef LAUNCH_ROWS
+#undef LAUNCH_ROWS1
     BZ_HIP(hipGetLastError());
     return BZ_OK;
   }
@@ -2325,7 +2472,7 @@ __device__ __forceinline__ float softplus_f(float x) { return x > 20.0f ? x : lo
 // grid = n_heads; 256 threads = 64 rows (p) x 4 state quarters.  h = R(h * dA + (dt x) B); y = R(sum_n h C + D x)
 template <int SDT>
 __global__ __launch_bounds__(256) void k_ssm_step(SsmArgs a) {
-  __shared__ float sB[256], sC[256];
+  __shared__ float sB[256], sC[256], sred[4];
   const int hd = blockIdx.x, tid = threadIdx.x;
   const int NS = a.d_state, HD = a.head_dim;
   const int g = hd / (a.n_heads / a.n_groups);
@@ -2335,6 +2482,7 @@ __global__ __launch_bounds__(256) void k_ssm_step(SsmArgs a) {
   const float Dh = a.D[hd];
   __syncthreads();
   const int q = tid & 3, nq = NS >> 2;            // this thread's quarter of the state row
+  float vsq = 0.f;
   for (int p0 = 0; p0 < HD; p0 += 64) {
     const int p = p0 + (tid >> 2);
     float acc = 0.f, xv = 0.f;
@@ -2377,7 +2525,15 @@ __global__ __launch_bounds__(256) void k_ssm_step(SsmArgs a) {
     }
     acc += __shfl_xor(acc, 1, 64);
     acc += __shfl_xor(acc, 2, 64);
-    if (p < HD && q == 0) a.y[hd * HD + p] = round_act(acc + Dh * xv, a.act);
+    if (p < HD && q == 0) {
+      float yv = round_act(acc + Dh * xv, a.act);
+      if (a.z) { yv = round_act(yv * round_act(silu_f(a.z[hd * HD + p]), a.act), a.act); vsq += yv * yv; }
+      a.y[hd * HD + p] = yv;
+    }
+  }
+  if (a.z) {
+    vsq = block_sum256(vsq, sred);   // fixed tree: the per-head sum is deterministic
+    if (tid == 0) a.vss[hd] = vsq;
   }
 }
 int bzk_ssm_step(hipStream_t s, const SsmArgs& a) {
