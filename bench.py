@@ -77,8 +77,8 @@ def main():
 
     from blazr_amd import runtime, synth
 
-    if args.preset in synth.MAMBA_PRESETS:
-        return bench_mamba2(args, rank, local_rank, world, dist)
+    if args.preset in synth.MAMBA_PRESETS or args.preset in synth.DSV2_PRESETS:
+        return bench_aux(args, rank, local_rank, world, dist)
     cfg = synth.make_config(args.preset)
     need = args.prompt_len + args.warmup + args.steps + 8
     if need > cfg["max_seq_len"]:
@@ -183,20 +183,29 @@ def main():
         dist.destroy_process_group()
 
 
-def bench_mamba2(args, rank, local_rank, world, dist):
-    """Secondary workload (BASELINE.json configs[3]): Mamba2 decode, state + weights streamed once per token."""
+def bench_aux(args, rank, local_rank, world, dist):
+    """Secondary workloads (BASELINE.json configs[3], [4]): Mamba2-2.7B (state + weights streamed once per token) and
+    DeepSeek-V2-Lite (MLA latent cache + MoE: only the routed + shared experts' weights are streamed)."""
     from blazr_amd import replicas, runtime, synth
-    cfg = synth.make_mamba_config(args.preset)
+    mamba = args.preset in synth.MAMBA_PRESETS
+    cfg = synth.make_mamba_config(args.preset) if mamba else synth.make_dsv2_config(args.preset)
+    need = args.prompt_len + args.warmup + args.steps + 8
+    if not mamba and need > cfg["max_seq_len"]:
+        cfg["max_seq_len"] = need
     dev = runtime.Device(local_rank)
     t0 = time.time()
     lm = runtime.LoadedModel.from_synth_streamed(dev, cfg)
     load_s = time.time() - t0
-    w_bytes, s_bytes = synth.mamba2_bytes_per_token(cfg)
+    w_bytes, s_bytes = synth.mamba2_bytes_per_token(cfg) if mamba else (synth.dsv2_bytes_per_token(cfg), 0)
     resident, per_token = lm.weight_bytes()
     assert per_token == w_bytes, (per_token, w_bytes)
     prompt = synth.prompt_tokens(args.prompt_len, cfg["vocab"])
-    st = runtime.LayeredSsmState(lm)
-    logits = lm.forward_with_ssm_state(prompt, st)
+    if mamba:
+        st = runtime.LayeredSsmState(lm)
+        logits = lm.forward_with_ssm_state(prompt, st)
+    else:
+        st = lm.new_kv_cache(need)
+        logits = lm.forward_with_kv_cache(prompt, st, 0)
     first = int(runtime.logits_to_token(dev, logits, [], []).to_numpy()[0])
     graph = runtime.DecodeGraph(lm, st)
     graph.seed_next_token(first, args.prompt_len)
@@ -220,7 +229,7 @@ def bench_mamba2(args, rank, local_rank, world, dist):
     n_gpus = max(world, 1)
     tok_s, wall_ms = replicas.aggregate_tokens_per_s(max(gpu_ms, host_ms), args.steps, dist, "cuda" if dist is not None else None)
     tokens = [first] + [graph.read_token(i) for i in range(args.warmup + args.steps)]
-    prof = lm.profile_step_ssm(st, tokens[-1], iters=4)
+    prof = lm.profile_step_ssm(st, tokens[-1], iters=4) if mamba else lm.profile_step(st, tokens[-1], args.prompt_len + args.warmup + args.steps, iters=4)
     for p in prof:
         p["avg_us"] = 1e3 * p["total_ms"] / max(p["launches"], 1)
         p["gbs"] = (p["algo_bytes"] / 1e9) / (p["total_ms"] / 1e3) if p["total_ms"] > 0 and p["algo_bytes"] > 0 else None

@@ -23,11 +23,12 @@ atexit.register(_at_exit)
 
 OK, E_INVALID, E_NODEVICE, E_HIP, E_UNSUPPORTED, E_NOTFOUND, E_OOM = 0, -1, -2, -3, -4, -5, -6
 F32, F16, BF16, I64, I32, U32, U8 = range(7)
-ABI_VERSION = 1
+ABI_VERSION = 2
 FWD_ALL_LOGITS = 1
 ROPE_NONE, ROPE_LINEAR, ROPE_LLAMA3 = 0, 1, 2
 ARCH_LLAMA = 0
 ARCH_MAMBA2 = 1
+ARCH_DEEPSEEK2 = 2
 
 
 class BlazrHipError(RuntimeError):
@@ -44,7 +45,11 @@ class ModelConfig(C.Structure):
                 ("rope_scaling", C.c_int32), ("rope_factor", C.c_float), ("rope_low_freq_factor", C.c_float),
                 ("rope_high_freq_factor", C.c_float), ("rope_original_max_pos", C.c_int32),
                 ("ssm_d_inner", C.c_int32), ("ssm_n_heads", C.c_int32), ("ssm_head_dim", C.c_int32), ("ssm_d_state", C.c_int32),
-                ("ssm_n_groups", C.c_int32), ("ssm_conv_kernel", C.c_int32), ("reserved", C.c_int32 * 10)]
+                ("ssm_n_groups", C.c_int32), ("ssm_conv_kernel", C.c_int32),
+                ("mla_kv_lora_rank", C.c_int32), ("mla_q_lora_rank", C.c_int32), ("mla_nope_dim", C.c_int32), ("mla_rope_dim", C.c_int32),
+                ("mla_v_dim", C.c_int32), ("moe_n_experts", C.c_int32), ("moe_top_k", C.c_int32), ("moe_n_shared", C.c_int32),
+                ("moe_inter", C.c_int32), ("moe_first_dense", C.c_int32), ("moe_norm_topk", C.c_int32), ("moe_routed_scale", C.c_float),
+                ("reserved", C.c_int32 * 8)]
 
 
 class GenConfig(C.Structure):

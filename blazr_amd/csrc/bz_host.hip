@@ -230,7 +230,19 @@ struct MambaLayerDev {
   FusedLinear in_proj, out_proj;
 };
 
+struct DsLayerDev {
+  float* attn_norm = nullptr; float* ffn_norm = nullptr; float* kv_norm = nullptr;
+  FusedLinear qkva, o;                       // [q_proj ; kv_a_proj_with_mqa], o_proj
+  void* kv_b = nullptr; int kv_b_dt = BZ_BF16;   // kv_b_proj [n_heads (nope+v)][rank], as stored
+  bool is_moe = false;
+  FusedLinear gateup, down;                  // dense layers
+  void* router = nullptr; int router_dt = BZ_BF16;   // [E][hidden]
+  void* e_gu = nullptr; void* e_dn = nullptr; int e_dt = BZ_BF16;   // stacked [E + n_shared][2 moe_inter][hidden] / [E + n_shared][hidden][moe_inter]
+};
+
 struct bz_model {
+  std::vector<DsLayerDev> dlayers;
+  float* moe_xn = nullptr; float* moe_gu = nullptr; float* moe_out = nullptr; long long* moe_acc = nullptr; int* moe_sel = nullptr; float* moe_w = nullptr;
   std::vector<MambaLayerDev> mlayers;
   float* xbc = nullptr; float* ybuf = nullptr; float* vss = nullptr;   // Mamba2 workspace
   bz_device* dev = nullptr;
@@ -275,8 +287,22 @@ static int upload(bz_device* d, void** out, const void* host, size_t bytes) {
 extern "C" int bz_model_create(bz_device* dev, const bz_model_config* cfg, bz_model** out) {
   if (!dev || !cfg || !out) BZ_FAIL(BZ_E_INVALID, "bz_model_create: null argument");
   if (cfg->abi_version != BZ_ABI_VERSION) BZ_FAIL(BZ_E_INVALID, "config abi_version %d != %d", cfg->abi_version, BZ_ABI_VERSION);
-  if (cfg->arch != BZ_ARCH_LLAMA && cfg->arch != BZ_ARCH_MAMBA2) BZ_FAIL(BZ_E_UNSUPPORTED, "arch %d not implemented in this build (llama family and mamba2)", cfg->arch);
-  if (cfg->arch == BZ_ARCH_MAMBA2) {
+  if (cfg->arch != BZ_ARCH_LLAMA && cfg->arch != BZ_ARCH_MAMBA2 && cfg->arch != BZ_ARCH_DEEPSEEK2) BZ_FAIL(BZ_E_UNSUPPORTED, "arch %d is not implemented", cfg->arch);
+  if (cfg->arch == BZ_ARCH_DEEPSEEK2) {
+    if (cfg->hidden <= 0 || cfg->n_layers <= 0 || cfg->n_heads <= 0 || cfg->vocab <= 0 || cfg->max_seq_len <= 0 || cfg->mla_kv_lora_rank <= 0 ||
+        cfg->mla_nope_dim <= 0 || cfg->mla_rope_dim <= 0 || cfg->mla_v_dim <= 0 || cfg->moe_n_experts < 0 || cfg->moe_first_dense < 0)
+      BZ_FAIL(BZ_E_INVALID, "config: non-positive deepseek2 dimension");
+    if (cfg->mla_q_lora_rank != 0) BZ_FAIL(BZ_E_UNSUPPORTED, "config: q_lora_rank > 0 (DeepSeek-V2 full) is not implemented; V2-Lite uses a plain q_proj");
+    if (cfg->hidden % 8 || cfg->mla_kv_lora_rank % 8 || cfg->mla_kv_lora_rank > 1024 || cfg->mla_rope_dim > 64 || (cfg->mla_rope_dim & 1) || cfg->mla_nope_dim % 4 ||
+        cfg->mla_v_dim % 4)
+      BZ_FAIL(BZ_E_UNSUPPORTED, "config: MLA dims unsupported (rank %% 8, rank <= 1024, rope <= 64 even, nope/v %% 4)");
+    if (cfg->moe_n_experts > 0 && (cfg->moe_top_k <= 0 || cfg->moe_top_k > cfg->moe_n_experts || cfg->moe_top_k > 16 || cfg->moe_n_shared < 0 || cfg->moe_n_shared > 8 ||
+                                   cfg->moe_inter <= 0 || cfg->moe_inter % 8 || cfg->moe_n_experts > 1024))
+      BZ_FAIL(BZ_E_INVALID, "config: bad MoE configuration");
+    if ((cfg->moe_first_dense > 0 || cfg->moe_n_experts == 0) && (cfg->inter <= 0 || cfg->inter % 8)) BZ_FAIL(BZ_E_INVALID, "config: dense layers need inter %% 8 == 0");
+    if ((size_t)(cfg->mla_kv_lora_rank * 6 + cfg->mla_rope_dim * 2 + cfg->mla_nope_dim + 8 + cfg->max_seq_len) * 4 + 64 > 160 * 1024)
+      BZ_FAIL(BZ_E_UNSUPPORTED, "config: max_seq_len %d too long for the single-pass MLA attention kernel", cfg->max_seq_len);
+  } else if (cfg->arch == BZ_ARCH_MAMBA2) {
     if (cfg->hidden <= 0 || cfg->n_layers <= 0 || cfg->vocab <= 0 || cfg->ssm_d_inner <= 0 || cfg->ssm_n_heads <= 0 || cfg->ssm_head_dim <= 0 ||
         cfg->ssm_d_state <= 0 || cfg->ssm_n_groups <= 0 || cfg->ssm_conv_kernel < 2)
       BZ_FAIL(BZ_E_INVALID, "config: non-positive mamba2 dimension");
@@ -292,6 +318,7 @@ extern "C" int bz_model_create(bz_device* dev, const bz_model_config* cfg, bz_mo
   if (cfg->act_dtype != BZ_F32 && cfg->act_dtype != BZ_F16 && cfg->act_dtype != BZ_BF16) BZ_FAIL(BZ_E_INVALID, "config: bad act_dtype");
   bz_model* m = new bz_model();
   m->dev = dev; m->cfg = *cfg;
+  if (cfg->arch == BZ_ARCH_DEEPSEEK2) { m->cfg.n_kv_heads = 1; m->cfg.head_dim = cfg->mla_kv_lora_rank + cfg->mla_rope_dim; }   // shape of the latent cache
   bz_dev_retain(dev);
   *out = m;
   return BZ_OK;
@@ -684,12 +711,14 @@ static void rope_tables_host(const bz_model_config& c, std::vector<float>& cs, s
 }
 
 static int finalize_mamba2(bz_model* m);
+static int finalize_dsv2(bz_model* m);
 
 extern "C" int bz_model_finalize(bz_model* m) {
   if (!m) BZ_FAIL(BZ_E_INVALID, "null model");
   if (m->finalized) BZ_FAIL(BZ_E_INVALID, "model already finalized");
   BZ_HIP(hipSetDevice(m->dev->id));
   if (m->cfg.arch == BZ_ARCH_MAMBA2) return finalize_mamba2(m);
+  if (m->cfg.arch == BZ_ARCH_DEEPSEEK2) return finalize_dsv2(m);
   const bz_model_config& c = m->cfg;
   const int H = c.hidden, nq = c.n_heads, nkv = c.n_kv_heads, hd = c.head_dim, I = c.inter, V = c.vocab;
   char nm[256];
@@ -785,6 +814,158 @@ extern "C" int bz_rope_caches(bz_model* m, float* c, float* s) {
   size_t n = (size_t)m->cfg.max_seq_len * (m->cfg.head_dim / 2) * 4;
   if (c) BZ_HIP(hipMemcpy(c, m->cos_t, n, hipMemcpyDeviceToHost));
   if (s) BZ_HIP(hipMemcpy(s, m->sin_t, n, hipMemcpyDeviceToHost));
+  return BZ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// DeepSeek-V2 family (BZ_ARCH_DEEPSEEK2): HF tensor names
+// ---------------------------------------------------------------------------------------------------------
+// take a dense 2-D tensor as stored (device pointer ownership moves to the model)
+static int take_dense(bz_model* m, const std::string& name, int64_t N, int64_t K, void** out, int* dt, size_t* bytes) {
+  auto it = m->raw.find(name);
+  if (it == m->raw.end()) BZ_FAIL(BZ_E_NOTFOUND, "finalize: tensor '%s' was not added", name.c_str());
+  RawTensor& r = it->second;
+  if (r.kind != 0 || r.N != N || r.K != K) BZ_FAIL(BZ_E_INVALID, "finalize: '%s' must be dense [%lld, %lld]", name.c_str(), (long long)N, (long long)K);
+  *out = r.d0; *dt = r.dtype; if (bytes) *bytes = r.bytes;
+  r.d0 = nullptr; m->owned.push_back(*out); r.consumed = true;
+  m->resident += r.bytes;
+  return BZ_OK;
+}
+// copy a dense 2-D tensor (or a column block of it) into a stacked buffer
+static int stack_dense(bz_model* m, const std::string& name, int64_t N, int64_t K, int dt, void* dst, int64_t col0, int64_t ncols) {
+  auto it = m->raw.find(name);
+  if (it == m->raw.end()) BZ_FAIL(BZ_E_NOTFOUND, "finalize: tensor '%s' was not added", name.c_str());
+  RawTensor& r = it->second;
+  if (r.kind != 0 || r.N != N || r.K != K || r.dtype != dt) BZ_FAIL(BZ_E_INVALID, "finalize: '%s' must be dense [%lld, %lld] of the experts' dtype", name.c_str(), (long long)N, (long long)K);
+  const size_t es = bz_dtype_size(dt);
+  BZ_HIP(hipMemcpy2D(dst, (size_t)ncols * es, (const char*)r.d0 + (size_t)col0 * es, (size_t)K * es, (size_t)ncols * es, (size_t)N, hipMemcpyDeviceToDevice));
+  return BZ_OK;
+}
+
+static int finalize_dsv2(bz_model* m) {
+  const bz_model_config& c = m->cfg;
+  const int H = c.hidden, NH = c.n_heads, R = c.mla_kv_lora_rank, DN = c.mla_nope_dim, DR = c.mla_rope_dim, DV = c.mla_v_dim, V = c.vocab;
+  const int E = c.moe_n_experts, TK = c.moe_top_k, NS = c.moe_n_shared, MI = c.moe_inter;
+  const size_t act_b = bz_dtype_size(c.act_dtype);
+  char nm[256];
+  m->dlayers.resize(c.n_layers);
+  size_t per_token = 0;
+  int ring_n = std::max(H, NH * DV);
+  for (int l = 0; l < c.n_layers; l++) {
+    DsLayerDev& L = m->dlayers[l];
+    snprintf(nm, sizeof nm, "model.layers.%d.", l);
+    std::string p = nm;
+    BZ_TRY(take_vector_f32(m, p + "input_layernorm.weight", H, &L.attn_norm));
+    BZ_TRY(take_vector_f32(m, p + "post_attention_layernorm.weight", H, &L.ffn_norm));
+    BZ_TRY(take_vector_f32(m, p + "self_attn.kv_a_layernorm.weight", R, &L.kv_norm));
+    BZ_TRY(build_fused(m, {p + "self_attn.q_proj", p + "self_attn.kv_a_proj_with_mqa"}, &L.qkva));
+    if (L.qkva.parts.size() != 1 || L.qkva.parts[0].kind != LK_ROWS || L.qkva.N != NH * (DN + DR) + R + DR || L.qkva.K != H)
+      BZ_FAIL(BZ_E_INVALID, "layer %d: q_proj / kv_a_proj_with_mqa must be dense tensors matching the config", l);
+    force_direct(&L.qkva);
+    size_t kvb_bytes = 0;
+    BZ_TRY(take_dense(m, p + "self_attn.kv_b_proj.weight", (int64_t)NH * (DN + DV), R, &L.kv_b, &L.kv_b_dt, &kvb_bytes));
+    BZ_TRY(build_fused(m, {p + "self_attn.o_proj"}, &L.o));
+    if (L.o.N != H || L.o.K != NH * DV || L.o.parts[0].kind != LK_ROWS) BZ_FAIL(BZ_E_INVALID, "layer %d: o_proj must be dense [hidden, n_heads v_dim]", l);
+    per_token += kvb_bytes + (size_t)(2 * H + R) * act_b;
+    for (FusedLinear* F : {&L.qkva, &L.o}) for (auto& P : F->parts) { m->resident += P.bytes; per_token += P.algo_bytes; }
+    L.is_moe = E > 0 && l >= c.moe_first_dense;
+    if (!L.is_moe) {
+      BZ_TRY(build_fused(m, {p + "mlp.gate_proj", p + "mlp.up_proj"}, &L.gateup));
+      BZ_TRY(build_fused(m, {p + "mlp.down_proj"}, &L.down));
+      if (L.gateup.N != 2 * c.inter || L.gateup.K != H || L.down.N != H || L.down.K != c.inter) BZ_FAIL(BZ_E_INVALID, "layer %d: dense MLP shapes do not match the config", l);
+      for (FusedLinear* F : {&L.gateup, &L.down}) for (auto& P : F->parts) { m->resident += P.bytes; per_token += P.algo_bytes; }
+      ring_n = std::max(ring_n, 2 * c.inter);
+    } else {
+      size_t rb = 0;
+      BZ_TRY(take_dense(m, p + "mlp.gate.weight", E, H, &L.router, &L.router_dt, &rb));
+      auto it = m->raw.find(p + "mlp.experts.0.gate_proj.weight");
+      if (it == m->raw.end()) BZ_FAIL(BZ_E_NOTFOUND, "finalize: layer %d has no expert tensors", l);
+      L.e_dt = it->second.dtype;
+      const size_t es = bz_dtype_size(L.e_dt);
+      const size_t gu_sz = (size_t)2 * MI * H * es, dn_sz = (size_t)H * MI * es;
+      BZ_TRY(dev_alloc(m, &L.e_gu, (size_t)(E + NS) * gu_sz));
+      BZ_TRY(dev_alloc(m, &L.e_dn, (size_t)(E + NS) * dn_sz));
+      for (int e = 0; e < E; e++) {
+        snprintf(nm, sizeof nm, "%smlp.experts.%d.", p.c_str(), e);
+        std::string q = nm;
+        BZ_TRY(stack_dense(m, q + "gate_proj.weight", MI, H, L.e_dt, (char*)L.e_gu + (size_t)e * gu_sz, 0, H));
+        BZ_TRY(stack_dense(m, q + "up_proj.weight", MI, H, L.e_dt, (char*)L.e_gu + (size_t)e * gu_sz + gu_sz / 2, 0, H));
+        BZ_TRY(stack_dense(m, q + "down_proj.weight", H, MI, L.e_dt, (char*)L.e_dn + (size_t)e * dn_sz, 0, MI));
+        for (const char* t : {"gate_proj.weight", "up_proj.weight", "down_proj.weight"}) { RawTensor& r = m->raw[q + t]; raw_free(r); r.consumed = true; }
+      }
+      if (NS > 0) {
+        // the shared experts are one MLP of width NS * moe_inter: split into NS expert-shaped slots (exact: the down projection is a sum over its input)
+        std::string q = p + "mlp.shared_experts.";
+        auto itg = m->raw.find(q + "gate_proj.weight"), itu = m->raw.find(q + "up_proj.weight");
+        if (itg == m->raw.end() || itu == m->raw.end()) BZ_FAIL(BZ_E_NOTFOUND, "finalize: layer %d shared experts missing", l);
+        if (itg->second.kind != 0 || itg->second.N != (int64_t)NS * MI || itg->second.K != H || itg->second.dtype != L.e_dt || itu->second.kind != 0 ||
+            itu->second.N != (int64_t)NS * MI || itu->second.K != H || itu->second.dtype != L.e_dt)
+          BZ_FAIL(BZ_E_INVALID, "finalize: layer %d shared expert shapes do not match the config", l);
+        for (int j = 0; j < NS; j++) {
+          const size_t half_rows = (size_t)MI * H * es;
+          BZ_HIP(hipMemcpy((char*)L.e_gu + (size_t)(E + j) * gu_sz, (const char*)itg->second.d0 + (size_t)j * half_rows, half_rows, hipMemcpyDeviceToDevice));
+          BZ_HIP(hipMemcpy((char*)L.e_gu + (size_t)(E + j) * gu_sz + gu_sz / 2, (const char*)itu->second.d0 + (size_t)j * half_rows, half_rows, hipMemcpyDeviceToDevice));
+          BZ_TRY(stack_dense(m, q + "down_proj.weight", H, (int64_t)NS * MI, L.e_dt, (char*)L.e_dn + (size_t)(E + j) * dn_sz, (int64_t)j * MI, MI));
+        }
+        for (const char* t : {"gate_proj.weight", "up_proj.weight", "down_proj.weight"}) { RawTensor& r = m->raw[q + t]; raw_free(r); r.consumed = true; }
+      }
+      m->resident += (size_t)(E + NS) * (gu_sz + dn_sz);
+      per_token += rb + (size_t)(TK + NS) * (gu_sz + dn_sz);
+    }
+  }
+  BZ_TRY(take_vector_f32(m, "model.norm.weight", H, &m->final_norm));
+  {
+    auto it = m->raw.find("model.embed_tokens.weight");
+    if (it == m->raw.end()) BZ_FAIL(BZ_E_NOTFOUND, "finalize: 'model.embed_tokens.weight' was not added");
+    RawTensor& r = it->second;
+    if (r.kind != 0 || r.N != V || r.K != H) BZ_FAIL(BZ_E_INVALID, "finalize: embed_tokens must be dense [vocab, hidden]");
+    m->embed = r.d0; m->embed_dt = r.dtype; r.d0 = nullptr; m->owned.push_back(m->embed); r.consumed = true;
+    m->resident += r.bytes;
+    if (c.tie_embeddings || !m->raw.count("lm_head.weight")) {
+      LinearDev L; L.kind = LK_ROWS; L.N = V; L.K = H; L.wdt = m->embed_dt; L.w = m->embed; L.owned = false; L.bytes = 0; L.algo_bytes = r.bytes;
+      m->lm_head.parts.push_back(L); m->lm_head.n_off.push_back(0); m->lm_head.N = V; m->lm_head.K = H; m->lm_head.fix_out = false;
+      m->named["lm_head.weight"] = L;
+    } else {
+      BZ_TRY(build_fused(m, {"lm_head"}, &m->lm_head));
+      force_direct(&m->lm_head);
+      if (m->lm_head.N != V || m->lm_head.K != H || m->lm_head.fix_out) BZ_FAIL(BZ_E_INVALID, "finalize: lm_head must be dense [vocab, hidden]");
+    }
+  }
+  for (auto& kv : m->raw) if (!kv.second.consumed) BZ_FAIL(BZ_E_INVALID, "finalize: tensor '%s' is not used by this architecture", kv.first.c_str());
+  m->raw.clear();
+  // decoupled RoPE tables over the rope dims only
+  bz_model_config rc = c; rc.head_dim = DR;
+  std::vector<float> cs, sn;
+  rope_tables_host(rc, cs, sn);
+  void* p;
+  BZ_TRY(dev_alloc(m, &p, cs.size() * 4)); m->cos_t = (float*)p; BZ_HIP(hipMemcpy(p, cs.data(), cs.size() * 4, hipMemcpyHostToDevice));
+  BZ_TRY(dev_alloc(m, &p, sn.size() * 4)); m->sin_t = (float*)p; BZ_HIP(hipMemcpy(p, sn.data(), sn.size() * 4, hipMemcpyHostToDevice));
+  m->ring_n = std::max(ring_n, NH * (DN + DR) + R + DR);
+  for (int i = 0; i < 3; i++) {
+    BZ_TRY(dev_alloc(m, &p, (size_t)m->ring_n * 8)); m->ring[i] = (long long*)p; BZ_HIP(hipMemset(p, 0, (size_t)m->ring_n * 8));
+    BZ_TRY(dev_alloc(m, &p, (size_t)m->ring_n * 4)); m->dring[i] = (float*)p; BZ_HIP(hipMemset(p, 0, (size_t)m->ring_n * 4));
+  }
+  for (int i = 0; i < 2; i++) { BZ_TRY(dev_alloc(m, &p, (size_t)H * 4)); m->hbuf[i] = (float*)p; }
+  BZ_TRY(dev_alloc(m, &p, (size_t)NH * DV * 4)); m->attn_out = (float*)p;
+  BZ_TRY(dev_alloc(m, &p, (size_t)V * 4)); m->logits = (float*)p;
+  if (E > 0) {
+    BZ_TRY(dev_alloc(m, &p, (size_t)H * 4)); m->moe_xn = (float*)p;
+    BZ_TRY(dev_alloc(m, &p, (size_t)(TK + NS) * 2 * MI * 4)); m->moe_gu = (float*)p;
+    BZ_TRY(dev_alloc(m, &p, (size_t)H * 4)); m->moe_out = (float*)p;
+    BZ_TRY(dev_alloc(m, &p, (size_t)(TK + 1) * H * 8)); m->moe_acc = (long long*)p; BZ_HIP(hipMemset(p, 0, (size_t)(TK + 1) * H * 8));
+    BZ_TRY(dev_alloc(m, &p, (size_t)(TK + NS + 4) * 4)); m->moe_sel = (int*)p; BZ_HIP(hipMemset(p, 0, (size_t)(TK + NS + 4) * 4));
+    BZ_TRY(dev_alloc(m, &p, (size_t)(TK + NS + 4) * 4)); m->moe_w = (float*)p; BZ_HIP(hipMemset(p, 0, (size_t)(TK + NS + 4) * 4));
+  }
+  m->nparts = bzk_gemv_rows_blocks(m->lm_head.parts[0]);
+  BZ_TRY(dev_alloc(m, &p, (size_t)m->nparts * 4)); m->pval = (float*)p;
+  BZ_TRY(dev_alloc(m, &p, (size_t)m->nparts * 4)); m->pidx = (int*)p;
+  BZ_TRY(dev_alloc(m, &p, 4096)); m->scratch = (float*)p;
+  BZ_TRY(dev_alloc(m, &p, 64)); m->tok_tmp = (long long*)p;
+  BZ_TRY(dev_alloc(m, &p, 64)); m->pos_tmp = (int*)p;
+  for (auto& L : m->lm_head.parts) { m->resident += L.bytes; per_token += L.algo_bytes; }
+  m->per_token = per_token + (size_t)H * bz_dtype_size(m->embed_dt) + (size_t)H * act_b;
+  BZ_HIP(hipDeviceSynchronize());
+  m->finalized = true;
   return BZ_OK;
 }
 
@@ -1223,7 +1404,84 @@ static int mamba_step(bz_model* m, const StepIO& io) {
   return BZ_OK;
 }
 
-static int model_step(bz_model* m, const StepIO& io) { return m->cfg.arch == BZ_ARCH_MAMBA2 ? mamba_step(m, io) : llama_step(m, io); }
+// DeepSeek-V2 decode step: per layer  [q_proj ; kv_a] GEMV (norm prologue) -> MLA attention over the latent cache -> o_proj GEMV ->
+//   dense layer: gate/up GEMV (norm prologue) -> down GEMV (SiLU prologue)
+//   MoE layer:   router (norm, top-k) -> grouped gate/up GEMV over the selected + shared experts -> grouped down GEMV -> combine
+static int dsv2_step(bz_model* m, const StepIO& io) {
+  const bz_model_config& c = m->cfg;
+  hipStream_t st = m->dev->stream;
+  const int H = c.hidden, NH = c.n_heads, R = c.mla_kv_lora_rank, DN = c.mla_nope_dim, DR = c.mla_rope_dim, DV = c.mla_v_dim, act = c.act_dtype;
+  const int E = c.moe_n_experts, TK = c.moe_top_k, NS = c.moe_n_shared, MI = c.moe_inter;
+  int cur = 0;
+  RingState rs;
+  VSrc prev{nullptr, 0};
+  BZ_TRY(bzk_embed(st, m->embed, m->embed_dt, io.d_tok, H, act, m->hbuf[cur]));
+  for (int l = 0; l < c.n_layers; l++) {
+    const DsLayerDev& L = m->dlayers[l];
+    Pro pn{}; pn.mode = PRO_NORM; pn.src = prev; pn.h_in = m->hbuf[cur]; pn.h_out = m->hbuf[cur ^ 1]; pn.norm_w = L.attn_norm; pn.eps = c.rms_eps; pn.H = H; pn.act = act;
+    VSrc qkva;
+    BZ_TRY(run_fused(m, L.qkva, pn, rs, &qkva));
+    cur ^= 1;
+    MlaArgs ma{};
+    ma.qkv = qkva; ma.kv_norm = L.kv_norm; ma.eps = c.rms_eps; ma.wkvb = L.kv_b; ma.wdt = L.kv_b_dt; ma.cos_t = m->cos_t; ma.sin_t = m->sin_t; ma.pos = io.d_pos;
+    ma.n_heads = NH; ma.rank = R; ma.nope = DN; ma.rope = DR; ma.vdim = DV; ma.act = act; ma.kv = io.kv; ma.layer = l; ma.out = m->attn_out;
+    ma.scale = 1.0f / sqrtf((float)(DN + DR));
+    BZ_TRY(bzk_mla_attn(st, ma, c.max_seq_len));
+    Pro pp{}; pp.mode = PRO_PLAIN; pp.src = VSrc{m->attn_out, 0}; pp.act = act; pp.H = 0;
+    VSrc ov;
+    BZ_TRY(run_fused(m, L.o, pp, rs, &ov));
+    Pro pf{}; pf.mode = PRO_NORM; pf.src = ov; pf.h_in = m->hbuf[cur]; pf.h_out = m->hbuf[cur ^ 1]; pf.norm_w = L.ffn_norm; pf.eps = c.rms_eps; pf.H = H; pf.act = act;
+    if (!L.is_moe) {
+      VSrc gu, dn;
+      BZ_TRY(run_fused(m, L.gateup, pf, rs, &gu));
+      cur ^= 1;
+      Pro ps{}; ps.mode = PRO_SILU; ps.src = gu; ps.H = c.inter; ps.act = act;
+      BZ_TRY(run_fused(m, L.down, ps, rs, &dn));
+      prev = dn;
+    } else {
+      BZ_TRY(bzk_moe_router(st, pf, L.router, L.router_dt, E, TK, NS, c.moe_routed_scale, c.moe_norm_topk, m->moe_xn, m->moe_sel, m->moe_w));
+      cur ^= 1;
+      const int slots = TK + NS;
+      const size_t es = bz_dtype_size(L.e_dt);
+      MoeGemvArgs g1{};
+      g1.w = L.e_gu; g1.expert_stride = (long long)2 * MI * H; g1.sel = m->moe_sel; g1.N = 2 * MI; g1.K = H; g1.src_stride = 0;
+      g1.out = m->moe_gu; g1.out_stride = 2 * MI;
+      Pro p1{}; p1.mode = PRO_PLAIN; p1.src = VSrc{m->moe_xn, 0}; p1.act = act;
+      BZ_TRY(bzk_moe_gemv(st, g1, L.e_dt, slots, p1, act, false, (double)slots * 2 * MI * H * es));
+      MoeGemvArgs g2{};
+      g2.w = L.e_dn; g2.expert_stride = (long long)H * MI; g2.sel = m->moe_sel; g2.N = H; g2.K = MI; g2.src_stride = 2 * MI;
+      g2.acc = m->moe_acc; g2.acc_stride = H; g2.acc_slots = TK + 1;
+      Pro p2{}; p2.mode = PRO_SILU; p2.src = VSrc{m->moe_gu, 0}; p2.H = MI; p2.act = act;
+      BZ_TRY(bzk_moe_gemv(st, g2, L.e_dt, slots, p2, act, true, (double)slots * H * MI * es));
+      BZ_TRY(bzk_moe_combine(st, m->moe_acc, m->moe_w, TK, NS > 0, H, act, m->moe_out));
+      prev = VSrc{m->moe_out, 0};
+    }
+  }
+  const int ra = (rs.ri + 2) % 3, rb = (rs.ri + 1) % 3;
+  if (io.do_head) {
+    Pro ph{}; ph.mode = PRO_NORM; ph.src = prev; ph.h_in = m->hbuf[cur]; ph.h_out = nullptr; ph.norm_w = m->final_norm; ph.eps = c.rms_eps; ph.H = H; ph.act = act;
+    GemvOut o{};
+    o.direct = m->logits; o.amax_val = m->pval; o.amax_idx = m->pidx;
+    o.zero_buf = rs.dirty[rb] > 0 ? m->ring[rb] : nullptr; o.zero_n = rs.dirty[rb];
+    BZ_TRY(bzk_gemv(st, m->lm_head.parts[0], ph, o, act));
+    rs.dirty[rb] = 0;
+    if (io.final_args) {
+      FinalArgs fa = *io.final_args;
+      fa.pval = m->pval; fa.pidx = m->pidx; fa.nparts = m->nparts;
+      fa.zero_buf = rs.dirty[ra] > 0 ? m->ring[ra] : nullptr; fa.zero_n = rs.dirty[ra];
+      BZ_TRY(bzk_argmax_final(st, fa));
+      rs.dirty[ra] = 0;
+    }
+  }
+  for (int i = 0; i < 3; i++) if (rs.dirty[i] > 0) BZ_TRY(bzk_zero64(st, m->ring[i], rs.dirty[i]));
+  return BZ_OK;
+}
+
+static int model_step(bz_model* m, const StepIO& io) {
+  if (m->cfg.arch == BZ_ARCH_MAMBA2) return mamba_step(m, io);
+  if (m->cfg.arch == BZ_ARCH_DEEPSEEK2) return dsv2_step(m, io);
+  return llama_step(m, io);
+}
 
 static int check_fwd(bz_model* m, const bz_tensor* tokens, int S) {
   if (!m || !m->finalized) BZ_FAIL(BZ_E_INVALID, "forward: model not finalized");
@@ -1242,7 +1500,7 @@ static int emit_logits(bz_model* m, bz_tensor* logits_out, int row) {
 extern "C" int bz_forward_kv(bz_model* m, const bz_tensor* tokens, int S, bz_kv* kv, int position, bz_tensor* logits_out, uint32_t flags) {
   BZ_TRY(check_fwd(m, tokens, S));
   BZ_TRACE("forward_kv: S=%d position=%d", S, position);
-  if (m->cfg.arch != BZ_ARCH_LLAMA) BZ_FAIL(BZ_E_INVALID, "forward_kv: model has no KV cache (use bz_forward_ssm)");
+  if (m->cfg.arch == BZ_ARCH_MAMBA2) BZ_FAIL(BZ_E_INVALID, "forward_kv: model has no KV cache (use bz_forward_ssm)");
   if (!kv || kv->layers != m->cfg.n_layers || kv->n_kv != m->cfg.n_kv_heads || kv->hd != m->cfg.head_dim) BZ_FAIL(BZ_E_INVALID, "forward_kv: cache does not match the model");
   if (position < 0 || position + S > m->cfg.max_seq_len) BZ_FAIL(BZ_E_INVALID, "forward_kv: position %d + S %d exceeds max_seq_len %d", position, S, m->cfg.max_seq_len);
   BZ_TRY(kv_grow(kv, position + S));
@@ -1252,7 +1510,7 @@ extern "C" int bz_forward_kv(bz_model* m, const bz_tensor* tokens, int S, bz_kv*
     StepIO io{};
     io.kv = view_of(kv); io.d_tok = (const long long*)tokens->ptr + s; io.d_pos = m->pos_tmp;
     io.do_head = all || s == S - 1;
-    BZ_TRY(llama_step(m, io));
+    BZ_TRY(model_step(m, io));
     if (io.do_head) BZ_TRY(emit_logits(m, logits_out, all ? s : 0));
   }
   kv->seq_len = position + S;
@@ -1262,7 +1520,7 @@ extern "C" int bz_forward_kv(bz_model* m, const bz_tensor* tokens, int S, bz_kv*
 extern "C" int bz_forward_paged(bz_model* m, const bz_tensor* tokens, int S, bz_paged_kv* kv, const bz_tensor* slot_mapping,
                                 const bz_tensor* block_table, int n_table, int seq_len_k, int start_pos, bz_tensor* logits_out, uint32_t flags) {
   BZ_TRY(check_fwd(m, tokens, S));
-  if (m->cfg.arch != BZ_ARCH_LLAMA) BZ_FAIL(BZ_E_INVALID, "forward_paged: model has no KV cache (use bz_forward_ssm)");
+  if (m->cfg.arch != BZ_ARCH_LLAMA) BZ_FAIL(BZ_E_UNSUPPORTED, "forward_paged: llama family only (Mamba2 has no KV cache; the MLA latent cache is contiguous in this build)");
   if (!kv || kv->layers != m->cfg.n_layers || kv->n_kv != m->cfg.n_kv_heads || kv->hd != m->cfg.head_dim) BZ_FAIL(BZ_E_INVALID, "forward_paged: cache does not match the model");
   if (!slot_mapping || slot_mapping->dtype != BZ_I32 || slot_mapping->nbytes < (size_t)S * 4) BZ_FAIL(BZ_E_INVALID, "forward_paged: slot_mapping must be I32[S]");
   if (!block_table || block_table->dtype != BZ_I32 || block_table->nbytes < (size_t)n_table * 4) BZ_FAIL(BZ_E_INVALID, "forward_paged: block_table must be I32[n_table]");
@@ -1381,7 +1639,7 @@ static int profile_collect(BzTimingSink& sink, int rc, bz_kernel_time* out, int 
 }
 
 extern "C" int bz_profile_step(bz_model* m, bz_kv* kv, int64_t token, int position, int iters, bz_kernel_time* out, int max_out, int* n_out) {
-  if (m && m->finalized && m->cfg.arch != BZ_ARCH_LLAMA) BZ_FAIL(BZ_E_UNSUPPORTED, "profile_step: llama family only (use bz_profile_step_ssm)");
+  if (m && m->finalized && m->cfg.arch == BZ_ARCH_MAMBA2) BZ_FAIL(BZ_E_UNSUPPORTED, "profile_step: model has no KV cache (use bz_profile_step_ssm)");
   if (!m || !m->finalized || !kv || !out || !n_out || iters <= 0 || max_out <= 0) BZ_FAIL(BZ_E_INVALID, "profile_step: bad argument");
   if (token < 0 || token >= m->cfg.vocab || position < 0 || position + iters > m->cfg.max_seq_len) BZ_FAIL(BZ_E_INVALID, "profile_step: token/position out of range");
   BZ_HIP(hipSetDevice(m->dev->id));
@@ -1399,7 +1657,7 @@ extern "C" int bz_profile_step(bz_model* m, bz_kv* kv, int64_t token, int positi
     StepIO io{};
     io.kv = view_of(kv); io.d_tok = m->tok_tmp; io.d_pos = m->pos_tmp; io.final_args = &fa;
     bzk_set_timing_sink(&sink);
-    rc = llama_step(m, io);
+    rc = model_step(m, io);
     bzk_set_timing_sink(nullptr);
   }
   hipStreamSynchronize(st);
@@ -1558,7 +1816,8 @@ static int graph_capture_common(bz_decode_graph* g, const KvView& view) {
 
 extern "C" int bz_decode_graph_capture(bz_model* m, bz_kv* kv, bz_decode_graph** out) {
   if (!m || !m->finalized || !kv || !out) BZ_FAIL(BZ_E_INVALID, "graph capture: bad argument");
-  if (m->cfg.arch != BZ_ARCH_LLAMA) BZ_FAIL(BZ_E_INVALID, "graph capture: model has no KV cache (use bz_decode_graph_capture_ssm)");
+  if (m->cfg.arch == BZ_ARCH_MAMBA2) BZ_FAIL(BZ_E_INVALID, "graph capture: model has no KV cache (use bz_decode_graph_capture_ssm)");
+  if (kv->layers != m->cfg.n_layers || kv->n_kv != m->cfg.n_kv_heads || kv->hd != m->cfg.head_dim) BZ_FAIL(BZ_E_INVALID, "graph capture: cache does not match the model");
   BZ_HIP(hipSetDevice(m->dev->id));
   // stable addresses: the cache must sit at full capacity (cuda_graphs.rs:70)
   BZ_TRY(kv_grow(kv, kv->max_len));

@@ -196,6 +196,31 @@ int bzk_rope(hipStream_t s, float* x, int S, int nh, int hd, int position, const
              int act);
 int bzk_silu_mul(hipStream_t s, const float* g, const float* u, long long n, int act, float* y);
 
+// DeepSeek-V2 kernels (MLA attention over the latent cache, MoE router / grouped GEMV / combine)
+struct MlaArgs {
+  VSrc qkv;                 // [n_heads (nope+rope) | rank | rope]: fused q_proj + kv_a_proj output
+  const float* kv_norm; float eps;
+  const void* wkvb; int wdt;   // kv_b_proj [n_heads (nope+v)][rank]
+  const float* cos_t; const float* sin_t; const int* pos;
+  int n_heads, rank, nope, rope, vdim, act;
+  KvView kv; int layer;     // n_kv = 1, hd = rank + rope, contiguous
+  float* out;               // [n_heads vdim]
+  float scale;
+};
+struct MoeGemvArgs {
+  const void* w; long long expert_stride;       // elements between experts
+  const int* sel;                               // [n_slots] expert index per slot
+  int N, K;
+  long long src_stride;                         // prologue source: floats between slots (0: shared input)
+  float* out; long long out_stride;             // direct output (SPLIT == false)
+  long long* acc; long long acc_stride; int acc_slots;   // SPLIT: slot s accumulates into acc[min(s, acc_slots-1)]
+};
+int bzk_moe_gemv(hipStream_t s, const MoeGemvArgs& g, int wdt, int n_slots, const Pro& pro, int act, bool split, double bytes);
+int bzk_mla_attn(hipStream_t s, const MlaArgs& a, int max_len);
+int bzk_moe_router(hipStream_t s, const Pro& pro, const void* wr, int wdt, int E, int top_k, int n_shared, float routed_scale, int norm_topk,
+                   float* xn_out, int* sel, float* wsel);
+int bzk_moe_combine(hipStream_t s, long long* acc, const float* wsel, int top_k, int has_shared, int H, int act, float* out);
+
 // Mamba2 kernels
 int bzk_conv_step(hipStream_t s, const float* zxbcdt, int x_off, int conv_dim, int kc, const float* w, const float* b, float* conv_state, int act,
                   float* xbc_out);

@@ -1144,16 +1144,16 @@ __device__ __forceinline__ float piece_dot(const RowPiece<WDT>& p, const float4&
 // SPLIT: split-K.  blockIdx = row block * SK + ks; slice ks covers KCs chunks of 512 k; partial sums go to the 64-bit
 // fixed-point accumulator `accbuf` (order-independent, hence deterministic) and are rounded by the consumer.
 template <int WDT, bool SPLIT>
-__global__ __launch_bounds__(256) void k_gemv_rows(const void* __restrict__ W, const float* __restrict__ bias, int N, int K,
-                                                   int rows_per_wg, Pro pro, float* out, int act, float* pval, int* pidx,
-                                                   long long* zero_buf, int zero_n, int SK, long long* accbuf) {
+__device__ __forceinline__ void rows_body(const void* __restrict__ W, const float* __restrict__ bias, int N, int K, int rows_per_wg, const Pro& pro,
+                                          float* out, int act, float* pval, int* pidx, long long* zero_buf, int zero_n, int SK, long long* accbuf,
+                                          const int bid) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int KP = (K + 511) & ~511;
   float* xs = (float*)smem;     // [KP] swizzled
   float* red = xs + KP;         // [4] + argmax scratch [4] + [4]
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int rpw = rows_per_wg >> 2;
-  const int rb = SPLIT ? blockIdx.x / SK : blockIdx.x, ks = SPLIT ? blockIdx.x % SK : 0;
+  const int rb = SPLIT ? bid / SK : bid, ks = SPLIT ? bid % SK : 0;
   const int rbeg = rb * rows_per_wg + wave * rpw;
   const int rend = min(rbeg + rpw, N);
   const int KCall = KP >> 9, KCs = SPLIT ? (KCall + SK - 1) / SK : KCall;
@@ -1181,12 +1181,12 @@ __global__ __launch_bounds__(256) void k_gemv_rows(const void* __restrict__ W, c
   if (!SPLIT || pro.mode == PRO_GATED) {
     // whole vector in LDS (the gated norm needs every element of its group anyway)
     for (int i = K + threadIdx.x; i < KP; i += 256) xs[xs_pos<true>(i)] = 0.f;
-    build_x_simple<true>(pro, 0, K, xs, red, blockIdx.x == 0);
+    build_x_simple<true>(pro, 0, K, xs, red, bid == 0);
     xs4 = (const float4*)(xs + kb);
   } else {
     const int KR = max(min(K - kb, KC * 512), 0);
     for (int i = KR + threadIdx.x; i < KC * 512; i += 256) xs[xs_pos<true>(i)] = 0.f;
-    build_x_simple<true>(pro, kb, KR, xs, red, blockIdx.x == 0);
+    build_x_simple<true>(pro, kb, KR, xs, red, bid == 0);
     xs4 = (const float4*)xs;
   }
   float bestv = -INFINITY; int besti = 0x7fffffff;
@@ -1231,9 +1231,30 @@ __global__ __launch_bounds__(256) void k_gemv_rows(const void* __restrict__ W, c
     if (threadIdx.x == 0) {
       float v = bv[0]; int ix = bi[0];
       for (int w2 = 1; w2 < 4; w2++) if (bv[w2] > v) { v = bv[w2]; ix = bi[w2]; }
-      pval[blockIdx.x] = v; pidx[blockIdx.x] = ix;
+      pval[bid] = v; pidx[bid] = ix;
     }
   }
+}
+
+template <int WDT, bool SPLIT>
+__global__ __launch_bounds__(256) void k_gemv_rows(const void* __restrict__ W, const float* __restrict__ bias, int N, int K,
+                                                   int rows_per_wg, Pro pro, float* out, int act, float* pval, int* pidx,
+                                                   long long* zero_buf, int zero_n, int SK, long long* accbuf) {
+  rows_body<WDT, SPLIT>(W, bias, N, K, rows_per_wg, pro, out, act, pval, pidx, zero_buf, zero_n, SK, accbuf, blockIdx.x);
+}
+
+// MoE grouped GEMV: blockIdx.y = expert slot.  The expert id comes from the router's device-side selection, so the whole MoE
+// layer stays capturable in a hipGraph.  Stacked weights [E + n_shared][N][K]; per-slot prologue source / output offsets.
+template <int WDT, bool SPLIT>
+__global__ __launch_bounds__(256) void k_moe_rows(MoeGemvArgs g, Pro pro, int act) {
+  const int slot = blockIdx.y;
+  const int e = g.sel[slot];
+  const size_t es = WDT == BZ_F32 ? 4 : 2;
+  const void* W = (const char*)g.w + (size_t)e * (size_t)g.expert_stride * es;
+  pro.src.p = (const float*)pro.src.p + (size_t)slot * g.src_stride;
+  float* out = SPLIT ? nullptr : g.out + (size_t)slot * g.out_stride;
+  long long* acc = SPLIT ? g.acc + (size_t)min(slot, g.acc_slots - 1) * g.acc_stride : nullptr;
+  rows_body<WDT, SPLIT>(W, nullptr, g.N, g.K, 16, pro, out, act, nullptr, nullptr, nullptr, 0, 1, acc, blockIdx.x);
 }
 
 static int rows_per_wg_for(int N) {
@@ -2542,6 +2563,306 @@ int bzk_ssm_step(hipStream_t s, const SsmArgs& a) {
   if (a.sdt == BZ_F32) BZ_LAUNCH("mamba2_ssm_step", bytes, (k_ssm_step<BZ_F32>), dim3(a.n_heads), dim3(256), 0, s, a);
   else if (a.sdt == BZ_F16) BZ_LAUNCH("mamba2_ssm_step", bytes, (k_ssm_step<BZ_F16>), dim3(a.n_heads), dim3(256), 0, s, a);
   else BZ_LAUNCH("mamba2_ssm_step", bytes, (k_ssm_step<BZ_BF16>), dim3(a.n_heads), dim3(256), 0, s, a);
+  BZ_HIP(hipGetLastError());
+  return BZ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// DeepSeek-V2: MLA decode attention over the compressed-latent cache (weight-absorbed form) + MoE router / combine
+// ---------------------------------------------------------------------------------------------------------
+// One workgroup per head.  Cache row = [latent c (rank) | roped k_pe (rope)] in the cache dtype; n_kv = 1.
+//   c = rmsnorm(kva[:rank]) ; kpe = R(rope(kva[rank:]))                        (block 0 appends the row at `pos`)
+//   qabs = R(Wuk_h^T q_nope) ; s_t = (qabs . c_t + qpe . kpe_t) * scale ; p = softmax(s)
+//   olat = R(sum_t p_t c_t) ; out_h = R(Wuv_h olat)
+// LDS: ccur[rank] kcur[rope] qn[nope] qp[rope] qabs[rank] part[4][rank] red[8] sc[len]
+__global__ __launch_bounds__(256) void k_mla_attn(MlaArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int R = a.rank, DN = a.nope, DR = a.rope, DV = a.vdim;
+  float* ccur = lds; float* kcur = ccur + R; float* qn = kcur + DR; float* qp = qn + DN; float* qabs = qp + DR;
+  float* part = qabs + R; float* red = part + 4 * R; float* sc = red + 8;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hd = blockIdx.x;
+  const int pos = a.pos[0], len = pos + 1;
+  const int QH = DN + DR, qoff = hd * QH, coff = a.n_heads * QH;
+  // ---- current token: latent norm, k_pe / q_pe rope, q_nope ----
+  float ss = 0.f;
+  for (int r = tid; r < R; r += 256) { const float v = vsrc_get(a.qkv, coff + r, a.act); ccur[r] = v; ss += v * v; }
+  ss = block_sum256(ss, red);
+  const float rs = 1.0f / sqrtf(ss / (float)R + a.eps);
+  for (int r = tid; r < R; r += 256) ccur[r] = round_act(a.kv_norm[r] * round_act(ccur[r] * rs, a.act), a.act);
+  const float* cr = a.cos_t + (size_t)pos * (DR / 2); const float* sr = a.sin_t + (size_t)pos * (DR / 2);
+  for (int j = tid; j < DR / 2; j += 256) {
+    const float c = cr[j], s = sr[j];
+    float x0 = vsrc_get(a.qkv, coff + R + 2 * j, a.act), x1 = vsrc_get(a.qkv, coff + R + 2 * j + 1, a.act);
+    kcur[2 * j] = round_act(x0 * c - x1 * s, a.act); kcur[2 * j + 1] = round_act(x1 * c + x0 * s, a.act);
+    x0 = vsrc_get(a.qkv, qoff + DN + 2 * j, a.act); x1 = vsrc_get(a.qkv, qoff + DN + 2 * j + 1, a.act);
+    qp[2 * j] = round_act(x0 * c - x1 * s, a.act); qp[2 * j + 1] = round_act(x1 * c + x0 * s, a.act);
+  }
+  for (int d = tid; d < DN; d += 256) qn[d] = vsrc_get(a.qkv, qoff + d, a.act);
+  __syncthreads();
+  const size_t rowbase = (size_t)a.layer * a.kv.layer_stride;
+  const int Wd = R + DR;
+  if (hd == 0) {
+    for (int i = tid; i < Wd; i += 256) kv_st(a.kv.k, rowbase + (size_t)pos * Wd + i, a.kv.dtype, i < R ? ccur[i] : kcur[i - R]);
+  }
+  // ---- qabs = R(Wuk^T q_nope): wave w takes nope rows [w DN/4, (w+1) DN/4); a lane owns 8 columns per 512-column chunk ----
+  const int NCH = (R + 511) >> 9;        // <= 2 (rank <= 1024)
+  const size_t wrow0 = (size_t)hd * (DN + DV);
+  {
+    float acc[2][8];
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+      for (int e = 0; e < 8; e++) acc[c][e] = 0.f;
+    const int d0 = wave * (DN / 4), d1 = d0 + DN / 4;
+    for (int d = d0; d < d1; d += 4) {
+      float w[4][2][8];
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+          const int col = c * 512 + lane * 8;
+          if (c < NCH) kv_ld8(a.wkvb, (wrow0 + (size_t)min(d + u, d1 - 1)) * R + (col < R ? col : 0), a.wdt, w[u][c]);
+        }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const float qd = (d + u < d1) ? qn[d + u] : 0.f;
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+          if (c < NCH)
+#pragma unroll
+            for (int e = 0; e < 8; e++) acc[c][e] += qd * w[u][c][e];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      const int col = c * 512 + lane * 8;
+      if (c < NCH && col < R)
+#pragma unroll
+        for (int e = 0; e < 8; e++) part[wave * R + col + e] = acc[c][e];
+    }
+  }
+  __syncthreads();
+  for (int r = tid; r < R; r += 256) qabs[r] = round_act((part[r] + part[R + r]) + (part[2 * R + r] + part[3 * R + r]), a.act);
+  __syncthreads();
+  // ---- scores ----
+  float qa[2][8], qpl = (lane < DR) ? qp[lane] : 0.f;
+#pragma unroll
+  for (int c = 0; c < 2; c++) {
+    const int col = c * 512 + lane * 8;
+#pragma unroll
+    for (int e = 0; e < 8; e++) qa[c][e] = (c < NCH && col < R) ? qabs[col + e] : 0.f;
+  }
+  for (int t = wave; t < len; t += 4) {
+    float dsum = 0.f;
+    if (t == pos) {
+#pragma unroll
+      for (int c = 0; c < 2; c++) {
+        const int col = c * 512 + lane * 8;
+        if (c < NCH && col < R)
+#pragma unroll
+          for (int e = 0; e < 8; e++) dsum += qa[c][e] * ccur[col + e];
+      }
+      if (lane < DR) dsum += qpl * kcur[lane];
+    } else {
+      const size_t ro = rowbase + (size_t)t * Wd;
+#pragma unroll
+      for (int c = 0; c < 2; c++) {
+        const int col = c * 512 + lane * 8;
+        if (c < NCH && col < R) {
+          float cv[8];
+          kv_ld8(a.kv.k, ro + col, a.kv.dtype, cv);
+#pragma unroll
+          for (int e = 0; e < 8; e++) dsum += qa[c][e] * cv[e];
+        }
+      }
+      if (lane < DR) dsum += qpl * kv_ld(a.kv.k, ro + R + lane, a.kv.dtype);
+    }
+    dsum = wave_sum(dsum);
+    if (lane == 0) sc[t] = dsum * a.scale;
+  }
+  __syncthreads();
+  float mx = -INFINITY;
+  for (int t = tid; t < len; t += 256) mx = fmaxf(mx, sc[t]);
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float psum = 0.f;
+  for (int t = tid; t < len; t += 256) { const float p = expf(sc[t] - mx); sc[t] = p; psum += p; }
+  psum = block_sum256(psum, red);
+  const float inv = 1.0f / psum;
+  // ---- olat = R(sum_t p_t c_t * inv) ----
+  {
+    float acc[2][8];
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+      for (int e = 0; e < 8; e++) acc[c][e] = 0.f;
+    for (int t = wave; t < len; t += 4) {
+      const float p = sc[t];
+      const size_t ro = rowbase + (size_t)t * Wd;
+#pragma unroll
+      for (int c = 0; c < 2; c++) {
+        const int col = c * 512 + lane * 8;
+        if (c < NCH && col < R) {
+          float cv[8];
+          if (t == pos) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) cv[e] = ccur[col + e];
+          } else {
+            kv_ld8(a.kv.k, ro + col, a.kv.dtype, cv);
+          }
+#pragma unroll
+          for (int e = 0; e < 8; e++) acc[c][e] += p * cv[e];
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      const int col = c * 512 + lane * 8;
+      if (c < NCH && col < R)
+#pragma unroll
+        for (int e = 0; e < 8; e++) part[wave * R + col + e] = acc[c][e];
+    }
+  }
+  __syncthreads();
+  for (int r = tid; r < R; r += 256) qabs[r] = round_act(((part[r] + part[R + r]) + (part[2 * R + r] + part[3 * R + r])) * inv, a.act);   // qabs now holds olat
+  __syncthreads();
+  // ---- out_h = R(Wuv olat): wave w takes v rows [w DV/4, (w+1) DV/4), 4 rows in flight ----
+#pragma unroll
+  for (int c = 0; c < 2; c++) {
+    const int col = c * 512 + lane * 8;
+#pragma unroll
+    for (int e = 0; e < 8; e++) qa[c][e] = (c < NCH && col < R) ? qabs[col + e] : 0.f;
+  }
+  const int v0 = wave * (DV / 4), v1 = v0 + DV / 4;
+  for (int d = v0; d < v1; d += 4) {
+    float w[4][2][8];
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+      for (int c = 0; c < 2; c++) {
+        const int col = c * 512 + lane * 8;
+        if (c < NCH) kv_ld8(a.wkvb, (wrow0 + DN + (size_t)min(d + u, v1 - 1)) * R + (col < R ? col : 0), a.wdt, w[u][c]);
+      }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < 2; c++)
+        if (c < NCH)
+#pragma unroll
+          for (int e = 0; e < 8; e++) s += w[u][c][e] * qa[c][e];
+      s = wave_sum(s);
+      if (lane == 0 && d + u < v1) a.out[hd * DV + d + u] = round_act(s, a.act);
+    }
+  }
+}
+
+size_t bzk_mla_smem(const MlaArgs& a, int max_len) { return (size_t)(a.rank * 6 + a.rope * 2 + a.nope + 8 + max_len) * 4 + 64; }
+
+int bzk_mla_attn(hipStream_t s, const MlaArgs& a, int max_len) {
+  if (a.rank % 8 || a.rank > 1024 || a.rope > 64 || (a.rope & 1) || a.nope % 4 || a.vdim % 4 || a.kv.paged || a.kv.n_kv != 1 || a.kv.hd != a.rank + a.rope)
+    BZ_FAIL(BZ_E_UNSUPPORTED, "mla_attn: rank %d / rope %d / nope %d / v %d unsupported", a.rank, a.rope, a.nope, a.vdim);
+  const size_t smem = bzk_mla_smem(a, max_len);
+  if (smem > 160 * 1024) BZ_FAIL(BZ_E_UNSUPPORTED, "mla_attn: context %d too long for the single-pass kernel", max_len);
+  static bool attr_done = false;
+  if (!attr_done) { BZ_HIP(hipFuncSetAttribute((const void*)k_mla_attn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_done = true; }
+  const double bytes = (double)a.n_heads * (a.nope + a.vdim) * a.rank * bz_dtype_size(a.wdt);
+  BZ_LAUNCH("mla_attn", bytes, k_mla_attn, dim3(a.n_heads), dim3(256), smem, s, a);
+  BZ_HIP(hipGetLastError());
+  return BZ_OK;
+}
+
+// Router: one workgroup.  Residual add + RMSNorm (writes h' and the normalised x for the expert GEMVs), f32 logits over E
+// experts, f32 softmax, greedy top-k (ties -> lowest index).  Slots [top_k, top_k + n_shared) are the shared-expert halves.
+__global__ __launch_bounds__(256) void k_moe_router(Pro pro, const void* wr, int wdt, int E, int top_k, int n_shared, float routed_scale, int norm_topk,
+                                                    float* xn_out, int* sel, float* wsel) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int H = pro.H;
+  float* xs = lds; float* red = xs + H; float* lg = red + 16;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  build_x_simple<false>(pro, 0, H, xs, red, true);
+  for (int i = tid; i < H; i += 256) xn_out[i] = xs[i];
+  for (int e0 = wave * 4; e0 < E; e0 += 16) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = lane * 8; k < H; k += 512) {
+      float w[4][8];
+#pragma unroll
+      for (int u = 0; u < 4; u++) kv_ld8(wr, (size_t)min(e0 + u, E - 1) * H + k, wdt, w[u]);
+      const float4 xa = *(const float4*)(xs + k), xb = *(const float4*)(xs + k + 4);
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        acc[u] += w[u][0] * xa.x + w[u][1] * xa.y + w[u][2] * xa.z + w[u][3] * xa.w + w[u][4] * xb.x + w[u][5] * xb.y + w[u][6] * xb.z + w[u][7] * xb.w;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const float v = wave_sum(acc[u]); if (lane == 0 && e0 + u < E) lg[e0 + u] = v; }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float m = -INFINITY, sum = 0.f;
+    for (int e = 0; e < E; e++) m = fmaxf(m, lg[e]);
+    for (int e = 0; e < E; e++) { lg[e] = expf(lg[e] - m); sum += lg[e]; }
+    for (int e = 0; e < E; e++) lg[e] = lg[e] / sum;
+    float tsum = 0.f;
+    for (int k = 0; k < top_k; k++) {
+      int best = -1;
+      for (int e = 0; e < E; e++) {
+        bool taken = false;
+        for (int j = 0; j < k; j++) taken = taken || sel[j] == e;
+        if (!taken && (best < 0 || lg[e] > lg[best])) best = e;
+      }
+      sel[k] = best; wsel[k] = lg[best]; tsum += lg[best];
+    }
+    for (int k = 0; k < top_k; k++) wsel[k] = norm_topk ? wsel[k] / (tsum + 1e-20f) * routed_scale : wsel[k] * routed_scale;
+    for (int j = 0; j < n_shared; j++) { sel[top_k + j] = E + j; wsel[top_k + j] = 1.0f; }
+  }
+}
+
+int bzk_moe_router(hipStream_t s, const Pro& pro, const void* wr, int wdt, int E, int top_k, int n_shared, float routed_scale, int norm_topk,
+                   float* xn_out, int* sel, float* wsel) {
+  if (E > 1024 || top_k > E || pro.H % 8) BZ_FAIL(BZ_E_UNSUPPORTED, "moe_router: E %d / top_k %d unsupported", E, top_k);
+  const size_t smem = (size_t)(pro.H + 16 + E) * 4 + 64;
+  if (smem > 64 * 1024) BZ_FAIL(BZ_E_UNSUPPORTED, "moe_router: hidden %d too large", pro.H);
+  BZ_LAUNCH("moe_router", (double)E * pro.H * bz_dtype_size(wdt), k_moe_router, dim3(1), dim3(256), smem, s, pro, wr, wdt, E, top_k, n_shared, routed_scale,
+            norm_topk, xn_out, sel, wsel);
+  BZ_HIP(hipGetLastError());
+  return BZ_OK;
+}
+
+int bzk_moe_gemv(hipStream_t s, const MoeGemvArgs& g, int wdt, int n_slots, const Pro& pro, int act, bool split, double bytes) {
+  const int KP = (g.K + 511) & ~511;
+  const size_t smem = (size_t)KP * 4 + 64;
+  if (g.K % 8 || smem > 160 * 1024) BZ_FAIL(BZ_E_UNSUPPORTED, "moe_gemv: K=%d unsupported", g.K);
+  const dim3 grid((g.N + 15) / 16, n_slots);
+  const char* lbl = split ? "moe_gemv<down>" : "moe_gemv<gate_up>";
+#define LAUNCH_MOE(DT) do { if (split) BZ_LAUNCH(lbl, bytes, (k_moe_rows<DT, true>), grid, dim3(256), smem, s, g, pro, act); \
+                            else BZ_LAUNCH(lbl, bytes, (k_moe_rows<DT, false>), grid, dim3(256), smem, s, g, pro, act); } while (0)
+  if (wdt == BZ_F16) LAUNCH_MOE(BZ_F16); else if (wdt == BZ_BF16) LAUNCH_MOE(BZ_BF16); else LAUNCH_MOE(BZ_F32);
+#undef LAUNCH_MOE
+  BZ_HIP(hipGetLastError());
+  return BZ_OK;
+}
+
+// routed = R(sum_k w_k * R(y_k)) (selection order, f32) ; out = R(routed + R(y_shared)) ; the accumulators are zeroed for the next layer
+__global__ void k_moe_combine(long long* acc, const float* wsel, int top_k, int has_shared, int H, int act, float* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= H) return;
+  float r = 0.f;
+  for (int k = 0; k < top_k; k++) {
+    r += wsel[k] * round_act(fix2f(acc[(size_t)k * H + i]), act);
+    acc[(size_t)k * H + i] = 0;
+  }
+  r = round_act(r, act);
+  if (has_shared) {
+    r = round_act(r + round_act(fix2f(acc[(size_t)top_k * H + i]), act), act);
+    acc[(size_t)top_k * H + i] = 0;
+  }
+  out[i] = r;
+}
+int bzk_moe_combine(hipStream_t s, long long* acc, const float* wsel, int top_k, int has_shared, int H, int act, float* out) {
+  BZ_LAUNCH("moe_combine", 0.0, k_moe_combine, dim3((H + 255) / 256), dim3(256), 0, s, acc, wsel, top_k, has_shared, H, act, out);
   BZ_HIP(hipGetLastError());
   return BZ_OK;
 }

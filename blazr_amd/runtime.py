@@ -121,6 +121,23 @@ def make_config(cfg):
         c.act_dtype = _DT[cfg["act_dtype"]]
         c.tie_embeddings = int(bool(cfg.get("tie_embeddings")))
         return c
+    if cfg.get("arch") == "deepseek2":
+        # AttentionConfig kv_latent_dim / q_latent_dim / d_rope (loader/gguf.rs:188-196), MoeConfig (loader/gguf.rs:271-283)
+        c.arch = L.ARCH_DEEPSEEK2
+        for k in ("hidden", "n_layers", "n_heads", "vocab", "max_seq_len", "inter"):
+            setattr(c, k, int(cfg[k]))
+        for k in ("kv_lora_rank", "q_lora_rank", "nope_dim", "rope_dim", "v_dim"):
+            setattr(c, "mla_" + k, int(cfg[k]))
+        c.moe_n_experts, c.moe_top_k, c.moe_n_shared = int(cfg["n_experts"]), int(cfg["top_k"]), int(cfg["n_shared"])
+        c.moe_inter, c.moe_first_dense, c.moe_norm_topk = int(cfg["moe_inter"]), int(cfg["first_dense"]), int(bool(cfg["norm_topk"]))
+        c.moe_routed_scale = float(cfg["routed_scale"])
+        c.rms_eps = cfg["rms_eps"]
+        c.act_dtype = _DT[cfg["act_dtype"]]
+        c.tie_embeddings = int(bool(cfg.get("tie_embeddings")))
+        c.rope_theta = cfg["rope_theta"]
+        c.rope_interleaved = 1
+        c.rope_scaling, c.rope_factor, c.rope_low_freq_factor, c.rope_high_freq_factor, c.rope_original_max_pos = L.ROPE_NONE, 1.0, 1.0, 4.0, 8192
+        return c
     c.arch = L.ARCH_LLAMA
     for k in ("hidden", "n_layers", "n_heads", "n_kv_heads", "head_dim", "inter", "vocab", "max_seq_len"):
         setattr(c, k, int(cfg[k]))
@@ -214,6 +231,27 @@ class LoadedModel:
         if not self.cfg.get("tie_embeddings"):
             self.add_linear("lm_head", lm_head)
 
+    def add_dsv2_layer(self, i, lay):
+        """HF DeepSeek-V2 tensor names"""
+        p = "model.layers.%d." % i
+        f32 = lambda a: np.asarray(a, dtype=np.float32)
+        self.add_dense(p + "input_layernorm.weight", f32(lay["attn_norm"]))
+        self.add_dense(p + "post_attention_layernorm.weight", f32(lay["ffn_norm"]))
+        self.add_dense(p + "self_attn.kv_a_layernorm.weight", f32(lay["kv_norm"]))
+        for short, hf in (("q_proj", "self_attn.q_proj"), ("kv_a", "self_attn.kv_a_proj_with_mqa"), ("kv_b", "self_attn.kv_b_proj"), ("o", "self_attn.o_proj")):
+            self.add_linear(p + hf, lay[short])
+        if not lay["is_moe"]:
+            for n in ("gate", "up", "down"):
+                self.add_linear(p + "mlp.%s_proj" % n, lay[n])
+        else:
+            self.add_linear(p + "mlp.gate", lay["router"])
+            for e, ex in enumerate(lay["experts"]):
+                for n in ("gate", "up", "down"):
+                    self.add_linear(p + "mlp.experts.%d.%s_proj" % (e, n), ex[n])
+            if "shared" in lay:
+                for n in ("gate", "up", "down"):
+                    self.add_linear(p + "mlp.shared_experts.%s_proj" % n, lay["shared"][n])
+
     def add_mamba2_layer(self, i, lay):
         """HF Mamba2 tensor names (backbone.layers.{i}.mixer.*)"""
         p = "backbone.layers.%d." % i
@@ -239,6 +277,12 @@ class LoadedModel:
     def from_synth(cls, dev, model):
         """Whole in-memory model dict (blazr_amd.synth.make_llama / make_mamba2)."""
         m = cls(dev, model["config"])
+        if model["config"].get("arch") == "deepseek2":
+            for i, lay in enumerate(model["layers"]):
+                m.add_dsv2_layer(i, lay)
+            m.add_llama_head(model["embed"], model["final_norm"], model["lm_head"])
+            m.finalize()
+            return m
         if model["config"].get("arch") == "mamba2":
             for i, lay in enumerate(model["layers"]):
                 m.add_mamba2_layer(i, lay)
@@ -257,6 +301,13 @@ class LoadedModel:
         from . import synth
         kw = {} if seed is None else {"seed": seed}
         m = cls(dev, cfg)
+        if cfg.get("arch") == "deepseek2":
+            for i in range(cfg["n_layers"]):
+                m.add_dsv2_layer(i, synth.dsv2_layer(cfg, i, **kw))
+            emb, fn, lm = synth.dsv2_head(cfg, **kw)
+            m.add_llama_head(emb, fn, lm)
+            m.finalize()
+            return m
         if cfg.get("arch") == "mamba2":
             for i in range(cfg["n_layers"]):
                 m.add_mamba2_layer(i, synth.mamba2_layer(cfg, i, **kw))
@@ -280,10 +331,10 @@ class LoadedModel:
         return self.c.n_layers
 
     def num_kv_heads(self):
-        return self.c.n_kv_heads
+        return 1 if self.c.arch == L.ARCH_DEEPSEEK2 else self.c.n_kv_heads
 
     def head_dim(self):
-        return self.c.head_dim
+        return self.c.mla_kv_lora_rank + self.c.mla_rope_dim if self.c.arch == L.ARCH_DEEPSEEK2 else self.c.head_dim
 
     def hidden_size(self):
         return self.c.hidden
@@ -296,6 +347,16 @@ class LoadedModel:
 
     def needs_ssm_state(self):
         return self.c.arch == L.ARCH_MAMBA2
+
+    def moe_config(self):
+        if self.c.arch != L.ARCH_DEEPSEEK2 or self.c.moe_n_experts == 0:
+            return None
+        return dict(num_experts=self.c.moe_n_experts, experts_per_tok=self.c.moe_top_k, shared_experts=self.c.moe_n_shared)
+
+    def new_kv_cache(self, capacity, max_seq_len=None):
+        """LayeredKvCache::new_positional with this model's cache shape (for MLA: one 'head' of kv_lora_rank + rope_dim latents)"""
+        dt = self.c.act_dtype
+        return LayeredKvCache(self.dev, self.c.n_layers, 1, self.num_kv_heads(), capacity, max_seq_len or self.c.max_seq_len, self.head_dim(), dt)
 
     def mamba_config(self):
         if self.c.arch != L.ARCH_MAMBA2:

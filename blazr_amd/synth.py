@@ -63,6 +63,21 @@ MAMBA_PRESETS = {
                            n_groups=2, conv_kernel=4, rms_eps=1e-5, act_dtype="f32", tie_embeddings=False, max_seq_len=1 << 20),
 }
 
+DSV2_PRESETS = {
+    # BASELINE.json configs[4]: DeepSeek-V2-Lite (SURVEY.md 8d cfg 5): MLA (kv_lora 512, nope 128 + rope 64, v 128), first layer dense,
+    # 26 MoE layers with 64 routed top-6 + 2 shared experts
+    "deepseek-v2-lite": dict(arch="deepseek2", hidden=2048, n_layers=27, n_heads=16, vocab=102400, max_seq_len=4096, kv_lora_rank=512,
+                             q_lora_rank=0, nope_dim=128, rope_dim=64, v_dim=128, inter=10944, n_experts=64, top_k=6, n_shared=2,
+                             moe_inter=1408, first_dense=1, routed_scale=1.0, norm_topk=False, rms_eps=1e-6, act_dtype="bf16",
+                             rope_theta=10000.0, tie_embeddings=False),
+    "tiny-dsv2": dict(arch="deepseek2", hidden=256, n_layers=3, n_heads=4, vocab=1024, max_seq_len=256, kv_lora_rank=128, q_lora_rank=0,
+                      nope_dim=64, rope_dim=32, v_dim=64, inter=512, n_experts=8, top_k=3, n_shared=2, moe_inter=128, first_dense=1,
+                      routed_scale=1.0, norm_topk=False, rms_eps=1e-6, act_dtype="bf16", rope_theta=10000.0, tie_embeddings=False),
+    "tiny-dsv2-f32": dict(arch="deepseek2", hidden=256, n_layers=2, n_heads=4, vocab=1024, max_seq_len=256, kv_lora_rank=64, q_lora_rank=0,
+                          nope_dim=64, rope_dim=32, v_dim=32, inter=512, n_experts=8, top_k=2, n_shared=1, moe_inter=128, first_dense=0,
+                          routed_scale=2.0, norm_topk=True, rms_eps=1e-6, act_dtype="f32", rope_theta=10000.0, tie_embeddings=True),
+}
+
 GGML_Q8_0, GGML_Q4_K, GGML_Q6_K = 8, 12, 14
 BASE_SEED = 0xB1A2
 
@@ -322,3 +337,66 @@ def mamba2_bytes_per_token(cfg):
     weights = L * per_layer + V * D * b + D * b + D * b
     state = L * (NH * HD * NS * b * 2 + conv_dim * (KC - 1) * 4 * 2)
     return weights, state
+
+
+# ---- DeepSeek-V2 family (MLA + MoE) ---------------------------------------------------------------------------------
+def make_dsv2_config(preset, **over):
+    cfg = dict(DSV2_PRESETS[preset]) if isinstance(preset, str) else dict(preset)
+    cfg.update(over)
+    return cfg
+
+
+def _dsv2_mlp(prefix, H, I, act, seed):
+    return dict(gate=dense_linear(prefix + "gate_proj", I, H, act, seed=seed), up=dense_linear(prefix + "up_proj", I, H, act, seed=seed),
+                down=dense_linear(prefix + "down_proj", H, I, act, seed=seed))
+
+
+def dsv2_layer(cfg, i, seed=BASE_SEED):
+    """HF DeepSeek-V2 tensor names: self_attn.{q_proj, kv_a_proj_with_mqa, kv_a_layernorm, kv_b_proj, o_proj}, mlp.{gate, experts.N, shared_experts}"""
+    H, NH, R, DN, DR, DV, act = cfg["hidden"], cfg["n_heads"], cfg["kv_lora_rank"], cfg["nope_dim"], cfg["rope_dim"], cfg["v_dim"], cfg["act_dtype"]
+    if cfg.get("q_lora_rank"):
+        raise ValueError("synthetic q_lora_rank > 0 is not generated")
+    p = "model.layers.%d." % i
+    lay = dict(attn_norm=_repr(1.0 + _normal(_rng(p + "input_layernorm.weight", seed), (H,), 0.02), act),
+               ffn_norm=_repr(1.0 + _normal(_rng(p + "post_attention_layernorm.weight", seed), (H,), 0.02), act),
+               kv_norm=_repr(1.0 + _normal(_rng(p + "self_attn.kv_a_layernorm.weight", seed), (R,), 0.02), act),
+               q_proj=dense_linear(p + "self_attn.q_proj", NH * (DN + DR), H, act, seed=seed),
+               kv_a=dense_linear(p + "self_attn.kv_a_proj_with_mqa", R + DR, H, act, seed=seed),
+               kv_b=dense_linear(p + "self_attn.kv_b_proj", NH * (DN + DV), R, act, std=0.05, seed=seed),
+               o=dense_linear(p + "self_attn.o_proj", H, NH * DV, act, seed=seed))
+    lay["is_moe"] = i >= cfg["first_dense"] and cfg["n_experts"] > 0
+    if not lay["is_moe"]:
+        lay.update(_dsv2_mlp(p + "mlp.", H, cfg["inter"], act, seed))
+    else:
+        lay["router"] = dense_linear(p + "mlp.gate", cfg["n_experts"], H, act, std=0.05, seed=seed)
+        lay["experts"] = [_dsv2_mlp(p + "mlp.experts.%d." % e, H, cfg["moe_inter"], act, seed) for e in range(cfg["n_experts"])]
+        if cfg["n_shared"] > 0:
+            lay["shared"] = _dsv2_mlp(p + "mlp.shared_experts.", H, cfg["n_shared"] * cfg["moe_inter"], act, seed)
+    return lay
+
+
+def dsv2_head(cfg, seed=BASE_SEED):
+    H, V, act = cfg["hidden"], cfg["vocab"], cfg["act_dtype"]
+    embed = _store(_normal(_rng("model.embed_tokens.weight", seed), (V, H), 0.02), act)
+    final_norm = _repr(1.0 + _normal(_rng("model.norm.weight", seed), (H,), 0.02), act)
+    lm = dict(kind="dense", N=V, K=H, weight=embed) if cfg.get("tie_embeddings") else dense_linear("lm_head", V, H, act, seed=seed)
+    return embed, final_norm, lm
+
+
+def make_dsv2(preset, seed=BASE_SEED, **over):
+    cfg = make_dsv2_config(preset, **over)
+    embed, final_norm, lm = dsv2_head(cfg, seed)
+    return dict(config=cfg, embed=embed, final_norm=final_norm, lm_head=lm, layers=[dsv2_layer(cfg, i, seed) for i in range(cfg["n_layers"])])
+
+
+def dsv2_bytes_per_token(cfg):
+    """active weight bytes one decoded token streams (SURVEY.md 8d cfg 5: 4.90 GB for DeepSeek-V2-Lite); latent cache excluded"""
+    H, NH, R, DN, DR, DV, V, L = (cfg[k] for k in ("hidden", "n_heads", "kv_lora_rank", "nope_dim", "rope_dim", "v_dim", "vocab", "n_layers"))
+    b = {"f16": 2, "bf16": 2, "f32": 4}[cfg["act_dtype"]]
+    attn = NH * (DN + DR) * H + (R + DR) * H + NH * (DN + DV) * R + H * NH * DV
+    dense = 3 * H * cfg["inter"]
+    moe = cfg["n_experts"] * H + (cfg["top_k"] + cfg["n_shared"]) * 3 * H * cfg["moe_inter"]
+    n_moe = sum(1 for i in range(L) if i >= cfg["first_dense"] and cfg["n_experts"] > 0)
+    params = L * attn + (L - n_moe) * dense + n_moe * moe + V * H
+    norms = L * (2 * H + R) + H
+    return (params + norms + H) * b

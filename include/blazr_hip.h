@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define BZ_ABI_VERSION 1
+#define BZ_ABI_VERSION 2
 
 enum {
   BZ_OK = 0,
@@ -73,7 +73,13 @@ typedef struct {
   int32_t rope_original_max_pos;
   /* boostr::model::SsmConfig (loader/gguf.rs:219-262) -- BZ_ARCH_MAMBA2 only */
   int32_t ssm_d_inner, ssm_n_heads, ssm_head_dim, ssm_d_state, ssm_n_groups, ssm_conv_kernel;
-  int32_t reserved[10];
+  /* BZ_ARCH_DEEPSEEK2 only: AttentionConfig kv_latent_dim / q_latent_dim / d_rope (loader/gguf.rs:188-196) plus the HF head split,
+   * MoeConfig expert_count / expert_used_count / shared experts (loader/gguf.rs:271-283).  For this arch `inter` is the dense MLP width of
+   * layers < moe_first_dense, `n_kv_heads` / `head_dim` are ignored (the latent cache is created with n_kv = 1, head_dim = rank + rope). */
+  int32_t mla_kv_lora_rank, mla_q_lora_rank, mla_nope_dim, mla_rope_dim, mla_v_dim;
+  int32_t moe_n_experts, moe_top_k, moe_n_shared, moe_inter, moe_first_dense, moe_norm_topk;
+  float   moe_routed_scale;
+  int32_t reserved[8];
 } bz_model_config;
 
 /* ---- errors / device ------------------------------------------------------------------------------- */

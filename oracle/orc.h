@@ -201,6 +201,45 @@ int orc_mamba2_forward(const orc_mamba2* m, const int64_t* tokens, int S, orc_ss
 int orc_mamba2_generate(const orc_mamba2* m, const int64_t* prompt, int n_prompt, int max_tokens, int64_t eos_id, int64_t* out_tokens,
                         float* logits_trace);
 
+/* ---- DeepSeek-V2 family (MLA + MoE), see orc_dsv2.c -------------------- */
+typedef struct {
+  int hidden, n_layers, n_heads, vocab, max_seq_len;
+  int kv_lora_rank, q_lora_rank, nope_dim, rope_dim, v_dim;   /* AttentionConfig kv_latent_dim / q_latent_dim / d_rope (gguf.rs:188-196) */
+  int inter;                                                  /* dense MLP of layers < first_dense */
+  int n_experts, top_k, n_shared, moe_inter, first_dense;     /* MoeConfig (gguf.rs:271-283) */
+  float routed_scale; int norm_topk;
+  float rms_eps; int act_dtype;
+  orc_rope_cfg rope;                                          /* head_dim / max_pos filled by orc_dsv2_new */
+} orc_dsv2_cfg;
+typedef struct {
+  const float* attn_norm; const float* ffn_norm; const float* kv_norm; const float* q_norm;
+  orc_linear q_proj;   /* [n_heads (nope+rope), hidden]; with q_lora_rank > 0 this is q_a [q_lora, hidden] and q_b expands */
+  orc_linear q_b, kv_a, kv_b, o;
+  int is_moe;
+  orc_linear gate, up, down;                    /* dense layers */
+  orc_linear router;                            /* [E, hidden] */
+  orc_linear *e_gate, *e_up, *e_down;           /* [E] each */
+  orc_linear s_gate, s_up, s_down;              /* shared experts as one MLP of n_shared * moe_inter */
+  float* kv_b_f32;                              /* owned (orc_dsv2_prepare) */
+} orc_dsv2_layer;
+typedef struct {
+  orc_dsv2_cfg cfg;
+  const void* embed; int embed_dtype;
+  const float* final_norm;
+  orc_linear lm_head;
+  orc_dsv2_layer* layers;
+  float *cos_t, *sin_t;
+} orc_dsv2;
+typedef struct { int n_layers, width, capacity, seq_len; float* lat; } orc_mla_cache;   /* [L][capacity][rank + rope] */
+orc_dsv2* orc_dsv2_new(const orc_dsv2_cfg* cfg);
+void orc_dsv2_prepare(orc_dsv2* m);
+void orc_dsv2_free(orc_dsv2* m);
+orc_mla_cache* orc_mla_cache_new(const orc_dsv2_cfg* cfg, int capacity);
+void orc_mla_cache_free(orc_mla_cache* k);
+void orc_moe_route(const float* logits, int E, int top_k, float routed_scale, int norm_topk, int* sel, float* w);
+int orc_dsv2_forward(const orc_dsv2* m, const int64_t* tokens, int S, orc_mla_cache* kc, int position, float* logits, int all_logits);
+int orc_dsv2_generate(const orc_dsv2* m, const int64_t* prompt, int n_prompt, int max_tokens, int64_t eos_id, int64_t* out_tokens, float* logits_trace);
+
 int orc_num_threads(void);
 void orc_set_num_threads(int n);
 

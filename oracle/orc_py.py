@@ -66,6 +66,31 @@ class Mamba2(C.Structure):
                 ("layers", C.POINTER(Mamba2Layer))]
 
 
+class Dsv2Cfg(C.Structure):
+    _fields_ = [("hidden", C.c_int), ("n_layers", C.c_int), ("n_heads", C.c_int), ("vocab", C.c_int), ("max_seq_len", C.c_int),
+                ("kv_lora_rank", C.c_int), ("q_lora_rank", C.c_int), ("nope_dim", C.c_int), ("rope_dim", C.c_int), ("v_dim", C.c_int),
+                ("inter", C.c_int), ("n_experts", C.c_int), ("top_k", C.c_int), ("n_shared", C.c_int), ("moe_inter", C.c_int),
+                ("first_dense", C.c_int), ("routed_scale", C.c_float), ("norm_topk", C.c_int), ("rms_eps", C.c_float),
+                ("act_dtype", C.c_int), ("rope", RopeCfg)]
+
+
+class Dsv2Layer(C.Structure):
+    _fields_ = [("attn_norm", C.c_void_p), ("ffn_norm", C.c_void_p), ("kv_norm", C.c_void_p), ("q_norm", C.c_void_p),
+                ("q_proj", Linear), ("q_b", Linear), ("kv_a", Linear), ("kv_b", Linear), ("o", Linear), ("is_moe", C.c_int),
+                ("gate", Linear), ("up", Linear), ("down", Linear), ("router", Linear),
+                ("e_gate", C.POINTER(Linear)), ("e_up", C.POINTER(Linear)), ("e_down", C.POINTER(Linear)),
+                ("s_gate", Linear), ("s_up", Linear), ("s_down", Linear), ("kv_b_f32", C.c_void_p)]
+
+
+class Dsv2(C.Structure):
+    _fields_ = [("cfg", Dsv2Cfg), ("embed", C.c_void_p), ("embed_dtype", C.c_int), ("final_norm", C.c_void_p), ("lm_head", Linear),
+                ("layers", C.POINTER(Dsv2Layer)), ("cos_t", C.c_void_p), ("sin_t", C.c_void_p)]
+
+
+class MlaCache(C.Structure):
+    _fields_ = [("n_layers", C.c_int), ("width", C.c_int), ("capacity", C.c_int), ("seq_len", C.c_int), ("lat", C.c_void_p)]
+
+
 class SsmState(C.Structure):
     _fields_ = [("ssm", C.c_void_p), ("conv", C.c_void_p)]
 
@@ -154,6 +179,18 @@ def lib():
         L.orc_mamba2_forward.argtypes = [C.POINTER(Mamba2), C.c_void_p, C.c_int, C.POINTER(SsmState), C.c_void_p, C.c_int]
         L.orc_mamba2_generate.restype = C.c_int
         L.orc_mamba2_generate.argtypes = [C.POINTER(Mamba2), C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]
+        L.orc_dsv2_new.restype = C.POINTER(Dsv2)
+        L.orc_dsv2_new.argtypes = [C.POINTER(Dsv2Cfg)]
+        L.orc_dsv2_prepare.argtypes = [C.POINTER(Dsv2)]
+        L.orc_dsv2_free.argtypes = [C.POINTER(Dsv2)]
+        L.orc_mla_cache_new.restype = C.POINTER(MlaCache)
+        L.orc_mla_cache_new.argtypes = [C.POINTER(Dsv2Cfg), C.c_int]
+        L.orc_mla_cache_free.argtypes = [C.POINTER(MlaCache)]
+        L.orc_moe_route.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_dsv2_forward.restype = C.c_int
+        L.orc_dsv2_forward.argtypes = [C.POINTER(Dsv2), C.c_void_p, C.c_int, C.POINTER(MlaCache), C.c_int, C.c_void_p, C.c_int]
+        L.orc_dsv2_generate.restype = C.c_int
+        L.orc_dsv2_generate.argtypes = [C.POINTER(Dsv2), C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]
         L.orc_num_threads.restype = C.c_int
         _LIB = L
     return _LIB
@@ -412,4 +449,82 @@ class OrcMamba2:
         out = np.zeros(max_tokens, dtype=np.int64)
         tr = np.zeros((max_tokens, self.cfg.vocab), dtype=np.float32) if trace else None
         n = lib().orc_mamba2_generate(self.h, _p(p), len(p), max_tokens, eos_id, _p(out), _p(tr))
+        return (out[:n], tr[:n]) if trace else out[:n]
+
+
+class OrcDsv2:
+    """Oracle DeepSeek-V2 (MLA + MoE) model built from a blazr_amd.synth.make_dsv2 dict."""
+
+    def __init__(self, model):
+        cfg = model["config"]
+        c = Dsv2Cfg()
+        for k in ("hidden", "n_layers", "n_heads", "vocab", "max_seq_len", "kv_lora_rank", "q_lora_rank", "nope_dim", "rope_dim", "v_dim",
+                  "inter", "n_experts", "top_k", "n_shared", "moe_inter", "first_dense"):
+            setattr(c, k, int(cfg[k]))
+        c.routed_scale, c.norm_topk = float(cfg["routed_scale"]), int(bool(cfg["norm_topk"]))
+        c.rms_eps, c.act_dtype = cfg["rms_eps"], _DT[cfg["act_dtype"]]
+        c.rope.theta, c.rope.scaling_type, c.rope.factor = cfg["rope_theta"], 0, 1.0
+        self.cfg = c
+        self.h = lib().orc_dsv2_new(C.byref(c))
+        self.keep = []
+        m = self.h.contents
+        emb = np.ascontiguousarray(model["embed"])
+        m.embed = _p(emb)
+        m.embed_dtype = {np.dtype(np.float32): F32, np.dtype(np.float16): F16, np.dtype(np.uint16): BF16}[emb.dtype]
+        fn = np.ascontiguousarray(model["final_norm"], dtype=np.float32)
+        m.final_norm = _p(fn)
+        lm = OrcLinear(model["lm_head"])
+        m.lm_head = lm.c
+        self.keep += [emb, fn, lm]
+
+        def lin(spec):
+            ol = OrcLinear(spec)
+            self.keep.append(ol)
+            return ol.c
+
+        for i, lay in enumerate(model["layers"]):
+            Lr = m.layers[i]
+            for name in ("attn_norm", "ffn_norm", "kv_norm"):
+                a = np.ascontiguousarray(lay[name], dtype=np.float32)
+                self.keep.append(a)
+                setattr(Lr, name, _p(a))
+            for name in ("q_proj", "kv_a", "kv_b", "o"):
+                setattr(Lr, name, lin(lay[name]))
+            Lr.is_moe = int(lay["is_moe"])
+            if not lay["is_moe"]:
+                for name in ("gate", "up", "down"):
+                    setattr(Lr, name, lin(lay[name]))
+            else:
+                Lr.router = lin(lay["router"])
+                E = len(lay["experts"])
+                for name in ("gate", "up", "down"):
+                    arr = (Linear * E)(*[lin(ex[name]) for ex in lay["experts"]])
+                    self.keep.append(arr)
+                    setattr(Lr, "e_" + name, C.cast(arr, C.POINTER(Linear)))
+                if "shared" in lay:
+                    for name in ("gate", "up", "down"):
+                        setattr(Lr, "s_" + name, lin(lay["shared"][name]))
+        lib().orc_dsv2_prepare(self.h)
+
+    def __del__(self):
+        try:
+            lib().orc_dsv2_free(self.h)
+        except Exception:
+            pass
+
+    def new_cache(self, capacity):
+        return lib().orc_mla_cache_new(C.byref(self.cfg), capacity)
+
+    def forward(self, tokens, cache, position, all_logits=False):
+        t = np.ascontiguousarray(tokens, dtype=np.int64)
+        out = np.empty((len(t) if all_logits else 1, self.cfg.vocab), dtype=np.float32)
+        rc = lib().orc_dsv2_forward(self.h, _p(t), len(t), cache, position, _p(out), int(all_logits))
+        assert rc == 0, "orc_dsv2_forward failed (cache capacity / max_seq_len)"
+        return out
+
+    def generate(self, prompt, max_tokens, eos_id=-1, trace=False):
+        p = np.ascontiguousarray(prompt, dtype=np.int64)
+        out = np.zeros(max(max_tokens, 1), dtype=np.int64)
+        tr = np.zeros((max(max_tokens, 1), self.cfg.vocab), dtype=np.float32) if trace else None
+        n = lib().orc_dsv2_generate(self.h, _p(p), len(p), max_tokens, eos_id, _p(out), _p(tr))
         return (out[:n], tr[:n]) if trace else out[:n]

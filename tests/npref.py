@@ -258,3 +258,82 @@ class NpMamba2:
             h = R(h + R(y @ self.Wout[l].T))
         xn = rms_norm(h, self.m["final_norm"], c["rms_eps"], act)
         return R(xn @ self.lm.T)
+
+
+class NpDsv2:
+    """Independent numpy DeepSeek-V2 step in the NAIVE (HF modeling_deepseek.py) form: the cached latents are expanded to per-head
+    k_nope / v through kv_b_proj for every cached token and ordinary attention is run -- no weight absorption.  In f32 this must
+    agree with the oracle's absorbed form to float precision (it validates the algebra, the RoPE convention, the router and the
+    MoE combine); in bf16 the two forms round at different places and agree only to a few bf16 ulps."""
+
+    def __init__(self, model):
+        self.m, self.cfg = model, model["config"]
+        self.emb = dequant(dict(kind="dense", weight=model["embed"]))
+        self.lm = dequant(model["lm_head"])
+        self.W = []
+        for lay in model["layers"]:
+            w = {k: dequant(lay[k]) for k in ("q_proj", "kv_a", "kv_b", "o")}
+            if lay["is_moe"]:
+                w["router"] = dequant(lay["router"])
+                w["experts"] = [{k: dequant(e[k]) for k in ("gate", "up", "down")} for e in lay["experts"]]
+                if "shared" in lay:
+                    w["shared"] = {k: dequant(lay["shared"][k]) for k in ("gate", "up", "down")}
+            else:
+                w.update({k: dequant(lay[k]) for k in ("gate", "up", "down")})
+            self.W.append(w)
+        self.lat = [[] for _ in model["layers"]]
+
+    def _rope(self, v, pos):
+        c = self.cfg
+        half = c["rope_dim"] // 2
+        inv = 1.0 / (np.float64(c["rope_theta"]) ** (np.arange(half, dtype=np.float64) * 2 / c["rope_dim"]))
+        ang = pos * inv
+        cs, sn = np.cos(ang).astype(np.float32), np.sin(ang).astype(np.float32)
+        x = v.reshape(-1, half, 2)
+        out = np.empty_like(x)
+        out[..., 0] = x[..., 0] * cs - x[..., 1] * sn
+        out[..., 1] = x[..., 1] * cs + x[..., 0] * sn
+        return out.reshape(v.shape)
+
+    def step(self, token, pos):
+        c = self.cfg
+        act = c["act_dtype"]
+        R = lambda a: round_act(a, act)
+        NH, RK, DN, DR, DV = c["n_heads"], c["kv_lora_rank"], c["nope_dim"], c["rope_dim"], c["v_dim"]
+        silu = lambda a: a / (1.0 + np.exp(-a))
+        mlp = lambda w, x: R(R(R(silu(R(x @ w["gate"].T))) * R(x @ w["up"].T)) @ w["down"].T)
+        h = R(self.emb[token])
+        for l, lay in enumerate(self.m["layers"]):
+            w = self.W[l]
+            xn = rms_norm(h, lay["attn_norm"], c["rms_eps"], act)
+            q = R(xn @ w["q_proj"].T).reshape(NH, DN + DR)
+            kva = R(xn @ w["kv_a"].T)
+            lat = rms_norm(kva[:RK], lay["kv_norm"], c["rms_eps"], act)
+            kpe = R(self._rope(kva[RK:], pos))
+            self.lat[l].append(np.concatenate([lat, kpe]))
+            Cm = np.stack(self.lat[l])                                   # [T, RK + DR]
+            kv = R(Cm[:, :RK] @ w["kv_b"].T).reshape(-1, NH, DN + DV)      # naive expansion
+            qpe = R(self._rope(q[:, DN:], pos))
+            sc = (np.einsum("hd,thd->ht", q[:, :DN], kv[:, :, :DN]) + qpe @ Cm[:, RK:].T) / np.sqrt(np.float32(DN + DR))
+            p = np.exp(sc - sc.max(axis=1, keepdims=True))
+            p = p / p.sum(axis=1, keepdims=True)
+            att = R(np.einsum("ht,thd->hd", p, kv[:, :, DN:])).reshape(-1)
+            h = R(h + R(att @ w["o"].T))
+            xn = rms_norm(h, lay["ffn_norm"], c["rms_eps"], act)
+            if not lay["is_moe"]:
+                out = mlp(w, xn)
+            else:
+                lg = (xn @ w["router"].T).astype(np.float32)
+                s = np.exp(lg - lg.max())
+                s = s / s.sum()
+                sel = np.argsort(-s, kind="stable")[:c["top_k"]]
+                wt = s[sel] / (s[sel].sum() + 1e-20) * c["routed_scale"] if c["norm_topk"] else s[sel] * c["routed_scale"]
+                routed = np.zeros_like(h)
+                for e, we in zip(sel, wt):
+                    routed = routed + np.float32(we) * mlp(w["experts"][int(e)], xn)
+                out = R(routed)
+                if "shared" in w:
+                    out = R(out + mlp(w["shared"], xn))
+            h = R(h + out)
+        xn = rms_norm(h, self.m["final_norm"], c["rms_eps"], act)
+        return R(xn @ self.lm.T)

@@ -1,0 +1,87 @@
+"""GPU parity for the DeepSeek-V2 path: MLA attention over the compressed-latent cache + MoE, against
+oracle/orc_dsv2.c (weight-absorbed form; itself checked against a naive HF-form numpy model in tests/test_oracle.py).
+
+The arithmetic lives in the absent boostr crate (parity unpinned, see oracle/orc_dsv2.c).  Bars as in test_gpu_llama.py.
+"""
+import numpy as np
+import pytest
+
+from blazr_amd import _lib as L
+from blazr_amd import runtime, synth
+from oracle import orc_py
+from test_gpu_llama import _check_logits, _fair_prefix
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", params=["tiny-dsv2", "tiny-dsv2-f32"])
+def pair(request, device):
+    model = synth.make_dsv2(request.param)
+    return model, runtime.LoadedModel.from_synth(device, model), orc_py.OrcDsv2(model)
+
+
+def test_accessors(pair):
+    model, lm, _ = pair
+    cfg = model["config"]
+    assert lm.needs_kv_cache() and not lm.needs_ssm_state()
+    assert lm.num_kv_heads() == 1 and lm.head_dim() == cfg["kv_lora_rank"] + cfg["rope_dim"]     # latent cache row
+    assert lm.moe_config()["experts_per_tok"] == cfg["top_k"]
+    assert lm.weight_bytes()[1] == synth.dsv2_bytes_per_token(cfg)
+
+
+def test_prefill_and_decode_logits(pair, device):
+    model, lm, om = pair
+    cfg = model["config"]
+    p = synth.prompt_tokens(9, cfg["vocab"])
+    kv, okc = lm.new_kv_cache(12), om.new_cache(64)
+    got = lm.forward_with_kv_cache(p, kv, 0, all_logits=True).to_numpy()
+    want = om.forward(p, okc, 0, all_logits=True)
+    _check_logits(got, want, cfg["act_dtype"])
+    assert kv.seq_len() == 9
+    # the latent cache itself (normalised latents | roped k_pe, rounded to the cache dtype)
+    W = cfg["kv_lora_rank"] + cfg["rope_dim"]
+    olat = np.ctypeslib.as_array((orc_py.C.c_float * (cfg["n_layers"] * 64 * W)).from_address(okc.contents.lat)).reshape(cfg["n_layers"], 64, W)
+    glat = kv.read(1, 0, 0, 9)
+    assert np.abs(glat - olat[1, :9]).max() <= 2 * {"bf16": 2 ** -7, "f32": 1e-5}[cfg["act_dtype"]] * np.abs(olat[1, :9]).max()
+    tok = int(want[-1].argmax())
+    for i in range(20):      # cache grows 12 -> 24 -> 48 under the decode
+        lg = lm.forward_with_kv_cache([tok], kv, kv.seq_len()).to_numpy()
+        lo = om.forward([tok], okc, 9 + i)
+        _check_logits(lg, lo, cfg["act_dtype"])
+        tok = int(lo[0].argmax())
+    orc_py.lib().orc_mla_cache_free(okc)
+
+
+@pytest.mark.parametrize("mode", ["eager", "graph"])
+def test_generate_greedy_token_parity(pair, mode):
+    model, lm, om = pair
+    cfg = model["config"]
+    for seed in range(3, 60):
+        p = synth.prompt_tokens(12, cfg["vocab"], seed=seed)
+        want, trace = om.generate(p, 24, trace=True)
+        n = _fair_prefix(trace)
+        if n >= 8:
+            break
+    assert n >= 8, "no prompt seed gives a fair fixture"
+    got = runtime.Executor(lm).generate(p, 24, use_graph=mode == "graph")
+    assert got[:n].tolist() == want[:n].tolist(), (mode, got.tolist(), want.tolist(), n)
+
+
+def test_graph_replay_equals_eager(pair):
+    model, lm, _ = pair
+    p = synth.prompt_tokens(6, model["config"]["vocab"], seed=5)
+    ex = runtime.Executor(lm)
+    assert ex.generate(p, 16, use_graph=True).tolist() == ex.generate(p, 16).tolist()
+
+
+def test_error_behaviour(pair, device):
+    model, lm, _ = pair
+    cfg = model["config"]
+    wrong = runtime.LayeredKvCache(device, cfg["n_layers"], 1, 2, 8, 64, 64, lm.c.act_dtype)
+    with pytest.raises(L.BlazrHipError):
+        lm.forward_with_kv_cache([1, 2], wrong, 0)                     # not the latent-cache shape
+    with pytest.raises(L.BlazrHipError):
+        runtime.Executor(lm).generate([1, 2, 3], 4, paged=True)        # paged MLA cache: not in this build
+    bad = dict(cfg, q_lora_rank=64)
+    with pytest.raises(L.BlazrHipError):
+        runtime.LoadedModel(device, bad)
