@@ -242,7 +242,7 @@ struct DsLayerDev {
 
 struct bz_model {
   std::vector<DsLayerDev> dlayers;
-  float* moe_xn = nullptr; float* moe_gu = nullptr; float* moe_out = nullptr; long long* moe_acc = nullptr; int* moe_sel = nullptr; float* moe_w = nullptr;
+  float* moe_xn = nullptr; float* moe_gu = nullptr; float* moe_out = nullptr; long long* moe_acc = nullptr; int* moe_sel = nullptr; float* moe_w = nullptr; float* moe_lg = nullptr; unsigned* moe_cnt = nullptr;
   std::vector<MambaLayerDev> mlayers;
   float* xbc = nullptr; float* ybuf = nullptr; float* vss = nullptr;   // Mamba2 workspace
   bz_device* dev = nullptr;
@@ -955,6 +955,8 @@ static int finalize_dsv2(bz_model* m) {
     BZ_TRY(dev_alloc(m, &p, (size_t)(TK + 1) * H * 8)); m->moe_acc = (long long*)p; BZ_HIP(hipMemset(p, 0, (size_t)(TK + 1) * H * 8));
     BZ_TRY(dev_alloc(m, &p, (size_t)(TK + NS + 4) * 4)); m->moe_sel = (int*)p; BZ_HIP(hipMemset(p, 0, (size_t)(TK + NS + 4) * 4));
     BZ_TRY(dev_alloc(m, &p, (size_t)(TK + NS + 4) * 4)); m->moe_w = (float*)p; BZ_HIP(hipMemset(p, 0, (size_t)(TK + NS + 4) * 4));
+    BZ_TRY(dev_alloc(m, &p, (size_t)(E + 4) * 4)); m->moe_lg = (float*)p;
+    BZ_TRY(dev_alloc(m, &p, 64)); m->moe_cnt = (unsigned*)p; BZ_HIP(hipMemset(p, 0, 64));
   }
   m->nparts = bzk_gemv_rows_blocks(m->lm_head.parts[0]);
   BZ_TRY(dev_alloc(m, &p, (size_t)m->nparts * 4)); m->pval = (float*)p;
@@ -1439,7 +1441,7 @@ static int dsv2_step(bz_model* m, const StepIO& io) {
       BZ_TRY(run_fused(m, L.down, ps, rs, &dn));
       prev = dn;
     } else {
-      BZ_TRY(bzk_moe_router(st, pf, L.router, L.router_dt, E, TK, NS, c.moe_routed_scale, c.moe_norm_topk, m->moe_xn, m->moe_sel, m->moe_w));
+      BZ_TRY(bzk_moe_router(st, pf, L.router, L.router_dt, E, TK, NS, c.moe_routed_scale, c.moe_norm_topk, m->moe_xn, m->moe_sel, m->moe_w, m->moe_lg, m->moe_cnt));
       cur ^= 1;
       const int slots = TK + NS;
       const size_t es = bz_dtype_size(L.e_dt);

@@ -218,7 +218,7 @@ struct MoeGemvArgs {
 int bzk_moe_gemv(hipStream_t s, const MoeGemvArgs& g, int wdt, int n_slots, const Pro& pro, int act, bool split, double bytes);
 int bzk_mla_attn(hipStream_t s, const MlaArgs& a, int max_len);
 int bzk_moe_router(hipStream_t s, const Pro& pro, const void* wr, int wdt, int E, int top_k, int n_shared, float routed_scale, int norm_topk,
-                   float* xn_out, int* sel, float* wsel);
+                   float* xn_out, int* sel, float* wsel, float* lg_glob, unsigned* counter);
 int bzk_moe_combine(hipStream_t s, long long* acc, const float* wsel, int top_k, int has_shared, int H, int act, float* out);
 
 // Mamba2 kernels

@@ -2575,6 +2575,17 @@ int bzk_ssm_step(hipStream_t s, const SsmArgs& a) {
 //   qabs = R(Wuk_h^T q_nope) ; s_t = (qabs . c_t + qpe . kpe_t) * scale ; p = softmax(s)
 //   olat = R(sum_t p_t c_t) ; out_h = R(Wuv_h olat)
 // LDS: ccur[rank] kcur[rope] qn[nope] qp[rope] qabs[rank] part[4][rank] red[8] sc[len]
+// compile-time dtype loaders: a run-time dtype switch puts every load behind a branch, and hipcc then drains vmcnt after each one
+template <int DT>
+__device__ __forceinline__ void ld8t(const void* base, size_t off, float (&o)[8]) { load8<DT>(base, off, true, o); }
+template <int DT>
+__device__ __forceinline__ float ld1t(const void* base, size_t off) {
+  if constexpr (DT == BZ_F16) return __half2float(((const __half*)base)[off]);
+  else if constexpr (DT == BZ_BF16) return __uint_as_float((unsigned)((const unsigned short*)base)[off] << 16);
+  else return ((const float*)base)[off];
+}
+
+template <int NCH, int DT>   // NCH: 512-column chunks of the latent, 1 (rank <= 512) or 2 (rank <= 1024); DT: dtype of kv_b and of the cache
 __global__ __launch_bounds__(256) void k_mla_attn(MlaArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int R = a.rank, DN = a.nope, DR = a.rope, DV = a.vdim;
@@ -2583,6 +2594,21 @@ __global__ __launch_bounds__(256) void k_mla_attn(MlaArgs a) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hd = blockIdx.x;
   const int pos = a.pos[0], len = pos + 1;
   const int QH = DN + DR, qoff = hd * QH, coff = a.n_heads * QH;
+  const size_t wrow0 = (size_t)hd * (DN + DV);
+  constexpr int RIF = 16 / NCH, TIF = 8 / NCH;   // weight rows / cache rows a wave keeps in flight
+  bool con[NCH]; int colc[NCH];                      // this lane's 8 columns per chunk (clamped when beyond the rank)
+#pragma unroll
+  for (int c = 0; c < NCH; c++) { const int col = c * 512 + lane * 8; con[c] = col < R; colc[c] = con[c] ? col : 0; }
+
+  // ---- qabs partials first (weights only depend on the head): wave w takes nope rows [w DN/4, (w+1) DN/4), 8 rows in flight ----
+  const int d0 = wave * (DN / 4), d1 = d0 + DN / 4;
+  float w0[RIF][NCH][8];
+#pragma unroll
+  for (int u = 0; u < RIF; u++)
+#pragma unroll
+    for (int c = 0; c < NCH; c++) ld8t<DT>(a.wkvb, (wrow0 + (size_t)min(d0 + u, d1 - 1)) * R + colc[c], w0[u][c]);
+  __builtin_amdgcn_sched_barrier(0);
+
   // ---- current token: latent norm, k_pe / q_pe rope, q_nope ----
   float ss = 0.f;
   for (int r = tid; r < R; r += 256) { const float v = vsrc_get(a.qkv, coff + r, a.act); ccur[r] = v; ss += v * v; }
@@ -2604,82 +2630,81 @@ __global__ __launch_bounds__(256) void k_mla_attn(MlaArgs a) {
   if (hd == 0) {
     for (int i = tid; i < Wd; i += 256) kv_st(a.kv.k, rowbase + (size_t)pos * Wd + i, a.kv.dtype, i < R ? ccur[i] : kcur[i - R]);
   }
-  // ---- qabs = R(Wuk^T q_nope): wave w takes nope rows [w DN/4, (w+1) DN/4); a lane owns 8 columns per 512-column chunk ----
-  const int NCH = (R + 511) >> 9;        // <= 2 (rank <= 1024)
-  const size_t wrow0 = (size_t)hd * (DN + DV);
   {
-    float acc[2][8];
+    float acc[NCH][8];
 #pragma unroll
-    for (int c = 0; c < 2; c++)
+    for (int c = 0; c < NCH; c++)
 #pragma unroll
       for (int e = 0; e < 8; e++) acc[c][e] = 0.f;
-    const int d0 = wave * (DN / 4), d1 = d0 + DN / 4;
-    for (int d = d0; d < d1; d += 4) {
-      float w[4][2][8];
+    for (int d = d0; d < d1; d += RIF) {
+      if (d > d0) {
 #pragma unroll
-      for (int u = 0; u < 4; u++)
+        for (int u = 0; u < RIF; u++)
 #pragma unroll
-        for (int c = 0; c < 2; c++) {
-          const int col = c * 512 + lane * 8;
-          if (c < NCH) kv_ld8(a.wkvb, (wrow0 + (size_t)min(d + u, d1 - 1)) * R + (col < R ? col : 0), a.wdt, w[u][c]);
-        }
+          for (int c = 0; c < NCH; c++) ld8t<DT>(a.wkvb, (wrow0 + (size_t)min(d + u, d1 - 1)) * R + colc[c], w0[u][c]);
+      }
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
+      for (int u = 0; u < RIF; u++) {
         const float qd = (d + u < d1) ? qn[d + u] : 0.f;
 #pragma unroll
-        for (int c = 0; c < 2; c++)
-          if (c < NCH)
+        for (int c = 0; c < NCH; c++)
 #pragma unroll
-            for (int e = 0; e < 8; e++) acc[c][e] += qd * w[u][c][e];
+          for (int e = 0; e < 8; e++) acc[c][e] += qd * w0[u][c][e];
       }
     }
 #pragma unroll
-    for (int c = 0; c < 2; c++) {
-      const int col = c * 512 + lane * 8;
-      if (c < NCH && col < R)
+    for (int c = 0; c < NCH; c++)
+      if (con[c])
 #pragma unroll
-        for (int e = 0; e < 8; e++) part[wave * R + col + e] = acc[c][e];
-    }
+        for (int e = 0; e < 8; e++) part[wave * R + colc[c] + e] = acc[c][e];
   }
   __syncthreads();
   for (int r = tid; r < R; r += 256) qabs[r] = round_act((part[r] + part[R + r]) + (part[2 * R + r] + part[3 * R + r]), a.act);
   __syncthreads();
-  // ---- scores ----
-  float qa[2][8], qpl = (lane < DR) ? qp[lane] : 0.f;
+  // ---- scores: wave w takes cached tokens w, w+4, ... four at a time; the current token comes from LDS ----
+  float qa[NCH][8];
+  const float qpl = (lane < DR) ? qp[lane] : 0.f;
 #pragma unroll
-  for (int c = 0; c < 2; c++) {
-    const int col = c * 512 + lane * 8;
+  for (int c = 0; c < NCH; c++)
 #pragma unroll
-    for (int e = 0; e < 8; e++) qa[c][e] = (c < NCH && col < R) ? qabs[col + e] : 0.f;
-  }
-  for (int t = wave; t < len; t += 4) {
-    float dsum = 0.f;
-    if (t == pos) {
+    for (int e = 0; e < 8; e++) qa[c][e] = con[c] ? qabs[colc[c] + e] : 0.f;
+  for (int t0 = wave; t0 < pos; t0 += 4 * TIF) {
+    float cv[TIF][NCH][8], kp[TIF];
 #pragma unroll
-      for (int c = 0; c < 2; c++) {
-        const int col = c * 512 + lane * 8;
-        if (c < NCH && col < R)
+    for (int u = 0; u < TIF; u++) {
+      const size_t ro = rowbase + (size_t)min(t0 + 4 * u, pos - 1) * Wd;
 #pragma unroll
-          for (int e = 0; e < 8; e++) dsum += qa[c][e] * ccur[col + e];
-      }
-      if (lane < DR) dsum += qpl * kcur[lane];
-    } else {
-      const size_t ro = rowbase + (size_t)t * Wd;
-#pragma unroll
-      for (int c = 0; c < 2; c++) {
-        const int col = c * 512 + lane * 8;
-        if (c < NCH && col < R) {
-          float cv[8];
-          kv_ld8(a.kv.k, ro + col, a.kv.dtype, cv);
-#pragma unroll
-          for (int e = 0; e < 8; e++) dsum += qa[c][e] * cv[e];
-        }
-      }
-      if (lane < DR) dsum += qpl * kv_ld(a.kv.k, ro + R + lane, a.kv.dtype);
+      for (int c = 0; c < NCH; c++) ld8t<DT>(a.kv.k, ro + colc[c], cv[u][c]);
+      kp[u] = ld1t<DT>(a.kv.k, ro + R + min(lane, DR - 1));
     }
-    dsum = wave_sum(dsum);
-    if (lane == 0) sc[t] = dsum * a.scale;
+#pragma unroll
+    for (int u = 0; u < TIF; u++) {
+      float dsum = (lane < DR) ? qpl * kp[u] : 0.f;
+#pragma unroll
+      for (int c = 0; c < NCH; c++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) dsum += qa[c][e] * cv[u][c][e];
+      dsum = wave_sum(dsum);
+      if (lane == 0 && t0 + 4 * u < pos) sc[t0 + 4 * u] = dsum * a.scale;
+    }
   }
+  if (wave == 0) {
+    float dsum = (lane < DR) ? qpl * kcur[lane] : 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; c++)
+      if (con[c])
+#pragma unroll
+        for (int e = 0; e < 8; e++) dsum += qa[c][e] * ccur[colc[c] + e];
+    dsum = wave_sum(dsum);
+    if (lane == 0) sc[pos] = dsum * a.scale;
+  }
+  // first rows of Wuv for the output phase: in flight during the softmax and the latent sum
+  const int v0 = wave * (DV / 4), v1 = v0 + DV / 4;
+#pragma unroll
+  for (int u = 0; u < RIF; u++)
+#pragma unroll
+    for (int c = 0; c < NCH; c++) ld8t<DT>(a.wkvb, (wrow0 + DN + (size_t)min(v0 + u, v1 - 1)) * R + colc[c], w0[u][c]);
+  __builtin_amdgcn_sched_barrier(0);
   __syncthreads();
   float mx = -INFINITY;
   for (int t = tid; t < len; t += 256) mx = fmaxf(mx, sc[t]);
@@ -2694,66 +2719,62 @@ __global__ __launch_bounds__(256) void k_mla_attn(MlaArgs a) {
   const float inv = 1.0f / psum;
   // ---- olat = R(sum_t p_t c_t * inv) ----
   {
-    float acc[2][8];
+    float acc[NCH][8];
 #pragma unroll
-    for (int c = 0; c < 2; c++)
+    for (int c = 0; c < NCH; c++)
 #pragma unroll
       for (int e = 0; e < 8; e++) acc[c][e] = 0.f;
-    for (int t = wave; t < len; t += 4) {
-      const float p = sc[t];
-      const size_t ro = rowbase + (size_t)t * Wd;
+    for (int t0 = wave; t0 < pos; t0 += 4 * TIF) {
+      float cv[TIF][NCH][8];
 #pragma unroll
-      for (int c = 0; c < 2; c++) {
-        const int col = c * 512 + lane * 8;
-        if (c < NCH && col < R) {
-          float cv[8];
-          if (t == pos) {
+      for (int u = 0; u < TIF; u++)
 #pragma unroll
-            for (int e = 0; e < 8; e++) cv[e] = ccur[col + e];
-          } else {
-            kv_ld8(a.kv.k, ro + col, a.kv.dtype, cv);
-          }
+        for (int c = 0; c < NCH; c++) ld8t<DT>(a.kv.k, rowbase + (size_t)min(t0 + 4 * u, pos - 1) * Wd + colc[c], cv[u][c]);
 #pragma unroll
-          for (int e = 0; e < 8; e++) acc[c][e] += p * cv[e];
-        }
+      for (int u = 0; u < TIF; u++) {
+        const float p = (t0 + 4 * u < pos) ? sc[t0 + 4 * u] : 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; c++)
+#pragma unroll
+          for (int e = 0; e < 8; e++) acc[c][e] += p * cv[u][c][e];
       }
     }
+    if (wave == (pos & 3)) {       // the current token, in the wave that would own it in token order
+      const float p = sc[pos];
 #pragma unroll
-    for (int c = 0; c < 2; c++) {
-      const int col = c * 512 + lane * 8;
-      if (c < NCH && col < R)
+      for (int c = 0; c < NCH; c++)
+        if (con[c])
 #pragma unroll
-        for (int e = 0; e < 8; e++) part[wave * R + col + e] = acc[c][e];
+          for (int e = 0; e < 8; e++) acc[c][e] += p * ccur[colc[c] + e];
     }
+#pragma unroll
+    for (int c = 0; c < NCH; c++)
+      if (con[c])
+#pragma unroll
+        for (int e = 0; e < 8; e++) part[wave * R + colc[c] + e] = acc[c][e];
   }
   __syncthreads();
   for (int r = tid; r < R; r += 256) qabs[r] = round_act(((part[r] + part[R + r]) + (part[2 * R + r] + part[3 * R + r])) * inv, a.act);   // qabs now holds olat
   __syncthreads();
-  // ---- out_h = R(Wuv olat): wave w takes v rows [w DV/4, (w+1) DV/4), 4 rows in flight ----
+  // ---- out_h = R(Wuv olat): wave w takes v rows [w DV/4, (w+1) DV/4), 8 rows in flight ----
 #pragma unroll
-  for (int c = 0; c < 2; c++) {
-    const int col = c * 512 + lane * 8;
+  for (int c = 0; c < NCH; c++)
 #pragma unroll
-    for (int e = 0; e < 8; e++) qa[c][e] = (c < NCH && col < R) ? qabs[col + e] : 0.f;
-  }
-  const int v0 = wave * (DV / 4), v1 = v0 + DV / 4;
-  for (int d = v0; d < v1; d += 4) {
-    float w[4][2][8];
+    for (int e = 0; e < 8; e++) qa[c][e] = con[c] ? qabs[colc[c] + e] : 0.f;
+  for (int d = v0; d < v1; d += RIF) {
+    if (d > v0) {
 #pragma unroll
-    for (int u = 0; u < 4; u++)
+      for (int u = 0; u < RIF; u++)
 #pragma unroll
-      for (int c = 0; c < 2; c++) {
-        const int col = c * 512 + lane * 8;
-        if (c < NCH) kv_ld8(a.wkvb, (wrow0 + DN + (size_t)min(d + u, v1 - 1)) * R + (col < R ? col : 0), a.wdt, w[u][c]);
-      }
+        for (int c = 0; c < NCH; c++) ld8t<DT>(a.wkvb, (wrow0 + DN + (size_t)min(d + u, v1 - 1)) * R + colc[c], w0[u][c]);
+    }
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < RIF; u++) {
       float s = 0.f;
 #pragma unroll
-      for (int c = 0; c < 2; c++)
-        if (c < NCH)
+      for (int c = 0; c < NCH; c++)
 #pragma unroll
-          for (int e = 0; e < 8; e++) s += w[u][c][e] * qa[c][e];
+        for (int e = 0; e < 8; e++) s += w0[u][c][e] * qa[c][e];
       s = wave_sum(s);
       if (lane == 0 && d + u < v1) a.out[hd * DV + d + u] = round_act(s, a.act);
     }
@@ -2767,66 +2788,107 @@ int bzk_mla_attn(hipStream_t s, const MlaArgs& a, int max_len) {
     BZ_FAIL(BZ_E_UNSUPPORTED, "mla_attn: rank %d / rope %d / nope %d / v %d unsupported", a.rank, a.rope, a.nope, a.vdim);
   const size_t smem = bzk_mla_smem(a, max_len);
   if (smem > 160 * 1024) BZ_FAIL(BZ_E_UNSUPPORTED, "mla_attn: context %d too long for the single-pass kernel", max_len);
-  static bool attr_done = false;
-  if (!attr_done) { BZ_HIP(hipFuncSetAttribute((const void*)k_mla_attn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_done = true; }
+  if (a.wdt != a.kv.dtype) BZ_FAIL(BZ_E_UNSUPPORTED, "mla_attn: kv_b_proj dtype %d must equal the cache dtype %d", a.wdt, a.kv.dtype);
   const double bytes = (double)a.n_heads * (a.nope + a.vdim) * a.rank * bz_dtype_size(a.wdt);
-  BZ_LAUNCH("mla_attn", bytes, k_mla_attn, dim3(a.n_heads), dim3(256), smem, s, a);
+#define LAUNCH_MLA(NCH, DT) do { \
+    static bool attr_done = false; \
+    if (!attr_done) { BZ_HIP(hipFuncSetAttribute((const void*)k_mla_attn<NCH, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_done = true; } \
+    BZ_LAUNCH("mla_attn", bytes, (k_mla_attn<NCH, DT>), dim3(a.n_heads), dim3(256), smem, s, a); } while (0)
+#define LAUNCH_MLA_DT(DT) do { if (a.rank <= 512) LAUNCH_MLA(1, DT); else LAUNCH_MLA(2, DT); } while (0)
+  if (a.wdt == BZ_F16) LAUNCH_MLA_DT(BZ_F16); else if (a.wdt == BZ_BF16) LAUNCH_MLA_DT(BZ_BF16); else LAUNCH_MLA_DT(BZ_F32);
+#undef LAUNCH_MLA_DT
+#undef LAUNCH_MLA
   BZ_HIP(hipGetLastError());
   return BZ_OK;
 }
 
 // Router: one workgroup.  Residual add + RMSNorm (writes h' and the normalised x for the expert GEMVs), f32 logits over E
 // experts, f32 softmax, greedy top-k (ties -> lowest index).  Slots [top_k, top_k + n_shared) are the shared-expert halves.
-__global__ __launch_bounds__(256) void k_moe_router(Pro pro, const void* wr, int wdt, int E, int top_k, int n_shared, float routed_scale, int norm_topk,
-                                                    float* xn_out, int* sel, float* wsel) {
+template <int WDT>
+__global__ __launch_bounds__(256) void k_moe_router(Pro pro, const void* wr, int E, int top_k, int n_shared, float routed_scale, int norm_topk,
+                                                    float* xn_out, int* sel, float* wsel, float* lg_glob, unsigned* counter) {
+  // grid = ceil(E / 4): workgroup b computes the logits of experts 4b .. 4b+3 (one per wave, every chunk load in flight at once);
+  // the last workgroup to finish (device-scope counter) runs the softmax / top-k.  Block 0 also writes h' and the normalised x.
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int H = pro.H;
   float* xs = lds; float* red = xs + H; float* lg = red + 16;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  build_x_simple<false>(pro, 0, H, xs, red, true);
-  for (int i = tid; i < H; i += 256) xn_out[i] = xs[i];
-  for (int e0 = wave * 4; e0 < E; e0 += 16) {
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int k = lane * 8; k < H; k += 512) {
-      float w[4][8];
+  const int e = min((int)blockIdx.x * 4 + wave, E - 1);
+  float w[8][8];                                 // hidden <= 4096 in one trip; longer rows loop
 #pragma unroll
-      for (int u = 0; u < 4; u++) kv_ld8(wr, (size_t)min(e0 + u, E - 1) * H + k, wdt, w[u]);
-      const float4 xa = *(const float4*)(xs + k), xb = *(const float4*)(xs + k + 4);
+  for (int j = 0; j < 8; j++) { const int k = j * 512 + lane * 8; load8<WDT>(wr, (size_t)e * H + (k < H ? k : 0), true, w[j]); }
+  __builtin_amdgcn_sched_barrier(0);
+  build_x_simple<false>(pro, 0, H, xs, red, blockIdx.x == 0);
+  if (blockIdx.x == 0) for (int i = tid; i < H; i += 256) xn_out[i] = xs[i];
+  float acc = 0.f;
+  for (int k0 = 0; k0 < H; k0 += 4096) {
+    if (k0 > 0) {
 #pragma unroll
-      for (int u = 0; u < 4; u++)
-        acc[u] += w[u][0] * xa.x + w[u][1] * xa.y + w[u][2] * xa.z + w[u][3] * xa.w + w[u][4] * xb.x + w[u][5] * xb.y + w[u][6] * xb.z + w[u][7] * xb.w;
+      for (int j = 0; j < 8; j++) { const int k = k0 + j * 512 + lane * 8; load8<WDT>(wr, (size_t)e * H + (k < H ? k : 0), true, w[j]); }
     }
 #pragma unroll
-    for (int u = 0; u < 4; u++) { const float v = wave_sum(acc[u]); if (lane == 0 && e0 + u < E) lg[e0 + u] = v; }
-  }
-  __syncthreads();
-  if (tid == 0) {
-    float m = -INFINITY, sum = 0.f;
-    for (int e = 0; e < E; e++) m = fmaxf(m, lg[e]);
-    for (int e = 0; e < E; e++) { lg[e] = expf(lg[e] - m); sum += lg[e]; }
-    for (int e = 0; e < E; e++) lg[e] = lg[e] / sum;
-    float tsum = 0.f;
-    for (int k = 0; k < top_k; k++) {
-      int best = -1;
-      for (int e = 0; e < E; e++) {
-        bool taken = false;
-        for (int j = 0; j < k; j++) taken = taken || sel[j] == e;
-        if (!taken && (best < 0 || lg[e] > lg[best])) best = e;
+    for (int j = 0; j < 8; j++) {
+      const int k = k0 + j * 512 + lane * 8;
+      if (k < H) {
+        const float4 xa = *(const float4*)(xs + k), xb = *(const float4*)(xs + k + 4);
+        acc += w[j][0] * xa.x + w[j][1] * xa.y + w[j][2] * xa.z + w[j][3] * xa.w + w[j][4] * xb.x + w[j][5] * xb.y + w[j][6] * xb.z + w[j][7] * xb.w;
       }
-      sel[k] = best; wsel[k] = lg[best]; tsum += lg[best];
     }
-    for (int k = 0; k < top_k; k++) wsel[k] = norm_topk ? wsel[k] / (tsum + 1e-20f) * routed_scale : wsel[k] * routed_scale;
-    for (int j = 0; j < n_shared; j++) { sel[top_k + j] = E + j; wsel[top_k + j] = 1.0f; }
+  }
+  acc = wave_sum(acc);
+  if (lane == 0 && (int)blockIdx.x * 4 + wave < E) lg_glob[blockIdx.x * 4 + wave] = acc;
+  __threadfence();
+  __syncthreads();
+  __shared__ unsigned s_last;
+  if (tid == 0) s_last = atomicAdd(counter, 1u) == gridDim.x - 1 ? 1u : 0u;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  for (int i = tid; i < E; i += 256) lg[i] = __builtin_nontemporal_load(lg_glob + i);
+  if (tid == 0) *counter = 0;                    // ready for the next launch (stream order)
+  __syncthreads();
+  if (wave == 0) {
+    // wave-parallel softmax + greedy top-k; lane l owns experts l, l + 64, ... (E <= 1024)
+    float v[16];
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 16; j++) { const int ee = lane + 64 * j; v[j] = ee < E ? lg[ee] : -INFINITY; m = fmaxf(m, v[j]); }
+    m = wave_max(m);
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; j++) { const int ee = lane + 64 * j; v[j] = ee < E ? expf(v[j] - m) : 0.f; }
+    for (int ee = 0; ee < E; ee++) sum += expf(lg[ee] - m);      // the oracle's sequential order
+#pragma unroll
+    for (int j = 0; j < 16; j++) { const int ee = lane + 64 * j; v[j] = ee < E ? v[j] / sum : -1.f; }
+    float tsum = 0.f, myw = 0.f; int mysel = 0;
+    for (int k = 0; k < top_k; k++) {
+      float bv = -1.f; int bi = 0x7fffffff;
+#pragma unroll
+      for (int j = 0; j < 16; j++) { const int ee = lane + 64 * j; if (v[j] > bv) { bv = v[j]; bi = ee; } }   // ascending e within a lane: first max wins
+#pragma unroll
+      for (int s2 = 32; s2 >= 1; s2 >>= 1) {
+        const float ov = __shfl_xor(bv, s2, 64); const int oi = __shfl_xor(bi, s2, 64);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+      }
+      if (lane == k) { mysel = bi; myw = bv; }
+      tsum += bv;
+#pragma unroll
+      for (int j = 0; j < 16; j++) if (lane + 64 * j == bi) v[j] = -1.f;
+    }
+    if (lane < top_k) { sel[lane] = mysel; wsel[lane] = norm_topk ? myw / (tsum + 1e-20f) * routed_scale : myw * routed_scale; }
+    if (lane < n_shared) { sel[top_k + lane] = E + lane; wsel[top_k + lane] = 1.0f; }
   }
 }
 
 int bzk_moe_router(hipStream_t s, const Pro& pro, const void* wr, int wdt, int E, int top_k, int n_shared, float routed_scale, int norm_topk,
-                   float* xn_out, int* sel, float* wsel) {
-  if (E > 1024 || top_k > E || pro.H % 8) BZ_FAIL(BZ_E_UNSUPPORTED, "moe_router: E %d / top_k %d unsupported", E, top_k);
+                   float* xn_out, int* sel, float* wsel, float* lg_glob, unsigned* counter) {
+  if (E > 1024 || top_k > E || top_k > 64 || n_shared > 64 || pro.H % 8) BZ_FAIL(BZ_E_UNSUPPORTED, "moe_router: E %d / top_k %d unsupported", E, top_k);
   const size_t smem = (size_t)(pro.H + 16 + E) * 4 + 64;
   if (smem > 64 * 1024) BZ_FAIL(BZ_E_UNSUPPORTED, "moe_router: hidden %d too large", pro.H);
-  BZ_LAUNCH("moe_router", (double)E * pro.H * bz_dtype_size(wdt), k_moe_router, dim3(1), dim3(256), smem, s, pro, wr, wdt, E, top_k, n_shared, routed_scale,
-            norm_topk, xn_out, sel, wsel);
+#define LAUNCH_ROUTER(DT) BZ_LAUNCH("moe_router", (double)E * pro.H * bz_dtype_size(wdt), k_moe_router<DT>, dim3((E + 3) / 4), dim3(256), smem, s, pro, wr, E, top_k, \
+                                   n_shared, routed_scale, norm_topk, xn_out, sel, wsel, lg_glob, counter)
+  if (wdt == BZ_F16) LAUNCH_ROUTER(BZ_F16); else if (wdt == BZ_BF16) LAUNCH_ROUTER(BZ_BF16); else LAUNCH_ROUTER(BZ_F32);
+#undef LAUNCH_ROUTER
   BZ_HIP(hipGetLastError());
   return BZ_OK;
 }
