@@ -71,6 +71,7 @@ void bz_dev_release(bz_device* d) {
   for (auto ev : d->events) hipEventDestroy(ev);
   if (d->pinned) hipHostFree(d->pinned);
   if (d->scratch) hipFree(d->scratch);
+  bzk_sample_free(d->samp_ws);
   hipStreamDestroy(d->stream);
   hipStreamDestroy(d->copy_stream);
   delete d;
@@ -1760,6 +1761,10 @@ extern "C" int bz_logits_to_token(bz_device* dev, const bz_tensor* logits, int64
     BZ_FAIL(BZ_E_INVALID, "logits_to_token: ids I64[n] / cnts I32[n] required");
   BZ_HIP(hipSetDevice(dev->id));
   float* scratch = dev->scratch;
+  if (temperature < 0.0f) BZ_FAIL(BZ_E_INVALID, "logits_to_token: negative temperature");
+  if (temperature != 0.0f)   // generation.rs:262-264: greedy == temperature 0; otherwise the sampled path
+    return bzk_sample(dev->stream, &dev->samp_ws, (const float*)logits->ptr + (size_t)(rows - 1) * vocab, vocab, n ? (const long long*)ids->ptr : nullptr,
+                      n ? (const int*)cnts->ptr : nullptr, n, rp, fp, pp, temperature, top_k, top_p, min_p, seed, (long long*)token_out->ptr);
   int rc = bzk_logits_to_token(dev->stream, (const float*)logits->ptr + (size_t)(rows - 1) * vocab, vocab, n ? (const long long*)ids->ptr : nullptr,
                                n ? (const int*)cnts->ptr : nullptr, n, rp, fp, pp, temperature, top_k, top_p, min_p, seed, scratch,
                                (long long*)token_out->ptr);

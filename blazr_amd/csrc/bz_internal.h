@@ -74,6 +74,7 @@ struct bz_device {
   size_t pinned_off = 0;
   uint64_t event_counter = 0;
   float* scratch = nullptr;   // 4 KiB device scratch (sampling partials)
+  void* samp_ws = nullptr;    // non-greedy sampling workspace (bz_sample.hip), grown on demand
   int refs = 1;               // the handle itself + every live child object (tensor/model/cache/graph)
 };
 void bz_dev_retain(bz_device* d);
@@ -220,6 +221,11 @@ int bzk_mla_attn(hipStream_t s, const MlaArgs& a, int max_len);
 int bzk_moe_router(hipStream_t s, const Pro& pro, const void* wr, int wdt, int E, int top_k, int n_shared, float routed_scale, int norm_topk,
                    float* xn_out, int* sel, float* wsel, float* lg_glob, unsigned* counter);
 int bzk_moe_combine(hipStream_t s, long long* acc, const float* wsel, int top_k, int has_shared, int H, int act, float* out);
+
+// non-greedy sampling (bz_sample.hip)
+int bzk_sample(hipStream_t s, void** ws, const float* logits, long long V, const long long* ids, const int* cnts, int n, float rp, float fp, float pp,
+               float temperature, int top_k, float top_p, float min_p, unsigned long long seed, long long* tok_out);
+int bzk_sample_free(void* ws);
 
 // Mamba2 kernels
 int bzk_conv_step(hipStream_t s, const float* zxbcdt, int x_off, int conv_dim, int kc, const float* w, const float* b, float* conv_state, int act,

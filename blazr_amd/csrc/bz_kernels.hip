@@ -2257,7 +2257,6 @@ int bzk_attn_oproj(hipStream_t s, const AttnArgs& a, const LinearDev& L, long lo
   const int CS = bzk_attn_oproj_slices(a, L);
   if (CS <= 0) BZ_FAIL(BZ_E_INVALID, "attn+o_proj fusion does not apply to this shape");
   const int TPW = (L.N / 64) / (CS * 4);
-  const size_t smem = (size_t)(3 * 128 + 8 + 128 + 96 + 8 + 256 * 132) * 4;
 #define LAUNCH_AO(DT, T) BZ_LAUNCH("attn+o_proj", L.algo_bytes, (k_attn2<DT, 1, T>), dim3(a.nq * CS), dim3(256), attn2_smem(), s, a, (const uint4*)L.w, \
     (const __half*)L.scales, (const unsigned char*)L.zeros, L.bias, CS, acc)
 #define LAUNCH_AO_T(DT) do { if (TPW == 1) LAUNCH_AO(DT, 1); else LAUNCH_AO(DT, 2); } while (0)

@@ -617,11 +617,11 @@ class Executor:
         self.model = model
 
     def generate(self, prompt_tokens, max_tokens, temperature=0.0, repeat_penalty=1.0, repeat_last_n=64, frequency_penalty=0.0,
-                 presence_penalty=0.0, eos_id=-1, use_graph=False, paged=False, block_size=16, seed=0):
+                 presence_penalty=0.0, eos_id=-1, use_graph=False, paged=False, block_size=16, seed=0, top_k=0, top_p=1.0, min_p=0.0):
         g = L.GenConfig()
         g.max_tokens, g.temperature, g.repeat_penalty, g.repeat_last_n = max_tokens, temperature, repeat_penalty, repeat_last_n
         g.frequency_penalty, g.presence_penalty = frequency_penalty, presence_penalty
-        g.top_k, g.top_p, g.min_p, g.seed = 0, 1.0, 0.0, seed
+        g.top_k, g.top_p, g.min_p, g.seed = top_k, top_p, min_p, seed
         g.eos_id, g.use_graph, g.paged, g.block_size = eos_id, int(use_graph), int(paged), block_size
         p = np.ascontiguousarray(prompt_tokens, dtype=np.int64)
         out = np.zeros(max(max_tokens, 1), dtype=np.int64)

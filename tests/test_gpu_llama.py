@@ -205,3 +205,15 @@ def test_full_width_layers(device, preset):
     got_t = runtime.Executor(lm).generate(p, 12, use_graph=True)
     n = _fair_prefix(trace)
     assert got_t[:n].tolist() == want_t[:n].tolist()
+
+
+def test_generate_with_sampling_is_seeded(device):
+    lm = runtime.LoadedModel.from_synth(device, synth.make_llama("tiny-awq"))
+    ex = runtime.Executor(lm)
+    p = synth.prompt_tokens(8, 1024, seed=2)
+    a = ex.generate(p, 16, temperature=0.9, seed=11).tolist()
+    b = ex.generate(p, 16, temperature=0.9, seed=11).tolist()
+    c = ex.generate(p, 16, temperature=0.9, seed=12).tolist()
+    assert a == b and a != c and len(a) == 16
+    with pytest.raises(L.BlazrHipError):
+        ex.generate(p, 4, temperature=0.9, use_graph=True)      # graph mode is greedy-only (cli/run.rs:144-157)
