@@ -53,6 +53,22 @@ def hip_events(stream):
     return T()
 
 
+def pmc_traffic(label):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this build (profiles/r01_pmc_traffic.json,
+    made by scripts/pmc_traffic.py: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction (2*FETCH + WRITE) * 1024).  A process cannot
+    collect PMC counters on itself, so this is read back from the file; None when the file or the kernel is missing."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        for lbl, sym in d["labels"].items():
+            if label.startswith(lbl):
+                for name, v in d["kernels"].items():
+                    if name.startswith(sym):
+                        return v["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -139,7 +155,7 @@ def main():
         p["gbs"] = (p["algo_bytes"] / 1e9) / (p["total_ms"] / 1e3) if p["total_ms"] > 0 and p["algo_bytes"] > 0 else None
     dom = max(prof, key=lambda p: p["total_ms"])
     roof = {"bound": "hbm", "kernel": dom["name"], "achieved": round(dom["gbs"], 1) if dom["gbs"] else None, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(dom["gbs"] / HBM_PEAK_GBS, 4) if dom["gbs"] else None, "traffic": None,
+            "unit": "GB/s", "frac": round(dom["gbs"] / HBM_PEAK_GBS, 4) if dom["gbs"] else None, "traffic": pmc_traffic(dom["name"]),
             "bytes_per_launch": dom["algo_bytes"] / max(dom["launches"], 1), "avg_launch_us": round(dom["avg_us"], 2),
             "whole_step_frac": round(algo_bytes * (tok_s / n_gpus) / (HBM_PEAK_GBS * 1e9), 4)}
 
