@@ -132,6 +132,7 @@ SYMBOLS = {
     "bz_forward_ssm": (C.c_int, [P, P, C.c_int, P, P, C.c_uint32]),
     "bz_decode_graph_capture_ssm": (C.c_int, [P, P, C.POINTER(P)]),
     "bz_tune_gemv": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    "bz_prefill_matmul": (C.c_int, [P, C.c_char_p, P, C.c_int, P]),
     "bz_quant_matmul": (C.c_int, [P, C.c_char_p, P, C.c_int, P]),
     "bz_dequant": (C.c_int, [P, C.c_char_p, P]),
     "bz_rms_norm": (C.c_int, [P, P, P, P, C.c_int, C.c_int, C.c_float, C.c_int, P, P]),

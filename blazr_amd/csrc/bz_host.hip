@@ -259,6 +259,8 @@ struct bz_model {
   float* cos_t = nullptr; float* sin_t = nullptr;
   // workspace
   float* hbuf[2] = {nullptr, nullptr};
+  // batched-prefill workspace (bz_prefill.hip), allocated on first use for `pf_rows` prompt rows
+  int pf_rows = 0; float* pf_h = nullptr; float* pf_t = nullptr; float* pf_qkv = nullptr; float* pf_gu = nullptr; void* pf_x16 = nullptr;
   long long* ring[3] = {nullptr, nullptr, nullptr};
   float* dring[3] = {nullptr, nullptr, nullptr};   // direct-output twins of the ring (ROWS kernels)
   int ring_n = 0;
@@ -1500,6 +1502,96 @@ static int emit_logits(bz_model* m, bz_tensor* logits_out, int row) {
   return BZ_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// batched prefill on the matrix cores (dense f16 / bf16 Llama-family models): SURVEY.md 8 row K4
+// ---------------------------------------------------------------------------------------------------------
+static int find_linear(bz_model* m, const char* name, LinearDev* out);
+static int prefill_min_rows() {
+  static const int v = getenv("BZ_NO_MFMA_PREFILL") ? (1 << 30) : (getenv("BZ_PREFILL_MIN") ? atoi(getenv("BZ_PREFILL_MIN")) : 8);
+  return v;
+}
+static bool prefill_eligible(const bz_model* m, int S, int total_len) {
+  const bz_model_config& c = m->cfg;
+  if (c.arch != BZ_ARCH_LLAMA || S < prefill_min_rows() || (c.act_dtype != BZ_F16 && c.act_dtype != BZ_BF16)) return false;
+  if (c.hidden % 64 || (c.n_heads * c.head_dim) % 64 || c.inter % 64 || total_len > 12000) return false;
+  for (const LayerDev& L : m->layers)
+    for (const FusedLinear* F : {&L.qkv, &L.o, &L.gateup, &L.down})
+      if (F->parts.size() != 1 || F->parts[0].kind != LK_ROWS || F->parts[0].wdt != c.act_dtype) return false;
+  return m->lm_head.parts.size() == 1 && m->lm_head.parts[0].kind == LK_ROWS && !m->lm_head.fix_out;
+}
+static int prefill_ws(bz_model* m, int rows) {
+  if (m->pf_rows >= rows) return BZ_OK;
+  const bz_model_config& c = m->cfg;
+  const size_t qn = (size_t)(c.n_heads + 2 * c.n_kv_heads) * c.head_dim, xw = std::max<size_t>(std::max<size_t>(c.hidden, c.inter), (size_t)c.n_heads * c.head_dim);
+  BZ_HIP(hipStreamSynchronize(m->dev->stream));
+  void* p;
+  BZ_TRY(dev_alloc(m, &p, (size_t)rows * c.hidden * 4)); m->pf_h = (float*)p;     // (earlier, smaller buffers stay owned until the model is freed)
+  BZ_TRY(dev_alloc(m, &p, (size_t)rows * c.hidden * 4)); m->pf_t = (float*)p;
+  BZ_TRY(dev_alloc(m, &p, (size_t)rows * qn * 4)); m->pf_qkv = (float*)p;
+  BZ_TRY(dev_alloc(m, &p, (size_t)rows * 2 * c.inter * 4)); m->pf_gu = (float*)p;
+  BZ_TRY(dev_alloc(m, &p, (size_t)rows * xw * 2)); m->pf_x16 = p;
+  m->pf_rows = rows;
+  return BZ_OK;
+}
+
+// tokens [S] at positions pos0 .. pos0+S-1; `slots` (paged only): device i32 [S].  Logits of the last row (or all rows) -> logits_out.
+static int prefill_dense(bz_model* m, const long long* d_tok, int S, const KvView& view, int pos0, const int* slots, bool all, bz_tensor* logits_out) {
+  const bz_model_config& c = m->cfg;
+  hipStream_t st = m->dev->stream;
+  const int H = c.hidden, I = c.inter, nq = c.n_heads, nkv = c.n_kv_heads, hd = c.head_dim, act = c.act_dtype, dt = c.act_dtype;
+  const int CH = 512;
+  BZ_TRY(prefill_ws(m, std::min(S, CH)));
+  for (int s0 = 0; s0 < S; s0 += CH) {
+    const int n = std::min(CH, S - s0), p0 = pos0 + s0;
+    BZ_TRY(bzk_pf_embed(st, m->embed, m->embed_dt, d_tok + s0, n, H, act, m->pf_h));
+    const float* prev = nullptr;
+    for (int l = 0; l < c.n_layers; l++) {
+      const LayerDev& L = m->layers[l];
+      BZ_TRY(bzk_pf_norm(st, dt, m->pf_h, prev, L.attn_norm, n, H, c.rms_eps, act, m->pf_x16));
+      BZ_TRY(bzk_gemm_nt(st, dt, m->pf_x16, L.qkv.parts[0].w, L.qkv.parts[0].bias, n, L.qkv.N, H, act, m->pf_qkv));
+      BZ_TRY(bzk_pf_rope_kv(st, m->pf_qkv, n, nq, nkv, hd, m->cos_t, m->sin_t, c.rope_interleaved, p0, act, view, l, slots ? slots + s0 : nullptr));
+      BZ_TRY(bzk_pf_attn(st, dt, m->pf_qkv, n, nq, nkv, hd, p0, act, view, l, m->pf_x16));
+      BZ_TRY(bzk_gemm_nt(st, dt, m->pf_x16, L.o.parts[0].w, L.o.parts[0].bias, n, H, nq * hd, act, m->pf_t));
+      BZ_TRY(bzk_pf_norm(st, dt, m->pf_h, m->pf_t, L.ffn_norm, n, H, c.rms_eps, act, m->pf_x16));
+      BZ_TRY(bzk_gemm_nt(st, dt, m->pf_x16, L.gateup.parts[0].w, L.gateup.parts[0].bias, n, 2 * I, H, act, m->pf_gu));
+      BZ_TRY(bzk_pf_silu(st, dt, m->pf_gu, n, I, act, m->pf_x16));
+      BZ_TRY(bzk_gemm_nt(st, dt, m->pf_x16, L.down.parts[0].w, L.down.parts[0].bias, n, H, I, act, m->pf_t));
+      prev = m->pf_t;
+    }
+    // head: rows that need logits go through the decode lm_head GEMV (final norm fused as its prologue)
+    for (int r = 0; r < n; r++) {
+      const int srow = s0 + r;
+      if (!all && srow != S - 1) continue;
+      Pro ph{}; ph.mode = PRO_NORM; ph.src = VSrc{prev + (size_t)r * H, 0}; ph.h_in = m->pf_h + (size_t)r * H; ph.h_out = nullptr; ph.norm_w = m->final_norm;
+      ph.eps = c.rms_eps; ph.H = H; ph.act = act;
+      GemvOut o{};
+      o.direct = m->logits; o.amax_val = m->pval; o.amax_idx = m->pidx;
+      BZ_TRY(bzk_gemv(st, m->lm_head.parts[0], ph, o, act));
+      BZ_TRY(emit_logits(m, logits_out, all ? srow : 0));
+    }
+  }
+  return BZ_OK;
+}
+
+// op-level: y[S,N] = x16[S,K] . W[N,K]^T on the matrix cores, x rounded to the weight dtype first, f32 accumulators returned unrounded
+extern "C" int bz_prefill_matmul(bz_model* m, const char* name, const bz_tensor* x, int S, bz_tensor* y) {
+  LinearDev L;
+  BZ_TRY(find_linear(m, name, &L));
+  if (L.kind != LK_ROWS || (L.wdt != BZ_F16 && L.wdt != BZ_BF16)) BZ_FAIL(BZ_E_UNSUPPORTED, "prefill_matmul: '%s' is not a dense f16 / bf16 weight", name);
+  if (!x || !y || x->dtype != BZ_F32 || y->dtype != BZ_F32 || S <= 0 || x->nbytes < (size_t)S * L.K * 4 || y->nbytes < (size_t)S * L.N * 4)
+    BZ_FAIL(BZ_E_INVALID, "prefill_matmul: x must be F32 [S,%d], y F32 [S,%d]", L.K, L.N);
+  BZ_HIP(hipSetDevice(m->dev->id));
+  hipStream_t st = m->dev->stream;
+  void* x16 = nullptr;
+  BZ_HIP(hipMalloc(&x16, (size_t)S * L.K * 2));
+  int rc = bzk_pf_cvt16(st, L.wdt, (const float*)x->ptr, (size_t)S * L.K, x16);
+  if (rc == BZ_OK) rc = bzk_gemm_nt(st, L.wdt, x16, L.w, L.bias, S, L.N, L.K, BZ_F32, (float*)y->ptr);
+  hipStreamSynchronize(st);
+  hipFree(x16);
+  return rc;
+}
+
 extern "C" int bz_forward_kv(bz_model* m, const bz_tensor* tokens, int S, bz_kv* kv, int position, bz_tensor* logits_out, uint32_t flags) {
   BZ_TRY(check_fwd(m, tokens, S));
   BZ_TRACE("forward_kv: S=%d position=%d", S, position);
@@ -1508,6 +1600,13 @@ extern "C" int bz_forward_kv(bz_model* m, const bz_tensor* tokens, int S, bz_kv*
   if (position < 0 || position + S > m->cfg.max_seq_len) BZ_FAIL(BZ_E_INVALID, "forward_kv: position %d + S %d exceeds max_seq_len %d", position, S, m->cfg.max_seq_len);
   BZ_TRY(kv_grow(kv, position + S));
   const bool all = flags & BZ_FWD_ALL_LOGITS;
+  if (prefill_eligible(m, S, position + S)) {
+    // prompt-sized inputs of dense 16-bit models: batched prefill, GEMMs on the matrix cores
+    if (!logits_out || logits_out->dtype != BZ_F32 || logits_out->nbytes < (size_t)(all ? S : 1) * m->cfg.vocab * 4) BZ_FAIL(BZ_E_INVALID, "forward: logits_out too small");
+    BZ_TRY(prefill_dense(m, (const long long*)tokens->ptr, S, view_of(kv), position, nullptr, all, logits_out));
+    kv->seq_len = position + S;
+    return BZ_OK;
+  }
   for (int s = 0; s < S; s++) {
     hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, m->dev->stream, m->pos_tmp, position + s);
     StepIO io{};
@@ -1531,6 +1630,12 @@ extern "C" int bz_forward_paged(bz_model* m, const bz_tensor* tokens, int S, bz_
   if ((seq_len_k + kv->block_size - 1) / kv->block_size > n_table) BZ_FAIL(BZ_E_INVALID, "forward_paged: block_table too short for seq_len_k");
   if (seq_len_k > m->cfg.max_seq_len) BZ_FAIL(BZ_E_INVALID, "forward_paged: seq_len_k exceeds max_seq_len");
   const bool all = flags & BZ_FWD_ALL_LOGITS;
+  if (prefill_eligible(m, S, seq_len_k)) {
+    if (!logits_out || logits_out->dtype != BZ_F32 || logits_out->nbytes < (size_t)(all ? S : 1) * m->cfg.vocab * 4) BZ_FAIL(BZ_E_INVALID, "forward: logits_out too small");
+    BZ_TRY(prefill_dense(m, (const long long*)tokens->ptr, S, view_of(kv, (const int*)block_table->ptr, nullptr), start_pos, (const int*)slot_mapping->ptr, all, logits_out));
+    kv->seq_len = seq_len_k;
+    return BZ_OK;
+  }
   for (int s = 0; s < S; s++) {
     hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, m->dev->stream, m->pos_tmp, start_pos + s);
     StepIO io{};

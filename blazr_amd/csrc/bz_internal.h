@@ -1,6 +1,7 @@
 // bz_internal.h -- internal types of libblazr_hip.so (host + device). Not part of the ABI.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 #include <string>
@@ -130,6 +131,22 @@ size_t bz_dtype_size(int dtype);
 struct BzTimingRec { const char* label; double bytes; hipEvent_t e0, e1; };
 struct BzTimingSink { std::vector<BzTimingRec> recs; };
 void bzk_set_timing_sink(BzTimingSink* s);
+BzTimingSink* bzk_timing_sink();
+// launch helper: plain launch, or -- while a profile is being taken -- hipExtLaunchKernelGGL with start/stop events bound to the dispatch
+// itself (pure kernel time on the launch stream, no inter-kernel gap)
+#define BZ_LAUNCH(label, bytes, kernel, grid, block, smem, stream, ...)                                              \
+  do {                                                                                                               \
+    BzTimingSink* sink__ = bzk_timing_sink();                                                                        \
+    if (sink__) {                                                                                                    \
+      hipEvent_t e0__, e1__;                                                                                         \
+      BZ_HIP(hipEventCreate(&e0__));                                                                                 \
+      BZ_HIP(hipEventCreate(&e1__));                                                                                 \
+      hipExtLaunchKernelGGL(kernel, grid, block, smem, stream, e0__, e1__, 0, __VA_ARGS__);                          \
+      sink__->recs.push_back(BzTimingRec{label, (double)(bytes), e0__, e1__});                                       \
+    } else {                                                                                                         \
+      hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__);                                            \
+    }                                                                                                                \
+  } while (0)
 
 // ---------------------------------------------------------------------------------------------------------
 // kernel launchers (bz_kernels.hip)
@@ -221,6 +238,16 @@ int bzk_mla_attn(hipStream_t s, const MlaArgs& a, int max_len);
 int bzk_moe_router(hipStream_t s, const Pro& pro, const void* wr, int wdt, int E, int top_k, int n_shared, float routed_scale, int norm_topk,
                    float* xn_out, int* sel, float* wsel, float* lg_glob, unsigned* counter);
 int bzk_moe_combine(hipStream_t s, long long* acc, const float* wsel, int top_k, int has_shared, int H, int act, float* out);
+
+// batched prefill for dense 16-bit models (bz_prefill.hip): MFMA GEMM + row-wise norm / RoPE + KV append / causal attention / SiLU*up
+int bzk_gemm_nt(hipStream_t s, int dt, const void* x16, const void* w, const float* bias, int S, int N, int K, int act, float* y);
+int bzk_pf_cvt16(hipStream_t s, int dt, const float* x, size_t n, void* y);
+int bzk_pf_embed(hipStream_t s, const void* table, int tdt, const long long* tok, int S, int H, int act, float* out);
+int bzk_pf_norm(hipStream_t s, int dt, float* hbuf, const float* prev, const float* w, int S, int H, float eps, int act, void* x16);
+int bzk_pf_rope_kv(hipStream_t s, float* qkv, int S, int nq, int nkv, int hd, const float* cos_t, const float* sin_t, int interleaved, int pos0, int act,
+                   const KvView& kv, int layer, const int* slots);
+int bzk_pf_attn(hipStream_t s, int dt, const float* qkv, int S, int nq, int nkv, int hd, int pos0, int act, const KvView& kv, int layer, void* out16);
+int bzk_pf_silu(hipStream_t s, int dt, const float* gu, int S, int I, int act, void* a16);
 
 // non-greedy sampling (bz_sample.hip)
 int bzk_sample(hipStream_t s, void** ws, const float* logits, long long V, const long long* ids, const int* cnts, int n, float rp, float fp, float pp,

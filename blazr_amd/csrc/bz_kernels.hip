@@ -27,19 +27,7 @@
 // ---------------------------------------------------------------------------------------------------------
 static thread_local BzTimingSink* g_sink = nullptr;
 void bzk_set_timing_sink(BzTimingSink* s) { g_sink = s; }
-
-#define BZ_LAUNCH(label, bytes, kernel, grid, block, smem, stream, ...)                                              \
-  do {                                                                                                               \
-    if (g_sink) {                                                                                                    \
-      hipEvent_t e0__, e1__;                                                                                         \
-      BZ_HIP(hipEventCreate(&e0__));                                                                                 \
-      BZ_HIP(hipEventCreate(&e1__));                                                                                 \
-      hipExtLaunchKernelGGL(kernel, grid, block, smem, stream, e0__, e1__, 0, __VA_ARGS__);                          \
-      g_sink->recs.push_back(BzTimingRec{label, (double)(bytes), e0__, e1__});                                       \
-    } else {                                                                                                         \
-      hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__);                                            \
-    }                                                                                                                \
-  } while (0)
+BzTimingSink* bzk_timing_sink() { return g_sink; }
 
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));

@@ -232,6 +232,10 @@ int bz_tune_gemv(bz_device* dev, int N, int K, int groups_per_wg, int mode, int 
 /* ---- op-level entry points (parity tests; each is the kernel the forward path uses) ------------------------ */
 /* QuantMatmulOps / dense matmul on a registered weight `name` ("….weight"): y[S,N] = x[S,K] W^T (+bias); x,y F32 device tensors */
 int bz_quant_matmul(bz_model* m, const char* name, const bz_tensor* x, int S, bz_tensor* y);
+/* Prefill GEMM on the matrix cores (dense f16 / bf16 weights, K % 64 == 0): y[S,N] = round_to_weight_dtype(x)[S,K] . W[N,K]^T, f32 accumulate,
+ * result unrounded.  The same kernel runs inside bz_forward_kv / bz_forward_paged when a dense 16-bit Llama-family model is given S >= 8 tokens
+ * (regular.rs:89-117 bf16 SafeTensors path; boostr's matmul behind LoadedModel::forward_with_kv_cache at executor_generate.rs:357). */
+int bz_prefill_matmul(bz_model* m, const char* name, const bz_tensor* x, int S, bz_tensor* y);
 /* DequantOps: whole weight -> F32 [N,K] on host (from the REPACKED device layout: validates the repack) */
 int bz_dequant(bz_model* m, const char* name, float* host_out);
 /* NormalizationOps::rms_norm with optional fused residual: h' = round(h + prev) ; y = w * round(h' * rsqrt(mean(h'^2)+eps)) */

@@ -217,3 +217,65 @@ def test_generate_with_sampling_is_seeded(device):
     assert a == b and a != c and len(a) == 16
     with pytest.raises(L.BlazrHipError):
         ex.generate(p, 4, temperature=0.9, use_graph=True)      # graph mode is greedy-only (cli/run.rs:144-157)
+
+
+# ---- batched prefill on the matrix cores (dense f16 / bf16 models, S >= 8) ------------------------------------------------------------
+def _np16(x, dt):
+    return orc_py.round_act(np.asarray(x, dtype=np.float32), dt)
+
+
+@pytest.mark.parametrize("S", [1, 7, 33, 130, 300])
+def test_prefill_matmul_mfma(device, S):
+    import ctypes as C
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    import npref
+    rng = np.random.default_rng(S)
+    for preset, name, dt in (("tiny-bf16", "model.layers.1.mlp.down_proj.weight", "bf16"), ("tiny-awq", "lm_head.weight", "f16")):
+        model = synth.make_llama(preset)
+        lm = runtime.LoadedModel.from_synth(device, model)
+        spec = model["layers"][1]["down"] if "down" in name else model["lm_head"]
+        W = npref.dequant(spec).astype(np.float64)
+        N, K = W.shape
+        x = rng.standard_normal((S, K)).astype(np.float32)
+        tx, ty = device.tensor(x), device.zeros((S, N))
+        L.check(L.lib().bz_prefill_matmul(lm.h, name.encode(), tx.h, S, ty.h))
+        want = _np16(x, dt).astype(np.float64) @ W.T
+        got = ty.to_numpy()
+        assert np.abs(got - want).max() <= 3e-6 * np.abs(want).max(), (preset, S)
+
+
+def test_batched_prefill_then_decode_matches_oracle(device):
+    # 24-token prompt -> MFMA prefill path; the following decode steps read the cache it wrote
+    for preset in ("tiny-bf16",):
+        model = synth.make_llama(preset)
+        cfg = model["config"]
+        lm, om = runtime.LoadedModel.from_synth(device, model), orc_py.OrcLlama(model)
+        p = synth.prompt_tokens(24, cfg["vocab"], seed=13)
+        kv = runtime.LayeredKvCache(device, cfg["n_layers"], 1, cfg["n_kv_heads"], 24, cfg["max_seq_len"], cfg["head_dim"], _kv_dt(cfg))
+        okv = om.new_kv(64)
+        _check_logits(lm.forward_with_kv_cache(p, kv, 0, all_logits=True).to_numpy(), om.forward_kv(p, okv, 0, all_logits=True), cfg["act_dtype"])
+        # a second prompt chunk appended at position 24 (chunked prefill), then single-token decode
+        p2 = synth.prompt_tokens(10, cfg["vocab"], seed=14)
+        lg, lo = lm.forward_with_kv_cache(p2, kv, 24).to_numpy(), om.forward_kv(p2, okv, 24)
+        _check_logits(lg, lo, cfg["act_dtype"])
+        tok = int(lo[0].argmax())
+        for i in range(6):
+            lg, lo = lm.forward_with_kv_cache([tok], kv, 34 + i).to_numpy(), om.forward_kv([tok], okv, 34 + i)
+            _check_logits(lg, lo, cfg["act_dtype"])
+            tok = int(lo[0].argmax())
+        orc_py.lib().orc_kv_free(okv)
+
+
+def test_batched_prefill_full_width_1b_shape(device):
+    # real layer widths of Llama-3.2-1B (H 2048, I 8192, 32q/8kv x 64), one layer, small vocab: K = 2048 / 8192 GEMMs, S = 70 (3 row tiles)
+    model = synth.make_llama("llama3.2-1b-bf16", n_layers=1, vocab=4096)
+    cfg = model["config"]
+    lm, om = runtime.LoadedModel.from_synth(device, model), orc_py.OrcLlama(model)
+    p = synth.prompt_tokens(70, cfg["vocab"], seed=3)
+    kv = runtime.LayeredKvCache(device, 1, 1, cfg["n_kv_heads"], 80, cfg["max_seq_len"], cfg["head_dim"], _kv_dt(cfg))
+    okv = om.new_kv(80)
+    got = lm.forward_with_kv_cache(p, kv, 0, all_logits=True).to_numpy()
+    want = om.forward_kv(p, okv, 0, all_logits=True)
+    _check_logits(got, want, cfg["act_dtype"], factor=1.0)
+    orc_py.lib().orc_kv_free(okv)
