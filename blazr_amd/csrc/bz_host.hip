@@ -1514,7 +1514,9 @@ static int prefill_min_rows() {
 static bool prefill_eligible(const bz_model* m, int S, int total_len) {
   const bz_model_config& c = m->cfg;
   if (c.arch != BZ_ARCH_LLAMA || S < prefill_min_rows() || (c.act_dtype != BZ_F16 && c.act_dtype != BZ_BF16)) return false;
-  if (c.hidden % 64 || (c.n_heads * c.head_dim) % 64 || c.inter % 64 || total_len > 12000) return false;
+  if (c.hidden % 64 || (c.n_heads * c.head_dim) % 64 || c.inter % 64 || c.head_dim % 8 || 256 % (c.head_dim / 8)) return false;
+  const int rep = c.n_heads / c.n_kv_heads;
+  if ((rep != 1 && rep != 2 && rep != 4 && rep != 8) || bzk_pf_attn_smem(c.n_heads, c.n_kv_heads, c.head_dim, total_len) > 160 * 1024) return false;
   for (const LayerDev& L : m->layers)
     for (const FusedLinear* F : {&L.qkv, &L.o, &L.gateup, &L.down})
       if (F->parts.size() != 1 || F->parts[0].kind != LK_ROWS || F->parts[0].wdt != c.act_dtype) return false;

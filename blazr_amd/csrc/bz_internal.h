@@ -248,6 +248,7 @@ int bzk_pf_rope_kv(hipStream_t s, float* qkv, int S, int nq, int nkv, int hd, co
                    const KvView& kv, int layer, const int* slots);
 int bzk_pf_attn(hipStream_t s, int dt, const float* qkv, int S, int nq, int nkv, int hd, int pos0, int act, const KvView& kv, int layer, void* out16);
 int bzk_pf_silu(hipStream_t s, int dt, const float* gu, int S, int I, int act, void* a16);
+size_t bzk_pf_attn_smem(int nq, int nkv, int hd, int len);
 
 // non-greedy sampling (bz_sample.hip)
 int bzk_sample(hipStream_t s, void** ws, const float* logits, long long V, const long long* ids, const int* cnts, int n, float rp, float fp, float pp,

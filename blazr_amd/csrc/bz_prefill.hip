@@ -43,56 +43,84 @@ __device__ __forceinline__ f32x16 mfma16(const uint4& a, const uint4& b, f32x16 
   else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
-// grid = (ceil(N / 128), ceil(S / (32 MT))); 256 threads = 4 waves, wave w -> columns n0 + 32 w .. +31
-template <int DT, int MT>
+// Workgroup = 4 waves side by side along N; wave tile = (32 MT) rows x (32 NT) columns.  The A tile (32 MT rows x 64 k) is shared by the four
+// waves through LDS (row stride 144 B: 16-byte fragment reads of 32 consecutive rows spread over all banks); B fragments have no reuse across
+// waves and go straight from global memory to registers.  Double buffered: the loads of tile i+1 (A -> registers -> LDS, B -> registers) are
+// in flight under the MFMAs of tile i; one barrier per tile.
+// grid = (ceil(N / (128 NT)), ceil(S / (32 MT)))
+constexpr int A_STRIDE = 144;   // bytes per LDS row: 64 k x 2 B + 16 B pad
+template <int DT, int MT, int NT>
 __global__ __launch_bounds__(256) void k_gemm_nt(const unsigned short* __restrict__ X, const unsigned short* __restrict__ W, const float* __restrict__ bias,
                                                  int S, int N, int K, int act, float* __restrict__ Y) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-  const int n0 = blockIdx.x * 128 + wave * 32, m0 = blockIdx.y * 32 * MT;
-  if (n0 >= N) return;
-  const unsigned short* wrow = W + (size_t)min(n0 + r, N - 1) * K + 32 * h;
-  const unsigned short* xrow[MT];
+  __shared__ __attribute__((aligned(16))) unsigned char sA[2][32 * MT * A_STRIDE];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int n0 = (blockIdx.x * 4 + wave) * 32 * NT, m0 = blockIdx.y * 32 * MT;
+  // B: lane (r,h) reads 64 contiguous bytes (k = 32 h .. 32 h + 31) of row n per 64-k tile
+  unsigned woff[NT];                      // element offsets (N K < 2^32 for every matrix on this path)
 #pragma unroll
-  for (int t = 0; t < MT; t++) xrow[t] = X + (size_t)min(m0 + 32 * t + r, S - 1) * K + 32 * h;
-  f32x16 acc[MT];
+  for (int j = 0; j < NT; j++) woff[j] = (unsigned)min(n0 + 32 * j + r, N - 1) * (unsigned)K + 32u * h;
+  // A staging: 32 MT rows x 128 B per tile = 8 MT pieces of 16 B per row-pair...: piece p = tid + 256 i covers row p / 8, 16-byte column p % 8
+  constexpr int APT = MT;                 // 32 MT rows x 8 pieces = 256 MT pieces: exactly MT per thread; piece i of thread t: row (t >> 3) + 32 i, column t & 7
+  unsigned xoff[APT];
+#pragma unroll
+  for (int i = 0; i < APT; i++) xoff[i] = (unsigned)min(m0 + (tid >> 3) + 32 * i, S - 1) * (unsigned)K + 8u * (tid & 7);
+  const int adst0 = (tid >> 3) * A_STRIDE + 16 * (tid & 7);
+  f32x16 acc[MT][NT];
 #pragma unroll
   for (int t = 0; t < MT; t++)
 #pragma unroll
-    for (int i = 0; i < 16; i++) acc[t][i] = 0.f;
-  uint4 b0[4], a0[MT][4], b1[4], a1[MT][4];
-  auto load = [&](int k0, uint4 (&b)[4], uint4 (&a)[MT][4]) {
+    for (int j = 0; j < NT; j++)
 #pragma unroll
-    for (int s = 0; s < 4; s++) b[s] = __builtin_bit_cast(uint4, __builtin_nontemporal_load((const u32x4*)(wrow + k0) + s));
+      for (int i = 0; i < 16; i++) acc[t][j][i] = 0.f;
+  uint4 bcur[NT][4], bnext[NT][4], areg[APT];
+#define GEMM_GLOAD(K0, B)                                                                                                          \
+  _Pragma("unroll") for (int j = 0; j < NT; j++)                                                                                   \
+    _Pragma("unroll") for (int s = 0; s < 4; s++)                                                                                  \
+      B[j][s] = __builtin_bit_cast(uint4, __builtin_nontemporal_load((const u32x4*)(W + woff[j] + (K0)) + s));                     \
+  _Pragma("unroll") for (int i = 0; i < APT; i++) areg[i] = *(const uint4*)(X + xoff[i] + (K0));
+#define GEMM_ASTORE(BUF) _Pragma("unroll") for (int i = 0; i < APT; i++) *(uint4*)(&sA[BUF][adst0 + 32 * i * A_STRIDE]) = areg[i];
+  GEMM_GLOAD(0, bcur)
+  GEMM_ASTORE(0)
+  __syncthreads();
+  const int nk = K >> 6;
+  for (int kt = 0; kt < nk; kt++) {
+    const int buf = kt & 1;
+    const int kn = min(kt + 1, nk - 1) << 6;             // clamped: one redundant reload at the tail, never a branch around a load
+    GEMM_GLOAD(kn, bnext)
+    const unsigned char* a0 = &sA[buf][r * A_STRIDE + 64 * h];
 #pragma unroll
-    for (int t = 0; t < MT; t++)
+    for (int s = 0; s < 4; s++) {
+      uint4 af[MT];
 #pragma unroll
-      for (int s = 0; s < 4; s++) a[t][s] = *((const uint4*)(xrow[t] + k0) + s);
-  };
-  auto fma = [&](const uint4 (&b)[4], const uint4 (&a)[MT][4]) {
+      for (int t = 0; t < MT; t++) af[t] = *(const uint4*)(a0 + 32 * t * A_STRIDE + 16 * s);
 #pragma unroll
-    for (int s = 0; s < 4; s++)
+      for (int t = 0; t < MT; t++)
 #pragma unroll
-      for (int t = 0; t < MT; t++) acc[t] = mfma16<DT>(a[t][s], b[s], acc[t]);
-  };
-  load(0, b0, a0);
-  for (int k0 = 0; k0 < K; k0 += 128) {
-    const int k1 = min(k0 + 64, K - 64), k2 = min(k0 + 128, K - 64);   // clamped: redundant reloads at the tail, never a branch around a load
-    load(k1, b1, a1);
-    fma(b0, a0);
-    load(k2, b0, a0);
-    if (k0 + 64 < K) fma(b1, a1);
+        for (int j = 0; j < NT; j++) acc[t][j] = mfma16<DT>(af[t], bcur[j][s], acc[t][j]);
+    }
+    GEMM_ASTORE(buf ^ 1)                                  // the other buffer was last read before the previous barrier
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NT; j++)
+#pragma unroll
+      for (int s = 0; s < 4; s++) bcur[j][s] = bnext[j][s];
   }
+#undef GEMM_GLOAD
+#undef GEMM_ASTORE
   // C layout: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
-  const int n = n0 + r;
-  if (n < N) {
-    const float bv = bias ? bias[n] : 0.f;
 #pragma unroll
-    for (int t = 0; t < MT; t++)
+  for (int j = 0; j < NT; j++) {
+    const int n = n0 + 32 * j + r;
+    if (n < N) {
+      const float bv = bias ? bias[n] : 0.f;
 #pragma unroll
-      for (int i = 0; i < 16; i++) {
-        const int m = m0 + 32 * t + (i & 3) + 8 * (i >> 2) + 4 * h;
-        if (m < S) Y[(size_t)m * N + n] = pf_round(acc[t][i] + bv, act);
-      }
+      for (int t = 0; t < MT; t++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+          const int m = m0 + 32 * t + (i & 3) + 8 * (i >> 2) + 4 * h;
+          if (m < S) Y[(size_t)m * N + n] = pf_round(acc[t][j][i] + bv, act);
+        }
+    }
   }
 }
 
@@ -161,46 +189,105 @@ __device__ __forceinline__ float kv_at(const KvView& kv, const void* base, int l
   return ((const float*)base)[off];
 }
 
-// causal attention of query (s, head) over cache positions [0, pos0 + s]; output rounded and stored as 16-bit (the o_proj GEMM input).
-// grid = (S, nq), 256 threads; scores in LDS (len <= max_len)
-template <int DT>
+// Causal attention for prefill: one workgroup per (query s, kv head) serves all REP = nq / nkv query heads of the group, so every K / V row
+// is loaded once per group (GQA).  PR = hd / 8 lanes share a cache row (16 bytes each, a row is one contiguous 16 * PR-byte read); 256 / PR
+// rows per pass.  Scores for the REP heads sit in LDS; output rounded and stored as 16-bit (the o_proj GEMM input).
+// grid = (S, nkv), 256 threads.  KVDT: cache dtype (compile time: no dtype switch around the loads).
+template <int DT, int KVDT>
+__device__ __forceinline__ void ld_row8(const void* base, size_t off, float (&o)[8]) {
+  if constexpr (KVDT == BZ_F32) {
+    const float4 a = *(const float4*)((const float*)base + off), b = *(const float4*)((const float*)base + off + 4);
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+  } else {
+    const uint4 rr = *(const uint4*)((const unsigned short*)base + off);
+    const unsigned u[4] = {rr.x, rr.y, rr.z, rr.w};
+#pragma unroll
+    for (int i = 0; i < 4; i++) { o[2 * i] = from16<KVDT>((unsigned short)(u[i] & 0xffffu)); o[2 * i + 1] = from16<KVDT>((unsigned short)(u[i] >> 16)); }
+  }
+}
+template <int DT, int KVDT, int REP>
 __global__ __launch_bounds__(256) void k_pf_attn(const float* qkv, int nq, int nkv, int hd, int pos0, int act, KvView kv, int layer, float scale, unsigned short* out16) {
-  extern __shared__ float lds[];
-  float* q = lds; float* red = q + hd; float* part = red + 8; float* sc = part + 4 * hd;
-  const int s = blockIdx.x, hq = blockIdx.y, kvh = hq / (nq / nkv), len = pos0 + s + 1;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int s = blockIdx.x, kvh = blockIdx.y, len = pos0 + s + 1;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  for (int i = tid; i < hd; i += 256) q[i] = qkv[(size_t)s * (nq + 2 * nkv) * hd + (size_t)hq * hd + i];
-  __syncthreads();
-  for (int p = tid; p < len; p += 256) {
-    float d = 0.f;
-    for (int i = 0; i < hd; i++) d += q[i] * kv_at(kv, kv.k, layer, kvh, p, i);
-    sc[p] = d * scale;
+  const int PR = hd >> 3, RPP = 256 / PR;              // lanes per row, rows per pass
+  const int c = tid % PR, g = tid / PR;                // this thread's 8-dim piece and row slot
+  float* red = lds;                                    // [REP][4] + [REP][4]
+  float* part = red + 8 * REP;                         // [RPP][REP][hd]
+  float* sc = part + RPP * REP * hd;                   // [REP][len]
+  float q[REP][8];
+#pragma unroll
+  for (int h = 0; h < REP; h++)
+#pragma unroll
+    for (int e = 0; e < 8; e++) q[h][e] = qkv[(size_t)s * (nq + 2 * nkv) * hd + (size_t)(kvh * REP + h) * hd + 8 * c + e];
+  auto row_off = [&](int p) -> size_t {
+    if (kv.paged) { const int blk = kv.block_table[p / kv.bs]; return (size_t)layer * kv.layer_stride + (((size_t)blk * kv.n_kv + kvh) * kv.bs + p % kv.bs) * kv.hd + 8 * c; }
+    return (size_t)layer * kv.layer_stride + ((size_t)kvh * kv.cap + p) * kv.hd + 8 * c;
+  };
+  // ---- scores ----
+  for (int p0 = 0; p0 < len; p0 += 2 * RPP) {
+    float k0[8], k1[8];
+    const int pa = p0 + g, pb = p0 + RPP + g;
+    ld_row8<DT, KVDT>(kv.k, row_off(min(pa, len - 1)), k0);
+    ld_row8<DT, KVDT>(kv.k, row_off(min(pb, len - 1)), k1);
+#pragma unroll
+    for (int h = 0; h < REP; h++) {
+      float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; e++) { d0 += q[h][e] * k0[e]; d1 += q[h][e] * k1[e]; }
+      for (int m = 1; m < PR; m <<= 1) { d0 += __shfl_xor(d0, m, 64); d1 += __shfl_xor(d1, m, 64); }
+      if (c == 0) { if (pa < len) sc[h * len + pa] = d0 * scale; if (pb < len) sc[h * len + pb] = d1 * scale; }
+    }
   }
   __syncthreads();
-  float m = -INFINITY;
-  for (int p = tid; p < len; p += 256) m = fmaxf(m, sc[p]);
-  for (int k = 32; k >= 1; k >>= 1) m = fmaxf(m, __shfl_xor(m, k, 64));
-  if (lane == 0) red[wave] = m;
+  // ---- softmax per head ----
+#pragma unroll
+  for (int h = 0; h < REP; h++) {
+    float m = -INFINITY;
+    for (int p = tid; p < len; p += 256) m = fmaxf(m, sc[h * len + p]);
+    for (int k = 32; k >= 1; k >>= 1) m = fmaxf(m, __shfl_xor(m, k, 64));
+    if (lane == 0) red[h * 4 + wave] = m;
+  }
   __syncthreads();
-  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+#pragma unroll
+  for (int h = 0; h < REP; h++) {
+    const float m = fmaxf(fmaxf(red[h * 4], red[h * 4 + 1]), fmaxf(red[h * 4 + 2], red[h * 4 + 3]));
+    float sum = 0.f;
+    for (int p = tid; p < len; p += 256) { const float e = expf(sc[h * len + p] - m); sc[h * len + p] = e; sum += e; }
+    for (int k = 32; k >= 1; k >>= 1) sum += __shfl_xor(sum, k, 64);
+    if (lane == 0) red[4 * REP + h * 4 + wave] = sum;
+  }
   __syncthreads();
-  float sum = 0.f;
-  for (int p = tid; p < len; p += 256) { const float e = expf(sc[p] - m); sc[p] = e; sum += e; }
-  for (int k = 32; k >= 1; k >>= 1) sum += __shfl_xor(sum, k, 64);
-  if (lane == 0) red[wave] = sum;
+  // ---- PV: thread (c, g) accumulates its 8 dims over rows g, g + RPP, ... ----
+  float acc[REP][8];
+#pragma unroll
+  for (int h = 0; h < REP; h++)
+#pragma unroll
+    for (int e = 0; e < 8; e++) acc[h][e] = 0.f;
+  for (int p0 = 0; p0 < len; p0 += 2 * RPP) {
+    float v0[8], v1[8];
+    const int pa = p0 + g, pb = p0 + RPP + g;
+    ld_row8<DT, KVDT>(kv.v, row_off(min(pa, len - 1)), v0);
+    ld_row8<DT, KVDT>(kv.v, row_off(min(pb, len - 1)), v1);
+#pragma unroll
+    for (int h = 0; h < REP; h++) {
+      const float w0 = pa < len ? sc[h * len + pa] : 0.f, w1 = pb < len ? sc[h * len + pb] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; e++) acc[h][e] += w0 * v0[e] + w1 * v1[e];
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < REP; h++)
+#pragma unroll
+    for (int e = 0; e < 8; e++) part[(g * REP + h) * hd + 8 * c + e] = acc[h][e];
   __syncthreads();
-  sum = (red[0] + red[1]) + (red[2] + red[3]);
-  const float inv = 1.0f / sum;
-  // PV: wave w takes positions w, w+4, ...; lane owns dims lane, lane+64, ...
-  for (int i0 = 0; i0 < hd; i0 += 64) {
-    const int i = i0 + lane;
+  for (int i = tid; i < REP * hd; i += 256) {
+    const int h = i / hd, d = i % hd;
     float a = 0.f;
-    if (i < hd) for (int p = wave; p < len; p += 4) a += sc[p] * kv_at(kv, kv.v, layer, kvh, p, i);
-    if (i < hd) part[wave * hd + i] = a;
+    for (int gg = 0; gg < RPP; gg++) a += part[(gg * REP + h) * hd + d];
+    const float invh = 1.0f / ((red[4 * REP + h * 4] + red[4 * REP + h * 4 + 1]) + (red[4 * REP + h * 4 + 2] + red[4 * REP + h * 4 + 3]));
+    out16[(size_t)s * nq * hd + (size_t)(kvh * REP + h) * hd + d] = to16<DT>(pf_round(a * invh, act));
   }
-  __syncthreads();
-  for (int i = tid; i < hd; i += 256)
-    out16[(size_t)s * nq * hd + (size_t)hq * hd + i] = to16<DT>(pf_round(((part[i] + part[hd + i]) + (part[2 * hd + i] + part[3 * hd + i])) * inv, act));
 }
 
 // a16[s][i] = to16(R(R(silu(g)) * u)),  gu rows = [gate (I) | up (I)]
@@ -236,13 +323,19 @@ __global__ void k_pf_embed(const void* table, int tdt, const long long* tok, int
 int bzk_gemm_nt(hipStream_t s, int dt, const void* x16, const void* w, const float* bias, int S, int N, int K, int act, float* y) {
   if (dt != BZ_F16 && dt != BZ_BF16) BZ_FAIL(BZ_E_UNSUPPORTED, "gemm_nt: 16-bit operands only");
   if (K % 64 || K < 64 || S <= 0 || N <= 0) BZ_FAIL(BZ_E_UNSUPPORTED, "gemm_nt: K=%d must be a positive multiple of 64", K);
-  const int MT = S > 96 ? 4 : (S > 64 ? 3 : (S > 32 ? 2 : 1));
-  const dim3 grid((N + 127) / 128, (S + 32 * MT - 1) / (32 * MT));
+  // wave tile (32 MT) x (32 NT): as large as the problem allows while still giving the chip >= 512 waves
+  int MT = S > 96 ? 4 : (S > 64 ? 3 : (S > 32 ? 2 : 1)), NT = 2;
+  auto waves = [&](int mt, int nt) { return (long long)((S + 32 * mt - 1) / (32 * mt)) * ((N + 32 * nt - 1) / (32 * nt)); };
+  if (waves(MT, NT) < 512) NT = 1;
+  while (MT > 1 && waves(MT, NT) < 512) MT = MT == 3 ? 2 : MT / 2;
+  const dim3 grid((N + 128 * NT - 1) / (128 * NT), (S + 32 * MT - 1) / (32 * MT));
   const double flops = 2.0 * S * (double)N * K;
-#define LAUNCH_GEMM(DT, M) BZ_LAUNCH("gemm_nt_mfma", flops, (k_gemm_nt<DT, M>), grid, dim3(256), 0, s, (const unsigned short*)x16, (const unsigned short*)w, bias, S, N, K, act, y)
-#define LAUNCH_GEMM_M(DT) do { if (MT == 4) LAUNCH_GEMM(DT, 4); else if (MT == 3) LAUNCH_GEMM(DT, 3); else if (MT == 2) LAUNCH_GEMM(DT, 2); else LAUNCH_GEMM(DT, 1); } while (0)
+#define LAUNCH_GEMM(DT, M, NN) BZ_LAUNCH("gemm_nt_mfma", flops, (k_gemm_nt<DT, M, NN>), grid, dim3(256), 0, s, (const unsigned short*)x16, (const unsigned short*)w, bias, S, N, K, act, y)
+#define LAUNCH_GEMM_N(DT, M) do { if (NT == 2) LAUNCH_GEMM(DT, M, 2); else LAUNCH_GEMM(DT, M, 1); } while (0)
+#define LAUNCH_GEMM_M(DT) do { if (MT == 4) LAUNCH_GEMM_N(DT, 4); else if (MT == 3) LAUNCH_GEMM_N(DT, 3); else if (MT == 2) LAUNCH_GEMM_N(DT, 2); else LAUNCH_GEMM_N(DT, 1); } while (0)
   if (dt == BZ_F16) LAUNCH_GEMM_M(BZ_F16); else LAUNCH_GEMM_M(BZ_BF16);
 #undef LAUNCH_GEMM_M
+#undef LAUNCH_GEMM_N
 #undef LAUNCH_GEMM
   BZ_HIP(hipGetLastError());
   return BZ_OK;
@@ -271,12 +364,25 @@ int bzk_pf_rope_kv(hipStream_t s, float* qkv, int S, int nq, int nkv, int hd, co
   BZ_HIP(hipGetLastError());
   return BZ_OK;
 }
+size_t bzk_pf_attn_smem(int nq, int nkv, int hd, int len) {
+  const int REP = nq / nkv, RPP = 256 / (hd / 8);
+  return (size_t)(8 * REP + RPP * REP * hd + REP * len) * 4 + 64;
+}
 int bzk_pf_attn(hipStream_t s, int dt, const float* qkv, int S, int nq, int nkv, int hd, int pos0, int act, const KvView& kv, int layer, void* out16) {
-  const size_t smem = (size_t)(hd * 5 + 8 + pos0 + S) * 4 + 64;
-  if (smem > 64 * 1024) BZ_FAIL(BZ_E_UNSUPPORTED, "prefill attention: context %d too long for this kernel", pos0 + S);
+  const int REP = nq / nkv;
+  if (hd % 8 || hd > 256 || (256 % (hd / 8)) || (REP != 1 && REP != 2 && REP != 4 && REP != 8) || kv.dtype != dt)
+    BZ_FAIL(BZ_E_UNSUPPORTED, "prefill attention: head_dim %d / group size %d / cache dtype unsupported", hd, REP);
+  const size_t smem = bzk_pf_attn_smem(nq, nkv, hd, pos0 + S);
+  if (smem > 160 * 1024) BZ_FAIL(BZ_E_UNSUPPORTED, "prefill attention: context %d too long for this kernel", pos0 + S);
   const float scale = 1.0f / sqrtf((float)hd);
-  if (dt == BZ_F16) hipLaunchKernelGGL(k_pf_attn<BZ_F16>, dim3(S, nq), dim3(256), smem, s, qkv, nq, nkv, hd, pos0, act, kv, layer, scale, (unsigned short*)out16);
-  else hipLaunchKernelGGL(k_pf_attn<BZ_BF16>, dim3(S, nq), dim3(256), smem, s, qkv, nq, nkv, hd, pos0, act, kv, layer, scale, (unsigned short*)out16);
+#define LAUNCH_PFA(DT, R) do { \
+    static bool attr_done = false; \
+    if (!attr_done) { BZ_HIP(hipFuncSetAttribute((const void*)k_pf_attn<DT, DT, R>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_done = true; } \
+    hipLaunchKernelGGL((k_pf_attn<DT, DT, R>), dim3(S, nkv), dim3(256), smem, s, qkv, nq, nkv, hd, pos0, act, kv, layer, scale, (unsigned short*)out16); } while (0)
+#define LAUNCH_PFA_R(DT) do { if (REP == 1) LAUNCH_PFA(DT, 1); else if (REP == 2) LAUNCH_PFA(DT, 2); else if (REP == 4) LAUNCH_PFA(DT, 4); else LAUNCH_PFA(DT, 8); } while (0)
+  if (dt == BZ_F16) LAUNCH_PFA_R(BZ_F16); else LAUNCH_PFA_R(BZ_BF16);
+#undef LAUNCH_PFA_R
+#undef LAUNCH_PFA
   BZ_HIP(hipGetLastError());
   return BZ_OK;
 }
