@@ -85,3 +85,22 @@ def test_error_behaviour(pair, device):
     bad = dict(cfg, q_lora_rank=64)
     with pytest.raises(L.BlazrHipError):
         runtime.LoadedModel(device, bad)
+
+
+@pytest.mark.parametrize("over", [dict(n_shared=0), dict(first_dense=0, n_layers=2), dict(top_k=8), dict(n_experts=0, first_dense=3),
+                                  dict(kv_lora_rank=64, nope_dim=32, v_dim=128, rope_dim=16), dict(act_dtype="f16")],
+                         ids=["no-shared", "all-moe", "topk-all", "dense-only", "odd-mla-dims", "f16"])
+def test_config_variants(device, over):
+    # edges of the MoE / MLA configuration space against the oracle (prefill rows + a few decode steps)
+    model = synth.make_dsv2("tiny-dsv2", **over)
+    cfg = model["config"]
+    lm, om = runtime.LoadedModel.from_synth(device, model), orc_py.OrcDsv2(model)
+    p = synth.prompt_tokens(6, cfg["vocab"], seed=17)
+    kv, okc = lm.new_kv_cache(16), om.new_cache(16)
+    _check_logits(lm.forward_with_kv_cache(p, kv, 0, all_logits=True).to_numpy(), om.forward(p, okc, 0, all_logits=True), cfg["act_dtype"])
+    tok = 5
+    for i in range(4):
+        lo = om.forward([tok], okc, 6 + i)
+        _check_logits(lm.forward_with_kv_cache([tok], kv, 6 + i).to_numpy(), lo, cfg["act_dtype"])
+        tok = int(lo[0].argmax())
+    orc_py.lib().orc_mla_cache_free(okc)

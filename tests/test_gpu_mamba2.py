@@ -101,3 +101,20 @@ def test_llama_model_rejects_ssm_calls(device):
     lm = runtime.LoadedModel.from_synth(device, synth.make_llama("tiny-bf16"))
     with pytest.raises(L.BlazrHipError):
         runtime.LayeredSsmState(lm)
+
+
+@pytest.mark.parametrize("over", [dict(d_state=16), dict(conv_kernel=2), dict(n_groups=4, d_state=32), dict(act_dtype="f16"), dict(head_dim=32, n_heads=16)],
+                         ids=["state16", "conv2", "groups4", "f16", "headdim32"])
+def test_config_variants(device, over):
+    model = synth.make_mamba2("tiny-mamba2", **over)
+    cfg = model["config"]
+    lm, om = runtime.LoadedModel.from_synth(device, model), orc_py.OrcMamba2(model)
+    p = synth.prompt_tokens(6, cfg["vocab"], seed=19)
+    st, ost = runtime.LayeredSsmState(lm), om.new_state()
+    _check_logits(lm.forward_with_ssm_state(p, st, all_logits=True).to_numpy(), om.forward(p, ost, all_logits=True), cfg["act_dtype"])
+    tok = 7
+    for _ in range(6):
+        lo = om.forward([tok], ost)
+        _check_logits(lm.forward_with_ssm_state([tok], st).to_numpy(), lo, cfg["act_dtype"])
+        tok = int(lo[0].argmax())
+    orc_py.lib().orc_ssm_state_free(ost)
