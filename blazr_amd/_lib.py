@@ -60,6 +60,19 @@ class GenConfig(C.Structure):
                 ("reserved", C.c_int32 * 8)]
 
 
+class ModelSource(C.Structure):
+    _fields_ = [("format", C.c_int32), ("has_config", C.c_int32), ("weights_path", C.c_char * 1024), ("config_path", C.c_char * 1024)]
+
+
+class QuantInfo(C.Structure):
+    _fields_ = [("quant_method", C.c_int32), ("group_size", C.c_int32), ("torch_dtype", C.c_int32)]
+
+
+class GgufInfo(C.Structure):
+    _fields_ = [("architecture", C.c_char * 64), ("n_tensors", C.c_int32), ("version", C.c_int32), ("dominant_ggml_type", C.c_int32),
+                ("is_mla", C.c_int32), ("is_moe", C.c_int32), ("is_ssm", C.c_int32), ("file_size_bytes", C.c_uint64)]
+
+
 class KernelTime(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_int32), ("total_ms", C.c_double), ("algo_bytes", C.c_double)]
 
@@ -132,6 +145,11 @@ SYMBOLS = {
     "bz_forward_ssm": (C.c_int, [P, P, C.c_int, P, P, C.c_uint32]),
     "bz_decode_graph_capture_ssm": (C.c_int, [P, P, C.POINTER(P)]),
     "bz_tune_gemv": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    "bz_detect_model_source": (C.c_int, [C.c_char_p, C.POINTER(ModelSource)]),
+    "bz_config_from_hf_json": (C.c_int, [C.c_char_p, C.POINTER(ModelConfig), C.POINTER(QuantInfo)]),
+    "bz_config_from_gguf": (C.c_int, [C.c_char_p, C.POINTER(ModelConfig), C.POINTER(GgufInfo)]),
+    "bz_safetensors_describe": (C.c_int, [C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "bz_load_model": (C.c_int, [P, C.c_char_p, C.POINTER(P), C.POINTER(ModelConfig)]),
     "bz_prefill_matmul": (C.c_int, [P, C.c_char_p, P, C.c_int, P]),
     "bz_quant_matmul": (C.c_int, [P, C.c_char_p, P, C.c_int, P]),
     "bz_dequant": (C.c_int, [P, C.c_char_p, P]),

@@ -12,6 +12,7 @@ Names and argument meaning follow the reference so that parity tests read like t
 All compute happens in libblazr_hip.so on the GPU; numpy arrays are only the host view of inputs/outputs.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -456,6 +457,46 @@ class LoadedModel:
         out = np.empty((N, K), dtype=np.float32)
         L.check(L.lib().bz_dequant(self.h, name.encode(), _ptr(out)))
         return out
+
+
+def detect_model_source(path):
+    """loader/detect.rs:34-150 -> dict(format 'safetensors' | 'gguf', weights_path, config_path or None)"""
+    s = L.ModelSource()
+    L.check(L.lib().bz_detect_model_source(os.fsencode(path), C.byref(s)))
+    return dict(format="gguf" if s.format == 1 else "safetensors", weights_path=os.fsdecode(s.weights_path),
+                config_path=os.fsdecode(s.config_path) if s.has_config else None)
+
+
+def config_from_hf_json(text):
+    """HF config.json text -> (bz_model_config POD, dict(quant_method, group_size, torch_dtype))"""
+    c, q = L.ModelConfig(), L.QuantInfo()
+    L.check(L.lib().bz_config_from_hf_json(text.encode(), C.byref(c), C.byref(q)))
+    return c, dict(quant_method={0: None, 1: "awq", 2: "gptq"}[q.quant_method], group_size=q.group_size, torch_dtype=q.torch_dtype)
+
+
+def config_from_gguf(path):
+    c, g = L.ModelConfig(), L.GgufInfo()
+    L.check(L.lib().bz_config_from_gguf(os.fsencode(path), C.byref(c), C.byref(g)))
+    return c, dict(architecture=g.architecture.decode(), n_tensors=g.n_tensors, version=g.version, dominant_ggml_type=g.dominant_ggml_type,
+                   is_mla=bool(g.is_mla), is_moe=bool(g.is_moe), is_ssm=bool(g.is_ssm), file_size_bytes=g.file_size_bytes)
+
+
+def safetensors_describe(path):
+    import json
+    n = C.c_size_t()
+    L.check(L.lib().bz_safetensors_describe(os.fsencode(path), None, 0, C.byref(n)))
+    buf = C.create_string_buffer(n.value)
+    L.check(L.lib().bz_safetensors_describe(os.fsencode(path), buf, n.value, None))
+    return json.loads(buf.value.decode())
+
+
+def load_model(dev, path):
+    """loaders.rs load_model: checkpoint directory / .safetensors / .gguf -> finalized LoadedModel"""
+    h, c = C.c_void_p(), L.ModelConfig()
+    L.check(L.lib().bz_load_model(dev.h, os.fsencode(path), C.byref(h), C.byref(c)))
+    m = LoadedModel.__new__(LoadedModel)
+    m.dev, m.cfg, m.c, m.h, m.finalized, m._shapes = dev, {}, c, h, True, {}
+    return m
 
 
 class LayeredKvCache:

@@ -128,6 +128,24 @@ int bz_model_get_config(const bz_model* m, bz_model_config* out);
 /* bytes of weights resident in HBM after repack, and the algorithmic bytes one decoded token streams */
 int bz_model_weight_bytes(const bz_model* m, size_t* resident, size_t* per_token_stream);
 
+/* ---- checkpoint ingestion (the loader either side of LoadedModel::load) ---------------- */
+enum { BZ_FORMAT_SAFETENSORS = 0, BZ_FORMAT_GGUF = 1 };          /* loader/detect.rs:9-15 ModelFormat */
+typedef struct { int32_t format; int32_t has_config; char weights_path[1024]; char config_path[1024]; } bz_model_source;   /* detect.rs:17-26 ModelSource */
+/* detect_model_source(path) (loader/detect.rs:34-150): a .safetensors / .gguf file, or a directory (model.safetensors, pytorch_model.safetensors,
+ * model-00001-of-*.safetensors, *.gguf in that order; SafeTensors preferred over GGUF); config.json / .yaml / .yml next to the weights. */
+int bz_detect_model_source(const char* path, bz_model_source* out);
+typedef struct { int32_t quant_method; /* 0 none, 1 awq, 2 gptq */ int32_t group_size; int32_t torch_dtype; /* BZ_* or -1 */ } bz_quant_info;
+/* HuggingFaceConfig::from_json(..).to_universal() + detect_dtype_from_config (loader/safetensors/config.rs:14-70,83-95): HF config.json text ->
+ * config POD; quantization_config (detect_arch.rs:79-90,118-131,146-196) -> quant info.  AWQ / GPTQ force f16 (awq.rs:69-71). */
+int bz_config_from_hf_json(const char* json_text, bz_model_config* cfg, bz_quant_info* quant);
+typedef struct { char architecture[64]; int32_t n_tensors, version, dominant_ggml_type, is_mla, is_moe, is_ssm; uint64_t file_size_bytes; } bz_gguf_info;
+/* config_from_gguf_metadata + get_gguf_info (loader/gguf.rs:101-306,309-346): GGUF metadata -> config POD (inference dtype f32, gguf.rs:305) */
+int bz_config_from_gguf(const char* path, bz_model_config* cfg, bz_gguf_info* info);
+/* SafeTensorsLoader::{tensor_names, tensor_info, is_sharded, num_shards, total_size} (regular.rs:38-61) as one JSON document */
+int bz_safetensors_describe(const char* path, char* json_out, size_t cap, size_t* needed);
+/* loaders.rs load_model -> regular.rs:20-86 / awq.rs:40-137 / gptq.rs:40-137 / gguf.rs:20-44: detect, configure, add every tensor, finalize */
+int bz_load_model(bz_device* dev, const char* path, bz_model** out, bz_model_config* cfg_out);
+
 /* ---- inference state ---------------------------------------------------------------------------------- */
 /* LayeredKvCache::new_positional(layers,batch,kv_heads,initial_capacity,max_seq_len,head_dim,dtype,device) (executor_generate.rs:350-353) */
 int bz_kv_create(bz_device* dev, int layers, int batch, int n_kv_heads, int initial_capacity, int max_seq_len, int head_dim,

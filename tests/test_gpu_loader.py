@@ -1,0 +1,100 @@
+"""Checkpoint ingestion end to end: a synthetic checkpoint is written in the on-disk format the reference loads, read back by
+bz_load_model (detect -> config -> add tensors -> finalize), and must give bit-identical logits to the same model handed over tensor by tensor."""
+import numpy as np
+import pytest
+
+from blazr_amd import _lib as L
+from blazr_amd import runtime, synth
+import ckpt_writer as W
+
+pytestmark = pytest.mark.gpu
+
+
+def _logits(lm, prompt):
+    if lm.needs_ssm_state():
+        return lm.forward_with_ssm_state(prompt, runtime.LayeredSsmState(lm), all_logits=True).to_numpy()
+    return lm.forward_with_kv_cache(prompt, lm.new_kv_cache(16), 0, all_logits=True).to_numpy()
+
+
+def _make(preset, over):
+    if preset in synth.MAMBA_PRESETS:
+        return synth.make_mamba2(preset, **over)
+    if preset in synth.DSV2_PRESETS:
+        return synth.make_dsv2(preset, **over)
+    return synth.make_llama(preset, **over)
+
+
+@pytest.mark.parametrize("preset,over,shards", [("tiny-bf16", {}, 1), ("tiny-awq", {}, 1), ("tiny-awq", {}, 3), ("tiny-gptq", dict(act_order=True, bias=True), 1),
+                                                ("tiny-gptq", {}, 2), ("tiny-mamba2", {}, 1), ("tiny-mamba2-g2", {}, 1), ("tiny-dsv2", {}, 2), ("tiny-dsv2-f32", {}, 1)])
+def test_safetensors_checkpoint_equals_in_memory_model(device, tmp_path, preset, over, shards):
+    model = _make(preset, over)
+    W.write_hf_checkpoint(str(tmp_path), model, shards=shards)
+    loaded = runtime.load_model(device, str(tmp_path))
+    direct = runtime.LoadedModel.from_synth(device, model)
+    p = synth.prompt_tokens(7, model["config"]["vocab"], seed=23)
+    assert np.array_equal(_logits(loaded, p), _logits(direct, p))
+    assert loaded.weight_bytes() == direct.weight_bytes()
+
+
+def test_bf16_tensors_of_an_awq_checkpoint_are_cast_to_f16(device, tmp_path):
+    # awq.rs:93-103: embeddings / norms stored as BF16 are cast to F16 at load
+    model = synth.make_llama("tiny-awq")
+    t = W.hf_tensors(model)
+    for name in ("model.embed_tokens.weight", "model.norm.weight", "lm_head.weight"):
+        f = np.asarray(t[name], dtype=np.float32)
+        t[name] = (synth.f32_to_bf16_bits(f))
+    import json, os
+    W.write_safetensors(str(tmp_path / "model.safetensors"), t)
+    json.dump(W.hf_config(model["config"]), open(tmp_path / "config.json", "w"))
+    loaded = runtime.load_model(device, str(tmp_path))
+    m2 = dict(model)
+    r = lambda a: synth.bf16_bits_to_f32(synth.f32_to_bf16_bits(np.asarray(a, np.float32))).astype(np.float16)
+    m2["embed"] = r(model["embed"])
+    m2["final_norm"] = r(model["final_norm"]).astype(np.float32)
+    m2["lm_head"] = dict(model["lm_head"], weight=r(model["lm_head"]["weight"]))
+    direct = runtime.LoadedModel.from_synth(device, m2)
+    p = synth.prompt_tokens(5, 1024, seed=2)
+    assert np.array_equal(_logits(loaded, p), _logits(direct, p))
+
+
+def test_checkpoint_without_config_json_is_detected_from_tensor_shapes(device, tmp_path):
+    # detect_arch.rs:13-63: hidden / vocab from embed_tokens, inter from gate_proj, heads = rows / 128 (default head_dim), defaults for the rest
+    model = synth.make_llama("tiny-awq", hidden=256, n_heads=2, n_kv_heads=1, head_dim=128, rope_theta=10000.0, rms_eps=1e-5, max_seq_len=4096)
+    W.write_hf_checkpoint(str(tmp_path), model, with_config=False)
+    loaded = runtime.load_model(device, str(tmp_path / "model.safetensors"))
+    assert (loaded.c.n_heads, loaded.c.n_kv_heads, loaded.c.head_dim, loaded.c.inter, loaded.c.n_layers, loaded.c.act_dtype) == (2, 1, 128, 512, 2, L.F16)
+    direct = runtime.LoadedModel.from_synth(device, model)
+    p = synth.prompt_tokens(6, 1024, seed=4)
+    assert np.array_equal(_logits(loaded, p), _logits(direct, p))
+
+
+@pytest.mark.parametrize("preset", ["tiny-q4km", "tiny-q8_0"])
+def test_gguf_checkpoint_equals_in_memory_model(device, tmp_path, preset):
+    model = synth.make_llama(preset)
+    path = str(tmp_path / "model.gguf")
+    W.write_gguf(path, model)
+    loaded = runtime.load_model(device, path)
+    direct = runtime.LoadedModel.from_synth(device, model)
+    p = synth.prompt_tokens(7, model["config"]["vocab"], seed=29)
+    assert np.array_equal(_logits(loaded, p), _logits(direct, p))
+    # and greedy generation straight from the file
+    assert runtime.Executor(loaded).generate(p, 8).tolist() == runtime.Executor(direct).generate(p, 8).tolist()
+
+
+def test_loader_errors(device, tmp_path):
+    model = synth.make_llama("tiny-awq")
+    t = W.hf_tensors(model)
+    del t["model.layers.1.mlp.down_proj.scales"]                         # incomplete triplet
+    W.write_safetensors(str(tmp_path / "model.safetensors"), t)
+    import json
+    json.dump(W.hf_config(model["config"]), open(tmp_path / "config.json", "w"))
+    with pytest.raises(L.BlazrHipError):
+        runtime.load_model(device, str(tmp_path))
+    t = W.hf_tensors(model)
+    t["model.layers.0.self_attn.rotary_emb.inv_freq"] = np.zeros(32, np.float32)     # legacy tensor: skipped
+    t["model.layers.0.unknown.weight"] = np.zeros((4, 4), np.float32)                # unknown tensor: loud
+    W.write_safetensors(str(tmp_path / "model.safetensors"), t)
+    with pytest.raises(L.BlazrHipError):
+        runtime.load_model(device, str(tmp_path))
+    with pytest.raises(L.BlazrHipError):
+        runtime.load_model(device, str(tmp_path / "missing"))
