@@ -64,6 +64,10 @@ class ModelSource(C.Structure):
     _fields_ = [("format", C.c_int32), ("has_config", C.c_int32), ("weights_path", C.c_char * 1024), ("config_path", C.c_char * 1024)]
 
 
+class DetectedArch(C.Structure):
+    _fields_ = [("format", C.c_int32), ("num_layers", C.c_int32), ("tie_word_embeddings", C.c_int32), ("layer_types", C.c_uint8 * 512)]
+
+
 class QuantInfo(C.Structure):
     _fields_ = [("quant_method", C.c_int32), ("group_size", C.c_int32), ("torch_dtype", C.c_int32)]
 
@@ -146,6 +150,7 @@ SYMBOLS = {
     "bz_decode_graph_capture_ssm": (C.c_int, [P, P, C.POINTER(P)]),
     "bz_tune_gemv": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "bz_detect_model_source": (C.c_int, [C.c_char_p, C.POINTER(ModelSource)]),
+    "bz_detect_architecture_from_names": (C.c_int, [C.POINTER(C.c_char_p), C.c_int, C.POINTER(DetectedArch)]),
     "bz_config_from_hf_json": (C.c_int, [C.c_char_p, C.POINTER(ModelConfig), C.POINTER(QuantInfo)]),
     "bz_config_from_gguf": (C.c_int, [C.c_char_p, C.POINTER(ModelConfig), C.POINTER(GgufInfo)]),
     "bz_safetensors_describe": (C.c_int, [C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),

@@ -344,16 +344,50 @@ void detect_quant(const std::string& dir, const StLoader& st, QuantInfo* q) {
   if (has_gidx) q->method = 2; else if (has_qw) q->method = 1;    // regular.rs:42-49: GPTQ is probed first
 }
 
+// boostr::model::detection::detect_architecture_from_names, as pinned by the reference's tests (loader/safetensors/detect_arch.rs:200-315):
+// format from the "model." prefix, layer count from the highest "layers.N." index, tied embeddings when lm_head.weight is absent, per-layer type
+// from the tensor names of that layer (mamba mixer tensors -> Mamba2; MLA latent projections -> MlaWithMoe / MlaWithMlp; else StandardTransformer).
+int detect_from_names(const std::vector<std::string>& names, bz_detected_arch* out) {
+  memset(out, 0, sizeof(*out));
+  bool hf = false, lm_head = false;
+  int layers = 0;
+  for (auto& n : names) {
+    if (n.compare(0, 6, "model.") == 0 || n.compare(0, 9, "backbone.") == 0) hf = true;
+    if (n == "lm_head.weight" || n == "lm_head.qweight") lm_head = true;
+    size_t p = n.find("layers.");
+    if (p != std::string::npos && isdigit((unsigned char)n[p + 7])) layers = std::max(layers, atoi(n.c_str() + p + 7) + 1);
+  }
+  if (layers == 0) BZ_FAIL(BZ_E_INVALID, "no transformer / mamba layers found in the tensor names");
+  out->format = hf ? 0 : 1;
+  out->num_layers = layers;
+  out->tie_word_embeddings = lm_head ? 0 : 1;
+  for (int l = 0; l < layers && l < 512; l++) {
+    const std::string key = "layers." + std::to_string(l) + ".";
+    bool mamba = false, mamba3 = false, mla = false, moe = false;
+    for (auto& n : names) {
+      size_t p = n.find(key);
+      if (p == std::string::npos) continue;
+      const std::string rest = n.substr(p + key.size());
+      if (rest.find("mamba3") != std::string::npos) mamba3 = true;
+      if (rest.find("mixer.") != std::string::npos || rest.find("mamba2") != std::string::npos || rest.find("A_log") != std::string::npos) mamba = true;
+      if (rest.find("w_dkv") != std::string::npos || rest.find("kv_a_proj") != std::string::npos || rest.find("kv_b_proj") != std::string::npos) mla = true;
+      if (rest.find("experts.") != std::string::npos || rest.find("moe.") != std::string::npos) moe = true;
+    }
+    out->layer_types[l] = mamba3 ? BZ_LAYER_MAMBA3 : mamba ? BZ_LAYER_MAMBA2 : (mla ? (moe ? BZ_LAYER_MLA_MOE : BZ_LAYER_MLA_MLP) : BZ_LAYER_TRANSFORMER);
+  }
+  return BZ_OK;
+}
+
 // detect_arch.rs:13-63 (+ boostr's name scan for the layer count / tied embeddings): used when no config.json is present
 int detect_from_tensors(const StLoader& st, bz_model_config* c) {
   config_defaults(c);
-  int layers = 0;
-  for (auto& kv : st.tensors) {
-    const std::string& n = kv.first;
-    size_t p = n.find("layers.");
-    if (p != std::string::npos) layers = std::max(layers, atoi(n.c_str() + p + 7) + 1);
-  }
-  c->n_layers = layers;
+  std::vector<std::string> names;
+  for (auto& kv : st.tensors) names.push_back(kv.first);
+  bz_detected_arch da;
+  BZ_TRY(detect_from_names(names, &da));
+  for (int l = 0; l < da.num_layers && l < 512; l++)
+    if (da.layer_types[l] != BZ_LAYER_TRANSFORMER) BZ_FAIL(BZ_E_UNSUPPORTED, "layer %d is not a standard transformer layer: a config.json is required for this architecture", l);
+  c->n_layers = da.num_layers;
   auto rows_of = [&](const std::string& base, int64_t* rows) {
     if (const StTensor* t = st.find(base + ".weight")) { if (t->shape.size() == 2) { *rows = t->shape[0]; return true; } }
     if (const StTensor* t = st.find(base + ".qweight")) {
@@ -646,6 +680,13 @@ extern "C" int bz_detect_model_source(const char* path_c, bz_model_source* out) 
   std::vector<std::string> ggufs = glob_list(path + "/*.gguf");                          // detect.rs:93-99
   if (!ggufs.empty()) { out->format = BZ_FORMAT_GGUF; return copy_path(out->weights_path, sizeof out->weights_path, ggufs[0]); }
   BZ_FAIL(BZ_E_NOTFOUND, "No supported model files found in directory: %s", path.c_str());
+}
+
+extern "C" int bz_detect_architecture_from_names(const char* const* names, int n, bz_detected_arch* out) {
+  if (!names || n < 0 || !out) BZ_FAIL(BZ_E_INVALID, "detect_architecture_from_names: null argument");
+  std::vector<std::string> v;
+  for (int i = 0; i < n; i++) v.push_back(names[i] ? names[i] : "");
+  return detect_from_names(v, out);
 }
 
 extern "C" int bz_config_from_hf_json(const char* json_text, bz_model_config* cfg, bz_quant_info* qinfo) {

@@ -467,6 +467,18 @@ def detect_model_source(path):
                 config_path=os.fsdecode(s.config_path) if s.has_config else None)
 
 
+LAYER_TYPES = ["StandardTransformer", "Mamba2", "Mamba3", "MlaWithMoe", "MlaWithMlp"]
+
+
+def detect_architecture_from_names(names):
+    """boostr::model::detection::detect_architecture_from_names (tests: loader/safetensors/detect_arch.rs:200-315)"""
+    arr = (C.c_char_p * len(names))(*[n.encode() for n in names])
+    d = L.DetectedArch()
+    L.check(L.lib().bz_detect_architecture_from_names(arr, len(names), C.byref(d)))
+    return dict(format="HuggingFace" if d.format == 0 else "Oxidizr", num_layers=d.num_layers, tie_word_embeddings=bool(d.tie_word_embeddings),
+                layer_types=[LAYER_TYPES[d.layer_types[i]] for i in range(d.num_layers)])
+
+
 def config_from_hf_json(text):
     """HF config.json text -> (bz_model_config POD, dict(quant_method, group_size, torch_dtype))"""
     c, q = L.ModelConfig(), L.QuantInfo()

@@ -134,6 +134,10 @@ typedef struct { int32_t format; int32_t has_config; char weights_path[1024]; ch
 /* detect_model_source(path) (loader/detect.rs:34-150): a .safetensors / .gguf file, or a directory (model.safetensors, pytorch_model.safetensors,
  * model-00001-of-*.safetensors, *.gguf in that order; SafeTensors preferred over GGUF); config.json / .yaml / .yml next to the weights. */
 int bz_detect_model_source(const char* path, bz_model_source* out);
+enum { BZ_LAYER_TRANSFORMER = 0, BZ_LAYER_MAMBA2 = 1, BZ_LAYER_MAMBA3 = 2, BZ_LAYER_MLA_MOE = 3, BZ_LAYER_MLA_MLP = 4 };   /* detection::LayerType */
+typedef struct { int32_t format; /* 0 HuggingFace ("model." prefix), 1 Oxidizr */ int32_t num_layers, tie_word_embeddings; uint8_t layer_types[512]; } bz_detected_arch;
+/* boostr::model::detection::detect_architecture_from_names as the reference's tests pin it (loader/safetensors/detect_arch.rs:200-315) */
+int bz_detect_architecture_from_names(const char* const* names, int n, bz_detected_arch* out);
 typedef struct { int32_t quant_method; /* 0 none, 1 awq, 2 gptq */ int32_t group_size; int32_t torch_dtype; /* BZ_* or -1 */ } bz_quant_info;
 /* HuggingFaceConfig::from_json(..).to_universal() + detect_dtype_from_config (loader/safetensors/config.rs:14-70,83-95): HF config.json text ->
  * config POD; quantization_config (detect_arch.rs:79-90,118-131,146-196) -> quant info.  AWQ / GPTQ force f16 (awq.rs:69-71). */

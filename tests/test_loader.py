@@ -81,6 +81,59 @@ def test_detect_sharded_directory(tmp_path):                      # detect.rs:80
     assert s["format"] == "safetensors" and s["weights_path"].endswith("model-00001-of-00002.safetensors")
 
 
+# ---- loader/safetensors/detect_arch.rs:200-315 (7 tests of detect_architecture_from_names) -------------------------------------------------
+def _hf_transformer_names(n):
+    names = ["model.embed_tokens.weight", "model.norm.weight", "lm_head.weight"]
+    for i in range(n):
+        p = "model.layers.%d." % i
+        names += [p + s for s in ("self_attn.q_proj.weight", "self_attn.k_proj.weight", "self_attn.v_proj.weight", "self_attn.o_proj.weight", "mlp.gate_proj.weight",
+                                  "mlp.up_proj.weight", "mlp.down_proj.weight", "input_layernorm.weight", "post_attention_layernorm.weight")]
+    return names
+
+
+def _hf_mla_moe_names(n):
+    names = ["model.embed_tokens.weight", "model.norm.weight", "lm_head.weight"]
+    for i in range(n):
+        p = "model.layers.%d." % i
+        names += [p + s for s in ("self_attn.w_dkv.weight", "self_attn.w_q.weight", "self_attn.w_o.weight", "moe.gate.weight", "moe.experts.0.up_proj.weight",
+                                  "moe.experts.0.down_proj.weight", "input_layernorm.weight")]
+    return names
+
+
+def test_hf_llama_32_layers():
+    c = runtime.detect_architecture_from_names(_hf_transformer_names(32))
+    assert c["format"] == "HuggingFace" and c["num_layers"] == 32 and not c["tie_word_embeddings"]
+    assert all(t == "StandardTransformer" for t in c["layer_types"])
+
+
+def test_hf_small_model_2_layers():
+    c = runtime.detect_architecture_from_names(_hf_transformer_names(2))
+    assert c["num_layers"] == 2 and c["format"] == "HuggingFace"
+
+
+def test_hf_tied_embeddings():
+    names = [n for n in _hf_transformer_names(4) if n != "lm_head.weight"]
+    assert runtime.detect_architecture_from_names(names)["tie_word_embeddings"]
+
+
+def test_hf_deepseek_mla_moe():
+    c = runtime.detect_architecture_from_names(_hf_mla_moe_names(8))
+    assert c["format"] == "HuggingFace" and c["num_layers"] == 8 and all(t == "MlaWithMoe" for t in c["layer_types"])
+
+
+def test_hf_hybrid_transformer_and_mamba():
+    names = ["model.embed_tokens.weight", "model.norm.weight", "lm_head.weight"]
+    names += ["model.layers.0." + s for s in ("self_attn.q_proj.weight", "self_attn.k_proj.weight", "mlp.gate_proj.weight")]
+    names += ["model.layers.1." + s for s in ("mamba2.mixer.A_log", "mamba2.mixer.conv1d.weight")]
+    c = runtime.detect_architecture_from_names(names)
+    assert c["num_layers"] == 2 and c["layer_types"] == ["StandardTransformer", "Mamba2"]
+
+
+def test_hf_no_layers_errors():
+    with pytest.raises(L.BlazrHipError):
+        runtime.detect_architecture_from_names(["model.embed_tokens.weight", "model.norm.weight"])
+
+
 # ---- loader/safetensors/config.rs:247-276 -------------------------------------------------------------------------------------------------
 def test_huggingface_config_rope_scaling():
     text = '''{
