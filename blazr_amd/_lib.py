@@ -23,7 +23,7 @@ atexit.register(_at_exit)
 
 OK, E_INVALID, E_NODEVICE, E_HIP, E_UNSUPPORTED, E_NOTFOUND, E_OOM = 0, -1, -2, -3, -4, -5, -6
 F32, F16, BF16, I64, I32, U32, U8 = range(7)
-ABI_VERSION = 2
+ABI_VERSION = 3
 FWD_ALL_LOGITS = 1
 ROPE_NONE, ROPE_LINEAR, ROPE_LLAMA3 = 0, 1, 2
 ARCH_LLAMA = 0
@@ -57,7 +57,10 @@ class GenConfig(C.Structure):
                 ("repeat_last_n", C.c_int32), ("frequency_penalty", C.c_float), ("presence_penalty", C.c_float),
                 ("top_k", C.c_int32), ("top_p", C.c_float), ("min_p", C.c_float), ("seed", C.c_uint64),
                 ("eos_id", C.c_int64), ("use_graph", C.c_int32), ("paged", C.c_int32), ("block_size", C.c_int32),
-                ("reserved", C.c_int32 * 8)]
+                ("dry_multiplier", C.c_float), ("dry_base", C.c_int32), ("dry_allowed_length", C.c_int32), ("typical_p", C.c_float),
+                ("dynatemp_range", C.c_float), ("dynatemp_exponent", C.c_float), ("mirostat_mode", C.c_int32), ("mirostat_tau", C.c_float),
+                ("mirostat_eta", C.c_float), ("n_logit_bias", C.c_int32), ("logit_bias_ids", C.c_void_p), ("logit_bias_vals", C.c_void_p),
+                ("reserved", C.c_int32 * 4)]
 
 
 class ModelSource(C.Structure):
@@ -149,6 +152,15 @@ SYMBOLS = {
     "bz_forward_ssm": (C.c_int, [P, P, C.c_int, P, P, C.c_uint32]),
     "bz_decode_graph_capture_ssm": (C.c_int, [P, P, C.POINTER(P)]),
     "bz_tune_gemv": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    "bz_compute_dynamic_temperature": (C.c_float, [P, C.c_int64, C.c_float, C.c_float, C.c_float]),
+    "bz_apply_dry_penalty": (C.c_int, [P, C.c_int64, P, C.c_int64, C.c_float, C.c_int, C.c_int]),
+    "bz_apply_typical_filter": (C.c_int, [P, C.c_int64, C.c_float]),
+    "bz_apply_logit_bias": (C.c_int, [P, C.c_int64, P, P, C.c_int]),
+    "bz_compute_logprobs": (C.c_int, [P, C.c_int64, C.c_uint32, C.c_int, C.POINTER(C.c_float), P, P, C.POINTER(C.c_int)]),
+    "bz_mirostat_create": (C.c_int, [C.c_float, C.c_float, C.c_uint64, C.POINTER(P)]),
+    "bz_mirostat_sample": (C.c_int, [P, P, C.c_int64, C.c_float, C.POINTER(C.c_uint32), C.POINTER(C.c_float)]),
+    "bz_mirostat_mu": (C.c_float, [P]),
+    "bz_mirostat_free": (C.c_int, [P]),
     "bz_detect_model_source": (C.c_int, [C.c_char_p, C.POINTER(ModelSource)]),
     "bz_detect_architecture_from_names": (C.c_int, [C.POINTER(C.c_char_p), C.c_int, C.POINTER(DetectedArch)]),
     "bz_config_from_hf_json": (C.c_int, [C.c_char_p, C.POINTER(ModelConfig), C.POINTER(QuantInfo)]),

@@ -2054,10 +2054,13 @@ extern "C" int bz_generate(bz_model* m, const int64_t* prompt, int n_prompt, con
   int max_tokens = std::min(gc->max_tokens, std::max(0, c.max_seq_len - n_prompt));  // :79-82
   const bool greedy = gc->temperature == 0.0f;
   if (gc->use_graph && !greedy) BZ_FAIL(BZ_E_INVALID, "generate: graph mode is greedy-only (cli/run.rs:144-157)");
+  if (gc->use_graph && (gc->dry_multiplier > 0.f || gc->typical_p > 0.f || gc->n_logit_bias > 0 || gc->mirostat_mode >= 2))
+    BZ_FAIL(BZ_E_INVALID, "generate: graph mode has no host-side sampler options");
+  if (gc->n_logit_bias < 0 || (gc->n_logit_bias > 0 && (!gc->logit_bias_ids || !gc->logit_bias_vals))) BZ_FAIL(BZ_E_INVALID, "generate: bad logit_bias arrays");
   const int kv_dt = c.act_dtype;
   int rc = BZ_OK;
   bz_tensor *t_prompt = nullptr, *t_logits = nullptr, *t_tok = nullptr, *t_ids = nullptr, *t_cnts = nullptr, *t_slot = nullptr, *t_bt = nullptr;
-  bz_kv* kv = nullptr; bz_paged_kv* pkv = nullptr; bz_decode_graph* graph = nullptr; bz_ssm_state* ssm = nullptr;
+  bz_kv* kv = nullptr; bz_paged_kv* pkv = nullptr; bz_decode_graph* graph = nullptr; bz_ssm_state* ssm = nullptr; bz_mirostat* mstate = nullptr;
   const bool mamba = c.arch == BZ_ARCH_MAMBA2;   // executor_generate.rs:123-181
   std::vector<uint32_t> history(prompt, prompt + n_prompt);
   std::vector<int32_t> bt;
@@ -2118,12 +2121,34 @@ extern "C" int bz_generate(bz_model* m, const int64_t* prompt, int n_prompt, con
   } else {
     std::vector<int64_t> ids; std::vector<int32_t> cnts;
     const bool has_pen = gc->repeat_penalty != 1.0f || gc->frequency_penalty != 0.f || gc->presence_penalty != 0.f;
+    // host-side options (sampling.rs:393-437): the reference pulls the logits to the CPU for these, and so does this loop
+    const bool needs_cpu = gc->dry_multiplier > 0.f || gc->typical_p > 0.f;
+    const bool dyn = !greedy && gc->dynatemp_range > 0.f, miro = gc->mirostat_mode >= 2;
+    const bool host_row = needs_cpu || gc->n_logit_bias > 0 || dyn || miro;
+    std::vector<float> row(host_row ? (size_t)c.vocab : 0);
     for (int i = 0; i < max_tokens; i++) {
+      float temperature = greedy ? 0.0f : gc->temperature;
+      if (host_row) {
+        GEN_TRY(bz_tensor_to_host(t_logits, row.data(), (size_t)c.vocab * 4));
+        if (gc->dry_multiplier > 0.f) GEN_TRY(bz_apply_dry_penalty(row.data(), c.vocab, history.data(), (int64_t)history.size(), gc->dry_multiplier, gc->dry_base > 0 ? gc->dry_base : 2, gc->dry_allowed_length));
+        if (gc->typical_p > 0.f) GEN_TRY(bz_apply_typical_filter(row.data(), c.vocab, gc->typical_p));
+        if (!miro && gc->n_logit_bias > 0) GEN_TRY(bz_apply_logit_bias(row.data(), c.vocab, gc->logit_bias_ids, gc->logit_bias_vals, gc->n_logit_bias));
+        if (!miro && dyn) temperature = bz_compute_dynamic_temperature(row.data(), c.vocab, gc->temperature, gc->dynatemp_range, gc->dynatemp_exponent > 0.f ? gc->dynatemp_exponent : 1.0f);
+        if (!miro) GEN_TRY(bz_tensor_copy_from_host(t_logits, row.data(), (size_t)c.vocab * 4));
+      }
+      if (miro) {       // sampling.rs:96-110,118-150: Mirostat v2 on the CPU row, token goes back to the device
+        if (!mstate) GEN_TRY(bz_mirostat_create(gc->mirostat_tau, gc->mirostat_eta, gc->seed, &mstate));
+        uint32_t mt = 0;
+        GEN_TRY(bz_mirostat_sample(mstate, row.data(), c.vocab, gc->temperature, &mt, nullptr));
+        const int64_t mt64 = mt;
+        GEN_TRY(bz_tensor_copy_from_host(t_tok, &mt64, 8));
+      } else {
       int n = has_pen ? penalty_window(history, gc->repeat_last_n, ids, cnts) : 0;  // sampling.rs:431
       if (n > 4096) { n = 4096; }
       if (n) { GEN_TRY(bz_tensor_copy_from_host(t_ids, ids.data(), (size_t)n * 8)); GEN_TRY(bz_tensor_copy_from_host(t_cnts, cnts.data(), (size_t)n * 4)); }
       GEN_TRY(bz_logits_to_token(dev, t_logits, 1, c.vocab, t_ids, t_cnts, n, gc->repeat_penalty, gc->frequency_penalty, gc->presence_penalty,
-                                 greedy ? 0.0f : gc->temperature, gc->top_k, gc->top_p, gc->min_p, gc->seed + (uint64_t)i, t_tok));
+                                 temperature, gc->top_k, gc->top_p, gc->min_p, gc->seed + (uint64_t)i, t_tok));
+      }
       uint64_t ev;
       GEN_TRY(bz_event_record(dev, &ev));                                           // :367 record_event
       const bool last = i + 1 == max_tokens;
@@ -2160,7 +2185,7 @@ done:
   bz_decode_graph_free(graph);
   bz_tensor_free(t_prompt); bz_tensor_free(t_logits); bz_tensor_free(t_tok); bz_tensor_free(t_ids); bz_tensor_free(t_cnts);
   bz_tensor_free(t_slot); bz_tensor_free(t_bt);
-  bz_kv_free(kv); bz_paged_kv_free(pkv); bz_ssm_state_free(ssm);
+  bz_kv_free(kv); bz_paged_kv_free(pkv); bz_ssm_state_free(ssm); bz_mirostat_free(mstate);
   return rc;
 #undef GEN_TRY
 }

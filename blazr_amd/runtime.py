@@ -670,12 +670,21 @@ class Executor:
         self.model = model
 
     def generate(self, prompt_tokens, max_tokens, temperature=0.0, repeat_penalty=1.0, repeat_last_n=64, frequency_penalty=0.0,
-                 presence_penalty=0.0, eos_id=-1, use_graph=False, paged=False, block_size=16, seed=0, top_k=0, top_p=1.0, min_p=0.0):
+                 presence_penalty=0.0, eos_id=-1, use_graph=False, paged=False, block_size=16, seed=0, top_k=0, top_p=1.0, min_p=0.0,
+                 dry_multiplier=0.0, dry_base=2, dry_allowed_length=0, typical_p=0.0, dynatemp_range=0.0, dynatemp_exponent=1.0, mirostat_mode=0,
+                 mirostat_tau=5.0, mirostat_eta=0.1, logit_bias=None):
         g = L.GenConfig()
         g.max_tokens, g.temperature, g.repeat_penalty, g.repeat_last_n = max_tokens, temperature, repeat_penalty, repeat_last_n
         g.frequency_penalty, g.presence_penalty = frequency_penalty, presence_penalty
         g.top_k, g.top_p, g.min_p, g.seed = top_k, top_p, min_p, seed
         g.eos_id, g.use_graph, g.paged, g.block_size = eos_id, int(use_graph), int(paged), block_size
+        g.dry_multiplier, g.dry_base, g.dry_allowed_length, g.typical_p = dry_multiplier, dry_base, dry_allowed_length, typical_p
+        g.dynatemp_range, g.dynatemp_exponent = dynatemp_range, dynatemp_exponent
+        g.mirostat_mode, g.mirostat_tau, g.mirostat_eta = mirostat_mode, mirostat_tau, mirostat_eta
+        if logit_bias:
+            b_ids = np.asarray(list(logit_bias.keys()), dtype=np.uint32)
+            b_vals = np.asarray(list(logit_bias.values()), dtype=np.float32)
+            g.n_logit_bias, g.logit_bias_ids, g.logit_bias_vals = len(b_ids), b_ids.ctypes.data, b_vals.ctypes.data
         p = np.ascontiguousarray(prompt_tokens, dtype=np.int64)
         out = np.zeros(max(max_tokens, 1), dtype=np.int64)
         st = L.GenStats()

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define BZ_ABI_VERSION 2
+#define BZ_ABI_VERSION 3
 
 enum {
   BZ_OK = 0,
@@ -232,9 +232,31 @@ typedef struct {
   int32_t use_graph;         /* --graphs (cli/run.rs:144-157): greedy only, penalties ignored as in the reference */
   int32_t paged;             /* --paged-attention */
   int32_t block_size;        /* 16 (inference.rs:189-191) */
-  int32_t reserved[8];
+  /* host-side sampler options (config/generation.rs:190-222; applied as sampling.rs:393-437 does: DRY, typical, logit bias, dynatemp, mirostat) */
+  float   dry_multiplier;    /* 0 disables */
+  int32_t dry_base;          /* default 2 */
+  int32_t dry_allowed_length;
+  float   typical_p;         /* 0 disables */
+  float   dynatemp_range;    /* 0 disables */
+  float   dynatemp_exponent; /* default 1.0 */
+  int32_t mirostat_mode;     /* >= 2: Mirostat v2 replaces logits_to_token (sampling.rs:96-110) */
+  float   mirostat_tau, mirostat_eta;
+  int32_t n_logit_bias; const uint32_t* logit_bias_ids; const float* logit_bias_vals;
+  int32_t reserved[4];
 } bz_gen_config;
 typedef struct { double prefill_ms, decode_ms; int32_t n_generated; int32_t finish_reason; /* 0 length, 1 eos */ } bz_gen_stats;
+/* ---- host-side sampler pieces, each a line-for-line restatement of the reference's Rust (they run on the CPU there too) ---------------- */
+float bz_compute_dynamic_temperature(const float* logits, int64_t vocab, float base, float range, float exponent);      /* sampling.rs:41-86 */
+int bz_apply_dry_penalty(float* logits, int64_t vocab, const uint32_t* recent, int64_t n_recent, float multiplier, int base, int allowed_length);   /* :270-320 */
+int bz_apply_typical_filter(float* logits, int64_t vocab, float typical_p);                                              /* :322-369 */
+int bz_apply_logit_bias(float* logits, int64_t vocab, const uint32_t* ids, const float* bias, int n);                   /* :464-480 */
+int bz_compute_logprobs(const float* logits, int64_t vocab, uint32_t chosen, int top_n, float* chosen_logprob, uint32_t* top_ids, float* top_logprobs,
+                        int* n_top);                                                                                     /* :197-256 */
+typedef struct bz_mirostat bz_mirostat;                                                                                  /* mirostat.rs:12-17 MirostatState */
+int bz_mirostat_create(float tau, float eta, uint64_t seed, bz_mirostat** out);                                          /* mirostat.rs:19-34 */
+int bz_mirostat_sample(bz_mirostat* s, const float* logits, int64_t vocab, float temperature, uint32_t* token, float* logprob);   /* :41-110 */
+float bz_mirostat_mu(const bz_mirostat* s);
+int bz_mirostat_free(bz_mirostat* s);
 /* prompt: host i64[n_prompt]; out_tokens: host i64[max_tokens] */
 int bz_generate(bz_model* m, const int64_t* prompt, int n_prompt, const bz_gen_config* gc, int64_t* out_tokens, bz_gen_stats* stats);
 

@@ -279,3 +279,23 @@ def test_batched_prefill_full_width_1b_shape(device):
     want = om.forward_kv(p, okv, 0, all_logits=True)
     _check_logits(got, want, cfg["act_dtype"], factor=1.0)
     orc_py.lib().orc_kv_free(okv)
+
+
+def test_generate_with_host_side_sampler_options(device):
+    # sampling.rs:393-437: DRY / typical / logit bias / dynatemp / mirostat run on a host copy of the logits row, as in the reference
+    lm = runtime.LoadedModel.from_synth(device, synth.make_llama("tiny-awq"))
+    ex = runtime.Executor(lm)
+    p = synth.prompt_tokens(8, 1024, seed=2)
+    assert ex.generate(p, 6, logit_bias={3: 1000.0}).tolist() == [3] * 6                        # a huge bias decides greedy decoding
+    plain = ex.generate(p, 12).tolist()
+    banned = ex.generate(p, 12, logit_bias={plain[0]: -1000.0}).tolist()
+    assert banned[0] != plain[0]
+    # the tiny model repeats itself; DRY must break the loop that plain greedy decoding falls into
+    rep = ex.generate(p, 24).tolist()
+    dry = ex.generate(p, 24, dry_multiplier=5.0, dry_base=2).tolist()
+    assert dry != rep and len(dry) == 24
+    for kw in (dict(temperature=0.8, typical_p=0.5), dict(temperature=0.9, dynatemp_range=0.5, dynatemp_exponent=1.5), dict(temperature=1.0, mirostat_mode=2)):
+        a, b = ex.generate(p, 10, seed=5, **kw).tolist(), ex.generate(p, 10, seed=5, **kw).tolist()
+        assert a == b and len(a) == 10, kw
+    with pytest.raises(L.BlazrHipError):
+        ex.generate(p, 4, use_graph=True, logit_bias={1: 1.0})
