@@ -1250,6 +1250,19 @@ static int llama_step(bz_model* m, const StepIO& io) {
     const LayerDev& Ld = m->layers[l];
     Pro pn{}; pn.mode = PRO_NORM; pn.src = prev; pn.h_in = m->hbuf[cur]; pn.h_out = m->hbuf[cur ^ 1]; pn.norm_w = Ld.attn_norm;
     pn.eps = c.rms_eps; pn.H = H; pn.act = act;
+    static long long* qkv_stamps = nullptr;
+    if (getenv("BZ_QKV_STAMPS")) {
+      if (!qkv_stamps) { hipMalloc(&qkv_stamps, 256); hipMemset(qkv_stamps, 0, 256); }
+      if (l == 2) {
+        long long hst[16]; hipStreamSynchronize(st); hipMemcpy(hst, qkv_stamps, 128, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[bz] qkv stamps us since block 0 entry: first block");
+        for (int q = 1; q <= 5; q++) fprintf(stderr, " %d:%.2f", q, (hst[q] - hst[0]) / 100.0);
+        fprintf(stderr, " | last block entry %.2f", (hst[8] - hst[0]) / 100.0);
+        for (int q = 1; q <= 5; q++) fprintf(stderr, " %d:%.2f", q, (hst[8 + q] - hst[0]) / 100.0);
+        fprintf(stderr, "\n");
+      }
+      pn.stamps = l == 1 ? qkv_stamps : nullptr;
+    }
     VSrc qkv;
     BZ_TRY(run_fused(m, Ld.qkv, pn, rs, &qkv));
     cur ^= 1;

@@ -728,6 +728,10 @@ __global__ __launch_bounds__(256) void k_gemv_q4g(const uint4* __restrict__ W, c
   const bool wave_on = nt * 64 < N;
   const int G = K >> 7;
   const int k0 = ks * KR, g0 = ks * GW;
+  // diagnostic build only (BZ_QKV_STAMPS): s_memrealtime (100 MHz) at phase boundaries of the first and the last block
+#define QSTAMP(i) do { if (pro.stamps && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) \
+    pro.stamps[(blockIdx.x == 0 ? 0 : 8) + (i)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+  QSTAMP(0);
 
   zero_duty(zero_buf, zero_n);
 
@@ -758,8 +762,10 @@ __global__ __launch_bounds__(256) void k_gemv_q4g(const uint4* __restrict__ W, c
     for (int c = 0; c < 4; c++) Wb[b][c] = ldnt(wp + (bc * 4 + c) * 64);
   }
 
+  QSTAMP(1);
   // (4) finish the prologue
   xfinish<MODE, FIX, MAXJ, Q4G_E>(pro, KR, xr, xs, red, blockIdx.x == 0);
+  QSTAMP(2);
   {
     unsigned* sSw = (unsigned*)(sS + wave * GW * 64);
     unsigned* sZw = (unsigned*)(sZ + wave * GW * 64);
@@ -770,6 +776,7 @@ __global__ __launch_bounds__(256) void k_gemv_q4g(const uint4* __restrict__ W, c
   }
   if (!(pro.dbg & 4)) quant_x128(xs, KR, xh, xm, xl, gpar);
   __syncthreads();
+  QSTAMP(3);
   if (!wave_on) return;
 
   // (5) stream the k-range with NPF groups (NPF * 4 KiB per wave) in flight
@@ -793,10 +800,103 @@ __global__ __launch_bounds__(256) void k_gemv_q4g(const uint4* __restrict__ W, c
       }
     }
   }
+  QSTAMP(4);
   const int n = nt * 64 + lane;
   if (bias != nullptr && ks == 0) y += bias[n];
   if (pro.dbg & 1) acc[n] = f2fix(y);
   else atomicAdd((unsigned long long*)(acc + n), (unsigned long long)f2fix(y));
+  QSTAMP(5);
+#undef QSTAMP
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// "Slim" int4 GEMV with the fused residual + RMSNorm prologue, for the q/k/v projection (N ~ 6K, K = H).
+// The stamp timeline of k_gemv_q4g on this shape (scripts/qkv_stamps.py) shows where its 12.7 us go: 3 us to reach the first
+// instruction past the load issue, 4.3 us waiting for the prologue's 48 KB per block (h + the 64-bit fixed-point sums of the
+// previous launch: 600 blocks x 48 KB = 29 MB through ~10 B/clk/CU), 1.4 us quantising, 0.6 us of dot products.  The weights
+// were never the problem.  Here a block is 512 threads = 8 waves that share one 256-k slice (so a block quantises 256 activations)
+// and take one 64-column tile each (8 KiB of weights per wave, all in flight before the prologue); grid = (K/256) x ceil(N/512):
+// 192 blocks for Llama-3-8B, i.e. 9 MB of prologue traffic instead of 29 MB.
+// ---------------------------------------------------------------------------------------------------------
+template <int FIX, int NJ>     // NJ = H / 2048
+__global__ __launch_bounds__(512) void k_gemv_q4g_slim(const uint4* __restrict__ W, const __half* __restrict__ S, const unsigned char* __restrict__ Z,
+                                                      const float* __restrict__ bias, int N, int H, Pro pro, long long* acc, long long* zero_buf, int zero_n) {
+  __shared__ __attribute__((aligned(16))) float xs[256];
+  __shared__ __attribute__((aligned(16))) unsigned xh[64], xm[64], xl[64];
+  __shared__ int4 gpar[4];
+  __shared__ float red[8];
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int NKS = H >> 8, G = H >> 7;
+  const int ksl = blockIdx.x % NKS, tq = (blockIdx.x / NKS) * 8 + wave;
+  const bool q_on = tq * 64 < N;
+  const int tqc = q_on ? tq : 0;
+  zero_duty(zero_buf, zero_n);
+  // (1) prologue loads (L2-resident): h, deferred residual, this slice's norm weights
+  const bool hasprev = pro.src.p != nullptr;
+  const void* prevp = hasprev ? pro.src.p : (const void*)pro.h_in;
+  float hv[NJ][4];
+  typename RawT<FIX>::T pv[NJ][4];
+#pragma unroll
+  for (int j = 0; j < NJ; j++) {
+    const int i = j * 2048 + tid * 4;
+    const float4 h4 = *(const float4*)(pro.h_in + i);
+    hv[j][0] = h4.x; hv[j][1] = h4.y; hv[j][2] = h4.z; hv[j][3] = h4.w;
+#pragma unroll
+    for (int e = 0; e < 4; e++) pv[j][e] = vraw<FIX>(prevp, (FIX || hasprev) ? i + e : 0);
+  }
+  float4 nw = make_float4(0, 0, 0, 0);
+  nw = *(const float4*)(pro.norm_w + ksl * 256 + (tid & 63) * 4);
+  __builtin_amdgcn_sched_barrier(0);
+  // (2) this wave's weights: one tile x two groups = 8 KiB, all in flight now
+  uint4 Q[2][4]; float sq[2]; int zq[2];
+  {
+    const uint4* wq = W + ((size_t)tqc * (H >> 5) + ksl * 8) * 64 + lane;
+#pragma unroll
+    for (int b = 0; b < 2; b++)
+#pragma unroll
+      for (int c = 0; c < 4; c++) Q[b][c] = ldnt(wq + (b * 4 + c) * 64);
+#pragma unroll
+    for (int b = 0; b < 2; b++) { const size_t ix = ((size_t)tqc * G + ksl * 2 + b) * 64 + lane; sq[b] = __half2float(S[ix]); zq[b] = Z[ix]; }
+  }
+  // (3) h' = R(h + R(prev)); sum of squares; this block's slice parked in LDS
+  float ss = 0.f;
+#pragma unroll
+  for (int j = 0; j < NJ; j++) {
+    const int i = j * 2048 + tid * 4;
+    if (hasprev) {
+#pragma unroll
+      for (int e = 0; e < 4; e++) hv[j][e] = round_act(hv[j][e] + vcvt<FIX>(pv[j][e], pro.act), pro.act);
+    }
+    ss += hv[j][0] * hv[j][0] + hv[j][1] * hv[j][1] + hv[j][2] * hv[j][2] + hv[j][3] * hv[j][3];
+    if (blockIdx.x == 0 && pro.h_out) *(float4*)(pro.h_out + i) = make_float4(hv[j][0], hv[j][1], hv[j][2], hv[j][3]);
+    if ((i >> 8) == ksl) *(float4*)(xs + (i & 255)) = make_float4(hv[j][0], hv[j][1], hv[j][2], hv[j][3]);
+  }
+  ss = wave_sum(ss);
+  if (lane == 0) red[wave] = ss;
+  __syncthreads();
+  ss = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
+  const float rs = 1.0f / sqrtf(ss / (float)H + pro.eps);
+  if (tid < 64) {
+    const float4 v = *(const float4*)(xs + tid * 4);
+    *(float4*)(xs + tid * 4) = make_float4(round_act(nw.x * round_act(v.x * rs, pro.act), pro.act), round_act(nw.y * round_act(v.y * rs, pro.act), pro.act),
+                                           round_act(nw.z * round_act(v.z * rs, pro.act), pro.act), round_act(nw.w * round_act(v.w * rs, pro.act), pro.act));
+  }
+  __syncthreads();
+  quant_x128(xs, 256, xh, xm, xl, gpar);
+  __syncthreads();
+  if (!q_on) return;
+  float y = 0.f;
+  q4g_consume(Q[0], 0, (const uint4*)xh, (const uint4*)xm, (const uint4*)xl, gpar, sq[0], zq[0], y);
+  q4g_consume(Q[1], 1, (const uint4*)xh, (const uint4*)xm, (const uint4*)xl, gpar, sq[1], zq[1], y);
+  const int n = tq * 64 + lane;
+  if (bias != nullptr && ksl == 0) y += bias[n];
+  atomicAdd((unsigned long long*)(acc + n), (unsigned long long)f2fix(y));
+}
+
+bool bzk_gemv_slim_ok(const LinearDev& L, const Pro& pro) {
+  static const bool off = getenv("BZ_NO_SLIM_QKV") != nullptr;
+  return !off && L.kind == LK_Q4G && !L.perm && pro.mode == PRO_NORM && pro.perm == nullptr && L.K == pro.H && (L.K == 2048 || L.K == 4096 || L.K == 8192) && L.N % 64 == 0 &&
+         L.N <= 16384 && !pro.dbg && !pro.stamps;
 }
 
 // =========================================================================================================
@@ -1407,6 +1507,18 @@ int bzk_dequant_gq(hipStream_t s, const LinearDev& L, float* out) {
 int bzk_argmax_partials(hipStream_t s, const float* v, long long n, float* pval, int* pidx, int nb);
 
 int bzk_gemv(hipStream_t s, const LinearDev& L, const Pro& pro, const GemvOut& out, int act) {
+  if (L.kind == LK_Q4G && bzk_gemv_slim_ok(L, pro)) {
+    if (!out.acc) BZ_FAIL(BZ_E_INVALID, "int4 gemv needs a fixed-point accumulator");
+    const int nks = L.K / 256, ntg = (L.N / 64 + 7) / 8;
+#define LAUNCH_SLIM(FIX, NJ) BZ_LAUNCH("gemv_q4g<norm>", L.algo_bytes, (k_gemv_q4g_slim<FIX, NJ>), dim3(nks * ntg), dim3(512), 0, s, (const uint4*)L.w, \
+    (const __half*)L.scales, (const unsigned char*)L.zeros, L.bias, L.N, L.K, pro, out.acc, out.zero_buf, out.zero_n)
+#define LAUNCH_SLIM_NJ(FIX) do { if (L.K == 2048) LAUNCH_SLIM(FIX, 1); else if (L.K == 4096) LAUNCH_SLIM(FIX, 2); else LAUNCH_SLIM(FIX, 4); } while (0)
+    if (pro.src.fix) LAUNCH_SLIM_NJ(1); else LAUNCH_SLIM_NJ(0);
+#undef LAUNCH_SLIM_NJ
+#undef LAUNCH_SLIM
+    BZ_HIP(hipGetLastError());
+    return BZ_OK;
+  }
   if (L.kind == LK_Q4G) {
     if (!out.acc) BZ_FAIL(BZ_E_INVALID, "q4g gemv needs a fixed-point accumulator");
     const int G = L.K / 128, GW = L.gw;
