@@ -13,7 +13,7 @@ import sys
 from collections import defaultdict
 
 # bench.py kernel label -> substring of the kernel symbol
-LABELS = {"mlp_q4g": "k_mlp_q4g", "attn+o_proj": "k_attn2", "gemv_rows<lm_head+argmax>": "k_gemv_rows", "gemv_q4g<norm>": "k_gemv_q4g<1",
+LABELS = {"mlp_q4g": "k_mlp_q4g", "attn+o_proj": "k_attn2", "gemv_rows<lm_head+argmax>": "k_gemv_rows", "gemv_q4g<norm>": "k_gemv_q4g_slim",
           "gemv_q4g<plain>": "k_gemv_q4g<0", "gemv_q4g<silu>": "k_gemv_q4g<2"}
 
 
