@@ -98,3 +98,20 @@ def test_loader_errors(device, tmp_path):
         runtime.load_model(device, str(tmp_path))
     with pytest.raises(L.BlazrHipError):
         runtime.load_model(device, str(tmp_path / "missing"))
+
+
+def test_bz_run_cpp_driver_generates_the_same_ids(device, tmp_path):
+    # tools/bz_run.cpp: the C ABI driven from compiled C++ (no Python in that process), cli/run.rs restated around the hot path
+    import os, subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "blazr_amd", "bz-run")
+    assert os.path.exists(exe), "bz-run was not built (python -c 'import __graft_entry__ as g; g.build()')"
+    model = synth.make_llama("tiny-awq")
+    W.write_hf_checkpoint(str(tmp_path), model, shards=2)
+    p = synth.prompt_tokens(9, 1024, seed=31)
+    want = runtime.Executor(runtime.LoadedModel.from_synth(device, model)).generate(p, 12).tolist()
+    for extra in ([], ["--graphs"], ["--paged-attention"]):
+        r = subprocess.run([exe, str(tmp_path), "--prompt", ",".join(str(int(x)) for x in p), "--max-tokens", "12", "--stats"] + extra, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        assert [int(x) for x in r.stdout.strip().split(",")] == want, (extra, r.stdout, r.stderr)
+    r = subprocess.run([exe, str(tmp_path / "nope"), "--prompt", "1"], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "bz-run: load" in r.stderr
