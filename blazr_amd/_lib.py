@@ -9,7 +9,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libblazr_hip.so")
+LIB_PATH = os.environ.get("BZ_LIB_PATH") or os.path.join(_HERE, "libblazr_hip.so")   # BZ_LIB_PATH: A/B builds of the library (tuning only)
 _LIB = None
 alive = True   # cleared at interpreter exit: handle destructors must not call into a torn-down HIP runtime
 
