@@ -149,6 +149,7 @@ SYMBOLS = {
     "bz_ssm_state_create": (C.c_int, [P, C.c_int, C.c_int, C.POINTER(P)]),
     "bz_ssm_state_free": (C.c_int, [P]),
     "bz_ssm_state_reset": (C.c_int, [P]),
+    "bz_forward_paged_batch": (C.c_int, [P, P, C.c_int, P, P, P, C.c_int, P, P]),
     "bz_forward_ssm": (C.c_int, [P, P, C.c_int, P, P, C.c_uint32]),
     "bz_decode_graph_capture_ssm": (C.c_int, [P, P, C.POINTER(P)]),
     "bz_tune_gemv": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),

@@ -1664,6 +1664,38 @@ extern "C" int bz_forward_paged(bz_model* m, const bz_tensor* tokens, int S, bz_
   return BZ_OK;
 }
 
+// Batched single-token decode over one paged cache (process_decode_batch, /root/reference/src/engine/batch_decode.rs:35-150): tokens [N,1],
+// slot_mapping [N], block_table [N, max_blocks] (rows padded with 0), one length per sequence.  Logits [N, vocab].
+// This build runs the sequences one after another through the single-stream step (each row of the block table is that sequence's
+// table), so the weights are streamed once per sequence; a weight-sharing multi-row GEMV is the next step.
+extern "C" int bz_forward_paged_batch(bz_model* m, const bz_tensor* tokens, int N, bz_paged_kv* kv, const bz_tensor* slot_mapping, const bz_tensor* block_table,
+                                      int max_blocks, const int32_t* seq_lens, bz_tensor* logits_out) {
+  BZ_TRY(check_fwd(m, tokens, N));
+  if (m->cfg.arch != BZ_ARCH_LLAMA) BZ_FAIL(BZ_E_UNSUPPORTED, "forward_paged_batch: llama family only");
+  if (!kv || kv->layers != m->cfg.n_layers || kv->n_kv != m->cfg.n_kv_heads || kv->hd != m->cfg.head_dim) BZ_FAIL(BZ_E_INVALID, "forward_paged_batch: cache does not match the model");
+  if (!slot_mapping || slot_mapping->dtype != BZ_I32 || slot_mapping->nbytes < (size_t)N * 4) BZ_FAIL(BZ_E_INVALID, "forward_paged_batch: slot_mapping must be I32[N]");
+  if (max_blocks <= 0 || !block_table || block_table->dtype != BZ_I32 || block_table->nbytes < (size_t)N * max_blocks * 4)
+    BZ_FAIL(BZ_E_INVALID, "forward_paged_batch: block_table must be I32[N, max_blocks]");
+  if (!seq_lens) BZ_FAIL(BZ_E_INVALID, "forward_paged_batch: seq_lens is null");
+  if (!logits_out || logits_out->dtype != BZ_F32 || logits_out->nbytes < (size_t)N * m->cfg.vocab * 4) BZ_FAIL(BZ_E_INVALID, "forward_paged_batch: logits_out must be F32 [N, vocab]");
+  int maxlen = 0;
+  for (int i = 0; i < N; i++) {
+    if (seq_lens[i] <= 0 || seq_lens[i] > m->cfg.max_seq_len || (seq_lens[i] + kv->block_size - 1) / kv->block_size > max_blocks)
+      BZ_FAIL(BZ_E_INVALID, "forward_paged_batch: sequence %d has length %d (max_seq_len %d, %d blocks of %d)", i, seq_lens[i], m->cfg.max_seq_len, max_blocks, kv->block_size);
+    maxlen = std::max(maxlen, seq_lens[i]);
+  }
+  for (int i = 0; i < N; i++) {
+    hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, m->dev->stream, m->pos_tmp, seq_lens[i] - 1);   // the new token's position (batch_decode.rs:79-88)
+    StepIO io{};
+    io.kv = view_of(kv, (const int*)block_table->ptr + (size_t)i * max_blocks, (const int*)slot_mapping->ptr + i);
+    io.d_tok = (const long long*)tokens->ptr + i; io.d_pos = m->pos_tmp;
+    BZ_TRY(model_step(m, io));
+    BZ_TRY(emit_logits(m, logits_out, i));
+  }
+  if (kv->seq_len < maxlen) kv->seq_len = maxlen;
+  return BZ_OK;
+}
+
 static int check_ssm(bz_model* m, bz_ssm_state* st) {
   const bz_model_config& c = m->cfg;
   if (c.arch != BZ_ARCH_MAMBA2) BZ_FAIL(BZ_E_INVALID, "forward_ssm: model is not a mamba2 model");

@@ -404,6 +404,19 @@ class LoadedModel:
         L.check(L.lib().bz_forward_ssm(self.h, t.h, S, ssm.h, out.h, L.FWD_ALL_LOGITS if all_logits else 0))
         return out
 
+    def forward_paged_batch(self, tokens, cache, slot_mapping, block_tables, seq_lens):
+        """process_decode_batch (batch_decode.rs:35-150): tokens [N], slots [N], block_tables [N][<= max_blocks] (ragged ok), seq_lens [N]"""
+        t, n = self._tokens(tokens)
+        nb = max(len(b) for b in block_tables)
+        bt = np.zeros((n, nb), dtype=np.int32)
+        for i, b in enumerate(block_tables):
+            bt[i, :len(b)] = b                                    # shorter tables padded with 0 (batch_decode.rs:118-126)
+        sm, btt = self.dev.tensor(np.asarray(slot_mapping, dtype=np.int32)), self.dev.tensor(bt)
+        sl = np.asarray(seq_lens, dtype=np.int32)
+        out = self.dev.zeros((n, self.c.vocab), L.F32)
+        L.check(L.lib().bz_forward_paged_batch(self.h, t.h, n, cache.h, sm.h, btt.h, nb, sl.ctypes.data_as(C.c_void_p), out.h))
+        return out
+
     def forward_embed(self, tokens):
         t, S = self._tokens(tokens)
         out = self.dev.zeros((S, self.c.hidden), L.F32)

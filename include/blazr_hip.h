@@ -173,6 +173,11 @@ int bz_ssm_state_free(bz_ssm_state* s);
 int bz_ssm_state_reset(bz_ssm_state* s);
 
 /* ---- forward ------------------------------------------------------------------------------------------ */
+/* process_decode_batch (engine/batch_decode.rs:35-150): N sequences, one new token each, one shared paged cache; slot_mapping I32[N],
+ * block_table I32[N, max_blocks] (rows padded with 0), seq_lens host i32[N] (length of each sequence including the new token).
+ * logits_out F32 [N, vocab].  Round 1: sequences run one after another (no weight sharing yet). */
+int bz_forward_paged_batch(bz_model* m, const bz_tensor* tokens, int N, bz_paged_kv* kv, const bz_tensor* slot_mapping, const bz_tensor* block_table,
+                           int max_blocks, const int32_t* seq_lens, bz_tensor* logits_out);
 /* LoadedModel::forward_with_ssm_state(&input, &mut ssm) (executor_generate.rs:137,148): Mamba2; tokens I64 [1,S] */
 int bz_forward_ssm(bz_model* m, const bz_tensor* tokens, int S, bz_ssm_state* state, bz_tensor* logits_out, uint32_t flags);
 #define BZ_FWD_ALL_LOGITS 1u  /* logits for all S positions ([S,V]); default: last position only ([1,V]) */

@@ -299,3 +299,36 @@ def test_generate_with_host_side_sampler_options(device):
         assert a == b and len(a) == 10, kw
     with pytest.raises(L.BlazrHipError):
         ex.generate(p, 4, use_graph=True, logit_bias={1: 1.0})
+
+
+def test_batched_paged_decode_matches_per_sequence_oracle(device):
+    # batch_decode.rs:35-150: three sequences of different lengths share one block pool (blocks interleaved), one new token each per step
+    model = synth.make_llama("tiny-awq")
+    cfg = model["config"]
+    lm, om = runtime.LoadedModel.from_synth(device, model), orc_py.OrcLlama(model)
+    bs = 16
+    pool = runtime.LayeredPagedKvCache(device, cfg["n_layers"], 12, bs, cfg["n_kv_heads"], cfg["head_dim"], _kv_dt(cfg))
+    tables = [[0, 3, 6, 9], [1, 4, 7, 10], [2, 5, 8, 11]]
+    prompts = [synth.prompt_tokens(n, cfg["vocab"], seed=40 + n) for n in (5, 17, 30)]
+    okvs, toks, lens = [], [], []
+    for p, tb in zip(prompts, tables):
+        slots = [tb[i // bs] * bs + i % bs for i in range(len(p))]
+        lg = lm.forward_with_paged_kv_cache(p, pool, slots, tb, len(p), 0).to_numpy()
+        okv = om.new_kv(64)
+        lo = om.forward_kv(p, okv, 0)
+        _check_logits(lg, lo, cfg["act_dtype"])
+        okvs.append(okv); toks.append(int(lo[0].argmax())); lens.append(len(p))
+    for step in range(6):
+        lens = [n + 1 for n in lens]
+        slots = [tb[(n - 1) // bs] * bs + (n - 1) % bs for n, tb in zip(lens, tables)]
+        got = lm.forward_paged_batch(toks, pool, slots, [tb[:(n + bs - 1) // bs] for n, tb in zip(lens, tables)], lens).to_numpy()
+        nxt = []
+        for i in range(3):
+            lo = om.forward_kv([toks[i]], okvs[i], lens[i] - 1)
+            _check_logits(got[i:i + 1], lo, cfg["act_dtype"])
+            nxt.append(int(lo[0].argmax()))
+        toks = nxt
+    for okv in okvs:
+        orc_py.lib().orc_kv_free(okv)
+    with pytest.raises(L.BlazrHipError):
+        lm.forward_paged_batch([1, 2], pool, [0, 1], [[0], [1]], [40, 2])      # 40 tokens do not fit one block
