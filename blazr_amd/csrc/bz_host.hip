@@ -1251,7 +1251,8 @@ static int llama_step(bz_model* m, const StepIO& io) {
     Pro pn{}; pn.mode = PRO_NORM; pn.src = prev; pn.h_in = m->hbuf[cur]; pn.h_out = m->hbuf[cur ^ 1]; pn.norm_w = Ld.attn_norm;
     pn.eps = c.rms_eps; pn.H = H; pn.act = act;
     static long long* qkv_stamps = nullptr;
-    if (getenv("BZ_QKV_STAMPS")) {
+    static const bool qkv_stamps_on = getenv("BZ_QKV_STAMPS") != nullptr;
+    if (qkv_stamps_on) {
       if (!qkv_stamps) { hipMalloc(&qkv_stamps, 256); hipMemset(qkv_stamps, 0, 256); }
       if (l == 2) {
         long long hst[16]; hipStreamSynchronize(st); hipMemcpy(hst, qkv_stamps, 128, hipMemcpyDeviceToHost);
@@ -1272,10 +1273,11 @@ static int llama_step(bz_model* m, const StepIO& io) {
     aa.nq = c.n_heads; aa.nkv = c.n_kv_heads; aa.hd = c.head_dim; aa.act = act; aa.kv = io.kv; aa.layer = l; aa.out = m->attn_out;
     aa.zero_buf = nullptr; aa.zero_n = 0; aa.q_only = 0;
     static long long* attn_stamps = nullptr;
-    if (getenv("BZ_ATTN_STAMPS")) {
+    static const bool attn_stamps_on = getenv("BZ_ATTN_STAMPS") != nullptr, attn_stamps_print = getenv("BZ_ATTN_STAMPS_PRINT") != nullptr;
+    if (attn_stamps_on) {
       if (!attn_stamps) { hipMalloc(&attn_stamps, 256); hipMemset(attn_stamps, 0, 256); }
       if (l == 1) {
-        if (getenv("BZ_ATTN_STAMPS_PRINT")) {
+        if (attn_stamps_print) {
           long long hst[16]; hipStreamSynchronize(st); hipMemcpy(hst, attn_stamps, 128, hipMemcpyDeviceToHost);
           fprintf(stderr, "[bz] attn stamps (us since entry):");
           for (int q = 1; q <= 8; q++) fprintf(stderr, " %d:%.2f", q, (hst[q] - hst[0]) / 100.0);
@@ -1301,17 +1303,6 @@ static int llama_step(bz_model* m, const StepIO& io) {
 
     Pro pf{}; pf.mode = PRO_NORM; pf.src = ov; pf.h_in = m->hbuf[cur]; pf.h_out = m->hbuf[cur ^ 1]; pf.norm_w = Ld.ffn_norm;
     pf.eps = c.rms_eps; pf.H = H; pf.act = act;
-    static long long* mlp_stamps = nullptr;
-    if (getenv("BZ_MLP_STAMPS")) {
-      if (!mlp_stamps) { hipMalloc(&mlp_stamps, 256); hipMemset(mlp_stamps, 0, 256); }
-      if (l == 1) {
-        long long hst[16]; hipStreamSynchronize(st); hipMemcpy(hst, mlp_stamps, 128, hipMemcpyDeviceToHost);
-        fprintf(stderr, "[bz] mlp stamps (us since entry):");
-        for (int q = 1; q <= 6; q++) fprintf(stderr, " %d:%.2f", q, (hst[q] - hst[0]) / 100.0);
-        fprintf(stderr, "\n");
-      }
-      pf.stamps = l == 0 ? mlp_stamps : nullptr;
-    }
     VSrc dn;
     static const bool no_mlp_fuse = getenv("BZ_NO_MLP_FUSION") != nullptr;
     if (!no_mlp_fuse && Ld.gateup.parts.size() == 1 && Ld.down.parts.size() == 1 && bzk_mlp_fusable(Ld.gateup.parts[0], Ld.down.parts[0], H, I)) {

@@ -1965,153 +1965,6 @@ __global__ __launch_bounds__(256) void k_attn_decode(AttnArgs a) {
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// attention decode FUSED with o_proj (INT4): grid = nq heads x CS column slices.  o_proj is a sum over heads,
-// out[n] = sum_h Wo[n, h*HD:(h+1)*HD] . attn_h, so block (h, cs) computes head h's attention (redundantly in each of the
-// CS slices -- the K/V rows are L2 hits) and multiplies it by its [N/CS columns x HD] slab of Wo, accumulating into the
-// fixed-point o accumulator.  The slab's weight loads and the K/V row loads are issued first, so HBM latency hides
-// behind the q/k/v finishing and the softmax; one launch (and its ramp/tail) per layer disappears.
-// HD == 128 == the quantisation group, so a head is exactly one k-group of Wo.
-// ---------------------------------------------------------------------------------------------------------
-template <int KVDT, int TPW>   // TPW = 64-column tiles per wave
-__global__ __launch_bounds__(256) void k_attn_oproj(AttnArgs a, const uint4* __restrict__ W, const __half* __restrict__ S,
-                                                    const unsigned char* __restrict__ Z, const float* __restrict__ bias, int N, int CS,
-                                                    long long* acc) {
-  constexpr int HD = 128, half = 64, LDR = HD + 4;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int rep = a.nq / a.nkv;
-  float* qs = (float*)smem;               // [HD]
-  float* knew = qs + HD;                  // [HD]
-  float* vnew = knew + HD;                // [HD]
-  float* wred = vnew + HD;                // [8]
-  float* outh = wred + 8;                 // [HD] head output (rounded), then its int8 planes
-  unsigned* xh = (unsigned*)(outh + HD);  // [32] [32] [32]
-  unsigned* xm = xh + 32;
-  unsigned* xl = xm + 32;
-  int4* gpar = (int4*)(xl + 32);          // [2]
-  float* ored = (float*)(gpar + 2);       // [256][LDR]
-  const int hq = blockIdx.x / CS, cs = blockIdx.x % CS, kvh = hq / rep;
-  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const int pos = a.pos[0];
-  const int len = pos + 1, ncache = pos;
-  const KvView& kv = a.kv;
-  const int K = a.nq * HD, G = K >> 7;
-  zero_duty(a.zero_buf, a.zero_n);
-
-  const int t0 = (cs * 4 + wave) * TPW;   // o_proj slab: tiles t0 .. t0+TPW-1 of this wave, k-group == this head
-  // (1) this lane's K/V rows (position p = tid; longer contexts loop below)
-  KvRow<HD, KVDT> kr, vr;
-  const bool own = tid < ncache;
-  if (own) { const size_t ro = kv_row_off(kv, a.layer, kvh, tid); kr.load(kv.k, ro); vr.load(kv.v, ro); }
-
-  // (3) q/k/v finishing (fixed point -> f32, rounding, RoPE), KV append
-  {
-    const float* cr = a.cos_t + (size_t)pos * half;
-    const float* sr = a.sin_t + (size_t)pos * half;
-    if (tid < 2 * half) {
-      const int hh = tid / half, i = tid % half;
-      const int base = hh == 0 ? hq * HD : a.nq * HD + kvh * HD;
-      const int ia = a.interleaved ? 2 * i : i, ib = a.interleaved ? 2 * i + 1 : i + half;
-      const float x0 = vsrc_get(a.qkv, base + ia, a.act), x1 = vsrc_get(a.qkv, base + ib, a.act);
-      const float c = cr[i], s = sr[i];
-      const float y0 = round_act(x0 * c - x1 * s, a.act), y1 = round_act(x1 * c + x0 * s, a.act);
-      if (hh == 0) { qs[ia] = y0; qs[ib] = y1; }
-      else { knew[ia] = y0; knew[ib] = y1; }
-    } else {
-      const int i = tid - 2 * half;
-      vnew[i] = vsrc_get(a.qkv, a.nq * HD + a.nkv * HD + kvh * HD + i, a.act);
-    }
-    __syncthreads();
-    if (hq % rep == 0 && cs == 0) {
-      size_t woff;
-      if (kv.paged) woff = kv_slot_off(kv, a.layer, kvh, kv.slot ? kv.slot[0] : (kv.block_table[pos / kv.bs] * kv.bs + pos % kv.bs));
-      else woff = kv_row_off(kv, a.layer, kvh, pos);
-      if (tid < HD) { kv_st(kv.k, woff + tid, kv.dtype, knew[tid]); kv_st(kv.v, woff + tid, kv.dtype, vnew[tid]); }
-    }
-  }
-
-  // (4) attention: lane == position stream
-  const float scale = 1.0f / sqrtf((float)HD);
-  float m = -INFINITY, l = 0.f;
-  float o[HD];
-#pragma unroll
-  for (int i = 0; i < HD; i++) o[i] = 0.f;
-  for (int p = tid; p < len; p += 256) {
-    if (p != tid || !own) {   // rows not preloaded: later positions of this stream, or the token being appended
-      if (p < ncache) { const size_t ro = kv_row_off(kv, a.layer, kvh, p); kr.load(kv.k, ro); vr.load(kv.v, ro); }
-      else { kr.from_f32(knew); vr.from_f32(vnew); }
-    }
-    float d = 0.f;
-#pragma unroll
-    for (int i = 0; i < HD; i += 4) {
-      const float4 qa = *(const float4*)(qs + i);
-      d += kr.get(i) * qa.x + kr.get(i + 1) * qa.y + kr.get(i + 2) * qa.z + kr.get(i + 3) * qa.w;
-    }
-    const float s = d * scale;
-    if (m == -INFINITY) {
-      m = s; l = 1.f;
-#pragma unroll
-      for (int i = 0; i < HD; i++) o[i] = vr.get(i);
-    } else {
-      const float mn = fmaxf(m, s);
-      const float alpha = expf(m - mn), e = expf(s - mn);
-      l = l * alpha + e;
-      m = mn;
-#pragma unroll
-      for (int i = 0; i < HD; i++) o[i] = o[i] * alpha + e * vr.get(i);
-    }
-  }
-  // (2) the K/V row registers are dead: issue the o_proj slab loads now; they fly during the merge and the quantisation
-  uint4 Wb[TPW][4];
-  float sc[TPW]; int zp[TPW];
-#pragma unroll
-  for (int t = 0; t < TPW; t++) {
-    const uint4* wp = W + ((size_t)(t0 + t) * (K >> 5) + hq * 4) * 64 + lane;
-#pragma unroll
-    for (int c = 0; c < 4; c++) Wb[t][c] = ldnt(wp + c * 64);
-    sc[t] = __half2float(S[((size_t)(t0 + t) * G + hq) * 64 + lane]);
-    zp[t] = Z[((size_t)(t0 + t) * G + hq) * 64 + lane];
-  }
-  const float wm = wave_max(m);
-  if (lane == 0) wred[wave] = wm;
-  __syncthreads();
-  const float M = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
-  const float w = (m == -INFINITY) ? 0.f : expf(m - M);
-  const float ws = wave_sum(l * w);
-  if (lane == 0) wred[4 + wave] = ws;
-  const int nrows = min(len, 256);
-  if (tid < nrows) {
-#pragma unroll
-    for (int i = 0; i < HD; i += 4) *(float4*)(ored + tid * LDR + i) = make_float4(o[i] * w, o[i + 1] * w, o[i + 2] * w, o[i + 3] * w);
-  }
-  __syncthreads();
-  const float inv = 1.0f / ((wred[4] + wred[5]) + (wred[6] + wred[7]));
-  {
-    const int col = tid % HD, ph = tid / HD;   // 2 row phases
-    float accv = 0.f;
-    for (int r = ph; r < nrows; r += 2) accv += ored[r * LDR + col];
-    __syncthreads();
-    ored[ph * LDR + col] = accv;
-    __syncthreads();
-    if (tid < HD) outh[tid] = round_act((ored[tid] + ored[LDR + tid]) * inv, a.act);
-  }
-  __syncthreads();
-
-  // (5) head output -> three int8 planes (one group of 128), then the slab GEMV
-  quant_x128(outh, HD, xh, xm, xl, gpar);
-  __syncthreads();
-  const uint4* xh4 = (const uint4*)xh;
-  const uint4* xm4 = (const uint4*)xm;
-  const uint4* xl4 = (const uint4*)xl;
-#pragma unroll
-  for (int t = 0; t < TPW; t++) {
-    float y = 0.f;
-    q4g_consume(Wb[t], 0, xh4, xm4, xl4, gpar, sc[t], zp[t], y);
-    const int n = (t0 + t) * 64 + lane;
-    if (bias != nullptr && hq == 0) y += bias[n];
-    atomicAdd((unsigned long long*)(acc + n), (unsigned long long)f2fix(y));
-  }
-}
 
 // ---------------------------------------------------------------------------------------------------------
 // attention decode v2 (head_dim 128, 16-bit cache), optionally fused with o_proj.
@@ -2119,7 +1972,7 @@ __global__ __launch_bounds__(256) void k_attn_oproj(AttnArgs a, const uint4* __r
 //   PV     : the packed V rows go through an LDS image [row][272 B] (conflict-free b128 writes); thread t sums
 //            d-pair (t & 63) over rows = (t >> 6) mod 4 with the softmax weights broadcast from LDS
 //   chunks of 256 positions are merged online (running max / sum / output in the 128 output threads)
-// FUSE: block (head, column slice) multiplies the head output by its slab of Wo (see k_attn_oproj) -- slab loads are
+// FUSE: block (head, column slice) multiplies the head output by its slab of Wo (o_proj = sum over heads of Wo[:, head slab] . attn_head) -- slab loads are
 // issued at kernel entry and stay in flight through the whole attention.
 // ---------------------------------------------------------------------------------------------------------
 typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
