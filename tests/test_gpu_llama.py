@@ -332,3 +332,33 @@ def test_batched_paged_decode_matches_per_sequence_oracle(device):
         orc_py.lib().orc_kv_free(okv)
     with pytest.raises(L.BlazrHipError):
         lm.forward_paged_batch([1, 2], pool, [0, 1], [[0], [1]], [40, 2])      # 40 tokens do not fit one block
+
+
+@pytest.mark.parametrize("paged", [False, True], ids=["contiguous", "paged"])
+def test_full_width_long_context(device, paged):
+    """The fused attention + o_proj kernel at the real head shape (32q / 8kv x 128) over several 256-position chunks of the cache (online
+    softmax merge across chunks, clamped tail rows, paged block-table walks): 600 cached positions, one layer, oracle logits at the end."""
+    model = synth.make_llama("llama3-8b-awq-2l", n_layers=1, max_seq_len=1024)
+    cfg = model["config"]
+    lm, om = runtime.LoadedModel.from_synth(device, model), orc_py.OrcLlama(model)
+    p = synth.prompt_tokens(600, cfg["vocab"], seed=8)
+    okv = om.new_kv(640)
+    want = om.forward_kv(p, okv, 0)
+    if paged:
+        bs, nb = 16, 48
+        cache = runtime.LayeredPagedKvCache(device, 1, nb, bs, cfg["n_kv_heads"], cfg["head_dim"], L.F16)
+        blocks = list(np.random.default_rng(1).permutation(nb))                     # scattered physical blocks
+        slots = [int(blocks[i // bs]) * bs + i % bs for i in range(640)]
+        got = lm.forward_with_paged_kv_cache(p, cache, slots[:600], blocks, 600, 0).to_numpy()
+        step = lambda tok, pos: lm.forward_with_paged_kv_cache([tok], cache, [slots[pos]], blocks, pos + 1, pos).to_numpy()
+    else:
+        cache = runtime.LayeredKvCache(device, 1, 1, cfg["n_kv_heads"], 64, cfg["max_seq_len"], cfg["head_dim"], L.F16)   # grows 64 -> ... -> 1024
+        got = lm.forward_with_kv_cache(p, cache, 0).to_numpy()
+        step = lambda tok, pos: lm.forward_with_kv_cache([tok], cache, pos).to_numpy()
+    _check_logits(got, want, "f16", factor=1.0)
+    tok = int(want[0].argmax())
+    for i in range(4):
+        lo = om.forward_kv([tok], okv, 600 + i)
+        _check_logits(step(tok, 600 + i), lo, "f16", factor=1.0)
+        tok = int(lo[0].argmax())
+    orc_py.lib().orc_kv_free(okv)
