@@ -589,14 +589,17 @@ __global__ __launch_bounds__(512) void k_mlp_q4g(const uint4* __restrict__ Wgu, 
     nw[j] = *(const float4*)(pro.norm_w + i);
   }
   __builtin_amdgcn_sched_barrier(0);   // keep the prologue's loads AHEAD of the weight stream (vmcnt is in-order)
-  // (2) all gate + up loads of this wave's k-range up front: 256 KB per block in flight while the norm prologue computes
+  // (2) gate + up weights of this wave's k-range, streamed two groups deep (8 KiB per matrix per wave in flight).  Measured with
+  //     scripts/stream_probe.hip on this grid: 6.2 TB/s with 8-16 KiB in flight per wave, 4.9 TB/s with 32 KiB -- issuing the whole
+  //     k-range up front (the first version of this kernel) over-subscribes the memory system.
   const uint4* wg = Wgu + ((size_t)sl * (H >> 5) + gbeg * 4) * 64 + lane;
   const uint4* wu = Wgu + ((size_t)(NTI + sl) * (H >> 5) + gbeg * 4) * 64 + lane;
-  uint4 Ag[GPW][4], Au[GPW][4];
+  uint4 Ag[2][4], Au[2][4];
 #pragma unroll
-  for (int b = 0; b < GPW; b++) {
+  for (int c = 0; c < 4; c++) { Ag[0][c] = ldnt(wg + c * 64); Au[0][c] = ldnt(wu + c * 64); }
+  if (GPW > 1) {
 #pragma unroll
-    for (int c = 0; c < 4; c++) { Ag[b][c] = ldnt(wg + (b * 4 + c) * 64); Au[b][c] = ldnt(wu + (b * 4 + c) * 64); }
+    for (int c = 0; c < 4; c++) { Ag[1][c] = ldnt(wg + (4 + c) * 64); Au[1][c] = ldnt(wu + (4 + c) * 64); }
   }
   float sg[GPW], su[GPW]; int zg[GPW], zu[GPW];
 #pragma unroll
@@ -631,31 +634,34 @@ __global__ __launch_bounds__(512) void k_mlp_q4g(const uint4* __restrict__ Wgu, 
   quant_x128(xs, H, xh, xm, xl, gpar);
   __syncthreads();
 
-  // (4) gate / up partial dot products over this wave's k-groups
+  // (4) gate / up partial dot products over this wave's k-groups; group b+2 is requested as soon as group b's registers are free,
+  //     and the down slab (16 KiB per wave) goes out behind the last gate/up group, so the stream never pauses
   const uint4* xh4 = (const uint4*)xh;
   const uint4* xm4 = (const uint4*)xm;
   const uint4* xl4 = (const uint4*)xl;
   float yg = 0.f, yu = 0.f;
-#pragma unroll
-  for (int b = 0; b < (GPW + 1) / 2; b++) {
-    q4g_consume(Ag[b], gbeg + b, xh4, xm4, xl4, gpar, sg[b], zg[b], yg);
-    q4g_consume(Au[b], gbeg + b, xh4, xm4, xl4, gpar, su[b], zu[b], yu);
-  }
-  // half of the gate/up registers are free: issue this wave's down slab now; it flies during the remaining dot products,
-  // the reduction, SiLU and the quantisation
   uint4 D[TPW][2];
   float sd[TPW]; int zd[TPW];
 #pragma unroll
-  for (int q = 0; q < TPW; q++) {
-    const uint4* wp = Wd + ((size_t)(tbeg + q) * (I >> 5) + 2 * sl) * 64 + lane;
-    D[q][0] = ldnt(wp); D[q][1] = ldnt(wp + 64);
-    const size_t si = ((size_t)(tbeg + q) * GD + gd) * 64 + lane;
-    sd[q] = __half2float(Sd[si]); zd[q] = Zd[si];
-  }
+  for (int b = 0; b < GPW; b++) {
+    q4g_consume(Ag[b & 1], gbeg + b, xh4, xm4, xl4, gpar, sg[b], zg[b], yg);
+    q4g_consume(Au[b & 1], gbeg + b, xh4, xm4, xl4, gpar, su[b], zu[b], yu);
+    if (b + 2 < GPW) {
 #pragma unroll
-  for (int b = (GPW + 1) / 2; b < GPW; b++) {
-    q4g_consume(Ag[b], gbeg + b, xh4, xm4, xl4, gpar, sg[b], zg[b], yg);
-    q4g_consume(Au[b], gbeg + b, xh4, xm4, xl4, gpar, su[b], zu[b], yu);
+      for (int c = 0; c < 4; c++) { Ag[b & 1][c] = ldnt(wg + ((b + 2) * 4 + c) * 64); Au[b & 1][c] = ldnt(wu + ((b + 2) * 4 + c) * 64); }
+    }
+    if (b >= GPW - 2) {     // the down slab follows in two halves, one behind each of the last two gate/up groups: never more than 16 KiB per wave in flight
+      const int q0 = (b == GPW - 2) ? 0 : TPW / 2, q1 = (b == GPW - 2) ? TPW / 2 : TPW;
+#pragma unroll
+      for (int q = 0; q < TPW; q++) {
+        if (q >= q0 && q < q1) {
+          const uint4* wp = Wd + ((size_t)(tbeg + q) * (I >> 5) + 2 * sl) * 64 + lane;
+          D[q][0] = ldnt(wp); D[q][1] = ldnt(wp + 64);
+          const size_t si = ((size_t)(tbeg + q) * GD + gd) * 64 + lane;
+          sd[q] = __half2float(Sd[si]); zd[q] = Zd[si];
+        }
+      }
+    }
   }
   part[wave * 128 + lane] = yg;
   part[wave * 128 + 64 + lane] = yu;
@@ -683,8 +689,7 @@ __global__ __launch_bounds__(512) void k_mlp_q4g(const uint4* __restrict__ Wgu, 
     const int n = (tbeg + q) * 64 + lane;
     if (bd != nullptr && sl == 0) y += bd[n];
     atomicAdd((unsigned long long*)(acc + n), (unsigned long long)f2fix(y));
-  }
-}
+  }}
 
 static size_t mlp_smem(int H) { return (size_t)H * 4 + (size_t)H * 3 + (size_t)(H >> 7) * 32 + 8 * 128 * 4 + 64 * 4 + 48 * 4 + 32 + 32 + 64; }
 
