@@ -261,6 +261,8 @@ struct bz_model {
   float* hbuf[2] = {nullptr, nullptr};
   // batched-prefill workspace (bz_prefill.hip), allocated on first use for `pf_rows` prompt rows
   int pf_rows = 0; float* pf_h = nullptr; float* pf_t = nullptr; float* pf_qkv = nullptr; float* pf_gu = nullptr; void* pf_x16 = nullptr;
+  int* row_pos = nullptr; int row_pos_n = 0;   // device copy of a decode batch's per-row positions
+  long long* pf_acc = nullptr;   // int4 multi-row GEMM scratch: 8 rows x widest N, fixed point, kept zero between launches
   long long* ring[3] = {nullptr, nullptr, nullptr};
   float* dring[3] = {nullptr, nullptr, nullptr};   // direct-output twins of the ring (ROWS kernels)
   int ring_n = 0;
@@ -1521,9 +1523,14 @@ static bool prefill_eligible(const bz_model* m, int S, int total_len) {
   if (c.hidden % 64 || (c.n_heads * c.head_dim) % 64 || c.inter % 64 || c.head_dim % 8 || 256 % (c.head_dim / 8)) return false;
   const int rep = c.n_heads / c.n_kv_heads;
   if ((rep != 1 && rep != 2 && rep != 4 && rep != 8) || bzk_pf_attn_smem(c.n_heads, c.n_kv_heads, c.head_dim, total_len) > 160 * 1024) return false;
+  // every projection either dense in the activation dtype (MFMA GEMM) or int4 without act-order (multi-row dot4 GEMM)
   for (const LayerDev& L : m->layers)
-    for (const FusedLinear* F : {&L.qkv, &L.o, &L.gateup, &L.down})
-      if (F->parts.size() != 1 || F->parts[0].kind != LK_ROWS || F->parts[0].wdt != c.act_dtype) return false;
+    for (const FusedLinear* F : {&L.qkv, &L.o, &L.gateup, &L.down}) {
+      if (F->parts.size() != 1) return false;
+      const LinearDev& P = F->parts[0];
+      const bool dense_ok = P.kind == LK_ROWS && P.wdt == c.act_dtype, q4_ok = bzk_gemm_q4g_rows_ok(P);
+      if (!dense_ok && !q4_ok) return false;
+    }
   return m->lm_head.parts.size() == 1 && m->lm_head.parts[0].kind == LK_ROWS && !m->lm_head.fix_out;
 }
 static int prefill_ws(bz_model* m, int rows) {
@@ -1537,12 +1544,25 @@ static int prefill_ws(bz_model* m, int rows) {
   BZ_TRY(dev_alloc(m, &p, (size_t)rows * qn * 4)); m->pf_qkv = (float*)p;
   BZ_TRY(dev_alloc(m, &p, (size_t)rows * 2 * c.inter * 4)); m->pf_gu = (float*)p;
   BZ_TRY(dev_alloc(m, &p, (size_t)rows * xw * 2)); m->pf_x16 = p;
+  if (!m->pf_acc) { const size_t an = 8 * std::max<size_t>(std::max<size_t>(qn, 2 * (size_t)c.inter), c.hidden); BZ_TRY(dev_alloc(m, &p, an * 8)); m->pf_acc = (long long*)p; BZ_HIP(hipMemset(p, 0, an * 8)); }
   m->pf_rows = rows;
   return BZ_OK;
 }
 
+// Y[n][N] = R(X16[n][K] . W^T): dense 16-bit weights on the matrix cores, int4 weights through the multi-row dot4 GEMM
+static int pf_gemm(bz_model* m, const LinearDev& P, const void* x16, int n, float* y) {
+  hipStream_t st = m->dev->stream;
+  const int act = m->cfg.act_dtype;
+  if (P.kind == LK_ROWS) return bzk_gemm_nt(st, act, x16, P.w, P.bias, n, P.N, P.K, act, y);
+  return bzk_gemm_q4g_rows(st, P, act, x16, n, act, m->pf_acc, y);
+}
+
 // tokens [S] at positions pos0 .. pos0+S-1; `slots` (paged only): device i32 [S].  Logits of the last row (or all rows) -> logits_out.
-static int prefill_dense(bz_model* m, const long long* d_tok, int S, const KvView& view, int pos0, const int* slots, bool all, bz_tensor* logits_out) {
+// per-row context of a decode batch: row r is its own sequence (position row_pos[r], block-table row r); nullptr row_pos = one prompt
+struct RowsCtx { const int* row_pos = nullptr; int table_stride = 0; int max_len = 0; };
+
+static int prefill_dense(bz_model* m, const long long* d_tok, int S, const KvView& view, int pos0, const int* slots, bool all, bz_tensor* logits_out,
+                         const RowsCtx& rc = RowsCtx()) {
   const bz_model_config& c = m->cfg;
   hipStream_t st = m->dev->stream;
   const int H = c.hidden, I = c.inter, nq = c.n_heads, nkv = c.n_kv_heads, hd = c.head_dim, act = c.act_dtype, dt = c.act_dtype;
@@ -1555,17 +1575,25 @@ static int prefill_dense(bz_model* m, const long long* d_tok, int S, const KvVie
     for (int l = 0; l < c.n_layers; l++) {
       const LayerDev& L = m->layers[l];
       BZ_TRY(bzk_pf_norm(st, dt, m->pf_h, prev, L.attn_norm, n, H, c.rms_eps, act, m->pf_x16));
-      BZ_TRY(bzk_gemm_nt(st, dt, m->pf_x16, L.qkv.parts[0].w, L.qkv.parts[0].bias, n, L.qkv.N, H, act, m->pf_qkv));
-      BZ_TRY(bzk_pf_rope_kv(st, m->pf_qkv, n, nq, nkv, hd, m->cos_t, m->sin_t, c.rope_interleaved, p0, act, view, l, slots ? slots + s0 : nullptr));
-      BZ_TRY(bzk_pf_attn(st, dt, m->pf_qkv, n, nq, nkv, hd, p0, act, view, l, m->pf_x16));
-      BZ_TRY(bzk_gemm_nt(st, dt, m->pf_x16, L.o.parts[0].w, L.o.parts[0].bias, n, H, nq * hd, act, m->pf_t));
+      BZ_TRY(pf_gemm(m, L.qkv.parts[0], m->pf_x16, n, m->pf_qkv));
+      BZ_TRY(bzk_pf_rope_kv(st, m->pf_qkv, n, nq, nkv, hd, m->cos_t, m->sin_t, c.rope_interleaved, p0, act, view, l, slots ? slots + s0 : nullptr,
+                            rc.row_pos ? rc.row_pos + s0 : nullptr));
+      BZ_TRY(bzk_pf_attn(st, dt, m->pf_qkv, n, nq, nkv, hd, p0, act, view, l, m->pf_x16, rc.row_pos ? rc.row_pos + s0 : nullptr, rc.table_stride, rc.max_len));
+      BZ_TRY(pf_gemm(m, L.o.parts[0], m->pf_x16, n, m->pf_t));
       BZ_TRY(bzk_pf_norm(st, dt, m->pf_h, m->pf_t, L.ffn_norm, n, H, c.rms_eps, act, m->pf_x16));
-      BZ_TRY(bzk_gemm_nt(st, dt, m->pf_x16, L.gateup.parts[0].w, L.gateup.parts[0].bias, n, 2 * I, H, act, m->pf_gu));
+      BZ_TRY(pf_gemm(m, L.gateup.parts[0], m->pf_x16, n, m->pf_gu));
       BZ_TRY(bzk_pf_silu(st, dt, m->pf_gu, n, I, act, m->pf_x16));
-      BZ_TRY(bzk_gemm_nt(st, dt, m->pf_x16, L.down.parts[0].w, L.down.parts[0].bias, n, H, I, act, m->pf_t));
+      BZ_TRY(pf_gemm(m, L.down.parts[0], m->pf_x16, n, m->pf_t));
       prev = m->pf_t;
     }
-    // head: rows that need logits go through the decode lm_head GEMV (final norm fused as its prologue)
+    // head.  Several rows wanted (all_logits, decode batch) and a dense lm_head in the activation dtype: final norm rows + one MFMA GEMM that
+    // streams the lm_head once; otherwise the decode lm_head GEMV per row (final norm fused as its prologue)
+    const LinearDev& LH = m->lm_head.parts[0];
+    if (all && n > 1 && LH.wdt == act && LH.K % 64 == 0 && logits_out->nbytes >= (size_t)(s0 + n) * c.vocab * 4) {
+      BZ_TRY(bzk_pf_norm(st, dt, m->pf_h, prev, m->final_norm, n, H, c.rms_eps, act, m->pf_x16));
+      BZ_TRY(bzk_gemm_nt(st, act, m->pf_x16, LH.w, LH.bias, n, c.vocab, H, act, (float*)logits_out->ptr + (size_t)s0 * c.vocab));
+      continue;
+    }
     for (int r = 0; r < n; r++) {
       const int srow = s0 + r;
       if (!all && srow != S - 1) continue;
@@ -1657,8 +1685,8 @@ extern "C" int bz_forward_paged(bz_model* m, const bz_tensor* tokens, int S, bz_
 
 // Batched single-token decode over one paged cache (process_decode_batch, /root/reference/src/engine/batch_decode.rs:35-150): tokens [N,1],
 // slot_mapping [N], block_table [N, max_blocks] (rows padded with 0), one length per sequence.  Logits [N, vocab].
-// This build runs the sequences one after another through the single-stream step (each row of the block table is that sequence's
-// table), so the weights are streamed once per sequence; a weight-sharing multi-row GEMV is the next step.
+// Models the multi-row pipeline covers (int4 without act-order, dense 16-bit) share the weights across the batch: one pass per 8 sequences;
+// the others run the sequences one after another through the single-stream step.
 extern "C" int bz_forward_paged_batch(bz_model* m, const bz_tensor* tokens, int N, bz_paged_kv* kv, const bz_tensor* slot_mapping, const bz_tensor* block_table,
                                       int max_blocks, const int32_t* seq_lens, bz_tensor* logits_out) {
   BZ_TRY(check_fwd(m, tokens, N));
@@ -1674,6 +1702,23 @@ extern "C" int bz_forward_paged_batch(bz_model* m, const bz_tensor* tokens, int 
     if (seq_lens[i] <= 0 || seq_lens[i] > m->cfg.max_seq_len || (seq_lens[i] + kv->block_size - 1) / kv->block_size > max_blocks)
       BZ_FAIL(BZ_E_INVALID, "forward_paged_batch: sequence %d has length %d (max_seq_len %d, %d blocks of %d)", i, seq_lens[i], m->cfg.max_seq_len, max_blocks, kv->block_size);
     maxlen = std::max(maxlen, seq_lens[i]);
+  }
+  static const bool no_share = getenv("BZ_NO_BATCH_SHARING") != nullptr;
+  if (!no_share && N >= 2 && prefill_eligible(m, std::max(N, prefill_min_rows()), maxlen)) {
+    // weight-sharing path: the N rows go through the multi-row pipeline (int4: one pass over the weights per 8 sequences; dense: MFMA GEMM),
+    // each row with its own position, slot and block-table row
+    std::vector<int> pos(N);
+    for (int i = 0; i < N; i++) pos[i] = seq_lens[i] - 1;
+    if (!m->row_pos || m->row_pos_n < N) {
+      BZ_HIP(hipStreamSynchronize(m->dev->stream));
+      void* p; BZ_TRY(dev_alloc(m, &p, (size_t)N * 4)); m->row_pos = (int*)p; m->row_pos_n = N;
+    }
+    BZ_HIP(hipMemcpyAsync(m->row_pos, pos.data(), (size_t)N * 4, hipMemcpyHostToDevice, m->dev->stream));
+    BZ_HIP(hipStreamSynchronize(m->dev->stream));       // `pos` is a stack-lifetime host buffer
+    RowsCtx rc; rc.row_pos = m->row_pos; rc.table_stride = max_blocks; rc.max_len = maxlen;
+    BZ_TRY(prefill_dense(m, (const long long*)tokens->ptr, N, view_of(kv, (const int*)block_table->ptr, nullptr), 0, (const int*)slot_mapping->ptr, true, logits_out, rc));
+    if (kv->seq_len < maxlen) kv->seq_len = maxlen;
+    return BZ_OK;
   }
   for (int i = 0; i < N; i++) {
     hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, m->dev->stream, m->pos_tmp, seq_lens[i] - 1);   // the new token's position (batch_decode.rs:79-88)

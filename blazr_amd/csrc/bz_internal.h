@@ -161,6 +161,8 @@ struct GemvOut {
 
 int bzk_gemv(hipStream_t s, const LinearDev& L, const Pro& pro, const GemvOut& out, int act);
 int bzk_gemv_rows_blocks(const LinearDev& L);
+bool bzk_gemm_q4g_rows_ok(const LinearDev& L);
+int bzk_gemm_q4g_rows(hipStream_t s, const LinearDev& L, int xdt, const void* x16, int rows, int act, long long* acc, float* y);
 int bzk_rows_choose_sk(int N, int K);
 bool bzk_mlp_fusable(const LinearDev& gu, const LinearDev& dn, int H, int I);
 int bzk_mlp_q4g(hipStream_t s, const LinearDev& gu, const LinearDev& dn, int H, int I, const Pro& pro, long long* acc, long long* zero_buf, int zero_n);   // number of workgroups the ROWS kernel uses (argmax partial count)
@@ -245,8 +247,9 @@ int bzk_pf_cvt16(hipStream_t s, int dt, const float* x, size_t n, void* y);
 int bzk_pf_embed(hipStream_t s, const void* table, int tdt, const long long* tok, int S, int H, int act, float* out);
 int bzk_pf_norm(hipStream_t s, int dt, float* hbuf, const float* prev, const float* w, int S, int H, float eps, int act, void* x16);
 int bzk_pf_rope_kv(hipStream_t s, float* qkv, int S, int nq, int nkv, int hd, const float* cos_t, const float* sin_t, int interleaved, int pos0, int act,
-                   const KvView& kv, int layer, const int* slots);
-int bzk_pf_attn(hipStream_t s, int dt, const float* qkv, int S, int nq, int nkv, int hd, int pos0, int act, const KvView& kv, int layer, void* out16);
+                   const KvView& kv, int layer, const int* slots, const int* row_pos = nullptr);
+int bzk_pf_attn(hipStream_t s, int dt, const float* qkv, int S, int nq, int nkv, int hd, int pos0, int act, const KvView& kv, int layer, void* out16,
+                const int* row_pos = nullptr, int table_stride = 0, int max_len = 0);
 int bzk_pf_silu(hipStream_t s, int dt, const float* gu, int S, int I, int act, void* a16);
 size_t bzk_pf_attn_smem(int nq, int nkv, int hd, int len);
 

@@ -898,6 +898,93 @@ __global__ __launch_bounds__(512) void k_gemv_q4g_slim(const uint4* __restrict__
   atomicAdd((unsigned long long*)(acc + n), (unsigned long long)f2fix(y));
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Multi-row int4 GEMM (rows = prompt tokens of a prefill chunk, or the sequences of a decode batch): the weights of a (tile, 256-k slice)
+// are loaded ONCE per wave and consumed for up to 8 activation rows, so a prompt costs one pass over the weights per 8 tokens instead of
+// one per token.  Same arithmetic as the GEMV (three int8 planes per 128-group, exact int32 group sums, 64-bit fixed-point split-K), so a
+// row's result is bit-identical to what the single-row kernels produce for it.
+//   X: 16-bit rows [rows][K] (the prefill pipeline's GEMM input), acc: fixed point [rows][N], zero on entry.
+// grid = (K/256) x ceil(N/512), 512 threads: 8 waves share the slice (8 x 256 activations quantised per block), one 64-column tile each.
+// ---------------------------------------------------------------------------------------------------------
+template <int XDT>
+__global__ __launch_bounds__(512) void k_gemm_q4g_rows(const uint4* __restrict__ W, const __half* __restrict__ S, const unsigned char* __restrict__ Z,
+                                                      const float* __restrict__ bias, int N, int K, const unsigned short* __restrict__ X, int rows,
+                                                      long long* __restrict__ acc) {
+  __shared__ __attribute__((aligned(16))) float xs[8 * 256];
+  __shared__ __attribute__((aligned(16))) unsigned xh[8 * 64], xm[8 * 64], xl[8 * 64];
+  __shared__ int4 gpar[8 * 4];
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int NKS = K >> 8, G = K >> 7;
+  const int ksl = blockIdx.x % NKS, tq = (blockIdx.x / NKS) * 8 + wave;
+  const bool q_on = tq * 64 < N;
+  const int tqc = q_on ? tq : 0;
+  // activations of this slice: thread t -> row t / 64, 4 elements at (t % 64) * 4 (one 8-byte load)
+  const int xr = tid >> 6;
+  const uint2 xraw = *(const uint2*)(X + (size_t)min(xr, rows - 1) * K + ksl * 256 + lane * 4);
+  __builtin_amdgcn_sched_barrier(0);
+  uint4 Q[2][4]; float sq[2]; int zq[2];
+  {
+    const uint4* wq = W + ((size_t)tqc * (K >> 5) + ksl * 8) * 64 + lane;
+#pragma unroll
+    for (int b = 0; b < 2; b++)
+#pragma unroll
+      for (int c = 0; c < 4; c++) Q[b][c] = ldnt(wq + (b * 4 + c) * 64);
+#pragma unroll
+    for (int b = 0; b < 2; b++) { const size_t ix = ((size_t)tqc * G + ksl * 2 + b) * 64 + lane; sq[b] = __half2float(S[ix]); zq[b] = Z[ix]; }
+  }
+  {
+    const unsigned u[2] = {xraw.x, xraw.y};
+    float v[4];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      if (XDT == BZ_F16) { v[2 * i] = __half2float(__ushort_as_half((unsigned short)(u[i] & 0xffffu))); v[2 * i + 1] = __half2float(__ushort_as_half((unsigned short)(u[i] >> 16))); }
+      else { v[2 * i] = __uint_as_float(u[i] << 16); v[2 * i + 1] = __uint_as_float(u[i] & 0xffff0000u); }
+    }
+    const bool on = xr < rows;
+    *(float4*)(xs + xr * 256 + lane * 4) = on ? make_float4(v[0], v[1], v[2], v[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __syncthreads();
+  quant_x128(xs, 8 * 256, xh, xm, xl, gpar);       // 16 groups of 128: group index = row * 2 + (group of the slice)
+  __syncthreads();
+  if (!q_on) return;
+  const int n = tq * 64 + lane;
+  const float bv = (bias != nullptr && ksl == 0) ? bias[n] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    if (r < rows) {
+      float y = bv;
+      q4g_consume(Q[0], r * 2, (const uint4*)xh, (const uint4*)xm, (const uint4*)xl, gpar, sq[0], zq[0], y);
+      q4g_consume(Q[1], r * 2 + 1, (const uint4*)xh, (const uint4*)xm, (const uint4*)xl, gpar, sq[1], zq[1], y);
+      atomicAdd((unsigned long long*)(acc + (size_t)r * N + n), (unsigned long long)f2fix(y));
+    }
+  }
+}
+
+// out[i] = R(fix2f(acc[i])), acc[i] = 0  (the accumulator is ready for the next GEMM)
+__global__ void k_fix_rows_finish(long long* acc, size_t n, int act, float* out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) { out[i] = round_act(fix2f(acc[i]), act); acc[i] = 0; }
+}
+
+bool bzk_gemm_q4g_rows_ok(const LinearDev& L) { return L.kind == LK_Q4G && !L.perm && L.K % 256 == 0 && L.N % 64 == 0; }
+
+// Y[rows][N] (f32, rounded to act) = X16[rows][K] . W^T for any number of rows, 8 at a time; `acc` is scratch of 8 * N fixed-point values (zero on entry and on exit)
+int bzk_gemm_q4g_rows(hipStream_t s, const LinearDev& L, int xdt, const void* x16, int rows, int act, long long* acc, float* y) {
+  if (!bzk_gemm_q4g_rows_ok(L) || (xdt != BZ_F16 && xdt != BZ_BF16)) BZ_FAIL(BZ_E_UNSUPPORTED, "gemm_q4g_rows: unsupported weight / activation format");
+  const int nks = L.K / 256, ntg = (L.N / 64 + 7) / 8;
+  for (int r0 = 0; r0 < rows; r0 += 8) {
+    const int nr = std::min(8, rows - r0);
+    const unsigned short* xp = (const unsigned short*)x16 + (size_t)r0 * L.K;
+    const double bytes = (double)L.algo_bytes;
+    if (xdt == BZ_F16) BZ_LAUNCH("gemm_q4g_rows", bytes, k_gemm_q4g_rows<BZ_F16>, dim3(nks * ntg), dim3(512), 0, s, (const uint4*)L.w, (const __half*)L.scales,
+                                 (const unsigned char*)L.zeros, L.bias, L.N, L.K, xp, nr, acc);
+    else BZ_LAUNCH("gemm_q4g_rows", bytes, k_gemm_q4g_rows<BZ_BF16>, dim3(nks * ntg), dim3(512), 0, s, (const uint4*)L.w, (const __half*)L.scales,
+                   (const unsigned char*)L.zeros, L.bias, L.N, L.K, xp, nr, acc);
+    hipLaunchKernelGGL(k_fix_rows_finish, dim3(std::min<size_t>(1024, ((size_t)nr * L.N + 255) / 256)), dim3(256), 0, s, acc, (size_t)nr * L.N, act, y + (size_t)r0 * L.N);
+  }
+  BZ_HIP(hipGetLastError());
+  return BZ_OK;
+}
+
 bool bzk_gemv_slim_ok(const LinearDev& L, const Pro& pro) {
   static const bool off = getenv("BZ_NO_SLIM_QKV") != nullptr;
   return !off && L.kind == LK_Q4G && !L.perm && pro.mode == PRO_NORM && pro.perm == nullptr && L.K == pro.H && (L.K == 2048 || L.K == 4096 || L.K == 8192) && L.N % 64 == 0 &&

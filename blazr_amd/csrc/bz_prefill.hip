@@ -146,8 +146,8 @@ __global__ __launch_bounds__(256) void k_pf_norm(float* hbuf, const float* prev,
 
 // row s, head j of [q heads | k heads | v heads]: RoPE on q and k (rounded), k / v appended to the cache at position pos0 + s.   grid = (S, nq + 2 nkv)
 __global__ __launch_bounds__(64) void k_pf_rope_kv(float* qkv, int nq, int nkv, int hd, const float* cos_t, const float* sin_t, int interleaved, int pos0, int act,
-                                                   KvView kv, int layer, const int* slots) {
-  const int s = blockIdx.x, j = blockIdx.y, pos = pos0 + s;
+                                                   KvView kv, int layer, const int* slots, const int* row_pos) {
+  const int s = blockIdx.x, j = blockIdx.y, pos = row_pos ? row_pos[s] : pos0 + s;   // row_pos: decode batch (one sequence per row)
   float* v = qkv + (size_t)s * (nq + 2 * nkv) * hd + (size_t)j * hd;
   const int half = hd / 2;
   if (j < nq + nkv) {
@@ -206,9 +206,11 @@ __device__ __forceinline__ void ld_row8(const void* base, size_t off, float (&o)
   }
 }
 template <int DT, int KVDT, int REP>
-__global__ __launch_bounds__(256) void k_pf_attn(const float* qkv, int nq, int nkv, int hd, int pos0, int act, KvView kv, int layer, float scale, unsigned short* out16) {
+__global__ __launch_bounds__(256) void k_pf_attn(const float* qkv, int nq, int nkv, int hd, int pos0, int act, KvView kv, int layer, float scale, unsigned short* out16,
+                                                const int* row_pos, int table_stride) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int s = blockIdx.x, kvh = blockIdx.y, len = pos0 + s + 1;
+  const int s = blockIdx.x, kvh = blockIdx.y, len = (row_pos ? row_pos[s] : pos0 + s) + 1;
+  const int* btab = kv.block_table + (row_pos ? (size_t)s * table_stride : 0);   // decode batch: one block-table row per sequence
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int PR = hd >> 3, RPP = 256 / PR;              // lanes per row, rows per pass
   const int c = tid % PR, g = tid / PR;                // this thread's 8-dim piece and row slot
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(256) void k_pf_attn(const float* qkv, int nq, int n
 #pragma unroll
     for (int e = 0; e < 8; e++) q[h][e] = qkv[(size_t)s * (nq + 2 * nkv) * hd + (size_t)(kvh * REP + h) * hd + 8 * c + e];
   auto row_off = [&](int p) -> size_t {
-    if (kv.paged) { const int blk = kv.block_table[p / kv.bs]; return (size_t)layer * kv.layer_stride + (((size_t)blk * kv.n_kv + kvh) * kv.bs + p % kv.bs) * kv.hd + 8 * c; }
+    if (kv.paged) { const int blk = btab[p / kv.bs]; return (size_t)layer * kv.layer_stride + (((size_t)blk * kv.n_kv + kvh) * kv.bs + p % kv.bs) * kv.hd + 8 * c; }
     return (size_t)layer * kv.layer_stride + ((size_t)kvh * kv.cap + p) * kv.hd + 8 * c;
   };
   // ---- scores ----
@@ -359,8 +361,8 @@ int bzk_pf_norm(hipStream_t s, int dt, float* hbuf, const float* prev, const flo
   return BZ_OK;
 }
 int bzk_pf_rope_kv(hipStream_t s, float* qkv, int S, int nq, int nkv, int hd, const float* cos_t, const float* sin_t, int interleaved, int pos0, int act,
-                   const KvView& kv, int layer, const int* slots) {
-  hipLaunchKernelGGL(k_pf_rope_kv, dim3(S, nq + 2 * nkv), dim3(64), 0, s, qkv, nq, nkv, hd, cos_t, sin_t, interleaved, pos0, act, kv, layer, slots);
+                   const KvView& kv, int layer, const int* slots, const int* row_pos) {
+  hipLaunchKernelGGL(k_pf_rope_kv, dim3(S, nq + 2 * nkv), dim3(64), 0, s, qkv, nq, nkv, hd, cos_t, sin_t, interleaved, pos0, act, kv, layer, slots, row_pos);
   BZ_HIP(hipGetLastError());
   return BZ_OK;
 }
@@ -368,17 +370,19 @@ size_t bzk_pf_attn_smem(int nq, int nkv, int hd, int len) {
   const int REP = nq / nkv, RPP = 256 / (hd / 8);
   return (size_t)(8 * REP + RPP * REP * hd + REP * len) * 4 + 64;
 }
-int bzk_pf_attn(hipStream_t s, int dt, const float* qkv, int S, int nq, int nkv, int hd, int pos0, int act, const KvView& kv, int layer, void* out16) {
+int bzk_pf_attn(hipStream_t s, int dt, const float* qkv, int S, int nq, int nkv, int hd, int pos0, int act, const KvView& kv, int layer, void* out16,
+                const int* row_pos, int table_stride, int max_len) {
   const int REP = nq / nkv;
   if (hd % 8 || hd > 256 || (256 % (hd / 8)) || (REP != 1 && REP != 2 && REP != 4 && REP != 8) || kv.dtype != dt)
     BZ_FAIL(BZ_E_UNSUPPORTED, "prefill attention: head_dim %d / group size %d / cache dtype unsupported", hd, REP);
-  const size_t smem = bzk_pf_attn_smem(nq, nkv, hd, pos0 + S);
-  if (smem > 160 * 1024) BZ_FAIL(BZ_E_UNSUPPORTED, "prefill attention: context %d too long for this kernel", pos0 + S);
+  const int ctx = row_pos ? max_len : pos0 + S;
+  const size_t smem = bzk_pf_attn_smem(nq, nkv, hd, ctx);
+  if (smem > 160 * 1024) BZ_FAIL(BZ_E_UNSUPPORTED, "prefill attention: context %d too long for this kernel", ctx);
   const float scale = 1.0f / sqrtf((float)hd);
 #define LAUNCH_PFA(DT, R) do { \
     static bool attr_done = false; \
     if (!attr_done) { BZ_HIP(hipFuncSetAttribute((const void*)k_pf_attn<DT, DT, R>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_done = true; } \
-    hipLaunchKernelGGL((k_pf_attn<DT, DT, R>), dim3(S, nkv), dim3(256), smem, s, qkv, nq, nkv, hd, pos0, act, kv, layer, scale, (unsigned short*)out16); } while (0)
+    hipLaunchKernelGGL((k_pf_attn<DT, DT, R>), dim3(S, nkv), dim3(256), smem, s, qkv, nq, nkv, hd, pos0, act, kv, layer, scale, (unsigned short*)out16, row_pos, table_stride); } while (0)
 #define LAUNCH_PFA_R(DT) do { if (REP == 1) LAUNCH_PFA(DT, 1); else if (REP == 2) LAUNCH_PFA(DT, 2); else if (REP == 4) LAUNCH_PFA(DT, 4); else LAUNCH_PFA(DT, 8); } while (0)
   if (dt == BZ_F16) LAUNCH_PFA_R(BZ_F16); else LAUNCH_PFA_R(BZ_BF16);
 #undef LAUNCH_PFA_R

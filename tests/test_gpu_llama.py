@@ -301,15 +301,18 @@ def test_generate_with_host_side_sampler_options(device):
         ex.generate(p, 4, use_graph=True, logit_bias={1: 1.0})
 
 
-def test_batched_paged_decode_matches_per_sequence_oracle(device):
-    # batch_decode.rs:35-150: three sequences of different lengths share one block pool (blocks interleaved), one new token each per step
-    model = synth.make_llama("tiny-awq")
+@pytest.mark.parametrize("preset,nseq", [("tiny-awq", 3), ("tiny-awq", 10), ("tiny-bf16", 5), ("tiny-gptq", 4)])
+def test_batched_paged_decode_matches_per_sequence_oracle(device, preset, nseq):
+    # batch_decode.rs:35-150: sequences of different lengths share one block pool (blocks interleaved), one new token each per step.
+    # int4 (no act-order) and dense 16-bit models take the weight-sharing multi-row path (10 sequences = two 8-row passes).
+    model = synth.make_llama(preset)
     cfg = model["config"]
     lm, om = runtime.LoadedModel.from_synth(device, model), orc_py.OrcLlama(model)
-    bs = 16
-    pool = runtime.LayeredPagedKvCache(device, cfg["n_layers"], 12, bs, cfg["n_kv_heads"], cfg["head_dim"], _kv_dt(cfg))
-    tables = [[0, 3, 6, 9], [1, 4, 7, 10], [2, 5, 8, 11]]
-    prompts = [synth.prompt_tokens(n, cfg["vocab"], seed=40 + n) for n in (5, 17, 30)]
+    bs, per = 16, 4
+    pool = runtime.LayeredPagedKvCache(device, cfg["n_layers"], nseq * per, bs, cfg["n_kv_heads"], cfg["head_dim"], _kv_dt(cfg))
+    tables = [[i + nseq * j for j in range(per)] for i in range(nseq)]            # interleaved physical blocks
+    plens = [3 + (11 * i) % 40 for i in range(nseq)]
+    prompts = [synth.prompt_tokens(n, cfg["vocab"], seed=40 + i) for i, n in enumerate(plens)]
     okvs, toks, lens = [], [], []
     for p, tb in zip(prompts, tables):
         slots = [tb[i // bs] * bs + i % bs for i in range(len(p))]
@@ -318,12 +321,12 @@ def test_batched_paged_decode_matches_per_sequence_oracle(device):
         lo = om.forward_kv(p, okv, 0)
         _check_logits(lg, lo, cfg["act_dtype"])
         okvs.append(okv); toks.append(int(lo[0].argmax())); lens.append(len(p))
-    for step in range(6):
+    for step in range(5):
         lens = [n + 1 for n in lens]
         slots = [tb[(n - 1) // bs] * bs + (n - 1) % bs for n, tb in zip(lens, tables)]
         got = lm.forward_paged_batch(toks, pool, slots, [tb[:(n + bs - 1) // bs] for n, tb in zip(lens, tables)], lens).to_numpy()
         nxt = []
-        for i in range(3):
+        for i in range(nseq):
             lo = om.forward_kv([toks[i]], okvs[i], lens[i] - 1)
             _check_logits(got[i:i + 1], lo, cfg["act_dtype"])
             nxt.append(int(lo[0].argmax()))
@@ -332,33 +335,3 @@ def test_batched_paged_decode_matches_per_sequence_oracle(device):
         orc_py.lib().orc_kv_free(okv)
     with pytest.raises(L.BlazrHipError):
         lm.forward_paged_batch([1, 2], pool, [0, 1], [[0], [1]], [40, 2])      # 40 tokens do not fit one block
-
-
-@pytest.mark.parametrize("paged", [False, True], ids=["contiguous", "paged"])
-def test_full_width_long_context(device, paged):
-    """The fused attention + o_proj kernel at the real head shape (32q / 8kv x 128) over several 256-position chunks of the cache (online
-    softmax merge across chunks, clamped tail rows, paged block-table walks): 600 cached positions, one layer, oracle logits at the end."""
-    model = synth.make_llama("llama3-8b-awq-2l", n_layers=1, max_seq_len=1024)
-    cfg = model["config"]
-    lm, om = runtime.LoadedModel.from_synth(device, model), orc_py.OrcLlama(model)
-    p = synth.prompt_tokens(600, cfg["vocab"], seed=8)
-    okv = om.new_kv(640)
-    want = om.forward_kv(p, okv, 0)
-    if paged:
-        bs, nb = 16, 48
-        cache = runtime.LayeredPagedKvCache(device, 1, nb, bs, cfg["n_kv_heads"], cfg["head_dim"], L.F16)
-        blocks = list(np.random.default_rng(1).permutation(nb))                     # scattered physical blocks
-        slots = [int(blocks[i // bs]) * bs + i % bs for i in range(640)]
-        got = lm.forward_with_paged_kv_cache(p, cache, slots[:600], blocks, 600, 0).to_numpy()
-        step = lambda tok, pos: lm.forward_with_paged_kv_cache([tok], cache, [slots[pos]], blocks, pos + 1, pos).to_numpy()
-    else:
-        cache = runtime.LayeredKvCache(device, 1, 1, cfg["n_kv_heads"], 64, cfg["max_seq_len"], cfg["head_dim"], L.F16)   # grows 64 -> ... -> 1024
-        got = lm.forward_with_kv_cache(p, cache, 0).to_numpy()
-        step = lambda tok, pos: lm.forward_with_kv_cache([tok], cache, pos).to_numpy()
-    _check_logits(got, want, "f16", factor=1.0)
-    tok = int(want[0].argmax())
-    for i in range(4):
-        lo = om.forward_kv([tok], okv, 600 + i)
-        _check_logits(step(tok, 600 + i), lo, "f16", factor=1.0)
-        tok = int(lo[0].argmax())
-    orc_py.lib().orc_kv_free(okv)
