@@ -77,7 +77,7 @@ def main():
     ap.add_argument("--preset", default="llama3-8b-awq")
     ap.add_argument("--prompt-len", type=int, default=16)   # 16 fixed prompt ids, context <= 144 + warmup
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-tokens", type=int, default=6)
+    ap.add_argument("--cpu-tokens", type=int, default=32)    # ~10 s of CPU work on the GPU box's host cores (bounded sample)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -179,18 +179,29 @@ def main():
         tp0 = time.perf_counter()
         lo = om.forward_kv(prompt, okv, 0)
         t_prefill = time.perf_counter() - tp0
+        def near_tie(row):      # the same guard as the tests: ids are only comparable while the oracle's top-2 gap is not a rounding-level tie
+            srt = np.sort(row)
+            return bool(srt[-1] - srt[-2] < 4e-3 * np.abs(row).max())
         cpu_tokens = [int(lo[0].argmax())]
+        fair = 0 if near_tie(lo[0]) else 1
+        tied = fair == 0
         td0 = time.perf_counter()
         for i in range(n_cpu - 1):
             lo = om.forward_kv([cpu_tokens[-1]], okv, args.prompt_len + i)
             cpu_tokens.append(int(lo[0].argmax()))
+            if not tied:
+                tied = near_tie(lo[0])
+                fair += 0 if tied else 1
         t_decode = time.perf_counter() - td0
         orc_py.lib().orc_kv_free(okv)
         cpu_tok_s = (n_cpu - 1) / t_decode          # bench.rs:299-306: (tokens - 1) / (total - TTFT)
         out["cpu_baseline"] = {"value": round(cpu_tok_s, 3), "unit": "tokens/s", "cores": orc_py.lib().orc_num_threads(), "kind": "port",
                                "sample": "oracle/liborc.so (C + OpenMP), same synthetic weights and prompt: %d-token prefill (%.1f s) + %d greedy "
                                          "decode tokens (%.1f s); host has %d logical CPUs" % (args.prompt_len, t_prefill, n_cpu - 1, t_decode, os.cpu_count())}
-        out["parity"] = {"greedy_ids_match": cpu_tokens == tokens[:n_cpu], "n_tokens": n_cpu, "cpu": cpu_tokens, "gpu": tokens[:n_cpu]}
+        n_cmp = max(fair, 1)
+        n_same = next((i for i, (a, g) in enumerate(zip(cpu_tokens, tokens)) if a != g), min(len(cpu_tokens), len(tokens)))
+        out["parity"] = {"greedy_ids_match": cpu_tokens[:n_cmp] == tokens[:n_cmp], "n_compared": n_cmp, "n_identical_prefix": n_same, "n_tokens": n_cpu,
+                         "note": "ids compared up to the first step whose oracle top-2 gap is a rounding-level tie", "cpu": cpu_tokens[:16], "gpu": tokens[:16]}
 
     if rank == 0:
         print(json.dumps(out))
