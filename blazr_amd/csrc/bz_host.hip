@@ -170,7 +170,8 @@ extern "C" int bz_tensor_copy_from_host(bz_tensor* t, const void* host, size_t b
 }
 extern "C" int bz_event_record(bz_device* d, uint64_t* out) {
   if (!d || !out) BZ_FAIL(BZ_E_INVALID, "null argument");
-  // small ring of reusable events
+  std::lock_guard<std::mutex> dlock__(d->mu);
+  // small ring of reusable events (a recycled id still orders after the work it was first recorded behind: waiting on it is conservative)
   const size_t RING = 64;
   if (d->events.size() < RING) {
     hipEvent_t ev;
@@ -183,14 +184,18 @@ extern "C" int bz_event_record(bz_device* d, uint64_t* out) {
   return BZ_OK;
 }
 extern "C" int bz_event_sync(bz_device* d, uint64_t ev) {
-  if (!d || ev >= d->events.size()) BZ_FAIL(BZ_E_INVALID, "bad event");
-  BZ_HIP(hipEventSynchronize(d->events[ev]));
+  if (!d) BZ_FAIL(BZ_E_INVALID, "bad event");
+  hipEvent_t e;
+  { std::lock_guard<std::mutex> dlock__(d->mu); if (ev >= d->events.size()) BZ_FAIL(BZ_E_INVALID, "bad event"); e = d->events[ev]; }
+  BZ_HIP(hipEventSynchronize(e));
   return BZ_OK;
 }
 extern "C" int bz_tensor_to_host_pipelined(const bz_tensor* t, uint64_t ev, void* host, size_t bytes) {
-  if (!t || !host || ev >= t->dev->events.size()) BZ_FAIL(BZ_E_INVALID, "bad argument");
+  if (!t || !host) BZ_FAIL(BZ_E_INVALID, "bad argument");
   if (bytes > t->nbytes) BZ_FAIL(BZ_E_INVALID, "to_host_pipelined: size");
   bz_device* d = t->dev;
+  std::lock_guard<std::mutex> dlock__(d->mu);       // one copy stream per device: concurrent readers take turns
+  if (ev >= d->events.size()) BZ_FAIL(BZ_E_INVALID, "bad event");
   // the copy waits only for `ev`, on the copy stream: the compute stream keeps running forward(t+1)
   BZ_HIP(hipStreamWaitEvent(d->copy_stream, d->events[ev], 0));
   BZ_HIP(hipMemcpyAsync(host, t->ptr, bytes, hipMemcpyDeviceToHost, d->copy_stream));
@@ -242,6 +247,9 @@ struct DsLayerDev {
 };
 
 struct bz_model {
+  // One step's kernels share the model's workspace (residual stream, accumulator ring, logits), so the enqueue of a step is atomic:
+  // concurrent generate() calls on one model (engine/scheduler.rs:67, startup.rs:234-236) interleave whole steps, never kernels.
+  std::recursive_mutex mu;
   std::vector<DsLayerDev> dlayers;
   float* moe_xn = nullptr; float* moe_gu = nullptr; float* moe_out = nullptr; long long* moe_acc = nullptr; int* moe_sel = nullptr; float* moe_w = nullptr; float* moe_lg = nullptr; unsigned* moe_cnt = nullptr;
   std::vector<MambaLayerDev> mlayers;
@@ -1193,6 +1201,11 @@ extern "C" int bz_paged_kv_seq_len(const bz_paged_kv* kv) { return kv ? kv->seq_
 // ---------------------------------------------------------------------------------------------------------
 __global__ void k_set_int(int* p, int v) { p[0] = v; }
 
+// Graph capture records a step on a private stream, so that other host threads can keep using the device stream meanwhile (a capturing
+// stream refuses their work).  The step functions ask step_stream() instead of reading the device stream directly.
+static thread_local hipStream_t tl_capture_stream = nullptr;
+static hipStream_t step_stream(const bz_model* m) { return tl_capture_stream ? tl_capture_stream : m->dev->stream; }
+
 struct StepIO {
   KvView kv;
   const long long* d_tok;   // token id (device)
@@ -1213,7 +1226,7 @@ struct RingState { int ri = 0; int dirty[3] = {0, 0, 0}; };
 
 // Launch every part of a fused linear.  Returns the VSrc describing its output.
 static int run_fused(bz_model* m, const FusedLinear& F, Pro pro, RingState& rs, VSrc* out) {
-  hipStream_t st = m->dev->stream;
+  hipStream_t st = step_stream(m);
   const int act = m->cfg.act_dtype;
   const int ri = rs.ri, rz = (rs.ri + 1) % 3;
   long long* acc = m->ring[ri];
@@ -1236,7 +1249,7 @@ static int run_fused(bz_model* m, const FusedLinear& F, Pro pro, RingState& rs, 
 
 static int llama_step(bz_model* m, const StepIO& io) {
   const bz_model_config& c = m->cfg;
-  hipStream_t st = m->dev->stream;
+  hipStream_t st = step_stream(m);
   const int H = c.hidden, I = c.inter, act = c.act_dtype;
   const int lend = io.layer_end < 0 ? c.n_layers : io.layer_end;
   int cur = 0;
@@ -1368,7 +1381,7 @@ static int llama_step(bz_model* m, const StepIO& io) {
 //   in_proj GEMV (prologue: residual add + RMSNorm) -> conv1d step + SiLU -> SSM recurrence -> out_proj GEMV (prologue: gate + grouped RMSNorm)
 static int mamba_step(bz_model* m, const StepIO& io) {
   const bz_model_config& c = m->cfg;
-  hipStream_t st = m->dev->stream;
+  hipStream_t st = step_stream(m);
   const int D = c.hidden, DI = c.ssm_d_inner, NH = c.ssm_n_heads, NS = c.ssm_d_state, G = c.ssm_n_groups, KC = c.ssm_conv_kernel, act = c.act_dtype;
   const int conv_dim = DI + 2 * G * NS;
   bz_ssm_state* S = io.ssm;
@@ -1420,7 +1433,7 @@ static int mamba_step(bz_model* m, const StepIO& io) {
 //   MoE layer:   router (norm, top-k) -> grouped gate/up GEMV over the selected + shared experts -> grouped down GEMV -> combine
 static int dsv2_step(bz_model* m, const StepIO& io) {
   const bz_model_config& c = m->cfg;
-  hipStream_t st = m->dev->stream;
+  hipStream_t st = step_stream(m);
   const int H = c.hidden, NH = c.n_heads, R = c.mla_kv_lora_rank, DN = c.mla_nope_dim, DR = c.mla_rope_dim, DV = c.mla_v_dim, act = c.act_dtype;
   const int E = c.moe_n_experts, TK = c.moe_top_k, NS = c.moe_n_shared, MI = c.moe_inter;
   int cur = 0;
@@ -1612,6 +1625,7 @@ static int prefill_dense(bz_model* m, const long long* d_tok, int S, const KvVie
 extern "C" int bz_prefill_matmul(bz_model* m, const char* name, const bz_tensor* x, int S, bz_tensor* y) {
   LinearDev L;
   BZ_TRY(find_linear(m, name, &L));
+  std::lock_guard<std::recursive_mutex> lock__(m->mu);
   if (L.kind != LK_ROWS || (L.wdt != BZ_F16 && L.wdt != BZ_BF16)) BZ_FAIL(BZ_E_UNSUPPORTED, "prefill_matmul: '%s' is not a dense f16 / bf16 weight", name);
   if (!x || !y || x->dtype != BZ_F32 || y->dtype != BZ_F32 || S <= 0 || x->nbytes < (size_t)S * L.K * 4 || y->nbytes < (size_t)S * L.N * 4)
     BZ_FAIL(BZ_E_INVALID, "prefill_matmul: x must be F32 [S,%d], y F32 [S,%d]", L.K, L.N);
@@ -1628,6 +1642,7 @@ extern "C" int bz_prefill_matmul(bz_model* m, const char* name, const bz_tensor*
 
 extern "C" int bz_forward_kv(bz_model* m, const bz_tensor* tokens, int S, bz_kv* kv, int position, bz_tensor* logits_out, uint32_t flags) {
   BZ_TRY(check_fwd(m, tokens, S));
+  std::lock_guard<std::recursive_mutex> lock__(m->mu);
   BZ_TRACE("forward_kv: S=%d position=%d", S, position);
   if (m->cfg.arch == BZ_ARCH_MAMBA2) BZ_FAIL(BZ_E_INVALID, "forward_kv: model has no KV cache (use bz_forward_ssm)");
   if (!kv || kv->layers != m->cfg.n_layers || kv->n_kv != m->cfg.n_kv_heads || kv->hd != m->cfg.head_dim) BZ_FAIL(BZ_E_INVALID, "forward_kv: cache does not match the model");
@@ -1656,6 +1671,7 @@ extern "C" int bz_forward_kv(bz_model* m, const bz_tensor* tokens, int S, bz_kv*
 extern "C" int bz_forward_paged(bz_model* m, const bz_tensor* tokens, int S, bz_paged_kv* kv, const bz_tensor* slot_mapping,
                                 const bz_tensor* block_table, int n_table, int seq_len_k, int start_pos, bz_tensor* logits_out, uint32_t flags) {
   BZ_TRY(check_fwd(m, tokens, S));
+  std::lock_guard<std::recursive_mutex> lock__(m->mu);
   if (m->cfg.arch != BZ_ARCH_LLAMA) BZ_FAIL(BZ_E_UNSUPPORTED, "forward_paged: llama family only (Mamba2 has no KV cache; the MLA latent cache is contiguous in this build)");
   if (!kv || kv->layers != m->cfg.n_layers || kv->n_kv != m->cfg.n_kv_heads || kv->hd != m->cfg.head_dim) BZ_FAIL(BZ_E_INVALID, "forward_paged: cache does not match the model");
   if (!slot_mapping || slot_mapping->dtype != BZ_I32 || slot_mapping->nbytes < (size_t)S * 4) BZ_FAIL(BZ_E_INVALID, "forward_paged: slot_mapping must be I32[S]");
@@ -1690,6 +1706,7 @@ extern "C" int bz_forward_paged(bz_model* m, const bz_tensor* tokens, int S, bz_
 extern "C" int bz_forward_paged_batch(bz_model* m, const bz_tensor* tokens, int N, bz_paged_kv* kv, const bz_tensor* slot_mapping, const bz_tensor* block_table,
                                       int max_blocks, const int32_t* seq_lens, bz_tensor* logits_out) {
   BZ_TRY(check_fwd(m, tokens, N));
+  std::lock_guard<std::recursive_mutex> lock__(m->mu);
   if (m->cfg.arch != BZ_ARCH_LLAMA) BZ_FAIL(BZ_E_UNSUPPORTED, "forward_paged_batch: llama family only");
   if (!kv || kv->layers != m->cfg.n_layers || kv->n_kv != m->cfg.n_kv_heads || kv->hd != m->cfg.head_dim) BZ_FAIL(BZ_E_INVALID, "forward_paged_batch: cache does not match the model");
   if (!slot_mapping || slot_mapping->dtype != BZ_I32 || slot_mapping->nbytes < (size_t)N * 4) BZ_FAIL(BZ_E_INVALID, "forward_paged_batch: slot_mapping must be I32[N]");
@@ -1743,6 +1760,7 @@ static int check_ssm(bz_model* m, bz_ssm_state* st) {
 
 extern "C" int bz_forward_ssm(bz_model* m, const bz_tensor* tokens, int S, bz_ssm_state* st, bz_tensor* logits_out, uint32_t flags) {
   BZ_TRY(check_fwd(m, tokens, S));
+  std::lock_guard<std::recursive_mutex> lock__(m->mu);
   BZ_TRY(check_ssm(m, st));
   const bool all = flags & BZ_FWD_ALL_LOGITS;
   for (int s = 0; s < S; s++) {
@@ -1757,6 +1775,7 @@ extern "C" int bz_forward_ssm(bz_model* m, const bz_tensor* tokens, int S, bz_ss
 
 extern "C" int bz_forward_embed(bz_model* m, const bz_tensor* tokens, int S, bz_tensor* hidden_out) {
   BZ_TRY(check_fwd(m, tokens, S));
+  std::lock_guard<std::recursive_mutex> lock__(m->mu);
   const int H = m->cfg.hidden;
   if (!hidden_out || hidden_out->dtype != BZ_F32 || hidden_out->nbytes < (size_t)S * H * 4) BZ_FAIL(BZ_E_INVALID, "forward_embed: hidden_out must be F32 [S,hidden]");
   for (int s = 0; s < S; s++)
@@ -1766,6 +1785,7 @@ extern "C" int bz_forward_embed(bz_model* m, const bz_tensor* tokens, int S, bz_
 
 extern "C" int bz_forward_layers_range(bz_model* m, bz_tensor* hidden, bz_tensor* prev_mlp, int* has_prev, int S, bz_kv* kv, int start, int end, int position) {
   if (!m || !m->finalized) BZ_FAIL(BZ_E_INVALID, "model not finalized");
+  std::lock_guard<std::recursive_mutex> lock__(m->mu);
   if (m->cfg.arch != BZ_ARCH_LLAMA) BZ_FAIL(BZ_E_UNSUPPORTED, "layers_range: llama family only");
   const int H = m->cfg.hidden;
   if (!hidden || hidden->dtype != BZ_F32 || hidden->nbytes < (size_t)S * H * 4 || !prev_mlp || prev_mlp->dtype != BZ_F32 || prev_mlp->nbytes < (size_t)S * H * 4 || !has_prev)
@@ -1793,6 +1813,7 @@ extern "C" int bz_forward_layers_range(bz_model* m, bz_tensor* hidden, bz_tensor
 
 extern "C" int bz_forward_head(bz_model* m, const bz_tensor* hidden, const bz_tensor* prev_mlp, int has_prev, int S, bz_tensor* logits_out, uint32_t flags) {
   if (!m || !m->finalized) BZ_FAIL(BZ_E_INVALID, "model not finalized");
+  std::lock_guard<std::recursive_mutex> lock__(m->mu);
   const int H = m->cfg.hidden;
   if (!hidden || hidden->dtype != BZ_F32 || hidden->nbytes < (size_t)S * H * 4) BZ_FAIL(BZ_E_INVALID, "forward_head: hidden must be F32 [S,hidden]");
   if (has_prev && (!prev_mlp || prev_mlp->nbytes < (size_t)S * H * 4)) BZ_FAIL(BZ_E_INVALID, "forward_head: prev_mlp must be F32 [S,hidden]");
@@ -1832,6 +1853,7 @@ static int profile_collect(BzTimingSink& sink, int rc, bz_kernel_time* out, int 
 extern "C" int bz_profile_step(bz_model* m, bz_kv* kv, int64_t token, int position, int iters, bz_kernel_time* out, int max_out, int* n_out) {
   if (m && m->finalized && m->cfg.arch == BZ_ARCH_MAMBA2) BZ_FAIL(BZ_E_UNSUPPORTED, "profile_step: model has no KV cache (use bz_profile_step_ssm)");
   if (!m || !m->finalized || !kv || !out || !n_out || iters <= 0 || max_out <= 0) BZ_FAIL(BZ_E_INVALID, "profile_step: bad argument");
+  std::lock_guard<std::recursive_mutex> lock__(m->mu);
   if (token < 0 || token >= m->cfg.vocab || position < 0 || position + iters > m->cfg.max_seq_len) BZ_FAIL(BZ_E_INVALID, "profile_step: token/position out of range");
   BZ_HIP(hipSetDevice(m->dev->id));
   BZ_TRY(kv_grow(kv, position + iters));
@@ -1858,6 +1880,7 @@ extern "C" int bz_profile_step(bz_model* m, bz_kv* kv, int64_t token, int positi
 
 extern "C" int bz_profile_step_ssm(bz_model* m, bz_ssm_state* ssm, int64_t token, int iters, bz_kernel_time* out, int max_out, int* n_out) {
   if (!m || !m->finalized || !out || !n_out || iters <= 0 || max_out <= 0) BZ_FAIL(BZ_E_INVALID, "profile_step_ssm: bad argument");
+  std::lock_guard<std::recursive_mutex> lock__(m->mu);
   BZ_TRY(check_ssm(m, ssm));
   if (token < 0 || token >= m->cfg.vocab) BZ_FAIL(BZ_E_INVALID, "profile_step_ssm: token out of range");
   BZ_HIP(hipSetDevice(m->dev->id));
@@ -1947,6 +1970,7 @@ extern "C" int bz_logits_to_token(bz_device* dev, const bz_tensor* logits, int64
   if (token_out->dtype != BZ_I64 || token_out->nbytes < 8) BZ_FAIL(BZ_E_INVALID, "logits_to_token: token_out must be I64[1]");
   if (n > 0 && (!ids || !cnts || ids->dtype != BZ_I64 || cnts->dtype != BZ_I32 || ids->nbytes < (size_t)n * 8 || cnts->nbytes < (size_t)n * 4))
     BZ_FAIL(BZ_E_INVALID, "logits_to_token: ids I64[n] / cnts I32[n] required");
+  std::lock_guard<std::mutex> dlock__(dev->mu);
   BZ_HIP(hipSetDevice(dev->id));
   float* scratch = dev->scratch;
   if (temperature < 0.0f) BZ_FAIL(BZ_E_INVALID, "logits_to_token: negative temperature");
@@ -1995,10 +2019,16 @@ static int graph_capture_common(bz_decode_graph* g, const KvView& view) {
   StepIO io{};
   io.kv = view; io.d_tok = g->tok_buf; io.d_pos = g->pos; io.final_args = &fa; io.ssm = g->ssm;
   BZ_TRACE("graph: begin capture");
-  BZ_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+  hipStream_t cap = nullptr;
+  BZ_HIP(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
+  hipError_t eb = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal);
+  if (eb != hipSuccess) { hipStreamDestroy(cap); BZ_FAIL(BZ_E_HIP, "hipStreamBeginCapture failed: %s", hipGetErrorString(eb)); }
+  tl_capture_stream = cap;
   int rc = model_step(m, io);
+  tl_capture_stream = nullptr;
   hipGraph_t graph = nullptr;
-  hipError_t e = hipStreamEndCapture(st, &graph);
+  hipError_t e = hipStreamEndCapture(cap, &graph);
+  hipStreamDestroy(cap);
   BZ_TRACE("graph: end capture rc=%d hip=%d", rc, (int)e);
   if (rc != BZ_OK) { if (graph) hipGraphDestroy(graph); return rc; }
   if (e != hipSuccess) BZ_FAIL(BZ_E_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
@@ -2011,6 +2041,7 @@ static int graph_capture_common(bz_decode_graph* g, const KvView& view) {
 
 extern "C" int bz_decode_graph_capture(bz_model* m, bz_kv* kv, bz_decode_graph** out) {
   if (!m || !m->finalized || !kv || !out) BZ_FAIL(BZ_E_INVALID, "graph capture: bad argument");
+  std::lock_guard<std::recursive_mutex> lock__(m->mu);
   if (m->cfg.arch == BZ_ARCH_MAMBA2) BZ_FAIL(BZ_E_INVALID, "graph capture: model has no KV cache (use bz_decode_graph_capture_ssm)");
   if (kv->layers != m->cfg.n_layers || kv->n_kv != m->cfg.n_kv_heads || kv->hd != m->cfg.head_dim) BZ_FAIL(BZ_E_INVALID, "graph capture: cache does not match the model");
   BZ_HIP(hipSetDevice(m->dev->id));
@@ -2026,6 +2057,7 @@ extern "C" int bz_decode_graph_capture(bz_model* m, bz_kv* kv, bz_decode_graph**
 }
 extern "C" int bz_decode_graph_capture_paged(bz_model* m, bz_paged_kv* kv, int max_blocks, bz_decode_graph** out) {
   if (!m || !m->finalized || !kv || !out || max_blocks <= 0) BZ_FAIL(BZ_E_INVALID, "graph capture: bad argument");
+  std::lock_guard<std::recursive_mutex> lock__(m->mu);
   if (m->cfg.arch != BZ_ARCH_LLAMA) BZ_FAIL(BZ_E_INVALID, "graph capture: model has no KV cache (use bz_decode_graph_capture_ssm)");
   BZ_HIP(hipSetDevice(m->dev->id));
   bz_decode_graph* g = new bz_decode_graph();
@@ -2040,6 +2072,7 @@ extern "C" int bz_decode_graph_capture_paged(bz_model* m, bz_paged_kv* kv, int m
 }
 extern "C" int bz_decode_graph_capture_ssm(bz_model* m, bz_ssm_state* st, bz_decode_graph** out) {
   if (!m || !m->finalized || !out) BZ_FAIL(BZ_E_INVALID, "graph capture: bad argument");
+  std::lock_guard<std::recursive_mutex> lock__(m->mu);
   BZ_TRY(check_ssm(m, st));
   BZ_HIP(hipSetDevice(m->dev->id));
   bz_decode_graph* g = new bz_decode_graph();
@@ -2070,6 +2103,7 @@ extern "C" int bz_decode_graph_seed(bz_decode_graph* g, int64_t token, int posit
 }
 extern "C" int bz_decode_graph_replay(bz_decode_graph* g) {
   if (!g || !g->exec) BZ_FAIL(BZ_E_INVALID, "null graph");
+  std::lock_guard<std::recursive_mutex> lock__(g->m->mu);
   hipStream_t st = g->m->dev->stream;
   BZ_HIP(hipGraphLaunch(g->exec, st));
   BZ_HIP(hipEventRecord(g->evs[g->replays % g->evs.size()], st));
@@ -2285,6 +2319,7 @@ static int find_linear(bz_model* m, const char* name, LinearDev* out) {
 extern "C" int bz_quant_matmul(bz_model* m, const char* name, const bz_tensor* x, int S, bz_tensor* y) {
   LinearDev L;
   BZ_TRY(find_linear(m, name, &L));
+  std::lock_guard<std::recursive_mutex> lock__(m->mu);
   if (!x || !y || x->dtype != BZ_F32 || y->dtype != BZ_F32 || S <= 0 || x->nbytes < (size_t)S * L.K * 4 || y->nbytes < (size_t)S * L.N * 4)
     BZ_FAIL(BZ_E_INVALID, "quant_matmul: x must be F32 [S,%d], y F32 [S,%d]", L.K, L.N);
   BZ_HIP(hipSetDevice(m->dev->id));

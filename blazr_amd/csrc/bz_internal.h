@@ -8,6 +8,7 @@
 #include <vector>
 #include <unordered_map>
 #include <memory>
+#include <mutex>
 #include "../../include/blazr_hip.h"
 
 // ---------------------------------------------------------------------------------------------------------
@@ -76,6 +77,7 @@ struct bz_device {
   uint64_t event_counter = 0;
   float* scratch = nullptr;   // 4 KiB device scratch (sampling partials)
   void* samp_ws = nullptr;    // non-greedy sampling workspace (bz_sample.hip), grown on demand
+  std::mutex mu;              // guards the per-device scratch / sampling workspace / staging ring (concurrent generate() calls share a device)
   int refs = 1;               // the handle itself + every live child object (tensor/model/cache/graph)
 };
 void bz_dev_retain(bz_device* d);

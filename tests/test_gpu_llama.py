@@ -335,3 +335,29 @@ def test_batched_paged_decode_matches_per_sequence_oracle(device, preset, nseq):
         orc_py.lib().orc_kv_free(okv)
     with pytest.raises(L.BlazrHipError):
         lm.forward_paged_batch([1, 2], pool, [0, 1], [[0], [1]], [40, 2])      # 40 tokens do not fit one block
+
+
+def test_concurrent_generate_calls_on_one_model(device):
+    # scheduler.rs:67 / startup.rs:234-236: several generate() calls share one Executor (one model, one device stream), each with its own cache.
+    # A decode step's kernels share the model's workspace, so the library serialises whole steps; results must equal the sequential ones.
+    import threading
+    lm = runtime.LoadedModel.from_synth(device, synth.make_llama("tiny-awq"))
+    prompts = [synth.prompt_tokens(5 + 3 * i, 1024, seed=60 + i) for i in range(6)]
+    kw = [dict(), dict(use_graph=True), dict(paged=True), dict(temperature=0.8, seed=3), dict(repeat_penalty=1.3), dict(paged=True, use_graph=True)]
+    want = [runtime.Executor(lm).generate(p, 24, **k).tolist() for p, k in zip(prompts, kw)]
+    got, errs = [None] * 6, []
+
+    def work(i):
+        try:
+            for _ in range(3):
+                got[i] = runtime.Executor(lm).generate(prompts[i], 24, **kw[i]).tolist()
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(6)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    assert got == want
