@@ -70,16 +70,41 @@ __device__ __forceinline__ float vsrc_get(const VSrc& s, int i, int act) {
 }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+// Cross-lane reductions without the LDS permute network (__shfl_xor compiles to ds_bpermute: ~100 clocks a step on the
+// latency chain of every prologue).  DPP covers lanes of a 16-lane row (the compiler folds the control into the add),
+// V_PERMLANE{16,32}_SWAP (gfx950) cover rows and halves.  Every step is symmetric (both partners form a+b), so all lanes
+// of a group end with the same bits.
+#define DPP_XOR1 0xB1     // quad_perm [1,0,3,2]
+#define DPP_XOR2 0x4E     // quad_perm [2,3,0,1]
+#define DPP_HMIRROR 0x141 // row_half_mirror: lane i <- 7 - i   (pairs the two quads of an 8-lane half once quads are uniform)
+#define DPP_MIRROR 0x140  // row_mirror:      lane i <- 15 - i  (pairs the two halves of a row once halves are uniform)
+typedef unsigned bz_u2_t __attribute__((ext_vector_type(2)));
+template <int CTRL> __device__ __forceinline__ int dpp_get(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+template <int CTRL> __device__ __forceinline__ float dpp_get(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true)); }
+struct OpAdd { template <class T> __device__ __forceinline__ static T f(T a, T b) { return a + b; } };
+struct OpMax { __device__ __forceinline__ static float f(float a, float b) { return fmaxf(a, b); } };
+// reduce over aligned groups of N = 4, 8, 16 lanes (result in every lane of the group)
+template <int N, class Op, class T>
+__device__ __forceinline__ T grp_reduce(T v) {
+  v = Op::f(v, dpp_get<DPP_XOR1>(v));
+  v = Op::f(v, dpp_get<DPP_XOR2>(v));
+  if (N >= 8) v = Op::f(v, dpp_get<DPP_HMIRROR>(v));
+  if (N >= 16) v = Op::f(v, dpp_get<DPP_MIRROR>(v));
   return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
-  return v;
+// combine lane l with l ^ 16 / l ^ 32 (rows uniform is not required: a true exchange)
+template <class Op>
+__device__ __forceinline__ float xrow16(float v) {
+  const bz_u2_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return Op::f(__uint_as_float(r.x), __uint_as_float(r.y));
 }
+template <class Op>
+__device__ __forceinline__ float xrow32(float v) {
+  const bz_u2_t r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return Op::f(__uint_as_float(r.x), __uint_as_float(r.y));
+}
+__device__ __forceinline__ float wave_sum(float v) { return xrow32<OpAdd>(xrow16<OpAdd>(grp_reduce<16, OpAdd>(v))); }
+__device__ __forceinline__ float wave_max(float v) { return xrow32<OpMax>(xrow16<OpMax>(grp_reduce<16, OpMax>(v))); }
 // deterministic block sum over 256 threads; red: LDS float[4]
 __device__ __forceinline__ float block_sum256(float v, float* red) {
   v = wave_sum(v);
@@ -386,8 +411,7 @@ __device__ __forceinline__ void quant_x128(const float* xs, int KR, unsigned* xh
     float am = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; i++) am = fmaxf(am, fabsf(v[i]));
-#pragma unroll
-    for (int m = 1; m <= 8; m <<= 1) am = fmaxf(am, __shfl_xor(am, m, 64));
+    am = grp_reduce<16, OpMax>(am);
     const float inv = am > 0.f ? XQ_MAX / am : 0.f;
     unsigned wh[2] = {0, 0}, wm[2] = {0, 0}, wl[2] = {0, 0};
     int s_hi = 0, s_mid = 0, s_lo = 0, b_hi = 0, b_mid = 0, b_lo = 0;
@@ -404,11 +428,8 @@ __device__ __forceinline__ void quant_x128(const float* xs, int KR, unsigned* xh
       s_hi += hi; s_mid += mid; s_lo += lo;
       if (i >= 4) { b_hi += hi; b_mid += mid; b_lo += lo; }
     }
-#pragma unroll
-    for (int m = 1; m <= 8; m <<= 1) {
-      s_hi += __shfl_xor(s_hi, m, 64); s_mid += __shfl_xor(s_mid, m, 64); s_lo += __shfl_xor(s_lo, m, 64);
-      b_hi += __shfl_xor(b_hi, m, 64); b_mid += __shfl_xor(b_mid, m, 64); b_lo += __shfl_xor(b_lo, m, 64);
-    }
+    s_hi = grp_reduce<16, OpAdd>(s_hi); s_mid = grp_reduce<16, OpAdd>(s_mid); s_lo = grp_reduce<16, OpAdd>(s_lo);
+    b_hi = grp_reduce<16, OpAdd>(b_hi); b_mid = grp_reduce<16, OpAdd>(b_mid); b_lo = grp_reduce<16, OpAdd>(b_lo);
     if (on) {
       *(uint2*)(xh + e0 / 4) = make_uint2(wh[0], wh[1]);
       *(uint2*)(xm + e0 / 4) = make_uint2(wm[0], wm[1]);
@@ -502,8 +523,7 @@ __device__ __forceinline__ void quant_x64(const float* a, unsigned* xh, unsigned
   float am = 0.f;
 #pragma unroll
   for (int i = 0; i < 8; i++) am = fmaxf(am, fabsf(v[i]));
-#pragma unroll
-  for (int m = 1; m <= 4; m <<= 1) am = fmaxf(am, __shfl_xor(am, m, 64));
+  am = grp_reduce<8, OpMax>(am);
   const float inv = am > 0.f ? XQ_MAX / am : 0.f;
   unsigned wh[2] = {0, 0}, wm[2] = {0, 0}, wl[2] = {0, 0};
   int s_hi = 0, s_mid = 0, s_lo = 0, b_hi = 0, b_mid = 0, b_lo = 0;
@@ -520,11 +540,8 @@ __device__ __forceinline__ void quant_x64(const float* a, unsigned* xh, unsigned
     s_hi += hi; s_mid += mid; s_lo += lo;
     if (i >= 4) { b_hi += hi; b_mid += mid; b_lo += lo; }
   }
-#pragma unroll
-  for (int m = 1; m <= 4; m <<= 1) {
-    s_hi += __shfl_xor(s_hi, m, 64); s_mid += __shfl_xor(s_mid, m, 64); s_lo += __shfl_xor(s_lo, m, 64);
-    b_hi += __shfl_xor(b_hi, m, 64); b_mid += __shfl_xor(b_mid, m, 64); b_lo += __shfl_xor(b_lo, m, 64);
-  }
+  s_hi = grp_reduce<8, OpAdd>(s_hi); s_mid = grp_reduce<8, OpAdd>(s_mid); s_lo = grp_reduce<8, OpAdd>(s_lo);
+  b_hi = grp_reduce<8, OpAdd>(b_hi); b_mid = grp_reduce<8, OpAdd>(b_mid); b_lo = grp_reduce<8, OpAdd>(b_lo);
   if (on) {
     *(uint2*)(xh + t * 2) = make_uint2(wh[0], wh[1]);
     *(uint2*)(xm + t * 2) = make_uint2(wm[0], wm[1]);
@@ -1025,7 +1042,7 @@ __device__ __forceinline__ void quant_x32(const float* xs, int KR, unsigned* xh,
     float am = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; i++) am = fmaxf(am, fabsf(v[i]));
-    am = fmaxf(am, __shfl_xor(am, 1, 64)); am = fmaxf(am, __shfl_xor(am, 2, 64));   // 4 lanes x 8 = one 32-k chunk
+    am = grp_reduce<4, OpMax>(am);   // 4 lanes x 8 = one 32-k chunk
     const float inv = am > 0.f ? XQ_MAX / am : 0.f;
     unsigned wh[2] = {0, 0}, wm[2] = {0, 0}, wl[2] = {0, 0};
     int sa[3] = {0, 0, 0}, sb[3] = {0, 0, 0};
@@ -1047,16 +1064,16 @@ __device__ __forceinline__ void quant_x32(const float* xs, int KR, unsigned* xh,
       const bool second = (threadIdx.x & 2) != 0;
 #pragma unroll
       for (int q = 0; q < 3; q++) {
-        const int mine = sa[q] + __shfl_xor(sa[q], 1, 64);          // sum of my half
-        const int other = __shfl_xor(mine, 2, 64);                  // the other half
+        const int mine = sa[q] + dpp_get<DPP_XOR1>(sa[q]);          // sum of my half
+        const int other = dpp_get<DPP_XOR2>(mine);                  // the other half
         sa[q] = second ? other : mine;                              // Sa = first half
         sb[q] = second ? mine : other;                              // Sb = second half
       }
     } else if (FMT == GQ_Q4K) {
 #pragma unroll
       for (int q = 0; q < 3; q++) {
-        sa[q] += __shfl_xor(sa[q], 1, 64); sa[q] += __shfl_xor(sa[q], 2, 64);
-        sb[q] += __shfl_xor(sb[q], 1, 64); sb[q] += __shfl_xor(sb[q], 2, 64);
+        sa[q] = grp_reduce<4, OpAdd>(sa[q]);
+        sb[q] = grp_reduce<4, OpAdd>(sb[q]);
       }
     }
     if (on) {
@@ -2085,21 +2102,21 @@ __device__ __forceinline__ void unpack2(unsigned u, float& x0, float& x1) {
   else { x0 = __uint_as_float(u << 16); x1 = __uint_as_float(u & 0xffff0000u); }
 }
 
-template <int KVDT, int FUSE, int TPW>
-__global__ __launch_bounds__(256) void k_attn2(AttnArgs a, const uint4* __restrict__ W, const __half* __restrict__ S,
+template <int KVDT, int FUSE, int TPW, int NW>   // NW waves per block: each owns 256/NW positions of a chunk
+__global__ __launch_bounds__(NW * 64) void k_attn2(AttnArgs a, const uint4* __restrict__ W, const __half* __restrict__ S,
                                                const unsigned char* __restrict__ Z, const float* __restrict__ bias, int CS, long long* acc) {
-  // Mapping: a chunk is 256 positions, wave w owns positions c0 + 64 w .. +63.  One wave-wide 16-byte load fetches 4 whole
+  // Mapping: a chunk is 256 positions, wave w owns positions c0 + PW w .. +PW-1 (PW = 256/NW).  One wave-wide 16-byte load fetches 4 whole
   // rows (1 KiB contiguous in the contiguous cache): lane l holds piece (l & 15) = elements 8*(l&15)..+7 of row 4 i + (l >> 4)
-  // for load i = 0..15.  A row's score is a 4-DOT2 partial per lane reduced over its 16 lanes -- and lands exactly in the
+  // for load i = 0..PW/4-1.  A row's score is a 4-DOT2 partial per lane reduced over its 16 lanes -- and lands exactly in the
   // lanes that hold that row's V pieces, so P.V accumulates in registers (8 outputs per lane) with no LDS image.
-  constexpr int HD = 128, half = 64;
+  constexpr int HD = 128, half = 64, PW = 256 / NW, NL = PW / 4, OW = NW > 8 ? 8 : NW;   // OW waves carry o_proj tiles
   extern __shared__ __attribute__((aligned(16))) char smem[];
   unsigned* q2 = (unsigned*)smem;             // [64] packed q pairs
   unsigned* k2 = q2 + 64;                     // [64] packed new key
   unsigned* v2 = k2 + 64;                     // [64] packed new value
-  float* wred = (float*)(v2 + 64);            // [8]
-  float* pout = wred + 8;                     // [4][128] PV partials of the 4 waves
-  float* outh = pout + 512;                   // [128] head output (FUSE)
+  float* wred = (float*)(v2 + 64);            // [2 NW]
+  float* pout = wred + 2 * NW;                // [NW][128] PV partials of the waves
+  float* outh = pout + NW * 128;                   // [128] head output (FUSE)
   unsigned* xh = (unsigned*)(outh + 128);     // [32] x3
   unsigned* xm = xh + 32;
   unsigned* xl = xm + 32;
@@ -2135,18 +2152,18 @@ __global__ __launch_bounds__(256) void k_attn2(AttnArgs a, const uint4* __restri
   // (unconditional loads at clamped rows: rows >= len get weight 0 below; the cache is zero-initialised and only ever holds
   //  finite values, so 0 * stale == 0)
   const int pmax = ncache > 0 ? ncache - 1 : 0;
-  uint4 kr[16], vr[16];
-  size_t ro[16];
+  uint4 kr[NL], vr[NL];
+  size_t ro[NL];
 #pragma unroll
-  for (int i = 0; i < 16; i++) ro[i] = kv_row_off(kv, a.layer, kvh, min(wave * 64 + 4 * i + rsub, pmax)) + piece * 8;
+  for (int i = 0; i < NL; i++) ro[i] = kv_row_off(kv, a.layer, kvh, min(wave * PW + 4 * i + rsub, pmax)) + piece * 8;
 #pragma unroll
-  for (int i = 0; i < 16; i++) {
+  for (int i = 0; i < NL; i++) {
     kr[i] = *(const uint4*)((const unsigned short*)kv.k + ro[i]);
     vr[i] = *(const uint4*)((const unsigned short*)kv.v + ro[i]);
   }
   // (0) o_proj slab of this wave (FUSE): in flight through the whole attention
   uint4 Wb[FUSE ? TPW : 1][4];
-  const int t0 = (cs * 4 + wave) * TPW;
+  const int t0 = (cs * OW + wave % OW) * TPW;   // waves >= OW mirror a slab (L2 hits) and skip the atomics
   if (FUSE) {
     const int K = a.nq * HD;
 #pragma unroll
@@ -2191,24 +2208,24 @@ __global__ __launch_bounds__(256) void k_attn2(AttnArgs a, const uint4* __restri
     if (c0 > 0) {
       __syncthreads();   // the previous chunk's pout / wred reads are done
 #pragma unroll
-      for (int i = 0; i < 16; i++) ro[i] = kv_row_off(kv, a.layer, kvh, min(c0 + wave * 64 + 4 * i + rsub, pmax)) + piece * 8;
+      for (int i = 0; i < NL; i++) ro[i] = kv_row_off(kv, a.layer, kvh, min(c0 + wave * PW + 4 * i + rsub, pmax)) + piece * 8;
 #pragma unroll
-      for (int i = 0; i < 16; i++) {
+      for (int i = 0; i < NL; i++) {
         kr[i] = *(const uint4*)((const unsigned short*)kv.k + ro[i]);
         vr[i] = *(const uint4*)((const unsigned short*)kv.v + ro[i]);
       }
     }
     // the token being appended (position pos == ncache) comes from LDS
-    float sc_[16];
+    float sc_[NL];
     float mloc = -INFINITY;
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-      const int p = c0 + wave * 64 + 4 * i + rsub;
+    for (int i = 0; i < NL; i++) {
+      const int p = c0 + wave * PW + 4 * i + rsub;
       uint4 kk = kr[i];
       if (!a.q_only && p == pos) { kk = ((const uint4*)k2)[piece]; vr[i] = ((const uint4*)v2)[piece]; }
       float d = dot2acc<KVDT>(kk.x, qq.x, 0.f);
       d = dot2acc<KVDT>(kk.y, qq.y, d); d = dot2acc<KVDT>(kk.z, qq.z, d); d = dot2acc<KVDT>(kk.w, qq.w, d);
-      d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64); d += __shfl_xor(d, 8, 64);
+      d = grp_reduce<16, OpAdd>(d);
       sc_[i] = (p < len) ? d * scale : -INFINITY;
       mloc = fmaxf(mloc, sc_[i]);
     }
@@ -2216,11 +2233,13 @@ __global__ __launch_bounds__(256) void k_attn2(AttnArgs a, const uint4* __restri
     const float wm = wave_max(mloc);
     if (lane == 0) wred[wave] = wm;
     __syncthreads();
-    const float Mc = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
+    float Mc = wred[0];
+#pragma unroll
+    for (int w = 1; w < NW; w++) Mc = fmaxf(Mc, wred[w]);
     float accv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float lsum = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
+    for (int i = 0; i < NL; i++) {
       const float e = (sc_[i] == -INFINITY) ? 0.f : expf(sc_[i] - Mc);
       lsum += e;
       float v[8];
@@ -2230,20 +2249,21 @@ __global__ __launch_bounds__(256) void k_attn2(AttnArgs a, const uint4* __restri
       for (int q = 0; q < 8; q++) accv[q] = fmaf(e, v[q], accv[q]);
     }
     // rows of the wave: the 4 lane groups hold different rows -> reduce over xor 16, 32 (the 16 lanes of a group are replicas for lsum)
-    lsum += __shfl_xor(lsum, 16, 64); lsum += __shfl_xor(lsum, 32, 64);
+    lsum = xrow32<OpAdd>(xrow16<OpAdd>(lsum));
 #pragma unroll
-    for (int q = 0; q < 8; q++) { accv[q] += __shfl_xor(accv[q], 16, 64); accv[q] += __shfl_xor(accv[q], 32, 64); }
+    for (int q = 0; q < 8; q++) accv[q] = xrow32<OpAdd>(xrow16<OpAdd>(accv[q]));
     STAMP(4);
     if (lane < 16) {
       *(float4*)(pout + wave * 128 + piece * 8) = make_float4(accv[0], accv[1], accv[2], accv[3]);
       *(float4*)(pout + wave * 128 + piece * 8 + 4) = make_float4(accv[4], accv[5], accv[6], accv[7]);
     }
-    if (lane == 0) wred[4 + wave] = lsum;
+    if (lane == 0) wred[NW + wave] = lsum;
     __syncthreads();
     STAMP(5);
     if (tid < 128) {
-      const float oc = (pout[tid] + pout[128 + tid]) + (pout[256 + tid] + pout[384 + tid]);
-      const float Lc = (wred[4] + wred[5]) + (wred[6] + wred[7]);
+      float oc = 0.f, Lc = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; w += 2) { oc += pout[w * 128 + tid] + pout[(w + 1) * 128 + tid]; Lc += wred[NW + w] + wred[NW + w + 1]; }
       const float Mn = fmaxf(Mrun, Mc);
       const float fa = (Mrun == -INFINITY) ? 0.f : expf(Mrun - Mn), fb = expf(Mc - Mn);
       Orun = Orun * fa + oc * fb;
@@ -2280,31 +2300,41 @@ __global__ __launch_bounds__(256) void k_attn2(AttnArgs a, const uint4* __restri
     q4g_consume(Wb[t], 0, xh4, xm4, xl4, gpar, sc[t], zp[t], y);
     const int n = (t0 + t) * 64 + lane;
     if (bias != nullptr && hq == 0) y += bias[n];
-    atomicAdd((unsigned long long*)(acc + n), (unsigned long long)f2fix(y));
+    if (wave < OW) atomicAdd((unsigned long long*)(acc + n), (unsigned long long)f2fix(y));
   }
   STAMP(8);
 #undef STAMP
 }
 
-static size_t attn2_smem() { return (size_t)(64 * 3 + 8 + 512 + 128 + 96 + 8) * 4; }
+static size_t attn2_smem(int nw) { return (size_t)(64 * 3 + 2 * nw + nw * 128 + 128 + 96 + 8) * 4; }
 
-// picks the column-slice count so that nq * CS ~ 256 workgroups; returns 0 when the fused form does not apply
-int bzk_attn_oproj_slices(const AttnArgs& a, const LinearDev& L) {
+// picks the column-slice count so that nq * CS ~ 256 workgroups, and the wave count (8 waves halve the per-wave attention chain);
+// returns 0 when the fused form does not apply
+static int attn_oproj_plan(const AttnArgs& a, const LinearDev& L, int& NW) {
+  NW = 0;
   if (a.hd != 128 || L.kind != LK_Q4G || L.perm != nullptr || L.K != a.nq * 128 || a.q_only) return 0;
+  static const bool nw4 = getenv("BZ_ATTN_NW4") != nullptr;
   const int NT = L.N / 64;
-  for (int cs = 8; cs >= 1; cs >>= 1) {
-    if (NT % (cs * 4) == 0 && NT / (cs * 4) <= 2 && a.nq * cs <= 1024) return cs;
+  static const char* nwe = getenv("BZ_ATTN_NW");
+  const int nw0 = nw4 ? 4 : (nwe ? atoi(nwe) : 8);
+  for (int nw = nw0; nw >= 4; nw >>= 1) {
+    const int ow = nw > 8 ? 8 : nw;
+    for (int cs = 8; cs >= 1; cs >>= 1)
+      if (NT % (cs * ow) == 0 && NT / (cs * ow) <= 2 && a.nq * cs <= 1024) { NW = nw; return cs; }
   }
   return 0;
 }
+int bzk_attn_oproj_slices(const AttnArgs& a, const LinearDev& L) { int nw; return attn_oproj_plan(a, L, nw); }
 
 int bzk_attn_oproj(hipStream_t s, const AttnArgs& a, const LinearDev& L, long long* acc) {
-  const int CS = bzk_attn_oproj_slices(a, L);
+  int NW;
+  const int CS = attn_oproj_plan(a, L, NW);
   if (CS <= 0) BZ_FAIL(BZ_E_INVALID, "attn+o_proj fusion does not apply to this shape");
-  const int TPW = (L.N / 64) / (CS * 4);
-#define LAUNCH_AO(DT, T) BZ_LAUNCH("attn+o_proj", L.algo_bytes, (k_attn2<DT, 1, T>), dim3(a.nq * CS), dim3(256), attn2_smem(), s, a, (const uint4*)L.w, \
-    (const __half*)L.scales, (const unsigned char*)L.zeros, L.bias, CS, acc)
-#define LAUNCH_AO_T(DT) do { if (TPW == 1) LAUNCH_AO(DT, 1); else LAUNCH_AO(DT, 2); } while (0)
+  const int TPW = (L.N / 64) / (CS * (NW > 8 ? 8 : NW));
+#define LAUNCH_AO(DT, T, W_) BZ_LAUNCH("attn+o_proj", L.algo_bytes, (k_attn2<DT, 1, T, W_>), dim3(a.nq * CS), dim3(W_ * 64), attn2_smem(W_), s, a, \
+    (const uint4*)L.w, (const __half*)L.scales, (const unsigned char*)L.zeros, L.bias, CS, acc)
+#define LAUNCH_AO_T(DT) do { if (NW == 16) { if (TPW == 1) LAUNCH_AO(DT, 1, 16); else LAUNCH_AO(DT, 2, 16); } else if (NW == 8) { if (TPW == 1) LAUNCH_AO(DT, 1, 8); else LAUNCH_AO(DT, 2, 8); } \
+                             else { if (TPW == 1) LAUNCH_AO(DT, 1, 4); else LAUNCH_AO(DT, 2, 4); } } while (0)
   if (a.kv.dtype == BZ_F16) LAUNCH_AO_T(BZ_F16);
   else if (a.kv.dtype == BZ_BF16) LAUNCH_AO_T(BZ_BF16);
   else BZ_FAIL(BZ_E_UNSUPPORTED, "attn+o_proj fusion: f32 KV cache not built");
@@ -2320,9 +2350,9 @@ int bzk_attn_decode(hipStream_t s, const AttnArgs& a) {
 #define LAUNCH_ATT_DT(HD) do { if (a.kv.dtype == BZ_F16) LAUNCH_ATT(HD, BZ_F16); else if (a.kv.dtype == BZ_BF16) LAUNCH_ATT(HD, BZ_BF16); \
                                else LAUNCH_ATT(HD, BZ_F32); } while (0)
   if (a.hd == 128 && a.kv.dtype != BZ_F32) {
-    if (a.kv.dtype == BZ_F16) BZ_LAUNCH("attn_decode", 0.0, (k_attn2<BZ_F16, 0, 1>), dim3(a.nq), dim3(256), attn2_smem(), s, a, (const uint4*)nullptr,
+    if (a.kv.dtype == BZ_F16) BZ_LAUNCH("attn_decode", 0.0, (k_attn2<BZ_F16, 0, 1, 8>), dim3(a.nq), dim3(512), attn2_smem(8), s, a, (const uint4*)nullptr,
                                         (const __half*)nullptr, (const unsigned char*)nullptr, (const float*)nullptr, 1, (long long*)nullptr);
-    else BZ_LAUNCH("attn_decode", 0.0, (k_attn2<BZ_BF16, 0, 1>), dim3(a.nq), dim3(256), attn2_smem(), s, a, (const uint4*)nullptr,
+    else BZ_LAUNCH("attn_decode", 0.0, (k_attn2<BZ_BF16, 0, 1, 8>), dim3(a.nq), dim3(512), attn2_smem(8), s, a, (const uint4*)nullptr,
                    (const __half*)nullptr, (const unsigned char*)nullptr, (const float*)nullptr, 1, (long long*)nullptr);
   }
   else if (a.hd == 64) LAUNCH_ATT_DT(64);
@@ -2588,8 +2618,7 @@ __global__ __launch_bounds__(256) void k_ssm_step(SsmArgs a) {
         }
       }
     }
-    acc += __shfl_xor(acc, 1, 64);
-    acc += __shfl_xor(acc, 2, 64);
+    acc = grp_reduce<4, OpAdd>(acc);
     if (p < HD && q == 0) {
       float yv = round_act(acc + Dh * xv, a.act);
       if (a.z) { yv = round_act(yv * round_act(silu_f(a.z[hd * HD + p]), a.act), a.act); vsq += yv * yv; }
