@@ -265,6 +265,7 @@ struct bz_model {
   std::unordered_map<std::string, LinearDev> named;  // views for the op-level API
   std::vector<void*> owned;                           // device allocations to free
   float* cos_t = nullptr; float* sin_t = nullptr;
+  float* rope_cur = nullptr;   // [cos | sin] row of the current position (staged by the embed kernel)
   // workspace
   float* hbuf[2] = {nullptr, nullptr};
   // batched-prefill workspace (bz_prefill.hip), allocated on first use for `pf_rows` prompt rows
@@ -781,6 +782,7 @@ extern "C" int bz_model_finalize(bz_model* m) {
   void* p;
   BZ_TRY(dev_alloc(m, &p, cs.size() * 4)); m->cos_t = (float*)p; BZ_HIP(hipMemcpy(p, cs.data(), cs.size() * 4, hipMemcpyHostToDevice));
   BZ_TRY(dev_alloc(m, &p, sn.size() * 4)); m->sin_t = (float*)p; BZ_HIP(hipMemcpy(p, sn.data(), sn.size() * 4, hipMemcpyHostToDevice));
+  BZ_TRY(dev_alloc(m, &p, 256 * 4)); m->rope_cur = (float*)p; BZ_HIP(hipMemset(p, 0, 256 * 4));
 
   // workspace
   m->ring_n = std::max(std::max((nq + 2 * nkv) * hd, 2 * I), std::max(H, nq * hd));
@@ -1256,8 +1258,9 @@ static int llama_step(bz_model* m, const StepIO& io) {
   RingState rs;
   VSrc prev{nullptr, 0};
   if (io.do_embed) {
-    BZ_TRY(bzk_embed(st, m->embed, m->embed_dt, io.d_tok, H, act, m->hbuf[cur]));
+    BZ_TRY(bzk_embed(st, m->embed, m->embed_dt, io.d_tok, H, act, m->hbuf[cur], io.d_pos, m->cos_t, m->sin_t, c.head_dim / 2, m->rope_cur));
   } else {
+    if (io.d_pos && lend > io.layer_start) BZ_TRY(bzk_rope_row(st, io.d_pos, m->cos_t, m->sin_t, c.head_dim / 2, m->rope_cur));
     BZ_HIP(hipMemcpyAsync(m->hbuf[cur], io.hidden_in, (size_t)H * 4, hipMemcpyDeviceToDevice, st));
     if (io.prev_in) { prev.p = io.prev_in; prev.fix = 0; }
   }
@@ -1284,16 +1287,16 @@ static int llama_step(bz_model* m, const StepIO& io) {
     cur ^= 1;
 
     AttnArgs aa{};
-    aa.qkv = qkv; aa.cos_t = m->cos_t; aa.sin_t = m->sin_t; aa.interleaved = c.rope_interleaved; aa.pos = io.d_pos;
+    aa.qkv = qkv; aa.cos_t = m->cos_t; aa.sin_t = m->sin_t; aa.interleaved = c.rope_interleaved; aa.pos = io.d_pos; aa.rope_cur = m->rope_cur;
     aa.nq = c.n_heads; aa.nkv = c.n_kv_heads; aa.hd = c.head_dim; aa.act = act; aa.kv = io.kv; aa.layer = l; aa.out = m->attn_out;
     aa.zero_buf = nullptr; aa.zero_n = 0; aa.q_only = 0;
     static long long* attn_stamps = nullptr;
     static const bool attn_stamps_on = getenv("BZ_ATTN_STAMPS") != nullptr, attn_stamps_print = getenv("BZ_ATTN_STAMPS_PRINT") != nullptr;
     if (attn_stamps_on) {
-      if (!attn_stamps) { hipMalloc(&attn_stamps, 256); hipMemset(attn_stamps, 0, 256); }
+      if (!attn_stamps) { hipMalloc(&attn_stamps, 512); hipMemset(attn_stamps, 0, 512); }
       if (l == 1) {
         if (attn_stamps_print) {
-          long long hst[16]; hipStreamSynchronize(st); hipMemcpy(hst, attn_stamps, 128, hipMemcpyDeviceToHost);
+          long long hst[64]; hipStreamSynchronize(st); hipMemcpy(hst, attn_stamps, 512, hipMemcpyDeviceToHost);
           fprintf(stderr, "[bz] attn stamps (us since entry):");
           for (int q = 1; q <= 8; q++) fprintf(stderr, " %d:%.2f", q, (hst[q] - hst[0]) / 100.0);
           fprintf(stderr, "\n");

@@ -177,13 +177,16 @@ int bzk_dequant_rows(hipStream_t s, const LinearDev& L, float* out);
 int bzk_repack_gq(hipStream_t s, int kind, const void* raw, int N, int K, void* wq, void* wh, void* hd, void* dd);
 int bzk_dequant_gq(hipStream_t s, const LinearDev& L, float* out);
 int bzk_argmax_partials(hipStream_t s, const float* v, long long n, float* pval, int* pidx, int nb);
-int bzk_embed(hipStream_t s, const void* table, int tdt, const long long* tok, int H, int act, float* h_out);
+int bzk_embed(hipStream_t s, const void* table, int tdt, const long long* tok, int H, int act, float* h_out, const int* pos = nullptr,
+              const float* cos_t = nullptr, const float* sin_t = nullptr, int half = 0, float* rope_cur = nullptr);   // rope_cur: stage [cos|sin] of *pos
+int bzk_rope_row(hipStream_t s, const int* pos, const float* cos_t, const float* sin_t, int half, float* rope_cur);
 int bzk_fix_to_f32(hipStream_t s, const long long* acc, int n, int act, float* out);
 int bzk_zero64(hipStream_t s, long long* p, int n);
 
 struct AttnArgs {
   VSrc qkv;                 // [nq*hd | nkv*hd | nkv*hd]
   const float* cos_t; const float* sin_t; // [max_pos][hd/2]
+  const float* rope_cur;    // [cos hd/2 | sin hd/2] of *pos, staged by bzk_embed / bzk_rope_row (head_dim 128 kernels read this, not the tables)
   int interleaved;
   const int* pos;           // device scalar: position of the new token
   int nq, nkv, hd, act;
@@ -275,3 +278,44 @@ struct SsmArgs {
   float* vss;            // [n_heads]
 };
 int bzk_ssm_step(hipStream_t s, const SsmArgs& a);
+
+#if defined(__HIPCC__)
+// ---------------------------------------------------------------------------------------------------------
+// device-side cross-lane helpers (shared by the kernel files)
+// ---------------------------------------------------------------------------------------------------------
+// Cross-lane reductions without the LDS permute network (__shfl_xor compiles to ds_bpermute: ~100 clocks a step on the
+// latency chain of every prologue).  DPP covers lanes of a 16-lane row (the compiler folds the control into the add),
+// V_PERMLANE{16,32}_SWAP (gfx950) cover rows and halves.  Every step is symmetric (both partners form a+b), so all lanes
+// of a group end with the same bits.
+#define DPP_XOR1 0xB1     // quad_perm [1,0,3,2]
+#define DPP_XOR2 0x4E     // quad_perm [2,3,0,1]
+#define DPP_HMIRROR 0x141 // row_half_mirror: lane i <- 7 - i   (pairs the two quads of an 8-lane half once quads are uniform)
+#define DPP_MIRROR 0x140  // row_mirror:      lane i <- 15 - i  (pairs the two halves of a row once halves are uniform)
+typedef unsigned bz_u2_t __attribute__((ext_vector_type(2)));
+template <int CTRL> __device__ __forceinline__ int dpp_get(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+template <int CTRL> __device__ __forceinline__ float dpp_get(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true)); }
+struct OpAdd { template <class T> __device__ __forceinline__ static T f(T a, T b) { return a + b; } };
+struct OpMax { __device__ __forceinline__ static float f(float a, float b) { return fmaxf(a, b); } };
+// reduce over aligned groups of N = 4, 8, 16 lanes (result in every lane of the group)
+template <int N, class Op, class T>
+__device__ __forceinline__ T grp_reduce(T v) {
+  v = Op::f(v, dpp_get<DPP_XOR1>(v));
+  v = Op::f(v, dpp_get<DPP_XOR2>(v));
+  if (N >= 8) v = Op::f(v, dpp_get<DPP_HMIRROR>(v));
+  if (N >= 16) v = Op::f(v, dpp_get<DPP_MIRROR>(v));
+  return v;
+}
+// combine lane l with l ^ 16 / l ^ 32 (rows uniform is not required: a true exchange)
+template <class Op>
+__device__ __forceinline__ float xrow16(float v) {
+  const bz_u2_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return Op::f(__uint_as_float(r.x), __uint_as_float(r.y));
+}
+template <class Op>
+__device__ __forceinline__ float xrow32(float v) {
+  const bz_u2_t r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return Op::f(__uint_as_float(r.x), __uint_as_float(r.y));
+}
+__device__ __forceinline__ float wave_sum(float v) { return xrow32<OpAdd>(xrow16<OpAdd>(grp_reduce<16, OpAdd>(v))); }
+__device__ __forceinline__ float wave_max(float v) { return xrow32<OpMax>(xrow16<OpMax>(grp_reduce<16, OpMax>(v))); }
+#endif  // __HIPCC__

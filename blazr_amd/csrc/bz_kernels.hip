@@ -70,41 +70,6 @@ __device__ __forceinline__ float vsrc_get(const VSrc& s, int i, int act) {
 }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
 
-// Cross-lane reductions without the LDS permute network (__shfl_xor compiles to ds_bpermute: ~100 clocks a step on the
-// latency chain of every prologue).  DPP covers lanes of a 16-lane row (the compiler folds the control into the add),
-// V_PERMLANE{16,32}_SWAP (gfx950) cover rows and halves.  Every step is symmetric (both partners form a+b), so all lanes
-// of a group end with the same bits.
-#define DPP_XOR1 0xB1     // quad_perm [1,0,3,2]
-#define DPP_XOR2 0x4E     // quad_perm [2,3,0,1]
-#define DPP_HMIRROR 0x141 // row_half_mirror: lane i <- 7 - i   (pairs the two quads of an 8-lane half once quads are uniform)
-#define DPP_MIRROR 0x140  // row_mirror:      lane i <- 15 - i  (pairs the two halves of a row once halves are uniform)
-typedef unsigned bz_u2_t __attribute__((ext_vector_type(2)));
-template <int CTRL> __device__ __forceinline__ int dpp_get(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
-template <int CTRL> __device__ __forceinline__ float dpp_get(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true)); }
-struct OpAdd { template <class T> __device__ __forceinline__ static T f(T a, T b) { return a + b; } };
-struct OpMax { __device__ __forceinline__ static float f(float a, float b) { return fmaxf(a, b); } };
-// reduce over aligned groups of N = 4, 8, 16 lanes (result in every lane of the group)
-template <int N, class Op, class T>
-__device__ __forceinline__ T grp_reduce(T v) {
-  v = Op::f(v, dpp_get<DPP_XOR1>(v));
-  v = Op::f(v, dpp_get<DPP_XOR2>(v));
-  if (N >= 8) v = Op::f(v, dpp_get<DPP_HMIRROR>(v));
-  if (N >= 16) v = Op::f(v, dpp_get<DPP_MIRROR>(v));
-  return v;
-}
-// combine lane l with l ^ 16 / l ^ 32 (rows uniform is not required: a true exchange)
-template <class Op>
-__device__ __forceinline__ float xrow16(float v) {
-  const bz_u2_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  return Op::f(__uint_as_float(r.x), __uint_as_float(r.y));
-}
-template <class Op>
-__device__ __forceinline__ float xrow32(float v) {
-  const bz_u2_t r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  return Op::f(__uint_as_float(r.x), __uint_as_float(r.y));
-}
-__device__ __forceinline__ float wave_sum(float v) { return xrow32<OpAdd>(xrow16<OpAdd>(grp_reduce<16, OpAdd>(v))); }
-__device__ __forceinline__ float wave_max(float v) { return xrow32<OpMax>(xrow16<OpMax>(grp_reduce<16, OpMax>(v))); }
 // deterministic block sum over 256 threads; red: LDS float[4]
 __device__ __forceinline__ float block_sum256(float v, float* red) {
   v = wave_sum(v);
@@ -115,9 +80,12 @@ __device__ __forceinline__ float block_sum256(float v, float* red) {
   return t;
 }
 
+// NTH = threads per block as a compile-time constant: blockDim.x is a 16-bit field of the dispatch packet, i.e. a VECTOR load plus a full
+// s_waitcnt vmcnt(0) in front of everything that follows (gridDim.x is a scalar load batched with the kernel arguments)
+template <int NTH>
 __device__ __forceinline__ void zero_duty(long long* zb, int zn) {
   if (zb)
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < zn; i += gridDim.x * blockDim.x) zb[i] = 0;
+    for (int i = blockIdx.x * NTH + threadIdx.x; i < zn; i += gridDim.x * NTH) zb[i] = 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -396,8 +364,9 @@ __device__ __forceinline__ void xfinish(const Pro& p, int KR, const XRegs<MODE, 
 // ---------------------------------------------------------------------------------------------------------
 #define XQ_MAX 8355000.0f  // < 127*65536 + 127*256 + 127
 
+template <int NTH>
 __device__ __forceinline__ void quant_x128(const float* xs, int KR, unsigned* xh, unsigned* xm, unsigned* xl, int4* gpar) {
-  for (int base = 0; base < KR; base += (int)blockDim.x * 8) {
+  for (int base = 0; base < KR; base += NTH * 8) {
     const int e0 = base + threadIdx.x * 8;
     const bool on = e0 < KR;
     float v[8];
@@ -586,7 +555,10 @@ __global__ __launch_bounds__(512) void k_mlp_q4g(const uint4* __restrict__ Wgu, 
   const int gbeg = wave * GPW;                // G == 8 * GPW
   const int tbeg = wave * TPW;                // H / 64 == 8 * TPW
   const int GD = I >> 7, gd = sl >> 1;        // down's quantisation group of these 64 k
-  zero_duty(zero_buf, zero_n);
+  // all kernel arguments in ONE scalar-load batch (the compiler otherwise fetches late-used ones lazily: a ~0.3 us round trip each time)
+  asm volatile("" :: "s"(zero_buf), "s"(zero_n), "s"(acc), "s"(pro.h_in), "s"(pro.src.p), "s"(pro.norm_w), "s"(pro.h_out), "s"(pro.H),
+               "s"(pro.act), "s"(H), "s"(I), "s"(Wgu), "s"(Sgu), "s"(Zgu), "s"(Wd), "s"(Sd), "s"(Zd));
+  zero_duty<512>(zero_buf, zero_n);
 
   // (1) prologue loads: full-H pass, 4 contiguous elements per thread per 2048 (h, deferred residual, norm weight) --
   //     loads only, unconditional (H == 2048 * NJ), arithmetic after the weight loads have been issued
@@ -648,7 +620,7 @@ __global__ __launch_bounds__(512) void k_mlp_q4g(const uint4* __restrict__ Wgu, 
                                      round_act(nw[j].z * round_act(hv[j][2] * rs, pro.act), pro.act), round_act(nw[j].w * round_act(hv[j][3] * rs, pro.act), pro.act));
   }
   __syncthreads();
-  quant_x128(xs, H, xh, xm, xl, gpar);
+  quant_x128<512>(xs, H, xh, xm, xl, gpar);
   __syncthreads();
 
   // (4) gate / up partial dot products over this wave's k-groups; group b+2 is requested as soon as group b's registers are free,
@@ -755,7 +727,7 @@ __global__ __launch_bounds__(256) void k_gemv_q4g(const uint4* __restrict__ W, c
     pro.stamps[(blockIdx.x == 0 ? 0 : 8) + (i)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
   QSTAMP(0);
 
-  zero_duty(zero_buf, zero_n);
+  zero_duty<256>(zero_buf, zero_n);
 
   // (1) group scales / zero points of this wave's tile: GW*128 B + GW*64 B, contiguous -> wide loads now, LDS later
   const int ntc = wave_on ? nt : 0;          // clamped tile for addressing: loads are unconditional (see xload)
@@ -796,7 +768,7 @@ __global__ __launch_bounds__(256) void k_gemv_q4g(const uint4* __restrict__ W, c
 #pragma unroll
     for (int j = 0; j < 4; j++) if (lane + 64 * j < GW * 16) sZw[lane + 64 * j] = zreg[j];
   }
-  if (!(pro.dbg & 4)) quant_x128(xs, KR, xh, xm, xl, gpar);
+  if (!(pro.dbg & 4)) quant_x128<256>(xs, KR, xh, xm, xl, gpar);
   __syncthreads();
   QSTAMP(3);
   if (!wave_on) return;
@@ -852,7 +824,9 @@ __global__ __launch_bounds__(512) void k_gemv_q4g_slim(const uint4* __restrict__
   const int ksl = blockIdx.x % NKS, tq = (blockIdx.x / NKS) * 8 + wave;
   const bool q_on = tq * 64 < N;
   const int tqc = q_on ? tq : 0;
-  zero_duty(zero_buf, zero_n);
+  asm volatile("" :: "s"(zero_buf), "s"(zero_n), "s"(acc), "s"(pro.h_in), "s"(pro.src.p), "s"(pro.norm_w), "s"(pro.h_out), "s"(pro.H),
+               "s"(pro.act), "s"(H), "s"(N), "s"(W), "s"(S), "s"(Z), "s"(bias));   // one scalar-load batch for all arguments
+  zero_duty<512>(zero_buf, zero_n);
   // (1) prologue loads (L2-resident): h, deferred residual, this slice's norm weights
   const bool hasprev = pro.src.p != nullptr;
   const void* prevp = hasprev ? pro.src.p : (const void*)pro.h_in;
@@ -904,7 +878,7 @@ __global__ __launch_bounds__(512) void k_gemv_q4g_slim(const uint4* __restrict__
                                            round_act(nw.z * round_act(v.z * rs, pro.act), pro.act), round_act(nw.w * round_act(v.w * rs, pro.act), pro.act));
   }
   __syncthreads();
-  quant_x128(xs, 256, xh, xm, xl, gpar);
+  quant_x128<512>(xs, 256, xh, xm, xl, gpar);
   __syncthreads();
   if (!q_on) return;
   float y = 0.f;
@@ -961,7 +935,7 @@ __global__ __launch_bounds__(512) void k_gemm_q4g_rows(const uint4* __restrict__
     *(float4*)(xs + xr * 256 + lane * 4) = on ? make_float4(v[0], v[1], v[2], v[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   __syncthreads();
-  quant_x128(xs, 8 * 256, xh, xm, xl, gpar);       // 16 groups of 128: group index = row * 2 + (group of the slice)
+  quant_x128<512>(xs, 8 * 256, xh, xm, xl, gpar);       // 16 groups of 128: group index = row * 2 + (group of the slice)
   __syncthreads();
   if (!q_on) return;
   const int n = tq * 64 + lane;
@@ -1028,7 +1002,7 @@ enum { GQ_Q80 = 0, GQ_Q4K = 1, GQ_Q6K = 2 };
 
 template <int FMT>
 __device__ __forceinline__ void quant_x32(const float* xs, int KR, unsigned* xh, unsigned* xm, unsigned* xl, int4* cpar) {
-  for (int base = 0; base < KR; base += (int)blockDim.x * 8) {
+  for (int base = 0; base < KR; base += 256 * 8) {
     const int e0 = base + threadIdx.x * 8;
     const bool on = e0 < KR;
     float v[8];
@@ -1133,7 +1107,7 @@ __global__ __launch_bounds__(256) void k_gemv_gq(const uint4* __restrict__ Wq, c
   const bool wave_on = nt * 64 < N;
   const int ntc = wave_on ? nt : 0;
   const int k0 = ks * KR;
-  zero_duty(zero_buf, zero_n);
+  zero_duty<256>(zero_buf, zero_n);
 
   XRegs<MODE, FIX, MAXJ, GQ_E> xr;
   xload<MODE, FIX, MAXJ, GQ_E>(pro, k0, KR, xr);
@@ -1373,7 +1347,7 @@ __device__ __forceinline__ void rows_body(const void* __restrict__ W, const floa
   issue(s0);
   issue(s1);
   __builtin_amdgcn_sched_barrier(0);
-  zero_duty(zero_buf, zero_n);
+  zero_duty<256>(zero_buf, zero_n);
   const float4* xs4;
   if (!SPLIT || pro.mode == PRO_GATED) {
     // whole vector in LDS (the gated norm needs every element of its group anyway)
@@ -1830,7 +1804,15 @@ int bzk_dequant_rows(hipStream_t s, const LinearDev& L, float* out) {
 // ---------------------------------------------------------------------------------------------------------
 // small kernels
 // ---------------------------------------------------------------------------------------------------------
-__global__ void k_embed(const void* table, int tdt, const long long* tok, int H, int act, float* h) {
+// embedding row of the new token; block 0 also stages the RoPE row of the new position at a FIXED address ([cos half | sin half]), so that the
+// attention kernels' cos/sin loads do not depend on the position word (one memory latency off every layer's critical path)
+__global__ void k_embed(const void* table, int tdt, const long long* tok, int H, int act, float* h, const int* pos, const float* cos_t,
+                        const float* sin_t, int half, float* rope_cur) {
+  if (rope_cur != nullptr && blockIdx.x == 0 && threadIdx.x < 2 * half) {
+    const int p = pos[0], i = threadIdx.x % half;
+    rope_cur[threadIdx.x] = threadIdx.x < half ? cos_t[(size_t)p * half + i] : sin_t[(size_t)p * half + i];
+  }
+  if (table == nullptr) return;
   const long long t = tok[0];
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < H; i += gridDim.x * blockDim.x) {
     const size_t idx = (size_t)t * H + i;
@@ -1841,8 +1823,17 @@ __global__ void k_embed(const void* table, int tdt, const long long* tok, int H,
     h[i] = round_act(v, act);
   }
 }
-int bzk_embed(hipStream_t s, const void* table, int tdt, const long long* tok, int H, int act, float* h) {
-  BZ_LAUNCH("embed", (double)H * (tdt == BZ_F32 ? 4 : 2), k_embed, dim3((H + 255) / 256), dim3(256), 0, s, table, tdt, tok, H, act, h);
+int bzk_embed(hipStream_t s, const void* table, int tdt, const long long* tok, int H, int act, float* h, const int* pos, const float* cos_t,
+              const float* sin_t, int half, float* rope_cur) {
+  if (rope_cur != nullptr && (2 * half > 256 || !pos || !cos_t || !sin_t)) BZ_FAIL(BZ_E_INVALID, "embed: bad RoPE staging arguments");
+  BZ_LAUNCH("embed", (double)H * (tdt == BZ_F32 ? 4 : 2), k_embed, dim3((H + 255) / 256), dim3(256), 0, s, table, tdt, tok, H, act, h, pos, cos_t, sin_t,
+            half, rope_cur);
+  BZ_HIP(hipGetLastError());
+  return BZ_OK;
+}
+int bzk_rope_row(hipStream_t s, const int* pos, const float* cos_t, const float* sin_t, int half, float* rope_cur) {
+  if (2 * half > 256 || !pos || !cos_t || !sin_t || !rope_cur) BZ_FAIL(BZ_E_INVALID, "rope_row: bad arguments");
+  hipLaunchKernelGGL(k_embed, dim3(1), dim3(256), 0, s, (const void*)nullptr, 0, (const long long*)nullptr, 0, 0, (float*)nullptr, pos, cos_t, sin_t, half, rope_cur);
   BZ_HIP(hipGetLastError());
   return BZ_OK;
 }
@@ -1983,7 +1974,7 @@ __global__ __launch_bounds__(256) void k_attn_decode(AttnArgs a) {
   const int len = a.q_only ? pos : pos + 1;
   const int ncache = pos;                 // positions [0, ncache) come from the cache; `pos` itself (if any) from LDS
   const KvView& kv = a.kv;
-  zero_duty(a.zero_buf, a.zero_n);
+  zero_duty<256>(a.zero_buf, a.zero_n);
 
   if (!a.q_only) {
     const float* cr = a.cos_t + (size_t)pos * half;
@@ -2102,21 +2093,51 @@ __device__ __forceinline__ void unpack2(unsigned u, float& x0, float& x1) {
   else { x0 = __uint_as_float(u << 16); x1 = __uint_as_float(u & 0xffff0000u); }
 }
 
-template <int KVDT, int FUSE, int TPW, int NW>   // NW waves per block: each owns 256/NW positions of a chunk
+// branch-free accessors for the activation source (f32 or 2^-32 fixed point): both loads are unconditional so that the compiler can batch them
+__device__ __forceinline__ void vsrc_issue(const void* p, int fix, int i, unsigned& lo, unsigned& hi) {
+  const unsigned* u = (const unsigned*)p;
+  const size_t e = (size_t)i << fix;
+  lo = u[e]; hi = u[e + fix];
+}
+__device__ __forceinline__ float vsrc_finish(int fix, unsigned lo, unsigned hi, int act) {
+  const float f = round_act(fix2f((long long)(((unsigned long long)hi << 32) | lo)), act);
+  return fix ? f : __uint_as_float(lo);
+}
+template <int PAGED>
+__device__ __forceinline__ size_t kv_row_off_t(const KvView& kv, int layer, int kvh, int p) {
+  if (PAGED) {
+    const int blk = kv.block_table[p / kv.bs];
+    return (size_t)layer * kv.layer_stride + (((size_t)blk * kv.n_kv + kvh) * kv.bs + (p % kv.bs)) * kv.hd;
+  }
+  return (size_t)layer * kv.layer_stride + ((size_t)kvh * kv.cap + p) * kv.hd;
+}
+
+template <int KVDT, int FUSE, int TPW, int NW, int PAGED>   // NW waves per block: each owns 256/NW positions of a chunk
 __global__ __launch_bounds__(NW * 64) void k_attn2(AttnArgs a, const uint4* __restrict__ W, const __half* __restrict__ S,
                                                const unsigned char* __restrict__ Z, const float* __restrict__ bias, int CS, long long* acc) {
   // Mapping: a chunk is 256 positions, wave w owns positions c0 + PW w .. +PW-1 (PW = 256/NW).  One wave-wide 16-byte load fetches 4 whole
   // rows (1 KiB contiguous in the contiguous cache): lane l holds piece (l & 15) = elements 8*(l&15)..+7 of row 4 i + (l >> 4)
   // for load i = 0..PW/4-1.  A row's score is a 4-DOT2 partial per lane reduced over its 16 lanes -- and lands exactly in the
   // lanes that hold that row's V pieces, so P.V accumulates in registers (8 outputs per lane) with no LDS image.
-  constexpr int HD = 128, half = 64, PW = 256 / NW, NL = PW / 4, OW = NW > 8 ? 8 : NW;   // OW waves carry o_proj tiles
+  //
+  // Prologue discipline (measured with s_memrealtime stamps per wave):
+  //  * every global load up to the first barrier is unconditional per lane (clamped indices, selects instead of branches) and batched -- a load
+  //    under a divergent branch costs a full s_waitcnt vmcnt(0), which used to serialise five ~1.4 us memory latencies here;
+  //  * all kernel arguments are fetched in one scalar-load batch; blockDim is never read (a vector load from the dispatch packet);
+  //  * cos/sin come from a row staged at a fixed address by the embed kernel, so RoPE does not wait for position -> table;
+  //  * the CU's vector-memory path moves 64 B/clk, so a full 256-row K/V chunk (128 KiB per block) is ~1 us of issue at ANY context length:
+  //    waves whose positions lie beyond the context skip their loads and their score / PV work.
+  constexpr int HD = 128, half = 64, PW = 256 / NW, NL = PW / 4, OW = NW > 8 ? 8 : NW, NTH = NW * 64;   // OW waves carry o_proj tiles
+  asm volatile("" :: "s"(a.zero_buf), "s"(a.zero_n), "s"(a.kv.k), "s"(a.kv.v), "s"(a.kv.cap), "s"(a.kv.layer_stride), "s"(a.layer), "s"(a.act),
+               "s"(a.interleaved), "s"(a.rope_cur), "s"(a.qkv.p), "s"(a.qkv.fix), "s"(a.nq), "s"(a.nkv), "s"(a.q_only), "s"(a.pos), "s"(W), "s"(S),
+               "s"(Z), "s"(bias), "s"(CS), "s"(acc), "s"(a.out), "s"(a.stamps), "s"(a.kv.bs), "s"(a.kv.n_kv));   // one scalar-load batch for all arguments
   extern __shared__ __attribute__((aligned(16))) char smem[];
   unsigned* q2 = (unsigned*)smem;             // [64] packed q pairs
   unsigned* k2 = q2 + 64;                     // [64] packed new key
   unsigned* v2 = k2 + 64;                     // [64] packed new value
   float* wred = (float*)(v2 + 64);            // [2 NW]
   float* pout = wred + 2 * NW;                // [NW][128] PV partials of the waves
-  float* outh = pout + NW * 128;                   // [128] head output (FUSE)
+  float* outh = pout + NW * 128;              // [128] head output (FUSE)
   unsigned* xh = (unsigned*)(outh + 128);     // [32] x3
   unsigned* xm = xh + 32;
   unsigned* xl = xm + 32;
@@ -2127,41 +2148,32 @@ __global__ __launch_bounds__(NW * 64) void k_attn2(AttnArgs a, const uint4* __re
   const int piece = lane & 15, rsub = lane >> 4;
 #define STAMP(i) do { if (a.stamps && blockIdx.x == 0 && tid == 0) a.stamps[i] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
   STAMP(0);
-  const int pos = a.pos[0];
-  const int len = a.q_only ? pos : pos + 1, ncache = pos;
   const KvView& kv = a.kv;
-  zero_duty(a.zero_buf, a.zero_n);
-
-  // (0a) the q/k/v finishing's own loads first (vmcnt is in-order: what is issued first returns first)
-  float px0 = 0.f, px1 = 0.f, pc = 0.f, ps = 0.f;
-  if (!a.q_only) {
-    if (tid < 2 * half) {
-      const int hh = tid / half, i = tid % half;
-      const int base = hh == 0 ? hq * HD : a.nq * HD + kvh * HD;
-      const int ia = a.interleaved ? 2 * i : i, ib = a.interleaved ? 2 * i + 1 : i + half;
-      px0 = vsrc_get(a.qkv, base + ia, a.act); px1 = vsrc_get(a.qkv, base + ib, a.act);
-      pc = a.cos_t[(size_t)pos * half + i]; ps = a.sin_t[(size_t)pos * half + i];
-    } else if (tid < 2 * half + 64) {
-      const int j = tid - 2 * half;
-      const int vb = a.nq * HD + a.nkv * HD + kvh * HD;
-      px0 = vsrc_get(a.qkv, vb + 2 * j, a.act); px1 = vsrc_get(a.qkv, vb + 2 * j + 1, a.act);
-    }
+  // (0) the position word: issued first, needed late
+  const int pos_v = a.pos[0];
+  const int slot_v = PAGED ? *(kv.slot ? kv.slot : a.pos) : 0;
+  // (0a) the q/k/v finishing's values (vmcnt is in-order: what is issued first returns first)
+  const int fixq = a.q_only ? 0 : a.qkv.fix;
+  int i0, i1;
+  {
+    const int hh = tid / half, i = tid % half;
+    const int base = hh == 0 ? hq * HD : a.nq * HD + kvh * HD;
+    const int ia = a.interleaved ? 2 * i : i, ib = a.interleaved ? 2 * i + 1 : i + half;
+    const int vb = a.nq * HD + a.nkv * HD + kvh * HD + 2 * i;
+    i0 = hh < 2 ? base + ia : vb; i1 = hh < 2 ? base + ib : vb + 1;
+    if (a.q_only) { i0 = hq * HD + 2 * i; i1 = i0 + 1; }
+    if (hh > 2) { i0 = 0; i1 = 0; }
   }
-  __builtin_amdgcn_sched_barrier(0);
-  // (1) first chunk's K/V rows: 32 coalesced loads per wave
-  // (unconditional loads at clamped rows: rows >= len get weight 0 below; the cache is zero-initialised and only ever holds
-  //  finite values, so 0 * stale == 0)
-  const int pmax = ncache > 0 ? ncache - 1 : 0;
-  uint4 kr[NL], vr[NL];
-  size_t ro[NL];
-#pragma unroll
-  for (int i = 0; i < NL; i++) ro[i] = kv_row_off(kv, a.layer, kvh, min(wave * PW + 4 * i + rsub, pmax)) + piece * 8;
-#pragma unroll
-  for (int i = 0; i < NL; i++) {
-    kr[i] = *(const uint4*)((const unsigned short*)kv.k + ro[i]);
-    vr[i] = *(const uint4*)((const unsigned short*)kv.v + ro[i]);
+  unsigned r0l, r0h, r1l, r1h;
+  vsrc_issue(a.qkv.p, fixq, i0, r0l, r0h);
+  vsrc_issue(a.qkv.p, fixq, i1, r1l, r1h);
+  const float* rc = a.q_only ? (const float*)a.qkv.p : a.rope_cur;   // staged RoPE row of this position (k_embed); unused values in q_only mode
+  const float pc = rc[tid % half], ps = rc[half + tid % half];
+  if (a.zero_buf) {   // zero duty (compile-time strides: blockDim / gridDim reads are loads from the dispatch packet)
+    const int nblk = FUSE ? a.nq * CS : a.nq;
+    for (int i = blockIdx.x * NTH + tid; i < a.zero_n; i += nblk * NTH) a.zero_buf[i] = 0;
   }
-  // (0) o_proj slab of this wave (FUSE): in flight through the whole attention
+  // (1) o_proj slab of this wave (FUSE): does not depend on the position; in flight through the whole attention
   uint4 Wb[FUSE ? TPW : 1][4];
   const int t0 = (cs * OW + wave % OW) * TPW;   // waves >= OW mirror a slab (L2 hits) and skip the atomics
   if (FUSE) {
@@ -2173,8 +2185,45 @@ __global__ __launch_bounds__(NW * 64) void k_attn2(AttnArgs a, const uint4* __re
       for (int c = 0; c < 4; c++) Wb[t][c] = ldnt(wp + c * 64);
     }
   }
+  __builtin_amdgcn_sched_barrier(0);
+  // (1a) the first chunk's K/V rows, only for waves whose positions exist.  The CU's vector-memory path moves 64 B/clk: a full 256-row chunk
+  //      is 128 KiB per block, ~1 us of issue at ANY context length (measured: the second wave of each SIMD reached the first barrier 1.3 us
+  //      after the first).  Waves beyond the context skip the loads here and the score / PV work below.
+  const int pos = __builtin_amdgcn_readfirstlane(pos_v);
+  const int pmax = pos > 0 ? pos - 1 : 0;
+  const int len = a.q_only ? pos : pos + 1;
+  const unsigned short* kb0 = (const unsigned short*)kv.k + (size_t)a.layer * kv.layer_stride;
+  const unsigned short* vb0 = (const unsigned short*)kv.v + (size_t)a.layer * kv.layer_stride;
+  uint4 kr[NL], vr[NL];
+#pragma unroll
+  for (int i = 0; i < NL; i++) { kr[i] = make_uint4(0, 0, 0, 0); vr[i] = make_uint4(0, 0, 0, 0); }
+  if (wave * PW < len) {
+    if (!PAGED) {
+      const unsigned short* kb = kb0 + (size_t)kvh * kv.cap * HD;
+      const unsigned short* vb = vb0 + (size_t)kvh * kv.cap * HD;
+      const int r0 = wave * PW + rsub;
+#pragma unroll
+      for (int i = 0; i < NL; i++) {
+        const unsigned off = (unsigned)min(r0 + 4 * i, pmax) * HD + piece * 8;
+        kr[i] = *(const uint4*)(kb + off);
+        vr[i] = *(const uint4*)(vb + off);
+      }
+    } else {
+      int blk[NL];
+#pragma unroll
+      for (int i = 0; i < NL; i++) blk[i] = kv.block_table[min(wave * PW + 4 * i + rsub, pmax) / kv.bs];
+#pragma unroll
+      for (int i = 0; i < NL; i++) {
+        const int pp = min(wave * PW + 4 * i + rsub, pmax);
+        const size_t off = (((size_t)blk[i] * kv.n_kv + kvh) * kv.bs + (pp % kv.bs)) * HD + piece * 8;
+        kr[i] = *(const uint4*)(kb0 + off);
+        vr[i] = *(const uint4*)(vb0 + off);
+      }
+    }
+  }
   STAMP(1);
   // (2) q/k/v finishing: fixed point -> f32, rounding, RoPE; packed q / new key / new value to LDS; KV append
+  const float px0 = vsrc_finish(fixq, r0l, r0h, a.act), px1 = vsrc_finish(fixq, r1l, r1h, a.act);
   if (!a.q_only) {
     if (tid < 2 * half) {
       const int hh = tid / half, i = tid % half;
@@ -2190,13 +2239,13 @@ __global__ __launch_bounds__(NW * 64) void k_attn2(AttnArgs a, const uint4* __re
     __syncthreads();
     if (hq % rep == 0 && cs == 0 && tid < 64) {   // KV append, once per kv head: 64 threads x 4-byte pairs
       size_t woff;
-      if (kv.paged) woff = kv_slot_off(kv, a.layer, kvh, kv.slot ? kv.slot[0] : (kv.block_table[pos / kv.bs] * kv.bs + pos % kv.bs));
-      else woff = kv_row_off(kv, a.layer, kvh, pos);
+      if (PAGED) woff = kv_slot_off(kv, a.layer, kvh, kv.slot ? slot_v : (kv.block_table[pos / kv.bs] * kv.bs + pos % kv.bs));
+      else woff = kv_row_off_t<0>(kv, a.layer, kvh, pos);
       ((unsigned*)((unsigned short*)kv.k + woff))[tid] = k2[tid];
       ((unsigned*)((unsigned short*)kv.v + woff))[tid] = v2[tid];
     }
   } else {
-    if (tid < 64) q2[tid] = pack2<KVDT>(((const float*)a.qkv.p)[hq * HD + 2 * tid], ((const float*)a.qkv.p)[hq * HD + 2 * tid + 1]);
+    if (tid < 64) q2[tid] = pack2<KVDT>(px0, px1);
     __syncthreads();
   }
   STAMP(2);
@@ -2205,53 +2254,59 @@ __global__ __launch_bounds__(NW * 64) void k_attn2(AttnArgs a, const uint4* __re
   const uint4 qq = ((const uint4*)q2)[piece];
   float Mrun = -INFINITY, Lrun = 0.f, Orun = 0.f;   // running state (threads < 128 own output d = tid)
   for (int c0 = 0; c0 < len; c0 += 256) {
+    const bool won = c0 + wave * PW < len;   // wave-uniform: this wave has live positions in the chunk
     if (c0 > 0) {
       __syncthreads();   // the previous chunk's pout / wred reads are done
+      if (won) {
 #pragma unroll
-      for (int i = 0; i < NL; i++) ro[i] = kv_row_off(kv, a.layer, kvh, min(c0 + wave * PW + 4 * i + rsub, pmax)) + piece * 8;
-#pragma unroll
-      for (int i = 0; i < NL; i++) {
-        kr[i] = *(const uint4*)((const unsigned short*)kv.k + ro[i]);
-        vr[i] = *(const uint4*)((const unsigned short*)kv.v + ro[i]);
+        for (int i = 0; i < NL; i++) {
+          const size_t off = kv_row_off_t<PAGED>(kv, 0, kvh, min(c0 + wave * PW + 4 * i + rsub, pmax)) + piece * 8;
+          kr[i] = *(const uint4*)(kb0 + off);
+          vr[i] = *(const uint4*)(vb0 + off);
+        }
       }
     }
     // the token being appended (position pos == ncache) comes from LDS
     float sc_[NL];
     float mloc = -INFINITY;
+    if (won) {
 #pragma unroll
-    for (int i = 0; i < NL; i++) {
-      const int p = c0 + wave * PW + 4 * i + rsub;
-      uint4 kk = kr[i];
-      if (!a.q_only && p == pos) { kk = ((const uint4*)k2)[piece]; vr[i] = ((const uint4*)v2)[piece]; }
-      float d = dot2acc<KVDT>(kk.x, qq.x, 0.f);
-      d = dot2acc<KVDT>(kk.y, qq.y, d); d = dot2acc<KVDT>(kk.z, qq.z, d); d = dot2acc<KVDT>(kk.w, qq.w, d);
-      d = grp_reduce<16, OpAdd>(d);
-      sc_[i] = (p < len) ? d * scale : -INFINITY;
-      mloc = fmaxf(mloc, sc_[i]);
+      for (int i = 0; i < NL; i++) {
+        const int p = c0 + wave * PW + 4 * i + rsub;
+        uint4 kk = kr[i];
+        if (!a.q_only && p == pos) { kk = ((const uint4*)k2)[piece]; vr[i] = ((const uint4*)v2)[piece]; }
+        float d = dot2acc<KVDT>(kk.x, qq.x, 0.f);
+        d = dot2acc<KVDT>(kk.y, qq.y, d); d = dot2acc<KVDT>(kk.z, qq.z, d); d = dot2acc<KVDT>(kk.w, qq.w, d);
+        d = grp_reduce<16, OpAdd>(d);
+        sc_[i] = (p < len) ? d * scale : -INFINITY;
+        mloc = fmaxf(mloc, sc_[i]);
+      }
+      mloc = wave_max(mloc);
     }
     STAMP(3);
-    const float wm = wave_max(mloc);
-    if (lane == 0) wred[wave] = wm;
+    if (lane == 0) wred[wave] = mloc;
     __syncthreads();
     float Mc = wred[0];
 #pragma unroll
     for (int w = 1; w < NW; w++) Mc = fmaxf(Mc, wred[w]);
     float accv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float lsum = 0.f;
+    if (won) {
 #pragma unroll
-    for (int i = 0; i < NL; i++) {
-      const float e = (sc_[i] == -INFINITY) ? 0.f : expf(sc_[i] - Mc);
-      lsum += e;
-      float v[8];
-      unpack2<KVDT>(vr[i].x, v[0], v[1]); unpack2<KVDT>(vr[i].y, v[2], v[3]);
-      unpack2<KVDT>(vr[i].z, v[4], v[5]); unpack2<KVDT>(vr[i].w, v[6], v[7]);
+      for (int i = 0; i < NL; i++) {
+        const float e = (sc_[i] == -INFINITY) ? 0.f : expf(sc_[i] - Mc);
+        lsum += e;
+        float v[8];
+        unpack2<KVDT>(vr[i].x, v[0], v[1]); unpack2<KVDT>(vr[i].y, v[2], v[3]);
+        unpack2<KVDT>(vr[i].z, v[4], v[5]); unpack2<KVDT>(vr[i].w, v[6], v[7]);
 #pragma unroll
-      for (int q = 0; q < 8; q++) accv[q] = fmaf(e, v[q], accv[q]);
+        for (int q = 0; q < 8; q++) accv[q] = fmaf(e, v[q], accv[q]);
+      }
+      // rows of the wave: the 4 lane groups hold different rows -> reduce over xor 16, 32 (the 16 lanes of a group are replicas for lsum)
+      lsum = xrow32<OpAdd>(xrow16<OpAdd>(lsum));
+#pragma unroll
+      for (int q = 0; q < 8; q++) accv[q] = xrow32<OpAdd>(xrow16<OpAdd>(accv[q]));
     }
-    // rows of the wave: the 4 lane groups hold different rows -> reduce over xor 16, 32 (the 16 lanes of a group are replicas for lsum)
-    lsum = xrow32<OpAdd>(xrow16<OpAdd>(lsum));
-#pragma unroll
-    for (int q = 0; q < 8; q++) accv[q] = xrow32<OpAdd>(xrow16<OpAdd>(accv[q]));
     STAMP(4);
     if (lane < 16) {
       *(float4*)(pout + wave * 128 + piece * 8) = make_float4(accv[0], accv[1], accv[2], accv[3]);
@@ -2288,7 +2343,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn2(AttnArgs a, const uint4* __re
   }
   __syncthreads();
   STAMP(6);
-  quant_x128(outh, HD, xh, xm, xl, gpar);
+  quant_x128<NW * 64>(outh, HD, xh, xm, xl, gpar);
   __syncthreads();
   STAMP(7);
   const uint4* xh4 = (const uint4*)xh;
@@ -2315,8 +2370,7 @@ static int attn_oproj_plan(const AttnArgs& a, const LinearDev& L, int& NW) {
   if (a.hd != 128 || L.kind != LK_Q4G || L.perm != nullptr || L.K != a.nq * 128 || a.q_only) return 0;
   static const bool nw4 = getenv("BZ_ATTN_NW4") != nullptr;
   const int NT = L.N / 64;
-  static const char* nwe = getenv("BZ_ATTN_NW");
-  const int nw0 = nw4 ? 4 : (nwe ? atoi(nwe) : 8);
+  const int nw0 = nw4 ? 4 : 8;
   for (int nw = nw0; nw >= 4; nw >>= 1) {
     const int ow = nw > 8 ? 8 : nw;
     for (int cs = 8; cs >= 1; cs >>= 1)
@@ -2331,13 +2385,16 @@ int bzk_attn_oproj(hipStream_t s, const AttnArgs& a, const LinearDev& L, long lo
   const int CS = attn_oproj_plan(a, L, NW);
   if (CS <= 0) BZ_FAIL(BZ_E_INVALID, "attn+o_proj fusion does not apply to this shape");
   const int TPW = (L.N / 64) / (CS * (NW > 8 ? 8 : NW));
-#define LAUNCH_AO(DT, T, W_) BZ_LAUNCH("attn+o_proj", L.algo_bytes, (k_attn2<DT, 1, T, W_>), dim3(a.nq * CS), dim3(W_ * 64), attn2_smem(W_), s, a, \
+#define LAUNCH_AO(DT, T, W_, PG) BZ_LAUNCH("attn+o_proj", L.algo_bytes, (k_attn2<DT, 1, T, W_, PG>), dim3(a.nq * CS), dim3(W_ * 64), attn2_smem(W_), s, a, \
     (const uint4*)L.w, (const __half*)L.scales, (const unsigned char*)L.zeros, L.bias, CS, acc)
-#define LAUNCH_AO_T(DT) do { if (NW == 16) { if (TPW == 1) LAUNCH_AO(DT, 1, 16); else LAUNCH_AO(DT, 2, 16); } else if (NW == 8) { if (TPW == 1) LAUNCH_AO(DT, 1, 8); else LAUNCH_AO(DT, 2, 8); } \
-                             else { if (TPW == 1) LAUNCH_AO(DT, 1, 4); else LAUNCH_AO(DT, 2, 4); } } while (0)
+#define LAUNCH_AO_W(DT, T, PG) do { if (NW == 8) LAUNCH_AO(DT, T, 8, PG); else LAUNCH_AO(DT, T, 4, PG); } while (0)
+#define LAUNCH_AO_P(DT, T) do { if (a.kv.paged) LAUNCH_AO_W(DT, T, 1); else LAUNCH_AO_W(DT, T, 0); } while (0)
+#define LAUNCH_AO_T(DT) do { if (TPW == 1) LAUNCH_AO_P(DT, 1); else LAUNCH_AO_P(DT, 2); } while (0)
   if (a.kv.dtype == BZ_F16) LAUNCH_AO_T(BZ_F16);
   else if (a.kv.dtype == BZ_BF16) LAUNCH_AO_T(BZ_BF16);
   else BZ_FAIL(BZ_E_UNSUPPORTED, "attn+o_proj fusion: f32 KV cache not built");
+#undef LAUNCH_AO_P
+#undef LAUNCH_AO_W
 #undef LAUNCH_AO_T
 #undef LAUNCH_AO
   BZ_HIP(hipGetLastError());
@@ -2350,10 +2407,11 @@ int bzk_attn_decode(hipStream_t s, const AttnArgs& a) {
 #define LAUNCH_ATT_DT(HD) do { if (a.kv.dtype == BZ_F16) LAUNCH_ATT(HD, BZ_F16); else if (a.kv.dtype == BZ_BF16) LAUNCH_ATT(HD, BZ_BF16); \
                                else LAUNCH_ATT(HD, BZ_F32); } while (0)
   if (a.hd == 128 && a.kv.dtype != BZ_F32) {
-    if (a.kv.dtype == BZ_F16) BZ_LAUNCH("attn_decode", 0.0, (k_attn2<BZ_F16, 0, 1, 8>), dim3(a.nq), dim3(512), attn2_smem(8), s, a, (const uint4*)nullptr,
-                                        (const __half*)nullptr, (const unsigned char*)nullptr, (const float*)nullptr, 1, (long long*)nullptr);
-    else BZ_LAUNCH("attn_decode", 0.0, (k_attn2<BZ_BF16, 0, 1, 8>), dim3(a.nq), dim3(512), attn2_smem(8), s, a, (const uint4*)nullptr,
-                   (const __half*)nullptr, (const unsigned char*)nullptr, (const float*)nullptr, 1, (long long*)nullptr);
+#define LAUNCH_A2(DT, PG) BZ_LAUNCH("attn_decode", 0.0, (k_attn2<DT, 0, 1, 8, PG>), dim3(a.nq), dim3(512), attn2_smem(8), s, a, (const uint4*)nullptr, \
+    (const __half*)nullptr, (const unsigned char*)nullptr, (const float*)nullptr, 1, (long long*)nullptr)
+    if (a.kv.dtype == BZ_F16) { if (a.kv.paged) LAUNCH_A2(BZ_F16, 1); else LAUNCH_A2(BZ_F16, 0); }
+    else { if (a.kv.paged) LAUNCH_A2(BZ_BF16, 1); else LAUNCH_A2(BZ_BF16, 0); }
+#undef LAUNCH_A2
   }
   else if (a.hd == 64) LAUNCH_ATT_DT(64);
   else if (a.hd == 128) LAUNCH_ATT_DT(128);

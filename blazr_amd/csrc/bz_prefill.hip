@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void k_pf_norm(float* hbuf, const float* prev,
     if (pr) { v = pf_round(v + pr[i], act); hr[i] = v; }
     ss += v * v;
   }
-  for (int m = 32; m >= 1; m >>= 1) ss += __shfl_xor(ss, m, 64);
+  ss = wave_sum(ss);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
   __syncthreads();
   ss = (red[0] + red[1]) + (red[2] + red[3]);
@@ -237,7 +237,9 @@ __global__ __launch_bounds__(256) void k_pf_attn(const float* qkv, int nq, int n
       float d0 = 0.f, d1 = 0.f;
 #pragma unroll
       for (int e = 0; e < 8; e++) { d0 += q[h][e] * k0[e]; d1 += q[h][e] * k1[e]; }
-      for (int m = 1; m < PR; m <<= 1) { d0 += __shfl_xor(d0, m, 64); d1 += __shfl_xor(d1, m, 64); }
+      if (PR == 16) { d0 = grp_reduce<16, OpAdd>(d0); d1 = grp_reduce<16, OpAdd>(d1); }
+      else if (PR == 8) { d0 = grp_reduce<8, OpAdd>(d0); d1 = grp_reduce<8, OpAdd>(d1); }
+      else for (int m = 1; m < PR; m <<= 1) { d0 += __shfl_xor(d0, m, 64); d1 += __shfl_xor(d1, m, 64); }
       if (c == 0) { if (pa < len) sc[h * len + pa] = d0 * scale; if (pb < len) sc[h * len + pb] = d1 * scale; }
     }
   }
@@ -247,7 +249,7 @@ __global__ __launch_bounds__(256) void k_pf_attn(const float* qkv, int nq, int n
   for (int h = 0; h < REP; h++) {
     float m = -INFINITY;
     for (int p = tid; p < len; p += 256) m = fmaxf(m, sc[h * len + p]);
-    for (int k = 32; k >= 1; k >>= 1) m = fmaxf(m, __shfl_xor(m, k, 64));
+    m = wave_max(m);
     if (lane == 0) red[h * 4 + wave] = m;
   }
   __syncthreads();
@@ -256,7 +258,7 @@ __global__ __launch_bounds__(256) void k_pf_attn(const float* qkv, int nq, int n
     const float m = fmaxf(fmaxf(red[h * 4], red[h * 4 + 1]), fmaxf(red[h * 4 + 2], red[h * 4 + 3]));
     float sum = 0.f;
     for (int p = tid; p < len; p += 256) { const float e = expf(sc[h * len + p] - m); sc[h * len + p] = e; sum += e; }
-    for (int k = 32; k >= 1; k >>= 1) sum += __shfl_xor(sum, k, 64);
+    sum = wave_sum(sum);
     if (lane == 0) red[4 * REP + h * 4 + wave] = sum;
   }
   __syncthreads();

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void k_samp_scale(const float* logits, long lo
     l2[i] = x;
     m = fmaxf(m, x);
   }
-  for (int s = 32; s >= 1; s >>= 1) m = fmaxf(m, __shfl_xor(m, s, 64));
+  m = wave_max(m);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
   __syncthreads();
   if (threadIdx.x == 0) pmax[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
