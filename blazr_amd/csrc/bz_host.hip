@@ -266,6 +266,7 @@ struct bz_model {
   std::vector<void*> owned;                           // device allocations to free
   float* cos_t = nullptr; float* sin_t = nullptr;
   float* rope_cur = nullptr;   // [cos | sin] row of the current position (staged by the embed kernel)
+  float* att_ws = nullptr;     // split-KV attention partials (bzk_attn_split_ws_bytes)
   // workspace
   float* hbuf[2] = {nullptr, nullptr};
   // batched-prefill workspace (bz_prefill.hip), allocated on first use for `pf_rows` prompt rows
@@ -783,6 +784,7 @@ extern "C" int bz_model_finalize(bz_model* m) {
   BZ_TRY(dev_alloc(m, &p, cs.size() * 4)); m->cos_t = (float*)p; BZ_HIP(hipMemcpy(p, cs.data(), cs.size() * 4, hipMemcpyHostToDevice));
   BZ_TRY(dev_alloc(m, &p, sn.size() * 4)); m->sin_t = (float*)p; BZ_HIP(hipMemcpy(p, sn.data(), sn.size() * 4, hipMemcpyHostToDevice));
   BZ_TRY(dev_alloc(m, &p, 256 * 4)); m->rope_cur = (float*)p; BZ_HIP(hipMemset(p, 0, 256 * 4));
+  BZ_TRY(dev_alloc(m, &p, bzk_attn_split_ws_bytes(c.n_heads))); m->att_ws = (float*)p;
 
   // workspace
   m->ring_n = std::max(std::max((nq + 2 * nkv) * hd, 2 * I), std::max(H, nq * hd));
@@ -1208,6 +1210,10 @@ __global__ void k_set_int(int* p, int v) { p[0] = v; }
 static thread_local hipStream_t tl_capture_stream = nullptr;
 static hipStream_t step_stream(const bz_model* m) { return tl_capture_stream ? tl_capture_stream : m->dev->stream; }
 
+// contexts beyond this many positions take the split-KV attention path (two launches; the fused single launch wins below it)
+static int att_split_min() { const char* e = getenv("BZ_SPLIT_MIN"); return e ? atoi(e) : 512; }   // read per call: tests move it
+static int att_positions_for(int len) { return len > att_split_min() ? len : 0; }
+
 struct StepIO {
   KvView kv;
   const long long* d_tok;   // token id (device)
@@ -1219,6 +1225,7 @@ struct StepIO {
   float* hidden_out = nullptr; float* prev_out = nullptr;   // pieces API outputs (f32 rows)
   FinalArgs* final_args = nullptr;                          // graph mode: fused argmax + bookkeeping
   bz_ssm_state* ssm = nullptr;                              // Mamba2: recurrent state instead of a KV cache
+  int att_positions = 0;    // > 0: long-context step -- split-KV attention sized for this many positions (eager: position + 1; graph: capacity)
 };
 
 // Fixed-point accumulator ring.  Launch j accumulates into ring[j % 3] (which must be zero), reads the output of
@@ -1306,15 +1313,26 @@ static int llama_step(bz_model* m, const StepIO& io) {
     }
     VSrc ov;
     static const bool no_fuse = getenv("BZ_NO_ATTN_FUSION") != nullptr;
-    if (!no_fuse && Ld.o.parts.size() == 1 && Ld.o.fix_out && bzk_attn_oproj_slices(aa, Ld.o.parts[0]) > 0) {
+    const bool fuse_o = !no_fuse && Ld.o.parts.size() == 1 && Ld.o.fix_out && bzk_attn_oproj_slices(aa, Ld.o.parts[0]) > 0;
+    static const bool no_split = getenv("BZ_NO_ATTN_SPLIT") != nullptr;
+    const bool split = !no_split && io.att_positions > 0 && m->att_ws && bzk_attn_split_ok(aa) && (!fuse_o || bzk_attn_merge_oproj_ok(aa, Ld.o.parts[0]));
+    int SPL = 0, nsplit = 0;
+    if (split) {
+      // long context: split-KV partials (all query heads of a group share the K/V rows), then merge (+ o_proj)
+      bzk_attn_split_plan(io.att_positions, &SPL, &nsplit);
+      BZ_TRY(bzk_attn_split(st, aa, SPL, nsplit, m->att_ws));
+    }
+    if (fuse_o) {
       // attention + o_proj in one launch: same ring protocol as a GEMV launch
       const int rz = (rs.ri + 1) % 3;
       aa.zero_buf = rs.dirty[rz] > 0 ? m->ring[rz] : nullptr; aa.zero_n = rs.dirty[rz];
-      BZ_TRY(bzk_attn_oproj(st, aa, Ld.o.parts[0], m->ring[rs.ri]));
+      if (split) BZ_TRY(bzk_attn_merge_oproj(st, aa, m->att_ws, SPL, nsplit, Ld.o.parts[0], m->ring[rs.ri]));
+      else BZ_TRY(bzk_attn_oproj(st, aa, Ld.o.parts[0], m->ring[rs.ri]));
       ov = VSrc{m->ring[rs.ri], 1};
       rs.dirty[rz] = 0; rs.dirty[rs.ri] = Ld.o.N; rs.ri = rz;
     } else {
-      BZ_TRY(bzk_attn_decode(st, aa));
+      if (split) BZ_TRY(bzk_attn_merge(st, aa, m->att_ws, SPL, nsplit));
+      else BZ_TRY(bzk_attn_decode(st, aa));
       Pro pp{}; pp.mode = PRO_PLAIN; pp.src = VSrc{m->attn_out, 0}; pp.act = act; pp.H = 0;
       BZ_TRY(run_fused(m, Ld.o, pp, rs, &ov));
     }
@@ -1663,6 +1681,7 @@ extern "C" int bz_forward_kv(bz_model* m, const bz_tensor* tokens, int S, bz_kv*
     hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, m->dev->stream, m->pos_tmp, position + s);
     StepIO io{};
     io.kv = view_of(kv); io.d_tok = (const long long*)tokens->ptr + s; io.d_pos = m->pos_tmp;
+    io.att_positions = att_positions_for(position + s + 1);
     io.do_head = all || s == S - 1;
     BZ_TRY(model_step(m, io));
     if (io.do_head) BZ_TRY(emit_logits(m, logits_out, all ? s : 0));
@@ -1694,6 +1713,7 @@ extern "C" int bz_forward_paged(bz_model* m, const bz_tensor* tokens, int S, bz_
     StepIO io{};
     io.kv = view_of(kv, (const int*)block_table->ptr, (const int*)slot_mapping->ptr + s);
     io.d_tok = (const long long*)tokens->ptr + s; io.d_pos = m->pos_tmp;
+    io.att_positions = att_positions_for(start_pos + s + 1);
     io.do_head = all || s == S - 1;
     BZ_TRY(llama_step(m, io));
     if (io.do_head) BZ_TRY(emit_logits(m, logits_out, all ? s : 0));
@@ -1745,6 +1765,7 @@ extern "C" int bz_forward_paged_batch(bz_model* m, const bz_tensor* tokens, int 
     StepIO io{};
     io.kv = view_of(kv, (const int*)block_table->ptr + (size_t)i * max_blocks, (const int*)slot_mapping->ptr + i);
     io.d_tok = (const long long*)tokens->ptr + i; io.d_pos = m->pos_tmp;
+    io.att_positions = att_positions_for(seq_lens[i]);
     BZ_TRY(model_step(m, io));
     BZ_TRY(emit_logits(m, logits_out, i));
   }
@@ -1802,6 +1823,7 @@ extern "C" int bz_forward_layers_range(bz_model* m, bz_tensor* hidden, bz_tensor
     hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, m->dev->stream, m->pos_tmp, position + s);
     StepIO io{};
     io.kv = view_of(kv); io.d_tok = nullptr; io.d_pos = m->pos_tmp;
+    io.att_positions = att_positions_for(position + s + 1);
     io.do_embed = false; io.do_head = false; io.layer_start = start; io.layer_end = end;
     io.hidden_in = (float*)hidden->ptr + (size_t)s * H;
     io.prev_in = *has_prev ? (float*)prev_mlp->ptr + (size_t)s * H : nullptr;
@@ -1872,6 +1894,7 @@ extern "C" int bz_profile_step(bz_model* m, bz_kv* kv, int64_t token, int positi
     fa.tok_out = m->tok_tmp + 1;   // scratch: do not feed the sampled token back (same input every iteration)
     StepIO io{};
     io.kv = view_of(kv); io.d_tok = m->tok_tmp; io.d_pos = m->pos_tmp; io.final_args = &fa;
+    io.att_positions = att_positions_for(position + i + 1);
     bzk_set_timing_sink(&sink);
     rc = model_step(m, io);
     bzk_set_timing_sink(nullptr);
@@ -1996,6 +2019,9 @@ struct bz_decode_graph {
   bz_model* m = nullptr;
   bz_device* dev = nullptr;
   hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+  hipGraph_t graph_long = nullptr; hipGraphExec_t exec_long = nullptr;   // split-KV attention variant (captured on first need)
+  KvView view{}; int capacity = 0;  // what the step was captured over; positions the long variant's grid covers
+  int seed_pos = 0;                 // host copy of the seeded position (position of replay r = seed_pos + r)
   long long* tok_buf = nullptr;     // device: input token of the next replay
   int* pos = nullptr;               // device: position of the next replay
   int* step = nullptr;              // device: replay counter
@@ -2007,20 +2033,14 @@ struct bz_decode_graph {
   static const int LOGCAP = 4096;
 };
 
-static int graph_capture_common(bz_decode_graph* g, const KvView& view) {
+// one capture of the decode step over the graph's device-resident token / position / step words; att_positions > 0 records the long-context
+// (split-KV attention) form of the step
+static int graph_capture_variant(bz_decode_graph* g, int att_positions, hipGraph_t* graph_out, hipGraphExec_t* exec_out) {
   bz_model* m = g->m;
-  hipStream_t st = m->dev->stream;
-  BZ_HIP(hipMalloc(&g->tok_buf, 64));
-  BZ_HIP(hipMalloc(&g->pos, 64));
-  BZ_HIP(hipMalloc(&g->step, 64));
-  BZ_HIP(hipMemset(g->tok_buf, 0, 64)); BZ_HIP(hipMemset(g->pos, 0, 64)); BZ_HIP(hipMemset(g->step, 0, 64));
-  BZ_HIP(hipHostMalloc(&g->tok_log, sizeof(long long) * bz_decode_graph::LOGCAP, hipHostMallocDefault));
-  memset(g->tok_log, 0xff, sizeof(long long) * bz_decode_graph::LOGCAP);
-  BZ_HIP(hipDeviceSynchronize());
   FinalArgs fa{};
   fa.tok_out = g->tok_buf; fa.tok_log = g->tok_log; fa.step = g->step; fa.logcap = bz_decode_graph::LOGCAP; fa.pos = g->pos;
   StepIO io{};
-  io.kv = view; io.d_tok = g->tok_buf; io.d_pos = g->pos; io.final_args = &fa; io.ssm = g->ssm;
+  io.kv = g->view; io.d_tok = g->tok_buf; io.d_pos = g->pos; io.final_args = &fa; io.ssm = g->ssm; io.att_positions = att_positions;
   BZ_TRACE("graph: begin capture");
   hipStream_t cap = nullptr;
   BZ_HIP(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
@@ -2035,9 +2055,24 @@ static int graph_capture_common(bz_decode_graph* g, const KvView& view) {
   BZ_TRACE("graph: end capture rc=%d hip=%d", rc, (int)e);
   if (rc != BZ_OK) { if (graph) hipGraphDestroy(graph); return rc; }
   if (e != hipSuccess) BZ_FAIL(BZ_E_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
-  g->graph = graph;
-  BZ_HIP(hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0));
+  *graph_out = graph;
+  BZ_HIP(hipGraphInstantiate(exec_out, graph, nullptr, nullptr, 0));
   BZ_TRACE("graph: instantiated");
+  return BZ_OK;
+}
+
+static int graph_capture_common(bz_decode_graph* g, const KvView& view) {
+  bz_model* m = g->m;
+  hipStream_t st = m->dev->stream;
+  BZ_HIP(hipMalloc(&g->tok_buf, 64));
+  BZ_HIP(hipMalloc(&g->pos, 64));
+  BZ_HIP(hipMalloc(&g->step, 64));
+  BZ_HIP(hipMemset(g->tok_buf, 0, 64)); BZ_HIP(hipMemset(g->pos, 0, 64)); BZ_HIP(hipMemset(g->step, 0, 64));
+  BZ_HIP(hipHostMalloc(&g->tok_log, sizeof(long long) * bz_decode_graph::LOGCAP, hipHostMallocDefault));
+  memset(g->tok_log, 0xff, sizeof(long long) * bz_decode_graph::LOGCAP);
+  BZ_HIP(hipDeviceSynchronize());
+  g->view = view;
+  BZ_TRY(graph_capture_variant(g, 0, &g->graph, &g->exec));
   for (int i = 0; i < 8; i++) { hipEvent_t ev; BZ_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); g->evs.push_back(ev); }
   return BZ_OK;
 }
@@ -2052,7 +2087,7 @@ extern "C" int bz_decode_graph_capture(bz_model* m, bz_kv* kv, bz_decode_graph**
   BZ_TRY(kv_grow(kv, kv->max_len));
   bz_decode_graph* g = new bz_decode_graph();
   bz_dev_retain(m->dev); g->dev = m->dev;
-  g->m = m; g->kv = kv;
+  g->m = m; g->kv = kv; g->capacity = kv->max_len;
   int rc = graph_capture_common(g, view_of(kv));
   if (rc != BZ_OK) { bz_decode_graph_free(g); return rc; }
   *out = g;
@@ -2065,7 +2100,7 @@ extern "C" int bz_decode_graph_capture_paged(bz_model* m, bz_paged_kv* kv, int m
   BZ_HIP(hipSetDevice(m->dev->id));
   bz_decode_graph* g = new bz_decode_graph();
   bz_dev_retain(m->dev); g->dev = m->dev;
-  g->m = m; g->pkv = kv; g->max_blocks = max_blocks;
+  g->m = m; g->pkv = kv; g->max_blocks = max_blocks; g->capacity = std::min(max_blocks * kv->block_size, m->cfg.max_seq_len);
   BZ_HIP(hipMalloc(&g->block_table, (size_t)max_blocks * 4));
   BZ_HIP(hipMemset(g->block_table, 0, (size_t)max_blocks * 4));
   int rc = graph_capture_common(g, view_of(kv, g->block_table, nullptr));
@@ -2101,14 +2136,24 @@ extern "C" int bz_decode_graph_seed(bz_decode_graph* g, int64_t token, int posit
   BZ_HIP(hipMemcpyAsync(g->pos, &p, 4, hipMemcpyHostToDevice, st));
   BZ_HIP(hipMemcpyAsync(g->step, &z, 4, hipMemcpyHostToDevice, st));
   BZ_HIP(hipStreamSynchronize(st));
-  g->replays = 0;
+  g->replays = 0; g->seed_pos = position;
   return BZ_OK;
 }
 extern "C" int bz_decode_graph_replay(bz_decode_graph* g) {
   if (!g || !g->exec) BZ_FAIL(BZ_E_INVALID, "null graph");
   std::lock_guard<std::recursive_mutex> lock__(g->m->mu);
   hipStream_t st = g->m->dev->stream;
-  BZ_HIP(hipGraphLaunch(g->exec, st));
+  hipGraphExec_t exec = g->exec;
+  // the position of this replay is known on the host (seeded position + replays since): long contexts replay the split-KV variant,
+  // captured on first need over the same device words and sized for the cache capacity
+  if (!g->ssm && g->capacity > 0 && att_positions_for((int)(g->seed_pos + g->replays + 1)) > 0) {
+    if (!g->exec_long) {
+      BZ_HIP(hipSetDevice(g->m->dev->id));
+      BZ_TRY(graph_capture_variant(g, g->capacity, &g->graph_long, &g->exec_long));
+    }
+    exec = g->exec_long;
+  }
+  BZ_HIP(hipGraphLaunch(exec, st));
   BZ_HIP(hipEventRecord(g->evs[g->replays % g->evs.size()], st));
   g->replays++;
   if (g->kv) g->kv->seq_len++;
@@ -2135,6 +2180,8 @@ extern "C" int bz_decode_graph_free(bz_decode_graph* g) {
   for (auto ev : g->evs) hipEventDestroy(ev);
   if (g->exec) hipGraphExecDestroy(g->exec);
   if (g->graph) hipGraphDestroy(g->graph);
+  if (g->exec_long) hipGraphExecDestroy(g->exec_long);
+  if (g->graph_long) hipGraphDestroy(g->graph_long);
   if (g->tok_buf) hipFree(g->tok_buf);
   if (g->pos) hipFree(g->pos);
   if (g->step) hipFree(g->step);

@@ -199,6 +199,14 @@ struct AttnArgs {
 int bzk_attn_decode(hipStream_t s, const AttnArgs& a);
 int bzk_attn_oproj_slices(const AttnArgs& a, const LinearDev& L);   // 0: fused form not applicable
 int bzk_attn_oproj(hipStream_t s, const AttnArgs& a, const LinearDev& L, long long* acc);
+// long-context path: split-KV partials + merge (see bz_kernels.hip); ws holds bzk_attn_split_ws_bytes(nq) bytes
+void bzk_attn_split_plan(int positions, int* SPL, int* nsplit);
+int bzk_attn_split_ok(const AttnArgs& a);
+size_t bzk_attn_split_ws_bytes(int nq);
+int bzk_attn_split(hipStream_t s, const AttnArgs& a, int SPL, int nsplit, float* ws);
+int bzk_attn_merge(hipStream_t s, const AttnArgs& a, const float* ws, int SPL, int nsplit);
+int bzk_attn_merge_oproj_ok(const AttnArgs& a, const LinearDev& L);
+int bzk_attn_merge_oproj(hipStream_t s, const AttnArgs& a, const float* ws, int SPL, int nsplit, const LinearDev& L, long long* acc);
 int bzk_kv_insert(hipStream_t s, const KvView& kv, int layer, const float* k, const float* v, const int* pos, int nkv, int hd);
 int bzk_kv_read(hipStream_t s, const KvView& kv, int layer, int kvh, int which, int len, float* out);
 

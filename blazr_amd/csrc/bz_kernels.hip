@@ -2401,6 +2401,344 @@ int bzk_attn_oproj(hipStream_t s, const AttnArgs& a, const LinearDev& L, long lo
   return BZ_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Long-context decode: split-KV attention (flash-decoding) + merge.
+// The fused kernel above gives every (head, column-slice) block the WHOLE context (8x redundant K/V reads, one 256-row chunk at a time):
+// fine up to a few hundred positions, 69 us per layer at 4096.  Beyond BZ_SPLIT_MIN positions the step runs two launches instead:
+//   k_attn_split       : block (kv head, split s) owns positions [s*SPL, (s+1)*SPL) for all REP query heads of the group (K/V rows are
+//                        loaded once per group); it also finishes q (RoPE), and the block that owns the new position appends K/V.
+//                        Writes one partial per (head, split): m, l, o[128] (unnormalised, relative to m).
+//   k_attn_merge[_oproj]: merges the live partials of a head (weights exp(m_s - M)), then -- fused form -- multiplies by the o_proj slab exactly
+//                        like k_attn2's tail.
+// The grid of k_attn_split is sized for the cache CAPACITY so that a captured graph is valid at every position; blocks beyond the
+// context return at once.
+// ---------------------------------------------------------------------------------------------------------
+#define ATT_PSTRIDE 132   // floats per partial: [0] m, [1] l, [4..131] o
+
+template <int KVDT, int PAGED, int REP>
+__global__ __launch_bounds__(REP == 8 ? 512 : 256) void k_attn_split(AttnArgs a, int SPL, int nsplit, float* __restrict__ ws) {
+  constexpr int HD = 128, half = 64, NW = REP == 8 ? 8 : 4, NTH = NW * 64, PW = 128 / NW, NL = PW / 4;
+  __shared__ __attribute__((aligned(16))) unsigned q2[REP][64];
+  __shared__ __attribute__((aligned(16))) unsigned k2[64], v2[64];
+  __shared__ float wred[REP][NW], lred[REP][NW];
+  __shared__ __attribute__((aligned(16))) float pout[NW][REP][128];
+  asm volatile("" :: "s"(a.kv.k), "s"(a.kv.v), "s"(a.kv.cap), "s"(a.kv.layer_stride), "s"(a.layer), "s"(a.act), "s"(a.interleaved), "s"(a.rope_cur),
+               "s"(a.qkv.p), "s"(a.qkv.fix), "s"(a.nq), "s"(a.nkv), "s"(a.pos), "s"(SPL), "s"(nsplit), "s"(ws), "s"(a.kv.bs), "s"(a.kv.n_kv),
+               "s"(a.zero_buf), "s"(a.zero_n));
+  const int kvh = blockIdx.x / nsplit, s = blockIdx.x % nsplit;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int piece = lane & 15, rsub = lane >> 4;
+  const KvView& kv = a.kv;
+  const int pos_v = a.pos[0];
+  const int slot_v = PAGED ? *(kv.slot ? kv.slot : a.pos) : 0;
+  // q pairs: thread t -> head kvh*REP + t/64, pair t%64 (threads beyond REP*64 repeat the last head); new k / v pairs: threads 0..63 / 64..127
+  const int hl = min(tid / half, REP - 1), i = tid % half;
+  const int ia = a.interleaved ? 2 * i : i, ib = a.interleaved ? 2 * i + 1 : i + half;
+  const int qb = (kvh * REP + hl) * HD;
+  unsigned q0l, q0h, q1l, q1h, n0l, n0h, n1l, n1h;
+  vsrc_issue(a.qkv.p, a.qkv.fix, qb + ia, q0l, q0h);
+  vsrc_issue(a.qkv.p, a.qkv.fix, qb + ib, q1l, q1h);
+  {
+    const int kb_ = a.nq * HD + kvh * HD, vb_ = a.nq * HD + a.nkv * HD + kvh * HD;
+    const bool isk = tid < half;
+    vsrc_issue(a.qkv.p, a.qkv.fix, isk ? kb_ + ia : vb_ + 2 * i, n0l, n0h);
+    vsrc_issue(a.qkv.p, a.qkv.fix, isk ? kb_ + ib : vb_ + 2 * i + 1, n1l, n1h);
+  }
+  const float pc = a.rope_cur[i], ps = a.rope_cur[half + i];
+  if (a.zero_buf)
+    for (int z = blockIdx.x * NTH + tid; z < a.zero_n; z += gridDim.x * NTH) a.zero_buf[z] = 0;
+  const int pos = __builtin_amdgcn_readfirstlane(pos_v);
+  const int len = pos + 1, pmax = pos > 0 ? pos - 1 : 0;
+  const int p0 = s * SPL;
+  if (p0 >= len) return;                    // split beyond the context (the grid covers the capacity)
+  const int p1 = min(p0 + SPL, len);
+  const bool owner = p1 == len;             // this block's range holds the new position
+  {
+    const float x0 = vsrc_finish(a.qkv.fix, q0l, q0h, a.act), x1 = vsrc_finish(a.qkv.fix, q1l, q1h, a.act);
+    const unsigned pk = pack2<KVDT>(round_act(x0 * pc - x1 * ps, a.act), round_act(x1 * pc + x0 * ps, a.act));
+    ((unsigned short*)q2[hl])[ia] = (unsigned short)(pk & 0xffffu);
+    ((unsigned short*)q2[hl])[ib] = (unsigned short)(pk >> 16);
+  }
+  if (owner && tid < 2 * half) {
+    const float x0 = vsrc_finish(a.qkv.fix, n0l, n0h, a.act), x1 = vsrc_finish(a.qkv.fix, n1l, n1h, a.act);
+    if (tid < half) {
+      const unsigned pk = pack2<KVDT>(round_act(x0 * pc - x1 * ps, a.act), round_act(x1 * pc + x0 * ps, a.act));
+      ((unsigned short*)k2)[ia] = (unsigned short)(pk & 0xffffu);
+      ((unsigned short*)k2)[ib] = (unsigned short)(pk >> 16);
+    } else {
+      v2[i] = pack2<KVDT>(x0, x1);
+    }
+  }
+  __syncthreads();
+  if (owner && tid < 64) {                  // KV append
+    size_t woff;
+    if (PAGED) woff = kv_slot_off(kv, a.layer, kvh, kv.slot ? slot_v : (kv.block_table[pos / kv.bs] * kv.bs + pos % kv.bs));
+    else woff = kv_row_off_t<0>(kv, a.layer, kvh, pos);
+    ((unsigned*)((unsigned short*)kv.k + woff))[tid] = k2[tid];
+    ((unsigned*)((unsigned short*)kv.v + woff))[tid] = v2[tid];
+  }
+  const unsigned short* kb0 = (const unsigned short*)kv.k + (size_t)a.layer * kv.layer_stride;
+  const unsigned short* vb0 = (const unsigned short*)kv.v + (size_t)a.layer * kv.layer_stride;
+  const float scale = 1.0f / sqrtf((float)HD);
+  uint4 qq[REP];
+#pragma unroll
+  for (int h = 0; h < REP; h++) qq[h] = ((const uint4*)q2[h])[piece];
+  float Mrun[REP], Lrun[REP], Orun[REP];    // threads < 128 own output dim tid of every head
+#pragma unroll
+  for (int h = 0; h < REP; h++) { Mrun[h] = -INFINITY; Lrun[h] = 0.f; Orun[h] = 0.f; }
+  for (int c0 = p0; c0 < p1; c0 += 128) {
+    if (c0 > p0) __syncthreads();           // the previous chunk's pout / wred / lred reads are done
+    const bool won = c0 + wave * PW < p1;   // wave-uniform
+    uint4 vr[NL];
+    float sc_[REP][NL], mloc[REP];
+#pragma unroll
+    for (int h = 0; h < REP; h++) mloc[h] = -INFINITY;
+    if (won) {
+      uint4 kr[NL];
+#pragma unroll
+      for (int r = 0; r < NL; r++) {
+        const size_t off = kv_row_off_t<PAGED>(kv, 0, kvh, min(c0 + wave * PW + 4 * r + rsub, pmax)) + piece * 8;
+        kr[r] = *(const uint4*)(kb0 + off);
+        vr[r] = *(const uint4*)(vb0 + off);
+      }
+#pragma unroll
+      for (int r = 0; r < NL; r++) {
+        const int p = c0 + wave * PW + 4 * r + rsub;
+        uint4 kk = kr[r];
+        if (p == pos) { kk = ((const uint4*)k2)[piece]; vr[r] = ((const uint4*)v2)[piece]; }
+#pragma unroll
+        for (int h = 0; h < REP; h++) {
+          float d = dot2acc<KVDT>(kk.x, qq[h].x, 0.f);
+          d = dot2acc<KVDT>(kk.y, qq[h].y, d); d = dot2acc<KVDT>(kk.z, qq[h].z, d); d = dot2acc<KVDT>(kk.w, qq[h].w, d);
+          d = grp_reduce<16, OpAdd>(d);
+          sc_[h][r] = (p < p1) ? d * scale : -INFINITY;
+          mloc[h] = fmaxf(mloc[h], sc_[h][r]);
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < REP; h++) mloc[h] = wave_max(mloc[h]);
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int h = 0; h < REP; h++) wred[h][wave] = mloc[h];
+    }
+    __syncthreads();
+    float Mc[REP];
+#pragma unroll
+    for (int h = 0; h < REP; h++) {
+      Mc[h] = wred[h][0];
+#pragma unroll
+      for (int w = 1; w < NW; w++) Mc[h] = fmaxf(Mc[h], wred[h][w]);
+    }
+    if (won) {
+      float accv[REP][8], lsum[REP];
+#pragma unroll
+      for (int h = 0; h < REP; h++) {
+        lsum[h] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; q++) accv[h][q] = 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < NL; r++) {
+        float v[8];
+        unpack2<KVDT>(vr[r].x, v[0], v[1]); unpack2<KVDT>(vr[r].y, v[2], v[3]);
+        unpack2<KVDT>(vr[r].z, v[4], v[5]); unpack2<KVDT>(vr[r].w, v[6], v[7]);
+#pragma unroll
+        for (int h = 0; h < REP; h++) {
+          const float e = (sc_[h][r] == -INFINITY) ? 0.f : expf(sc_[h][r] - Mc[h]);
+          lsum[h] += e;
+#pragma unroll
+          for (int q = 0; q < 8; q++) accv[h][q] = fmaf(e, v[q], accv[h][q]);
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < REP; h++) {
+        lsum[h] = xrow32<OpAdd>(xrow16<OpAdd>(lsum[h]));
+#pragma unroll
+        for (int q = 0; q < 8; q++) accv[h][q] = xrow32<OpAdd>(xrow16<OpAdd>(accv[h][q]));
+        if (lane < 16) {
+          *(float4*)(&pout[wave][h][piece * 8]) = make_float4(accv[h][0], accv[h][1], accv[h][2], accv[h][3]);
+          *(float4*)(&pout[wave][h][piece * 8 + 4]) = make_float4(accv[h][4], accv[h][5], accv[h][6], accv[h][7]);
+        }
+        if (lane == 0) lred[h][wave] = lsum[h];
+      }
+    } else {
+      if (lane < 16) {
+#pragma unroll
+        for (int h = 0; h < REP; h++) {
+          *(float4*)(&pout[wave][h][piece * 8]) = make_float4(0.f, 0.f, 0.f, 0.f);
+          *(float4*)(&pout[wave][h][piece * 8 + 4]) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+      if (lane == 0) {
+#pragma unroll
+        for (int h = 0; h < REP; h++) lred[h][wave] = 0.f;
+      }
+    }
+    __syncthreads();
+    if (tid < 128) {
+#pragma unroll
+      for (int h = 0; h < REP; h++) {
+        float oc = 0.f, Lc = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; w++) { oc += pout[w][h][tid]; Lc += lred[h][w]; }
+        const float Mn = fmaxf(Mrun[h], Mc[h]);
+        const float fa = (Mrun[h] == -INFINITY) ? 0.f : expf(Mrun[h] - Mn), fb = expf(Mc[h] - Mn);
+        Orun[h] = Orun[h] * fa + oc * fb;
+        Lrun[h] = Lrun[h] * fa + Lc * fb;
+        Mrun[h] = Mn;
+      }
+    }
+  }
+  if (tid < 128) {
+#pragma unroll
+    for (int h = 0; h < REP; h++) {
+      float* dst = ws + ((size_t)(kvh * REP + h) * nsplit + s) * ATT_PSTRIDE;
+      dst[4 + tid] = Orun[h];
+      if (tid == 0) { dst[0] = Mrun[h]; dst[1] = Lrun[h]; }
+    }
+  }
+}
+
+// merge of the live partials of head hq into outh[128] (LDS, rounded to the activation dtype); 512 threads; ns <= 128
+__device__ __forceinline__ void att_merge_512(const float* __restrict__ ws, int hq, int nsplit, int ns, int act, float* wS, float* red, float (*osum)[128],
+                                              float* outh) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const float* base = ws + (size_t)hq * nsplit * ATT_PSTRIDE;
+  const int sc = min(tid, ns - 1);
+  float m = base[(size_t)sc * ATT_PSTRIDE], l = base[(size_t)sc * ATT_PSTRIDE + 1];
+  if (tid >= ns) { m = -INFINITY; l = 0.f; }
+  const float wm = wave_max(m);
+  if (lane == 0) red[wave] = wm;
+  __syncthreads();
+  float M = red[0];
+#pragma unroll
+  for (int w = 1; w < 8; w++) M = fmaxf(M, red[w]);
+  const float wgt = (m == -INFINITY) ? 0.f : expf(m - M);
+  if (tid < 128) wS[tid] = wgt;
+  const float wl = wave_sum(wgt * l);
+  if (lane == 0) red[8 + wave] = wl;
+  __syncthreads();
+  float L = 0.f;
+#pragma unroll
+  for (int w = 0; w < 8; w++) L += red[8 + w];
+  const int d = tid & 127, ph = tid >> 7;
+  float o = 0.f;
+#pragma unroll 8
+  for (int s = ph; s < ns; s += 4) o += wS[s] * base[(size_t)s * ATT_PSTRIDE + 4 + d];
+  osum[ph][d] = o;
+  __syncthreads();
+  if (tid < 128) outh[tid] = round_act(((osum[0][tid] + osum[1][tid]) + (osum[2][tid] + osum[3][tid])) / L, act);
+}
+
+__global__ __launch_bounds__(512) void k_attn_merge(AttnArgs a, const float* __restrict__ ws, int SPL, int nsplit) {
+  __shared__ float wS[128], red[16], osum[4][128], outh[128];
+  const int hq = blockIdx.x;
+  const int pos = a.pos[0];
+  const int ns = (pos + 1 + SPL - 1) / SPL;
+  att_merge_512(ws, hq, nsplit, ns, a.act, wS, red, osum, outh);
+  __syncthreads();
+  if (threadIdx.x < 128) a.out[(size_t)hq * 128 + threadIdx.x] = outh[threadIdx.x];
+}
+
+template <int TPW>
+__global__ __launch_bounds__(512) void k_attn_merge_oproj(AttnArgs a, const float* __restrict__ ws, int SPL, int nsplit, const uint4* __restrict__ W,
+                                                          const __half* __restrict__ S, const unsigned char* __restrict__ Z,
+                                                          const float* __restrict__ bias, int CS, long long* acc) {
+  constexpr int HD = 128;
+  __shared__ float wS[128], red[16], osum[4][128];
+  __shared__ __attribute__((aligned(16))) float outh[128];
+  __shared__ __attribute__((aligned(16))) unsigned xh[32], xm[32], xl[32];
+  __shared__ int4 gpar[2];
+  asm volatile("" :: "s"(a.pos), "s"(a.act), "s"(a.nq), "s"(ws), "s"(SPL), "s"(nsplit), "s"(W), "s"(S), "s"(Z), "s"(bias), "s"(CS), "s"(acc),
+               "s"(a.zero_buf), "s"(a.zero_n));
+  const int hq = blockIdx.x / CS, cs = blockIdx.x % CS;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int pos_v = a.pos[0];
+  uint4 Wb[TPW][4];
+  const int t0 = (cs * 8 + wave) * TPW;
+  const int K = a.nq * HD;
+#pragma unroll
+  for (int t = 0; t < TPW; t++) {
+    const uint4* wp = W + ((size_t)(t0 + t) * (K >> 5) + hq * 4) * 64 + lane;
+#pragma unroll
+    for (int c = 0; c < 4; c++) Wb[t][c] = ldnt(wp + c * 64);
+  }
+  float sc[TPW]; int zp[TPW];
+  {
+    const int G = K >> 7;
+#pragma unroll
+    for (int t = 0; t < TPW; t++) {
+      sc[t] = __half2float(S[((size_t)(t0 + t) * G + hq) * 64 + lane]);
+      zp[t] = Z[((size_t)(t0 + t) * G + hq) * 64 + lane];
+    }
+  }
+  if (a.zero_buf)
+    for (int z = blockIdx.x * 512 + tid; z < a.zero_n; z += gridDim.x * 512) a.zero_buf[z] = 0;
+  const int pos = __builtin_amdgcn_readfirstlane(pos_v);
+  const int ns = (pos + 1 + SPL - 1) / SPL;
+  att_merge_512(ws, hq, nsplit, ns, a.act, wS, red, osum, outh);
+  __syncthreads();
+  quant_x128<512>(outh, HD, xh, xm, xl, gpar);
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < TPW; t++) {
+    float y = 0.f;
+    q4g_consume(Wb[t], 0, (const uint4*)xh, (const uint4*)xm, (const uint4*)xl, gpar, sc[t], zp[t], y);
+    const int n = (t0 + t) * 64 + lane;
+    if (bias != nullptr && hq == 0) y += bias[n];
+    atomicAdd((unsigned long long*)(acc + n), (unsigned long long)f2fix(y));
+  }
+}
+
+// split plan from the positions the launch must cover: SPL positions per block (multiple of 128), at most 128 splits
+void bzk_attn_split_plan(int positions, int* SPL, int* nsplit) {
+  int spl = 128;
+  while ((positions + spl - 1) / spl > 128) spl *= 2;
+  *SPL = spl; *nsplit = (positions + spl - 1) / spl;
+  if (*nsplit < 1) *nsplit = 1;
+}
+int bzk_attn_split_ok(const AttnArgs& a) {
+  const int rep = a.nkv > 0 ? a.nq / a.nkv : 0;
+  return a.hd == 128 && (a.kv.dtype == BZ_F16 || a.kv.dtype == BZ_BF16) && !a.q_only && a.nq % a.nkv == 0 && (rep == 1 || rep == 2 || rep == 4 || rep == 8) &&
+         a.rope_cur != nullptr;
+}
+size_t bzk_attn_split_ws_bytes(int nq) { return (size_t)nq * 128 * ATT_PSTRIDE * 4; }
+
+int bzk_attn_split(hipStream_t s, const AttnArgs& a, int SPL, int nsplit, float* ws) {
+  if (!bzk_attn_split_ok(a) || nsplit < 1 || nsplit > 128 || SPL % 128) BZ_FAIL(BZ_E_INVALID, "split attention does not apply to this shape");
+  const int rep = a.nq / a.nkv;
+#define LAUNCH_SP(DT, PG, R) BZ_LAUNCH("attn_split", 0.0, (k_attn_split<DT, PG, R>), dim3(a.nkv * nsplit), dim3(R == 8 ? 512 : 256), 0, s, a, SPL, nsplit, ws)
+#define LAUNCH_SP_R(DT, PG) do { if (rep == 1) LAUNCH_SP(DT, PG, 1); else if (rep == 2) LAUNCH_SP(DT, PG, 2); else if (rep == 4) LAUNCH_SP(DT, PG, 4); \
+                                 else LAUNCH_SP(DT, PG, 8); } while (0)
+#define LAUNCH_SP_P(DT) do { if (a.kv.paged) LAUNCH_SP_R(DT, 1); else LAUNCH_SP_R(DT, 0); } while (0)
+  if (a.kv.dtype == BZ_F16) LAUNCH_SP_P(BZ_F16); else LAUNCH_SP_P(BZ_BF16);
+#undef LAUNCH_SP_P
+#undef LAUNCH_SP_R
+#undef LAUNCH_SP
+  BZ_HIP(hipGetLastError());
+  return BZ_OK;
+}
+int bzk_attn_merge(hipStream_t s, const AttnArgs& a, const float* ws, int SPL, int nsplit) {
+  BZ_LAUNCH("attn_merge", 0.0, k_attn_merge, dim3(a.nq), dim3(512), 0, s, a, ws, SPL, nsplit);
+  BZ_HIP(hipGetLastError());
+  return BZ_OK;
+}
+int bzk_attn_merge_oproj_ok(const AttnArgs& a, const LinearDev& L) { int nw; return attn_oproj_plan(a, L, nw) > 0 && nw == 8; }
+int bzk_attn_merge_oproj(hipStream_t s, const AttnArgs& a, const float* ws, int SPL, int nsplit, const LinearDev& L, long long* acc) {
+  int NW;
+  const int CS = attn_oproj_plan(a, L, NW);
+  if (CS <= 0 || NW != 8) BZ_FAIL(BZ_E_INVALID, "attn merge + o_proj fusion does not apply to this shape");
+  const int TPW = (L.N / 64) / (CS * 8);
+#define LAUNCH_MO(T) BZ_LAUNCH("attn_merge+o_proj", L.algo_bytes, (k_attn_merge_oproj<T>), dim3(a.nq * CS), dim3(512), 0, s, a, ws, SPL, nsplit, \
+    (const uint4*)L.w, (const __half*)L.scales, (const unsigned char*)L.zeros, L.bias, CS, acc)
+  if (TPW == 1) LAUNCH_MO(1); else LAUNCH_MO(2);
+#undef LAUNCH_MO
+  BZ_HIP(hipGetLastError());
+  return BZ_OK;
+}
+
 int bzk_attn_decode(hipStream_t s, const AttnArgs& a) {
   const size_t smem = (size_t)(3 * a.hd + 8 + 256 * (a.hd + 4)) * 4;
 #define LAUNCH_ATT(HD, DT) BZ_LAUNCH("attn_decode", 0.0, (k_attn_decode<HD, DT>), dim3(a.nq), dim3(256), smem, s, a)

@@ -361,3 +361,74 @@ def test_concurrent_generate_calls_on_one_model(device):
         t.join()
     assert not errs, errs
     assert got == want
+
+
+# ---------------------------------------------------------------------------------------------------------
+# long-context decode: split-KV attention + merge (two launches), forced on by a low BZ_SPLIT_MIN
+# ---------------------------------------------------------------------------------------------------------
+@pytest.fixture
+def split_min(monkeypatch):
+    def _set(n):
+        monkeypatch.setenv("BZ_SPLIT_MIN", str(n))
+    return _set
+
+
+SPLIT_CASES = [
+    ("tiny-bf16", dict(n_heads=8, n_kv_heads=8, head_dim=128)),    # REP 1, unfused merge
+    ("tiny-bf16", dict(n_heads=8, n_kv_heads=4, head_dim=128)),    # REP 2
+    ("tiny-bf16", dict(n_heads=8, n_kv_heads=2, head_dim=128)),    # REP 4
+    ("tiny-bf16", dict(n_heads=8, n_kv_heads=1, head_dim=128)),    # REP 8 (512-thread blocks)
+    ("llama3-8b-awq-2l", {}),                                      # REP 4, f16, merge fused with o_proj
+]
+
+
+@pytest.mark.parametrize("case", SPLIT_CASES, ids=lambda c: c[0] + "".join("+%s%s" % (k[2], v) for k, v in c[1].items() if k != "head_dim"))
+def test_split_attention_decode_matches_oracle(device, split_min, case):
+    """every decode step beyond BZ_SPLIT_MIN positions takes the split-KV path; 150 positions cross the 128-position split boundary, so the
+    merge sees two live partials per head and the new token's position moves from one split's owner block to the next"""
+    preset, over = case
+    split_min(4)
+    model = synth.make_llama(preset, **over)
+    cfg = model["config"]
+    lm = runtime.LoadedModel.from_synth(device, model)
+    om = orc_py.OrcLlama(model)
+    n = 150
+    p = synth.prompt_tokens(n, cfg["vocab"], seed=5)
+    kv = runtime.LayeredKvCache(device, cfg["n_layers"], 1, cfg["n_kv_heads"], 8, cfg["max_seq_len"], cfg["head_dim"], _kv_dt(cfg))
+    okv = om.new_kv(256)
+    want = om.forward_kv(p, okv, 0, all_logits=True)
+    # token-by-token decode of this 150-token fixture sits at 1.0-1.3e-3 relative L2 against the oracle on BOTH attention paths (measured:
+    # mean 1.126e-3 single-launch, 1.125e-3 split; scripts/dbg_split.py) -- rounding-flip noise of two correct f16 pipelines, see REL above
+    factor = 1.5 if preset.startswith("llama3") else TINY
+    for i in range(n):   # token by token: every step is a decode step
+        lg = lm.forward_with_kv_cache([int(p[i])], kv, i)
+        if i in (2, 5, 64, 127, 128, 129, n - 1):
+            _check_logits(lg.to_numpy()[0], want[i], cfg["act_dtype"], factor=factor)
+    orc_py.lib().orc_kv_free(okv)
+
+
+@pytest.mark.parametrize("mode", ["graph", "paged", "paged-graph"])
+@pytest.mark.parametrize("case", [SPLIT_CASES[2], SPLIT_CASES[4]], ids=["bf16-rep4", "awq-2l"])
+def test_split_attention_generate_modes_agree(device, split_min, case, mode):
+    """graph replay switches from the short executable to the split-KV one when the host-tracked position crosses the threshold; paged caches
+    take the block-table form of the same kernels.  Ids must equal the eager ids of the single-launch path (threshold out of reach)."""
+    preset, over = case
+    model = synth.make_llama(preset, **over)
+    cfg = model["config"]
+    lm = runtime.LoadedModel.from_synth(device, model)
+    om = orc_py.OrcLlama(model)
+    k = 0
+    for seed in range(3, 60):   # first prompt whose oracle run has no near-tie before the switch plus a margin (deterministic)
+        p = synth.prompt_tokens(9, cfg["vocab"], seed=seed)
+        _, trace = om.generate(p, 40, trace=True)
+        k = _fair_prefix(trace)
+        if k >= 16:
+            break
+    assert k >= 16, "no prompt seed gives a fair fixture"
+    ex = runtime.Executor(lm)
+    split_min(100000)
+    base = ex.generate(p, 40, use_graph=False)
+    split_min(16)                       # prompt 9 + 40 new tokens: the switch happens after 7 generated tokens
+    got = ex.generate(p, 40, use_graph="graph" in mode, paged="paged" in mode)
+    # both paths are deterministic; they differ only in fp32 summation order inside attention, so ids agree wherever the top-2 gap is not a tie
+    assert got[:k].tolist() == base[:k].tolist(), (mode, got.tolist(), base.tolist(), k)
