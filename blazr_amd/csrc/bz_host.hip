@@ -618,16 +618,19 @@ static int build_fused(bz_model* m, const std::vector<std::string>& names, Fused
   }
   F->K = (int)rs[0]->K; F->N = 0;
   for (auto* r : rs) { if (r->K != F->K) BZ_FAIL(BZ_E_INVALID, "finalize: fused parts disagree on K"); F->N += (int)r->N; }
-  bool fusable = true;
-  for (auto* r : rs) {
-    if (r->kind != rs[0]->kind) fusable = false;
-    if (r->kind == 2 && !same_perm(r, rs[0])) fusable = false;
-    if (r->kind == 0 && r->dtype != rs[0]->dtype) fusable = false;
-    if (r->kind == 3 && r->ggml_type != rs[0]->ggml_type) fusable = false;
-  }
+  // consecutive parts of one storage kind share a launch (Q4_K_M gives q, k in Q4_K and v in Q6_K: [q, k] + [v])
+  auto compatible = [&](const RawTensor* a, const RawTensor* b) {
+    if (a->kind != b->kind) return false;
+    if (a->kind == 2 && !same_perm(a, b)) return false;
+    if (a->kind == 0 && a->dtype != b->dtype) return false;
+    if (a->kind == 3 && a->ggml_type != b->ggml_type) return false;
+    return true;
+  };
   std::vector<std::vector<RawTensor*>> groups;
-  if (fusable) groups.push_back(rs);
-  else for (auto* r : rs) groups.push_back({r});
+  for (auto* r : rs) {
+    if (!groups.empty() && compatible(groups.back()[0], r)) groups.back().push_back(r);
+    else groups.push_back({r});
+  }
   int noff = 0; size_t ri = 0;
   for (auto& g : groups) {
     LinearDev L;
