@@ -1591,6 +1591,7 @@ static int pf_gemm(bz_model* m, const LinearDev& P, const void* x16, int n, floa
   hipStream_t st = m->dev->stream;
   const int act = m->cfg.act_dtype;
   if (P.kind == LK_ROWS) return bzk_gemm_nt(st, act, x16, P.w, P.bias, n, P.N, P.K, act, y);
+  if (bzk_gemm_q4g_mfma_ok(P, act, n)) return bzk_gemm_q4g_mfma(st, P, x16, n, act, y);
   return bzk_gemm_q4g_rows(st, P, act, x16, n, act, m->pf_acc, y);
 }
 
@@ -1650,15 +1651,18 @@ extern "C" int bz_prefill_matmul(bz_model* m, const char* name, const bz_tensor*
   LinearDev L;
   BZ_TRY(find_linear(m, name, &L));
   std::lock_guard<std::recursive_mutex> lock__(m->mu);
-  if (L.kind != LK_ROWS || (L.wdt != BZ_F16 && L.wdt != BZ_BF16)) BZ_FAIL(BZ_E_UNSUPPORTED, "prefill_matmul: '%s' is not a dense f16 / bf16 weight", name);
+  const bool q4 = L.kind == LK_Q4G;   // int4 group-quantised weights x f16 activations (the AWQ / GPTQ prefill GEMM), S >= 32
+  if (q4 ? !bzk_gemm_q4g_mfma_ok(L, BZ_F16, S) : (L.kind != LK_ROWS || (L.wdt != BZ_F16 && L.wdt != BZ_BF16)))
+    BZ_FAIL(BZ_E_UNSUPPORTED, "prefill_matmul: '%s' is neither a dense f16 / bf16 weight nor an int4 weight without act-order (S >= 32)", name);
   if (!x || !y || x->dtype != BZ_F32 || y->dtype != BZ_F32 || S <= 0 || x->nbytes < (size_t)S * L.K * 4 || y->nbytes < (size_t)S * L.N * 4)
     BZ_FAIL(BZ_E_INVALID, "prefill_matmul: x must be F32 [S,%d], y F32 [S,%d]", L.K, L.N);
   BZ_HIP(hipSetDevice(m->dev->id));
   hipStream_t st = m->dev->stream;
   void* x16 = nullptr;
   BZ_HIP(hipMalloc(&x16, (size_t)S * L.K * 2));
-  int rc = bzk_pf_cvt16(st, L.wdt, (const float*)x->ptr, (size_t)S * L.K, x16);
-  if (rc == BZ_OK) rc = bzk_gemm_nt(st, L.wdt, x16, L.w, L.bias, S, L.N, L.K, BZ_F32, (float*)y->ptr);
+  const int xdt = q4 ? BZ_F16 : L.wdt;
+  int rc = bzk_pf_cvt16(st, xdt, (const float*)x->ptr, (size_t)S * L.K, x16);
+  if (rc == BZ_OK) rc = q4 ? bzk_gemm_q4g_mfma(st, L, x16, S, BZ_F32, (float*)y->ptr) : bzk_gemm_nt(st, L.wdt, x16, L.w, L.bias, S, L.N, L.K, BZ_F32, (float*)y->ptr);
   hipStreamSynchronize(st);
   hipFree(x16);
   return rc;

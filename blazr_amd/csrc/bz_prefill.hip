@@ -323,6 +323,113 @@ __global__ void k_pf_embed(const void* table, int tdt, const long long* tok, int
 
 }  // namespace
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// W4A16 GEMM on the matrix cores: Y[S,N] = R(X[S,K] . dequant(W)^T) for the int4 group-quantised layout of the decode kernels
+//   W [N/64][K/32][64 lanes][16 B] : lane = column, word j of a chunk = k 8j..8j+7 (byte b: low nibble k 8j+b, high nibble (q ^ 8) of k 8j+4+b)
+// A wave owns 64 rows x 64 columns; no LDS.  Per 32-k chunk it loads ONE 16-byte weight piece per lane and turns it into the four MFMA
+// B-fragments (two 32-column halves x two 16-k steps) with two V_PERMLANE32_SWAPs: swap(word0, word1) leaves {columns 0-31: k 0-7 | k 8-15}
+// in the first result and {columns 32-63: k 0-7 | k 8-15} in the second -- exactly the (column = lane & 31, k-half = lane >> 5) operand
+// layout of v_mfma_f32_32x32x16.  A nibble word becomes 8 f16 values (q - z), exact small integers: V_PERM_B32 drops each nibble under a
+// 0x64 exponent byte (1024 + q), one packed subtract of (1024 + z) -- 12 VALU per fragment against >= 2 MFMAs of 16 passes.  The group scale is
+// applied in f32 when a 128-k group's partial product is folded into the running sum, so the products are exact and the sums f32, as in the
+// decode kernels and the oracle.  A fragments (16 contiguous bytes of an activation row per lane) come straight from global memory / L1.
+// grid = (ceil(N / 256), ceil(S / 64)), 4 waves side by side along N.
+// ---------------------------------------------------------------------------------------------------------------------------------------
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint4 q4_frag_f16(unsigned w, f16x2 mz) {   // mz = -(1024 + z) in both halves
+  const unsigned lo = w & 0x0F0F0F0Fu, hi = ((w >> 4) & 0x0F0F0F0Fu) ^ 0x08080808u;
+  const unsigned p0 = __builtin_amdgcn_perm(0x64646464u, lo, 0x04010400u), p1 = __builtin_amdgcn_perm(0x64646464u, lo, 0x04030402u);
+  const unsigned p2 = __builtin_amdgcn_perm(0x64646464u, hi, 0x04010400u), p3 = __builtin_amdgcn_perm(0x64646464u, hi, 0x04030402u);
+  uint4 r;
+  r.x = __builtin_bit_cast(unsigned, (f16x2)(__builtin_bit_cast(f16x2, p0) + mz));
+  r.y = __builtin_bit_cast(unsigned, (f16x2)(__builtin_bit_cast(f16x2, p1) + mz));
+  r.z = __builtin_bit_cast(unsigned, (f16x2)(__builtin_bit_cast(f16x2, p2) + mz));
+  r.w = __builtin_bit_cast(unsigned, (f16x2)(__builtin_bit_cast(f16x2, p3) + mz));
+  return r;
+}
+
+__global__ __launch_bounds__(256) void k_gemm_q4g_mfma(const uint4* __restrict__ W, const __half* __restrict__ Sc, const unsigned char* __restrict__ Z,
+                                                       const float* __restrict__ bias, int N, int K, const unsigned short* __restrict__ X, int S, int act,
+                                                       float* __restrict__ Y) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
+  const int tile = blockIdx.x * 4 + wave;              // 64-column tile of this wave
+  if (tile * 64 >= N) return;
+  const int r0 = blockIdx.y * 64;
+  const int G = K >> 7, C32 = K >> 5;
+  const uint4* wp = W + (size_t)tile * C32 * 64 + lane;
+  const unsigned short* xa0 = X + (size_t)min(r0 + c, S - 1) * K + 8 * h;        // rows r0 + c and r0 + 32 + c (clamped; masked at the store)
+  const unsigned short* xa1 = X + (size_t)min(r0 + 32 + c, S - 1) * K + 8 * h;
+  const __half* sp = Sc + (size_t)tile * G * 64 + c;
+  const unsigned char* zp = Z + (size_t)tile * G * 64 + c;
+  f32x16 tot[2][2], grp[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int b = 0; b < 2; b++)
+#pragma unroll
+      for (int i = 0; i < 16; i++) tot[a][b][i] = 0.f;
+  // software pipeline: chunk kc+1's loads are in flight under chunk kc's MFMAs
+  u32x4 wn = __builtin_nontemporal_load((const u32x4*)wp);
+  uint4 an[2][2];
+  an[0][0] = *(const uint4*)(xa0); an[0][1] = *(const uint4*)(xa0 + 16);
+  an[1][0] = *(const uint4*)(xa1); an[1][1] = *(const uint4*)(xa1 + 16);
+  for (int g = 0; g < G; g++) {
+    const float s0 = __half2float(sp[(size_t)g * 64]), s1 = __half2float(sp[(size_t)g * 64 + 32]);
+    const _Float16 m0 = (_Float16)(-(1024.0f + (float)zp[(size_t)g * 64])), m1 = (_Float16)(-(1024.0f + (float)zp[(size_t)g * 64 + 32]));
+    const f16x2 mz0 = {m0, m0}, mz1 = {m1, m1};
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int b = 0; b < 2; b++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) grp[a][b][i] = 0.f;
+#pragma unroll
+    for (int cc = 0; cc < 4; cc++) {
+      const int kc = g * 4 + cc;
+      const u32x4 w = wn;
+      uint4 a[2][2];
+      a[0][0] = an[0][0]; a[0][1] = an[0][1]; a[1][0] = an[1][0]; a[1][1] = an[1][1];
+      {
+        const int kn = min(kc + 1, C32 - 1);            // last chunk: a harmless re-load
+        wn = __builtin_nontemporal_load((const u32x4*)(wp + (size_t)kn * 64));
+        an[0][0] = *(const uint4*)(xa0 + kn * 32); an[0][1] = *(const uint4*)(xa0 + kn * 32 + 16);
+        an[1][0] = *(const uint4*)(xa1 + kn * 32); an[1][1] = *(const uint4*)(xa1 + kn * 32 + 16);
+      }
+      const u32x2 r01 = __builtin_amdgcn_permlane32_swap(w.x, w.y, false, false);   // .x: columns 0-31 {k 0-7 | k 8-15}; .y: columns 32-63
+      const u32x2 r23 = __builtin_amdgcn_permlane32_swap(w.z, w.w, false, false);   // same for k 16-31
+      const uint4 b00 = q4_frag_f16(r01.x, mz0), b01 = q4_frag_f16(r01.y, mz1);
+      const uint4 b10 = q4_frag_f16(r23.x, mz0), b11 = q4_frag_f16(r23.y, mz1);
+#pragma unroll
+      for (int mt = 0; mt < 2; mt++) {
+        grp[mt][0] = mfma16<BZ_F16>(a[mt][0], b00, grp[mt][0]);
+        grp[mt][1] = mfma16<BZ_F16>(a[mt][0], b01, grp[mt][1]);
+        grp[mt][0] = mfma16<BZ_F16>(a[mt][1], b10, grp[mt][0]);
+        grp[mt][1] = mfma16<BZ_F16>(a[mt][1], b11, grp[mt][1]);
+      }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+      for (int i = 0; i < 16; i++) { tot[mt][0][i] = fmaf(s0, grp[mt][0][i], tot[mt][0][i]); tot[mt][1][i] = fmaf(s1, grp[mt][1][i], tot[mt][1][i]); }
+  }
+  // C layout: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+#pragma unroll
+  for (int T = 0; T < 2; T++) {
+    const int n = tile * 64 + 32 * T + c;
+    const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const int m = r0 + 32 * mt + (i & 3) + 8 * (i >> 2) + 4 * h;
+        if (m < S) Y[(size_t)m * N + n] = pf_round(tot[mt][T][i] + bv, act);
+      }
+  }
+}
+
 // ---- launchers ---------------------------------------------------------------------------------------------------------------------------
 int bzk_gemm_nt(hipStream_t s, int dt, const void* x16, const void* w, const float* bias, int S, int N, int K, int act, float* y) {
   if (dt != BZ_F16 && dt != BZ_BF16) BZ_FAIL(BZ_E_UNSUPPORTED, "gemm_nt: 16-bit operands only");
@@ -341,6 +448,20 @@ int bzk_gemm_nt(hipStream_t s, int dt, const void* x16, const void* w, const flo
 #undef LAUNCH_GEMM_M
 #undef LAUNCH_GEMM_N
 #undef LAUNCH_GEMM
+  BZ_HIP(hipGetLastError());
+  return BZ_OK;
+}
+
+bool bzk_gemm_q4g_mfma_ok(const LinearDev& L, int xdt, int rows) {
+  static const bool off = getenv("BZ_NO_Q4G_MFMA") != nullptr;
+  return !off && L.kind == LK_Q4G && !L.perm && L.K % 128 == 0 && L.N % 64 == 0 && xdt == BZ_F16 && rows >= 32;
+}
+// Y[S][N] (f32, rounded to act) = X16[S][K] . dequant(W)^T on the matrix cores (f16 activations)
+int bzk_gemm_q4g_mfma(hipStream_t s, const LinearDev& L, const void* x16, int S, int act, float* y) {
+  if (!bzk_gemm_q4g_mfma_ok(L, BZ_F16, S)) BZ_FAIL(BZ_E_UNSUPPORTED, "gemm_q4g_mfma: unsupported weight / activation format");
+  const dim3 grid((L.N / 64 + 3) / 4, (S + 63) / 64);
+  BZ_LAUNCH("gemm_q4g_mfma", 2.0 * S * (double)L.N * L.K, k_gemm_q4g_mfma, grid, dim3(256), 0, s, (const uint4*)L.w, (const __half*)L.scales,
+            (const unsigned char*)L.zeros, L.bias, L.N, L.K, (const unsigned short*)x16, S, act, y);
   BZ_HIP(hipGetLastError());
   return BZ_OK;
 }

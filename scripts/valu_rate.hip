@@ -1,4 +1,4 @@
-// micro-benchmark: issue rate of v_dot4c_i32_i8 vs v_fma_f32 vs v_and on gfx950 (wave64), 1..4 waves per SIMD
+// micro-benchmark: issue rate of v_dot4c_i32_i8 / v_dot8_i32_i4 vs v_fma_f32 vs v_and on gfx950 (wave64), 1..4 waves per SIMD
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 template <int OP>
@@ -11,7 +11,8 @@ __global__ void k(int* out, int iters, int a0, int b0) {
     for (int j = 0; j < 8; j++) {
       if (OP == 0) acc[j] = __builtin_amdgcn_sdot4(a, b + j, acc[j], false);
       else if (OP == 1) f[j] = __builtin_fmaf(f[j], 1.0001f, 0.5f);
-      else acc[j] = (acc[j] & a) + b;
+      else if (OP == 2) acc[j] = (acc[j] & a) + b;
+      else acc[j] = __builtin_amdgcn_sdot8(a, b + j, acc[j], false);
     }
   }
   int s = 0;
@@ -23,19 +24,20 @@ int main() {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const int iters = 20000;
   for (int wps = 1; wps <= 4; wps *= 2) {
-    for (int op = 0; op < 3; op++) {
+    for (int op = 0; op < 4; op++) {
       dim3 grid(256), block(256 * wps);   // 256 CUs, wps waves per SIMD
       for (int rep = 0; rep < 2; rep++) {
         hipEventRecord(e0);
         if (op == 0) hipLaunchKernelGGL(k<0>, grid, block, 0, 0, d, iters, 3, 5);
         else if (op == 1) hipLaunchKernelGGL(k<1>, grid, block, 0, 0, d, iters, 3, 5);
-        else hipLaunchKernelGGL(k<2>, grid, block, 0, 0, d, iters, 3, 5);
+        else if (op == 2) hipLaunchKernelGGL(k<2>, grid, block, 0, 0, d, iters, 3, 5);
+        else hipLaunchKernelGGL(k<3>, grid, block, 0, 0, d, iters, 3, 5);
         hipEventRecord(e1); hipEventSynchronize(e1);
       }
       float ms; hipEventElapsedTime(&ms, e0, e1);
       double instr_per_wave = (double)iters * 8 * (op == 2 ? 2 : 1);
       double ns_per_instr_per_simd = ms * 1e6 / (instr_per_wave * wps);
-      printf("waves/SIMD=%d op=%s: %.3f ms -> %.2f ns per wave-instr per SIMD (%.1f cycles @2.4GHz)\n", wps, op == 0 ? "dot4" : (op == 1 ? "fma " : "and+add"), ms,
+      printf("waves/SIMD=%d op=%s: %.3f ms -> %.2f ns per wave-instr per SIMD (%.1f cycles @2.4GHz)\n", wps, op == 0 ? "dot4" : (op == 1 ? "fma " : (op == 2 ? "and+add" : "dot8")), ms,
              ns_per_instr_per_simd, ns_per_instr_per_simd * 2.4);
     }
   }

@@ -245,6 +245,35 @@ def test_prefill_matmul_mfma(device, S):
         assert np.abs(got - want).max() <= 3e-6 * np.abs(want).max(), (preset, S)
 
 
+@pytest.mark.parametrize("S", [32, 33, 130, 300])
+def test_prefill_matmul_q4g_mfma(device, S):
+    """W4A16 GEMM on the matrix cores (int4 group-quantised weights, f16 activations): exact (q - z) fragments, f32 sums, group scale in f32"""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    import npref
+    rng = np.random.default_rng(100 + S)
+    cases = [("tiny-awq", {}, [("model.layers.1.mlp.down_proj.weight", "down"), ("model.layers.0.mlp.gate_proj.weight", "gate")]),
+             ("tiny-gptq", dict(bias=True), [("model.layers.1.self_attn.q_proj.weight", "q")])]
+    if S in (33, 130):
+        cases.append(("llama3-8b-awq-2l", {}, [("model.layers.1.mlp.down_proj.weight", "down"), ("model.layers.0.self_attn.k_proj.weight", "k")]))
+    for preset, over, names in cases:
+        model = synth.make_llama(preset, **over)
+        lm = runtime.LoadedModel.from_synth(device, model)
+        for name, short in names:
+            layer = int(name.split(".")[2])
+            spec = model["layers"][layer][short]
+            W = npref.dequant(spec).astype(np.float64)
+            N, K = W.shape
+            x = rng.standard_normal((S, K)).astype(np.float32)
+            tx, ty = device.tensor(x), device.zeros((S, N))
+            L.check(L.lib().bz_prefill_matmul(lm.h, name.encode(), tx.h, S, ty.h))
+            want = _np16(x, "f16").astype(np.float64) @ W.T
+            if spec.get("bias") is not None:
+                want = want + np.asarray(spec["bias"], dtype=np.float64)[None, :]
+            got = ty.to_numpy()
+            assert np.abs(got - want).max() <= 3e-6 * np.abs(want).max(), (preset, name, S, float(np.abs(got - want).max()), float(np.abs(want).max()))
+
+
 def test_batched_prefill_then_decode_matches_oracle(device):
     # 24-token prompt -> MFMA prefill path; the following decode steps read the cache it wrote
     for preset in ("tiny-bf16",):
