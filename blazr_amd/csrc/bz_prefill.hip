@@ -334,7 +334,7 @@ __global__ void k_pf_embed(const void* table, int tdt, const long long* tok, int
 // 0x64 exponent byte (1024 + q), one packed subtract of (1024 + z) -- 12 VALU per fragment against >= 2 MFMAs of 16 passes.  The group scale is
 // applied in f32 when a 128-k group's partial product is folded into the running sum, so the products are exact and the sums f32, as in the
 // decode kernels and the oracle.  A fragments (16 contiguous bytes of an activation row per lane) come straight from global memory / L1.
-// grid = (ceil(N / 256), ceil(S / 64)), 4 waves side by side along N.
+// grid = (N / 64, ceil(S / 64)) single-wave blocks.
 // ---------------------------------------------------------------------------------------------------------------------------------------
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -351,11 +351,12 @@ __device__ __forceinline__ uint4 q4_frag_f16(unsigned w, f16x2 mz) {   // mz = -
   return r;
 }
 
-__global__ __launch_bounds__(256) void k_gemm_q4g_mfma(const uint4* __restrict__ W, const __half* __restrict__ Sc, const unsigned char* __restrict__ Z,
+template <int WPB>   // waves per block, side by side along N
+__global__ __launch_bounds__(WPB * 64) void k_gemm_q4g_mfma(const uint4* __restrict__ W, const __half* __restrict__ Sc, const unsigned char* __restrict__ Z,
                                                        const float* __restrict__ bias, int N, int K, const unsigned short* __restrict__ X, int S, int act,
                                                        float* __restrict__ Y) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
-  const int tile = blockIdx.x * 4 + wave;              // 64-column tile of this wave
+  const int tile = blockIdx.x * WPB + wave;            // 64-column tile of this wave
   if (tile * 64 >= N) return;
   const int r0 = blockIdx.y * 64;
   const int G = K >> 7, C32 = K >> 5;
@@ -459,9 +460,20 @@ bool bzk_gemm_q4g_mfma_ok(const LinearDev& L, int xdt, int rows) {
 // Y[S][N] (f32, rounded to act) = X16[S][K] . dequant(W)^T on the matrix cores (f16 activations)
 int bzk_gemm_q4g_mfma(hipStream_t s, const LinearDev& L, const void* x16, int S, int act, float* y) {
   if (!bzk_gemm_q4g_mfma_ok(L, BZ_F16, S)) BZ_FAIL(BZ_E_UNSUPPORTED, "gemm_q4g_mfma: unsupported weight / activation format");
-  const dim3 grid((L.N / 64 + 3) / 4, (S + 63) / 64);
-  BZ_LAUNCH("gemm_q4g_mfma", 2.0 * S * (double)L.N * L.K, k_gemm_q4g_mfma, grid, dim3(256), 0, s, (const uint4*)L.w, (const __half*)L.scales,
-            (const unsigned char*)L.zeros, L.bias, L.N, L.K, (const unsigned short*)x16, S, act, y);
+  // one wave per block (measured faster than four at every prompt length, 32..2000 tokens): the A rows are shared through L1 / L2 either
+  // way, and single-wave blocks spread a small grid (o_proj / down at a few hundred rows: 64 x 8 tiles) over the whole chip
+  static const char* wpb_env = getenv("BZ_Q4G_MFMA_WPB");
+  const int wpb = wpb_env ? atoi(wpb_env) : 1;
+  const double flops = 2.0 * S * (double)L.N * L.K;
+  if (wpb == 4) {
+    const dim3 grid((L.N / 64 + 3) / 4, (S + 63) / 64);
+    BZ_LAUNCH("gemm_q4g_mfma", flops, k_gemm_q4g_mfma<4>, grid, dim3(256), 0, s, (const uint4*)L.w, (const __half*)L.scales,
+              (const unsigned char*)L.zeros, L.bias, L.N, L.K, (const unsigned short*)x16, S, act, y);
+  } else {
+    const dim3 grid(L.N / 64, (S + 63) / 64);
+    BZ_LAUNCH("gemm_q4g_mfma", flops, k_gemm_q4g_mfma<1>, grid, dim3(64), 0, s, (const uint4*)L.w, (const __half*)L.scales,
+              (const unsigned char*)L.zeros, L.bias, L.N, L.K, (const unsigned short*)x16, S, act, y);
+  }
   BZ_HIP(hipGetLastError());
   return BZ_OK;
 }
