@@ -273,6 +273,7 @@ struct bz_model {
   int pf_rows = 0; float* pf_h = nullptr; float* pf_t = nullptr; float* pf_qkv = nullptr; float* pf_gu = nullptr; void* pf_x16 = nullptr;
   int* row_pos = nullptr; int row_pos_n = 0;   // device copy of a decode batch's per-row positions
   long long* pf_acc = nullptr;   // int4 multi-row GEMM scratch: 8 rows x widest N, fixed point, kept zero between launches
+  float* pf_ws = nullptr; size_t pf_ws_bytes = 0;   // W4A16 MFMA GEMM: split-K partials for short prompts / decode batches
   long long* ring[3] = {nullptr, nullptr, nullptr};
   float* dring[3] = {nullptr, nullptr, nullptr};   // direct-output twins of the ring (ROWS kernels)
   int ring_n = 0;
@@ -1582,6 +1583,7 @@ static int prefill_ws(bz_model* m, int rows) {
   BZ_TRY(dev_alloc(m, &p, (size_t)rows * 2 * c.inter * 4)); m->pf_gu = (float*)p;
   BZ_TRY(dev_alloc(m, &p, (size_t)rows * xw * 2)); m->pf_x16 = p;
   if (!m->pf_acc) { const size_t an = 8 * std::max<size_t>(std::max<size_t>(qn, 2 * (size_t)c.inter), c.hidden); BZ_TRY(dev_alloc(m, &p, an * 8)); m->pf_acc = (long long*)p; BZ_HIP(hipMemset(p, 0, an * 8)); }
+  if (!m->pf_ws) { m->pf_ws_bytes = (size_t)48 << 20; BZ_TRY(dev_alloc(m, &p, m->pf_ws_bytes)); m->pf_ws = (float*)p; }
   m->pf_rows = rows;
   return BZ_OK;
 }
@@ -1591,7 +1593,7 @@ static int pf_gemm(bz_model* m, const LinearDev& P, const void* x16, int n, floa
   hipStream_t st = m->dev->stream;
   const int act = m->cfg.act_dtype;
   if (P.kind == LK_ROWS) return bzk_gemm_nt(st, act, x16, P.w, P.bias, n, P.N, P.K, act, y);
-  if (bzk_gemm_q4g_mfma_ok(P, act, n)) return bzk_gemm_q4g_mfma(st, P, x16, n, act, y);
+  if (bzk_gemm_q4g_mfma_ok(P, act, n)) return bzk_gemm_q4g_mfma(st, P, x16, n, act, y, m->pf_ws, m->pf_ws_bytes);
   return bzk_gemm_q4g_rows(st, P, act, x16, n, act, m->pf_acc, y);
 }
 
@@ -1651,9 +1653,9 @@ extern "C" int bz_prefill_matmul(bz_model* m, const char* name, const bz_tensor*
   LinearDev L;
   BZ_TRY(find_linear(m, name, &L));
   std::lock_guard<std::recursive_mutex> lock__(m->mu);
-  const bool q4 = L.kind == LK_Q4G;   // int4 group-quantised weights x f16 activations (the AWQ / GPTQ prefill GEMM), S >= 32
+  const bool q4 = L.kind == LK_Q4G;   // int4 group-quantised weights x f16 activations (the AWQ / GPTQ prefill GEMM), S >= 9
   if (q4 ? !bzk_gemm_q4g_mfma_ok(L, BZ_F16, S) : (L.kind != LK_ROWS || (L.wdt != BZ_F16 && L.wdt != BZ_BF16)))
-    BZ_FAIL(BZ_E_UNSUPPORTED, "prefill_matmul: '%s' is neither a dense f16 / bf16 weight nor an int4 weight without act-order (S >= 32)", name);
+    BZ_FAIL(BZ_E_UNSUPPORTED, "prefill_matmul: '%s' is neither a dense f16 / bf16 weight nor an int4 weight without act-order (S >= 9)", name);
   if (!x || !y || x->dtype != BZ_F32 || y->dtype != BZ_F32 || S <= 0 || x->nbytes < (size_t)S * L.K * 4 || y->nbytes < (size_t)S * L.N * 4)
     BZ_FAIL(BZ_E_INVALID, "prefill_matmul: x must be F32 [S,%d], y F32 [S,%d]", L.K, L.N);
   BZ_HIP(hipSetDevice(m->dev->id));

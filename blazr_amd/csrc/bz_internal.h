@@ -164,8 +164,8 @@ struct GemvOut {
 int bzk_gemv(hipStream_t s, const LinearDev& L, const Pro& pro, const GemvOut& out, int act);
 int bzk_gemv_rows_blocks(const LinearDev& L);
 bool bzk_gemm_q4g_rows_ok(const LinearDev& L);
-bool bzk_gemm_q4g_mfma_ok(const LinearDev& L, int xdt, int rows);   // int4 weights x f16 activations on the matrix cores (rows >= 32)
-int bzk_gemm_q4g_mfma(hipStream_t s, const LinearDev& L, const void* x16, int S, int act, float* y);
+bool bzk_gemm_q4g_mfma_ok(const LinearDev& L, int xdt, int rows);   // int4 weights x f16 activations on the matrix cores (rows >= 9)
+int bzk_gemm_q4g_mfma(hipStream_t s, const LinearDev& L, const void* x16, int S, int act, float* y, float* ws = nullptr, size_t ws_bytes = 0);   // ws: split-K partials (short prompts)
 int bzk_gemm_q4g_rows(hipStream_t s, const LinearDev& L, int xdt, const void* x16, int rows, int act, long long* acc, float* y);
 int bzk_rows_choose_sk(int N, int K);
 bool bzk_mlp_fusable(const LinearDev& gu, const LinearDev& dn, int H, int I);

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 
+#include <algorithm>
 #include "bz_internal.h"
 
 namespace {
@@ -354,7 +355,7 @@ __device__ __forceinline__ uint4 q4_frag_f16(unsigned w, f16x2 mz) {   // mz = -
 template <int WPB>   // waves per block, side by side along N
 __global__ __launch_bounds__(WPB * 64) void k_gemm_q4g_mfma(const uint4* __restrict__ W, const __half* __restrict__ Sc, const unsigned char* __restrict__ Z,
                                                        const float* __restrict__ bias, int N, int K, const unsigned short* __restrict__ X, int S, int act,
-                                                       float* __restrict__ Y) {
+                                                       float* __restrict__ Y, int GPB, float* __restrict__ part) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
   const int tile = blockIdx.x * WPB + wave;            // 64-column tile of this wave
   if (tile * 64 >= N) return;
@@ -373,11 +374,14 @@ __global__ __launch_bounds__(WPB * 64) void k_gemm_q4g_mfma(const uint4* __restr
 #pragma unroll
       for (int i = 0; i < 16; i++) tot[a][b][i] = 0.f;
   // software pipeline: chunk kc+1's loads are in flight under chunk kc's MFMAs
-  u32x4 wn = __builtin_nontemporal_load((const u32x4*)wp);
+  const int kc0 = blockIdx.z * GPB * 4;
+  u32x4 wn = __builtin_nontemporal_load((const u32x4*)(wp + (size_t)kc0 * 64));
   uint4 an[2][2];
-  an[0][0] = *(const uint4*)(xa0); an[0][1] = *(const uint4*)(xa0 + 16);
-  an[1][0] = *(const uint4*)(xa1); an[1][1] = *(const uint4*)(xa1 + 16);
-  for (int g = 0; g < G; g++) {
+  an[0][0] = *(const uint4*)(xa0 + kc0 * 32); an[0][1] = *(const uint4*)(xa0 + kc0 * 32 + 16);
+  an[1][0] = *(const uint4*)(xa1 + kc0 * 32); an[1][1] = *(const uint4*)(xa1 + kc0 * 32 + 16);
+  // K split (small S): block z owns groups [z GPB, (z+1) GPB) and writes an unrounded partial; k_q4g_mfma_reduce sums them in a fixed order
+  const int g_beg = blockIdx.z * GPB, g_end = min(G, g_beg + GPB);
+  for (int g = g_beg; g < g_end; g++) {
     const float s0 = __half2float(sp[(size_t)g * 64]), s1 = __half2float(sp[(size_t)g * 64 + 32]);
     const _Float16 m0 = (_Float16)(-(1024.0f + (float)zp[(size_t)g * 64])), m1 = (_Float16)(-(1024.0f + (float)zp[(size_t)g * 64 + 32]));
     const f16x2 mz0 = {m0, m0}, mz1 = {m1, m1};
@@ -426,8 +430,19 @@ __global__ __launch_bounds__(WPB * 64) void k_gemm_q4g_mfma(const uint4* __restr
 #pragma unroll
       for (int i = 0; i < 16; i++) {
         const int m = r0 + 32 * mt + (i & 3) + 8 * (i >> 2) + 4 * h;
-        if (m < S) Y[(size_t)m * N + n] = pf_round(tot[mt][T][i] + bv, act);
+        if (m < S) {
+          if (part) part[((size_t)blockIdx.z * S + m) * N + n] = tot[mt][T][i];
+          else Y[(size_t)m * N + n] = pf_round(tot[mt][T][i] + bv, act);
+        }
       }
+  }
+}
+
+__global__ void k_q4g_mfma_reduce(const float* __restrict__ part, int KS, size_t SN, int N, const float* __restrict__ bias, int act, float* __restrict__ Y) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < SN; i += (size_t)gridDim.x * 256) {
+    float v = 0.f;
+    for (int z = 0; z < KS; z++) v += part[(size_t)z * SN + i];      // fixed order: deterministic
+    Y[i] = pf_round(v + (bias ? bias[i % N] : 0.f), act);
   }
 }
 
@@ -455,26 +470,43 @@ int bzk_gemm_nt(hipStream_t s, int dt, const void* x16, const void* w, const flo
 
 bool bzk_gemm_q4g_mfma_ok(const LinearDev& L, int xdt, int rows) {
   static const bool off = getenv("BZ_NO_Q4G_MFMA") != nullptr;
-  return !off && L.kind == LK_Q4G && !L.perm && L.K % 128 == 0 && L.N % 64 == 0 && xdt == BZ_F16 && rows >= 32;
+  return !off && L.kind == LK_Q4G && !L.perm && L.K % 128 == 0 && L.N % 64 == 0 && xdt == BZ_F16 && rows >= 9;   // 9+: the multi-row dot4 kernel would need a second pass over the weights
 }
 // Y[S][N] (f32, rounded to act) = X16[S][K] . dequant(W)^T on the matrix cores (f16 activations)
-int bzk_gemm_q4g_mfma(hipStream_t s, const LinearDev& L, const void* x16, int S, int act, float* y) {
+int bzk_gemm_q4g_mfma(hipStream_t s, const LinearDev& L, const void* x16, int S, int act, float* y, float* ws, size_t ws_bytes) {
   if (!bzk_gemm_q4g_mfma_ok(L, BZ_F16, S)) BZ_FAIL(BZ_E_UNSUPPORTED, "gemm_q4g_mfma: unsupported weight / activation format");
   // one wave per block (measured faster than four at every prompt length, 32..2000 tokens): the A rows are shared through L1 / L2 either
   // way, and single-wave blocks spread a small grid (o_proj / down at a few hundred rows: 64 x 8 tiles) over the whole chip
   static const char* wpb_env = getenv("BZ_Q4G_MFMA_WPB");
+  static const bool no_ks = getenv("BZ_Q4G_MFMA_NO_KSPLIT") != nullptr;
   const int wpb = wpb_env ? atoi(wpb_env) : 1;
   const double flops = 2.0 * S * (double)L.N * L.K;
+  const int G = L.K / 128, rt = (S + 63) / 64;
+  // short prompts / decode batches: too few 64 x 64 tiles to fill the chip -> split K over blockIdx.z into partials (summed in a fixed order)
+  const long long tiles = (long long)(L.N / 64) * rt;
+  int KS = 1, GPB = G;
+  if (!no_ks && ws && tiles < 768) {
+    const int want = (int)std::min<long long>(G, (1024 + tiles - 1) / tiles);
+    GPB = (G + want - 1) / want;
+    KS = (G + GPB - 1) / GPB;
+    if (KS < 2 || (size_t)KS * S * L.N * 4 > ws_bytes) { KS = 1; GPB = G; }
+  }
+  float* part = KS > 1 ? ws : nullptr;
   if (wpb == 4) {
-    const dim3 grid((L.N / 64 + 3) / 4, (S + 63) / 64);
+    const dim3 grid((L.N / 64 + 3) / 4, rt, KS);
     BZ_LAUNCH("gemm_q4g_mfma", flops, k_gemm_q4g_mfma<4>, grid, dim3(256), 0, s, (const uint4*)L.w, (const __half*)L.scales,
-              (const unsigned char*)L.zeros, L.bias, L.N, L.K, (const unsigned short*)x16, S, act, y);
+              (const unsigned char*)L.zeros, L.bias, L.N, L.K, (const unsigned short*)x16, S, act, y, GPB, part);
   } else {
-    const dim3 grid(L.N / 64, (S + 63) / 64);
+    const dim3 grid(L.N / 64, rt, KS);
     BZ_LAUNCH("gemm_q4g_mfma", flops, k_gemm_q4g_mfma<1>, grid, dim3(64), 0, s, (const uint4*)L.w, (const __half*)L.scales,
-              (const unsigned char*)L.zeros, L.bias, L.N, L.K, (const unsigned short*)x16, S, act, y);
+              (const unsigned char*)L.zeros, L.bias, L.N, L.K, (const unsigned short*)x16, S, act, y, GPB, part);
   }
   BZ_HIP(hipGetLastError());
+  if (KS > 1) {
+    const size_t SN = (size_t)S * L.N;
+    hipLaunchKernelGGL(k_q4g_mfma_reduce, dim3((unsigned)std::min<size_t>((SN + 255) / 256, 2048)), dim3(256), 0, s, (const float*)ws, KS, SN, L.N, L.bias, act, y);
+    BZ_HIP(hipGetLastError());
+  }
   return BZ_OK;
 }
 

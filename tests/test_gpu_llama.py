@@ -245,7 +245,7 @@ def test_prefill_matmul_mfma(device, S):
         assert np.abs(got - want).max() <= 3e-6 * np.abs(want).max(), (preset, S)
 
 
-@pytest.mark.parametrize("S", [32, 33, 130, 300])
+@pytest.mark.parametrize("S", [9, 17, 32, 33, 130, 300])
 def test_prefill_matmul_q4g_mfma(device, S):
     """W4A16 GEMM on the matrix cores (int4 group-quantised weights, f16 activations): exact (q - z) fragments, f32 sums, group scale in f32"""
     import sys, os
