@@ -448,6 +448,45 @@ __device__ __forceinline__ void q4g_consume(const uint4 (&w)[4], int g, const ui
   y += (s * __int_as_float(g1.x)) * f;
 }
 
+// two weight tiles against the SAME activation group (gate and up of the fused MLP): the x planes are read from LDS once
+__device__ __forceinline__ void q4g_consume2(const uint4 (&wa)[4], const uint4 (&wb)[4], int g, const uint4* xh4, const uint4* xm4, const uint4* xl4,
+                                             const int4* gpar, float sa, int za, float sb, int zb, float& ya, float& yb) {
+  int Aa[3] = {0, 0, 0}, Ba[3] = {0, 0, 0}, Ab[3] = {0, 0, 0}, Bb[3] = {0, 0, 0};
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    const uint4 h0 = xh4[g * 8 + c * 2], h1 = xh4[g * 8 + c * 2 + 1];
+    const uint4 m0 = xm4[g * 8 + c * 2], m1 = xm4[g * 8 + c * 2 + 1];
+    const uint4 l0 = xl4[g * 8 + c * 2], l1 = xl4[g * 8 + c * 2 + 1];
+    const unsigned Xh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+    const unsigned Xm[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+    const unsigned Xl[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+    const unsigned Wa[4] = {wa[c].x, wa[c].y, wa[c].z, wa[c].w};
+    const unsigned Wb[4] = {wb[c].x, wb[c].y, wb[c].z, wb[c].w};
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int a0 = (int)(Wa[j] & 0x0F0F0F0Fu), b0 = (int)(Wa[j] & 0xF0F0F0F0u);
+      const int a1 = (int)(Wb[j] & 0x0F0F0F0Fu), b1 = (int)(Wb[j] & 0xF0F0F0F0u);
+      Aa[0] = __builtin_amdgcn_sdot4(a0, (int)Xh[2 * j], Aa[0], false); Aa[1] = __builtin_amdgcn_sdot4(a0, (int)Xm[2 * j], Aa[1], false);
+      Aa[2] = __builtin_amdgcn_sdot4(a0, (int)Xl[2 * j], Aa[2], false);
+      Ba[0] = __builtin_amdgcn_sdot4(b0, (int)Xh[2 * j + 1], Ba[0], false); Ba[1] = __builtin_amdgcn_sdot4(b0, (int)Xm[2 * j + 1], Ba[1], false);
+      Ba[2] = __builtin_amdgcn_sdot4(b0, (int)Xl[2 * j + 1], Ba[2], false);
+      Ab[0] = __builtin_amdgcn_sdot4(a1, (int)Xh[2 * j], Ab[0], false); Ab[1] = __builtin_amdgcn_sdot4(a1, (int)Xm[2 * j], Ab[1], false);
+      Ab[2] = __builtin_amdgcn_sdot4(a1, (int)Xl[2 * j], Ab[2], false);
+      Bb[0] = __builtin_amdgcn_sdot4(b1, (int)Xh[2 * j + 1], Bb[0], false); Bb[1] = __builtin_amdgcn_sdot4(b1, (int)Xm[2 * j + 1], Bb[1], false);
+      Bb[2] = __builtin_amdgcn_sdot4(b1, (int)Xl[2 * j + 1], Bb[2], false);
+    }
+  }
+  const int4 g1 = gpar[2 * g], g2 = gpar[2 * g + 1];
+  {
+    const int Uh = (Aa[0] << 4) + Ba[0] + g1.y - za * g2.x, Um = (Aa[1] << 4) + Ba[1] + g1.z - za * g2.y, Ul = (Aa[2] << 4) + Ba[2] + g1.w - za * g2.z;
+    ya += (sa * __int_as_float(g1.x)) * fmaf((float)Uh, 65536.0f, fmaf((float)Um, 256.0f, (float)Ul));
+  }
+  {
+    const int Uh = (Ab[0] << 4) + Bb[0] + g1.y - zb * g2.x, Um = (Ab[1] << 4) + Bb[1] + g1.z - zb * g2.y, Ul = (Ab[2] << 4) + Bb[2] + g1.w - zb * g2.z;
+    yb += (sb * __int_as_float(g1.x)) * fmaf((float)Uh, 65536.0f, fmaf((float)Um, 256.0f, (float)Ul));
+  }
+}
+
 // same arithmetic over NCH 32-k chunks whose x planes start at uint4 index xo; group parameters at gpar[gp], gpar[gp+1]
 template <int NCH>
 __device__ __forceinline__ void q4g_consume_n(const uint4 (&w)[NCH], int xo, int gp, const uint4* xh4, const uint4* xm4, const uint4* xl4,
@@ -633,8 +672,7 @@ __global__ __launch_bounds__(512) void k_mlp_q4g(const uint4* __restrict__ Wgu, 
   float sd[TPW]; int zd[TPW];
 #pragma unroll
   for (int b = 0; b < GPW; b++) {
-    q4g_consume(Ag[b & 1], gbeg + b, xh4, xm4, xl4, gpar, sg[b], zg[b], yg);
-    q4g_consume(Au[b & 1], gbeg + b, xh4, xm4, xl4, gpar, su[b], zu[b], yu);
+    q4g_consume2(Ag[b & 1], Au[b & 1], gbeg + b, xh4, xm4, xl4, gpar, sg[b], zg[b], su[b], zu[b], yg, yu);
     if (b + 2 < GPW) {
 #pragma unroll
       for (int c = 0; c < 4; c++) { Ag[b & 1][c] = ldnt(wg + ((b + 2) * 4 + c) * 64); Au[b & 1][c] = ldnt(wu + ((b + 2) * 4 + c) * 64); }
