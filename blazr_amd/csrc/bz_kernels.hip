@@ -568,6 +568,9 @@ __device__ __forceinline__ void quant_x64(const float* a, unsigned* xh, unsigned
 // down_proj is a sum over the intermediate dimension, so the slabs combine through the fixed-point accumulator.
 // One launch streams 81 % of a layer's bytes with one fused-norm prologue per block.
 // ---------------------------------------------------------------------------------------------------------
+#ifndef MLP_DEPTH
+#define MLP_DEPTH 2
+#endif
 template <int FIX, int GPW, int TPW>   // GPW k-groups per wave (gate/up), TPW output tiles per wave (down)
 __global__ __launch_bounds__(512) void k_mlp_q4g(const uint4* __restrict__ Wgu, const __half* __restrict__ Sgu, const unsigned char* __restrict__ Zgu,
                                                  const float* __restrict__ bgu, const uint4* __restrict__ Wd, const __half* __restrict__ Sd,
@@ -622,12 +625,17 @@ __global__ __launch_bounds__(512) void k_mlp_q4g(const uint4* __restrict__ Wgu, 
   //     k-range up front (the first version of this kernel) over-subscribes the memory system.
   const uint4* wg = Wgu + ((size_t)sl * (H >> 5) + gbeg * 4) * 64 + lane;
   const uint4* wu = Wgu + ((size_t)(NTI + sl) * (H >> 5) + gbeg * 4) * 64 + lane;
-  uint4 Ag[2][4], Au[2][4];
+  constexpr int ND = (GPW >= 3 && MLP_DEPTH == 3) ? 3 : 2;   // groups in flight per wave
+  uint4 Ag[ND][4], Au[ND][4];
 #pragma unroll
   for (int c = 0; c < 4; c++) { Ag[0][c] = ldnt(wg + c * 64); Au[0][c] = ldnt(wu + c * 64); }
   if (GPW > 1) {
 #pragma unroll
     for (int c = 0; c < 4; c++) { Ag[1][c] = ldnt(wg + (4 + c) * 64); Au[1][c] = ldnt(wu + (4 + c) * 64); }
+  if (ND == 3) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) { Ag[ND - 1][c] = ldnt(wg + (8 + c) * 64); Au[ND - 1][c] = ldnt(wu + (8 + c) * 64); }
+  }
   }
   float sg[GPW], su[GPW]; int zg[GPW], zu[GPW];
 #pragma unroll
@@ -672,10 +680,10 @@ __global__ __launch_bounds__(512) void k_mlp_q4g(const uint4* __restrict__ Wgu, 
   float sd[TPW]; int zd[TPW];
 #pragma unroll
   for (int b = 0; b < GPW; b++) {
-    q4g_consume2(Ag[b & 1], Au[b & 1], gbeg + b, xh4, xm4, xl4, gpar, sg[b], zg[b], su[b], zu[b], yg, yu);
-    if (b + 2 < GPW) {
+    q4g_consume2(Ag[b % ND], Au[b % ND], gbeg + b, xh4, xm4, xl4, gpar, sg[b], zg[b], su[b], zu[b], yg, yu);
+    if (b + ND < GPW) {
 #pragma unroll
-      for (int c = 0; c < 4; c++) { Ag[b & 1][c] = ldnt(wg + ((b + 2) * 4 + c) * 64); Au[b & 1][c] = ldnt(wu + ((b + 2) * 4 + c) * 64); }
+      for (int c = 0; c < 4; c++) { Ag[b % ND][c] = ldnt(wg + ((b + ND) * 4 + c) * 64); Au[b % ND][c] = ldnt(wu + ((b + ND) * 4 + c) * 64); }
     }
     if (b >= GPW - 2) {     // the down slab follows in two halves, one behind each of the last two gate/up groups: never more than 16 KiB per wave in flight
       const int q0 = (b == GPW - 2) ? 0 : TPW / 2, q1 = (b == GPW - 2) ? TPW / 2 : TPW;
