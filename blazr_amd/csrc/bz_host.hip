@@ -254,6 +254,8 @@ struct bz_model {
   float* moe_xn = nullptr; float* moe_gu = nullptr; float* moe_out = nullptr; long long* moe_acc = nullptr; int* moe_sel = nullptr; float* moe_w = nullptr; float* moe_lg = nullptr; unsigned* moe_cnt = nullptr;
   std::vector<MambaLayerDev> mlayers;
   float* xbc = nullptr; float* ybuf = nullptr; float* vss = nullptr;   // Mamba2 workspace
+  int mpf_rows = 0; float* mpf_h = nullptr; float* mpf_t = nullptr; float* mpf_zx = nullptr; float* mpf_xbc = nullptr; float* mpf_y = nullptr; float* mpf_vss = nullptr;
+  void* mpf_x16 = nullptr;   // Mamba2 batched-prefill rows (allocated on first use)
   bz_device* dev = nullptr;
   bz_model_config cfg;
   bool finalized = false;
@@ -1791,11 +1793,85 @@ static int check_ssm(bz_model* m, bz_ssm_state* st) {
   return BZ_OK;
 }
 
+// Mamba2 batched prefill (prompts of >= prefill_min_rows() tokens, dense 16-bit in_proj / out_proj in the activation dtype): rows through the
+// MFMA GEMMs, conv as a map over (token, channel), the recurrence as an in-kernel scan per head (bz_prefill.hip).  Same rounding points as
+// mamba_step, token for token.
+static bool mamba_prefill_eligible(const bz_model* m, int S) {
+  static const bool off = getenv("BZ_NO_MFMA_PREFILL") != nullptr;
+  const bz_model_config& c = m->cfg;
+  if (off || c.arch != BZ_ARCH_MAMBA2 || S < prefill_min_rows()) return false;
+  if (c.act_dtype != BZ_F16 && c.act_dtype != BZ_BF16) return false;
+  if (!bzk_ssm_scan_ok(c.ssm_head_dim, c.ssm_d_state, c.ssm_n_groups, c.ssm_conv_kernel) || c.ssm_d_inner % c.ssm_n_groups || c.ssm_n_heads % c.ssm_n_groups) return false;
+  for (const MambaLayerDev& L : m->mlayers)
+    for (const FusedLinear* F : {&L.in_proj, &L.out_proj}) {
+      if (F->parts.size() != 1) return false;
+      const LinearDev& P = F->parts[0];
+      if (P.kind != LK_ROWS || P.wdt != c.act_dtype || P.K % 64) return false;
+    }
+  return m->lm_head.parts.size() == 1 && m->lm_head.parts[0].kind == LK_ROWS && !m->lm_head.fix_out;
+}
+static int mamba_prefill(bz_model* m, const long long* d_tok, int S, bz_ssm_state* state, bool all, bz_tensor* logits_out) {
+  const bz_model_config& c = m->cfg;
+  hipStream_t st = m->dev->stream;
+  const int D = c.hidden, DI = c.ssm_d_inner, NH = c.ssm_n_heads, NS = c.ssm_d_state, G = c.ssm_n_groups, KC = c.ssm_conv_kernel, act = c.act_dtype, dt = c.act_dtype;
+  const int conv_dim = DI + 2 * G * NS, ld = DI + conv_dim + NH;
+  const int CH = 512;
+  const int rows = std::min(S, CH);
+  if (m->mpf_rows < rows) {
+    BZ_HIP(hipStreamSynchronize(st));
+    void* p;
+    BZ_TRY(dev_alloc(m, &p, (size_t)rows * D * 4)); m->mpf_h = (float*)p;
+    BZ_TRY(dev_alloc(m, &p, (size_t)rows * D * 4)); m->mpf_t = (float*)p;
+    BZ_TRY(dev_alloc(m, &p, (size_t)rows * ld * 4)); m->mpf_zx = (float*)p;
+    BZ_TRY(dev_alloc(m, &p, (size_t)rows * conv_dim * 4)); m->mpf_xbc = (float*)p;
+    BZ_TRY(dev_alloc(m, &p, (size_t)rows * DI * 4)); m->mpf_y = (float*)p;
+    BZ_TRY(dev_alloc(m, &p, (size_t)rows * NH * 4)); m->mpf_vss = (float*)p;
+    BZ_TRY(dev_alloc(m, &p, (size_t)rows * std::max(D, DI) * 2)); m->mpf_x16 = p;
+    m->mpf_rows = rows;
+  }
+  for (int s0 = 0; s0 < S; s0 += CH) {
+    const int n = std::min(CH, S - s0);
+    BZ_TRY(bzk_pf_embed(st, m->embed, m->embed_dt, d_tok + s0, n, D, act, m->mpf_h));
+    const float* prev = nullptr;
+    for (int l = 0; l < c.n_layers; l++) {
+      const MambaLayerDev& L = m->mlayers[l];
+      const LinearDev& Pin = L.in_proj.parts[0]; const LinearDev& Pout = L.out_proj.parts[0];
+      BZ_TRY(bzk_pf_norm(st, dt, m->mpf_h, prev, L.norm, n, D, c.rms_eps, act, m->mpf_x16));
+      BZ_TRY(bzk_gemm_nt(st, act, m->mpf_x16, Pin.w, Pin.bias, n, Pin.N, Pin.K, act, m->mpf_zx));
+      BZ_TRY(bzk_pf_conv(st, m->mpf_zx, ld, DI, conv_dim, KC, L.conv_w, L.conv_b, state->conv + (size_t)l * conv_dim * (KC - 1), n, act, m->mpf_xbc));
+      BzSsmScan sc{};
+      sc.xbc = m->mpf_xbc; sc.conv_dim = conv_dim; sc.zx = m->mpf_zx; sc.ld = ld; sc.dt_off = DI + conv_dim; sc.dt_bias = L.dt_bias; sc.A_log = L.A_log; sc.D = L.D;
+      sc.state = (char*)state->ssm + (size_t)l * NH * c.ssm_head_dim * NS * bz_dtype_size(state->dtype);
+      sc.n_heads = NH; sc.head_dim = c.ssm_head_dim; sc.d_state = NS; sc.n_groups = G; sc.d_inner = DI; sc.act = act; sc.S = n; sc.y = m->mpf_y; sc.vss = m->mpf_vss;
+      BZ_TRY(bzk_ssm_scan(st, sc, state->dtype));
+      BZ_TRY(bzk_pf_gnorm(st, dt, m->mpf_y, m->mpf_vss, L.gnorm, n, DI, G, NH, c.rms_eps, act, m->mpf_x16));
+      BZ_TRY(bzk_gemm_nt(st, act, m->mpf_x16, Pout.w, Pout.bias, n, Pout.N, Pout.K, act, m->mpf_t));
+      prev = m->mpf_t;
+    }
+    for (int r = 0; r < n; r++) {
+      const int srow = s0 + r;
+      if (!all && srow != S - 1) continue;
+      Pro ph{}; ph.mode = PRO_NORM; ph.src = VSrc{prev + (size_t)r * D, 0}; ph.h_in = m->mpf_h + (size_t)r * D; ph.h_out = nullptr; ph.norm_w = m->final_norm;
+      ph.eps = c.rms_eps; ph.H = D; ph.act = act;
+      GemvOut o{};
+      o.direct = m->logits; o.amax_val = m->pval; o.amax_idx = m->pidx;
+      BZ_TRY(bzk_gemv(st, m->lm_head.parts[0], ph, o, act));
+      BZ_TRY(emit_logits(m, logits_out, all ? srow : 0));
+    }
+  }
+  return BZ_OK;
+}
+
 extern "C" int bz_forward_ssm(bz_model* m, const bz_tensor* tokens, int S, bz_ssm_state* st, bz_tensor* logits_out, uint32_t flags) {
   BZ_TRY(check_fwd(m, tokens, S));
   std::lock_guard<std::recursive_mutex> lock__(m->mu);
   BZ_TRY(check_ssm(m, st));
   const bool all = flags & BZ_FWD_ALL_LOGITS;
+  if (mamba_prefill_eligible(m, S)) {
+    if (!logits_out || logits_out->dtype != BZ_F32 || logits_out->nbytes < (size_t)(all ? S : 1) * m->cfg.vocab * 4) BZ_FAIL(BZ_E_INVALID, "forward: logits_out too small");
+    BZ_HIP(hipSetDevice(m->dev->id));
+    return mamba_prefill(m, (const long long*)tokens->ptr, S, st, all, logits_out);
+  }
   for (int s = 0; s < S; s++) {
     StepIO io{};
     io.ssm = st; io.d_tok = (const long long*)tokens->ptr + s;

@@ -446,6 +446,155 @@ __global__ void k_q4g_mfma_reduce(const float* __restrict__ part, int KS, size_t
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// Mamba2 batched prefill: the prompt's rows go through the GEMMs together (in_proj / out_proj on the matrix cores); the depthwise conv is
+// a parallel map over (token, channel); the SSM recurrence is a scan INSIDE one kernel -- one workgroup per head keeps its state in
+// registers and walks the tokens, so a prompt costs one pass over the state instead of a read-modify-write of it per token.
+// Arithmetic and rounding points are those of the decode-step kernels (k_conv_step, k_ssm_step, the GATED2 prologue).
+// ---------------------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float pf_silu(float x) { return x / (1.0f + expf(-x)); }
+__device__ __forceinline__ float pf_softplus(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+
+// out[t][ch] = R(silu(R(conv window + bias))): window = the kc-1 inputs before t (from the rows, or from the carried conv state) and in[t]
+__global__ void k_pf_conv(const float* __restrict__ zx, int ld, int x_off, int conv_dim, int kc, const float* __restrict__ w, const float* __restrict__ b,
+                          const float* __restrict__ cs, int S, int act, float* __restrict__ out) {
+  const int ch = blockIdx.x * 256 + threadIdx.x, t = blockIdx.y;
+  if (ch >= conv_dim) return;
+  float a = 0.f;
+  for (int j = 0; j < kc - 1; j++) {
+    const int tau = t - (kc - 1) + j;
+    const float v = tau >= 0 ? zx[(size_t)tau * ld + x_off + ch] : cs[(size_t)ch * (kc - 1) + (tau + kc - 1)];
+    a += v * w[(size_t)ch * kc + j];
+  }
+  a += zx[(size_t)t * ld + x_off + ch] * w[(size_t)ch * kc + kc - 1];
+  a = pf_round(a + b[ch], act);
+  out[(size_t)t * conv_dim + ch] = pf_round(pf_silu(a), act);
+}
+// conv state after the prompt: the last kc-1 inputs
+__global__ void k_pf_conv_state(const float* __restrict__ zx, int ld, int x_off, int conv_dim, int kc, float* cs, int S) {
+  const int ch = blockIdx.x * 256 + threadIdx.x;
+  if (ch >= conv_dim) return;
+  float nv[8];
+  for (int j = 0; j < kc - 1; j++) {
+    const int tau = S - (kc - 1) + j;
+    nv[j] = tau >= 0 ? zx[(size_t)tau * ld + x_off + ch] : cs[(size_t)ch * (kc - 1) + (tau + kc - 1)];
+  }
+  for (int j = 0; j < kc - 1; j++) cs[(size_t)ch * (kc - 1) + j] = nv[j];
+}
+
+struct SsmScanArgs {
+  const float* xbc; int conv_dim;          // rows [S][conv_dim]: x (d_inner) | B (groups x d_state) | C (groups x d_state)
+  const float* zx; int ld; int dt_off;     // rows [S][ld]: z at 0, dt at dt_off
+  const float* dt_bias; const float* A_log; const float* D;
+  void* state;                             // this layer's [n_heads][head_dim][d_state]
+  int n_heads, head_dim, d_state, n_groups, d_inner, act, S;
+  float* y;                                // rows [S][d_inner]: R(y * R(silu z))
+  float* vss;                              // rows [S][n_heads]: sum of squares of the gated y per head
+};
+
+template <int SDT> __device__ __forceinline__ float st_load(const void* p, size_t i) {
+  if (SDT == BZ_F32) return ((const float*)p)[i];
+  if (SDT == BZ_F16) return __half2float(((const __half*)p)[i]);
+  return __uint_as_float((unsigned)((const unsigned short*)p)[i] << 16);
+}
+template <int SDT> __device__ __forceinline__ void st_store(void* p, size_t i, float v) {
+  if (SDT == BZ_F32) ((float*)p)[i] = v;
+  else if (SDT == BZ_F16) ((__half*)p)[i] = __float2half_rn(v);
+  else ((unsigned short*)p)[i] = to16<BZ_BF16>(v);
+}
+template <int SDT> __device__ __forceinline__ float st_round(float v) {     // what a store + load of the state dtype does to a value
+  if (SDT == BZ_F32) return v;
+  if (SDT == BZ_F16) return __half2float(__float2half_rn(v));
+  return from16<BZ_BF16>(to16<BZ_BF16>(v));
+}
+
+// grid = n_heads; 256 threads = 64 rows (p) x 4 state quarters (as k_ssm_step); NQ = d_state / 4 state values per thread in registers;
+// tokens in chunks of 8 (B, C, dt, dA staged in LDS once per chunk; x and z of the chunk prefetched into registers)
+template <int SDT, int NQ>
+__global__ __launch_bounds__(256) void k_ssm_scan(SsmScanArgs a) {
+  constexpr int TC = 8, NS = NQ * 4;
+  __shared__ float sB[TC][NS], sC[TC][NS], sdt[TC], sdA[TC], sred[TC][4];
+  const int hd = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int HD = a.head_dim;
+  const int g = hd / (a.n_heads / a.n_groups);
+  const int p = tid >> 2, q = tid & 3;
+  const bool on = p < HD;
+  const float Dh = a.D[hd], Aneg = -expf(a.A_log[hd]), dtb = a.dt_bias[hd];
+  const size_t soff = ((size_t)hd * HD + (on ? p : 0)) * NS + q * NQ;
+  float h[NQ];
+#pragma unroll
+  for (int n = 0; n < NQ; n++) h[n] = on ? st_load<SDT>(a.state, soff + n) : 0.f;
+  for (int t0 = 0; t0 < a.S; t0 += TC) {
+    const int nt = min(TC, a.S - t0);
+    __syncthreads();                       // the previous chunk's LDS reads are done
+    for (int i = tid; i < nt * NS; i += 256) {
+      const int tt = i / NS, n = i % NS;
+      const float* row = a.xbc + (size_t)(t0 + tt) * a.conv_dim;
+      sB[tt][n] = row[a.d_inner + g * NS + n];
+      sC[tt][n] = row[a.d_inner + a.n_groups * NS + g * NS + n];
+    }
+    if (tid < nt) {
+      const float dt = pf_round(pf_softplus(pf_round(a.zx[(size_t)(t0 + tid) * a.ld + a.dt_off + hd] + dtb, a.act)), a.act);
+      sdt[tid] = dt; sdA[tid] = expf(dt * Aneg);
+    }
+    float xv[TC], zv[TC], vsq[TC];
+#pragma unroll
+    for (int tt = 0; tt < TC; tt++) {
+      const int t = min(t0 + tt, a.S - 1);
+      xv[tt] = on ? a.xbc[(size_t)t * a.conv_dim + hd * HD + p] : 0.f;
+      zv[tt] = on ? a.zx[(size_t)t * a.ld + hd * HD + p] : 0.f;
+      vsq[tt] = 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tt = 0; tt < TC; tt++) {
+      if (tt < nt) {
+        const float dt = sdt[tt], dA = sdA[tt], dtx = dt * xv[tt];
+        float acc = 0.f;
+#pragma unroll
+        for (int n = 0; n < NQ; n++) {
+          const float hn = pf_round(h[n] * dA + dtx * sB[tt][q * NQ + n], a.act);
+          acc += hn * sC[tt][q * NQ + n];     // (the step kernel multiplies the activation-rounded value and stores the state-dtype one)
+          h[n] = st_round<SDT>(hn);
+        }
+        acc = grp_reduce<4, OpAdd>(acc);
+        if (on && q == 0) {
+          float yv = pf_round(acc + Dh * xv[tt], a.act);
+          yv = pf_round(yv * pf_round(pf_silu(zv[tt]), a.act), a.act);
+          vsq[tt] = yv * yv;
+          a.y[(size_t)(t0 + tt) * a.d_inner + hd * HD + p] = yv;
+        }
+      }
+    }
+    // per-token sums of squares over the head: eight block reductions at once (same fixed tree as block_sum256)
+#pragma unroll
+    for (int tt = 0; tt < TC; tt++) { const float s = wave_sum(vsq[tt]); if (lane == 0) sred[tt][wave] = s; }
+    __syncthreads();
+    if (tid < nt) a.vss[(size_t)(t0 + tid) * a.n_heads + hd] = (sred[tid][0] + sred[tid][1]) + (sred[tid][2] + sred[tid][3]);
+  }
+  if (on) {
+#pragma unroll
+    for (int n = 0; n < NQ; n++) st_store<SDT>(a.state, soff + n, h[n]);
+  }
+}
+
+// row t: x16 = to16(R(w * R(v * rs_group))), rs_group = rsqrt(sum over the group's heads of vss / group size + eps)     grid = S
+template <int DT>
+__global__ __launch_bounds__(256) void k_pf_gnorm(const float* __restrict__ v, const float* __restrict__ vss, const float* __restrict__ w, int DI, int G, int NH,
+                                                  float eps, int act, unsigned short* __restrict__ x16) {
+  __shared__ float rs[64];
+  const int t = blockIdx.x, gsz = DI / G, hpg = NH / G;
+  if (threadIdx.x < G) {
+    float ss = 0.f;
+    for (int h = 0; h < hpg; h++) ss += vss[(size_t)t * NH + threadIdx.x * hpg + h];
+    rs[threadIdx.x] = 1.0f / sqrtf(ss / (float)gsz + eps);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < DI; i += 256)
+    x16[(size_t)t * DI + i] = to16<DT>(pf_round(w[i] * pf_round(v[(size_t)t * DI + i] * rs[i / gsz], act), act));
+}
+
 // ---- launchers ---------------------------------------------------------------------------------------------------------------------------
 int bzk_gemm_nt(hipStream_t s, int dt, const void* x16, const void* w, const float* bias, int S, int N, int K, int act, float* y) {
   if (dt != BZ_F16 && dt != BZ_BF16) BZ_FAIL(BZ_E_UNSUPPORTED, "gemm_nt: 16-bit operands only");
@@ -507,6 +656,35 @@ int bzk_gemm_q4g_mfma(hipStream_t s, const LinearDev& L, const void* x16, int S,
     hipLaunchKernelGGL(k_q4g_mfma_reduce, dim3((unsigned)std::min<size_t>((SN + 255) / 256, 2048)), dim3(256), 0, s, (const float*)ws, KS, SN, L.N, L.bias, act, y);
     BZ_HIP(hipGetLastError());
   }
+  return BZ_OK;
+}
+
+bool bzk_ssm_scan_ok(int head_dim, int d_state, int n_groups, int kc) {
+  return head_dim <= 64 && (d_state == 16 || d_state == 64 || d_state == 128) && n_groups <= 64 && kc >= 2 && kc <= 9;
+}
+int bzk_pf_conv(hipStream_t s, const float* zx, int ld, int x_off, int conv_dim, int kc, const float* w, const float* b, float* cs, int S, int act, float* out) {
+  hipLaunchKernelGGL(k_pf_conv, dim3((conv_dim + 255) / 256, S), dim3(256), 0, s, zx, ld, x_off, conv_dim, kc, w, b, (const float*)cs, S, act, out);
+  hipLaunchKernelGGL(k_pf_conv_state, dim3((conv_dim + 255) / 256), dim3(256), 0, s, zx, ld, x_off, conv_dim, kc, cs, S);
+  BZ_HIP(hipGetLastError());
+  return BZ_OK;
+}
+int bzk_ssm_scan(hipStream_t s, const BzSsmScan& b, int sdt) {
+  if (!bzk_ssm_scan_ok(b.head_dim, b.d_state, b.n_groups, 4)) BZ_FAIL(BZ_E_UNSUPPORTED, "ssm_scan: unsupported state shape");
+  SsmScanArgs a;
+  a.xbc = b.xbc; a.conv_dim = b.conv_dim; a.zx = b.zx; a.ld = b.ld; a.dt_off = b.dt_off; a.dt_bias = b.dt_bias; a.A_log = b.A_log; a.D = b.D; a.state = b.state;
+  a.n_heads = b.n_heads; a.head_dim = b.head_dim; a.d_state = b.d_state; a.n_groups = b.n_groups; a.d_inner = b.d_inner; a.act = b.act; a.S = b.S; a.y = b.y; a.vss = b.vss;
+#define LAUNCH_SCAN(SDT, NQ) BZ_LAUNCH("mamba2_ssm_scan", 0.0, (k_ssm_scan<SDT, NQ>), dim3(b.n_heads), dim3(256), 0, s, a)
+#define LAUNCH_SCAN_N(SDT) do { if (b.d_state == 16) LAUNCH_SCAN(SDT, 4); else if (b.d_state == 64) LAUNCH_SCAN(SDT, 16); else LAUNCH_SCAN(SDT, 32); } while (0)
+  if (sdt == BZ_F32) LAUNCH_SCAN_N(BZ_F32); else if (sdt == BZ_F16) LAUNCH_SCAN_N(BZ_F16); else LAUNCH_SCAN_N(BZ_BF16);
+#undef LAUNCH_SCAN_N
+#undef LAUNCH_SCAN
+  BZ_HIP(hipGetLastError());
+  return BZ_OK;
+}
+int bzk_pf_gnorm(hipStream_t s, int dt, const float* v, const float* vss, const float* w, int S, int DI, int G, int NH, float eps, int act, void* x16) {
+  if (dt == BZ_F16) hipLaunchKernelGGL(k_pf_gnorm<BZ_F16>, dim3(S), dim3(256), 0, s, v, vss, w, DI, G, NH, eps, act, (unsigned short*)x16);
+  else hipLaunchKernelGGL(k_pf_gnorm<BZ_BF16>, dim3(S), dim3(256), 0, s, v, vss, w, DI, G, NH, eps, act, (unsigned short*)x16);
+  BZ_HIP(hipGetLastError());
   return BZ_OK;
 }
 

@@ -118,3 +118,30 @@ def test_config_variants(device, over):
         _check_logits(lm.forward_with_ssm_state([tok], st).to_numpy(), lo, cfg["act_dtype"])
         tok = int(lo[0].argmax())
     orc_py.lib().orc_ssm_state_free(ost)
+
+
+@pytest.mark.parametrize("over", [dict(), dict(d_state=16), dict(conv_kernel=2), dict(n_groups=4, d_state=64), dict(act_dtype="f16"), dict(head_dim=32, n_heads=16)],
+                         ids=["base", "state16", "conv2", "groups4", "f16", "headdim32"])
+@pytest.mark.parametrize("S", [8, 21, 70])
+def test_batched_prefill_scan_matches_oracle_and_steps(device, over, S):
+    """prompts of >= 8 tokens take the batched path (rows through the MFMA GEMMs, conv as a map over (token, channel), the recurrence as an
+    in-kernel scan over the tokens); 21 and 70 leave a partial chunk of the scan's 8-token staging.  Checked against the oracle (every
+    position's logits), and the state it leaves must continue exactly like the state the token-by-token path leaves: decode steps after the
+    prompt are compared with the oracle too."""
+    model = synth.make_mamba2("tiny-mamba2", **over)
+    cfg = model["config"]
+    lm, om = runtime.LoadedModel.from_synth(device, model), orc_py.OrcMamba2(model)
+    p = synth.prompt_tokens(S, cfg["vocab"], seed=23 + S)
+    st, ost = runtime.LayeredSsmState(lm), om.new_state()
+    got = lm.forward_with_ssm_state(p, st, all_logits=True).to_numpy()
+    want = om.forward(p, ost, all_logits=True)
+    _check_logits(got, want, cfg["act_dtype"])
+    # a second prompt continues from the carried conv window and SSM state
+    p2 = synth.prompt_tokens(9, cfg["vocab"], seed=5)
+    _check_logits(lm.forward_with_ssm_state(p2, st).to_numpy(), om.forward(p2, ost), cfg["act_dtype"])
+    tok = int(want[-1].argmax())
+    for _ in range(8):
+        lo = om.forward([tok], ost)
+        _check_logits(lm.forward_with_ssm_state([tok], st).to_numpy(), lo, cfg["act_dtype"])
+        tok = int(lo[0].argmax())
+    orc_py.lib().orc_ssm_state_free(ost)
