@@ -511,16 +511,17 @@ template <int SDT> __device__ __forceinline__ float st_round(float v) {     // w
 
 // grid = n_heads; 256 threads = 64 rows (p) x 4 state quarters (as k_ssm_step); NQ = d_state / 4 state values per thread in registers;
 // tokens in chunks of 8 (B, C, dt, dA staged in LDS once per chunk; x and z of the chunk prefetched into registers)
-template <int SDT, int NQ>
-__global__ __launch_bounds__(256) void k_ssm_scan(SsmScanArgs a) {
-  constexpr int TC = 8, NS = NQ * 4;
-  __shared__ float sB[TC][NS], sC[TC][NS], sdt[TC], sdA[TC], sred[TC][4];
+template <int SDT, int NQ, int PARTS>   // PARTS threads share a state row (NQ = d_state / PARTS values each); 64 rows x PARTS threads per block
+__global__ __launch_bounds__(64 * PARTS) void k_ssm_scan(SsmScanArgs a) {
+  constexpr int TC = 8, NS = NQ * PARTS, NP = NQ + 1, NTH = 64 * PARTS, NWV = PARTS;   // NP: padded part stride (the parts of a row would otherwise share banks)
+  __shared__ float sB[TC][PARTS * NP], sC[TC][PARTS * NP], sdt[TC], sdA[TC], sred[TC][NWV];
   const int hd = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int HD = a.head_dim;
   const int g = hd / (a.n_heads / a.n_groups);
-  const int p = tid >> 2, q = tid & 3;
+  const int p = tid / PARTS, q = tid % PARTS;
   const bool on = p < HD;
   const float Dh = a.D[hd], Aneg = -expf(a.A_log[hd]), dtb = a.dt_bias[hd];
+  const bool same = a.act == SDT;          // state dtype == activation dtype: the activation rounding already is the storage rounding
   const size_t soff = ((size_t)hd * HD + (on ? p : 0)) * NS + q * NQ;
   float h[NQ];
 #pragma unroll
@@ -528,23 +529,35 @@ __global__ __launch_bounds__(256) void k_ssm_scan(SsmScanArgs a) {
   for (int t0 = 0; t0 < a.S; t0 += TC) {
     const int nt = min(TC, a.S - t0);
     __syncthreads();                       // the previous chunk's LDS reads are done
-    for (int i = tid; i < nt * NS; i += 256) {
-      const int tt = i / NS, n = i % NS;
-      const float* row = a.xbc + (size_t)(t0 + tt) * a.conv_dim;
-      sB[tt][n] = row[a.d_inner + g * NS + n];
-      sC[tt][n] = row[a.d_inner + a.n_groups * NS + g * NS + n];
+    // every global load of the chunk is unconditional (clamped rows / channels) and issued before anything waits: a load under a divergent
+    // branch drains vmcnt each time, which made this staging cost 20 us per chunk
+    constexpr int NBC = (TC * NS + NTH - 1) / NTH;     // B and C elements per thread per chunk
+    float bv[NBC], cv[NBC];
+#pragma unroll
+    for (int k = 0; k < NBC; k++) {
+      const int i = min(k * NTH + tid, TC * NS - 1), tt = i / NS, n = i % NS;
+      const float* row = a.xbc + (size_t)min(t0 + tt, a.S - 1) * a.conv_dim;
+      bv[k] = row[a.d_inner + g * NS + n];
+      cv[k] = row[a.d_inner + a.n_groups * NS + g * NS + n];
     }
-    if (tid < nt) {
-      const float dt = pf_round(pf_softplus(pf_round(a.zx[(size_t)(t0 + tid) * a.ld + a.dt_off + hd] + dtb, a.act)), a.act);
-      sdt[tid] = dt; sdA[tid] = expf(dt * Aneg);
-    }
+    const float dtraw = a.zx[(size_t)min(t0 + (tid & (TC - 1)), a.S - 1) * a.ld + a.dt_off + hd];
     float xv[TC], zv[TC], vsq[TC];
+    const int pc = on ? p : 0;
 #pragma unroll
     for (int tt = 0; tt < TC; tt++) {
       const int t = min(t0 + tt, a.S - 1);
-      xv[tt] = on ? a.xbc[(size_t)t * a.conv_dim + hd * HD + p] : 0.f;
-      zv[tt] = on ? a.zx[(size_t)t * a.ld + hd * HD + p] : 0.f;
+      xv[tt] = a.xbc[(size_t)t * a.conv_dim + hd * HD + pc];
+      zv[tt] = a.zx[(size_t)t * a.ld + hd * HD + pc];
       vsq[tt] = 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < NBC; k++) {
+      const int i = k * NTH + tid, tt = i / NS, n = i % NS;
+      if (i < TC * NS) { sB[tt][(n / NQ) * NP + n % NQ] = bv[k]; sC[tt][(n / NQ) * NP + n % NQ] = cv[k]; }
+    }
+    if (tid < TC) {
+      const float dt = pf_round(pf_softplus(pf_round(dtraw + dtb, a.act)), a.act);
+      sdt[tid] = dt; sdA[tid] = expf(dt * Aneg);
     }
     __syncthreads();
 #pragma unroll
@@ -554,11 +567,11 @@ __global__ __launch_bounds__(256) void k_ssm_scan(SsmScanArgs a) {
         float acc = 0.f;
 #pragma unroll
         for (int n = 0; n < NQ; n++) {
-          const float hn = pf_round(h[n] * dA + dtx * sB[tt][q * NQ + n], a.act);
-          acc += hn * sC[tt][q * NQ + n];     // (the step kernel multiplies the activation-rounded value and stores the state-dtype one)
-          h[n] = st_round<SDT>(hn);
+          const float hn = pf_round(h[n] * dA + dtx * sB[tt][q * NP + n], a.act);
+          acc += hn * sC[tt][q * NP + n];     // (the step kernel multiplies the activation-rounded value and stores the state-dtype one)
+          h[n] = same ? hn : st_round<SDT>(hn);
         }
-        acc = grp_reduce<4, OpAdd>(acc);
+        acc = grp_reduce<PARTS, OpAdd>(acc);
         if (on && q == 0) {
           float yv = pf_round(acc + Dh * xv[tt], a.act);
           yv = pf_round(yv * pf_round(pf_silu(zv[tt]), a.act), a.act);
@@ -571,7 +584,12 @@ __global__ __launch_bounds__(256) void k_ssm_scan(SsmScanArgs a) {
 #pragma unroll
     for (int tt = 0; tt < TC; tt++) { const float s = wave_sum(vsq[tt]); if (lane == 0) sred[tt][wave] = s; }
     __syncthreads();
-    if (tid < nt) a.vss[(size_t)(t0 + tid) * a.n_heads + hd] = (sred[tid][0] + sred[tid][1]) + (sred[tid][2] + sred[tid][3]);
+    if (tid < nt) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < NWV; w += 2) v += sred[tid][w] + sred[tid][w + 1];     // fixed order
+      a.vss[(size_t)(t0 + tid) * a.n_heads + hd] = v;
+    }
   }
   if (on) {
 #pragma unroll
@@ -673,8 +691,8 @@ int bzk_ssm_scan(hipStream_t s, const BzSsmScan& b, int sdt) {
   SsmScanArgs a;
   a.xbc = b.xbc; a.conv_dim = b.conv_dim; a.zx = b.zx; a.ld = b.ld; a.dt_off = b.dt_off; a.dt_bias = b.dt_bias; a.A_log = b.A_log; a.D = b.D; a.state = b.state;
   a.n_heads = b.n_heads; a.head_dim = b.head_dim; a.d_state = b.d_state; a.n_groups = b.n_groups; a.d_inner = b.d_inner; a.act = b.act; a.S = b.S; a.y = b.y; a.vss = b.vss;
-#define LAUNCH_SCAN(SDT, NQ) BZ_LAUNCH("mamba2_ssm_scan", 0.0, (k_ssm_scan<SDT, NQ>), dim3(b.n_heads), dim3(256), 0, s, a)
-#define LAUNCH_SCAN_N(SDT) do { if (b.d_state == 16) LAUNCH_SCAN(SDT, 4); else if (b.d_state == 64) LAUNCH_SCAN(SDT, 16); else LAUNCH_SCAN(SDT, 32); } while (0)
+#define LAUNCH_SCAN(SDT, NQ) BZ_LAUNCH("mamba2_ssm_scan", 0.0, (k_ssm_scan<SDT, NQ, 16>), dim3(b.n_heads), dim3(1024), 0, s, a)
+#define LAUNCH_SCAN_N(SDT) do { if (b.d_state == 16) LAUNCH_SCAN(SDT, 1); else if (b.d_state == 64) LAUNCH_SCAN(SDT, 4); else LAUNCH_SCAN(SDT, 8); } while (0)
   if (sdt == BZ_F32) LAUNCH_SCAN_N(BZ_F32); else if (sdt == BZ_F16) LAUNCH_SCAN_N(BZ_F16); else LAUNCH_SCAN_N(BZ_BF16);
 #undef LAUNCH_SCAN_N
 #undef LAUNCH_SCAN
