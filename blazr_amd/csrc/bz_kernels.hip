@@ -3007,21 +3007,22 @@ int bzk_conv_step(hipStream_t s, const float* zxbcdt, int x_off, int conv_dim, i
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
 
 // grid = n_heads; 256 threads = 64 rows (p) x 4 state quarters.  h = R(h * dA + (dt x) B); y = R(sum_n h C + D x)
-template <int SDT>
-__global__ __launch_bounds__(256) void k_ssm_step(SsmArgs a) {
-  __shared__ float sB[256], sC[256], sred[4];
+template <int SDT, int PARTS>   // PARTS threads share a state row: 4 (256-thread blocks) or 16 (1024 threads: 4 waves per SIMD, one 16-byte piece per thread)
+__global__ __launch_bounds__(64 * PARTS) void k_ssm_step(SsmArgs a) {
+  constexpr int NTH = 64 * PARTS;
+  __shared__ float sB[256], sC[256], sred[PARTS];
   const int hd = blockIdx.x, tid = threadIdx.x;
   const int NS = a.d_state, HD = a.head_dim;
   const int g = hd / (a.n_heads / a.n_groups);
-  for (int i = tid; i < NS; i += 256) { sB[i] = a.xbc[a.d_inner + g * NS + i]; sC[i] = a.xbc[a.d_inner + a.n_groups * NS + g * NS + i]; }
+  for (int i = tid; i < NS; i += NTH) { sB[i] = a.xbc[a.d_inner + g * NS + i]; sC[i] = a.xbc[a.d_inner + a.n_groups * NS + g * NS + i]; }
   const float dt = round_act(softplus_f(round_act(a.zxbcdt[a.dt_off + hd] + a.dt_bias[hd], a.act)), a.act);
   const float dA = expf(dt * -expf(a.A_log[hd]));
   const float Dh = a.D[hd];
   __syncthreads();
-  const int q = tid & 3, nq = NS >> 2;            // this thread's quarter of the state row
+  const int q = tid % PARTS, nq = NS / PARTS;      // this thread's part of the state row
   float vsq = 0.f;
   for (int p0 = 0; p0 < HD; p0 += 64) {
-    const int p = p0 + (tid >> 2);
+    const int p = p0 + tid / PARTS;
     float acc = 0.f, xv = 0.f;
     if (p < HD) {
       xv = a.xbc[hd * HD + p];
@@ -3060,7 +3061,7 @@ __global__ __launch_bounds__(256) void k_ssm_step(SsmArgs a) {
         }
       }
     }
-    acc = grp_reduce<4, OpAdd>(acc);
+    acc = grp_reduce<PARTS, OpAdd>(acc);
     if (p < HD && q == 0) {
       float yv = round_act(acc + Dh * xv, a.act);
       if (a.z) { yv = round_act(yv * round_act(silu_f(a.z[hd * HD + p]), a.act), a.act); vsq += yv * yv; }
@@ -3068,16 +3069,27 @@ __global__ __launch_bounds__(256) void k_ssm_step(SsmArgs a) {
     }
   }
   if (a.z) {
-    vsq = block_sum256(vsq, sred);   // fixed tree: the per-head sum is deterministic
-    if (tid == 0) a.vss[hd] = vsq;
+    vsq = wave_sum(vsq);             // fixed tree: the per-head sum is deterministic
+    if ((tid & 63) == 0) sred[tid >> 6] = vsq;
+    __syncthreads();
+    if (tid == 0) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < PARTS; w += 2) t += sred[w] + sred[w + 1];
+      a.vss[hd] = t;
+    }
   }
 }
 int bzk_ssm_step(hipStream_t s, const SsmArgs& a) {
   if (a.d_state > 256 || (a.d_state & 3) || a.n_heads % a.n_groups) BZ_FAIL(BZ_E_UNSUPPORTED, "ssm_step: d_state %d / groups %d unsupported", a.d_state, a.n_groups);
   const double bytes = 2.0 * a.n_heads * a.head_dim * a.d_state * (a.sdt == BZ_F32 ? 4 : 2);
-  if (a.sdt == BZ_F32) BZ_LAUNCH("mamba2_ssm_step", bytes, (k_ssm_step<BZ_F32>), dim3(a.n_heads), dim3(256), 0, s, a);
-  else if (a.sdt == BZ_F16) BZ_LAUNCH("mamba2_ssm_step", bytes, (k_ssm_step<BZ_F16>), dim3(a.n_heads), dim3(256), 0, s, a);
-  else BZ_LAUNCH("mamba2_ssm_step", bytes, (k_ssm_step<BZ_BF16>), dim3(a.n_heads), dim3(256), 0, s, a);
+  // 16 threads per state row when a part is then a whole number of 16-byte pieces (d_state 128 with a 16-bit state) or the state is f32
+  static const bool p4 = getenv("BZ_SSM_PARTS4") != nullptr;
+  const bool wide = !p4 && a.d_state % 16 == 0 && (a.sdt == BZ_F32 || (a.d_state / 16) % 8 == 0);
+#define LAUNCH_SSM(SDT) do { if (wide) BZ_LAUNCH("mamba2_ssm_step", bytes, (k_ssm_step<SDT, 16>), dim3(a.n_heads), dim3(1024), 0, s, a); \
+                             else BZ_LAUNCH("mamba2_ssm_step", bytes, (k_ssm_step<SDT, 4>), dim3(a.n_heads), dim3(256), 0, s, a); } while (0)
+  if (a.sdt == BZ_F32) LAUNCH_SSM(BZ_F32); else if (a.sdt == BZ_F16) LAUNCH_SSM(BZ_F16); else LAUNCH_SSM(BZ_BF16);
+#undef LAUNCH_SSM
   BZ_HIP(hipGetLastError());
   return BZ_OK;
 }
