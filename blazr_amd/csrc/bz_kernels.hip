@@ -3112,23 +3112,36 @@ __device__ __forceinline__ float ld1t(const void* base, size_t off) {
   else return ((const float*)base)[off];
 }
 
-template <int NCH, int DT>   // NCH: 512-column chunks of the latent, 1 (rank <= 512) or 2 (rank <= 1024); DT: dtype of kv_b and of the cache
-__global__ __launch_bounds__(256) void k_mla_attn(MlaArgs a) {
+// NW waves per head: 16 (1024 threads) when the per-wave row ranges divide evenly -- with one workgroup per head (16 of them for V2-Lite) the
+// kernel is starved of parallelism, and 4 waves per SIMD let one wave's dependent chain hide under the others'
+template <int NW> __device__ __forceinline__ float block_sum_nw(float v, float* red) {   // deterministic; red: LDS float[NW]
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int w = 0; w < NW; w += 2) t += red[w] + red[w + 1];
+  __syncthreads();
+  return t;
+}
+template <int NCH, int DT, int NW>   // NCH: 512-column chunks of the latent, 1 (rank <= 512) or 2 (rank <= 1024); DT: dtype of kv_b and of the cache
+__global__ __launch_bounds__(NW * 64) void k_mla_attn(MlaArgs a) {
+  constexpr int NTH = NW * 64;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int R = a.rank, DN = a.nope, DR = a.rope, DV = a.vdim;
   float* ccur = lds; float* kcur = ccur + R; float* qn = kcur + DR; float* qp = qn + DN; float* qabs = qp + DR;
-  float* part = qabs + R; float* red = part + 4 * R; float* sc = red + 8;
+  float* part = qabs + R; float* red = part + NW * R; float* sc = red + 16;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hd = blockIdx.x;
   const int pos = a.pos[0], len = pos + 1;
   const int QH = DN + DR, qoff = hd * QH, coff = a.n_heads * QH;
   const size_t wrow0 = (size_t)hd * (DN + DV);
-  constexpr int RIF = 16 / NCH, TIF = 8 / NCH;   // weight rows / cache rows a wave keeps in flight
+  constexpr int RIF = (NW == 4 ? 16 : 8) / NCH, TIF = (NW == 4 ? 8 : 4) / NCH;   // weight rows / cache rows a wave keeps in flight
   bool con[NCH]; int colc[NCH];                      // this lane's 8 columns per chunk (clamped when beyond the rank)
 #pragma unroll
   for (int c = 0; c < NCH; c++) { const int col = c * 512 + lane * 8; con[c] = col < R; colc[c] = con[c] ? col : 0; }
 
   // ---- qabs partials first (weights only depend on the head): wave w takes nope rows [w DN/4, (w+1) DN/4), 8 rows in flight ----
-  const int d0 = wave * (DN / 4), d1 = d0 + DN / 4;
+  const int d0 = wave * (DN / NW), d1 = d0 + DN / NW;
   float w0[RIF][NCH][8];
 #pragma unroll
   for (int u = 0; u < RIF; u++)
@@ -3138,24 +3151,24 @@ __global__ __launch_bounds__(256) void k_mla_attn(MlaArgs a) {
 
   // ---- current token: latent norm, k_pe / q_pe rope, q_nope ----
   float ss = 0.f;
-  for (int r = tid; r < R; r += 256) { const float v = vsrc_get(a.qkv, coff + r, a.act); ccur[r] = v; ss += v * v; }
-  ss = block_sum256(ss, red);
+  for (int r = tid; r < R; r += NTH) { const float v = vsrc_get(a.qkv, coff + r, a.act); ccur[r] = v; ss += v * v; }
+  ss = block_sum_nw<NW>(ss, red);
   const float rs = 1.0f / sqrtf(ss / (float)R + a.eps);
-  for (int r = tid; r < R; r += 256) ccur[r] = round_act(a.kv_norm[r] * round_act(ccur[r] * rs, a.act), a.act);
+  for (int r = tid; r < R; r += NTH) ccur[r] = round_act(a.kv_norm[r] * round_act(ccur[r] * rs, a.act), a.act);
   const float* cr = a.cos_t + (size_t)pos * (DR / 2); const float* sr = a.sin_t + (size_t)pos * (DR / 2);
-  for (int j = tid; j < DR / 2; j += 256) {
+  for (int j = tid; j < DR / 2; j += NTH) {
     const float c = cr[j], s = sr[j];
     float x0 = vsrc_get(a.qkv, coff + R + 2 * j, a.act), x1 = vsrc_get(a.qkv, coff + R + 2 * j + 1, a.act);
     kcur[2 * j] = round_act(x0 * c - x1 * s, a.act); kcur[2 * j + 1] = round_act(x1 * c + x0 * s, a.act);
     x0 = vsrc_get(a.qkv, qoff + DN + 2 * j, a.act); x1 = vsrc_get(a.qkv, qoff + DN + 2 * j + 1, a.act);
     qp[2 * j] = round_act(x0 * c - x1 * s, a.act); qp[2 * j + 1] = round_act(x1 * c + x0 * s, a.act);
   }
-  for (int d = tid; d < DN; d += 256) qn[d] = vsrc_get(a.qkv, qoff + d, a.act);
+  for (int d = tid; d < DN; d += NTH) qn[d] = vsrc_get(a.qkv, qoff + d, a.act);
   __syncthreads();
   const size_t rowbase = (size_t)a.layer * a.kv.layer_stride;
   const int Wd = R + DR;
   if (hd == 0) {
-    for (int i = tid; i < Wd; i += 256) kv_st(a.kv.k, rowbase + (size_t)pos * Wd + i, a.kv.dtype, i < R ? ccur[i] : kcur[i - R]);
+    for (int i = tid; i < Wd; i += NTH) kv_st(a.kv.k, rowbase + (size_t)pos * Wd + i, a.kv.dtype, i < R ? ccur[i] : kcur[i - R]);
   }
   {
     float acc[NCH][8];
@@ -3186,7 +3199,12 @@ __global__ __launch_bounds__(256) void k_mla_attn(MlaArgs a) {
         for (int e = 0; e < 8; e++) part[wave * R + colc[c] + e] = acc[c][e];
   }
   __syncthreads();
-  for (int r = tid; r < R; r += 256) qabs[r] = round_act((part[r] + part[R + r]) + (part[2 * R + r] + part[3 * R + r]), a.act);
+  for (int r = tid; r < R; r += NTH) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; w += 2) t += part[w * R + r] + part[(w + 1) * R + r];
+    qabs[r] = round_act(t, a.act);
+  }
   __syncthreads();
   // ---- scores: wave w takes cached tokens w, w+4, ... four at a time; the current token comes from LDS ----
   float qa[NCH][8];
@@ -3195,11 +3213,11 @@ __global__ __launch_bounds__(256) void k_mla_attn(MlaArgs a) {
   for (int c = 0; c < NCH; c++)
 #pragma unroll
     for (int e = 0; e < 8; e++) qa[c][e] = con[c] ? qabs[colc[c] + e] : 0.f;
-  for (int t0 = wave; t0 < pos; t0 += 4 * TIF) {
+  for (int t0 = wave; t0 < pos; t0 += NW * TIF) {
     float cv[TIF][NCH][8], kp[TIF];
 #pragma unroll
     for (int u = 0; u < TIF; u++) {
-      const size_t ro = rowbase + (size_t)min(t0 + 4 * u, pos - 1) * Wd;
+      const size_t ro = rowbase + (size_t)min(t0 + NW * u, pos - 1) * Wd;
 #pragma unroll
       for (int c = 0; c < NCH; c++) ld8t<DT>(a.kv.k, ro + colc[c], cv[u][c]);
       kp[u] = ld1t<DT>(a.kv.k, ro + R + min(lane, DR - 1));
@@ -3212,7 +3230,7 @@ __global__ __launch_bounds__(256) void k_mla_attn(MlaArgs a) {
 #pragma unroll
         for (int e = 0; e < 8; e++) dsum += qa[c][e] * cv[u][c][e];
       dsum = wave_sum(dsum);
-      if (lane == 0 && t0 + 4 * u < pos) sc[t0 + 4 * u] = dsum * a.scale;
+      if (lane == 0 && t0 + NW * u < pos) sc[t0 + NW * u] = dsum * a.scale;
     }
   }
   if (wave == 0) {
@@ -3226,7 +3244,7 @@ __global__ __launch_bounds__(256) void k_mla_attn(MlaArgs a) {
     if (lane == 0) sc[pos] = dsum * a.scale;
   }
   // first rows of Wuv for the output phase: in flight during the softmax and the latent sum
-  const int v0 = wave * (DV / 4), v1 = v0 + DV / 4;
+  const int v0 = wave * (DV / NW), v1 = v0 + DV / NW;
 #pragma unroll
   for (int u = 0; u < RIF; u++)
 #pragma unroll
@@ -3234,15 +3252,17 @@ __global__ __launch_bounds__(256) void k_mla_attn(MlaArgs a) {
   __builtin_amdgcn_sched_barrier(0);
   __syncthreads();
   float mx = -INFINITY;
-  for (int t = tid; t < len; t += 256) mx = fmaxf(mx, sc[t]);
+  for (int t = tid; t < len; t += NTH) mx = fmaxf(mx, sc[t]);
   mx = wave_max(mx);
   if (lane == 0) red[wave] = mx;
   __syncthreads();
-  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  mx = red[0];
+#pragma unroll
+  for (int w = 1; w < NW; w++) mx = fmaxf(mx, red[w]);
   __syncthreads();
   float psum = 0.f;
-  for (int t = tid; t < len; t += 256) { const float p = expf(sc[t] - mx); sc[t] = p; psum += p; }
-  psum = block_sum256(psum, red);
+  for (int t = tid; t < len; t += NTH) { const float p = expf(sc[t] - mx); sc[t] = p; psum += p; }
+  psum = block_sum_nw<NW>(psum, red);
   const float inv = 1.0f / psum;
   // ---- olat = R(sum_t p_t c_t * inv) ----
   {
@@ -3251,22 +3271,22 @@ __global__ __launch_bounds__(256) void k_mla_attn(MlaArgs a) {
     for (int c = 0; c < NCH; c++)
 #pragma unroll
       for (int e = 0; e < 8; e++) acc[c][e] = 0.f;
-    for (int t0 = wave; t0 < pos; t0 += 4 * TIF) {
+    for (int t0 = wave; t0 < pos; t0 += NW * TIF) {
       float cv[TIF][NCH][8];
 #pragma unroll
       for (int u = 0; u < TIF; u++)
 #pragma unroll
-        for (int c = 0; c < NCH; c++) ld8t<DT>(a.kv.k, rowbase + (size_t)min(t0 + 4 * u, pos - 1) * Wd + colc[c], cv[u][c]);
+        for (int c = 0; c < NCH; c++) ld8t<DT>(a.kv.k, rowbase + (size_t)min(t0 + NW * u, pos - 1) * Wd + colc[c], cv[u][c]);
 #pragma unroll
       for (int u = 0; u < TIF; u++) {
-        const float p = (t0 + 4 * u < pos) ? sc[t0 + 4 * u] : 0.f;
+        const float p = (t0 + NW * u < pos) ? sc[t0 + NW * u] : 0.f;
 #pragma unroll
         for (int c = 0; c < NCH; c++)
 #pragma unroll
           for (int e = 0; e < 8; e++) acc[c][e] += p * cv[u][c][e];
       }
     }
-    if (wave == (pos & 3)) {       // the current token, in the wave that would own it in token order
+    if (wave == (pos % NW)) {       // the current token, in the wave that would own it in token order
       const float p = sc[pos];
 #pragma unroll
       for (int c = 0; c < NCH; c++)
@@ -3281,7 +3301,12 @@ __global__ __launch_bounds__(256) void k_mla_attn(MlaArgs a) {
         for (int e = 0; e < 8; e++) part[wave * R + colc[c] + e] = acc[c][e];
   }
   __syncthreads();
-  for (int r = tid; r < R; r += 256) qabs[r] = round_act(((part[r] + part[R + r]) + (part[2 * R + r] + part[3 * R + r])) * inv, a.act);   // qabs now holds olat
+  for (int r = tid; r < R; r += NTH) {   // qabs now holds olat
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; w += 2) t += part[w * R + r] + part[(w + 1) * R + r];
+    qabs[r] = round_act(t * inv, a.act);
+  }
   __syncthreads();
   // ---- out_h = R(Wuv olat): wave w takes v rows [w DV/4, (w+1) DV/4), 8 rows in flight ----
 #pragma unroll
@@ -3308,7 +3333,11 @@ __global__ __launch_bounds__(256) void k_mla_attn(MlaArgs a) {
   }
 }
 
-size_t bzk_mla_smem(const MlaArgs& a, int max_len) { return (size_t)(a.rank * 6 + a.rope * 2 + a.nope + 8 + max_len) * 4 + 64; }
+static int mla_waves(const MlaArgs& a) {
+  static const bool w4 = getenv("BZ_MLA_NW4") != nullptr;
+  return (!w4 && a.nope % 16 == 0 && a.vdim % 16 == 0) ? 16 : 4;
+}
+size_t bzk_mla_smem(const MlaArgs& a, int max_len) { return (size_t)(a.rank * (2 + mla_waves(a)) + a.rope * 2 + a.nope + 16 + max_len) * 4 + 64; }
 
 int bzk_mla_attn(hipStream_t s, const MlaArgs& a, int max_len) {
   if (a.rank % 8 || a.rank > 1024 || a.rope > 64 || (a.rope & 1) || a.nope % 4 || a.vdim % 4 || a.kv.paged || a.kv.n_kv != 1 || a.kv.hd != a.rank + a.rope)
@@ -3317,14 +3346,17 @@ int bzk_mla_attn(hipStream_t s, const MlaArgs& a, int max_len) {
   if (smem > 160 * 1024) BZ_FAIL(BZ_E_UNSUPPORTED, "mla_attn: context %d too long for the single-pass kernel", max_len);
   if (a.wdt != a.kv.dtype) BZ_FAIL(BZ_E_UNSUPPORTED, "mla_attn: kv_b_proj dtype %d must equal the cache dtype %d", a.wdt, a.kv.dtype);
   const double bytes = (double)a.n_heads * (a.nope + a.vdim) * a.rank * bz_dtype_size(a.wdt);
-#define LAUNCH_MLA(NCH, DT) do { \
+  const int NWV = mla_waves(a);
+#define LAUNCH_MLA_W(NCH, DT, W_) do { \
     static bool attr_done = false; \
-    if (!attr_done) { BZ_HIP(hipFuncSetAttribute((const void*)k_mla_attn<NCH, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_done = true; } \
-    BZ_LAUNCH("mla_attn", bytes, (k_mla_attn<NCH, DT>), dim3(a.n_heads), dim3(256), smem, s, a); } while (0)
+    if (!attr_done) { BZ_HIP(hipFuncSetAttribute((const void*)k_mla_attn<NCH, DT, W_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_done = true; } \
+    BZ_LAUNCH("mla_attn", bytes, (k_mla_attn<NCH, DT, W_>), dim3(a.n_heads), dim3(W_ * 64), smem, s, a); } while (0)
+#define LAUNCH_MLA(NCH, DT) do { if (NWV == 16) LAUNCH_MLA_W(NCH, DT, 16); else LAUNCH_MLA_W(NCH, DT, 4); } while (0)
 #define LAUNCH_MLA_DT(DT) do { if (a.rank <= 512) LAUNCH_MLA(1, DT); else LAUNCH_MLA(2, DT); } while (0)
   if (a.wdt == BZ_F16) LAUNCH_MLA_DT(BZ_F16); else if (a.wdt == BZ_BF16) LAUNCH_MLA_DT(BZ_BF16); else LAUNCH_MLA_DT(BZ_F32);
 #undef LAUNCH_MLA_DT
 #undef LAUNCH_MLA
+#undef LAUNCH_MLA_W
   BZ_HIP(hipGetLastError());
   return BZ_OK;
 }
