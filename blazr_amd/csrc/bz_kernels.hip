@@ -571,8 +571,8 @@ __device__ __forceinline__ void quant_x64(const float* a, unsigned* xh, unsigned
 #ifndef MLP_DEPTH
 #define MLP_DEPTH 2
 #endif
-template <int FIX, int GPW, int TPW>   // GPW k-groups per wave (gate/up), TPW output tiles per wave (down)
-__global__ __launch_bounds__(512) void k_mlp_q4g(const uint4* __restrict__ Wgu, const __half* __restrict__ Sgu, const unsigned char* __restrict__ Zgu,
+template <int FIX, int GPW, int TPW, int NW>   // NW waves per block; GPW k-groups per wave (gate/up), TPW output tiles per wave (down)
+__global__ __launch_bounds__(NW * 64) void k_mlp_q4g(const uint4* __restrict__ Wgu, const __half* __restrict__ Sgu, const unsigned char* __restrict__ Zgu,
                                                  const float* __restrict__ bgu, const uint4* __restrict__ Wd, const __half* __restrict__ Sd,
                                                  const unsigned char* __restrict__ Zd, const float* __restrict__ bd, int H, int I, Pro pro,
                                                  long long* acc, long long* zero_buf, int zero_n) {
@@ -583,28 +583,29 @@ __global__ __launch_bounds__(512) void k_mlp_q4g(const uint4* __restrict__ Wgu, 
   unsigned* xl = xm + H / 4;
   const int G = H >> 7;
   int4* gpar = (int4*)(xl + H / 4);           // [2G]
-  float* part = (float*)(gpar + 2 * G);       // [8][128]
-  float* av = part + 8 * 128;                 // [64]
+  constexpr int NTH = NW * 64;
+  float* part = (float*)(gpar + 2 * G);       // [NW][128]
+  float* av = part + NW * 128;                // [64]
   unsigned* ah = (unsigned*)(av + 64);        // [16] x3
   unsigned* am_ = ah + 16;
   unsigned* al = am_ + 16;
   int4* apar = (int4*)(al + 16);              // [2]
-  float* red = (float*)(apar + 2);            // [8]
+  float* red = (float*)(apar + 2);            // [NW]
 
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int sl = blockIdx.x;                  // intermediate slice: columns [64 sl, 64 sl + 64)
   const int NTI = I >> 6;                     // gate tile = sl, up tile = NTI + sl
-  const int gbeg = wave * GPW;                // G == 8 * GPW
-  const int tbeg = wave * TPW;                // H / 64 == 8 * TPW
+  const int gbeg = wave * GPW;                // G == NW * GPW
+  const int tbeg = wave * TPW;                // H / 64 == NW * TPW
   const int GD = I >> 7, gd = sl >> 1;        // down's quantisation group of these 64 k
   // all kernel arguments in ONE scalar-load batch (the compiler otherwise fetches late-used ones lazily: a ~0.3 us round trip each time)
   asm volatile("" :: "s"(zero_buf), "s"(zero_n), "s"(acc), "s"(pro.h_in), "s"(pro.src.p), "s"(pro.norm_w), "s"(pro.h_out), "s"(pro.H),
                "s"(pro.act), "s"(H), "s"(I), "s"(Wgu), "s"(Sgu), "s"(Zgu), "s"(Wd), "s"(Sd), "s"(Zd));
-  zero_duty<512>(zero_buf, zero_n);
+  zero_duty<NTH>(zero_buf, zero_n);
 
   // (1) prologue loads: full-H pass, 4 contiguous elements per thread per 2048 (h, deferred residual, norm weight) --
   //     loads only, unconditional (H == 2048 * NJ), arithmetic after the weight loads have been issued
-  constexpr int NJ = GPW / 2 > 0 ? GPW / 2 : 1;
+  constexpr int NJ = (GPW * NW * 128) / (NTH * 4);   // H / (4 NTH): whole passes of 4 elements per thread
   const bool hasprev = pro.src.p != nullptr;
   const void* prevp = hasprev ? pro.src.p : (const void*)pro.h_in;
   float hv[NJ][4];
@@ -612,7 +613,7 @@ __global__ __launch_bounds__(512) void k_mlp_q4g(const uint4* __restrict__ Wgu, 
   float4 nw[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; j++) {
-    const int i = j * 2048 + tid * 4;
+    const int i = j * (NTH * 4) + tid * 4;
     const float4 h4 = *(const float4*)(pro.h_in + i);
     hv[j][0] = h4.x; hv[j][1] = h4.y; hv[j][2] = h4.z; hv[j][3] = h4.w;
 #pragma unroll
@@ -647,7 +648,7 @@ __global__ __launch_bounds__(512) void k_mlp_q4g(const uint4* __restrict__ Wgu, 
   float ss = 0.f;
 #pragma unroll
   for (int j = 0; j < NJ; j++) {
-    const int i = j * 2048 + tid * 4;
+    const int i = j * (NTH * 4) + tid * 4;
     if (hasprev) {
 #pragma unroll
       for (int e = 0; e < 4; e++) hv[j][e] = round_act(hv[j][e] + vcvt<FIX>(pv[j][e], pro.act), pro.act);
@@ -659,15 +660,16 @@ __global__ __launch_bounds__(512) void k_mlp_q4g(const uint4* __restrict__ Wgu, 
   if (lane == 0) red[wave] = ss;
   __syncthreads();
   ss = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
+  if (NW == 16) ss += ((red[8] + red[9]) + (red[10] + red[11])) + ((red[12] + red[13]) + (red[14] + red[15]));
   const float rs = 1.0f / sqrtf(ss / (float)H + pro.eps);
 #pragma unroll
   for (int j = 0; j < NJ; j++) {
-    const int i = j * 2048 + tid * 4;
+    const int i = j * (NTH * 4) + tid * 4;
     *(float4*)(xs + i) = make_float4(round_act(nw[j].x * round_act(hv[j][0] * rs, pro.act), pro.act), round_act(nw[j].y * round_act(hv[j][1] * rs, pro.act), pro.act),
                                      round_act(nw[j].z * round_act(hv[j][2] * rs, pro.act), pro.act), round_act(nw[j].w * round_act(hv[j][3] * rs, pro.act), pro.act));
   }
   __syncthreads();
-  quant_x128<512>(xs, H, xh, xm, xl, gpar);
+  quant_x128<NTH>(xs, H, xh, xm, xl, gpar);
   __syncthreads();
 
   // (4) gate / up partial dot products over this wave's k-groups; group b+2 is requested as soon as group b's registers are free,
@@ -704,7 +706,7 @@ __global__ __launch_bounds__(512) void k_mlp_q4g(const uint4* __restrict__ Wgu, 
   if (tid < 128) {
     float t = 0.f;
 #pragma unroll
-    for (int w2 = 0; w2 < 8; w2++) t += part[w2 * 128 + tid];
+    for (int w2 = 0; w2 < NW; w2++) t += part[w2 * 128 + tid];
     if (bgu) t += bgu[tid < 64 ? sl * 64 + tid : I + sl * 64 + (tid - 64)];
     part[tid] = round_act(t, pro.act);
   }
@@ -726,7 +728,7 @@ __global__ __launch_bounds__(512) void k_mlp_q4g(const uint4* __restrict__ Wgu, 
     atomicAdd((unsigned long long*)(acc + n), (unsigned long long)f2fix(y));
   }}
 
-static size_t mlp_smem(int H) { return (size_t)H * 4 + (size_t)H * 3 + (size_t)(H >> 7) * 32 + 8 * 128 * 4 + 64 * 4 + 48 * 4 + 32 + 32 + 64; }
+static size_t mlp_smem(int H) { return (size_t)H * 4 + (size_t)H * 3 + (size_t)(H >> 7) * 32 + 16 * 128 * 4 + 64 * 4 + 48 * 4 + 32 + 64 + 64; }
 
 bool bzk_mlp_fusable(const LinearDev& gu, const LinearDev& dn, int H, int I) {
   return gu.kind == LK_Q4G && dn.kind == LK_Q4G && !gu.perm && !dn.perm && gu.N == 2 * I && gu.K == H && dn.N == H && dn.K == I &&
@@ -737,11 +739,13 @@ int bzk_mlp_q4g(hipStream_t s, const LinearDev& gu, const LinearDev& dn, int H, 
   if (!bzk_mlp_fusable(gu, dn, H, I)) BZ_FAIL(BZ_E_INVALID, "fused MLP does not apply to this shape");
   const size_t smem = mlp_smem(H);
   const double bytes = (double)gu.algo_bytes + (double)dn.algo_bytes;
-#define LAUNCH_MLP(FIX, GP, TP) BZ_LAUNCH("mlp_q4g<norm+gate/up+silu+down>", bytes, (k_mlp_q4g<FIX, GP, TP>), dim3(I / 64), dim3(512), smem, s, \
+  static const bool w16 = getenv("BZ_MLP_NW16") != nullptr;
+#define LAUNCH_MLP(FIX, GP, TP, W_) BZ_LAUNCH("mlp_q4g<norm+gate/up+silu+down>", bytes, (k_mlp_q4g<FIX, GP, TP, W_>), dim3(I / 64), dim3(W_ * 64), smem, s, \
     (const uint4*)gu.w, (const __half*)gu.scales, (const unsigned char*)gu.zeros, gu.bias, (const uint4*)dn.w, (const __half*)dn.scales,            \
     (const unsigned char*)dn.zeros, dn.bias, H, I, pro, acc, zero_buf, zero_n)
-  if (H == 4096) { if (pro.src.fix) LAUNCH_MLP(1, 4, 8); else LAUNCH_MLP(0, 4, 8); }
-  else { if (pro.src.fix) LAUNCH_MLP(1, 2, 4); else LAUNCH_MLP(0, 2, 4); }
+  if (H == 4096 && w16) { if (pro.src.fix) LAUNCH_MLP(1, 2, 4, 16); else LAUNCH_MLP(0, 2, 4, 16); }
+  else if (H == 4096) { if (pro.src.fix) LAUNCH_MLP(1, 4, 8, 8); else LAUNCH_MLP(0, 4, 8, 8); }
+  else { if (pro.src.fix) LAUNCH_MLP(1, 2, 4, 8); else LAUNCH_MLP(0, 2, 4, 8); }
 #undef LAUNCH_MLP
   BZ_HIP(hipGetLastError());
   return BZ_OK;
