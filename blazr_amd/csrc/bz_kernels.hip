@@ -630,7 +630,7 @@ __global__ __launch_bounds__(NW * 64) void k_mlp_q4g(const uint4* __restrict__ W
   uint4 Ag[ND][4], Au[ND][4];
 #pragma unroll
   for (int c = 0; c < 4; c++) { Ag[0][c] = ldnt(wg + c * 64); Au[0][c] = ldnt(wu + c * 64); }
-  if (GPW > 1) {
+  if (GPW > 1 && NW == 8) {
 #pragma unroll
     for (int c = 0; c < 4; c++) { Ag[1][c] = ldnt(wg + (4 + c) * 64); Au[1][c] = ldnt(wu + (4 + c) * 64); }
   if (ND == 3) {
@@ -671,6 +671,10 @@ __global__ __launch_bounds__(NW * 64) void k_mlp_q4g(const uint4* __restrict__ W
   __syncthreads();
   quant_x128<NTH>(xs, H, xh, xm, xl, gpar);
   __syncthreads();
+  if (GPW > 1 && NW == 16) {   // 16 waves: the second group goes out only now, so that no more than 8 KiB per wave (128 KiB per CU) is in flight at a time
+#pragma unroll
+    for (int c = 0; c < 4; c++) { Ag[1][c] = ldnt(wg + (4 + c) * 64); Au[1][c] = ldnt(wu + (4 + c) * 64); }
+  }
 
   // (4) gate / up partial dot products over this wave's k-groups; group b+2 is requested as soon as group b's registers are free,
   //     and the down slab (16 KiB per wave) goes out behind the last gate/up group, so the stream never pauses
@@ -739,7 +743,7 @@ int bzk_mlp_q4g(hipStream_t s, const LinearDev& gu, const LinearDev& dn, int H, 
   if (!bzk_mlp_fusable(gu, dn, H, I)) BZ_FAIL(BZ_E_INVALID, "fused MLP does not apply to this shape");
   const size_t smem = mlp_smem(H);
   const double bytes = (double)gu.algo_bytes + (double)dn.algo_bytes;
-  static const bool w16 = getenv("BZ_MLP_NW16") != nullptr;
+  static const bool w16 = getenv("BZ_MLP_NW8") == nullptr;   // 16 waves per block with the second gate/up group issued after the quantisation: 24.1 vs 24.4 us
 #define LAUNCH_MLP(FIX, GP, TP, W_) BZ_LAUNCH("mlp_q4g<norm+gate/up+silu+down>", bytes, (k_mlp_q4g<FIX, GP, TP, W_>), dim3(I / 64), dim3(W_ * 64), smem, s, \
     (const uint4*)gu.w, (const __half*)gu.scales, (const unsigned char*)gu.zeros, gu.bias, (const uint4*)dn.w, (const __half*)dn.scales,            \
     (const unsigned char*)dn.zeros, dn.bias, H, I, pro, acc, zero_buf, zero_n)
