@@ -175,10 +175,12 @@ int bz_ssm_state_reset(bz_ssm_state* s);
 /* ---- forward ------------------------------------------------------------------------------------------ */
 /* process_decode_batch (engine/batch_decode.rs:35-150): N sequences, one new token each, one shared paged cache; slot_mapping I32[N],
  * block_table I32[N, max_blocks] (rows padded with 0), seq_lens host i32[N] (length of each sequence including the new token).
- * logits_out F32 [N, vocab].  Round 1: sequences run one after another (no weight sharing yet). */
+ * logits_out F32 [N, vocab].  int4 (no act-order) and dense 16-bit models share the weights across the batch (multi-row dot4 kernel up to 8
+ * sequences, matrix-core GEMMs beyond); other formats run the sequences one after another. */
 int bz_forward_paged_batch(bz_model* m, const bz_tensor* tokens, int N, bz_paged_kv* kv, const bz_tensor* slot_mapping, const bz_tensor* block_table,
                            int max_blocks, const int32_t* seq_lens, bz_tensor* logits_out);
-/* LoadedModel::forward_with_ssm_state(&input, &mut ssm) (executor_generate.rs:137,148): Mamba2; tokens I64 [1,S] */
+/* LoadedModel::forward_with_ssm_state(&input, &mut ssm) (executor_generate.rs:137,148): Mamba2; tokens I64 [1,S].  S >= 8 on a dense 16-bit
+ * model takes the batched prefill (matrix-core GEMMs + in-kernel scan over the tokens); the state it leaves continues like the per-token one. */
 int bz_forward_ssm(bz_model* m, const bz_tensor* tokens, int S, bz_ssm_state* state, bz_tensor* logits_out, uint32_t flags);
 #define BZ_FWD_ALL_LOGITS 1u  /* logits for all S positions ([S,V]); default: last position only ([1,V]) */
 /* LoadedModel::forward_with_kv_cache(&input,&mut kv,position) (executor_generate.rs:357,372).
@@ -281,8 +283,8 @@ int bz_tune_gemv(bz_device* dev, int N, int K, int groups_per_wg, int mode, int 
 /* ---- op-level entry points (parity tests; each is the kernel the forward path uses) ------------------------ */
 /* QuantMatmulOps / dense matmul on a registered weight `name` ("….weight"): y[S,N] = x[S,K] W^T (+bias); x,y F32 device tensors */
 int bz_quant_matmul(bz_model* m, const char* name, const bz_tensor* x, int S, bz_tensor* y);
-/* Prefill GEMM on the matrix cores (dense f16 / bf16 weights, K % 64 == 0): y[S,N] = round_to_weight_dtype(x)[S,K] . W[N,K]^T, f32 accumulate,
- * result unrounded.  The same kernel runs inside bz_forward_kv / bz_forward_paged when a dense 16-bit Llama-family model is given S >= 8 tokens
+/* Prefill GEMM on the matrix cores: y[S,N] = round16(x)[S,K] . W[N,K]^T, f32 accumulate, result unrounded.  Dense f16 / bf16 weights
+ * (K % 64 == 0, x rounded to the weight dtype), or int4 group-quantised weights without act-order (AWQ / GPTQ: x rounded to f16, S >= 9).  The same kernel runs inside bz_forward_kv / bz_forward_paged when a dense 16-bit Llama-family model is given S >= 8 tokens
  * (regular.rs:89-117 bf16 SafeTensors path; boostr's matmul behind LoadedModel::forward_with_kv_cache at executor_generate.rs:357). */
 int bz_prefill_matmul(bz_model* m, const char* name, const bz_tensor* x, int S, bz_tensor* y);
 /* DequantOps: whole weight -> F32 [N,K] on host (from the REPACKED device layout: validates the repack) */
