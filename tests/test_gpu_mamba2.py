@@ -145,3 +145,21 @@ def test_batched_prefill_scan_matches_oracle_and_steps(device, over, S):
         _check_logits(lm.forward_with_ssm_state([tok], st).to_numpy(), lo, cfg["act_dtype"])
         tok = int(lo[0].argmax())
     orc_py.lib().orc_ssm_state_free(ost)
+
+
+def test_batched_prefill_crosses_the_row_chunk(device):
+    """prompts longer than the 512-row workspace chunk: the conv window and the SSM state carry from one chunk of rows to the next"""
+    model = synth.make_mamba2("tiny-mamba2")
+    cfg = model["config"]
+    lm, om = runtime.LoadedModel.from_synth(device, model), orc_py.OrcMamba2(model)
+    p = synth.prompt_tokens(530, cfg["vocab"], seed=77)
+    st, ost = runtime.LayeredSsmState(lm), om.new_state()
+    got = lm.forward_with_ssm_state(p, st).to_numpy()
+    want = om.forward(p, ost)
+    _check_logits(got, want, cfg["act_dtype"])
+    tok = int(want[-1].argmax())
+    for _ in range(4):
+        lo = om.forward([tok], ost)
+        _check_logits(lm.forward_with_ssm_state([tok], st).to_numpy(), lo, cfg["act_dtype"])
+        tok = int(lo[0].argmax())
+    orc_py.lib().orc_ssm_state_free(ost)
