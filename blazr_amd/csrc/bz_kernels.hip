@@ -3403,15 +3403,18 @@ __global__ __launch_bounds__(256) void k_moe_router(Pro pro, const void* wr, int
     }
   }
   acc = wave_sum(acc);
-  if (lane == 0 && (int)blockIdx.x * 4 + wave < E) lg_glob[blockIdx.x * 4 + wave] = acc;
-  __threadfence();
+  // hand-off to the last workgroup without __threadfence() (an L2 write-back per block): the logits are published with device-scope atomic
+  // stores, vmcnt(0) says they have been performed, then the counter; the reader uses device-scope loads (scripts/overlap_probe.hip checks
+  // exactly this pattern)
+  if (lane == 0 && (int)blockIdx.x * 4 + wave < E)
+    __hip_atomic_store(lg_glob + blockIdx.x * 4 + wave, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
   __shared__ unsigned s_last;
-  if (tid == 0) s_last = atomicAdd(counter, 1u) == gridDim.x - 1 ? 1u : 0u;
+  if (tid == 0) s_last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
   __syncthreads();
   if (!s_last) return;
-  __threadfence();
-  for (int i = tid; i < E; i += 256) lg[i] = __builtin_nontemporal_load(lg_glob + i);
+  for (int i = tid; i < E; i += 256) lg[i] = __hip_atomic_load(lg_glob + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (tid == 0) *counter = 0;                    // ready for the next launch (stream order)
   __syncthreads();
   if (wave == 0) {
@@ -3432,11 +3435,27 @@ __global__ __launch_bounds__(256) void k_moe_router(Pro pro, const void* wr, int
       float bv = -1.f; int bi = 0x7fffffff;
 #pragma unroll
       for (int j = 0; j < 16; j++) { const int ee = lane + 64 * j; if (v[j] > bv) { bv = v[j]; bi = ee; } }   // ascending e within a lane: first max wins
-#pragma unroll
-      for (int s2 = 32; s2 >= 1; s2 >>= 1) {
-        const float ov = __shfl_xor(bv, s2, 64); const int oi = __shfl_xor(bi, s2, 64);
-        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+      // wave argmax (larger value, then smaller index) without the LDS permute network: every step is symmetric, so all lanes agree
+#define ROUTER_STEP(OV, OI) do { const float ov_ = (OV); const int oi_ = (OI); if (ov_ > bv || (ov_ == bv && oi_ < bi)) { bv = ov_; bi = oi_; } } while (0)
+      ROUTER_STEP(dpp_get<DPP_XOR1>(bv), dpp_get<DPP_XOR1>(bi));
+      ROUTER_STEP(dpp_get<DPP_XOR2>(bv), dpp_get<DPP_XOR2>(bi));
+      ROUTER_STEP(dpp_get<DPP_HMIRROR>(bv), dpp_get<DPP_HMIRROR>(bi));
+      ROUTER_STEP(dpp_get<DPP_MIRROR>(bv), dpp_get<DPP_MIRROR>(bi));
+      {
+        const bz_u2_t rv = __builtin_amdgcn_permlane16_swap(__float_as_uint(bv), __float_as_uint(bv), false, false);
+        const bz_u2_t ri = __builtin_amdgcn_permlane16_swap((unsigned)bi, (unsigned)bi, false, false);
+        const float v0 = __uint_as_float(rv.x), v1 = __uint_as_float(rv.y); const int i0 = (int)ri.x, i1 = (int)ri.y;
+        const bool first = v0 > v1 || (v0 == v1 && i0 < i1);
+        bv = first ? v0 : v1; bi = first ? i0 : i1;
       }
+      {
+        const bz_u2_t rv = __builtin_amdgcn_permlane32_swap(__float_as_uint(bv), __float_as_uint(bv), false, false);
+        const bz_u2_t ri = __builtin_amdgcn_permlane32_swap((unsigned)bi, (unsigned)bi, false, false);
+        const float v0 = __uint_as_float(rv.x), v1 = __uint_as_float(rv.y); const int i0 = (int)ri.x, i1 = (int)ri.y;
+        const bool first = v0 > v1 || (v0 == v1 && i0 < i1);
+        bv = first ? v0 : v1; bi = first ? i0 : i1;
+      }
+#undef ROUTER_STEP
       if (lane == k) { mysel = bi; myw = bv; }
       tsum += bv;
 #pragma unroll
