@@ -1297,6 +1297,185 @@ __global__ __launch_bounds__(256) void k_gemv_gq(const uint4* __restrict__ Wq, c
   atomicAdd((unsigned long long*)(acc + n), (unsigned long long)f2fix(y));
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Slim form of the GGUF block-quant GEMV (Q4_K / Q6_K): the structure of k_gemv_q4g_slim -- 8 waves share ONE 256-k slice, which here is
+// exactly one superblock, each wave owns one 64-column tile (its 8 KiB of nibbles + header in flight before the prologue) -- with the
+// per-32-k-chunk activation planes and the block arithmetic of k_gemv_gq.  The generic kernel holds > 256 registers per lane (one
+// workgroup of 4 waves per CU) and runs q/k/v in two rounds: 18.2 us against 7.0 us for the same bytes in AWQ form.
+//   MODE NORM: x = RMSNorm(h + prev) slice (full-H sum of squares per block)      MODE SILU: x = R(R(silu(gate)) * up) slice
+// grid = (K / 256) x ceil(N / 512), 512 threads
+// ---------------------------------------------------------------------------------------------------------
+template <int FMT, int MODE, int FIX, int NJ>     // NJ = H / 2048 (NORM only)
+__global__ __launch_bounds__(512) void k_gemv_gq_slim(const uint4* __restrict__ Wq, const uint2* __restrict__ Wh, const uint4* __restrict__ Hd,
+                                                     const __half* __restrict__ Dd, const float* __restrict__ bias, int N, int K, Pro pro, long long* acc,
+                                                     long long* zero_buf, int zero_n) {
+  __shared__ __attribute__((aligned(16))) float xs[256];
+  __shared__ __attribute__((aligned(16))) unsigned xh[64], xm[64], xl[64];
+  __shared__ int4 cpar[16];
+  __shared__ float red[8];
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int SB = K >> 8, C32 = K >> 5;
+  const int ksl = blockIdx.x % SB, tq = (blockIdx.x / SB) * 8 + wave;
+  const bool q_on = tq * 64 < N;
+  const int tqc = q_on ? tq : 0;
+  asm volatile("" :: "s"(zero_buf), "s"(zero_n), "s"(acc), "s"(pro.h_in), "s"(pro.src.p), "s"(pro.norm_w), "s"(pro.h_out), "s"(pro.H),
+               "s"(pro.act), "s"(K), "s"(N), "s"(Wq), "s"(Wh), "s"(Hd), "s"(Dd), "s"(bias));   // one scalar-load batch for all arguments
+  zero_duty<512>(zero_buf, zero_n);
+  // (1) prologue loads
+  const bool hasprev = pro.src.p != nullptr;
+  float hv[NJ][4];
+  typename RawT<FIX>::T pv[NJ][4];
+  float4 nw = make_float4(0, 0, 0, 0);
+  typename RawT<FIX>::T ga = 0, ua = 0;
+  if (MODE == PRO_NORM) {
+    const void* prevp = hasprev ? pro.src.p : (const void*)pro.h_in;
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+      const int i = j * 2048 + tid * 4;
+      const float4 h4 = *(const float4*)(pro.h_in + i);
+      hv[j][0] = h4.x; hv[j][1] = h4.y; hv[j][2] = h4.z; hv[j][3] = h4.w;
+#pragma unroll
+      for (int e = 0; e < 4; e++) pv[j][e] = vraw<FIX>(prevp, (FIX || hasprev) ? i + e : 0);
+    }
+    nw = *(const float4*)(pro.norm_w + ksl * 256 + (tid & 63) * 4);
+  } else {
+    const int kk = ksl * 256 + (tid & 255);
+    ga = vraw<FIX>(pro.src.p, kk); ua = vraw<FIX>(pro.src.p, pro.H + kk);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // (2) this wave's superblock: 8 x 16 B of nibbles (+ Q6_K: 8 x 8 B of high bits), header, all in flight now
+  uint4 q[8]; uint2 qh[8]; uint4 hd; __half dsb = __float2half(0.f);
+  {
+    const uint4* p = Wq + ((size_t)tqc * C32 + (size_t)ksl * 8) * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < 8; i++) q[i] = ldnt(p + i * 64);
+    hd = Hd[((size_t)tqc * SB + ksl) * 64 + lane];
+    if (FMT == GQ_Q6K) {
+      const uint2* ph = Wh + ((size_t)tqc * C32 + (size_t)ksl * 8) * 64 + lane;
+#pragma unroll
+      for (int i = 0; i < 8; i++) qh[i] = ph[i * 64];
+      dsb = Dd[((size_t)tqc * SB + ksl) * 64 + lane];
+    }
+  }
+  // (3) the activation slice
+  if (MODE == PRO_NORM) {
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+      const int i = j * 2048 + tid * 4;
+      if (hasprev) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) hv[j][e] = round_act(hv[j][e] + vcvt<FIX>(pv[j][e], pro.act), pro.act);
+      }
+      ss += hv[j][0] * hv[j][0] + hv[j][1] * hv[j][1] + hv[j][2] * hv[j][2] + hv[j][3] * hv[j][3];
+      if (blockIdx.x == 0 && pro.h_out) *(float4*)(pro.h_out + i) = make_float4(hv[j][0], hv[j][1], hv[j][2], hv[j][3]);
+      if ((i >> 8) == ksl) *(float4*)(xs + (i & 255)) = make_float4(hv[j][0], hv[j][1], hv[j][2], hv[j][3]);
+    }
+    ss = wave_sum(ss);
+    if (lane == 0) red[wave] = ss;
+    __syncthreads();
+    ss = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
+    const float rs = 1.0f / sqrtf(ss / (float)pro.H + pro.eps);
+    if (tid < 64) {
+      const float4 v = *(const float4*)(xs + tid * 4);
+      *(float4*)(xs + tid * 4) = make_float4(round_act(nw.x * round_act(v.x * rs, pro.act), pro.act), round_act(nw.y * round_act(v.y * rs, pro.act), pro.act),
+                                             round_act(nw.z * round_act(v.z * rs, pro.act), pro.act), round_act(nw.w * round_act(v.w * rs, pro.act), pro.act));
+    }
+  } else {
+    if (tid < 256) xs[tid] = round_act(round_act(silu_f(vcvt<FIX>(ga, pro.act)), pro.act) * vcvt<FIX>(ua, pro.act), pro.act);
+  }
+  __syncthreads();
+  quant_x32<FMT>(xs, 256, xh, xm, xl, cpar);
+  __syncthreads();
+  if (!q_on) return;
+  const uint4* xh4 = (const uint4*)xh;
+  const uint4* xm4 = (const uint4*)xm;
+  const uint4* xl4 = (const uint4*)xl;
+  float y = 0.f;
+  if (FMT == GQ_Q4K) {
+    const unsigned hw[4] = {hd.x, hd.y, hd.z, hd.w};
+    const float d = __half2float(__ushort_as_half((unsigned short)(hw[0] & 0xffffu)));
+    const float dmin = __half2float(__ushort_as_half((unsigned short)(hw[0] >> 16)));
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+      const unsigned ww[4] = {q[c].x, q[c].y, q[c].z, q[c].w};
+      unsigned w[8];
+#pragma unroll
+      for (int j = 0; j < 4; j++) { w[2 * j] = ww[j] & 0x0F0F0F0Fu; w[2 * j + 1] = ww[j] & 0xF0F0F0F0u; }
+      int ua_[3] = {0, 0, 0}, ub_[3] = {0, 0, 0};
+      const uint4 h0 = xh4[c * 2], h1 = xh4[c * 2 + 1], m0 = xm4[c * 2], m1 = xm4[c * 2 + 1], l0 = xl4[c * 2], l1 = xl4[c * 2 + 1];
+      const unsigned Xh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+      const unsigned Xm[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+      const unsigned Xl[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        ua_[0] = __builtin_amdgcn_sdot4((int)w[2 * j], (int)Xh[2 * j], ua_[0], false);
+        ua_[1] = __builtin_amdgcn_sdot4((int)w[2 * j], (int)Xm[2 * j], ua_[1], false);
+        ua_[2] = __builtin_amdgcn_sdot4((int)w[2 * j], (int)Xl[2 * j], ua_[2], false);
+        ub_[0] = __builtin_amdgcn_sdot4((int)w[2 * j + 1], (int)Xh[2 * j + 1], ub_[0], false);
+        ub_[1] = __builtin_amdgcn_sdot4((int)w[2 * j + 1], (int)Xm[2 * j + 1], ub_[1], false);
+        ub_[2] = __builtin_amdgcn_sdot4((int)w[2 * j + 1], (int)Xl[2 * j + 1], ub_[2], false);
+      }
+      const int4 p0 = cpar[2 * c], p1 = cpar[2 * c + 1];
+      const float qx = planes_f((ua_[0] << 4) + ub_[0] + 128 * p1.x, (ua_[1] << 4) + ub_[1] + 128 * p1.y, (ua_[2] << 4) + ub_[2] + 128 * p1.z) * (1.0f / 16.0f);
+      const float sx_ = planes_f(p0.y, p0.z, p0.w);
+      int sc, mn;
+      q4k_scale_min(hw, c, sc, mn);
+      y += __int_as_float(p0.x) * ((d * (float)sc) * qx - (dmin * (float)mn) * sx_);
+    }
+  } else {   // Q6_K
+    const unsigned sw[4] = {hd.x, hd.y, hd.z, hd.w};   // 16 int8 scales
+    const float d = __half2float(dsb);
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+      const unsigned ww[4] = {q[c].x, q[c].y, q[c].z, q[c].w};
+      const unsigned hh[2] = {qh[c].x, qh[c].y};
+      unsigned w[8];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const unsigned lo_a = ww[j] & 0x0F0F0F0Fu, lo_b = (ww[j] >> 4) & 0x0F0F0F0Fu;
+        const int fa = 2 * j, fb = 2 * j + 1;
+        const unsigned hi_a = ((hh[fa >> 2] >> (2 * (fa & 3))) & 0x03030303u) << 4;
+        const unsigned hi_b = ((hh[fb >> 2] >> (2 * (fb & 3))) & 0x03030303u) << 4;
+        w[2 * j] = lo_a | hi_a;
+        w[2 * j + 1] = lo_b | hi_b;
+      }
+      const uint4 h0 = xh4[c * 2], h1 = xh4[c * 2 + 1], m0 = xm4[c * 2], m1 = xm4[c * 2 + 1], l0 = xl4[c * 2], l1 = xl4[c * 2 + 1];
+      const unsigned Xh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+      const unsigned Xm[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+      const unsigned Xl[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+      int u0[3] = {0, 0, 0}, u1[3] = {0, 0, 0};
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        u0[0] = __builtin_amdgcn_sdot4((int)w[j], (int)Xh[j], u0[0], false);
+        u0[1] = __builtin_amdgcn_sdot4((int)w[j], (int)Xm[j], u0[1], false);
+        u0[2] = __builtin_amdgcn_sdot4((int)w[j], (int)Xl[j], u0[2], false);
+        u1[0] = __builtin_amdgcn_sdot4((int)w[4 + j], (int)Xh[4 + j], u1[0], false);
+        u1[1] = __builtin_amdgcn_sdot4((int)w[4 + j], (int)Xm[4 + j], u1[1], false);
+        u1[2] = __builtin_amdgcn_sdot4((int)w[4 + j], (int)Xl[4 + j], u1[2], false);
+      }
+      const int4 p0 = cpar[2 * c], p1 = cpar[2 * c + 1];
+      const int s0 = (int)(signed char)((sw[(2 * c) >> 2] >> (8 * ((2 * c) & 3))) & 255u);
+      const int s1 = (int)(signed char)((sw[(2 * c + 1) >> 2] >> (8 * ((2 * c + 1) & 3))) & 255u);
+      const float f0 = planes_f(u0[0] - 32 * p0.y, u0[1] - 32 * p0.z, u0[2] - 32 * p0.w);
+      const float f1 = planes_f(u1[0] - 32 * p1.x, u1[1] - 32 * p1.y, u1[2] - 32 * p1.z);
+      y += __int_as_float(p0.x) * ((d * (float)s0) * f0 + (d * (float)s1) * f1);
+    }
+  }
+  const int n = tq * 64 + lane;
+  if (bias != nullptr && ksl == 0) y += bias[n];
+  atomicAdd((unsigned long long*)(acc + n), (unsigned long long)f2fix(y));
+}
+
+bool bzk_gq_slim_ok(const LinearDev& L, const Pro& pro) {
+  static const bool off = getenv("BZ_NO_GQ_SLIM") != nullptr;
+  if (off || (L.kind != LK_Q4K && L.kind != LK_Q6K) || pro.perm != nullptr || pro.dbg || pro.stamps || L.N % 64 || L.K % 256) return false;
+  if (pro.mode == PRO_NORM) return L.K == pro.H && (L.K == 2048 || L.K == 4096 || L.K == 8192);
+  if (pro.mode == PRO_SILU) return L.K == pro.H;
+  return false;
+}
+
+
 static size_t gq_smem(int SBW) { size_t KR = (size_t)SBW * 256; return KR * 4 + KR * 3 + KR + 64; }
 
 static size_t q4g_smem(int GW) {
@@ -1700,6 +1879,22 @@ int bzk_gemv(hipStream_t s, const LinearDev& L, const Pro& pro, const GemvOut& o
     if (L.wdt == BZ_F16) LAUNCH_ROWS(BZ_F16); else if (L.wdt == BZ_BF16) LAUNCH_ROWS(BZ_BF16); else LAUNCH_ROWS(BZ_F32);
 #undef LAUNCH_ROWS
 #undef LAUNCH_ROWS1
+    BZ_HIP(hipGetLastError());
+    return BZ_OK;
+  }
+  if ((L.kind == LK_Q4K || L.kind == LK_Q6K) && bzk_gq_slim_ok(L, pro)) {
+    if (!out.acc) BZ_FAIL(BZ_E_INVALID, "block-quant gemv needs a fixed-point accumulator");
+    const int nsb = L.K / 256, ntg = (L.N / 64 + 7) / 8;
+    const char* label = L.kind == LK_Q4K ? "gemv_q4_K<slim>" : "gemv_q6_K<slim>";
+#define LAUNCH_GQS(FMT, MODE, FIX, NJ) BZ_LAUNCH(label, L.algo_bytes, (k_gemv_gq_slim<FMT, MODE, FIX, NJ>), dim3(nsb * ntg), dim3(512), 0, s, (const uint4*)L.w, \
+    (const uint2*)L.zeros, (const uint4*)L.hdr, (const __half*)L.scales, L.bias, L.N, L.K, pro, out.acc, out.zero_buf, out.zero_n)
+#define LAUNCH_GQS_NJ(FMT, FIX) do { if (pro.mode == PRO_SILU) LAUNCH_GQS(FMT, PRO_SILU, FIX, 1); else if (L.K == 2048) LAUNCH_GQS(FMT, PRO_NORM, FIX, 1); \
+    else if (L.K == 4096) LAUNCH_GQS(FMT, PRO_NORM, FIX, 2); else LAUNCH_GQS(FMT, PRO_NORM, FIX, 4); } while (0)
+#define LAUNCH_GQS_F(FMT) do { if (pro.src.fix) LAUNCH_GQS_NJ(FMT, 1); else LAUNCH_GQS_NJ(FMT, 0); } while (0)
+    if (L.kind == LK_Q4K) LAUNCH_GQS_F(GQ_Q4K); else LAUNCH_GQS_F(GQ_Q6K);
+#undef LAUNCH_GQS_F
+#undef LAUNCH_GQS_NJ
+#undef LAUNCH_GQS
     BZ_HIP(hipGetLastError());
     return BZ_OK;
   }
