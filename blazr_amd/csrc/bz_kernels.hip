@@ -2610,6 +2610,159 @@ __global__ __launch_bounds__(NW * 64) void k_attn2(AttnArgs a, const uint4* __re
 #undef STAMP
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// attention decode, head_dim 128, F32 cache (GGUF models keep f32 activations and an f32 cache): k_attn2's structure and prologue
+// discipline -- 8 waves, lane = (row l >> 4, 8-element piece l & 15), in-register PV, online merge of 256-position chunks, dead waves
+// skipped -- with 32-byte row pieces and plain FMAs.  Replaces the one-thread-per-position kernel (14 us per layer on the Mistral shape).
+// grid = n_heads, 512 threads; not fused with o_proj.
+// ---------------------------------------------------------------------------------------------------------
+template <int PAGED>
+__global__ __launch_bounds__(512) void k_attn2f(AttnArgs a) {
+  constexpr int HD = 128, half = 64, NW = 8, PW = 256 / NW, NL = PW / 4, NTH = NW * 64;
+  __shared__ __attribute__((aligned(16))) float qf[HD], kf[HD], vf[HD];
+  __shared__ float wred[2 * NW];
+  __shared__ __attribute__((aligned(16))) float pout[NW * 128];
+  asm volatile("" :: "s"(a.zero_buf), "s"(a.zero_n), "s"(a.kv.k), "s"(a.kv.v), "s"(a.kv.cap), "s"(a.kv.layer_stride), "s"(a.layer), "s"(a.act),
+               "s"(a.interleaved), "s"(a.rope_cur), "s"(a.qkv.p), "s"(a.qkv.fix), "s"(a.nq), "s"(a.nkv), "s"(a.q_only), "s"(a.pos), "s"(a.out),
+               "s"(a.kv.bs), "s"(a.kv.n_kv));
+  const int rep = a.nq / a.nkv;
+  const int hq = blockIdx.x, kvh = hq / rep;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int piece = lane & 15, rsub = lane >> 4;
+  const KvView& kv = a.kv;
+  const int pos_v = a.pos[0];
+  const int slot_v = PAGED ? *(kv.slot ? kv.slot : a.pos) : 0;
+  const int fixq = a.q_only ? 0 : a.qkv.fix;
+  int i0, i1;
+  {
+    const int hh = tid / half, i = tid % half;
+    const int base = hh == 0 ? hq * HD : a.nq * HD + kvh * HD;
+    const int ia = a.interleaved ? 2 * i : i, ib = a.interleaved ? 2 * i + 1 : i + half;
+    const int vb = a.nq * HD + a.nkv * HD + kvh * HD + 2 * i;
+    i0 = hh < 2 ? base + ia : vb; i1 = hh < 2 ? base + ib : vb + 1;
+    if (a.q_only) { i0 = hq * HD + 2 * i; i1 = i0 + 1; }
+    if (hh > 2) { i0 = 0; i1 = 0; }
+  }
+  unsigned r0l, r0h, r1l, r1h;
+  vsrc_issue(a.qkv.p, fixq, i0, r0l, r0h);
+  vsrc_issue(a.qkv.p, fixq, i1, r1l, r1h);
+  const float* rc = a.q_only ? (const float*)a.qkv.p : a.rope_cur;
+  const float pc = rc[tid % half], ps = rc[half + tid % half];
+  if (a.zero_buf)
+    for (int i = blockIdx.x * NTH + tid; i < a.zero_n; i += a.nq * NTH) a.zero_buf[i] = 0;
+  const int pos = __builtin_amdgcn_readfirstlane(pos_v);
+  const int pmax = pos > 0 ? pos - 1 : 0;
+  const int len = a.q_only ? pos : pos + 1;
+  const float* kb0 = (const float*)kv.k + (size_t)a.layer * kv.layer_stride;
+  const float* vb0 = (const float*)kv.v + (size_t)a.layer * kv.layer_stride;
+  float4 kr[NL][2], vr[NL][2];
+#pragma unroll
+  for (int i = 0; i < NL; i++) { kr[i][0] = kr[i][1] = vr[i][0] = vr[i][1] = make_float4(0.f, 0.f, 0.f, 0.f); }
+  if (wave * PW < len) {
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+      const size_t off = kv_row_off_t<PAGED>(kv, 0, kvh, min(wave * PW + 4 * i + rsub, pmax)) + piece * 8;
+      kr[i][0] = *(const float4*)(kb0 + off); kr[i][1] = *(const float4*)(kb0 + off + 4);
+      vr[i][0] = *(const float4*)(vb0 + off); vr[i][1] = *(const float4*)(vb0 + off + 4);
+    }
+  }
+  const float px0 = vsrc_finish(fixq, r0l, r0h, a.act), px1 = vsrc_finish(fixq, r1l, r1h, a.act);
+  if (!a.q_only) {
+    if (tid < 2 * half) {
+      const int hh = tid / half, i = tid % half;
+      const int ia = a.interleaved ? 2 * i : i, ib = a.interleaved ? 2 * i + 1 : i + half;
+      float* dst = hh == 0 ? qf : kf;
+      dst[ia] = round_act(px0 * pc - px1 * ps, a.act);
+      dst[ib] = round_act(px1 * pc + px0 * ps, a.act);
+    } else if (tid < 2 * half + 64) {
+      vf[2 * (tid - 2 * half)] = px0; vf[2 * (tid - 2 * half) + 1] = px1;
+    }
+    __syncthreads();
+    if (hq % rep == 0 && tid < HD) {     // KV append, once per kv head
+      size_t woff;
+      if (PAGED) woff = kv_slot_off(kv, a.layer, kvh, kv.slot ? slot_v : (kv.block_table[pos / kv.bs] * kv.bs + pos % kv.bs));
+      else woff = kv_row_off_t<0>(kv, a.layer, kvh, pos);
+      ((float*)kv.k)[woff + tid] = kf[tid];
+      ((float*)kv.v)[woff + tid] = vf[tid];
+    }
+  } else {
+    if (tid < 64) { qf[2 * tid] = px0; qf[2 * tid + 1] = px1; }
+    __syncthreads();
+  }
+  const float scale = 1.0f / sqrtf((float)HD);
+  const float4 qa = *(const float4*)(qf + piece * 8), qb = *(const float4*)(qf + piece * 8 + 4);
+  float Mrun = -INFINITY, Lrun = 0.f, Orun = 0.f;   // running state (threads < 128 own output d = tid)
+  for (int c0 = 0; c0 < len; c0 += 256) {
+    const bool won = c0 + wave * PW < len;
+    if (c0 > 0) {
+      __syncthreads();
+      if (won) {
+#pragma unroll
+        for (int i = 0; i < NL; i++) {
+          const size_t off = kv_row_off_t<PAGED>(kv, 0, kvh, min(c0 + wave * PW + 4 * i + rsub, pmax)) + piece * 8;
+          kr[i][0] = *(const float4*)(kb0 + off); kr[i][1] = *(const float4*)(kb0 + off + 4);
+          vr[i][0] = *(const float4*)(vb0 + off); vr[i][1] = *(const float4*)(vb0 + off + 4);
+        }
+      }
+    }
+    float sc_[NL];
+    float mloc = -INFINITY;
+    if (won) {
+#pragma unroll
+      for (int i = 0; i < NL; i++) {
+        const int p = c0 + wave * PW + 4 * i + rsub;
+        float4 k0 = kr[i][0], k1 = kr[i][1];
+        if (!a.q_only && p == pos) {
+          k0 = *(const float4*)(kf + piece * 8); k1 = *(const float4*)(kf + piece * 8 + 4);
+          vr[i][0] = *(const float4*)(vf + piece * 8); vr[i][1] = *(const float4*)(vf + piece * 8 + 4);
+        }
+        float d = k0.x * qa.x + k0.y * qa.y + k0.z * qa.z + k0.w * qa.w + k1.x * qb.x + k1.y * qb.y + k1.z * qb.z + k1.w * qb.w;
+        d = grp_reduce<16, OpAdd>(d);
+        sc_[i] = (p < len) ? d * scale : -INFINITY;
+        mloc = fmaxf(mloc, sc_[i]);
+      }
+      mloc = wave_max(mloc);
+    }
+    if (lane == 0) wred[wave] = mloc;
+    __syncthreads();
+    float Mc = wred[0];
+#pragma unroll
+    for (int w = 1; w < NW; w++) Mc = fmaxf(Mc, wred[w]);
+    float accv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float lsum = 0.f;
+    if (won) {
+#pragma unroll
+      for (int i = 0; i < NL; i++) {
+        const float e = (sc_[i] == -INFINITY) ? 0.f : expf(sc_[i] - Mc);
+        lsum += e;
+        accv[0] = fmaf(e, vr[i][0].x, accv[0]); accv[1] = fmaf(e, vr[i][0].y, accv[1]); accv[2] = fmaf(e, vr[i][0].z, accv[2]); accv[3] = fmaf(e, vr[i][0].w, accv[3]);
+        accv[4] = fmaf(e, vr[i][1].x, accv[4]); accv[5] = fmaf(e, vr[i][1].y, accv[5]); accv[6] = fmaf(e, vr[i][1].z, accv[6]); accv[7] = fmaf(e, vr[i][1].w, accv[7]);
+      }
+      lsum = xrow32<OpAdd>(xrow16<OpAdd>(lsum));
+#pragma unroll
+      for (int q = 0; q < 8; q++) accv[q] = xrow32<OpAdd>(xrow16<OpAdd>(accv[q]));
+    }
+    if (lane < 16) {
+      *(float4*)(pout + wave * 128 + piece * 8) = make_float4(accv[0], accv[1], accv[2], accv[3]);
+      *(float4*)(pout + wave * 128 + piece * 8 + 4) = make_float4(accv[4], accv[5], accv[6], accv[7]);
+    }
+    if (lane == 0) wred[NW + wave] = lsum;
+    __syncthreads();
+    if (tid < 128) {
+      float oc = 0.f, Lc = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; w += 2) { oc += pout[w * 128 + tid] + pout[(w + 1) * 128 + tid]; Lc += wred[NW + w] + wred[NW + w + 1]; }
+      const float Mn = fmaxf(Mrun, Mc);
+      const float fa = (Mrun == -INFINITY) ? 0.f : expf(Mrun - Mn), fb = expf(Mc - Mn);
+      Orun = Orun * fa + oc * fb;
+      Lrun = Lrun * fa + Lc * fb;
+      Mrun = Mn;
+    }
+  }
+  if (tid < 128) a.out[(size_t)hq * HD + tid] = round_act(Orun / Lrun, a.act);
+}
+
 static size_t attn2_smem(int nw) { return (size_t)(64 * 3 + 2 * nw + nw * 128 + 128 + 96 + 8) * 4; }
 
 // picks the column-slice count so that nq * CS ~ 256 workgroups, and the wave count (8 waves halve the per-wave attention chain);
@@ -2999,6 +3152,10 @@ int bzk_attn_decode(hipStream_t s, const AttnArgs& a) {
     if (a.kv.dtype == BZ_F16) { if (a.kv.paged) LAUNCH_A2(BZ_F16, 1); else LAUNCH_A2(BZ_F16, 0); }
     else { if (a.kv.paged) LAUNCH_A2(BZ_BF16, 1); else LAUNCH_A2(BZ_BF16, 0); }
 #undef LAUNCH_A2
+  }
+  else if (a.hd == 128 && a.kv.dtype == BZ_F32 && a.rope_cur != nullptr && getenv("BZ_NO_ATTN_F32") == nullptr) {
+    if (a.kv.paged) BZ_LAUNCH("attn_decode", 0.0, k_attn2f<1>, dim3(a.nq), dim3(512), 0, s, a);
+    else BZ_LAUNCH("attn_decode", 0.0, k_attn2f<0>, dim3(a.nq), dim3(512), 0, s, a);
   }
   else if (a.hd == 64) LAUNCH_ATT_DT(64);
   else if (a.hd == 128) LAUNCH_ATT_DT(128);

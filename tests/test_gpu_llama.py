@@ -461,3 +461,30 @@ def test_split_attention_generate_modes_agree(device, split_min, case, mode):
     got = ex.generate(p, 40, use_graph="graph" in mode, paged="paged" in mode)
     # both paths are deterministic; they differ only in fp32 summation order inside attention, so ids agree wherever the top-2 gap is not a tie
     assert got[:k].tolist() == base[:k].tolist(), (mode, got.tolist(), base.tolist(), k)
+
+
+@pytest.mark.parametrize("over", [dict(n_heads=4, n_kv_heads=2, head_dim=128), dict(n_heads=4, n_kv_heads=4, head_dim=128), dict(n_heads=8, n_kv_heads=1, head_dim=128)],
+                         ids=["rep2", "rep1", "rep8"])
+def test_f32_cache_head_dim_128_attention(device, over):
+    """GGUF models keep f32 activations and an f32 cache; head_dim 128 takes k_attn2f (the Mistral shape).  Prompt token by token across the
+    256-position chunk boundary against the oracle, then graph / paged generation against the eager ids."""
+    model = synth.make_llama("tiny-q8_0", max_seq_len=512, **over)
+    cfg = model["config"]
+    lm = runtime.LoadedModel.from_synth(device, model)
+    om = orc_py.OrcLlama(model)
+    n = 270
+    p = synth.prompt_tokens(n, cfg["vocab"], seed=31)
+    kv = runtime.LayeredKvCache(device, cfg["n_layers"], 1, cfg["n_kv_heads"], 8, cfg["max_seq_len"], cfg["head_dim"], L.F32)
+    okv = om.new_kv(512)
+    want = om.forward_kv(p, okv, 0, all_logits=True)
+    for i in range(n):
+        lg = lm.forward_with_kv_cache([int(p[i])], kv, i)
+        if i in (0, 1, 17, 255, 256, 257, n - 1):
+            _check_logits(lg.to_numpy()[0], want[i], "f32")
+    orc_py.lib().orc_kv_free(okv)
+    ex = runtime.Executor(lm)
+    q = synth.prompt_tokens(7, cfg["vocab"], seed=4)
+    base = ex.generate(q, 20)
+    for mode in ("graph", "paged", "paged-graph"):
+        got = ex.generate(q, 20, use_graph="graph" in mode, paged="paged" in mode)
+        assert got.tolist() == base.tolist(), mode
