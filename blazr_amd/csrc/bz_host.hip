@@ -39,6 +39,7 @@ size_t bz_dtype_size(int dt) {
 // device
 // ---------------------------------------------------------------------------------------------------------
 extern "C" int bz_device_open(int id, bz_device** out) {
+  BZ_API_BEGIN
   if (!out) BZ_FAIL(BZ_E_INVALID, "bz_device_open: out is null");
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
@@ -60,6 +61,7 @@ extern "C" int bz_device_open(int id, bz_device** out) {
   BZ_HIP(hipMalloc((void**)&d->scratch, 4096));
   *out = d;
   return BZ_OK;
+  BZ_API_END
 }
 // The device handle is reference counted: children (tensors, models, caches, graphs) keep it alive, so that a host
 // language whose destructors run in arbitrary order (GC) cannot free a child against a destroyed stream.
@@ -77,28 +79,36 @@ void bz_dev_release(bz_device* d) {
   delete d;
 }
 extern "C" int bz_device_close(bz_device* d) {
+  BZ_API_BEGIN
   if (!d) return BZ_OK;
   hipSetDevice(d->id);
   hipStreamSynchronize(d->stream);
   bz_dev_release(d);
   return BZ_OK;
+  BZ_API_END
 }
 extern "C" int bz_device_synchronize(bz_device* d) {
+  BZ_API_BEGIN
   if (!d) BZ_FAIL(BZ_E_INVALID, "null device");
   BZ_HIP(hipStreamSynchronize(d->stream));
   BZ_HIP(hipStreamSynchronize(d->copy_stream));
   return BZ_OK;
+  BZ_API_END
 }
 extern "C" int bz_device_memory_info(bz_device* d, size_t* f, size_t* t) {
+  BZ_API_BEGIN
   if (!d) BZ_FAIL(BZ_E_INVALID, "null device");
   BZ_HIP(hipSetDevice(d->id));
   BZ_HIP(hipMemGetInfo(f, t));
   return BZ_OK;
+  BZ_API_END
 }
 extern "C" int bz_device_name(bz_device* d, char* buf, size_t n) {
+  BZ_API_BEGIN
   if (!d || !buf) BZ_FAIL(BZ_E_INVALID, "null argument");
   snprintf(buf, n, "%s (%s, %d CUs)", d->prop.name, d->prop.gcnArchName, d->prop.multiProcessorCount);
   return BZ_OK;
+  BZ_API_END
 }
 extern "C" void* bz_device_stream(bz_device* d) { return d ? (void*)d->stream : nullptr; }
 
@@ -130,45 +140,58 @@ static int tensor_alloc(bz_device* dev, int dtype, const int64_t* shape, int ndi
   return BZ_OK;
 }
 extern "C" int bz_tensor_from_host(bz_device* dev, int dtype, const int64_t* shape, int ndim, const void* host, bz_tensor** out) {
+  BZ_API_BEGIN
   BZ_TRY(tensor_alloc(dev, dtype, shape, ndim, out));
   if ((*out)->nbytes && host) {
     BZ_HIP(hipMemcpyAsync((*out)->ptr, host, (*out)->nbytes, hipMemcpyHostToDevice, dev->stream));
     BZ_HIP(hipStreamSynchronize(dev->stream));
   }
   return BZ_OK;
+  BZ_API_END
 }
 extern "C" int bz_tensor_zeros(bz_device* dev, int dtype, const int64_t* shape, int ndim, bz_tensor** out) {
+  BZ_API_BEGIN
   BZ_TRY(tensor_alloc(dev, dtype, shape, ndim, out));
   if ((*out)->nbytes) BZ_HIP(hipMemsetAsync((*out)->ptr, 0, (*out)->nbytes, dev->stream));
   return BZ_OK;
+  BZ_API_END
 }
 extern "C" int bz_tensor_free(bz_tensor* t) {
+  BZ_API_BEGIN
   if (!t) return BZ_OK;
   if (t->owned && t->ptr) { hipStreamSynchronize(t->dev->stream); hipFree(t->ptr); }
   bz_dev_release(t->dev);
   delete t;
   return BZ_OK;
+  BZ_API_END
 }
 extern "C" int bz_tensor_nbytes(const bz_tensor* t, size_t* out) {
+  BZ_API_BEGIN
   if (!t || !out) BZ_FAIL(BZ_E_INVALID, "null argument");
   *out = t->nbytes;
   return BZ_OK;
+  BZ_API_END
 }
 extern "C" int bz_tensor_to_host(const bz_tensor* t, void* host, size_t bytes) {
+  BZ_API_BEGIN
   if (!t || !host) BZ_FAIL(BZ_E_INVALID, "null argument");
   if (bytes > t->nbytes) BZ_FAIL(BZ_E_INVALID, "to_host: %zu bytes requested, tensor holds %zu", bytes, t->nbytes);
   BZ_HIP(hipMemcpyAsync(host, t->ptr, bytes, hipMemcpyDeviceToHost, t->dev->stream));
   BZ_HIP(hipStreamSynchronize(t->dev->stream));
   return BZ_OK;
+  BZ_API_END
 }
 extern "C" int bz_tensor_copy_from_host(bz_tensor* t, const void* host, size_t bytes) {
+  BZ_API_BEGIN
   if (!t || !host) BZ_FAIL(BZ_E_INVALID, "null argument");
   if (bytes > t->nbytes) BZ_FAIL(BZ_E_INVALID, "copy_from_host: %zu bytes given, tensor holds %zu", bytes, t->nbytes);
   BZ_HIP(hipMemcpyAsync(t->ptr, host, bytes, hipMemcpyHostToDevice, t->dev->stream));
   BZ_HIP(hipStreamSynchronize(t->dev->stream));
   return BZ_OK;
+  BZ_API_END
 }
 extern "C" int bz_event_record(bz_device* d, uint64_t* out) {
+  BZ_API_BEGIN
   if (!d || !out) BZ_FAIL(BZ_E_INVALID, "null argument");
   std::lock_guard<std::mutex> dlock__(d->mu);
   // small ring of reusable events (a recycled id still orders after the work it was first recorded behind: waiting on it is conservative)
@@ -182,15 +205,19 @@ extern "C" int bz_event_record(bz_device* d, uint64_t* out) {
   BZ_HIP(hipEventRecord(d->events[id], d->stream));
   *out = id;
   return BZ_OK;
+  BZ_API_END
 }
 extern "C" int bz_event_sync(bz_device* d, uint64_t ev) {
+  BZ_API_BEGIN
   if (!d) BZ_FAIL(BZ_E_INVALID, "bad event");
   hipEvent_t e;
   { std::lock_guard<std::mutex> dlock__(d->mu); if (ev >= d->events.size()) BZ_FAIL(BZ_E_INVALID, "bad event"); e = d->events[ev]; }
   BZ_HIP(hipEventSynchronize(e));
   return BZ_OK;
+  BZ_API_END
 }
 extern "C" int bz_tensor_to_host_pipelined(const bz_tensor* t, uint64_t ev, void* host, size_t bytes) {
+  BZ_API_BEGIN
   if (!t || !host) BZ_FAIL(BZ_E_INVALID, "bad argument");
   if (bytes > t->nbytes) BZ_FAIL(BZ_E_INVALID, "to_host_pipelined: size");
   bz_device* d = t->dev;
@@ -201,6 +228,7 @@ extern "C" int bz_tensor_to_host_pipelined(const bz_tensor* t, uint64_t ev, void
   BZ_HIP(hipMemcpyAsync(host, t->ptr, bytes, hipMemcpyDeviceToHost, d->copy_stream));
   BZ_HIP(hipStreamSynchronize(d->copy_stream));
   return BZ_OK;
+  BZ_API_END
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -303,6 +331,7 @@ static int upload(bz_device* d, void** out, const void* host, size_t bytes) {
 }
 
 extern "C" int bz_model_create(bz_device* dev, const bz_model_config* cfg, bz_model** out) {
+  BZ_API_BEGIN
   if (!dev || !cfg || !out) BZ_FAIL(BZ_E_INVALID, "bz_model_create: null argument");
   if (cfg->abi_version != BZ_ABI_VERSION) BZ_FAIL(BZ_E_INVALID, "config abi_version %d != %d", cfg->abi_version, BZ_ABI_VERSION);
   if (cfg->arch != BZ_ARCH_LLAMA && cfg->arch != BZ_ARCH_MAMBA2 && cfg->arch != BZ_ARCH_DEEPSEEK2) BZ_FAIL(BZ_E_UNSUPPORTED, "arch %d is not implemented", cfg->arch);
@@ -340,6 +369,7 @@ extern "C" int bz_model_create(bz_device* dev, const bz_model_config* cfg, bz_mo
   bz_dev_retain(dev);
   *out = m;
   return BZ_OK;
+  BZ_API_END
 }
 
 static void raw_free(RawTensor& r) {
@@ -351,6 +381,7 @@ static void raw_free(RawTensor& r) {
 }
 
 extern "C" int bz_model_free(bz_model* m) {
+  BZ_API_BEGIN
   if (!m) return BZ_OK;
   hipSetDevice(m->dev->id);
   hipStreamSynchronize(m->dev->stream);
@@ -359,6 +390,7 @@ extern "C" int bz_model_free(bz_model* m) {
   bz_dev_release(m->dev);
   delete m;
   return BZ_OK;
+  BZ_API_END
 }
 
 static int check_add(bz_model* m, const char* name) {
@@ -370,6 +402,7 @@ static int check_add(bz_model* m, const char* name) {
 }
 
 extern "C" int bz_model_add_dense(bz_model* m, const char* name, int dtype, const int64_t* shape, int ndim, const void* host) {
+  BZ_API_BEGIN
   BZ_TRY(check_add(m, name));
   if (!host || ndim < 1 || ndim > 3) BZ_FAIL(BZ_E_INVALID, "add_dense '%s': need 1-D .. 3-D host data", name);
   if (dtype != BZ_F32 && dtype != BZ_F16 && dtype != BZ_BF16) BZ_FAIL(BZ_E_INVALID, "add_dense '%s': dtype %d", name, dtype);
@@ -381,10 +414,12 @@ extern "C" int bz_model_add_dense(bz_model* m, const char* name, int dtype, cons
   BZ_TRY(upload(m->dev, &r.d0, host, r.bytes));
   m->raw[name] = r;
   return BZ_OK;
+  BZ_API_END
 }
 
 extern "C" int bz_model_add_awq(bz_model* m, const char* name, int64_t N, int64_t K, const uint32_t* qweight, const float* scales,
                                 const float* zeros, int gs) {
+  BZ_API_BEGIN
   BZ_TRY(check_add(m, name));
   if (!qweight || !scales || !zeros) BZ_FAIL(BZ_E_INVALID, "add_awq '%s': null data", name);
   if (gs != 128) BZ_FAIL(BZ_E_UNSUPPORTED, "add_awq '%s': group_size %d (only 128 is implemented)", name, gs);
@@ -404,10 +439,12 @@ extern "C" int bz_model_add_awq(bz_model* m, const char* name, int64_t N, int64_
   BZ_TRY(upload(m->dev, &r.d2, zeros, G * N * 4));
   m->raw[name] = r;
   return BZ_OK;
+  BZ_API_END
 }
 
 extern "C" int bz_model_add_gptq(bz_model* m, const char* name, int64_t N, int64_t K, const uint32_t* qweight, const float* scales,
                                  const uint32_t* qzeros, const int32_t* g_idx, const float* bias, int gs) {
+  BZ_API_BEGIN
   BZ_TRY(check_add(m, name));
   if (!qweight || !scales || !qzeros) BZ_FAIL(BZ_E_INVALID, "add_gptq '%s': null data", name);
   if (gs != 128) BZ_FAIL(BZ_E_UNSUPPORTED, "add_gptq '%s': group_size %d (only 128 is implemented)", name, gs);
@@ -431,9 +468,11 @@ extern "C" int bz_model_add_gptq(bz_model* m, const char* name, int64_t N, int64
   if (bias) { void* b; BZ_TRY(upload(m->dev, &b, bias, (size_t)N * 4)); r.d_bias = (float*)b; }
   m->raw[name] = r;
   return BZ_OK;
+  BZ_API_END
 }
 
 extern "C" int bz_model_add_gguf(bz_model* m, const char* name, int ggml_type, int64_t N, int64_t K, const void* blocks) {
+  BZ_API_BEGIN
   BZ_TRY(check_add(m, name));
   if (!blocks) BZ_FAIL(BZ_E_INVALID, "add_gguf '%s': null data", name);
   if (ggml_type == BZ_GGML_F32 || ggml_type == BZ_GGML_F16 || ggml_type == BZ_GGML_BF16) {
@@ -452,6 +491,7 @@ extern "C" int bz_model_add_gguf(bz_model* m, const char* name, int ggml_type, i
   BZ_TRY(upload(m->dev, &r.d0, blocks, r.bytes));
   m->raw[name] = r;
   return BZ_OK;
+  BZ_API_END
 }
 
 // --- finalize helpers ---------------------------------------------------------------------------------------
@@ -735,6 +775,7 @@ static int finalize_mamba2(bz_model* m);
 static int finalize_dsv2(bz_model* m);
 
 extern "C" int bz_model_finalize(bz_model* m) {
+  BZ_API_BEGIN
   if (!m) BZ_FAIL(BZ_E_INVALID, "null model");
   if (m->finalized) BZ_FAIL(BZ_E_INVALID, "model already finalized");
   BZ_HIP(hipSetDevice(m->dev->id));
@@ -819,25 +860,32 @@ extern "C" int bz_model_finalize(bz_model* m) {
   BZ_HIP(hipDeviceSynchronize());   // null-stream memsets above vs. the non-blocking compute stream
   m->finalized = true;
   return BZ_OK;
+  BZ_API_END
 }
 
 extern "C" int bz_model_get_config(const bz_model* m, bz_model_config* out) {
+  BZ_API_BEGIN
   if (!m || !out) BZ_FAIL(BZ_E_INVALID, "null argument");
   *out = m->cfg;
   return BZ_OK;
+  BZ_API_END
 }
 extern "C" int bz_model_weight_bytes(const bz_model* m, size_t* resident, size_t* per_token) {
+  BZ_API_BEGIN
   if (!m || !m->finalized) BZ_FAIL(BZ_E_INVALID, "model not finalized");
   if (resident) *resident = m->resident;
   if (per_token) *per_token = m->per_token;
   return BZ_OK;
+  BZ_API_END
 }
 extern "C" int bz_rope_caches(bz_model* m, float* c, float* s) {
+  BZ_API_BEGIN
   if (!m || !m->finalized) BZ_FAIL(BZ_E_INVALID, "model not finalized");
   size_t n = (size_t)m->cfg.max_seq_len * (m->cfg.head_dim / 2) * 4;
   if (c) BZ_HIP(hipMemcpy(c, m->cos_t, n, hipMemcpyDeviceToHost));
   if (s) BZ_HIP(hipMemcpy(s, m->sin_t, n, hipMemcpyDeviceToHost));
   return BZ_OK;
+  BZ_API_END
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1070,6 +1118,7 @@ static int finalize_mamba2(bz_model* m) {
 }
 
 extern "C" int bz_ssm_state_create(bz_model* m, int batch, int dtype, bz_ssm_state** out) {
+  BZ_API_BEGIN
   if (!m || !m->finalized || m->cfg.arch != BZ_ARCH_MAMBA2 || !out) BZ_FAIL(BZ_E_INVALID, "ssm_state_create: needs a finalized mamba2 model");
   if (batch != 1) BZ_FAIL(BZ_E_UNSUPPORTED, "ssm state: batch %d (single-stream decode only)", batch);
   if (dtype != BZ_F32 && dtype != BZ_F16 && dtype != BZ_BF16) BZ_FAIL(BZ_E_INVALID, "ssm state: dtype %d", dtype);
@@ -1087,28 +1136,34 @@ extern "C" int bz_ssm_state_create(bz_model* m, int batch, int dtype, bz_ssm_sta
   bz_dev_retain(m->dev);
   *out = s;
   return BZ_OK;
+  BZ_API_END
 }
 extern "C" int bz_ssm_state_free(bz_ssm_state* s) {
+  BZ_API_BEGIN
   if (!s) return BZ_OK;
   hipStreamSynchronize(s->dev->stream);
   hipFree(s->ssm); hipFree(s->conv);
   bz_dev_release(s->dev);
   delete s;
   return BZ_OK;
+  BZ_API_END
 }
 extern "C" int bz_ssm_state_reset(bz_ssm_state* s) {
+  BZ_API_BEGIN
   if (!s) BZ_FAIL(BZ_E_INVALID, "null state");
   const size_t sb = (size_t)s->layers * s->n_heads * s->head_dim * s->d_state * bz_dtype_size(s->dtype);
   const size_t cb = (size_t)s->layers * s->conv_dim * (s->kc - 1) * 4;
   BZ_HIP(hipMemsetAsync(s->ssm, 0, sb, s->dev->stream));
   BZ_HIP(hipMemsetAsync(s->conv, 0, cb, s->dev->stream));
   return BZ_OK;
+  BZ_API_END
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // KV caches
 // ---------------------------------------------------------------------------------------------------------
 extern "C" int bz_kv_create(bz_device* dev, int layers, int batch, int n_kv, int init_cap, int max_len, int hd, int dtype, bz_kv** out) {
+  BZ_API_BEGIN
   if (!dev || !out) BZ_FAIL(BZ_E_INVALID, "null argument");
   if (batch != 1) BZ_FAIL(BZ_E_UNSUPPORTED, "kv cache: batch %d (single-stream decode only)", batch);
   if (layers <= 0 || n_kv <= 0 || init_cap <= 0 || max_len < init_cap || hd <= 0) BZ_FAIL(BZ_E_INVALID, "kv cache: bad dimensions");
@@ -1123,14 +1178,17 @@ extern "C" int bz_kv_create(bz_device* dev, int layers, int batch, int n_kv, int
   bz_dev_retain(dev);
   *out = kv;
   return BZ_OK;
+  BZ_API_END
 }
 extern "C" int bz_kv_free(bz_kv* kv) {
+  BZ_API_BEGIN
   if (!kv) return BZ_OK;
   hipStreamSynchronize(kv->dev->stream);
   hipFree(kv->k); hipFree(kv->v);
   bz_dev_release(kv->dev);
   delete kv;
   return BZ_OK;
+  BZ_API_END
 }
 extern "C" int bz_kv_reset(bz_kv* kv) { if (!kv) BZ_FAIL(BZ_E_INVALID, "null kv"); kv->seq_len = 0; return BZ_OK; }
 extern "C" int bz_kv_seq_len(const bz_kv* kv) { return kv ? kv->seq_len : -1; }
@@ -1171,6 +1229,7 @@ static KvView view_of(const bz_paged_kv* kv, const int* block_table, const int* 
 }
 
 extern "C" int bz_kv_read(const bz_kv* kv, int layer, int kvh, int which, int len, float* host) {
+  BZ_API_BEGIN
   if (!kv || !host || layer < 0 || layer >= kv->layers || kvh < 0 || kvh >= kv->n_kv || len < 0 || len > kv->cap) BZ_FAIL(BZ_E_INVALID, "kv_read: bad argument");
   float* d;
   BZ_HIP(hipMalloc(&d, std::max<size_t>((size_t)len * kv->hd * 4, 16)));
@@ -1178,9 +1237,11 @@ extern "C" int bz_kv_read(const bz_kv* kv, int layer, int kvh, int which, int le
   if (rc == BZ_OK) { hipMemcpyAsync(host, d, (size_t)len * kv->hd * 4, hipMemcpyDeviceToHost, kv->dev->stream); hipStreamSynchronize(kv->dev->stream); }
   hipFree(d);
   return rc;
+  BZ_API_END
 }
 
 extern "C" int bz_paged_kv_create(bz_device* dev, int layers, int num_blocks, int block_size, int n_kv, int hd, int dtype, bz_paged_kv** out) {
+  BZ_API_BEGIN
   if (!dev || !out) BZ_FAIL(BZ_E_INVALID, "null argument");
   if (layers <= 0 || num_blocks <= 0 || block_size <= 0 || n_kv <= 0 || hd <= 0) BZ_FAIL(BZ_E_INVALID, "paged kv: bad dimensions");
   if (dtype != BZ_F16 && dtype != BZ_BF16 && dtype != BZ_F32) BZ_FAIL(BZ_E_INVALID, "paged kv: dtype %d", dtype);
@@ -1194,14 +1255,17 @@ extern "C" int bz_paged_kv_create(bz_device* dev, int layers, int num_blocks, in
   bz_dev_retain(dev);
   *out = kv;
   return BZ_OK;
+  BZ_API_END
 }
 extern "C" int bz_paged_kv_free(bz_paged_kv* kv) {
+  BZ_API_BEGIN
   if (!kv) return BZ_OK;
   hipStreamSynchronize(kv->dev->stream);
   hipFree(kv->k); hipFree(kv->v);
   bz_dev_release(kv->dev);
   delete kv;
   return BZ_OK;
+  BZ_API_END
 }
 extern "C" int bz_paged_kv_set_seq_len(bz_paged_kv* kv, int n) { if (!kv || n < 0) BZ_FAIL(BZ_E_INVALID, "bad argument"); kv->seq_len = n; return BZ_OK; }
 extern "C" int bz_paged_kv_seq_len(const bz_paged_kv* kv) { return kv ? kv->seq_len : -1; }
@@ -1612,15 +1676,19 @@ static int prefill_dense(bz_model* m, const long long* d_tok, int S, const KvVie
   BZ_TRY(prefill_ws(m, std::min(S, CH)));
   for (int s0 = 0; s0 < S; s0 += CH) {
     const int n = std::min(CH, S - s0), p0 = pos0 + s0;
+    // decode batch (row_pos set): one block-table row per sequence -- the kernels index rows by the row number INSIDE the chunk, so the chunk
+    // starting at sequence s0 gets the table advanced to its first row (sequences >= 512 read another sequence's blocks)
+    KvView vw = view;
+    if (rc.row_pos && vw.block_table) vw.block_table = view.block_table + (size_t)s0 * rc.table_stride;
     BZ_TRY(bzk_pf_embed(st, m->embed, m->embed_dt, d_tok + s0, n, H, act, m->pf_h));
     const float* prev = nullptr;
     for (int l = 0; l < c.n_layers; l++) {
       const LayerDev& L = m->layers[l];
       BZ_TRY(bzk_pf_norm(st, dt, m->pf_h, prev, L.attn_norm, n, H, c.rms_eps, act, m->pf_x16));
       BZ_TRY(pf_gemm(m, L.qkv.parts[0], m->pf_x16, n, m->pf_qkv));
-      BZ_TRY(bzk_pf_rope_kv(st, m->pf_qkv, n, nq, nkv, hd, m->cos_t, m->sin_t, c.rope_interleaved, p0, act, view, l, slots ? slots + s0 : nullptr,
+      BZ_TRY(bzk_pf_rope_kv(st, m->pf_qkv, n, nq, nkv, hd, m->cos_t, m->sin_t, c.rope_interleaved, p0, act, vw, l, slots ? slots + s0 : nullptr,
                             rc.row_pos ? rc.row_pos + s0 : nullptr));
-      BZ_TRY(bzk_pf_attn(st, dt, m->pf_qkv, n, nq, nkv, hd, p0, act, view, l, m->pf_x16, rc.row_pos ? rc.row_pos + s0 : nullptr, rc.table_stride, rc.max_len));
+      BZ_TRY(bzk_pf_attn(st, dt, m->pf_qkv, n, nq, nkv, hd, p0, act, vw, l, m->pf_x16, rc.row_pos ? rc.row_pos + s0 : nullptr, rc.table_stride, rc.max_len));
       BZ_TRY(pf_gemm(m, L.o.parts[0], m->pf_x16, n, m->pf_t));
       BZ_TRY(bzk_pf_norm(st, dt, m->pf_h, m->pf_t, L.ffn_norm, n, H, c.rms_eps, act, m->pf_x16));
       BZ_TRY(pf_gemm(m, L.gateup.parts[0], m->pf_x16, n, m->pf_gu));
@@ -1652,6 +1720,7 @@ static int prefill_dense(bz_model* m, const long long* d_tok, int S, const KvVie
 
 // op-level: y[S,N] = x16[S,K] . W[N,K]^T on the matrix cores, x rounded to the weight dtype first, f32 accumulators returned unrounded
 extern "C" int bz_prefill_matmul(bz_model* m, const char* name, const bz_tensor* x, int S, bz_tensor* y) {
+  BZ_API_BEGIN
   LinearDev L;
   BZ_TRY(find_linear(m, name, &L));
   std::lock_guard<std::recursive_mutex> lock__(m->mu);
@@ -1670,9 +1739,11 @@ extern "C" int bz_prefill_matmul(bz_model* m, const char* name, const bz_tensor*
   hipStreamSynchronize(st);
   hipFree(x16);
   return rc;
+  BZ_API_END
 }
 
 extern "C" int bz_forward_kv(bz_model* m, const bz_tensor* tokens, int S, bz_kv* kv, int position, bz_tensor* logits_out, uint32_t flags) {
+  BZ_API_BEGIN
   BZ_TRY(check_fwd(m, tokens, S));
   std::lock_guard<std::recursive_mutex> lock__(m->mu);
   BZ_TRACE("forward_kv: S=%d position=%d", S, position);
@@ -1699,10 +1770,12 @@ extern "C" int bz_forward_kv(bz_model* m, const bz_tensor* tokens, int S, bz_kv*
   }
   kv->seq_len = position + S;
   return BZ_OK;
+  BZ_API_END
 }
 
 extern "C" int bz_forward_paged(bz_model* m, const bz_tensor* tokens, int S, bz_paged_kv* kv, const bz_tensor* slot_mapping,
                                 const bz_tensor* block_table, int n_table, int seq_len_k, int start_pos, bz_tensor* logits_out, uint32_t flags) {
+  BZ_API_BEGIN
   BZ_TRY(check_fwd(m, tokens, S));
   std::lock_guard<std::recursive_mutex> lock__(m->mu);
   if (m->cfg.arch != BZ_ARCH_LLAMA) BZ_FAIL(BZ_E_UNSUPPORTED, "forward_paged: llama family only (Mamba2 has no KV cache; the MLA latent cache is contiguous in this build)");
@@ -1731,6 +1804,7 @@ extern "C" int bz_forward_paged(bz_model* m, const bz_tensor* tokens, int S, bz_
   }
   kv->seq_len = seq_len_k;
   return BZ_OK;
+  BZ_API_END
 }
 
 // Batched single-token decode over one paged cache (process_decode_batch, /root/reference/src/engine/batch_decode.rs:35-150): tokens [N,1],
@@ -1739,6 +1813,7 @@ extern "C" int bz_forward_paged(bz_model* m, const bz_tensor* tokens, int S, bz_
 // the others run the sequences one after another through the single-stream step.
 extern "C" int bz_forward_paged_batch(bz_model* m, const bz_tensor* tokens, int N, bz_paged_kv* kv, const bz_tensor* slot_mapping, const bz_tensor* block_table,
                                       int max_blocks, const int32_t* seq_lens, bz_tensor* logits_out) {
+  BZ_API_BEGIN
   BZ_TRY(check_fwd(m, tokens, N));
   std::lock_guard<std::recursive_mutex> lock__(m->mu);
   if (m->cfg.arch != BZ_ARCH_LLAMA) BZ_FAIL(BZ_E_UNSUPPORTED, "forward_paged_batch: llama family only");
@@ -1782,6 +1857,7 @@ extern "C" int bz_forward_paged_batch(bz_model* m, const bz_tensor* tokens, int 
   }
   if (kv->seq_len < maxlen) kv->seq_len = maxlen;
   return BZ_OK;
+  BZ_API_END
 }
 
 static int check_ssm(bz_model* m, bz_ssm_state* st) {
@@ -1863,6 +1939,7 @@ static int mamba_prefill(bz_model* m, const long long* d_tok, int S, bz_ssm_stat
 }
 
 extern "C" int bz_forward_ssm(bz_model* m, const bz_tensor* tokens, int S, bz_ssm_state* st, bz_tensor* logits_out, uint32_t flags) {
+  BZ_API_BEGIN
   BZ_TRY(check_fwd(m, tokens, S));
   std::lock_guard<std::recursive_mutex> lock__(m->mu);
   BZ_TRY(check_ssm(m, st));
@@ -1880,9 +1957,11 @@ extern "C" int bz_forward_ssm(bz_model* m, const bz_tensor* tokens, int S, bz_ss
     if (io.do_head) BZ_TRY(emit_logits(m, logits_out, all ? s : 0));
   }
   return BZ_OK;
+  BZ_API_END
 }
 
 extern "C" int bz_forward_embed(bz_model* m, const bz_tensor* tokens, int S, bz_tensor* hidden_out) {
+  BZ_API_BEGIN
   BZ_TRY(check_fwd(m, tokens, S));
   std::lock_guard<std::recursive_mutex> lock__(m->mu);
   const int H = m->cfg.hidden;
@@ -1890,9 +1969,11 @@ extern "C" int bz_forward_embed(bz_model* m, const bz_tensor* tokens, int S, bz_
   for (int s = 0; s < S; s++)
     BZ_TRY(bzk_embed(m->dev->stream, m->embed, m->embed_dt, (const long long*)tokens->ptr + s, H, m->cfg.act_dtype, (float*)hidden_out->ptr + (size_t)s * H));
   return BZ_OK;
+  BZ_API_END
 }
 
 extern "C" int bz_forward_layers_range(bz_model* m, bz_tensor* hidden, bz_tensor* prev_mlp, int* has_prev, int S, bz_kv* kv, int start, int end, int position) {
+  BZ_API_BEGIN
   if (!m || !m->finalized) BZ_FAIL(BZ_E_INVALID, "model not finalized");
   std::lock_guard<std::recursive_mutex> lock__(m->mu);
   if (m->cfg.arch != BZ_ARCH_LLAMA) BZ_FAIL(BZ_E_UNSUPPORTED, "layers_range: llama family only");
@@ -1919,9 +2000,11 @@ extern "C" int bz_forward_layers_range(bz_model* m, bz_tensor* hidden, bz_tensor
   *has_prev = 1;
   if (end == m->cfg.n_layers) kv->seq_len = position + S;
   return BZ_OK;
+  BZ_API_END
 }
 
 extern "C" int bz_forward_head(bz_model* m, const bz_tensor* hidden, const bz_tensor* prev_mlp, int has_prev, int S, bz_tensor* logits_out, uint32_t flags) {
+  BZ_API_BEGIN
   if (!m || !m->finalized) BZ_FAIL(BZ_E_INVALID, "model not finalized");
   std::lock_guard<std::recursive_mutex> lock__(m->mu);
   const int H = m->cfg.hidden;
@@ -1938,6 +2021,7 @@ extern "C" int bz_forward_head(bz_model* m, const bz_tensor* hidden, const bz_te
     BZ_TRY(emit_logits(m, logits_out, all ? s : 0));
   }
   return BZ_OK;
+  BZ_API_END
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1961,6 +2045,7 @@ static int profile_collect(BzTimingSink& sink, int rc, bz_kernel_time* out, int 
 }
 
 extern "C" int bz_profile_step(bz_model* m, bz_kv* kv, int64_t token, int position, int iters, bz_kernel_time* out, int max_out, int* n_out) {
+  BZ_API_BEGIN
   if (m && m->finalized && m->cfg.arch == BZ_ARCH_MAMBA2) BZ_FAIL(BZ_E_UNSUPPORTED, "profile_step: model has no KV cache (use bz_profile_step_ssm)");
   if (!m || !m->finalized || !kv || !out || !n_out || iters <= 0 || max_out <= 0) BZ_FAIL(BZ_E_INVALID, "profile_step: bad argument");
   std::lock_guard<std::recursive_mutex> lock__(m->mu);
@@ -1987,9 +2072,11 @@ extern "C" int bz_profile_step(bz_model* m, bz_kv* kv, int64_t token, int positi
   hipStreamSynchronize(st);
   if (kv->seq_len < position + iters) kv->seq_len = position + iters;
   return profile_collect(sink, rc, out, max_out, n_out);
+  BZ_API_END
 }
 
 extern "C" int bz_profile_step_ssm(bz_model* m, bz_ssm_state* ssm, int64_t token, int iters, bz_kernel_time* out, int max_out, int* n_out) {
+  BZ_API_BEGIN
   if (!m || !m->finalized || !out || !n_out || iters <= 0 || max_out <= 0) BZ_FAIL(BZ_E_INVALID, "profile_step_ssm: bad argument");
   std::lock_guard<std::recursive_mutex> lock__(m->mu);
   BZ_TRY(check_ssm(m, ssm));
@@ -2012,6 +2099,7 @@ extern "C" int bz_profile_step_ssm(bz_model* m, bz_ssm_state* ssm, int64_t token
   }
   hipStreamSynchronize(st);
   return profile_collect(sink, rc, out, max_out, n_out);
+  BZ_API_END
 }
 
 __global__ void k_fill_u32(uint32_t* p, size_t n, uint32_t seed) {
@@ -2025,6 +2113,7 @@ __global__ void k_fill_u32(uint32_t* p, size_t n, uint32_t seed) {
 // (so that every launch streams from HBM, not from the 256 MiB Infinity Cache).  mode: 0 plain f32 x, 1 fused
 // residual+RMSNorm prologue (fixed-point prev), 2 SiLU*up prologue (fixed-point gate/up).  Returns the mean dispatch time.
 extern "C" int bz_tune_gemv(bz_device* dev, int N, int K, int gw, int mode, int nbuf, int iters, int flags, double* avg_us) {
+  BZ_API_BEGIN
   if (!dev || !avg_us || N % 64 || K % 128 || gw <= 0 || (K / 128) % gw || gw > 16 || nbuf <= 0 || iters <= 0 || mode < 0 || mode > 2) BZ_FAIL(BZ_E_INVALID, "tune_gemv: bad argument");
   BZ_HIP(hipSetDevice(dev->id));
   hipStream_t st = dev->stream;
@@ -2068,6 +2157,57 @@ extern "C" int bz_tune_gemv(bz_device* dev, int N, int K, int gw, int mode, int 
   *avg_us = n ? 1e3 * tot / n : 0.0;
   for (void* q : bufs) hipFree(q);
   return rc;
+  BZ_API_END
+}
+
+// Measured HBM read ceiling of THIS device ("record the measured peak on the box and report against both"): a streaming read of
+// `bytes` (spread over rotating buffers far beyond the 256 MiB Infinity Cache) with 16-byte non-temporal loads, 8 KiB in flight per wave,
+// 256 x 512-thread workgroups -- the access pattern of the decode kernels without any arithmetic.  Best of `iters` launches, GB/s.
+typedef unsigned int bz_u32x4_t __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(512) void k_probe_read(const bz_u32x4_t* __restrict__ src, size_t per_wave_vec, unsigned* sink) {
+  const int wave = (blockIdx.x * 512 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  const bz_u32x4_t* p = src + (size_t)wave * per_wave_vec + lane;
+  bz_u32x4_t acc = {0, 0, 0, 0};
+  for (size_t i = 0; i < per_wave_vec; i += 64 * 8) {
+    bz_u32x4_t v[8];
+#pragma unroll
+    for (int d = 0; d < 8; d++) v[d] = __builtin_nontemporal_load(p + i + 64 * d);
+#pragma unroll
+    for (int d = 0; d < 8; d++) acc ^= v[d];
+  }
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[0] = 1;
+}
+extern "C" int bz_probe_hbm_read(bz_device* dev, size_t bytes, int iters, double* gbs) {
+  BZ_API_BEGIN
+  if (!dev || !gbs || iters <= 0 || bytes < (64u << 20)) BZ_FAIL(BZ_E_INVALID, "probe_hbm_read: bad argument (>= 64 MiB)");
+  BZ_HIP(hipSetDevice(dev->id));
+  hipStream_t st = dev->stream;
+  const int NBUF = 4, waves = 256 * 8;
+  const size_t per_wave_vec = bytes / 16 / waves / 512 * 512;
+  const size_t used = per_wave_vec * 16 * waves;
+  void* bufs[NBUF] = {nullptr, nullptr, nullptr, nullptr}; unsigned* sink = nullptr;
+  int rc = BZ_OK;
+  for (int b = 0; b < NBUF; b++) if (hipMalloc(&bufs[b], used) != hipSuccess) { rc = BZ_E_OOM; bufs[b] = nullptr; break; } else hipMemsetAsync(bufs[b], b + 1, used, st);
+  if (rc == BZ_OK && hipMalloc((void**)&sink, 64) != hipSuccess) rc = BZ_E_OOM;
+  double best = 0.0;
+  if (rc == BZ_OK) {
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < iters + 2; i++) {
+      hipEventRecord(e0, st);
+      hipLaunchKernelGGL(k_probe_read, dim3(256), dim3(512), 0, st, (const bz_u32x4_t*)bufs[i % NBUF], per_wave_vec, sink);
+      hipEventRecord(e1, st);
+      hipEventSynchronize(e1);
+      float ms = 0.f; hipEventElapsedTime(&ms, e0, e1);
+      if (i >= 2 && ms > 0.f) best = std::max(best, (double)used / 1e9 / (ms * 1e-3));
+    }
+    hipEventDestroy(e0); hipEventDestroy(e1);
+  }
+  for (int b = 0; b < NBUF; b++) if (bufs[b]) hipFree(bufs[b]);
+  if (sink) hipFree(sink);
+  if (rc != BZ_OK) BZ_FAIL(rc, "probe_hbm_read: out of device memory");
+  *gbs = best;
+  return BZ_OK;
+  BZ_API_END
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -2076,6 +2216,7 @@ extern "C" int bz_tune_gemv(bz_device* dev, int N, int K, int gw, int mode, int 
 extern "C" int bz_logits_to_token(bz_device* dev, const bz_tensor* logits, int64_t rows, int64_t vocab, const bz_tensor* ids, const bz_tensor* cnts,
                                   int n, float rp, float fp, float pp, float temperature, int top_k, float top_p, float min_p, uint64_t seed,
                                   bz_tensor* token_out) {
+  BZ_API_BEGIN
   if (!dev || !logits || !token_out || rows <= 0 || vocab <= 0) BZ_FAIL(BZ_E_INVALID, "logits_to_token: bad argument");
   if (logits->dtype != BZ_F32 || logits->nbytes < (size_t)rows * vocab * 4) BZ_FAIL(BZ_E_INVALID, "logits_to_token: logits must be F32 [rows,vocab]");
   if (token_out->dtype != BZ_I64 || token_out->nbytes < 8) BZ_FAIL(BZ_E_INVALID, "logits_to_token: token_out must be I64[1]");
@@ -2092,9 +2233,12 @@ extern "C" int bz_logits_to_token(bz_device* dev, const bz_tensor* logits, int64
                                n ? (const int*)cnts->ptr : nullptr, n, rp, fp, pp, temperature, top_k, top_p, min_p, seed, scratch,
                                (long long*)token_out->ptr);
   return rc;
+  BZ_API_END
 }
 extern "C" int bz_argmax_to_buf(bz_device* dev, const bz_tensor* logits, int64_t rows, int64_t vocab, bz_tensor* token_out) {
+  BZ_API_BEGIN
   return bz_logits_to_token(dev, logits, rows, vocab, nullptr, nullptr, 0, 1.0f, 0.f, 0.f, 0.f, 0, 1.f, 0.f, 0, token_out);
+  BZ_API_END
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -2163,6 +2307,7 @@ static int graph_capture_common(bz_decode_graph* g, const KvView& view) {
 }
 
 extern "C" int bz_decode_graph_capture(bz_model* m, bz_kv* kv, bz_decode_graph** out) {
+  BZ_API_BEGIN
   if (!m || !m->finalized || !kv || !out) BZ_FAIL(BZ_E_INVALID, "graph capture: bad argument");
   std::lock_guard<std::recursive_mutex> lock__(m->mu);
   if (m->cfg.arch == BZ_ARCH_MAMBA2) BZ_FAIL(BZ_E_INVALID, "graph capture: model has no KV cache (use bz_decode_graph_capture_ssm)");
@@ -2177,8 +2322,10 @@ extern "C" int bz_decode_graph_capture(bz_model* m, bz_kv* kv, bz_decode_graph**
   if (rc != BZ_OK) { bz_decode_graph_free(g); return rc; }
   *out = g;
   return BZ_OK;
+  BZ_API_END
 }
 extern "C" int bz_decode_graph_capture_paged(bz_model* m, bz_paged_kv* kv, int max_blocks, bz_decode_graph** out) {
+  BZ_API_BEGIN
   if (!m || !m->finalized || !kv || !out || max_blocks <= 0) BZ_FAIL(BZ_E_INVALID, "graph capture: bad argument");
   std::lock_guard<std::recursive_mutex> lock__(m->mu);
   if (m->cfg.arch != BZ_ARCH_LLAMA) BZ_FAIL(BZ_E_INVALID, "graph capture: model has no KV cache (use bz_decode_graph_capture_ssm)");
@@ -2192,8 +2339,10 @@ extern "C" int bz_decode_graph_capture_paged(bz_model* m, bz_paged_kv* kv, int m
   if (rc != BZ_OK) { bz_decode_graph_free(g); return rc; }
   *out = g;
   return BZ_OK;
+  BZ_API_END
 }
 extern "C" int bz_decode_graph_capture_ssm(bz_model* m, bz_ssm_state* st, bz_decode_graph** out) {
+  BZ_API_BEGIN
   if (!m || !m->finalized || !out) BZ_FAIL(BZ_E_INVALID, "graph capture: bad argument");
   std::lock_guard<std::recursive_mutex> lock__(m->mu);
   BZ_TRY(check_ssm(m, st));
@@ -2205,16 +2354,22 @@ extern "C" int bz_decode_graph_capture_ssm(bz_model* m, bz_ssm_state* st, bz_dec
   if (rc != BZ_OK) { bz_decode_graph_free(g); return rc; }
   *out = g;
   return BZ_OK;
+  BZ_API_END
 }
 extern "C" int bz_decode_graph_set_block_table(bz_decode_graph* g, const int32_t* bt, int n) {
+  BZ_API_BEGIN
   if (!g || !g->block_table || !bt || n < 0 || n > g->max_blocks) BZ_FAIL(BZ_E_INVALID, "set_block_table: bad argument");
   BZ_HIP(hipMemcpyAsync(g->block_table, bt, (size_t)n * 4, hipMemcpyHostToDevice, g->m->dev->stream));
   BZ_HIP(hipStreamSynchronize(g->m->dev->stream));
   return BZ_OK;
+  BZ_API_END
 }
 extern "C" int bz_decode_graph_seed(bz_decode_graph* g, int64_t token, int position) {
+  BZ_API_BEGIN
   if (!g) BZ_FAIL(BZ_E_INVALID, "null graph");
-  if (position < 0 || (!g->ssm && position >= g->m->cfg.max_seq_len)) BZ_FAIL(BZ_E_INVALID, "graph seed: position %d out of range", position);
+  // the captured kernels index K/V rows, the RoPE tables and the block table by the device-resident position without a guard of their own
+  const int limit = g->ssm ? INT32_MAX : std::min(g->capacity, g->m->cfg.max_seq_len);
+  if (position < 0 || position >= limit) BZ_FAIL(BZ_E_INVALID, "graph seed: position %d out of range (cache capacity %d, max_seq_len %d)", position, g->capacity, g->m->cfg.max_seq_len);
   hipStream_t st = g->m->dev->stream;
   long long t = token; int p = position, z = 0;
   BZ_HIP(hipMemcpyAsync(g->tok_buf, &t, 8, hipMemcpyHostToDevice, st));
@@ -2223,12 +2378,17 @@ extern "C" int bz_decode_graph_seed(bz_decode_graph* g, int64_t token, int posit
   BZ_HIP(hipStreamSynchronize(st));
   g->replays = 0; g->seed_pos = position;
   return BZ_OK;
+  BZ_API_END
 }
 extern "C" int bz_decode_graph_replay(bz_decode_graph* g) {
+  BZ_API_BEGIN
   if (!g || !g->exec) BZ_FAIL(BZ_E_INVALID, "null graph");
   std::lock_guard<std::recursive_mutex> lock__(g->m->mu);
   hipStream_t st = g->m->dev->stream;
   hipGraphExec_t exec = g->exec;
+  if (!g->ssm && g->seed_pos + g->replays >= (long long)std::min(g->capacity, g->m->cfg.max_seq_len))
+    BZ_FAIL(BZ_E_INVALID, "graph replay: position %lld is beyond the cache capacity %d / max_seq_len %d the step was captured over", g->seed_pos + g->replays, g->capacity,
+            g->m->cfg.max_seq_len);
   // the position of this replay is known on the host (seeded position + replays since): long contexts replay the split-KV variant,
   // captured on first need over the same device words and sized for the cache capacity
   if (!g->ssm && g->capacity > 0 && att_positions_for((int)(g->seed_pos + g->replays + 1)) > 0) {
@@ -2244,22 +2404,28 @@ extern "C" int bz_decode_graph_replay(bz_decode_graph* g) {
   if (g->kv) g->kv->seq_len++;
   if (g->pkv) g->pkv->seq_len++;
   return BZ_OK;
+  BZ_API_END
 }
 extern "C" int bz_decode_graph_read_token(bz_decode_graph* g, int64_t step, int64_t* out) {
+  BZ_API_BEGIN
   if (!g || !out || step < 0 || step >= g->replays) BZ_FAIL(BZ_E_INVALID, "read_token: step %lld of %lld", (long long)step, g ? g->replays : 0);
   if (g->replays - step > (long long)g->evs.size()) BZ_HIP(hipStreamSynchronize(g->m->dev->stream));
   else BZ_HIP(hipEventSynchronize(g->evs[step % g->evs.size()]));
   if (g->replays - step > bz_decode_graph::LOGCAP) BZ_FAIL(BZ_E_INVALID, "read_token: step %lld fell out of the token log", (long long)step);
   *out = ((volatile long long*)g->tok_log)[step % bz_decode_graph::LOGCAP];
   return BZ_OK;
+  BZ_API_END
 }
 extern "C" int bz_decode_graph_read_logits(bz_decode_graph* g, float* host, size_t n) {
+  BZ_API_BEGIN
   if (!g || !host || n > (size_t)g->m->cfg.vocab) BZ_FAIL(BZ_E_INVALID, "read_logits: bad argument");
   BZ_HIP(hipMemcpyAsync(host, g->m->logits, n * 4, hipMemcpyDeviceToHost, g->m->dev->stream));
   BZ_HIP(hipStreamSynchronize(g->m->dev->stream));
   return BZ_OK;
+  BZ_API_END
 }
 extern "C" int bz_decode_graph_free(bz_decode_graph* g) {
+  BZ_API_BEGIN
   if (!g) return BZ_OK;
   hipStreamSynchronize(g->dev->stream);
   for (auto ev : g->evs) hipEventDestroy(ev);
@@ -2275,6 +2441,7 @@ extern "C" int bz_decode_graph_free(bz_decode_graph* g) {
   bz_dev_release(g->dev);
   delete g;
   return BZ_OK;
+  BZ_API_END
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -2295,6 +2462,7 @@ static int penalty_window(const std::vector<uint32_t>& hist, int last_n, std::ve
 }
 
 extern "C" int bz_generate(bz_model* m, const int64_t* prompt, int n_prompt, const bz_gen_config* gc, int64_t* out_tokens, bz_gen_stats* stats) {
+  BZ_API_BEGIN
   if (!m || !m->finalized || !prompt || !gc || !out_tokens) BZ_FAIL(BZ_E_INVALID, "generate: bad argument");
   if (n_prompt <= 0) { if (stats) memset(stats, 0, sizeof(*stats)); return BZ_OK; }  // executor_generate.rs:75-77
   const bz_model_config& c = m->cfg;
@@ -2438,6 +2606,7 @@ done:
   bz_kv_free(kv); bz_paged_kv_free(pkv); bz_ssm_state_free(ssm); bz_mirostat_free(mstate);
   return rc;
 #undef GEN_TRY
+  BZ_API_END
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -2452,6 +2621,7 @@ static int find_linear(bz_model* m, const char* name, LinearDev* out) {
 }
 
 extern "C" int bz_quant_matmul(bz_model* m, const char* name, const bz_tensor* x, int S, bz_tensor* y) {
+  BZ_API_BEGIN
   LinearDev L;
   BZ_TRY(find_linear(m, name, &L));
   std::lock_guard<std::recursive_mutex> lock__(m->mu);
@@ -2477,9 +2647,11 @@ extern "C" int bz_quant_matmul(bz_model* m, const char* name, const bz_tensor* x
   hipStreamSynchronize(st);
   if (acc) hipFree(acc);
   return rc;
+  BZ_API_END
 }
 
 extern "C" int bz_dequant(bz_model* m, const char* name, float* host) {
+  BZ_API_BEGIN
   LinearDev L;
   BZ_TRY(find_linear(m, name, &L));
   if (!host) BZ_FAIL(BZ_E_INVALID, "dequant: null output");
@@ -2504,10 +2676,12 @@ extern "C" int bz_dequant(bz_model* m, const char* name, float* host) {
   }
   hipFree(d);
   return rc;
+  BZ_API_END
 }
 
 extern "C" int bz_rms_norm(bz_device* dev, const bz_tensor* x, const bz_tensor* prev, const bz_tensor* w, int rows, int n, float eps, int act,
                            bz_tensor* y, bz_tensor* h_out) {
+  BZ_API_BEGIN
   if (!dev || !x || !w || !y || rows <= 0 || n <= 0) BZ_FAIL(BZ_E_INVALID, "rms_norm: bad argument");
   const size_t need = (size_t)rows * n * 4;
   if (x->dtype != BZ_F32 || y->dtype != BZ_F32 || w->dtype != BZ_F32 || x->nbytes < need || y->nbytes < need || w->nbytes < (size_t)n * 4 ||
@@ -2518,9 +2692,11 @@ extern "C" int bz_rms_norm(bz_device* dev, const bz_tensor* x, const bz_tensor* 
                       (float*)y->ptr, h_out ? (float*)h_out->ptr : nullptr));
   BZ_HIP(hipStreamSynchronize(dev->stream));
   return BZ_OK;
+  BZ_API_END
 }
 
 extern "C" int bz_rope(bz_model* m, bz_tensor* x, int S, int n_heads, int position) {
+  BZ_API_BEGIN
   if (!m || !m->finalized || !x || x->dtype != BZ_F32 || S <= 0 || n_heads <= 0) BZ_FAIL(BZ_E_INVALID, "rope: bad argument");
   if (x->nbytes < (size_t)S * n_heads * m->cfg.head_dim * 4) BZ_FAIL(BZ_E_INVALID, "rope: x must be F32 [S,n_heads,head_dim]");
   if (position < 0 || position + S > m->cfg.max_seq_len) BZ_FAIL(BZ_E_INVALID, "rope: positions out of range");
@@ -2528,14 +2704,17 @@ extern "C" int bz_rope(bz_model* m, bz_tensor* x, int S, int n_heads, int positi
   BZ_TRY(bzk_rope(m->dev->stream, (float*)x->ptr, S, n_heads, m->cfg.head_dim, position, m->cos_t, m->sin_t, m->cfg.rope_interleaved, m->cfg.act_dtype));
   BZ_HIP(hipStreamSynchronize(m->dev->stream));
   return BZ_OK;
+  BZ_API_END
 }
 
 extern "C" int bz_silu_mul(bz_device* dev, const bz_tensor* g, const bz_tensor* u, int64_t n, int act, bz_tensor* y) {
+  BZ_API_BEGIN
   if (!dev || !g || !u || !y || n <= 0 || g->nbytes < (size_t)n * 4 || u->nbytes < (size_t)n * 4 || y->nbytes < (size_t)n * 4) BZ_FAIL(BZ_E_INVALID, "silu_mul: bad argument");
   BZ_HIP(hipSetDevice(dev->id));
   BZ_TRY(bzk_silu_mul(dev->stream, (const float*)g->ptr, (const float*)u->ptr, n, act, (float*)y->ptr));
   BZ_HIP(hipStreamSynchronize(dev->stream));
   return BZ_OK;
+  BZ_API_END
 }
 
 static int attn_common(bz_model* m, const bz_tensor* q, const KvView& view, int layer, int len, bz_tensor* out) {
@@ -2554,17 +2733,22 @@ static int attn_common(bz_model* m, const bz_tensor* q, const KvView& view, int 
   return BZ_OK;
 }
 extern "C" int bz_attn_decode(bz_model* m, const bz_tensor* q, bz_kv* kv, int layer, int len, bz_tensor* out) {
+  BZ_API_BEGIN
   if (!m || !m->finalized || !kv || len > kv->cap) BZ_FAIL(BZ_E_INVALID, "attn_decode: bad argument");
   BZ_HIP(hipSetDevice(m->dev->id));
   return attn_common(m, q, view_of(kv), layer, len, out);
+  BZ_API_END
 }
 extern "C" int bz_paged_attn_decode(bz_model* m, const bz_tensor* q, bz_paged_kv* kv, int layer, const bz_tensor* block_table, int len, bz_tensor* out) {
+  BZ_API_BEGIN
   if (!m || !m->finalized || !kv || !block_table || block_table->dtype != BZ_I32) BZ_FAIL(BZ_E_INVALID, "paged_attn_decode: bad argument");
   if ((size_t)((len + kv->block_size - 1) / kv->block_size) * 4 > block_table->nbytes) BZ_FAIL(BZ_E_INVALID, "paged_attn_decode: block_table too short");
   BZ_HIP(hipSetDevice(m->dev->id));
   return attn_common(m, q, view_of(kv, (const int*)block_table->ptr, nullptr), layer, len, out);
+  BZ_API_END
 }
 extern "C" int bz_kv_insert(bz_model* m, bz_kv* kv, int layer, int position, const bz_tensor* k, const bz_tensor* v) {
+  BZ_API_BEGIN
   if (!m || !m->finalized || !kv || !k || !v) BZ_FAIL(BZ_E_INVALID, "kv_insert: bad argument");
   const size_t need = (size_t)kv->n_kv * kv->hd * 4;
   if (k->dtype != BZ_F32 || v->dtype != BZ_F32 || k->nbytes < need || v->nbytes < need) BZ_FAIL(BZ_E_INVALID, "kv_insert: k/v must be F32 [n_kv_heads,head_dim]");
@@ -2577,4 +2761,5 @@ extern "C" int bz_kv_insert(bz_model* m, bz_kv* kv, int layer, int position, con
   BZ_HIP(hipStreamSynchronize(st));
   if (position + 1 > kv->seq_len) kv->seq_len = position + 1;
   return BZ_OK;
+  BZ_API_END
 }

@@ -9,6 +9,8 @@
 #include <unordered_map>
 #include <memory>
 #include <mutex>
+#include <new>
+#include <stdexcept>
 #include "../../include/blazr_hip.h"
 
 // ---------------------------------------------------------------------------------------------------------
@@ -19,6 +21,13 @@ void bz_set_error(const char* fmt, ...);
 #define BZ_HIP(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { \
   bz_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); return BZ_E_HIP; } } while (0)
 #define BZ_TRY(expr) do { int rc__ = (expr); if (rc__ != BZ_OK) return rc__; } while (0)
+// include/blazr_hip.h: "No C++ exception crosses the boundary" -- every status-returning extern "C" body sits between these two
+// (an exception unwinding through extern "C" into a Rust / ctypes caller aborts the host or is undefined behaviour)
+#define BZ_API_BEGIN try {
+#define BZ_API_END } catch (const std::bad_alloc&) { bz_set_error("out of host memory (std::bad_alloc)"); return BZ_E_OOM; } \
+  catch (const std::length_error& e__) { bz_set_error("size out of range (%s)", e__.what()); return BZ_E_OOM; }             \
+  catch (const std::exception& e__) { bz_set_error("internal error: %s", e__.what()); return BZ_E_INVALID; }               \
+  catch (...) { bz_set_error("internal error: unknown C++ exception"); return BZ_E_INVALID; }
 
 // ---------------------------------------------------------------------------------------------------------
 // device-visible PODs
@@ -336,5 +345,38 @@ __device__ __forceinline__ float xrow32(float v) {
   return Op::f(__uint_as_float(r.x), __uint_as_float(r.y));
 }
 __device__ __forceinline__ float wave_sum(float v) { return xrow32<OpAdd>(xrow16<OpAdd>(grp_reduce<16, OpAdd>(v))); }
+// the same for a double (RMSNorm sums of squares are carried exactly: the oracle defines ss as the rounded exact sum, and a 1e-7 difference
+// in 1/rms flips f16 roundings of the normalised vector): the two 32-bit halves travel through the same DPP / permlane controls
+template <int CTRL> __device__ __forceinline__ double dpp_get(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xf, 0xf, true), hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
+  return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+  v += dpp_get<DPP_XOR1>(v); v += dpp_get<DPP_XOR2>(v); v += dpp_get<DPP_HMIRROR>(v); v += dpp_get<DPP_MIRROR>(v);
+  {
+    const long long b = __double_as_longlong(v);
+    const bz_u2_t l = __builtin_amdgcn_permlane16_swap((unsigned)b, (unsigned)b, false, false), h = __builtin_amdgcn_permlane16_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
+    v = __longlong_as_double(((long long)h.x << 32) | l.x) + __longlong_as_double(((long long)h.y << 32) | l.y);
+  }
+  {
+    const long long b = __double_as_longlong(v);
+    const bz_u2_t l = __builtin_amdgcn_permlane32_swap((unsigned)b, (unsigned)b, false, false), h = __builtin_amdgcn_permlane32_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
+    v = __longlong_as_double(((long long)h.x << 32) | l.x) + __longlong_as_double(((long long)h.y << 32) | l.y);
+  }
+  return v;
+}
+// deterministic block sum of a double over NW waves (own LDS words; two barriers)
+template <int NW> __device__ __forceinline__ double block_sum_d(double v) {
+  __shared__ double dred__[NW];
+  v = wave_sum_d(v);
+  if ((threadIdx.x & 63) == 0) dred__[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double t = 0.0;
+#pragma unroll
+  for (int w = 0; w < NW; w++) t += dred__[w];
+  __syncthreads();
+  return t;
+}
 __device__ __forceinline__ float wave_max(float v) { return xrow32<OpMax>(xrow16<OpMax>(grp_reduce<16, OpMax>(v))); }
 #endif  // __HIPCC__

@@ -5,11 +5,12 @@
 //     once at load into [N/64 tiles][K/32 chunks][64 lanes][16 B] so that one wave-wide `global_load_dwordx4`
 //     reads 1 KiB contiguous = 32 k-values for 64 output columns; lane == output column, so there is no
 //     cross-lane reduction, and the activation slice is wave-uniform (broadcast reads from LDS).
-//   * The dot products run on V_DOT4_I32_I8: the f16 activation slice is split, per group of 128, into three
-//     int8 planes (x ~= sx * (65536*hi + 256*mid + lo)), i.e. 24-bit fixed point relative to the group maximum --
-//     the integer path reproduces f32 arithmetic on f16/bf16 activations.  Low nibbles are used as stored
-//     (q, 0..15), high nibbles are stored as (q-8) in two's complement so that `w & 0xF0F0F0F0` IS the signed
-//     byte 16*(q-8): one V_AND per 4 weights, no shifts.  All group arithmetic is exact in int32.
+//   * The int4 (AWQ / GPTQ) dot products run on V_DOT8_I32_I4: weights are stored as signed nibbles (q - 8), the f16
+//     activation slice is split, per group of 128, into six balanced signed-nibble planes under a power-of-two scale
+//     (x = 2^-e * sum_p 16^p n_p, exact for f16 data), so one 32-bit weight word meets one 32-bit plane word per
+//     instruction: six dots per eight weights, no unpacking.  All group arithmetic is exact integer arithmetic and
+//     the groups are summed in double: the kernel computes the exactly rounded dot product (as the oracle defines it).
+//     The GGUF block formats (f32 activations) run on V_DOT4_I32_I8 over three int8 planes per 32-k chunk.
 //   * Split-K partial sums are added with 64-bit INTEGER atomics in 2^-32 fixed point: integer addition is
 //     associative, so the result is bit-reproducible regardless of block scheduling.  The consumer kernel
 //     converts and rounds in its prologue -- there are no separate reduce / norm / activation launches.
@@ -57,10 +58,11 @@ __device__ __forceinline__ float round_act(float x, int act) {
 }
 // 2^-32 fixed point
 __device__ __forceinline__ float fix2f(long long a) {
-  // sign-magnitude: (float)hi + (float)lo*2^-32 on the two's-complement halves cancels catastrophically for small
-  // negative values (hi = -1, lo ~ 2^32)
+  // ONE rounding of the exact fixed-point sum to f32 (the oracle rounds its double sum to f32 once): both 32-bit halves are exact in
+  // double, so is their join below 2^53, and the cast rounds to nearest even
   const unsigned long long m = a < 0 ? (unsigned long long)(-a) : (unsigned long long)a;
-  const float r = (float)(unsigned)(m >> 32) + (float)(unsigned)(m & 0xffffffffull) * 2.3283064365386963e-10f;
+  const double d = fma((double)(unsigned)(m >> 32), 4294967296.0, (double)(unsigned)(m & 0xffffffffull)) * 2.3283064365386963e-10;
+  const float r = (float)d;
   return a < 0 ? -r : r;
 }
 __device__ __forceinline__ long long f2fix(float p) { return __float2ll_rn(p * 4294967296.0f); }
@@ -114,9 +116,9 @@ __device__ __forceinline__ float src_cvt(typename SrcRaw<FIX>::T r, int act) {
 
 // NORM pass 1: v = R(h + prev) for the whole row -> sum of squares; slice elements [k0, k0+KR) are parked in xs
 template <bool SWZ, bool FIX, bool PREV>
-__device__ __forceinline__ float norm_pass1(const Pro& p, int k0, int KR, float* xs, bool writer) {
+__device__ __forceinline__ double norm_pass1(const Pro& p, int k0, int KR, float* xs, bool writer) {
   const int tid = threadIdx.x;
-  float ss = 0.f;
+  double ss = 0.0;
   for (int base = 0; base < p.H; base += 4096) {
     float4 hv[4];
     typename SrcRaw<FIX>::T pr[4][4];
@@ -138,7 +140,7 @@ __device__ __forceinline__ float norm_pass1(const Pro& p, int k0, int KR, float*
         for (int e = 0; e < 4; e++) v[e] = round_act(v[e] + src_cvt<FIX>(pr[j][e], p.act), p.act);
       }
       if (i < p.H) {
-        ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+        ss += ((double)(v[0] * v[0]) + (double)(v[1] * v[1])) + ((double)(v[2] * v[2]) + (double)(v[3] * v[3]));
         if (writer && p.h_out) *(float4*)(p.h_out + i) = make_float4(v[0], v[1], v[2], v[3]);
         if (i >= k0 && i < k0 + KR) {       // k0, KR and i are multiples of 4
 #pragma unroll
@@ -177,11 +179,11 @@ __device__ void build_x_simple(const Pro& p, int k0, int KR, float* xs, float* r
   const int tid = threadIdx.x;
   if (KR <= 0) { __syncthreads(); return; }
   if (p.mode == PRO_NORM) {
-    float ss;
-    if (p.src.p == nullptr) ss = norm_pass1<SWZ, false, false>(p, k0, KR, xs, writer);
-    else if (p.src.fix) ss = norm_pass1<SWZ, true, true>(p, k0, KR, xs, writer);
-    else ss = norm_pass1<SWZ, false, true>(p, k0, KR, xs, writer);
-    ss = block_sum256(ss, red);           // (also orders the xs writes of pass 1 before the reads below)
+    double ssd;
+    if (p.src.p == nullptr) ssd = norm_pass1<SWZ, false, false>(p, k0, KR, xs, writer);
+    else if (p.src.fix) ssd = norm_pass1<SWZ, true, true>(p, k0, KR, xs, writer);
+    else ssd = norm_pass1<SWZ, false, true>(p, k0, KR, xs, writer);
+    const float ss = (float)block_sum_d<4>(ssd);   // the rounded exact sum (also orders the xs writes of pass 1 before the reads below)
     const float rs = 1.0f / sqrtf(ss / (float)p.H + p.eps);
     for (int base = 0; base < KR; base += 2048) {
       float ww[8];
@@ -319,7 +321,7 @@ __device__ __forceinline__ void xfinish(const Pro& p, int KR, const XRegs<MODE, 
   const int tid = threadIdx.x;
   const bool hasprev = p.src.p != nullptr;
   if (MODE == PRO_NORM) {
-    float ss = 0.f;
+    double ssd = 0.0;
 #pragma unroll
     for (int j = 0; j < MAXJ; j++) {
       const int i = j * 1024 + tid * 4;
@@ -329,11 +331,11 @@ __device__ __forceinline__ void xfinish(const Pro& p, int KR, const XRegs<MODE, 
         for (int e = 0; e < 4; e++) v[e] = round_act(v[e] + vcvt<FIX>(r.pf[j][e], p.act), p.act);
       }
       if (i < p.H) {
-        ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+        ssd += ((double)(v[0] * v[0]) + (double)(v[1] * v[1])) + ((double)(v[2] * v[2]) + (double)(v[3] * v[3]));
         if (writer && p.h_out) *(float4*)(p.h_out + i) = make_float4(v[0], v[1], v[2], v[3]);
       }
     }
-    ss = block_sum256(ss, red);
+    const float ss = (float)block_sum_d<4>(ssd);
     const float rs = 1.0f / sqrtf(ss / (float)p.H + p.eps);
 #pragma unroll
     for (int e = 0; e < E; e++) {
@@ -356,16 +358,44 @@ __device__ __forceinline__ void xfinish(const Pro& p, int KR, const XRegs<MODE, 
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// activation slice -> three int8 planes + per-group parameters   (QG = 128 k per group, 16 lanes x 8 each)
-//   x ~= sx * xi,  xi = 65536*hi + 256*mid + lo  (24-bit fixed point relative to the group maximum: exact for f16/bf16
-//   activations down to 2^-13 of the group max, i.e. the int path reproduces f32 arithmetic)
-//   gpar[2g]   = { sx/16 (float bits), 128*SB_hi, 128*SB_mid, 128*SB_lo }   SB = sum over the k with (k%8) >= 4
-//   gpar[2g+1] = { 16*S_hi, 16*S_mid, 16*S_lo, 0 }                          S  = sum over the whole group
+// activation slice -> six signed-nibble planes + per-group parameters   (QG = 128 k per group, 16 lanes x 8 each)
+//   x = c * xi exactly, c = 2^-e with am * 2^e in [2^21, 2^22) (am = the group's maximum magnitude): a power-of-two scale, so xi is the
+//   activation itself (f16 values carry 11 bits; every element within 2^-11 of the group maximum is represented exactly, smaller ones to
+//   2^-22 of the maximum).  xi = sum_p 16^p n_p with balanced nibbles n_p in [-8, 7]: the weights are signed nibbles (q - 8) as well, so a
+//   32-bit weight word meets a 32-bit plane word in ONE V_DOT8_I32_I4 -- six per eight weights, no unpacking at all (round 1: three int8
+//   planes on V_DOT4_I32_I8 = six dots + two ANDs per eight weights).
+//   LDS image: pl[(g*4 + c)*6 + p] = uint4, the four plane-p words for the four weight words of 32-k chunk c of group g; nibble i of a word
+//   is k offset (i >> 1) + 4 (i & 1), the order of the weight words (repack kernels below).
+//   gpar[2g] = { c (float bits), S_0, S_1, S_2 }   gpar[2g+1] = { S_3, S_4, S_5, 0 }     S_p = sum of n_p over the group
+//   sum_k (q_k - z) x_k = c * sum_p 16^p (D_p + (8 - z) S_p),  D_p = sum_k (q_k - 8) n_p,k   -- all of it exact integer arithmetic.
 // ---------------------------------------------------------------------------------------------------------
-#define XQ_MAX 8355000.0f  // < 127*65536 + 127*256 + 127
+#define XQ_NP 6
+
+// one thread: 8 consecutive activations -> one word per plane (+ the plane sums); am = group maximum (already reduced)
+__device__ __forceinline__ void xq_split8(const float (&v)[8], float am, unsigned (&w)[XQ_NP], int (&sp)[XQ_NP], float& cscale) {
+  const unsigned eb = (__float_as_uint(am) >> 23) & 255u;               // biased exponent of the group maximum
+  const bool live = eb >= 24u && eb < 255u;
+  const float inv = live ? __uint_as_float((275u - eb) << 23) : 0.f;    // 2^(21 - (eb - 127))
+  cscale = live ? __uint_as_float((eb - 21u) << 23) : 0.f;              // its reciprocal
+#pragma unroll
+  for (int p = 0; p < XQ_NP; p++) { w[p] = 0; sp[p] = 0; }
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    int r = (int)rintf(v[i] * inv);
+    const int sh = 4 * (2 * (i & 3) + (i >> 2));                         // k offset i -> nibble 2 (i & 3) + (i >> 2)
+#pragma unroll
+    for (int p = 0; p < XQ_NP; p++) {
+      const int n = ((r + 8) & 15) - 8;
+      r = (r - n) >> 4;
+      w[p] |= ((unsigned)n & 15u) << sh;
+      sp[p] += n;
+    }
+  }
+}
 
 template <int NTH>
-__device__ __forceinline__ void quant_x128(const float* xs, int KR, unsigned* xh, unsigned* xm, unsigned* xl, int4* gpar) {
+__device__ __forceinline__ void quant_x128(const float* xs, int KR, uint4* pl, int4* gpar) {
+  unsigned* plw = (unsigned*)pl;
   for (int base = 0; base < KR; base += NTH * 8) {
     const int e0 = base + threadIdx.x * 8;
     const bool on = e0 < KR;
@@ -381,32 +411,46 @@ __device__ __forceinline__ void quant_x128(const float* xs, int KR, unsigned* xh
 #pragma unroll
     for (int i = 0; i < 8; i++) am = fmaxf(am, fabsf(v[i]));
     am = grp_reduce<16, OpMax>(am);
-    const float inv = am > 0.f ? XQ_MAX / am : 0.f;
-    unsigned wh[2] = {0, 0}, wm[2] = {0, 0}, wl[2] = {0, 0};
-    int s_hi = 0, s_mid = 0, s_lo = 0, b_hi = 0, b_mid = 0, b_lo = 0;
+    unsigned w[XQ_NP]; int sp[XQ_NP]; float cs;
+    xq_split8(v, am, w, sp, cs);
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const int xi = (int)rintf(v[i] * inv);
-      const int lo = ((xi + 128) & 255) - 128;
-      const int r1 = (xi - lo) >> 8;
-      const int mid = ((r1 + 128) & 255) - 128;
-      const int hi = (r1 - mid) >> 8;
-      wh[i >> 2] |= ((unsigned)hi & 255u) << (8 * (i & 3));
-      wm[i >> 2] |= ((unsigned)mid & 255u) << (8 * (i & 3));
-      wl[i >> 2] |= ((unsigned)lo & 255u) << (8 * (i & 3));
-      s_hi += hi; s_mid += mid; s_lo += lo;
-      if (i >= 4) { b_hi += hi; b_mid += mid; b_lo += lo; }
-    }
-    s_hi = grp_reduce<16, OpAdd>(s_hi); s_mid = grp_reduce<16, OpAdd>(s_mid); s_lo = grp_reduce<16, OpAdd>(s_lo);
-    b_hi = grp_reduce<16, OpAdd>(b_hi); b_mid = grp_reduce<16, OpAdd>(b_mid); b_lo = grp_reduce<16, OpAdd>(b_lo);
+    for (int p = 0; p < XQ_NP; p++) sp[p] = grp_reduce<16, OpAdd>(sp[p]);
     if (on) {
-      *(uint2*)(xh + e0 / 4) = make_uint2(wh[0], wh[1]);
-      *(uint2*)(xm + e0 / 4) = make_uint2(wm[0], wm[1]);
-      *(uint2*)(xl + e0 / 4) = make_uint2(wl[0], wl[1]);
+      const int word = ((e0 >> 5) * XQ_NP) * 4 + ((e0 >> 3) & 3);       // chunk e0 / 32, weight word (e0 / 8) % 4
+#pragma unroll
+      for (int p = 0; p < XQ_NP; p++) plw[word + p * 4] = w[p];
       if ((threadIdx.x & 15) == 0) {
-        gpar[2 * (e0 >> 7)] = make_int4(__float_as_int(am * (1.0f / (XQ_MAX * 16.0f))), 128 * b_hi, 128 * b_mid, 128 * b_lo);
-        gpar[2 * (e0 >> 7) + 1] = make_int4(16 * s_hi, 16 * s_mid, 16 * s_lo, 0);
+        gpar[2 * (e0 >> 7)] = make_int4(__float_as_int(cs), sp[0], sp[1], sp[2]);
+        gpar[2 * (e0 >> 7) + 1] = make_int4(sp[3], sp[4], sp[5], 0);
       }
+    }
+  }
+}
+
+// 64 values -> planes + parameters (one 64-k half group = two chunks; threads 0..7 of the block, 8 values each)
+__device__ __forceinline__ void quant_x64(const float* a, uint4* pl, int4* gpar) {
+  const int t = threadIdx.x;
+  if (t >= 64) return;                       // first wave only (the reductions below stay inside it)
+  const bool on = t < 8;
+  float v[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) v[i] = on ? a[t * 8 + i] : 0.f;
+  float am = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; i++) am = fmaxf(am, fabsf(v[i]));
+  am = grp_reduce<8, OpMax>(am);
+  unsigned w[XQ_NP]; int sp[XQ_NP]; float cs;
+  xq_split8(v, am, w, sp, cs);
+#pragma unroll
+  for (int p = 0; p < XQ_NP; p++) sp[p] = grp_reduce<8, OpAdd>(sp[p]);
+  if (on) {
+    unsigned* plw = (unsigned*)pl;
+    const int word = ((t >> 2) * XQ_NP) * 4 + (t & 3);
+#pragma unroll
+    for (int p = 0; p < XQ_NP; p++) plw[word + p * 4] = w[p];
+    if (t == 0) {
+      gpar[0] = make_int4(__float_as_int(cs), sp[0], sp[1], sp[2]);
+      gpar[1] = make_int4(sp[3], sp[4], sp[5], 0);
     }
   }
 }
@@ -416,150 +460,68 @@ __device__ __forceinline__ void quant_x128(const float* xs, int KR, unsigned* xh
 // ---------------------------------------------------------------------------------------------------------
 #define Q4G_E 8  // slice elements per thread (KR <= 2048)
 
-__device__ __forceinline__ void q4g_consume(const uint4 (&w)[4], int g, const uint4* xh4, const uint4* xm4, const uint4* xl4,
-                                            const int4* gpar, float s, int z, float& y) {
-  int Ah = 0, Am = 0, Al = 0, Bh = 0, Bm = 0, Bl = 0;
+// one 32-k chunk: the lane's 16-byte weight piece against the six planes (24 V_DOT8_I32_I4, 6 broadcast ds_read_b128)
+__device__ __forceinline__ void q4_chunk(const uint4& w, const uint4* pl6, int (&D)[XQ_NP]) {
+  const unsigned W[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
-  for (int c = 0; c < 4; c++) {
-    const uint4 h0 = xh4[g * 8 + c * 2], h1 = xh4[g * 8 + c * 2 + 1];
-    const uint4 m0 = xm4[g * 8 + c * 2], m1 = xm4[g * 8 + c * 2 + 1];
-    const uint4 l0 = xl4[g * 8 + c * 2], l1 = xl4[g * 8 + c * 2 + 1];
-    const unsigned Xh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
-    const unsigned Xm[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
-    const unsigned Xl[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
-    const unsigned W[4] = {w[c].x, w[c].y, w[c].z, w[c].w};
+  for (int p = 0; p < XQ_NP; p++) {
+    const uint4 P = pl6[p];
+    const unsigned X[4] = {P.x, P.y, P.z, P.w};
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int a = (int)(W[j] & 0x0F0F0F0Fu), b = (int)(W[j] & 0xF0F0F0F0u);
-      Ah = __builtin_amdgcn_sdot4(a, (int)Xh[2 * j], Ah, false);
-      Am = __builtin_amdgcn_sdot4(a, (int)Xm[2 * j], Am, false);
-      Al = __builtin_amdgcn_sdot4(a, (int)Xl[2 * j], Al, false);
-      Bh = __builtin_amdgcn_sdot4(b, (int)Xh[2 * j + 1], Bh, false);
-      Bm = __builtin_amdgcn_sdot4(b, (int)Xm[2 * j + 1], Bm, false);
-      Bl = __builtin_amdgcn_sdot4(b, (int)Xl[2 * j + 1], Bl, false);
-    }
-  }
-  const int4 g1 = gpar[2 * g], g2 = gpar[2 * g + 1];
-  // per plane: 16 * sum_k (q_k - z) * plane_k, exact in int32 (|.| < 2^23)
-  const int Uh = (Ah << 4) + Bh + g1.y - z * g2.x;
-  const int Um = (Am << 4) + Bm + g1.z - z * g2.y;
-  const int Ul = (Al << 4) + Bl + g1.w - z * g2.z;
-  const float f = fmaf((float)Uh, 65536.0f, fmaf((float)Um, 256.0f, (float)Ul));
-  y += (s * __int_as_float(g1.x)) * f;
-}
-
-// two weight tiles against the SAME activation group (gate and up of the fused MLP): the x planes are read from LDS once
-__device__ __forceinline__ void q4g_consume2(const uint4 (&wa)[4], const uint4 (&wb)[4], int g, const uint4* xh4, const uint4* xm4, const uint4* xl4,
-                                             const int4* gpar, float sa, int za, float sb, int zb, float& ya, float& yb) {
-  int Aa[3] = {0, 0, 0}, Ba[3] = {0, 0, 0}, Ab[3] = {0, 0, 0}, Bb[3] = {0, 0, 0};
-#pragma unroll
-  for (int c = 0; c < 4; c++) {
-    const uint4 h0 = xh4[g * 8 + c * 2], h1 = xh4[g * 8 + c * 2 + 1];
-    const uint4 m0 = xm4[g * 8 + c * 2], m1 = xm4[g * 8 + c * 2 + 1];
-    const uint4 l0 = xl4[g * 8 + c * 2], l1 = xl4[g * 8 + c * 2 + 1];
-    const unsigned Xh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
-    const unsigned Xm[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
-    const unsigned Xl[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
-    const unsigned Wa[4] = {wa[c].x, wa[c].y, wa[c].z, wa[c].w};
-    const unsigned Wb[4] = {wb[c].x, wb[c].y, wb[c].z, wb[c].w};
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int a0 = (int)(Wa[j] & 0x0F0F0F0Fu), b0 = (int)(Wa[j] & 0xF0F0F0F0u);
-      const int a1 = (int)(Wb[j] & 0x0F0F0F0Fu), b1 = (int)(Wb[j] & 0xF0F0F0F0u);
-      Aa[0] = __builtin_amdgcn_sdot4(a0, (int)Xh[2 * j], Aa[0], false); Aa[1] = __builtin_amdgcn_sdot4(a0, (int)Xm[2 * j], Aa[1], false);
-      Aa[2] = __builtin_amdgcn_sdot4(a0, (int)Xl[2 * j], Aa[2], false);
-      Ba[0] = __builtin_amdgcn_sdot4(b0, (int)Xh[2 * j + 1], Ba[0], false); Ba[1] = __builtin_amdgcn_sdot4(b0, (int)Xm[2 * j + 1], Ba[1], false);
-      Ba[2] = __builtin_amdgcn_sdot4(b0, (int)Xl[2 * j + 1], Ba[2], false);
-      Ab[0] = __builtin_amdgcn_sdot4(a1, (int)Xh[2 * j], Ab[0], false); Ab[1] = __builtin_amdgcn_sdot4(a1, (int)Xm[2 * j], Ab[1], false);
-      Ab[2] = __builtin_amdgcn_sdot4(a1, (int)Xl[2 * j], Ab[2], false);
-      Bb[0] = __builtin_amdgcn_sdot4(b1, (int)Xh[2 * j + 1], Bb[0], false); Bb[1] = __builtin_amdgcn_sdot4(b1, (int)Xm[2 * j + 1], Bb[1], false);
-      Bb[2] = __builtin_amdgcn_sdot4(b1, (int)Xl[2 * j + 1], Bb[2], false);
-    }
-  }
-  const int4 g1 = gpar[2 * g], g2 = gpar[2 * g + 1];
-  {
-    const int Uh = (Aa[0] << 4) + Ba[0] + g1.y - za * g2.x, Um = (Aa[1] << 4) + Ba[1] + g1.z - za * g2.y, Ul = (Aa[2] << 4) + Ba[2] + g1.w - za * g2.z;
-    ya += (sa * __int_as_float(g1.x)) * fmaf((float)Uh, 65536.0f, fmaf((float)Um, 256.0f, (float)Ul));
-  }
-  {
-    const int Uh = (Ab[0] << 4) + Bb[0] + g1.y - zb * g2.x, Um = (Ab[1] << 4) + Bb[1] + g1.z - zb * g2.y, Ul = (Ab[2] << 4) + Bb[2] + g1.w - zb * g2.z;
-    yb += (sb * __int_as_float(g1.x)) * fmaf((float)Uh, 65536.0f, fmaf((float)Um, 256.0f, (float)Ul));
+    for (int j = 0; j < 4; j++) D[p] = __builtin_amdgcn_sdot8((int)W[j], (int)X[j], D[p], false);
   }
 }
+// the same planes against two weight pieces (gate and up of the fused MLP): the planes are read from LDS once
+__device__ __forceinline__ void q4_chunk2(const uint4& wa, const uint4& wb, const uint4* pl6, int (&Da)[XQ_NP], int (&Db)[XQ_NP]) {
+  const unsigned Wa[4] = {wa.x, wa.y, wa.z, wa.w}, Wb[4] = {wb.x, wb.y, wb.z, wb.w};
+#pragma unroll
+  for (int p = 0; p < XQ_NP; p++) {
+    const uint4 P = pl6[p];
+    const unsigned X[4] = {P.x, P.y, P.z, P.w};
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      Da[p] = __builtin_amdgcn_sdot8((int)Wa[j], (int)X[j], Da[p], false);
+      Db[p] = __builtin_amdgcn_sdot8((int)Wb[j], (int)X[j], Db[p], false);
+    }
+  }
+}
+// group epilogue: s * c * sum_p 16^p (D_p + (8 - z) S_p), exact -- |V_p| <= 2^14, the two three-plane halves fit int32, their join
+// (< 2^36) and the product with the f32 factor s c are exact in double
+__device__ __forceinline__ double q4_term(const int (&D)[XQ_NP], const int4 g1, const int4 g2, float s, int z) {
+  const int zz = 8 - z;
+  const int V0 = D[0] + zz * g1.y, V1 = D[1] + zz * g1.z, V2 = D[2] + zz * g1.w, V3 = D[3] + zz * g2.x, V4 = D[4] + zz * g2.y, V5 = D[5] + zz * g2.z;
+  const int lo = V0 + (V1 << 4) + (V2 << 8), hi = V3 + (V4 << 4) + (V5 << 8);
+  return (double)(s * __int_as_float(g1.x)) * fma((double)hi, 4096.0, (double)lo);
+}
 
-// same arithmetic over NCH 32-k chunks whose x planes start at uint4 index xo; group parameters at gpar[gp], gpar[gp+1]
+// one 128-k group (four chunks) of one tile
+__device__ __forceinline__ void q4g_consume(const uint4 (&w)[4], int g, const uint4* pl, const int4* gpar, float s, int z, double& y) {
+  int D[XQ_NP] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int c = 0; c < 4; c++) q4_chunk(w[c], pl + (g * 4 + c) * XQ_NP, D);
+  y += q4_term(D, gpar[2 * g], gpar[2 * g + 1], s, z);
+}
+// two weight tiles against the SAME activation group (gate and up of the fused MLP)
+__device__ __forceinline__ void q4g_consume2(const uint4 (&wa)[4], const uint4 (&wb)[4], int g, const uint4* pl, const int4* gpar, float sa, int za, float sb, int zb,
+                                             double& ya, double& yb) {
+  int Da[XQ_NP] = {0, 0, 0, 0, 0, 0}, Db[XQ_NP] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int c = 0; c < 4; c++) q4_chunk2(wa[c], wb[c], pl + (g * 4 + c) * XQ_NP, Da, Db);
+  const int4 g1 = gpar[2 * g], g2 = gpar[2 * g + 1];
+  ya += q4_term(Da, g1, g2, sa, za);
+  yb += q4_term(Db, g1, g2, sb, zb);
+}
+// the same arithmetic over NCH 32-k chunks whose planes start at chunk index co; group parameters at gpar[gp], gpar[gp + 1]
 template <int NCH>
-__device__ __forceinline__ void q4g_consume_n(const uint4 (&w)[NCH], int xo, int gp, const uint4* xh4, const uint4* xm4, const uint4* xl4,
-                                              const int4* gpar, float s, int z, float& y) {
-  int Ah = 0, Am = 0, Al = 0, Bh = 0, Bm = 0, Bl = 0;
+__device__ __forceinline__ void q4g_consume_n(const uint4 (&w)[NCH], int co, int gp, const uint4* pl, const int4* gpar, float s, int z, double& y) {
+  int D[XQ_NP] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
-  for (int c = 0; c < NCH; c++) {
-    const uint4 h0 = xh4[xo + c * 2], h1 = xh4[xo + c * 2 + 1];
-    const uint4 m0 = xm4[xo + c * 2], m1 = xm4[xo + c * 2 + 1];
-    const uint4 l0 = xl4[xo + c * 2], l1 = xl4[xo + c * 2 + 1];
-    const unsigned Xh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
-    const unsigned Xm[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
-    const unsigned Xl[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
-    const unsigned W[4] = {w[c].x, w[c].y, w[c].z, w[c].w};
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int a = (int)(W[j] & 0x0F0F0F0Fu), b = (int)(W[j] & 0xF0F0F0F0u);
-      Ah = __builtin_amdgcn_sdot4(a, (int)Xh[2 * j], Ah, false);
-      Am = __builtin_amdgcn_sdot4(a, (int)Xm[2 * j], Am, false);
-      Al = __builtin_amdgcn_sdot4(a, (int)Xl[2 * j], Al, false);
-      Bh = __builtin_amdgcn_sdot4(b, (int)Xh[2 * j + 1], Bh, false);
-      Bm = __builtin_amdgcn_sdot4(b, (int)Xm[2 * j + 1], Bm, false);
-      Bl = __builtin_amdgcn_sdot4(b, (int)Xl[2 * j + 1], Bl, false);
-    }
-  }
-  const int4 g1 = gpar[gp], g2 = gpar[gp + 1];
-  const int Uh = (Ah << 4) + Bh + g1.y - z * g2.x;
-  const int Um = (Am << 4) + Bm + g1.z - z * g2.y;
-  const int Ul = (Al << 4) + Bl + g1.w - z * g2.z;
-  const float f = fmaf((float)Uh, 65536.0f, fmaf((float)Um, 256.0f, (float)Ul));
-  y += (s * __int_as_float(g1.x)) * f;
+  for (int c = 0; c < NCH; c++) q4_chunk(w[c], pl + (co + c) * XQ_NP, D);
+  y += q4_term(D, gpar[gp], gpar[gp + 1], s, z);
 }
 
-// 64 values -> three int8 planes + parameters (one 64-k half group; threads 0..7 of the block, 8 values each)
-__device__ __forceinline__ void quant_x64(const float* a, unsigned* xh, unsigned* xm, unsigned* xl, int4* gpar) {
-  const int t = threadIdx.x;
-  if (t >= 64) return;                       // first wave only (shuffles below stay inside it)
-  const bool on = t < 8;
-  float v[8];
-#pragma unroll
-  for (int i = 0; i < 8; i++) v[i] = on ? a[t * 8 + i] : 0.f;
-  float am = 0.f;
-#pragma unroll
-  for (int i = 0; i < 8; i++) am = fmaxf(am, fabsf(v[i]));
-  am = grp_reduce<8, OpMax>(am);
-  const float inv = am > 0.f ? XQ_MAX / am : 0.f;
-  unsigned wh[2] = {0, 0}, wm[2] = {0, 0}, wl[2] = {0, 0};
-  int s_hi = 0, s_mid = 0, s_lo = 0, b_hi = 0, b_mid = 0, b_lo = 0;
-#pragma unroll
-  for (int i = 0; i < 8; i++) {
-    const int xi = (int)rintf(v[i] * inv);
-    const int lo = ((xi + 128) & 255) - 128;
-    const int r1 = (xi - lo) >> 8;
-    const int mid = ((r1 + 128) & 255) - 128;
-    const int hi = (r1 - mid) >> 8;
-    wh[i >> 2] |= ((unsigned)hi & 255u) << (8 * (i & 3));
-    wm[i >> 2] |= ((unsigned)mid & 255u) << (8 * (i & 3));
-    wl[i >> 2] |= ((unsigned)lo & 255u) << (8 * (i & 3));
-    s_hi += hi; s_mid += mid; s_lo += lo;
-    if (i >= 4) { b_hi += hi; b_mid += mid; b_lo += lo; }
-  }
-  s_hi = grp_reduce<8, OpAdd>(s_hi); s_mid = grp_reduce<8, OpAdd>(s_mid); s_lo = grp_reduce<8, OpAdd>(s_lo);
-  b_hi = grp_reduce<8, OpAdd>(b_hi); b_mid = grp_reduce<8, OpAdd>(b_mid); b_lo = grp_reduce<8, OpAdd>(b_lo);
-  if (on) {
-    *(uint2*)(xh + t * 2) = make_uint2(wh[0], wh[1]);
-    *(uint2*)(xm + t * 2) = make_uint2(wm[0], wm[1]);
-    *(uint2*)(xl + t * 2) = make_uint2(wl[0], wl[1]);
-    if (t == 0) {
-      gpar[0] = make_int4(__float_as_int(am * (1.0f / (XQ_MAX * 16.0f))), 128 * b_hi, 128 * b_mid, 128 * b_lo);
-      gpar[1] = make_int4(16 * s_hi, 16 * s_mid, 16 * s_lo, 0);
-    }
-  }
-}
+// 2^-32 fixed point from the double a lane accumulated over its groups
+__device__ __forceinline__ long long d2fix(double p) { return __double2ll_rn(p * 4294967296.0); }
 
 // ---------------------------------------------------------------------------------------------------------
 // Fused MLP (INT4):  acc_down += Wd[:, slice] . R(R(silu(R(Wg[slice] x))) * R(Wu[slice] x)),  x = RMSNorm(R(h + prev))
@@ -578,18 +540,14 @@ __global__ __launch_bounds__(NW * 64) void k_mlp_q4g(const uint4* __restrict__ W
                                                  long long* acc, long long* zero_buf, int zero_n) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* xs = (float*)smem;                   // [H]
-  unsigned* xh = (unsigned*)(xs + H);         // [H/4] x3
-  unsigned* xm = xh + H / 4;
-  unsigned* xl = xm + H / 4;
+  uint4* xpl = (uint4*)(xs + H);              // [H/32 chunks][6 planes]: 3 H bytes
   const int G = H >> 7;
-  int4* gpar = (int4*)(xl + H / 4);           // [2G]
+  int4* gpar = (int4*)(xpl + (H >> 5) * XQ_NP);   // [2G]
   constexpr int NTH = NW * 64;
-  float* part = (float*)(gpar + 2 * G);       // [NW][128]
-  float* av = part + NW * 128;                // [64]
-  unsigned* ah = (unsigned*)(av + 64);        // [16] x3
-  unsigned* am_ = ah + 16;
-  unsigned* al = am_ + 16;
-  int4* apar = (int4*)(al + 16);              // [2]
+  double* part = (double*)(gpar + 2 * G);     // [NW][128]
+  float* av = (float*)(part + NW * 128);      // [64]
+  uint4* apl = (uint4*)(av + 64);             // [2 chunks][6 planes]
+  int4* apar = (int4*)(apl + 2 * XQ_NP);      // [2]
   float* red = (float*)(apar + 2);            // [NW]
 
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -645,7 +603,7 @@ __global__ __launch_bounds__(NW * 64) void k_mlp_q4g(const uint4* __restrict__ W
     sg[b] = __half2float(Sgu[ig]); zg[b] = Zgu[ig]; su[b] = __half2float(Sgu[iu]); zu[b] = Zgu[iu];
   }
   // (3) finish the norm
-  float ss = 0.f;
+  double ssd = 0.0;
 #pragma unroll
   for (int j = 0; j < NJ; j++) {
     const int i = j * (NTH * 4) + tid * 4;
@@ -653,14 +611,16 @@ __global__ __launch_bounds__(NW * 64) void k_mlp_q4g(const uint4* __restrict__ W
 #pragma unroll
       for (int e = 0; e < 4; e++) hv[j][e] = round_act(hv[j][e] + vcvt<FIX>(pv[j][e], pro.act), pro.act);
     }
-    ss += hv[j][0] * hv[j][0] + hv[j][1] * hv[j][1] + hv[j][2] * hv[j][2] + hv[j][3] * hv[j][3];
+    ssd += ((double)(hv[j][0] * hv[j][0]) + (double)(hv[j][1] * hv[j][1])) + ((double)(hv[j][2] * hv[j][2]) + (double)(hv[j][3] * hv[j][3]));
     if (blockIdx.x == 0 && pro.h_out) *(float4*)(pro.h_out + i) = make_float4(hv[j][0], hv[j][1], hv[j][2], hv[j][3]);
   }
-  ss = wave_sum(ss);
-  if (lane == 0) red[wave] = ss;
+  ssd = wave_sum_d(ssd);
+  double* dred = (double*)red;
+  if (lane == 0) dred[wave] = ssd;
   __syncthreads();
-  ss = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
-  if (NW == 16) ss += ((red[8] + red[9]) + (red[10] + red[11])) + ((red[12] + red[13]) + (red[14] + red[15]));
+  ssd = ((dred[0] + dred[1]) + (dred[2] + dred[3])) + ((dred[4] + dred[5]) + (dred[6] + dred[7]));
+  if (NW == 16) ssd += ((dred[8] + dred[9]) + (dred[10] + dred[11])) + ((dred[12] + dred[13]) + (dred[14] + dred[15]));
+  const float ss = (float)ssd;                  // the rounded exact sum of squares (oracle: orc_rms_norm)
   const float rs = 1.0f / sqrtf(ss / (float)H + pro.eps);
 #pragma unroll
   for (int j = 0; j < NJ; j++) {
@@ -669,7 +629,7 @@ __global__ __launch_bounds__(NW * 64) void k_mlp_q4g(const uint4* __restrict__ W
                                      round_act(nw[j].z * round_act(hv[j][2] * rs, pro.act), pro.act), round_act(nw[j].w * round_act(hv[j][3] * rs, pro.act), pro.act));
   }
   __syncthreads();
-  quant_x128<NTH>(xs, H, xh, xm, xl, gpar);
+  quant_x128<NTH>(xs, H, xpl, gpar);
   __syncthreads();
   if (GPW > 1 && NW == 16) {   // 16 waves: the second group goes out only now, so that no more than 8 KiB per wave (128 KiB per CU) is in flight at a time
 #pragma unroll
@@ -678,15 +638,12 @@ __global__ __launch_bounds__(NW * 64) void k_mlp_q4g(const uint4* __restrict__ W
 
   // (4) gate / up partial dot products over this wave's k-groups; group b+2 is requested as soon as group b's registers are free,
   //     and the down slab (16 KiB per wave) goes out behind the last gate/up group, so the stream never pauses
-  const uint4* xh4 = (const uint4*)xh;
-  const uint4* xm4 = (const uint4*)xm;
-  const uint4* xl4 = (const uint4*)xl;
-  float yg = 0.f, yu = 0.f;
+  double yg = 0.0, yu = 0.0;
   uint4 D[TPW][2];
   float sd[TPW]; int zd[TPW];
 #pragma unroll
   for (int b = 0; b < GPW; b++) {
-    q4g_consume2(Ag[b % ND], Au[b % ND], gbeg + b, xh4, xm4, xl4, gpar, sg[b], zg[b], su[b], zu[b], yg, yu);
+    q4g_consume2(Ag[b % ND], Au[b % ND], gbeg + b, xpl, gpar, sg[b], zg[b], su[b], zu[b], yg, yu);
     if (b + ND < GPW) {
 #pragma unroll
       for (int c = 0; c < 4; c++) { Ag[b % ND][c] = ldnt(wg + ((b + ND) * 4 + c) * 64); Au[b % ND][c] = ldnt(wu + ((b + ND) * 4 + c) * 64); }
@@ -707,32 +664,31 @@ __global__ __launch_bounds__(NW * 64) void k_mlp_q4g(const uint4* __restrict__ W
   part[wave * 128 + lane] = yg;
   part[wave * 128 + 64 + lane] = yu;
   __syncthreads();
+  float* gu = (float*)(xs);                    // [128] rounded gate | up (the activation image is dead by now)
   if (tid < 128) {
-    float t = 0.f;
+    double t = 0.0;                            // the waves' k-range partials, exact, in a fixed order
 #pragma unroll
     for (int w2 = 0; w2 < NW; w2++) t += part[w2 * 128 + tid];
-    if (bgu) t += bgu[tid < 64 ? sl * 64 + tid : I + sl * 64 + (tid - 64)];
-    part[tid] = round_act(t, pro.act);
+    float tf = (float)t;                       // ONE rounding of the exact dot product to f32 (the oracle's definition)
+    if (bgu) tf += bgu[tid < 64 ? sl * 64 + tid : I + sl * 64 + (tid - 64)];
+    gu[tid] = round_act(tf, pro.act);
   }
   __syncthreads();
-  if (tid < 64) av[tid] = round_act(round_act(silu_f(part[tid]), pro.act) * part[64 + tid], pro.act);
+  if (tid < 64) av[tid] = round_act(round_act(silu_f(gu[tid]), pro.act) * gu[64 + tid], pro.act);
   __syncthreads();
-  quant_x64(av, ah, am_, al, apar);
+  quant_x64(av, apl, apar);
   __syncthreads();
   // (5) this wave's down slab
-  const uint4* ah4 = (const uint4*)ah;
-  const uint4* am4 = (const uint4*)am_;
-  const uint4* al4 = (const uint4*)al;
 #pragma unroll
   for (int q = 0; q < TPW; q++) {
-    float y = 0.f;
-    q4g_consume_n<2>(D[q], 0, 0, ah4, am4, al4, apar, sd[q], zd[q], y);
+    double y = 0.0;
+    q4g_consume_n<2>(D[q], 0, 0, apl, apar, sd[q], zd[q], y);
     const int n = (tbeg + q) * 64 + lane;
-    if (bd != nullptr && sl == 0) y += bd[n];
-    atomicAdd((unsigned long long*)(acc + n), (unsigned long long)f2fix(y));
+    if (bd != nullptr && sl == 0) y += (double)bd[n];
+    atomicAdd((unsigned long long*)(acc + n), (unsigned long long)d2fix(y));
   }}
 
-static size_t mlp_smem(int H) { return (size_t)H * 4 + (size_t)H * 3 + (size_t)(H >> 7) * 32 + 16 * 128 * 4 + 64 * 4 + 48 * 4 + 32 + 64 + 64; }
+static size_t mlp_smem(int H) { return (size_t)H * 4 + (size_t)H * 3 + (size_t)(H >> 7) * 32 + 16 * 128 * 8 + 64 * 4 + 2 * XQ_NP * 16 + 32 + 64 + 64; }
 
 bool bzk_mlp_fusable(const LinearDev& gu, const LinearDev& dn, int H, int I) {
   return gu.kind == LK_Q4G && dn.kind == LK_Q4G && !gu.perm && !dn.perm && gu.N == 2 * I && gu.K == H && dn.N == H && dn.K == I &&
@@ -762,10 +718,8 @@ __global__ __launch_bounds__(256) void k_gemv_q4g(const uint4* __restrict__ W, c
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int KR = GW * 128;
   float* xs = (float*)smem;                               // [KR]
-  unsigned* xh = (unsigned*)(xs + KR);                    // [KR/4]
-  unsigned* xm = xh + KR / 4;                             // [KR/4]
-  unsigned* xl = xm + KR / 4;                             // [KR/4]
-  int4* gpar = (int4*)(xl + KR / 4);                      // [2*GW]
+  uint4* xpl = (uint4*)(xs + KR);                         // [KR/32 chunks][6 planes]: 3 KR bytes
+  int4* gpar = (int4*)(xpl + (KR >> 5) * XQ_NP);          // [2*GW]
   __half* sS = (__half*)(gpar + 2 * GW);                  // [4][GW][64]
   unsigned char* sZ = (unsigned char*)(sS + 4 * GW * 64); // [4][GW][64]
   float* red = (float*)(sZ + 4 * GW * 64);                // [4]
@@ -822,16 +776,13 @@ __global__ __launch_bounds__(256) void k_gemv_q4g(const uint4* __restrict__ W, c
 #pragma unroll
     for (int j = 0; j < 4; j++) if (lane + 64 * j < GW * 16) sZw[lane + 64 * j] = zreg[j];
   }
-  if (!(pro.dbg & 4)) quant_x128<256>(xs, KR, xh, xm, xl, gpar);
+  if (!(pro.dbg & 4)) quant_x128<256>(xs, KR, xpl, gpar);
   __syncthreads();
   QSTAMP(3);
   if (!wave_on) return;
 
   // (5) stream the k-range with NPF groups (NPF * 4 KiB per wave) in flight
-  const uint4* xh4 = (const uint4*)xh;
-  const uint4* xm4 = (const uint4*)xm;
-  const uint4* xl4 = (const uint4*)xl;
-  float y = 0.f;
+  double y = 0.0;
   for (int gb = 0; gb < GW; gb += NPF) {
 #pragma unroll
     for (int b = 0; b < NPF; b++) {
@@ -839,8 +790,8 @@ __global__ __launch_bounds__(256) void k_gemv_q4g(const uint4* __restrict__ W, c
       if (g < GW) {
         const float s = __half2float(sS[(wave * GW + g) * 64 + lane]);
         const int z = sZ[(wave * GW + g) * 64 + lane];
-        if (pro.dbg & 2) y += __uint_as_float((Wb[b][0].x ^ Wb[b][1].y ^ Wb[b][2].z ^ Wb[b][3].w) & 0x007fffffu);
-        else q4g_consume(Wb[b], g, xh4, xm4, xl4, gpar, s, z, y);
+        if (pro.dbg & 2) y += (double)__uint_as_float((Wb[b][0].x ^ Wb[b][1].y ^ Wb[b][2].z ^ Wb[b][3].w) & 0x007fffffu);
+        else q4g_consume(Wb[b], g, xpl, gpar, s, z, y);
         if (g + NPF < GW) {
 #pragma unroll
           for (int c = 0; c < 4; c++) Wb[b][c] = ldnt(wp + ((g + NPF) * 4 + c) * 64);
@@ -850,9 +801,9 @@ __global__ __launch_bounds__(256) void k_gemv_q4g(const uint4* __restrict__ W, c
   }
   QSTAMP(4);
   const int n = nt * 64 + lane;
-  if (bias != nullptr && ks == 0) y += bias[n];
-  if (pro.dbg & 1) acc[n] = f2fix(y);
-  else atomicAdd((unsigned long long*)(acc + n), (unsigned long long)f2fix(y));
+  if (bias != nullptr && ks == 0) y += (double)bias[n];
+  if (pro.dbg & 1) acc[n] = d2fix(y);
+  else atomicAdd((unsigned long long*)(acc + n), (unsigned long long)d2fix(y));
   QSTAMP(5);
 #undef QSTAMP
 }
@@ -870,9 +821,9 @@ template <int FIX, int NJ>     // NJ = H / 2048
 __global__ __launch_bounds__(512) void k_gemv_q4g_slim(const uint4* __restrict__ W, const __half* __restrict__ S, const unsigned char* __restrict__ Z,
                                                       const float* __restrict__ bias, int N, int H, Pro pro, long long* acc, long long* zero_buf, int zero_n) {
   __shared__ __attribute__((aligned(16))) float xs[256];
-  __shared__ __attribute__((aligned(16))) unsigned xh[64], xm[64], xl[64];
+  __shared__ uint4 xpl[8 * XQ_NP];
   __shared__ int4 gpar[4];
-  __shared__ float red[8];
+  __shared__ double red[8];
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int NKS = H >> 8, G = H >> 7;
   const int ksl = blockIdx.x % NKS, tq = (blockIdx.x / NKS) * 8 + wave;
@@ -909,7 +860,7 @@ __global__ __launch_bounds__(512) void k_gemv_q4g_slim(const uint4* __restrict__
     for (int b = 0; b < 2; b++) { const size_t ix = ((size_t)tqc * G + ksl * 2 + b) * 64 + lane; sq[b] = __half2float(S[ix]); zq[b] = Z[ix]; }
   }
   // (3) h' = R(h + R(prev)); sum of squares; this block's slice parked in LDS
-  float ss = 0.f;
+  double ssd = 0.0;
 #pragma unroll
   for (int j = 0; j < NJ; j++) {
     const int i = j * 2048 + tid * 4;
@@ -917,14 +868,14 @@ __global__ __launch_bounds__(512) void k_gemv_q4g_slim(const uint4* __restrict__
 #pragma unroll
       for (int e = 0; e < 4; e++) hv[j][e] = round_act(hv[j][e] + vcvt<FIX>(pv[j][e], pro.act), pro.act);
     }
-    ss += hv[j][0] * hv[j][0] + hv[j][1] * hv[j][1] + hv[j][2] * hv[j][2] + hv[j][3] * hv[j][3];
+    ssd += ((double)(hv[j][0] * hv[j][0]) + (double)(hv[j][1] * hv[j][1])) + ((double)(hv[j][2] * hv[j][2]) + (double)(hv[j][3] * hv[j][3]));
     if (blockIdx.x == 0 && pro.h_out) *(float4*)(pro.h_out + i) = make_float4(hv[j][0], hv[j][1], hv[j][2], hv[j][3]);
     if ((i >> 8) == ksl) *(float4*)(xs + (i & 255)) = make_float4(hv[j][0], hv[j][1], hv[j][2], hv[j][3]);
   }
-  ss = wave_sum(ss);
-  if (lane == 0) red[wave] = ss;
+  ssd = wave_sum_d(ssd);
+  if (lane == 0) red[wave] = ssd;
   __syncthreads();
-  ss = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
+  const float ss = (float)(((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7])));
   const float rs = 1.0f / sqrtf(ss / (float)H + pro.eps);
   if (tid < 64) {
     const float4 v = *(const float4*)(xs + tid * 4);
@@ -932,15 +883,15 @@ __global__ __launch_bounds__(512) void k_gemv_q4g_slim(const uint4* __restrict__
                                            round_act(nw.z * round_act(v.z * rs, pro.act), pro.act), round_act(nw.w * round_act(v.w * rs, pro.act), pro.act));
   }
   __syncthreads();
-  quant_x128<512>(xs, 256, xh, xm, xl, gpar);
+  quant_x128<512>(xs, 256, xpl, gpar);
   __syncthreads();
   if (!q_on) return;
-  float y = 0.f;
-  q4g_consume(Q[0], 0, (const uint4*)xh, (const uint4*)xm, (const uint4*)xl, gpar, sq[0], zq[0], y);
-  q4g_consume(Q[1], 1, (const uint4*)xh, (const uint4*)xm, (const uint4*)xl, gpar, sq[1], zq[1], y);
+  double y = 0.0;
+  q4g_consume(Q[0], 0, xpl, gpar, sq[0], zq[0], y);
+  q4g_consume(Q[1], 1, xpl, gpar, sq[1], zq[1], y);
   const int n = tq * 64 + lane;
-  if (bias != nullptr && ksl == 0) y += bias[n];
-  atomicAdd((unsigned long long*)(acc + n), (unsigned long long)f2fix(y));
+  if (bias != nullptr && ksl == 0) y += (double)bias[n];
+  atomicAdd((unsigned long long*)(acc + n), (unsigned long long)d2fix(y));
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -956,7 +907,7 @@ __global__ __launch_bounds__(512) void k_gemm_q4g_rows(const uint4* __restrict__
                                                       const float* __restrict__ bias, int N, int K, const unsigned short* __restrict__ X, int rows,
                                                       long long* __restrict__ acc) {
   __shared__ __attribute__((aligned(16))) float xs[8 * 256];
-  __shared__ __attribute__((aligned(16))) unsigned xh[8 * 64], xm[8 * 64], xl[8 * 64];
+  __shared__ uint4 xpl[8 * 8 * XQ_NP];
   __shared__ int4 gpar[8 * 4];
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int NKS = K >> 8, G = K >> 7;
@@ -989,18 +940,18 @@ __global__ __launch_bounds__(512) void k_gemm_q4g_rows(const uint4* __restrict__
     *(float4*)(xs + xr * 256 + lane * 4) = on ? make_float4(v[0], v[1], v[2], v[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   __syncthreads();
-  quant_x128<512>(xs, 8 * 256, xh, xm, xl, gpar);       // 16 groups of 128: group index = row * 2 + (group of the slice)
+  quant_x128<512>(xs, 8 * 256, xpl, gpar);              // 16 groups of 128: group index = row * 2 + (group of the slice)
   __syncthreads();
   if (!q_on) return;
   const int n = tq * 64 + lane;
-  const float bv = (bias != nullptr && ksl == 0) ? bias[n] : 0.f;
+  const double bv = (bias != nullptr && ksl == 0) ? (double)bias[n] : 0.0;
 #pragma unroll
   for (int r = 0; r < 8; r++) {
     if (r < rows) {
-      float y = bv;
-      q4g_consume(Q[0], r * 2, (const uint4*)xh, (const uint4*)xm, (const uint4*)xl, gpar, sq[0], zq[0], y);
-      q4g_consume(Q[1], r * 2 + 1, (const uint4*)xh, (const uint4*)xm, (const uint4*)xl, gpar, sq[1], zq[1], y);
-      atomicAdd((unsigned long long*)(acc + (size_t)r * N + n), (unsigned long long)f2fix(y));
+      double y = bv;
+      q4g_consume(Q[0], r * 2, xpl, gpar, sq[0], zq[0], y);
+      q4g_consume(Q[1], r * 2 + 1, xpl, gpar, sq[1], zq[1], y);
+      atomicAdd((unsigned long long*)(acc + (size_t)r * N + n), (unsigned long long)d2fix(y));
     }
   }
 }
@@ -1053,6 +1004,7 @@ bool bzk_gemv_slim_ok(const LinearDev& L, const Pro& pro) {
 //   first / second 16;  Q8_0: unused.
 // =========================================================================================================
 enum { GQ_Q80 = 0, GQ_Q4K = 1, GQ_Q6K = 2 };
+#define XQ_MAX 8355000.0f  // < 127*65536 + 127*256 + 127: the largest magnitude of three balanced int8 planes
 
 template <int FMT>
 __device__ __forceinline__ void quant_x32(const float* xs, int KR, unsigned* xh, unsigned* xm, unsigned* xl, int4* cpar) {
@@ -1948,7 +1900,7 @@ __global__ void k_repack_awq(const uint32_t* qw, const float* sc, const float* z
     for (int bb = 0; bb < 4; bb++) {
       const int k1 = kc * 32 + j * 8 + bb;
       const unsigned q1 = awq_nib(qw, N, k1, n), q2 = awq_nib(qw, N, k1 + 4, n);
-      word |= (q1 | ((q2 ^ 8u) << 4)) << (8 * bb);
+      word |= ((q1 ^ 8u) | ((q2 ^ 8u) << 4)) << (8 * bb);     // both nibbles as two's-complement (q - 8): V_DOT8_I32_I4 operands
     }
     wout[idx] = word;
   }
@@ -1983,7 +1935,7 @@ __global__ void k_repack_gptq(const uint32_t* qw, const float* sc, const uint32_
       if (perm) { k1 = perm[k1]; k2 = perm[k2]; }
       const unsigned q1 = (qw[(size_t)(k1 >> 3) * N + n] >> (4 * (k1 & 7))) & 15u;
       const unsigned q2 = (qw[(size_t)(k2 >> 3) * N + n] >> (4 * (k2 & 7))) & 15u;
-      word |= (q1 | ((q2 ^ 8u) << 4)) << (8 * bb);
+      word |= ((q1 ^ 8u) | ((q2 ^ 8u) << 4)) << (8 * bb);     // both nibbles as two's-complement (q - 8): V_DOT8_I32_I4 operands
     }
     wout[idx] = word;
   }
@@ -2024,7 +1976,7 @@ __global__ void k_dequant_q4g(const uint32_t* W, const __half* S, const unsigned
     const int nt = n >> 6, lane = n & 63, kc = k >> 5, j = (k & 31) >> 3, r = k & 7;
     const unsigned word = W[(((size_t)nt * (K >> 5) + kc) * 64 + lane) * 4 + j];
     const unsigned byte = (word >> (8 * (r & 3))) & 255u;
-    const float q = (r < 4) ? (float)(byte & 15u) : (float)((byte >> 4) ^ 8u);
+    const float q = (r < 4) ? (float)((byte & 15u) ^ 8u) : (float)((byte >> 4) ^ 8u);
     const size_t gi = ((size_t)nt * G + (k >> 7)) * 64 + lane;
     out[idx] = (q - (float)Z[gi]) * __half2float(S[gi]);
   }
@@ -2387,10 +2339,8 @@ __global__ __launch_bounds__(NW * 64) void k_attn2(AttnArgs a, const uint4* __re
   float* wred = (float*)(v2 + 64);            // [2 NW]
   float* pout = wred + 2 * NW;                // [NW][128] PV partials of the waves
   float* outh = pout + NW * 128;              // [128] head output (FUSE)
-  unsigned* xh = (unsigned*)(outh + 128);     // [32] x3
-  unsigned* xm = xh + 32;
-  unsigned* xl = xm + 32;
-  int4* gpar = (int4*)(xl + 32);              // [2]
+  uint4* xpl = (uint4*)(outh + 128);          // [4 chunks][6 planes]: 384 B (as the three int8 planes before)
+  int4* gpar = (int4*)(xpl + 4 * XQ_NP);      // [2]
   const int rep = a.nq / a.nkv;
   const int hq = FUSE ? blockIdx.x / CS : blockIdx.x, cs = FUSE ? blockIdx.x % CS : 0, kvh = hq / rep;
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -2592,19 +2542,16 @@ __global__ __launch_bounds__(NW * 64) void k_attn2(AttnArgs a, const uint4* __re
   }
   __syncthreads();
   STAMP(6);
-  quant_x128<NW * 64>(outh, HD, xh, xm, xl, gpar);
+  quant_x128<NW * 64>(outh, HD, xpl, gpar);
   __syncthreads();
   STAMP(7);
-  const uint4* xh4 = (const uint4*)xh;
-  const uint4* xm4 = (const uint4*)xm;
-  const uint4* xl4 = (const uint4*)xl;
 #pragma unroll
   for (int t = 0; t < (FUSE ? TPW : 1); t++) {
-    float y = 0.f;
-    q4g_consume(Wb[t], 0, xh4, xm4, xl4, gpar, sc[t], zp[t], y);
+    double y = 0.0;
+    q4g_consume(Wb[t], 0, xpl, gpar, sc[t], zp[t], y);
     const int n = (t0 + t) * 64 + lane;
-    if (bias != nullptr && hq == 0) y += bias[n];
-    if (wave < OW) atomicAdd((unsigned long long*)(acc + n), (unsigned long long)f2fix(y));
+    if (bias != nullptr && hq == 0) y += (double)bias[n];
+    if (wave < OW) atomicAdd((unsigned long long*)(acc + n), (unsigned long long)d2fix(y));
   }
   STAMP(8);
 #undef STAMP
@@ -3051,7 +2998,7 @@ __global__ __launch_bounds__(512) void k_attn_merge_oproj(AttnArgs a, const floa
   constexpr int HD = 128;
   __shared__ float wS[128], red[16], osum[4][128];
   __shared__ __attribute__((aligned(16))) float outh[128];
-  __shared__ __attribute__((aligned(16))) unsigned xh[32], xm[32], xl[32];
+  __shared__ uint4 xpl[4 * XQ_NP];
   __shared__ int4 gpar[2];
   asm volatile("" :: "s"(a.pos), "s"(a.act), "s"(a.nq), "s"(ws), "s"(SPL), "s"(nsplit), "s"(W), "s"(S), "s"(Z), "s"(bias), "s"(CS), "s"(acc),
                "s"(a.zero_buf), "s"(a.zero_n));
@@ -3082,15 +3029,15 @@ __global__ __launch_bounds__(512) void k_attn_merge_oproj(AttnArgs a, const floa
   const int ns = (pos + 1 + SPL - 1) / SPL;
   att_merge_512(ws, hq, nsplit, ns, a.act, wS, red, osum, outh);
   __syncthreads();
-  quant_x128<512>(outh, HD, xh, xm, xl, gpar);
+  quant_x128<512>(outh, HD, xpl, gpar);
   __syncthreads();
 #pragma unroll
   for (int t = 0; t < TPW; t++) {
-    float y = 0.f;
-    q4g_consume(Wb[t], 0, (const uint4*)xh, (const uint4*)xm, (const uint4*)xl, gpar, sc[t], zp[t], y);
+    double y = 0.0;
+    q4g_consume(Wb[t], 0, xpl, gpar, sc[t], zp[t], y);
     const int n = (t0 + t) * 64 + lane;
-    if (bias != nullptr && hq == 0) y += bias[n];
-    atomicAdd((unsigned long long*)(acc + n), (unsigned long long)f2fix(y));
+    if (bias != nullptr && hq == 0) y += (double)bias[n];
+    atomicAdd((unsigned long long*)(acc + n), (unsigned long long)d2fix(y));
   }
 }
 

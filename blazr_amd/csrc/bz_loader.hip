@@ -114,9 +114,13 @@ struct JParser {
     else if (lit("false")) { v.t = JVal::BOOL; v.b = false; }
     else if (lit("null")) { v.t = JVal::NUL; }
     else {
+      // the header is a mapped file region with no terminating NUL: parse the number from a bounded copy
+      char buf[64]; size_t n = 0;
+      while (p + n < e && n < sizeof(buf) - 1 && (isdigit((unsigned char)p[n]) || p[n] == '-' || p[n] == '+' || p[n] == '.' || p[n] == 'e' || p[n] == 'E')) { buf[n] = p[n]; n++; }
+      buf[n] = 0;
       char* end = nullptr;
-      v.t = JVal::NUM; v.n = strtod(p, &end);
-      if (end == p || end > e) ok = false; else p = end;
+      v.t = JVal::NUM; v.n = strtod(buf, &end);
+      if (n == 0 || end == buf) ok = false; else p += (end - buf);
     }
     return v;
   }
@@ -159,7 +163,8 @@ struct Mapped {
   int open(const std::string& path) {
     int fd = ::open(path.c_str(), O_RDONLY);
     if (fd < 0) BZ_FAIL(BZ_E_NOTFOUND, "cannot open '%s'", path.c_str());
-    struct stat st; fstat(fd, &st);
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) { ::close(fd); BZ_FAIL(BZ_E_INVALID, "cannot stat '%s' (not a regular file?)", path.c_str()); }
     n = (size_t)st.st_size;
     p = n ? mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0) : nullptr;
     ::close(fd);
@@ -177,6 +182,22 @@ std::string find_config_in_dir(const std::string& dir) {
 // ---------------------------------------------------------------------------------------------------------
 // SafeTensors: 8-byte little-endian header length, JSON header {name: {dtype, shape, data_offsets}}, raw data
 // ---------------------------------------------------------------------------------------------------------
+// overflow-checked size arithmetic for header-controlled values
+bool mul_ok(size_t a, size_t b, size_t* out) { return !__builtin_mul_overflow(a, b, out); }
+bool shape_elems(const std::vector<int64_t>& shape, size_t* out) {
+  size_t n = 1;
+  for (int64_t d : shape) { if (d <= 0 || !mul_ok(n, (size_t)d, &n)) return false; }
+  *out = n;
+  return true;
+}
+size_t st_dtype_size(const std::string& d) {
+  if (d == "F64" || d == "I64" || d == "U64") return 8;
+  if (d == "F32" || d == "I32" || d == "U32") return 4;
+  if (d == "F16" || d == "BF16" || d == "I16" || d == "U16") return 2;
+  if (d == "I8" || d == "U8" || d == "BOOL" || d == "F8_E4M3" || d == "F8_E5M2") return 1;
+  return 0;
+}
+
 struct StTensor { std::string dtype; std::vector<int64_t> shape; const unsigned char* data = nullptr; size_t bytes = 0; };
 struct StLoader {
   std::vector<std::unique_ptr<Mapped>> files;
@@ -199,10 +220,23 @@ struct StLoader {
       const JVal* sh = t.get("shape"); const JVal* off = t.get("data_offsets");
       if (!sh || sh->t != JVal::ARR || !off || off->t != JVal::ARR || off->a.size() != 2) BZ_FAIL(BZ_E_INVALID, "'%s': bad entry for tensor '%s'", path.c_str(), kv.first.c_str());
       StTensor st; st.dtype = t.str("dtype");
-      for (auto& d : sh->a) st.shape.push_back((int64_t)d.n);
+      for (auto& d : sh->a) {
+        if (d.t != JVal::NUM || !(d.n >= 0) || d.n > 9.0e15 || d.n != (double)(int64_t)d.n) BZ_FAIL(BZ_E_INVALID, "'%s': tensor '%s' has a bad dimension", path.c_str(), kv.first.c_str());
+        st.shape.push_back((int64_t)d.n);
+      }
+      if (off->a[0].t != JVal::NUM || off->a[1].t != JVal::NUM || !(off->a[0].n >= 0) || !(off->a[1].n >= 0) || off->a[0].n > 9.0e15 || off->a[1].n > 9.0e15)
+        BZ_FAIL(BZ_E_INVALID, "'%s': tensor '%s' data_offsets malformed", path.c_str(), kv.first.c_str());
       const size_t b = (size_t)off->a[0].n, e = (size_t)off->a[1].n;
       if (b > e || e > data_n) BZ_FAIL(BZ_E_INVALID, "'%s': tensor '%s' data_offsets out of range", path.c_str(), kv.first.c_str());
       st.data = base + b; st.bytes = e - b;
+      // the safetensors crate the reference uses rejects a header whose byte range disagrees with dtype x shape (TensorInvalidInfo)
+      size_t ne = 0, want = 0;
+      const size_t es = st_dtype_size(st.dtype);
+      bool empty_dim = false;
+      for (int64_t d : st.shape) if (d == 0) empty_dim = true;
+      if (empty_dim) { if (st.bytes != 0) BZ_FAIL(BZ_E_INVALID, "'%s': tensor '%s' has an empty shape but %zu bytes", path.c_str(), kv.first.c_str(), st.bytes); }
+      else if (es && (!shape_elems(st.shape, &ne) || !mul_ok(ne, es, &want) || want != st.bytes))
+        BZ_FAIL(BZ_E_INVALID, "'%s': tensor '%s' (%s): %zu bytes in the file but shape x dtype needs %zu", path.c_str(), kv.first.c_str(), st.dtype.c_str(), st.bytes, want);
       tensors[kv.first] = st;
     }
     total += mf->n;
@@ -436,6 +470,21 @@ int load_safetensors(bz_device* dev, const std::string& path, bz_model** out, bz
       const StTensor* sc = st.find(base + ".scales"); const StTensor* qz = st.find(base + ".qzeros");
       if (!sc || !qz || t.shape.size() != 2 || sc->shape.size() != 2 || qz->shape.size() != 2 || sc->dtype != "F16")
         { rc = BZ_E_INVALID; bz_set_error("quantised layer '%s': qweight / scales (F16) / qzeros triplet incomplete", base.c_str()); break; }
+      {   // every byte count the add_* calls will read, checked against the file (a lying triplet must fail here, not read out of bounds)
+        const bool gptq = q.method == 2;
+        const int64_t K = gptq ? t.shape[0] * 8 : t.shape[0], N = gptq ? t.shape[1] : t.shape[1] * 8;
+        const int gs = q.group_size;
+        const StTensor* gi = st.find(base + ".g_idx"); const StTensor* bi = st.find(base + ".bias");
+        bool bad = t.dtype != "I32" && t.dtype != "U32";
+        bad = bad || gs <= 0 || K <= 0 || N <= 0 || K % gs != 0 || N % 8 != 0 || K > (1 << 24) || N > (1 << 24);
+        const int64_t G = bad ? 0 : K / gs;
+        bad = bad || sc->shape[0] != G || sc->shape[1] != N || sc->bytes != (size_t)G * N * 2;
+        bad = bad || (qz->dtype != "I32" && qz->dtype != "U32") || qz->shape[0] != G || qz->shape[1] != N / 8 || qz->bytes != (size_t)G * (N / 8) * 4;
+        bad = bad || t.bytes != (size_t)K * N / 2;
+        if (gptq && gi) bad = bad || gi->dtype != "I32" || gi->shape.size() != 1 || gi->shape[0] != K || gi->bytes != (size_t)K * 4;
+        if (gptq && bi) bad = bad || bi->shape.size() != 1 || bi->shape[0] != N || (bi->dtype != "F32" && bi->dtype != "F16") || bi->bytes != (size_t)N * (bi->dtype == "F32" ? 4 : 2);
+        if (bad) { rc = BZ_E_INVALID; bz_set_error("quantised layer '%s': qweight / scales / qzeros / g_idx / bias shapes or byte counts are inconsistent (group size %d)", base.c_str(), gs); break; }
+      }
       f32a.resize((size_t)sc->shape[0] * sc->shape[1]);
       for (size_t i = 0; i < f32a.size(); i++) f32a[i] = f16_to_f32(((const uint16_t*)sc->data)[i]);   // awq.rs:202-206 cast_f16_bytes_to_f32
       if (q.method == 2) {
@@ -521,15 +570,25 @@ struct Gguf {
       GgufTensor t; t.name = rstr();
       const uint32_t nd = rd<uint32_t>();
       if (nd > 4) { ok = false; break; }
-      for (uint32_t d = 0; d < nd; d++) t.ne.push_back((int64_t)rd<uint64_t>());
+      for (uint32_t d = 0; d < nd; d++) {
+        const uint64_t x = rd<uint64_t>();
+        if (x == 0 || x > (1ull << 40)) { ok = false; break; }      // negative (as i64) / absurd extents
+        t.ne.push_back((int64_t)x);
+      }
       t.type = (int)rd<uint32_t>(); t.offset = rd<uint64_t>();
       tensors.push_back(t);
     }
     if (!ok) BZ_FAIL(BZ_E_INVALID, "'%s': truncated or malformed GGUF header", path.c_str());
     size_t align = 32;
-    auto it = kv.find("general.alignment"); if (it != kv.end() && it->second.u) align = (size_t)it->second.u;
+    auto it = kv.find("general.alignment");
+    if (it != kv.end()) {
+      const uint64_t a = it->second.u;
+      if (a == 0 || a > 4096 || (a & (a - 1))) BZ_FAIL(BZ_E_INVALID, "'%s': general.alignment %llu is not a power of two <= 4096", path.c_str(), (unsigned long long)a);
+      align = (size_t)a;
+    }
     data_off = (size_t)(p - (const unsigned char*)file.p);
     data_off = (data_off + align - 1) / align * align;
+    if (!tensors.empty() && data_off > file.n) BZ_FAIL(BZ_E_INVALID, "'%s': truncated GGUF file (no data section)", path.c_str());
     return BZ_OK;
   }
   bool u32(const std::string& k, long long* out) const { auto it = kv.find(k); if (it == kv.end() || it->second.type == 8 || it->second.type == 9) return false; *out = (long long)it->second.u; return true; }
@@ -624,7 +683,12 @@ int load_gguf(bz_device* dev, const std::string& path, bz_model** out, bz_model_
     const int64_t K = t.ne[0], N = t.ne.size() == 2 ? t.ne[1] : 1;      // ne[0] is the contiguous dimension
     const size_t rb = ggml_row_bytes(t.type, K);
     if (!rb) { rc = BZ_E_UNSUPPORTED; bz_set_error("GGUF tensor '%s': ggml type %d is not implemented (F32, F16, BF16, Q8_0, Q4_K, Q6_K)", t.name.c_str(), t.type); break; }
-    if (g.data_off + t.offset + rb * (size_t)N > g.file.n) { rc = BZ_E_INVALID; bz_set_error("GGUF tensor '%s' runs past the end of the file", t.name.c_str()); break; }
+    {   // checked: offset / extents are file-controlled 64-bit values
+      const size_t room = g.file.n - g.data_off;
+      size_t need = 0;
+      if (K <= 0 || N <= 0 || t.offset > room || !mul_ok(rb, (size_t)N, &need) || need > room - (size_t)t.offset)
+        { rc = BZ_E_INVALID; bz_set_error("GGUF tensor '%s' runs past the end of the file", t.name.c_str()); break; }
+    }
     const void* data = (const unsigned char*)g.file.p + g.data_off + t.offset;
     if (t.type == 0 || t.type == 1 || t.type == 30) {
       const int dt = t.type == 0 ? BZ_F32 : (t.type == 1 ? BZ_F16 : BZ_BF16);
@@ -641,6 +705,16 @@ int load_gguf(bz_device* dev, const std::string& path, bz_model** out, bz_model_
   return BZ_OK;
 }
 
+std::string json_escape(const std::string& in) {
+  std::string o;
+  for (unsigned char ch : in) {
+    if (ch == '"' || ch == '\\') { o += '\\'; o += (char)ch; }
+    else if (ch < 0x20) { char b[8]; snprintf(b, sizeof b, "\\u%04x", ch); o += b; }
+    else o += (char)ch;
+  }
+  return o;
+}
+
 int copy_path(char* dst, size_t cap, const std::string& s) {
   if (s.size() + 1 > cap) BZ_FAIL(BZ_E_INVALID, "path too long");
   memcpy(dst, s.c_str(), s.size() + 1);
@@ -651,6 +725,7 @@ int copy_path(char* dst, size_t cap, const std::string& s) {
 
 // ---- C ABI ---------------------------------------------------------------------------------------------------------------------------------
 extern "C" int bz_detect_model_source(const char* path_c, bz_model_source* out) {
+  BZ_API_BEGIN
   if (!path_c || !out) BZ_FAIL(BZ_E_INVALID, "detect_model_source: null argument");
   memset(out, 0, sizeof(*out));
   const std::string path = path_c;
@@ -680,16 +755,20 @@ extern "C" int bz_detect_model_source(const char* path_c, bz_model_source* out) 
   std::vector<std::string> ggufs = glob_list(path + "/*.gguf");                          // detect.rs:93-99
   if (!ggufs.empty()) { out->format = BZ_FORMAT_GGUF; return copy_path(out->weights_path, sizeof out->weights_path, ggufs[0]); }
   BZ_FAIL(BZ_E_NOTFOUND, "No supported model files found in directory: %s", path.c_str());
+  BZ_API_END
 }
 
 extern "C" int bz_detect_architecture_from_names(const char* const* names, int n, bz_detected_arch* out) {
+  BZ_API_BEGIN
   if (!names || n < 0 || !out) BZ_FAIL(BZ_E_INVALID, "detect_architecture_from_names: null argument");
   std::vector<std::string> v;
   for (int i = 0; i < n; i++) v.push_back(names[i] ? names[i] : "");
   return detect_from_names(v, out);
+  BZ_API_END
 }
 
 extern "C" int bz_config_from_hf_json(const char* json_text, bz_model_config* cfg, bz_quant_info* qinfo) {
+  BZ_API_BEGIN
   if (!json_text || !cfg) BZ_FAIL(BZ_E_INVALID, "config_from_hf_json: null argument");
   JVal j;
   if (!json_parse(json_text, strlen(json_text), &j)) BZ_FAIL(BZ_E_INVALID, "config.json: JSON syntax error");
@@ -698,9 +777,11 @@ extern "C" int bz_config_from_hf_json(const char* json_text, bz_model_config* cf
   if (q.method) cfg->act_dtype = BZ_F16;
   if (qinfo) { qinfo->quant_method = q.method; qinfo->group_size = q.group_size; qinfo->torch_dtype = q.has_dtype ? q.torch_dtype : -1; }
   return BZ_OK;
+  BZ_API_END
 }
 
 extern "C" int bz_config_from_gguf(const char* path, bz_model_config* cfg, bz_gguf_info* info) {
+  BZ_API_BEGIN
   if (!path || !cfg) BZ_FAIL(BZ_E_INVALID, "config_from_gguf: null argument");
   Gguf g;
   BZ_TRY(g.open(path));
@@ -719,10 +800,12 @@ extern "C" int bz_config_from_gguf(const char* path, bz_model_config* cfg, bz_gg
     info->file_size_bytes = (uint64_t)g.file.n;
   }
   return BZ_OK;
+  BZ_API_END
 }
 
 // JSON listing of a SafeTensors checkpoint (single file, first shard or directory): names, dtypes, shapes -- SafeTensorsLoader::{tensor_names, tensor_info}
 extern "C" int bz_safetensors_describe(const char* path, char* json_out, size_t cap, size_t* needed) {
+  BZ_API_BEGIN
   if (!path) BZ_FAIL(BZ_E_INVALID, "safetensors_describe: null argument");
   StLoader st;
   BZ_TRY(st.open(path));
@@ -731,7 +814,7 @@ extern "C" int bz_safetensors_describe(const char* path, char* json_out, size_t 
   for (auto& kv : st.tensors) {
     if (!first) s += ", ";
     first = false;
-    s += "\"" + kv.first + "\": {\"dtype\": \"" + kv.second.dtype + "\", \"shape\": [";
+    s += "\"" + json_escape(kv.first) + "\": {\"dtype\": \"" + json_escape(kv.second.dtype) + "\", \"shape\": [";
     for (size_t i = 0; i < kv.second.shape.size(); i++) s += (i ? ", " : "") + std::to_string(kv.second.shape[i]);
     s += "], \"bytes\": " + std::to_string(kv.second.bytes) + "}";
   }
@@ -739,13 +822,16 @@ extern "C" int bz_safetensors_describe(const char* path, char* json_out, size_t 
   if (needed) *needed = s.size() + 1;
   if (json_out && cap) { const size_t n = std::min(cap - 1, s.size()); memcpy(json_out, s.data(), n); json_out[n] = 0; }
   return BZ_OK;
+  BZ_API_END
 }
 
 // loaders.rs load_model: detect the source, read the config, move every tensor through bz_model_add_*, finalize
 extern "C" int bz_load_model(bz_device* dev, const char* path, bz_model** out, bz_model_config* cfg_out) {
+  BZ_API_BEGIN
   if (!dev || !path || !out) BZ_FAIL(BZ_E_INVALID, "load_model: null argument");
   bz_model_source src;
   BZ_TRY(bz_detect_model_source(path, &src));
   if (src.format == BZ_FORMAT_GGUF) return load_gguf(dev, src.weights_path, out, cfg_out);
   return load_safetensors(dev, is_dir(path) ? std::string(path) : std::string(src.weights_path), out, cfg_out);
+  BZ_API_END
 }

@@ -327,7 +327,7 @@ __global__ void k_pf_embed(const void* table, int tdt, const long long* tok, int
 
 // ---------------------------------------------------------------------------------------------------------------------------------------
 // W4A16 GEMM on the matrix cores: Y[S,N] = R(X[S,K] . dequant(W)^T) for the int4 group-quantised layout of the decode kernels
-//   W [N/64][K/32][64 lanes][16 B] : lane = column, word j of a chunk = k 8j..8j+7 (byte b: low nibble k 8j+b, high nibble (q ^ 8) of k 8j+4+b)
+//   W [N/64][K/32][64 lanes][16 B] : lane = column, word j of a chunk = k 8j..8j+7 (byte b: low nibble k 8j+b, high nibble k 8j+4+b, both stored as q ^ 8 = two's-complement q - 8)
 // A wave owns 64 rows x 64 columns; no LDS.  Per 32-k chunk it loads ONE 16-byte weight piece per lane and turns it into the four MFMA
 // B-fragments (two 32-column halves x two 16-k steps) with two V_PERMLANE32_SWAPs: swap(word0, word1) leaves {columns 0-31: k 0-7 | k 8-15}
 // in the first result and {columns 32-63: k 0-7 | k 8-15} in the second -- exactly the (column = lane & 31, k-half = lane >> 5) operand
@@ -341,7 +341,8 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ uint4 q4_frag_f16(unsigned w, f16x2 mz) {   // mz = -(1024 + z) in both halves
-  const unsigned lo = w & 0x0F0F0F0Fu, hi = ((w >> 4) & 0x0F0F0F0Fu) ^ 0x08080808u;
+  const unsigned wq = w ^ 0x88888888u;      // stored nibbles are (q - 8) in two's complement (the decode kernels' V_DOT8 operands): back to q
+  const unsigned lo = wq & 0x0F0F0F0Fu, hi = (wq >> 4) & 0x0F0F0F0Fu;
   const unsigned p0 = __builtin_amdgcn_perm(0x64646464u, lo, 0x04010400u), p1 = __builtin_amdgcn_perm(0x64646464u, lo, 0x04030402u);
   const unsigned p2 = __builtin_amdgcn_perm(0x64646464u, hi, 0x04010400u), p3 = __builtin_amdgcn_perm(0x64646464u, hi, 0x04030402u);
   uint4 r;

@@ -31,6 +31,7 @@ extern "C" float bz_compute_dynamic_temperature(const float* logits, int64_t V, 
 }
 
 extern "C" int bz_apply_dry_penalty(float* logits, int64_t V, const uint32_t* recent, int64_t n_recent, float multiplier, int base, int allowed_length) {
+  BZ_API_BEGIN
   if (!logits || (!recent && n_recent) || base < 1) BZ_FAIL(BZ_E_INVALID, "apply_dry_penalty: bad argument");
   const uint32_t* h = recent; int64_t hn = n_recent;
   if (allowed_length > 0 && allowed_length < n_recent) { h = recent + (n_recent - allowed_length); hn = allowed_length; }
@@ -48,9 +49,11 @@ extern "C" int bz_apply_dry_penalty(float* logits, int64_t V, const uint32_t* re
     }
   }
   return BZ_OK;
+  BZ_API_END
 }
 
 extern "C" int bz_apply_typical_filter(float* logits, int64_t V, float typical_p) {
+  BZ_API_BEGIN
   if (!logits || V <= 0) BZ_FAIL(BZ_E_INVALID, "apply_typical_filter: bad argument");
   float max_logit = -INFINITY;
   for (int64_t i = 0; i < V; i++) max_logit = fmaxf(max_logit, logits[i]);
@@ -76,17 +79,21 @@ extern "C" int bz_apply_typical_filter(float* logits, int64_t V, float typical_p
   }
   for (int64_t i = 0; i < V; i++) if (!keep[i]) logits[i] = -INFINITY;
   return BZ_OK;
+  BZ_API_END
 }
 
 extern "C" int bz_apply_logit_bias(float* logits, int64_t V, const uint32_t* ids, const float* bias, int n) {
+  BZ_API_BEGIN
   if (!logits || (n && (!ids || !bias))) BZ_FAIL(BZ_E_INVALID, "apply_logit_bias: bad argument");
   std::vector<float> b((size_t)V, 0.f);           // sampling.rs:470-476: a dense bias vector, later entries of the map overwrite earlier ones
   for (int i = 0; i < n; i++) if ((int64_t)ids[i] < V) b[ids[i]] = bias[i];
   for (int64_t i = 0; i < V; i++) logits[i] += b[i];
   return BZ_OK;
+  BZ_API_END
 }
 
 extern "C" int bz_compute_logprobs(const float* logits, int64_t V, uint32_t chosen, int top_n, float* chosen_logprob, uint32_t* top_ids, float* top_lps, int* n_top) {
+  BZ_API_BEGIN
   if (!logits || V <= 0 || !chosen_logprob || !n_top) BZ_FAIL(BZ_E_INVALID, "compute_logprobs: bad argument");
   float max_logit = -INFINITY;
   for (int64_t i = 0; i < V; i++) max_logit = fmaxf(max_logit, logits[i]);
@@ -107,17 +114,21 @@ extern "C" int bz_compute_logprobs(const float* logits, int64_t V, uint32_t chos
   *n_top = (int)top.size();
   for (size_t i = 0; i < top.size(); i++) { if (top_ids) top_ids[i] = (uint32_t)top[i].id; if (top_lps) top_lps[i] = top[i].lp; }
   return BZ_OK;
+  BZ_API_END
 }
 
 struct bz_mirostat { float mu, tau, eta; uint64_t rng; };
 extern "C" int bz_mirostat_create(float tau, float eta, uint64_t seed, bz_mirostat** out) {
+  BZ_API_BEGIN
   if (!out) BZ_FAIL(BZ_E_INVALID, "mirostat_create: null argument");
   *out = new bz_mirostat{2.0f * tau, tau, eta, seed};     // mirostat.rs:27-33: mu = 2 tau
   return BZ_OK;
+  BZ_API_END
 }
 extern "C" int bz_mirostat_free(bz_mirostat* s) { delete s; return BZ_OK; }
 extern "C" float bz_mirostat_mu(const bz_mirostat* s) { return s ? s->mu : 0.f; }
 extern "C" int bz_mirostat_sample(bz_mirostat* st, const float* logits, int64_t V, float temperature, uint32_t* token, float* logprob) {
+  BZ_API_BEGIN
   if (!st || !logits || V <= 0 || !token) BZ_FAIL(BZ_E_INVALID, "mirostat_sample: bad argument");
   std::vector<float> scaled(logits, logits + V);
   if (temperature != 1.0f && temperature > 0.0f) { const float inv_t = 1.0f / temperature; for (auto& l : scaled) l *= inv_t; }
@@ -145,4 +156,5 @@ extern "C" int bz_mirostat_sample(bz_mirostat* st, const float* logits, int64_t 
   *token = (uint32_t)chosen;
   if (logprob) *logprob = logf(chosen_prob);
   return BZ_OK;
+  BZ_API_END
 }

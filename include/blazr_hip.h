@@ -280,6 +280,11 @@ int bz_profile_step_ssm(bz_model* m, bz_ssm_state* state, int64_t token, int ite
  * HBM buffers.  mode 0 plain x / 1 fused residual+RMSNorm prologue / 2 SiLU*up prologue; flags are debugging knobs (0). */
 int bz_tune_gemv(bz_device* dev, int N, int K, int groups_per_wg, int mode, int nbuf, int iters, int flags, double* avg_us);
 
+/* Measured HBM read ceiling of this device, GB/s: a streaming read of `bytes` (rotating buffers beyond the Infinity Cache) with the decode
+ * kernels' load pattern and no arithmetic.  bench.py reports roofline fractions against the 8 TB/s spec peak AND against this number
+ * (SURVEY.md 8d "record the measured peak on the box and report against both"). */
+int bz_probe_hbm_read(bz_device* dev, size_t bytes, int iters, double* gbs);
+
 /* ---- op-level entry points (parity tests; each is the kernel the forward path uses) ------------------------ */
 /* QuantMatmulOps / dense matmul on a registered weight `name` ("….weight"): y[S,N] = x[S,K] W^T (+bias); x,y F32 device tensors */
 int bz_quant_matmul(bz_model* m, const char* name, const bz_tensor* x, int S, bz_tensor* y);

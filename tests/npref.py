@@ -211,6 +211,57 @@ class NpLlama:
         return R(xn @ self.lm.T)
 
 
+class NpLlamaTruth:
+    """The same model with NO rounding anywhere: every tensor and every sum in float64 (weights are the exact dequantised values).
+    This is what both the oracle and the HIP path approximate; tests/test_gpu_parity_truth.py measures each one's distance to it."""
+
+    def __init__(self, model):
+        self.m = model
+        self.cfg = model["config"]
+        c, s = rope_tables(self.cfg)
+        self.cos, self.sin = c.astype(np.float64), s.astype(np.float64)
+        f = lambda spec: dequant(spec).astype(np.float64)
+        self.W = [{k: f(lay[k]) for k in ("q", "k", "v", "o", "gate", "up", "down")} for lay in model["layers"]]
+        self.B = [{k: lay[k].get("bias") for k in ("q", "k", "v", "o", "gate", "up", "down")} for lay in model["layers"]]
+        self.lm = f(model["lm_head"])
+        self.emb = dequant(dict(kind="dense", weight=model["embed"]))
+        self.K = [[] for _ in model["layers"]]
+        self.V = [[] for _ in model["layers"]]
+
+    def _lin(self, l, name, x):
+        y = self.W[l][name] @ x
+        b = self.B[l][name]
+        return (y + b.astype(np.float64)) if b is not None else y
+
+    @staticmethod
+    def _norm(x, w, eps):
+        return w.astype(np.float64) * (x / np.sqrt(np.mean(x * x) + eps))
+
+    def step(self, token, pos):
+        c = self.cfg
+        nq, nkv, hd = c["n_heads"], c["n_kv_heads"], c["head_dim"]
+        h = self.emb[token].astype(np.float64)
+        for l, lay in enumerate(self.m["layers"]):
+            xn = self._norm(h, lay["attn_norm"], c["rms_eps"])
+            q = rope(self._lin(l, "q", xn).reshape(nq, hd), self.cos[pos], self.sin[pos], c["rope_interleaved"])
+            k = rope(self._lin(l, "k", xn).reshape(nkv, hd), self.cos[pos], self.sin[pos], c["rope_interleaved"])
+            v = self._lin(l, "v", xn).reshape(nkv, hd)
+            self.K[l].append(k)
+            self.V[l].append(v)
+            Kc, Vc = np.stack(self.K[l], axis=1), np.stack(self.V[l], axis=1)
+            rep = nq // nkv
+            o = np.empty((nq, hd), dtype=np.float64)
+            for hh in range(nq):
+                s = (Kc[hh // rep] @ q[hh]) / np.sqrt(hd)
+                p = np.exp(s - s.max())
+                o[hh] = (p / p.sum()) @ Vc[hh // rep]
+            h = h + self._lin(l, "o", o.reshape(-1))
+            xn = self._norm(h, lay["ffn_norm"], c["rms_eps"])
+            g, u = self._lin(l, "gate", xn), self._lin(l, "up", xn)
+            h = h + self._lin(l, "down", (g / (1.0 + np.exp(-g))) * u)
+        return self.lm @ self._norm(h, self.m["final_norm"], c["rms_eps"])
+
+
 class NpMamba2:
     """Independent numpy Mamba2 step (vectorised over heads / state; public Mamba2 recurrence)."""
 

@@ -44,6 +44,41 @@ def test_product_does_not_touch_oracle():
                     assert bad not in text, (os.path.join(dirpath, f), bad)
 
 
+def test_product_does_not_touch_oracle_outside_the_package():
+    """the same for the other product sources: the C header, the C++ driver, and bench.py outside its cpu_baseline / parity leg"""
+    for rel in ("include/blazr_hip.h", "tools/bz_run.cpp"):
+        text = open(os.path.join(ROOT, rel), errors="replace").read()
+        for bad in ("liborc", "orc_py", "from oracle", "import oracle", "orc.h\"", "dlopen"):
+            assert bad not in text, (rel, bad)
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    head, marker, tail = bench.partition("        # CPU baseline: the oracle")
+    assert marker, "bench.py lost its cpu_baseline marker"
+    for bad in ("liborc", "orc_py", "from oracle", "import oracle"):
+        assert bad not in head, "bench.py touches oracle/ (%s) before its cpu_baseline leg" % bad
+
+
+def test_no_cpp_exception_can_cross_the_c_abi():
+    """include/blazr_hip.h promises that no C++ exception crosses the boundary: every status-returning extern "C" function with a body of more
+    than one line sits between BZ_API_BEGIN / BZ_API_END (bz_internal.h: bad_alloc -> BZ_E_OOM, anything else -> BZ_E_INVALID)"""
+    n = 0
+    for f in sorted(os.listdir(os.path.join(ROOT, "blazr_amd", "csrc"))):
+        if not f.endswith(".hip"):
+            continue
+        lines = open(os.path.join(ROOT, "blazr_amd", "csrc", f)).read().split("\n")
+        for i, ln in enumerate(lines):
+            if ln.startswith('extern "C" int ') and not ln.rstrip().endswith("}"):
+                j = i
+                while not lines[j].rstrip().endswith("{"):
+                    j += 1
+                assert lines[j + 1].strip() == "BZ_API_BEGIN", (f, i + 1, ln)
+                k = j + 1
+                while lines[k] != "}":
+                    k += 1
+                assert lines[k - 1].strip() == "BZ_API_END", (f, i + 1, ln)
+                n += 1
+    assert n >= 70
+
+
 @pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="GPU present")
 def test_no_device_fails_loudly():
     import ctypes as C

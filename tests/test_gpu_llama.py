@@ -366,6 +366,66 @@ def test_batched_paged_decode_matches_per_sequence_oracle(device, preset, nseq):
         lm.forward_paged_batch([1, 2], pool, [0, 1], [[0], [1]], [40, 2])      # 40 tokens do not fit one block
 
 
+def test_batched_paged_decode_beyond_one_512_row_chunk(device):
+    """the multi-row pipeline works in 512-row chunks; sequence 512 + s of the second chunk must read ITS block-table row (it read
+    row s before: another sequence's K/V).  520 one-block sequences, every sequence a different prompt, against per-sequence results."""
+    model = synth.make_llama("tiny-bf16")
+    cfg = model["config"]
+    lm = runtime.LoadedModel.from_synth(device, model)
+    nseq, bs = 520, 16
+    pool = runtime.LayeredPagedKvCache(device, cfg["n_layers"], nseq, bs, cfg["n_kv_heads"], cfg["head_dim"], _kv_dt(cfg))
+    rng = np.random.default_rng(5)
+    plens = rng.integers(1, 9, size=nseq)
+    prompts = [rng.integers(0, cfg["vocab"], size=int(n)) for n in plens]
+    perm = rng.permutation(nseq)                       # sequence i lives in physical block perm[i]
+    for i, p in enumerate(prompts):
+        blk = int(perm[i])
+        lm.forward_with_paged_kv_cache(p, pool, [blk * bs + j for j in range(len(p))], [blk], len(p), 0)
+    toks = [int(rng.integers(0, cfg["vocab"])) for _ in range(nseq)]
+    lens = [int(n) + 1 for n in plens]
+    slots = [int(perm[i]) * bs + lens[i] - 1 for i in range(nseq)]
+    got = lm.forward_paged_batch(toks, pool, slots, [[int(perm[i])] for i in range(nseq)], lens).to_numpy()
+    # per-sequence truth on the same device path, one sequence at a time (its parity with the oracle is covered above), for a sample that
+    # includes both sides of the chunk boundary
+    om = orc_py.OrcLlama(model)
+    for i in (0, 1, 255, 511, 512, 513, 519):
+        okv = om.new_kv(32)
+        om.forward_kv(prompts[i], okv, 0)
+        lo = om.forward_kv([toks[i]], okv, lens[i] - 1)
+        _check_logits(got[i:i + 1], lo, cfg["act_dtype"])
+        orc_py.lib().orc_kv_free(okv)
+
+
+def test_graph_replay_stops_at_the_cache_capacity(device):
+    """bz_decode_graph_replay past the capacity the step was captured over would write K/V out of bounds; it must refuse"""
+    model = synth.make_llama("tiny-awq", max_seq_len=24)
+    cfg = model["config"]
+    lm = runtime.LoadedModel.from_synth(device, model)
+    kv = runtime.LayeredKvCache(device, cfg["n_layers"], 1, cfg["n_kv_heads"], 8, cfg["max_seq_len"], cfg["head_dim"], _kv_dt(cfg))
+    p = synth.prompt_tokens(20, cfg["vocab"], seed=3)
+    lg = lm.forward_with_kv_cache(p, kv, 0)
+    g = runtime.DecodeGraph(lm, kv)
+    with pytest.raises(L.BlazrHipError):
+        g.seed_next_token(1, 24)                        # position == capacity
+    g.seed_next_token(int(lg.to_numpy()[0].argmax()), 20)
+    for _ in range(4):                                  # positions 20..23
+        g.replay()
+    with pytest.raises(L.BlazrHipError):
+        g.replay()                                      # position 24 does not exist
+    assert g.read_token(3) >= 0
+    # paged: capacity = max_blocks * block_size
+    pk = runtime.LayeredPagedKvCache(device, cfg["n_layers"], 4, 4, cfg["n_kv_heads"], cfg["head_dim"], _kv_dt(cfg))
+    pk.set_blocks([2, 0])
+    lm.forward_with_paged_kv_cache(p[:6], pk, pk.compute_slot_mapping(0, 6), pk.block_table_device_format(), 6, 0)
+    pk.set_seq_len(6)
+    g2 = runtime.DecodeGraph(lm, pk, max_blocks=2)
+    g2.set_block_table([2, 0])
+    g2.seed_next_token(5, 6)
+    g2.replay(); g2.replay()
+    with pytest.raises(L.BlazrHipError):
+        g2.replay()                                     # position 8 is beyond 2 blocks of 4
+
+
 def test_concurrent_generate_calls_on_one_model(device):
     # scheduler.rs:67 / startup.rs:234-236: several generate() calls share one Executor (one model, one device stream), each with its own cache.
     # A decode step's kernels share the model's workspace, so the library serialises whole steps; results must equal the sequential ones.

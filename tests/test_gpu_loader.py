@@ -100,6 +100,50 @@ def test_loader_errors(device, tmp_path):
         runtime.load_model(device, str(tmp_path / "missing"))
 
 
+def test_lying_quantised_triplets_and_gguf_extents_are_rejected(device, tmp_path):
+    """an AWQ / GPTQ triplet whose shapes disagree, or a GGUF tensor whose offset / extent leaves the file, must fail with an error
+    code -- not read out of bounds and upload neighbouring memory as weights"""
+    import json
+    model = synth.make_llama("tiny-awq")
+    json.dump(W.hf_config(model["config"]), open(tmp_path / "config.json", "w"))
+    base = "model.layers.1.mlp.down_proj"
+    for mutate in (lambda t: t.__setitem__(base + ".scales", t[base + ".scales"][:1]),                 # one group of scales instead of K/128
+                   lambda t: t.__setitem__(base + ".qzeros", t[base + ".qzeros"][:, :4]),              # too few zero-point words
+                   lambda t: t.__setitem__(base + ".qweight", t[base + ".qweight"][:100]),             # K no multiple of the group size
+                   lambda t: t.__setitem__(base + ".scales", t[base + ".scales"].astype(np.float32))): # F32 scales
+        t = W.hf_tensors(model)
+        mutate(t)
+        W.write_safetensors(str(tmp_path / "model.safetensors"), t)
+        with pytest.raises(L.BlazrHipError):
+            runtime.load_model(device, str(tmp_path))
+    gm = synth.make_llama("tiny-gptq", act_order=True, bias=True)
+    d2 = tmp_path / "gptq"
+    d2.mkdir()
+    json.dump(W.hf_config(gm["config"]), open(d2 / "config.json", "w"))
+    for mutate in (lambda t: t.__setitem__(base + ".g_idx", t[base + ".g_idx"][:7]), lambda t: t.__setitem__(base + ".bias", t[base + ".bias"][:3])):
+        t = W.hf_tensors(gm)
+        mutate(t)
+        W.write_safetensors(str(d2 / "model.safetensors"), t)
+        with pytest.raises(L.BlazrHipError):
+            runtime.load_model(device, str(d2))
+    # GGUF: patch one tensor's offset / extent in place
+    qm = synth.make_llama("tiny-q8_0")
+    g = tmp_path / "m.gguf"
+    W.write_gguf(str(g), qm)
+    raw = bytearray(g.read_bytes())
+    name = b"blk.1.ffn_down.weight"
+    at = raw.find(name) + len(name)            # n_dims u32, ne[0] u64, ne[1] u64, type u32, offset u64
+    import struct
+    nd, = struct.unpack_from("<I", raw, at)
+    assert nd == 2
+    for field_off, value in ((at + 4 + 16 + 4, (1 << 64) - 64), (at + 4 + 8, 1 << 39), (at + 4 + 16 + 4, len(raw))):   # wrapping offset, absurd rows, offset past the end
+        bad = bytearray(raw)
+        struct.pack_into("<Q", bad, field_off, value)
+        (tmp_path / "bad.gguf").write_bytes(bytes(bad))
+        with pytest.raises(L.BlazrHipError):
+            runtime.load_model(device, str(tmp_path / "bad.gguf"))
+
+
 def test_bz_run_cpp_driver_generates_the_same_ids(device, tmp_path):
     # tools/bz_run.cpp: the C ABI driven from compiled C++ (no Python in that process), cli/run.rs restated around the hot path
     import os, subprocess

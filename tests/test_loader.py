@@ -229,6 +229,57 @@ def test_safetensors_malformed_files_fail_loudly(tmp_path):
         runtime.safetensors_describe(str(f))
 
 
+def test_safetensors_lying_headers_are_rejected(tmp_path):
+    """sizes in the header are not trusted -- byte range != dtype x shape, absurd / negative / fractional dimensions, overflowing
+    products (the safetensors crate the reference uses rejects these files: TensorInvalidInfo / ValidationOverflow)"""
+    f = tmp_path / "model.safetensors"
+
+    def write(entry, data=b"\0" * 64):
+        hdr = json.dumps({"x": entry}).encode()
+        f.write_bytes(struct.pack("<Q", len(hdr)) + hdr + data)
+
+    write({"dtype": "F32", "shape": [4], "data_offsets": [0, 16]})
+    assert runtime.safetensors_describe(str(f))["tensors"]["x"]["bytes"] == 16      # the honest file passes
+    for entry in ({"dtype": "F32", "shape": [4096, 4096], "data_offsets": [0, 16]},             # 16 bytes claimed to be a 64 MiB matrix
+                  {"dtype": "F16", "shape": [4], "data_offsets": [0, 16]},                      # twice the bytes the shape needs
+                  {"dtype": "F32", "shape": [-4], "data_offsets": [0, 16]},
+                  {"dtype": "F32", "shape": [2.5], "data_offsets": [0, 16]},
+                  {"dtype": "F32", "shape": [1 << 40, 1 << 40], "data_offsets": [0, 16]},       # product overflows 64 bits
+                  {"dtype": "F32", "shape": ["4"], "data_offsets": [0, 16]},
+                  {"dtype": "F32", "shape": [4], "data_offsets": [-16, 0]},
+                  {"dtype": "F32", "shape": [4], "data_offsets": [16, 0]}):
+        write(entry)
+        with pytest.raises(L.BlazrHipError):
+            runtime.safetensors_describe(str(f))
+    # a number that runs to the very end of the mapped header (no terminating NUL behind it) parses from a bounded copy
+    hdr = b'{"x": {"dtype": "F32", "shape": [4], "data_offsets": [0, 16]}}'
+    f.write_bytes(struct.pack("<Q", len(hdr)) + hdr + b"\0" * 16)
+    assert runtime.safetensors_describe(str(f))["tensors"]["x"]["shape"] == [4]
+    # names with quotes / backslashes / control characters come back as valid JSON
+    hdr = json.dumps({'we"ird\\na\tme': {"dtype": "F32", "shape": [4], "data_offsets": [0, 16]}}).encode()
+    f.write_bytes(struct.pack("<Q", len(hdr)) + hdr + b"\0" * 16)
+    assert list(runtime.safetensors_describe(str(f))["tensors"]) == ['we"ird\\na\tme']
+
+
+def test_gguf_lying_headers_are_rejected(tmp_path):
+    model = synth.make_llama("tiny-q8_0")
+    path = tmp_path / "m.gguf"
+    W.write_gguf(str(path), model)
+    cfg, info = runtime.config_from_gguf(str(path))
+    assert info["n_tensors"] > 0
+    raw = path.read_bytes()
+    bad = tmp_path / "bad.gguf"
+    bad.write_bytes(raw[:200])                                              # truncated inside the metadata
+    with pytest.raises(L.BlazrHipError):
+        runtime.config_from_gguf(str(bad))
+    W.write_gguf(str(bad), model, extra_kv=[("general.alignment", W.GG_U32, 48)])   # not a power of two
+    with pytest.raises(L.BlazrHipError):
+        runtime.config_from_gguf(str(bad))
+    W.write_gguf(str(bad), model, extra_kv=[("general.alignment", W.GG_U32, 1 << 20)])
+    with pytest.raises(L.BlazrHipError):
+        runtime.config_from_gguf(str(bad))
+
+
 # ---- GGUF container + metadata (loader/gguf.rs:101-306) -----------------------------------------------------------------------------------------
 def test_gguf_metadata_to_config(tmp_path):
     model = synth.make_llama("tiny-q4km")
