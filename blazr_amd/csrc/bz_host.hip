@@ -1411,7 +1411,7 @@ static int llama_step(bz_model* m, const StepIO& io) {
     pf.eps = c.rms_eps; pf.H = H; pf.act = act;
     VSrc dn;
     static const bool no_mlp_fuse = getenv("BZ_NO_MLP_FUSION") != nullptr;
-    if (!no_mlp_fuse && Ld.gateup.parts.size() == 1 && Ld.down.parts.size() == 1 && bzk_mlp_fusable(Ld.gateup.parts[0], Ld.down.parts[0], H, I)) {
+    if (!no_mlp_fuse && act == BZ_F16 && Ld.gateup.parts.size() == 1 && Ld.down.parts.size() == 1 && bzk_mlp_fusable(Ld.gateup.parts[0], Ld.down.parts[0], H, I)) {
       // norm + gate/up + SiLU*up + down in one launch (same ring protocol as one GEMV launch)
       const int rz = (rs.ri + 1) % 3;
       BZ_TRY(bzk_mlp_q4g(st, Ld.gateup.parts[0], Ld.down.parts[0], H, I, pf, m->ring[rs.ri], rs.dirty[rz] > 0 ? m->ring[rz] : nullptr, rs.dirty[rz]));
@@ -2155,6 +2155,59 @@ extern "C" int bz_tune_gemv(bz_device* dev, int N, int K, int gw, int mode, int 
   double tot = 0; int n = 0;
   for (auto& r : sink.recs) { float ms = 0.f; if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) { tot += ms; n++; } hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
   *avg_us = n ? 1e3 * tot / n : 0.0;
+  for (void* q : bufs) hipFree(q);
+  return rc;
+  BZ_API_END
+}
+
+// Tuning aid for the fused MLP kernel alone: synthetic gate/up [2I,H] and down [H,I] int4 weights in `nbuf` rotating sets (cold HBM), the
+// real launcher, mean dispatch time; stamps_out (optional, 2 x 16 x 16 values): the diagnostic build's per-wave s_memrealtime stamps
+// (100 MHz) of workgroup 0 and workgroup 113, relative to the earliest stamp of each workgroup.
+extern "C" int bz_tune_mlp(bz_device* dev, int H, int I, int nbuf, int iters, int flags, double* avg_us, long long* stamps_out) {
+  BZ_API_BEGIN
+  if (!dev || !avg_us || (H != 2048 && H != 4096) || I % 128 || nbuf <= 0 || iters <= 0) BZ_FAIL(BZ_E_INVALID, "tune_mlp: bad argument");
+  BZ_HIP(hipSetDevice(dev->id));
+  hipStream_t st = dev->stream;
+  std::vector<void*> bufs;
+  int rc = BZ_OK;
+  auto alloc = [&](size_t bytes, void** p) { if (hipMalloc(p, bytes) != hipSuccess) { rc = BZ_E_OOM; *p = nullptr; } else bufs.push_back(*p); };
+  auto mk = [&](int N, int K, LinearDev& L, unsigned seed) {
+    const size_t G = (size_t)K / 128, wb = (size_t)N * K / 2, sb = (size_t)N * G * 2, zb = (size_t)N * G;
+    void *w = nullptr, *s2 = nullptr, *z = nullptr;
+    alloc(wb, &w); alloc(sb, &s2); alloc(zb, &z);
+    if (rc != BZ_OK) return;
+    hipLaunchKernelGGL(k_fill_u32, dim3(2048), dim3(256), 0, st, (uint32_t*)w, wb / 4, seed);
+    hipMemsetAsync(s2, 0x1c, sb, st); hipMemsetAsync(z, 8, zb, st);
+    L.kind = LK_Q4G; L.N = N; L.K = K; L.gs = 128; L.w = w; L.scales = s2; L.zeros = z; L.algo_bytes = wb + sb + zb / 2;
+  };
+  std::vector<LinearDev> GU(nbuf), DN(nbuf);
+  for (int b = 0; b < nbuf && rc == BZ_OK; b++) { mk(2 * I, H, GU[b], 17u * b + 1u); mk(H, I, DN[b], 29u * b + 3u); }
+  void *src = nullptr, *acc = nullptr, *hin = nullptr, *hout = nullptr, *nw = nullptr, *stp = nullptr;
+  alloc((size_t)H * 8, &src); alloc((size_t)H * 8, &acc); alloc((size_t)H * 4, &hin); alloc((size_t)H * 4, &hout); alloc((size_t)H * 4, &nw); alloc(2 * 16 * 16 * 8, &stp);
+  if (rc != BZ_OK) { for (void* p : bufs) hipFree(p); BZ_FAIL(BZ_E_OOM, "tune_mlp: out of memory"); }
+  hipLaunchKernelGGL(k_fill_u32, dim3(64), dim3(256), 0, st, (uint32_t*)src, (size_t)H * 2, 5u);
+  hipMemsetAsync(hin, 0x3c, (size_t)H * 4, st); hipMemsetAsync(nw, 0x3c, (size_t)H * 4, st); hipMemsetAsync(acc, 0, (size_t)H * 8, st); hipMemsetAsync(stp, 0, 2 * 16 * 16 * 8, st);
+  Pro p{};
+  p.mode = PRO_NORM; p.act = BZ_F16; p.eps = 1e-5f; p.src = VSrc{src, 1}; p.h_in = (float*)hin; p.h_out = (float*)hout; p.norm_w = (float*)nw; p.H = H; p.dbg = flags;
+  p.stamps = stamps_out ? (long long*)stp : nullptr;
+  BzTimingSink sink;
+  for (int i = 0; i < iters + 2 && rc == BZ_OK; i++) {
+    if (i == 2) bzk_set_timing_sink(&sink);
+    rc = bzk_mlp_q4g(st, GU[i % nbuf], DN[i % nbuf], H, I, p, (long long*)acc, nullptr, 0);
+  }
+  bzk_set_timing_sink(nullptr);
+  hipStreamSynchronize(st);
+  double tot = 0; int n = 0;
+  for (auto& r : sink.recs) { float ms = 0.f; if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) { tot += ms; n++; } hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+  *avg_us = n ? 1e3 * tot / n : 0.0;
+  if (stamps_out) {
+    hipMemcpy(stamps_out, stp, 2 * 16 * 16 * 8, hipMemcpyDeviceToHost);
+    for (int b = 0; b < 2; b++) {
+      long long t0 = INT64_MAX;
+      for (int i = 0; i < 256; i++) if (stamps_out[b * 256 + i] > 0) t0 = std::min(t0, stamps_out[b * 256 + i]);
+      for (int i = 0; i < 256; i++) if (stamps_out[b * 256 + i] > 0) stamps_out[b * 256 + i] -= t0; else stamps_out[b * 256 + i] = -1;
+    }
+  }
   for (void* q : bufs) hipFree(q);
   return rc;
   BZ_API_END

@@ -371,26 +371,32 @@ __device__ __forceinline__ void xfinish(const Pro& p, int KR, const XRegs<MODE, 
 // ---------------------------------------------------------------------------------------------------------
 #define XQ_NP 6
 
-// one thread: 8 consecutive activations -> one word per plane (+ the plane sums); am = group maximum (already reduced)
+// one thread: 8 consecutive activations -> one word per plane (+ the plane sums); am = group maximum (already reduced).
+// The balanced digits of xi are the unsigned base-16 digits of xi + 0x888888 minus 8, i.e. in two's complement simply
+// code = (xi + 0x888888) ^ 0x888888: nibble p of the 24-bit code IS the stored nibble of plane p.  What remains is an 8 x 6 nibble
+// transpose: pairs (k, k + 4) are interleaved into bytes with three mask ops, the bytes gathered per plane with V_PERM_B32.
 __device__ __forceinline__ void xq_split8(const float (&v)[8], float am, unsigned (&w)[XQ_NP], int (&sp)[XQ_NP], float& cscale) {
   const unsigned eb = (__float_as_uint(am) >> 23) & 255u;               // biased exponent of the group maximum
   const bool live = eb >= 24u && eb < 255u;
   const float inv = live ? __uint_as_float((275u - eb) << 23) : 0.f;    // 2^(21 - (eb - 127))
   cscale = live ? __uint_as_float((eb - 21u) << 23) : 0.f;              // its reciprocal
+  unsigned code[8];
 #pragma unroll
-  for (int p = 0; p < XQ_NP; p++) { w[p] = 0; sp[p] = 0; }
+  for (int i = 0; i < 8; i++) code[i] = ((unsigned)((int)rintf(v[i] * inv) + 0x888888)) ^ 0x888888u;
+  unsigned E[4], O[4];          // byte k of E[i] / O[i]: plane 2k / 2k + 1, k offsets i (low nibble) and i + 4 (high nibble)
 #pragma unroll
-  for (int i = 0; i < 8; i++) {
-    int r = (int)rintf(v[i] * inv);
-    const int sh = 4 * (2 * (i & 3) + (i >> 2));                         // k offset i -> nibble 2 (i & 3) + (i >> 2)
-#pragma unroll
-    for (int p = 0; p < XQ_NP; p++) {
-      const int n = ((r + 8) & 15) - 8;
-      r = (r - n) >> 4;
-      w[p] |= ((unsigned)n & 15u) << sh;
-      sp[p] += n;
-    }
+  for (int i = 0; i < 4; i++) {
+    E[i] = ((code[i + 4] & 0x0F0F0Fu) << 4) | (code[i] & 0x0F0F0Fu);
+    O[i] = ((code[i] >> 4) & 0x0F0F0Fu) | (code[i + 4] & 0xF0F0F0u);
   }
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const unsigned sel = 0x0c0c0000u | ((4u + k) << 8) | (unsigned)k;   // [lo.byte k, hi.byte k, 0, 0]
+    w[2 * k] = __builtin_amdgcn_perm(E[1], E[0], sel) | (__builtin_amdgcn_perm(E[3], E[2], sel) << 16);
+    w[2 * k + 1] = __builtin_amdgcn_perm(O[1], O[0], sel) | (__builtin_amdgcn_perm(O[3], O[2], sel) << 16);
+  }
+#pragma unroll
+  for (int p = 0; p < XQ_NP; p++) sp[p] = __builtin_amdgcn_sdot8((int)w[p], 0x11111111, 0, false);   // sum of the eight signed nibbles
 }
 
 template <int NTH>
@@ -530,27 +536,48 @@ __device__ __forceinline__ long long d2fix(double p) { return __double2ll_rn(p *
 // down_proj is a sum over the intermediate dimension, so the slabs combine through the fixed-point accumulator.
 // One launch streams 81 % of a layer's bytes with one fused-norm prologue per block.
 // ---------------------------------------------------------------------------------------------------------
-#ifndef MLP_DEPTH
-#define MLP_DEPTH 2
-#endif
-template <int FIX, int GPW, int TPW, int NW>   // NW waves per block; GPW k-groups per wave (gate/up), TPW output tiles per wave (down)
+template <int ACT> __device__ __forceinline__ float round_t(float x) {
+  if (ACT == BZ_F16) return __half2float(__float2half_rn(x));
+  if (ACT == BZ_BF16) return bf16_round(x);
+  return x;
+}
+#define DPP_ROR4 0x124   // row_ror:4 / row_ror:8: rotate within a 16-lane row (sums that must not mix even and odd lanes)
+#define DPP_ROR8 0x128
+struct OpOr { __device__ __forceinline__ static int f(int a, int b) { return a | b; } };
+
+// Structure of the launch (per-wave stamps of the diagnostic build, profiles/r02_mlp_stamps_*.txt):
+//  * a CU keeps ~40 KiB of HBM loads in flight; a wave that asks for more STALLS AT ISSUE -- in program order, so whatever it would do
+//    next waits too.  Round 1 issued 8 KiB of weights per wave ahead of the norm: waves 10..15 sat in the issue queue until 4.4 us, the
+//    block-wide sum of squares (every wave held 1/16 of the row) was complete at 5.7 us and the planes at 7.8 us; asking for little
+//    before the norm instead (one chunk per wave) finished the planes at 4 us but left HBM idle from 1.5 to 4 us -- same total.
+//    Now the waves have ROLES: the first half ("streamers") request their whole gate / up range at entry and sit in the issue queue,
+//    which is exactly what keeps HBM busy from 0.2 us on; the second half holds the row (an octet per thread), does the norm and builds
+//    the planes undisturbed, and starts its own stream afterwards.  The two halves meet through two LDS counters (sum of squares
+//    complete; planes published) instead of workgroup barriers, which a streamer could only reach after its issue stall.
+//  * the row never goes through LDS as f32: a thread normalises its eight elements in registers and builds the six plane words.
+//  * the tail (sum of the waves' partials, SiLU * up, its 64-value quantisation) runs in ONE wave between two barriers instead of four.
+__device__ __forceinline__ void lds_wait_count(volatile unsigned* cnt, unsigned n) {
+  while (*cnt < n) __builtin_amdgcn_s_sleep(1);
+}
+template <int FIX, int GPW, int TPW, int NW, int ACT, int DIAG = 0>   // NW waves per block; GPW k-groups per wave (gate/up), TPW output tiles per wave (down); DIAG: stamp build
 __global__ __launch_bounds__(NW * 64) void k_mlp_q4g(const uint4* __restrict__ Wgu, const __half* __restrict__ Sgu, const unsigned char* __restrict__ Zgu,
                                                  const float* __restrict__ bgu, const uint4* __restrict__ Wd, const __half* __restrict__ Sd,
                                                  const unsigned char* __restrict__ Zd, const float* __restrict__ bd, int H, int I, Pro pro,
                                                  long long* acc, long long* zero_buf, int zero_n) {
+  static_assert(GPW == 2, "a wave owns two 128-k groups of gate / up");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* xs = (float*)smem;                   // [H]
-  uint4* xpl = (uint4*)(xs + H);              // [H/32 chunks][6 planes]: 3 H bytes
+  uint4* xpl = (uint4*)smem;                  // [H/32 chunks][6 planes]: 3 H bytes
   const int G = H >> 7;
   int4* gpar = (int4*)(xpl + (H >> 5) * XQ_NP);   // [2G]
-  constexpr int NTH = NW * 64;
+  constexpr int NTH = NW * 64, NP = NW / 2;   // NP prologue waves (the second half)
   double* part = (double*)(gpar + 2 * G);     // [NW][128]
-  float* av = (float*)(part + NW * 128);      // [64]
-  uint4* apl = (uint4*)(av + 64);             // [2 chunks][6 planes]
+  uint4* apl = (uint4*)(part + NW * 128);     // [2 chunks][6 planes]
   int4* apar = (int4*)(apl + 2 * XQ_NP);      // [2]
-  float* red = (float*)(apar + 2);            // [NW]
+  double* dred = (double*)(apar + 2);         // [NP]
+  volatile unsigned* cnt = (volatile unsigned*)(dred + NW);   // [0]: waves whose sum of squares is stored, [1]: waves whose planes are stored
 
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const bool prolog = wave >= NP;             // wave-uniform role
   const int sl = blockIdx.x;                  // intermediate slice: columns [64 sl, 64 sl + 64)
   const int NTI = I >> 6;                     // gate tile = sl, up tile = NTI + sl
   const int gbeg = wave * GPW;                // G == NW * GPW
@@ -558,154 +585,195 @@ __global__ __launch_bounds__(NW * 64) void k_mlp_q4g(const uint4* __restrict__ W
   const int GD = I >> 7, gd = sl >> 1;        // down's quantisation group of these 64 k
   // all kernel arguments in ONE scalar-load batch (the compiler otherwise fetches late-used ones lazily: a ~0.3 us round trip each time)
   asm volatile("" :: "s"(zero_buf), "s"(zero_n), "s"(acc), "s"(pro.h_in), "s"(pro.src.p), "s"(pro.norm_w), "s"(pro.h_out), "s"(pro.H),
-               "s"(pro.act), "s"(H), "s"(I), "s"(Wgu), "s"(Sgu), "s"(Zgu), "s"(Wd), "s"(Sd), "s"(Zd));
-  zero_duty<NTH>(zero_buf, zero_n);
-
-  // (1) prologue loads: full-H pass, 4 contiguous elements per thread per 2048 (h, deferred residual, norm weight) --
-  //     loads only, unconditional (H == 2048 * NJ), arithmetic after the weight loads have been issued
-  constexpr int NJ = (GPW * NW * 128) / (NTH * 4);   // H / (4 NTH): whole passes of 4 elements per thread
-  const bool hasprev = pro.src.p != nullptr;
-  const void* prevp = hasprev ? pro.src.p : (const void*)pro.h_in;
-  float hv[NJ][4];
-  typename RawT<FIX>::T pv[NJ][4];
-  float4 nw[NJ];
+               "s"(H), "s"(I), "s"(Wgu), "s"(Sgu), "s"(Zgu), "s"(Wd), "s"(Sd), "s"(Zd));
+  // diagnostic instantiation only (bz_tune_mlp): s_memrealtime (100 MHz) per wave at phase boundaries, kept in scalar registers and stored
+  // once at the end (a store per stamp would sit in every later vmcnt wait)
+  unsigned long long T[15];
+#define MSTAMP(i) do { if (DIAG) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(T[i]) :: "memory"); \
+    __builtin_amdgcn_sched_barrier(0); } } while (0)
 #pragma unroll
-  for (int j = 0; j < NJ; j++) {
-    const int i = j * (NTH * 4) + tid * 4;
-    const float4 h4 = *(const float4*)(pro.h_in + i);
-    hv[j][0] = h4.x; hv[j][1] = h4.y; hv[j][2] = h4.z; hv[j][3] = h4.w;
-#pragma unroll
-    for (int e = 0; e < 4; e++) pv[j][e] = vraw<FIX>(prevp, (FIX || hasprev) ? i + e : 0);
-    nw[j] = *(const float4*)(pro.norm_w + i);
-  }
-  __builtin_amdgcn_sched_barrier(0);   // keep the prologue's loads AHEAD of the weight stream (vmcnt is in-order)
-  // (2) gate + up weights of this wave's k-range, streamed two groups deep (8 KiB per matrix per wave in flight).  Measured with
-  //     scripts/stream_probe.hip on this grid: 6.2 TB/s with 8-16 KiB in flight per wave, 4.9 TB/s with 32 KiB -- issuing the whole
-  //     k-range up front (the first version of this kernel) over-subscribes the memory system.
+  for (int i = 0; i < 15; i++) T[i] = 0;
+  MSTAMP(0);
+  static_assert(GPW * NW * 128 == NP * 64 * 8, "the prologue half covers the row with eight elements per thread");
   const uint4* wg = Wgu + ((size_t)sl * (H >> 5) + gbeg * 4) * 64 + lane;
   const uint4* wu = Wgu + ((size_t)(NTI + sl) * (H >> 5) + gbeg * 4) * 64 + lane;
-  constexpr int ND = (GPW >= 3 && MLP_DEPTH == 3) ? 3 : 2;   // groups in flight per wave
-  uint4 Ag[ND][4], Au[ND][4];
+  uint4 Ag[8], Au[8];                  // chunk c of this wave's 256-k range: group c >> 2
+  if (tid == 0) { cnt[0] = 0; cnt[1] = 0; }
+  if (prolog) {
+    // (1p) prologue loads: an octet per thread -- h, deferred residual, norm weight; then the head of this wave's stream (2 KiB: no stall)
+    const bool hasprev = pro.src.p != nullptr;
+    const void* prevp = hasprev ? pro.src.p : (const void*)pro.h_in;
+    const int i0 = (tid - NP * 64) * 8;
+    const float4 ha = *(const float4*)(pro.h_in + i0), hb = *(const float4*)(pro.h_in + i0 + 4);
+    typename RawT<FIX>::T pv[8];
 #pragma unroll
-  for (int c = 0; c < 4; c++) { Ag[0][c] = ldnt(wg + c * 64); Au[0][c] = ldnt(wu + c * 64); }
-  if (GPW > 1 && NW == 8) {
+    for (int e = 0; e < 8; e++) pv[e] = vraw<FIX>(prevp, (FIX || hasprev) ? i0 + e : 0);
+    const float4 na = *(const float4*)(pro.norm_w + i0), nb = *(const float4*)(pro.norm_w + i0 + 4);
+    __builtin_amdgcn_sched_barrier(0);   // the prologue's loads go AHEAD of the weight stream (vmcnt is in-order)
+    Ag[0] = ldnt(wg); Au[0] = ldnt(wu);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();                     // the counters are zero (nobody waits for data here)
+    MSTAMP(1);
+    // (2p) h' = R(h + R(prev)), sum of squares (exact: double), 1 / rms
+    float v[8] = {ha.x, ha.y, ha.z, ha.w, hb.x, hb.y, hb.z, hb.w};
+    if (hasprev) {
 #pragma unroll
-    for (int c = 0; c < 4; c++) { Ag[1][c] = ldnt(wg + (4 + c) * 64); Au[1][c] = ldnt(wu + (4 + c) * 64); }
-  if (ND == 3) {
+      for (int e = 0; e < 8; e++) v[e] = round_t<ACT>(v[e] + round_t<ACT>(FIX ? fix2f((long long)pv[e]) : (float)pv[e]));
+    }
+    if (blockIdx.x == 0 && pro.h_out) { *(float4*)(pro.h_out + i0) = make_float4(v[0], v[1], v[2], v[3]); *(float4*)(pro.h_out + i0 + 4) = make_float4(v[4], v[5], v[6], v[7]); }
+    double ssd = 0.0;
 #pragma unroll
-    for (int c = 0; c < 4; c++) { Ag[ND - 1][c] = ldnt(wg + (8 + c) * 64); Au[ND - 1][c] = ldnt(wu + (8 + c) * 64); }
+    for (int e = 0; e < 8; e += 2) ssd += (double)(v[e] * v[e]) + (double)(v[e + 1] * v[e + 1]);
+    ssd = wave_sum_d(ssd);
+    if (lane == 0) { dred[wave - NP] = ssd; __builtin_amdgcn_s_waitcnt(0xc07f); atomicAdd((unsigned*)&cnt[0], 1u); }
+    lds_wait_count(&cnt[0], NP);
+    ssd = ((dred[0] + dred[1]) + (dred[2] + dred[3]));
+    if (NP == 8) ssd += ((dred[4] + dred[5]) + (dred[6] + dred[7]));
+    const float ss = (float)ssd;                  // the rounded exact sum of squares (oracle: orc_rms_norm)
+    const float rs = 1.0f / sqrtf(ss / (float)H + pro.eps);
+    MSTAMP(2);
+    // (3p) x = R(w R(h' rs)) in registers -> the octet's six plane words, the group's sums (16 threads)
+    const float nwv[8] = {na.x, na.y, na.z, na.w, nb.x, nb.y, nb.z, nb.w};
+    float x[8];
+    float am = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; e++) { x[e] = round_t<ACT>(nwv[e] * round_t<ACT>(v[e] * rs)); am = fmaxf(am, fabsf(x[e])); }
+    am = grp_reduce<16, OpMax>(am);
+    unsigned w[XQ_NP]; int sp[XQ_NP]; float cs;
+    xq_split8(x, am, w, sp, cs);
+#pragma unroll
+    for (int p = 0; p < XQ_NP; p++) sp[p] = grp_reduce<16, OpAdd>(sp[p]);
+    const int oct = tid - NP * 64;                                        // octet index in the row: chunk oct >> 2, weight word oct & 3
+    unsigned* plw = (unsigned*)xpl + ((oct >> 2) * XQ_NP) * 4 + (oct & 3);
+#pragma unroll
+    for (int p = 0; p < XQ_NP; p++) plw[p * 4] = w[p];
+    if ((lane & 15) == 0) {
+      gpar[2 * (oct >> 4)] = make_int4(__float_as_int(cs), sp[0], sp[1], sp[2]);
+      gpar[2 * (oct >> 4) + 1] = make_int4(sp[3], sp[4], sp[5], 0);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);                                   // lgkmcnt(0): this wave's LDS stores are done
+    if (lane == 0) atomicAdd((unsigned*)&cnt[1], 1u);
+    MSTAMP(4);
+    // (4p) the rest of this wave's stream
+#pragma unroll
+    for (int c = 1; c < 8; c++) { Ag[c] = ldnt(wg + c * 64); Au[c] = ldnt(wu + c * 64); }
+  } else {
+    // (1s) streamers: the whole gate / up range of the wave goes out now (16 KiB; the wave sits in the issue queue, HBM stays busy)
+    __syncthreads();                     // the counters are zero
+#pragma unroll
+    for (int c = 0; c < 8; c++) { Ag[c] = ldnt(wg + c * 64); Au[c] = ldnt(wu + c * 64); }
+    MSTAMP(1);
+    zero_duty<NP * 64>(zero_buf, zero_n);   // (threads 0 .. NP*64-1 are exactly the streamers)
+    MSTAMP(2);
+    MSTAMP(4);
   }
-  }
-  float sg[GPW], su[GPW]; int zg[GPW], zu[GPW];
+  float sg[2], su[2]; int zg[2], zu[2];
 #pragma unroll
-  for (int b = 0; b < GPW; b++) {
+  for (int b = 0; b < 2; b++) {
     const size_t ig = ((size_t)sl * G + gbeg + b) * 64 + lane, iu = ((size_t)(NTI + sl) * G + gbeg + b) * 64 + lane;
     sg[b] = __half2float(Sgu[ig]); zg[b] = Zgu[ig]; su[b] = __half2float(Sgu[iu]); zu[b] = Zgu[iu];
   }
-  // (3) finish the norm
-  double ssd = 0.0;
-#pragma unroll
-  for (int j = 0; j < NJ; j++) {
-    const int i = j * (NTH * 4) + tid * 4;
-    if (hasprev) {
-#pragma unroll
-      for (int e = 0; e < 4; e++) hv[j][e] = round_act(hv[j][e] + vcvt<FIX>(pv[j][e], pro.act), pro.act);
-    }
-    ssd += ((double)(hv[j][0] * hv[j][0]) + (double)(hv[j][1] * hv[j][1])) + ((double)(hv[j][2] * hv[j][2]) + (double)(hv[j][3] * hv[j][3]));
-    if (blockIdx.x == 0 && pro.h_out) *(float4*)(pro.h_out + i) = make_float4(hv[j][0], hv[j][1], hv[j][2], hv[j][3]);
-  }
-  ssd = wave_sum_d(ssd);
-  double* dred = (double*)red;
-  if (lane == 0) dred[wave] = ssd;
-  __syncthreads();
-  ssd = ((dred[0] + dred[1]) + (dred[2] + dred[3])) + ((dred[4] + dred[5]) + (dred[6] + dred[7]));
-  if (NW == 16) ssd += ((dred[8] + dred[9]) + (dred[10] + dred[11])) + ((dred[12] + dred[13]) + (dred[14] + dred[15]));
-  const float ss = (float)ssd;                  // the rounded exact sum of squares (oracle: orc_rms_norm)
-  const float rs = 1.0f / sqrtf(ss / (float)H + pro.eps);
-#pragma unroll
-  for (int j = 0; j < NJ; j++) {
-    const int i = j * (NTH * 4) + tid * 4;
-    *(float4*)(xs + i) = make_float4(round_act(nw[j].x * round_act(hv[j][0] * rs, pro.act), pro.act), round_act(nw[j].y * round_act(hv[j][1] * rs, pro.act), pro.act),
-                                     round_act(nw[j].z * round_act(hv[j][2] * rs, pro.act), pro.act), round_act(nw[j].w * round_act(hv[j][3] * rs, pro.act), pro.act));
-  }
-  __syncthreads();
-  quant_x128<NTH>(xs, H, xpl, gpar);
-  __syncthreads();
-  if (GPW > 1 && NW == 16) {   // 16 waves: the second group goes out only now, so that no more than 8 KiB per wave (128 KiB per CU) is in flight at a time
-#pragma unroll
-    for (int c = 0; c < 4; c++) { Ag[1][c] = ldnt(wg + (4 + c) * 64); Au[1][c] = ldnt(wu + (4 + c) * 64); }
-  }
-
-  // (4) gate / up partial dot products over this wave's k-groups; group b+2 is requested as soon as group b's registers are free,
-  //     and the down slab (16 KiB per wave) goes out behind the last gate/up group, so the stream never pauses
+  lds_wait_count(&cnt[1], NP);           // the planes of the whole row are in LDS
+  // (5) gate / up dots chunk by chunk (the compiler counts the waits); the down slab goes out behind the first group
   double yg = 0.0, yu = 0.0;
   uint4 D[TPW][2];
   float sd[TPW]; int zd[TPW];
 #pragma unroll
-  for (int b = 0; b < GPW; b++) {
-    q4g_consume2(Ag[b % ND], Au[b % ND], gbeg + b, xpl, gpar, sg[b], zg[b], su[b], zu[b], yg, yu);
-    if (b + ND < GPW) {
+  for (int b = 0; b < 2; b++) {
+    if (b == 0) MSTAMP(5);
+    if (b == 1) MSTAMP(7);
+    int Da[XQ_NP] = {0, 0, 0, 0, 0, 0}, Db[XQ_NP] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
-      for (int c = 0; c < 4; c++) { Ag[b % ND][c] = ldnt(wg + ((b + ND) * 4 + c) * 64); Au[b % ND][c] = ldnt(wu + ((b + ND) * 4 + c) * 64); }
-    }
-    if (b >= GPW - 2) {     // the down slab follows in two halves, one behind each of the last two gate/up groups: never more than 16 KiB per wave in flight
-      const int q0 = (b == GPW - 2) ? 0 : TPW / 2, q1 = (b == GPW - 2) ? TPW / 2 : TPW;
+    for (int c = 0; c < 4; c++) q4_chunk2(Ag[b * 4 + c], Au[b * 4 + c], xpl + ((gbeg + b) * 4 + c) * XQ_NP, Da, Db);
+    const int4 g1 = gpar[2 * (gbeg + b)], g2 = gpar[2 * (gbeg + b) + 1];
+    yg += q4_term(Da, g1, g2, sg[b], zg[b]);
+    yu += q4_term(Db, g1, g2, su[b], zu[b]);
+    if (b == 0) MSTAMP(6);
+    if (b == 1) MSTAMP(8);
+    if (b == 0) {
 #pragma unroll
       for (int q = 0; q < TPW; q++) {
-        if (q >= q0 && q < q1) {
-          const uint4* wp = Wd + ((size_t)(tbeg + q) * (I >> 5) + 2 * sl) * 64 + lane;
-          D[q][0] = ldnt(wp); D[q][1] = ldnt(wp + 64);
-          const size_t si = ((size_t)(tbeg + q) * GD + gd) * 64 + lane;
-          sd[q] = __half2float(Sd[si]); zd[q] = Zd[si];
-        }
+        const uint4* wp = Wd + ((size_t)(tbeg + q) * (I >> 5) + 2 * sl) * 64 + lane;
+        D[q][0] = ldnt(wp); D[q][1] = ldnt(wp + 64);
+        const size_t si = ((size_t)(tbeg + q) * GD + gd) * 64 + lane;
+        sd[q] = __half2float(Sd[si]); zd[q] = Zd[si];
       }
     }
   }
+  MSTAMP(9);
   part[wave * 128 + lane] = yg;
   part[wave * 128 + 64 + lane] = yu;
   __syncthreads();
-  float* gu = (float*)(xs);                    // [128] rounded gate | up (the activation image is dead by now)
-  if (tid < 128) {
-    double t = 0.0;                            // the waves' k-range partials, exact, in a fixed order
+  MSTAMP(10);
+  // (6) wave 0: sum of the waves' k-range partials (exact, fixed order), ONE rounding to f32 (the oracle's definition), + bias, R, SiLU * up,
+  //     and the 64 values' planes -- one value per lane, an octet = 8 lanes
+  if (wave == 0) {
+    double tg = 0.0, tu = 0.0;
 #pragma unroll
-    for (int w2 = 0; w2 < NW; w2++) t += part[w2 * 128 + tid];
-    float tf = (float)t;                       // ONE rounding of the exact dot product to f32 (the oracle's definition)
-    if (bgu) tf += bgu[tid < 64 ? sl * 64 + tid : I + sl * 64 + (tid - 64)];
-    gu[tid] = round_act(tf, pro.act);
+    for (int w2 = 0; w2 < NW; w2++) { tg += part[w2 * 128 + lane]; tu += part[w2 * 128 + 64 + lane]; }
+    float fg = (float)tg, fu = (float)tu;
+    if (bgu) { fg += bgu[sl * 64 + lane]; fu += bgu[I + sl * 64 + lane]; }
+    const float a = round_t<ACT>(round_t<ACT>(silu_f(round_t<ACT>(fg))) * round_t<ACT>(fu));
+    const float am = wave_max(fabsf(a));
+    const unsigned eb = (__float_as_uint(am) >> 23) & 255u;
+    const bool live = eb >= 24u && eb < 255u;
+    const float inv = live ? __uint_as_float((275u - eb) << 23) : 0.f;
+    const float cs = live ? __uint_as_float((eb - 21u) << 23) : 0.f;
+    const unsigned code = ((unsigned)((int)rintf(a * inv) + 0x888888)) ^ 0x888888u;
+    const int o = lane & 7, sh = 4 * (2 * (o & 3) + (o >> 2));                // k offset o -> nibble 2 (o & 3) + (o >> 2)
+    int sp[XQ_NP];
+#pragma unroll
+    for (int p = 0; p < XQ_NP; p++) {
+      const int wv = grp_reduce<8, OpOr>((int)(((code >> (4 * p)) & 15u) << sh));   // the octet's word of plane p, in all of its lanes
+      if (o == 0) ((unsigned*)apl)[((lane >> 5) * XQ_NP + p) * 4 + ((lane >> 3) & 3)] = (unsigned)wv;
+      int t = __builtin_amdgcn_sdot8(wv, 0x11111111, 0, false);                    // the octet's sum (the same in its 8 lanes)
+      t += dpp_get<DPP_ROR8>(t);                                                   // + the other octet of the 16-lane row
+      const bz_u2_t r1 = __builtin_amdgcn_permlane16_swap((unsigned)t, (unsigned)t, false, false);
+      t = (int)r1.x + (int)r1.y;
+      const bz_u2_t r2 = __builtin_amdgcn_permlane32_swap((unsigned)t, (unsigned)t, false, false);
+      sp[p] = (int)r2.x + (int)r2.y;
+    }
+    if (lane == 0) { apar[0] = make_int4(__float_as_int(cs), sp[0], sp[1], sp[2]); apar[1] = make_int4(sp[3], sp[4], sp[5], 0); }
   }
   __syncthreads();
-  if (tid < 64) av[tid] = round_act(round_act(silu_f(gu[tid]), pro.act) * gu[64 + tid], pro.act);
-  __syncthreads();
-  quant_x64(av, apl, apar);
-  __syncthreads();
-  // (5) this wave's down slab
+  MSTAMP(11);
+  // (7) this wave's down slab
 #pragma unroll
   for (int q = 0; q < TPW; q++) {
     double y = 0.0;
     q4g_consume_n<2>(D[q], 0, 0, apl, apar, sd[q], zd[q], y);
     const int n = (tbeg + q) * 64 + lane;
     if (bd != nullptr && sl == 0) y += (double)bd[n];
+    if (q == 0) MSTAMP(12);
     atomicAdd((unsigned long long*)(acc + n), (unsigned long long)d2fix(y));
-  }}
+  }
+  MSTAMP(13);
+  if (DIAG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+  MSTAMP(14);
+  if (DIAG && pro.stamps && lane == 0 && (blockIdx.x == 0 || blockIdx.x == 113)) {
+#pragma unroll
+    for (int i = 0; i < 15; i++) pro.stamps[((blockIdx.x ? 1 : 0) * 16 + wave) * 16 + i] = (long long)((i == 3) ? T[2] : T[i]);
+  }
+#undef MSTAMP
+}
 
-static size_t mlp_smem(int H) { return (size_t)H * 4 + (size_t)H * 3 + (size_t)(H >> 7) * 32 + 16 * 128 * 8 + 64 * 4 + 2 * XQ_NP * 16 + 32 + 64 + 64; }
+static size_t mlp_smem(int H) { return (size_t)H * 3 + (size_t)(H >> 7) * 32 + 16 * 128 * 8 + 2 * XQ_NP * 16 + 32 + 16 * 8 + 64; }   // planes, gpar, part, apl, apar, dred, counters
 
 bool bzk_mlp_fusable(const LinearDev& gu, const LinearDev& dn, int H, int I) {
   return gu.kind == LK_Q4G && dn.kind == LK_Q4G && !gu.perm && !dn.perm && gu.N == 2 * I && gu.K == H && dn.N == H && dn.K == I &&
-         (H == 2048 || H == 4096) && I % 128 == 0 && mlp_smem(H) <= 64 * 1024;
+         (H == 2048 || H == 4096) && I % 128 == 0 && mlp_smem(H) <= 64 * 1024;   // (+ f16 activations: checked by the launcher)
 }
 
 int bzk_mlp_q4g(hipStream_t s, const LinearDev& gu, const LinearDev& dn, int H, int I, const Pro& pro, long long* acc, long long* zero_buf, int zero_n) {
-  if (!bzk_mlp_fusable(gu, dn, H, I)) BZ_FAIL(BZ_E_INVALID, "fused MLP does not apply to this shape");
+  if (!bzk_mlp_fusable(gu, dn, H, I) || pro.act != BZ_F16) BZ_FAIL(BZ_E_INVALID, "fused MLP does not apply to this shape / activation dtype");
   const size_t smem = mlp_smem(H);
   const double bytes = (double)gu.algo_bytes + (double)dn.algo_bytes;
-  static const bool w16 = getenv("BZ_MLP_NW8") == nullptr;   // 16 waves per block with the second gate/up group issued after the quantisation: 24.1 vs 24.4 us
-#define LAUNCH_MLP(FIX, GP, TP, W_) BZ_LAUNCH("mlp_q4g<norm+gate/up+silu+down>", bytes, (k_mlp_q4g<FIX, GP, TP, W_>), dim3(I / 64), dim3(W_ * 64), smem, s, \
+#define LAUNCH_MLP(FIX, GP, TP, W_, DG) BZ_LAUNCH("mlp_q4g<norm+gate/up+silu+down>", bytes, (k_mlp_q4g<FIX, GP, TP, W_, BZ_F16, DG>), dim3(I / 64), dim3(W_ * 64), smem, s, \
     (const uint4*)gu.w, (const __half*)gu.scales, (const unsigned char*)gu.zeros, gu.bias, (const uint4*)dn.w, (const __half*)dn.scales,            \
     (const unsigned char*)dn.zeros, dn.bias, H, I, pro, acc, zero_buf, zero_n)
-  if (H == 4096 && w16) { if (pro.src.fix) LAUNCH_MLP(1, 2, 4, 16); else LAUNCH_MLP(0, 2, 4, 16); }
-  else if (H == 4096) { if (pro.src.fix) LAUNCH_MLP(1, 4, 8, 8); else LAUNCH_MLP(0, 4, 8, 8); }
-  else { if (pro.src.fix) LAUNCH_MLP(1, 2, 4, 8); else LAUNCH_MLP(0, 2, 4, 8); }
+  if (H == 4096 && pro.stamps) LAUNCH_MLP(1, 2, 4, 16, 1);     // diagnostic build (bz_tune_mlp)
+  else if (H == 4096) { if (pro.src.fix) LAUNCH_MLP(1, 2, 4, 16, 0); else LAUNCH_MLP(0, 2, 4, 16, 0); }
+  else { if (pro.src.fix) LAUNCH_MLP(1, 2, 4, 8, 0); else LAUNCH_MLP(0, 2, 4, 8, 0); }
 #undef LAUNCH_MLP
   BZ_HIP(hipGetLastError());
   return BZ_OK;

@@ -280,6 +280,10 @@ int bz_profile_step_ssm(bz_model* m, bz_ssm_state* state, int64_t token, int ite
  * HBM buffers.  mode 0 plain x / 1 fused residual+RMSNorm prologue / 2 SiLU*up prologue; flags are debugging knobs (0). */
 int bz_tune_gemv(bz_device* dev, int N, int K, int groups_per_wg, int mode, int nbuf, int iters, int flags, double* avg_us);
 
+/* the same for the fused MLP kernel (norm + gate/up + SiLU*up + down) on synthetic int4 weights; stamps_out (optional, 2 x 16 x 16 values) receives the
+ * diagnostic build's per-wave phase stamps in 10 ns units */
+int bz_tune_mlp(bz_device* dev, int H, int I, int nbuf, int iters, int flags, double* avg_us, long long* stamps_out);
+
 /* Measured HBM read ceiling of this device, GB/s: a streaming read of `bytes` (rotating buffers beyond the Infinity Cache) with the decode
  * kernels' load pattern and no arithmetic.  bench.py reports roofline fractions against the 8 TB/s spec peak AND against this number
  * (SURVEY.md 8d "record the measured peak on the box and report against both"). */
