@@ -1310,6 +1310,14 @@ static int run_fused(bz_model* m, const FusedLinear& F, Pro pro, RingState& rs, 
   const int ri = rs.ri, rz = (rs.ri + 1) % 3;
   long long* acc = m->ring[ri];
   float* direct = m->dring[ri];
+  if (F.parts.size() == 1 && F.fix_out && bzk_gemv_cols_ok(F.parts[0], pro, act)) {
+    // the whole K inside one workgroup per 64-column tile: finished values, stored directly (no accumulator to fill or to zero for THIS launch;
+    // the ring protocol's zeroing duty for the buffer after next stays)
+    BZ_TRY(bzk_gemv_cols(st, F.parts[0], pro, direct, rs.dirty[rz] > 0 ? m->ring[rz] : nullptr, rs.dirty[rz]));
+    rs.dirty[rz] = 0; rs.dirty[ri] = 0; rs.ri = rz;
+    out->fix = 0; out->p = (const void*)direct;
+    return BZ_OK;
+  }
   for (size_t i = 0; i < F.parts.size(); i++) {
     const LinearDev& L = F.parts[i];
     Pro p = pro; p.perm = L.perm;
@@ -2145,6 +2153,8 @@ extern "C" int bz_tune_gemv(bz_device* dev, int N, int K, int gw, int mode, int 
   else if (mode == 1) { p.mode = PRO_NORM; p.src = VSrc{src, 1}; p.h_in = (float*)hin; p.h_out = (float*)hout; p.norm_w = (float*)nw; p.H = K; }
   else { p.mode = PRO_SILU; p.src = VSrc{src, 1}; p.H = K; }
   BzTimingSink sink;
+  long long* stp = nullptr;
+  if (flags & 16) { p.dbg = 0; if (hipMalloc((void**)&stp, 2 * 12 * 8 * 8) == hipSuccess) { hipMemsetAsync(stp, 0, 2 * 12 * 8 * 8, st); p.stamps = stp; bufs.push_back(stp); } }
   for (int i = 0; i < iters + 2 && rc == BZ_OK; i++) {
     GemvOut o{}; o.acc = (long long*)acc;
     if (i == 2) bzk_set_timing_sink(&sink);
@@ -2152,6 +2162,15 @@ extern "C" int bz_tune_gemv(bz_device* dev, int N, int K, int gw, int mode, int 
   }
   bzk_set_timing_sink(nullptr);
   hipStreamSynchronize(st);
+  if (stp) {   // diagnostic: per-wave phase stamps of the slim kernel's workgroups 0 and 97 (10 ns units, relative to the workgroup's first)
+    long long h[192]; hipMemcpy(h, stp, sizeof h, hipMemcpyDeviceToHost);
+    for (int b = 0; b < 2; b++) {
+      long long t0 = INT64_MAX;
+      for (int i = 0; i < 96; i++) if (h[b * 96 + i] > 0) t0 = std::min(t0, h[b * 96 + i]);
+      fprintf(stderr, "[bz] slim stamps, workgroup %s (us): rows = waves 0..11 (0-3 row waves, 4-11 tile waves); entry, loads issued, ssd, rs known, planes published / seen, group 0 done, atomics issued, drained\n", b ? "97" : "0");
+      for (int w = 0; w < 12; w++) { fprintf(stderr, "   "); for (int i = 0; i < 8; i++) fprintf(stderr, " %6.2f", h[(b * 12 + w) * 8 + i] > 0 ? (h[(b * 12 + w) * 8 + i] - t0) / 100.0 : -1.0); fprintf(stderr, "\n"); }
+    }
+  }
   double tot = 0; int n = 0;
   for (auto& r : sink.recs) { float ms = 0.f; if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) { tot += ms; n++; } hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
   *avg_us = n ? 1e3 * tot / n : 0.0;

@@ -885,81 +885,274 @@ __global__ __launch_bounds__(256) void k_gemv_q4g(const uint4* __restrict__ W, c
 // and take one 64-column tile each (8 KiB of weights per wave, all in flight before the prologue); grid = (K/256) x ceil(N/512):
 // 192 blocks for Llama-3-8B, i.e. 9 MB of prologue traffic instead of 29 MB.
 // ---------------------------------------------------------------------------------------------------------
-template <int FIX, int NJ>     // NJ = H / 2048
-__global__ __launch_bounds__(512) void k_gemv_q4g_slim(const uint4* __restrict__ W, const __half* __restrict__ S, const unsigned char* __restrict__ Z,
+// Wave roles (round 2, as in the fused MLP), 12 waves: waves 0-3 hold the row (8 NJ elements per thread), do the norm and build the slice's
+// planes; waves 4-11 own one 64-column tile each (8 KiB of weights, requested at entry) and do the dots once the planes are published.  The
+// halves meet through LDS counters.  Per-wave stamps (scripts/tune_qkv.py, profiles/r02_qkv_stamps.txt): a CU sustains ~27 GB/s, so the
+// block's 64 KiB need ~2.4 us from the moment they are requested -- the launch is as long as [request -> data] + dots + atomic drain, and
+// everything else (the prologue's dependent loads, norm, planes: done at ~2.8 us) hides under it.
+template <int FIX, int NJ, int ACT, int DIAG = 0>     // NJ = H / 2048
+__global__ __launch_bounds__(768) void k_gemv_q4g_slim(const uint4* __restrict__ W, const __half* __restrict__ S, const unsigned char* __restrict__ Z,
                                                       const float* __restrict__ bias, int N, int H, Pro pro, long long* acc, long long* zero_buf, int zero_n) {
-  __shared__ __attribute__((aligned(16))) float xs[256];
   __shared__ uint4 xpl[8 * XQ_NP];
   __shared__ int4 gpar[4];
-  __shared__ double red[8];
+  __shared__ double red[4];
+  __shared__ unsigned cntv[2];
+  volatile unsigned* cnt = cntv;
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const bool prolog = wave < 4;
   const int NKS = H >> 8, G = H >> 7;
-  const int ksl = blockIdx.x % NKS, tq = (blockIdx.x / NKS) * 8 + wave;
+  const int ksl = blockIdx.x % NKS, tg = blockIdx.x / NKS;
+  asm volatile("" :: "s"(zero_buf), "s"(zero_n), "s"(acc), "s"(pro.h_in), "s"(pro.src.p), "s"(pro.norm_w), "s"(pro.h_out), "s"(pro.H),
+               "s"(H), "s"(N), "s"(W), "s"(S), "s"(Z), "s"(bias));   // one scalar-load batch for all arguments
+  unsigned long long T[8];
+#define SSTAMP(i) do { if (DIAG) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(T[i]) :: "memory"); \
+    __builtin_amdgcn_sched_barrier(0); } } while (0)
+#define SFLUSH() do { if (DIAG && pro.stamps && lane == 0 && (blockIdx.x == 0 || blockIdx.x == 97)) { \
+    _Pragma("unroll") for (int i = 0; i < 8; i++) pro.stamps[((blockIdx.x ? 1 : 0) * 12 + wave) * 8 + i] = (long long)T[i]; } } while (0)
+#pragma unroll
+  for (int i = 0; i < 8; i++) T[i] = 0;
+  SSTAMP(0);
+  if (tid == 0) { cnt[0] = 0; cnt[1] = 0; }
+  if (prolog) {
+    // (1p) the row: octet j * 256 + pt of thread pt
+    const int pt = tid;
+    const bool hasprev = pro.src.p != nullptr;
+    const void* prevp = hasprev ? pro.src.p : (const void*)pro.h_in;
+    float4 ha[NJ], hb[NJ];
+    typename RawT<FIX>::T pv[NJ][8];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+      const int i0 = (j * 256 + pt) * 8;
+      ha[j] = *(const float4*)(pro.h_in + i0); hb[j] = *(const float4*)(pro.h_in + i0 + 4);
+#pragma unroll
+      for (int e = 0; e < 8; e++) pv[j][e] = vraw<FIX>(prevp, (FIX || hasprev) ? i0 + e : 0);
+    }
+    const int osl = 32 * ksl, jsel = osl >> 8, p0 = osl & 255;              // the slice's 32 octets: register jsel of threads p0 .. p0 + 31
+    const bool mine = pt >= p0 && pt < p0 + 32;
+    const int so = min(max(pt - p0, 0), 31);                                // this thread's octet of the slice (clamped: loads are unconditional)
+    const float4 na = *(const float4*)(pro.norm_w + (osl + so) * 8), nb = *(const float4*)(pro.norm_w + (osl + so) * 8 + 4);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();                     // counters zeroed; the row's loads are all in the CU's queue AHEAD of the tile waves' weight loads
+    __builtin_amdgcn_sched_barrier(0);
+    SSTAMP(1);
+    // (2p) h' = R(h + R(prev)), exact sum of squares
+    float v[NJ][8];
+    double ssd = 0.0;
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+      const float t[8] = {ha[j].x, ha[j].y, ha[j].z, ha[j].w, hb[j].x, hb[j].y, hb[j].z, hb[j].w};
+#pragma unroll
+      for (int e = 0; e < 8; e++) v[j][e] = hasprev ? round_t<ACT>(t[e] + round_t<ACT>(FIX ? fix2f((long long)pv[j][e]) : (float)pv[j][e])) : t[e];
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) ssd += (double)(v[j][e] * v[j][e]) + (double)(v[j][e + 1] * v[j][e + 1]);
+      if (blockIdx.x == 0 && pro.h_out) {
+        const int i0 = (j * 256 + pt) * 8;
+        *(float4*)(pro.h_out + i0) = make_float4(v[j][0], v[j][1], v[j][2], v[j][3]); *(float4*)(pro.h_out + i0 + 4) = make_float4(v[j][4], v[j][5], v[j][6], v[j][7]);
+      }
+    }
+    ssd = wave_sum_d(ssd);
+    SSTAMP(2);
+    if (lane == 0) { red[wave] = ssd; __builtin_amdgcn_s_waitcnt(0xc07f); atomicAdd((unsigned*)&cnt[0], 1u); }
+    if (p0 / 64 == wave) {               // only the wave that holds the slice goes on (wave-uniform)
+      lds_wait_count(&cnt[0], 4);
+      SSTAMP(3);
+      const float ss = (float)((red[0] + red[1]) + (red[2] + red[3]));
+      const float rs = 1.0f / sqrtf(ss / (float)H + pro.eps);
+      float sv[8];
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        sv[e] = v[0][e];
+#pragma unroll
+        for (int j = 1; j < NJ; j++) sv[e] = (j == jsel) ? v[j][e] : sv[e];
+      }
+      const float nwv[8] = {na.x, na.y, na.z, na.w, nb.x, nb.y, nb.z, nb.w};
+      float x[8];
+      float am = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; e++) { x[e] = mine ? round_t<ACT>(nwv[e] * round_t<ACT>(sv[e] * rs)) : 0.f; am = fmaxf(am, fabsf(x[e])); }
+      am = grp_reduce<16, OpMax>(am);    // p0 is a multiple of 32: a 128-k group is an aligned run of 16 lanes, the other half wave carries zeros
+      unsigned w[XQ_NP]; int sp[XQ_NP]; float cs;
+      xq_split8(x, am, w, sp, cs);
+#pragma unroll
+      for (int p = 0; p < XQ_NP; p++) sp[p] = grp_reduce<16, OpAdd>(sp[p]);
+      if (mine) {
+        unsigned* plw = (unsigned*)xpl + ((so >> 2) * XQ_NP) * 4 + (so & 3);
+#pragma unroll
+        for (int p = 0; p < XQ_NP; p++) plw[p * 4] = w[p];
+        if ((so & 15) == 0) {
+          gpar[2 * (so >> 4)] = make_int4(__float_as_int(cs), sp[0], sp[1], sp[2]);
+          gpar[2 * (so >> 4) + 1] = make_int4(sp[3], sp[4], sp[5], 0);
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      if (lane == 0) atomicAdd((unsigned*)&cnt[1], 1u);
+      SSTAMP(4);
+    }
+    SFLUSH();
+    return;
+  }
+  // (1s) tile waves: the rendezvous, then the tile's weights
+  const int tq = tg * 8 + (wave - 4);
   const bool q_on = tq * 64 < N;
   const int tqc = q_on ? tq : 0;
-  asm volatile("" :: "s"(zero_buf), "s"(zero_n), "s"(acc), "s"(pro.h_in), "s"(pro.src.p), "s"(pro.norm_w), "s"(pro.h_out), "s"(pro.H),
-               "s"(pro.act), "s"(H), "s"(N), "s"(W), "s"(S), "s"(Z), "s"(bias));   // one scalar-load batch for all arguments
-  zero_duty<512>(zero_buf, zero_n);
-  // (1) prologue loads (L2-resident): h, deferred residual, this slice's norm weights
-  const bool hasprev = pro.src.p != nullptr;
-  const void* prevp = hasprev ? pro.src.p : (const void*)pro.h_in;
-  float hv[NJ][4];
-  typename RawT<FIX>::T pv[NJ][4];
-#pragma unroll
-  for (int j = 0; j < NJ; j++) {
-    const int i = j * 2048 + tid * 4;
-    const float4 h4 = *(const float4*)(pro.h_in + i);
-    hv[j][0] = h4.x; hv[j][1] = h4.y; hv[j][2] = h4.z; hv[j][3] = h4.w;
-#pragma unroll
-    for (int e = 0; e < 4; e++) pv[j][e] = vraw<FIX>(prevp, (FIX || hasprev) ? i + e : 0);
-  }
-  float4 nw = make_float4(0, 0, 0, 0);
-  nw = *(const float4*)(pro.norm_w + ksl * 256 + (tid & 63) * 4);
+  const uint4* wq = W + ((size_t)tqc * (H >> 5) + ksl * 8) * 64 + lane;
+  uint4 Q[8]; float sq[2]; int zq[2];
+  __syncthreads();                       // (the row waves' loads go first: the CU issues ~64 B per clock, 120 KiB of requests take ~0.9 us)
   __builtin_amdgcn_sched_barrier(0);
-  // (2) this wave's weights: one tile x two groups = 8 KiB, all in flight now
-  uint4 Q[2][4]; float sq[2]; int zq[2];
-  {
-    const uint4* wq = W + ((size_t)tqc * (H >> 5) + ksl * 8) * 64 + lane;
 #pragma unroll
-    for (int b = 0; b < 2; b++)
+  for (int c = 0; c < 8; c++) Q[c] = ldnt(wq + c * 64);
 #pragma unroll
-      for (int c = 0; c < 4; c++) Q[b][c] = ldnt(wq + (b * 4 + c) * 64);
+  for (int b = 0; b < 2; b++) { const size_t ix = ((size_t)tqc * G + ksl * 2 + b) * 64 + lane; sq[b] = __half2float(S[ix]); zq[b] = Z[ix]; }
+  SSTAMP(1);
+  if (zero_buf)
+    for (int i = blockIdx.x * 512 + (tid - 256); i < zero_n; i += gridDim.x * 512) zero_buf[i] = 0;
+  lds_wait_count(&cnt[1], 1);
+  SSTAMP(4);
+  if (q_on) {
+    double y = 0.0;
 #pragma unroll
-    for (int b = 0; b < 2; b++) { const size_t ix = ((size_t)tqc * G + ksl * 2 + b) * 64 + lane; sq[b] = __half2float(S[ix]); zq[b] = Z[ix]; }
+    for (int b = 0; b < 2; b++) {
+      int D[XQ_NP] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int c = 0; c < 4; c++) q4_chunk(Q[b * 4 + c], xpl + (b * 4 + c) * XQ_NP, D);
+      y += q4_term(D, gpar[2 * b], gpar[2 * b + 1], sq[b], zq[b]);
+      if (b == 0) SSTAMP(5);
+    }
+    const int n = tq * 64 + lane;
+    if (bias != nullptr && ksl == 0) y += (double)bias[n];
+    atomicAdd((unsigned long long*)(acc + n), (unsigned long long)d2fix(y));
   }
-  // (3) h' = R(h + R(prev)); sum of squares; this block's slice parked in LDS
-  double ssd = 0.0;
+  SSTAMP(6);
+  if (DIAG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+  SSTAMP(7);
+  SFLUSH();
+#undef SSTAMP
+#undef SFLUSH
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// int4 GEMV with the fused residual + RMSNorm prologue, FULL K per workgroup, direct output (the q/k/v projection of the decode step).
+// The slim kernel above splits K over 16 workgroups per tile group: 49 k 64-bit atomics whose drain the launch waits for (~1.5 us), and a
+// consumer that reads 8-byte fixed point.  Here a workgroup owns ONE 64-column tile over the whole K: its NW waves take 256 k each
+// (8 KiB of weights per wave), meet through LDS, and the block stores 64 finished values -- no atomics, nothing to zero, the attention
+// kernel reads plain f32.  N / 64 workgroups (96 for Llama-3-8B) leave most CUs idle, but the launch is a latency chain, not a stream:
+// 13 MB over 96 CUs is ~2 us, hidden under the prologue's dependent loads.  Same wave roles as the fused MLP: the first half requests its
+// weights at entry, the second half holds the row (an octet per thread), does the norm and publishes the nibble planes.
+// ---------------------------------------------------------------------------------------------------------
+template <int FIX, int NW, int ACT>     // H = NW * 256
+__global__ __launch_bounds__(NW * 64) void k_gemv_q4g_cols(const uint4* __restrict__ W, const __half* __restrict__ S, const unsigned char* __restrict__ Z,
+                                                          const float* __restrict__ bias, int N, int H, Pro pro, float* __restrict__ out, long long* zero_buf, int zero_n) {
+  constexpr int NP = NW / 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint4* xpl = (uint4*)smem;                       // [H/32 chunks][6 planes]
+  const int G = H >> 7;
+  int4* gpar = (int4*)(xpl + (H >> 5) * XQ_NP);    // [2G]
+  double* part = (double*)(gpar + 2 * G);          // [NW][64]
+  double* dred = part + NW * 64;                   // [NP]
+  volatile unsigned* cnt = (volatile unsigned*)(dred + NW);
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const bool prolog = wave >= NP;
+  const int tile = blockIdx.x;
+  asm volatile("" :: "s"(zero_buf), "s"(zero_n), "s"(out), "s"(pro.h_in), "s"(pro.src.p), "s"(pro.norm_w), "s"(pro.h_out), "s"(H), "s"(N), "s"(W), "s"(S), "s"(Z), "s"(bias));
+  const uint4* wq = W + ((size_t)tile * (H >> 5) + wave * 8) * 64 + lane;
+  uint4 Q[8];
+  if (tid == 0) { cnt[0] = 0; cnt[1] = 0; }
+  if (prolog) {
+    const bool hasprev = pro.src.p != nullptr;
+    const void* prevp = hasprev ? pro.src.p : (const void*)pro.h_in;
+    const int i0 = (tid - NP * 64) * 8;
+    const float4 ha = *(const float4*)(pro.h_in + i0), hb = *(const float4*)(pro.h_in + i0 + 4);
+    typename RawT<FIX>::T pv[8];
 #pragma unroll
-  for (int j = 0; j < NJ; j++) {
-    const int i = j * 2048 + tid * 4;
+    for (int e = 0; e < 8; e++) pv[e] = vraw<FIX>(prevp, (FIX || hasprev) ? i0 + e : 0);
+    const float4 na = *(const float4*)(pro.norm_w + i0), nb = *(const float4*)(pro.norm_w + i0 + 4);
+    __builtin_amdgcn_sched_barrier(0);
+    Q[0] = ldnt(wq); Q[1] = ldnt(wq + 64);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();                     // the counters are zero (nobody waits for data here)
+    float v[8] = {ha.x, ha.y, ha.z, ha.w, hb.x, hb.y, hb.z, hb.w};
     if (hasprev) {
 #pragma unroll
-      for (int e = 0; e < 4; e++) hv[j][e] = round_act(hv[j][e] + vcvt<FIX>(pv[j][e], pro.act), pro.act);
+      for (int e = 0; e < 8; e++) v[e] = round_t<ACT>(v[e] + round_t<ACT>(FIX ? fix2f((long long)pv[e]) : (float)pv[e]));
     }
-    ssd += ((double)(hv[j][0] * hv[j][0]) + (double)(hv[j][1] * hv[j][1])) + ((double)(hv[j][2] * hv[j][2]) + (double)(hv[j][3] * hv[j][3]));
-    if (blockIdx.x == 0 && pro.h_out) *(float4*)(pro.h_out + i) = make_float4(hv[j][0], hv[j][1], hv[j][2], hv[j][3]);
-    if ((i >> 8) == ksl) *(float4*)(xs + (i & 255)) = make_float4(hv[j][0], hv[j][1], hv[j][2], hv[j][3]);
+    if (blockIdx.x == 0 && pro.h_out) { *(float4*)(pro.h_out + i0) = make_float4(v[0], v[1], v[2], v[3]); *(float4*)(pro.h_out + i0 + 4) = make_float4(v[4], v[5], v[6], v[7]); }
+    double ssd = 0.0;
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) ssd += (double)(v[e] * v[e]) + (double)(v[e + 1] * v[e + 1]);
+    ssd = wave_sum_d(ssd);
+    if (lane == 0) { dred[wave - NP] = ssd; __builtin_amdgcn_s_waitcnt(0xc07f); atomicAdd((unsigned*)&cnt[0], 1u); }
+    lds_wait_count(&cnt[0], NP);
+    ssd = ((dred[0] + dred[1]) + (dred[2] + dred[3]));
+    if (NP == 8) ssd += ((dred[4] + dred[5]) + (dred[6] + dred[7]));
+    const float rs = 1.0f / sqrtf((float)ssd / (float)H + pro.eps);
+    const float nwv[8] = {na.x, na.y, na.z, na.w, nb.x, nb.y, nb.z, nb.w};
+    float x[8];
+    float am = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; e++) { x[e] = round_t<ACT>(nwv[e] * round_t<ACT>(v[e] * rs)); am = fmaxf(am, fabsf(x[e])); }
+    am = grp_reduce<16, OpMax>(am);
+    unsigned w[XQ_NP]; int sp[XQ_NP]; float cs;
+    xq_split8(x, am, w, sp, cs);
+#pragma unroll
+    for (int p = 0; p < XQ_NP; p++) sp[p] = grp_reduce<16, OpAdd>(sp[p]);
+    const int oct = tid - NP * 64;
+    unsigned* plw = (unsigned*)xpl + ((oct >> 2) * XQ_NP) * 4 + (oct & 3);
+#pragma unroll
+    for (int p = 0; p < XQ_NP; p++) plw[p * 4] = w[p];
+    if ((lane & 15) == 0) {
+      gpar[2 * (oct >> 4)] = make_int4(__float_as_int(cs), sp[0], sp[1], sp[2]);
+      gpar[2 * (oct >> 4) + 1] = make_int4(sp[3], sp[4], sp[5], 0);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    if (lane == 0) atomicAdd((unsigned*)&cnt[1], 1u);
+#pragma unroll
+    for (int c = 2; c < 8; c++) Q[c] = ldnt(wq + c * 64);
+  } else {
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 8; c++) Q[c] = ldnt(wq + c * 64);
+    if (zero_buf)
+      for (int i = blockIdx.x * (NP * 64) + tid; i < zero_n; i += gridDim.x * (NP * 64)) zero_buf[i] = 0;
   }
-  ssd = wave_sum_d(ssd);
-  if (lane == 0) red[wave] = ssd;
-  __syncthreads();
-  const float ss = (float)(((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7])));
-  const float rs = 1.0f / sqrtf(ss / (float)H + pro.eps);
-  if (tid < 64) {
-    const float4 v = *(const float4*)(xs + tid * 4);
-    *(float4*)(xs + tid * 4) = make_float4(round_act(nw.x * round_act(v.x * rs, pro.act), pro.act), round_act(nw.y * round_act(v.y * rs, pro.act), pro.act),
-                                           round_act(nw.z * round_act(v.z * rs, pro.act), pro.act), round_act(nw.w * round_act(v.w * rs, pro.act), pro.act));
-  }
-  __syncthreads();
-  quant_x128<512>(xs, 256, xpl, gpar);
-  __syncthreads();
-  if (!q_on) return;
+  float sq[2]; int zq[2];
+#pragma unroll
+  for (int b = 0; b < 2; b++) { const size_t ix = ((size_t)tile * G + wave * 2 + b) * 64 + lane; sq[b] = __half2float(S[ix]); zq[b] = Z[ix]; }
+  lds_wait_count(&cnt[1], NP);
   double y = 0.0;
-  q4g_consume(Q[0], 0, xpl, gpar, sq[0], zq[0], y);
-  q4g_consume(Q[1], 1, xpl, gpar, sq[1], zq[1], y);
-  const int n = tq * 64 + lane;
-  if (bias != nullptr && ksl == 0) y += (double)bias[n];
-  atomicAdd((unsigned long long*)(acc + n), (unsigned long long)d2fix(y));
+#pragma unroll
+  for (int b = 0; b < 2; b++) {
+    int D[XQ_NP] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < 4; c++) q4_chunk(Q[b * 4 + c], xpl + ((wave * 2 + b) * 4 + c) * XQ_NP, D);
+    y += q4_term(D, gpar[2 * (wave * 2 + b)], gpar[2 * (wave * 2 + b) + 1], sq[b], zq[b]);
+  }
+  part[wave * 64 + lane] = y;
+  __syncthreads();
+  if (tid < 64) {
+    double t = 0.0;
+#pragma unroll
+    for (int w2 = 0; w2 < NW; w2++) t += part[w2 * 64 + tid];
+    float f = (float)t;                      // ONE rounding of the exact dot product (the oracle's definition)
+    const int n = tile * 64 + tid;
+    if (bias) f += bias[n];
+    out[n] = round_t<ACT>(f);
+  }
+}
+static size_t q4g_cols_smem(int H) { return (size_t)H * 3 + (size_t)(H >> 7) * 32 + 16 * 64 * 8 + 16 * 8 + 64; }
+bool bzk_gemv_cols_ok(const LinearDev& L, const Pro& pro, int act) {
+  static const bool off = getenv("BZ_COLS_QKV") == nullptr;   // opt-in: measured slower than the slim kernel (7.8 vs 6.8 us: a CU sustains ~27 GB/s, 96 CUs x 128 KiB take longer than 192 x 64 KiB)
+  return !off && act == BZ_F16 && L.kind == LK_Q4G && !L.perm && pro.mode == PRO_NORM && pro.perm == nullptr && L.K == pro.H && (L.K == 2048 || L.K == 4096) && L.N % 64 == 0 &&
+         L.N <= 16384 && !pro.dbg && !pro.stamps;
+}
+int bzk_gemv_cols(hipStream_t s, const LinearDev& L, const Pro& pro, float* out, long long* zero_buf, int zero_n) {
+  const size_t smem = q4g_cols_smem(L.K);
+#define LAUNCH_COLS(FIX, NW_) BZ_LAUNCH("gemv_q4g<norm,cols>", L.algo_bytes, (k_gemv_q4g_cols<FIX, NW_, BZ_F16>), dim3(L.N / 64), dim3(NW_ * 64), smem, s, (const uint4*)L.w, \
+    (const __half*)L.scales, (const unsigned char*)L.zeros, L.bias, L.N, L.K, pro, out, zero_buf, zero_n)
+  if (L.K == 4096) { if (pro.src.fix) LAUNCH_COLS(1, 16); else LAUNCH_COLS(0, 16); }
+  else { if (pro.src.fix) LAUNCH_COLS(1, 8); else LAUNCH_COLS(0, 8); }
+#undef LAUNCH_COLS
+  BZ_HIP(hipGetLastError());
+  return BZ_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1052,7 +1245,7 @@ int bzk_gemm_q4g_rows(hipStream_t s, const LinearDev& L, int xdt, const void* x1
 bool bzk_gemv_slim_ok(const LinearDev& L, const Pro& pro) {
   static const bool off = getenv("BZ_NO_SLIM_QKV") != nullptr;
   return !off && L.kind == LK_Q4G && !L.perm && pro.mode == PRO_NORM && pro.perm == nullptr && L.K == pro.H && (L.K == 2048 || L.K == 4096 || L.K == 8192) && L.N % 64 == 0 &&
-         L.N <= 16384 && !pro.dbg && !pro.stamps;
+         L.N <= 16384 && !pro.dbg;
 }
 
 // =========================================================================================================
@@ -1843,13 +2036,14 @@ int bzk_dequant_gq(hipStream_t s, const LinearDev& L, float* out) {
 int bzk_argmax_partials(hipStream_t s, const float* v, long long n, float* pval, int* pidx, int nb);
 
 int bzk_gemv(hipStream_t s, const LinearDev& L, const Pro& pro, const GemvOut& out, int act) {
-  if (L.kind == LK_Q4G && bzk_gemv_slim_ok(L, pro)) {
+  if (L.kind == LK_Q4G && act == BZ_F16 && bzk_gemv_slim_ok(L, pro)) {
     if (!out.acc) BZ_FAIL(BZ_E_INVALID, "int4 gemv needs a fixed-point accumulator");
     const int nks = L.K / 256, ntg = (L.N / 64 + 7) / 8;
-#define LAUNCH_SLIM(FIX, NJ) BZ_LAUNCH("gemv_q4g<norm>", L.algo_bytes, (k_gemv_q4g_slim<FIX, NJ>), dim3(nks * ntg), dim3(512), 0, s, (const uint4*)L.w, \
+#define LAUNCH_SLIM(FIX, NJ, DG) BZ_LAUNCH("gemv_q4g<norm>", L.algo_bytes, (k_gemv_q4g_slim<FIX, NJ, BZ_F16, DG>), dim3(nks * ntg), dim3(768), 0, s, (const uint4*)L.w, \
     (const __half*)L.scales, (const unsigned char*)L.zeros, L.bias, L.N, L.K, pro, out.acc, out.zero_buf, out.zero_n)
-#define LAUNCH_SLIM_NJ(FIX) do { if (L.K == 2048) LAUNCH_SLIM(FIX, 1); else if (L.K == 4096) LAUNCH_SLIM(FIX, 2); else LAUNCH_SLIM(FIX, 4); } while (0)
-    if (pro.src.fix) LAUNCH_SLIM_NJ(1); else LAUNCH_SLIM_NJ(0);
+#define LAUNCH_SLIM_NJ(FIX) do { if (L.K == 2048) LAUNCH_SLIM(FIX, 1, 0); else if (L.K == 4096) LAUNCH_SLIM(FIX, 2, 0); else LAUNCH_SLIM(FIX, 4, 0); } while (0)
+    if (pro.stamps && L.K == 4096 && pro.src.fix) LAUNCH_SLIM(1, 2, 1);   // diagnostic build (bz_tune_gemv flag 16)
+    else if (pro.src.fix) LAUNCH_SLIM_NJ(1); else LAUNCH_SLIM_NJ(0);
 #undef LAUNCH_SLIM_NJ
 #undef LAUNCH_SLIM
     BZ_HIP(hipGetLastError());
