@@ -114,6 +114,8 @@ def main():
     from blazr_amd import runtime, synth
 
     if args.preset in synth.MAMBA_PRESETS or args.preset in synth.DSV2_PRESETS:
+        if args.preset in synth.DSV2_PRESETS and "--prompt-len" not in sys.argv:
+            args.prompt_len = 512          # BASELINE.json configs[4]: prefill 512 + decode 128
         return bench_aux(args, rank, local_rank, world, dist)
     cfg = synth.make_config(args.preset)
     need = args.prompt_len + args.warmup + args.steps + 8
@@ -279,12 +281,19 @@ def bench_aux(args, rank, local_rank, world, dist):
     resident, per_token = lm.weight_bytes()
     assert per_token == w_bytes, (per_token, w_bytes)
     prompt = synth.prompt_tokens(args.prompt_len, cfg["vocab"])
-    if mamba:
-        st = runtime.LayeredSsmState(lm)
-        logits = lm.forward_with_ssm_state(prompt, st)
-    else:
-        st = lm.new_kv_cache(need)
-        logits = lm.forward_with_kv_cache(prompt, st, 0)
+    ptimer = hip_events(C.c_void_p(dev.stream()))
+    pf_ms = []
+    for rep_i in range(3):          # prompt prefill, timed on its own (BASELINE.json configs[4]: "prefill 512 (MFMA) + decode 128"); first pass = warm-up
+        if mamba:
+            st = runtime.LayeredSsmState(lm)
+        else:
+            st = lm.new_kv_cache(need)
+        dev.synchronize()
+        ptimer.start()
+        logits = lm.forward_with_ssm_state(prompt, st) if mamba else lm.forward_with_kv_cache(prompt, st, 0)
+        ptimer.stop()
+        pf_ms.append(ptimer.ms())
+    prefill_ms = sorted(pf_ms[1:])[0]
     first = int(runtime.logits_to_token(dev, logits, [], []).to_numpy()[0])
     graph = runtime.DecodeGraph(lm, st)
     graph.seed_next_token(first, args.prompt_len)
@@ -324,6 +333,13 @@ def bench_aux(args, rank, local_rank, world, dist):
                         "whole_step_frac": round(algo * (tok_s / n_gpus) / (HBM_PEAK_GBS * 1e9), 4)},
            "kernels": [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in p.items()} for p in prof],
            "gpu_ms_events": round(gpu_ms, 3), "host_ms": round(host_ms, 3), "load_s": round(load_s, 1), "tokens_head": tokens[:8]}
+    # the prompt phase: 2 FLOP per active weight per token (embedding row and norms excluded), against the dense 16-bit MFMA peak
+    active_params = w_bytes / {"f16": 2, "bf16": 2, "f32": 4}[cfg["act_dtype"]]
+    pf_flops = 2.0 * active_params * args.prompt_len
+    out["prefill"] = {"tokens": args.prompt_len, "ms": round(prefill_ms, 3), "tokens_per_s": round(args.prompt_len / (prefill_ms / 1e3), 1),
+                      "tflops": round(pf_flops / (prefill_ms / 1e3) / 1e12, 2), "mfma_peak_tflops": 2500.0,
+                      "frac_of_mfma_peak": round(pf_flops / (prefill_ms / 1e3) / 2.5e15, 4), "runs_ms": [round(v, 3) for v in pf_ms],
+                      "note": "whole prompt phase (GEMMs on the matrix cores + attention / scan + routing), 2 x active weights x tokens FLOP"}
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

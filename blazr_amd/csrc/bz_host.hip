@@ -280,6 +280,9 @@ struct bz_model {
   std::recursive_mutex mu;
   std::vector<DsLayerDev> dlayers;
   float* moe_xn = nullptr; float* moe_gu = nullptr; float* moe_out = nullptr; long long* moe_acc = nullptr; int* moe_sel = nullptr; float* moe_w = nullptr; float* moe_lg = nullptr; unsigned* moe_cnt = nullptr;
+  // DeepSeek-V2 batched-prefill rows (allocated on first use for dpf_rows prompt rows)
+  int dpf_rows = 0; float* dpf_att = nullptr; void* dpf_xg16 = nullptr; float* dpf_gu = nullptr; void* dpf_a16 = nullptr; float* dpf_ye = nullptr; float* dpf_ysh = nullptr;
+  int* dpf_sel = nullptr; float* dpf_w = nullptr; int* dpf_cnt = nullptr; int* dpf_off = nullptr; int* dpf_rowof = nullptr; int* dpf_tokof = nullptr;
   std::vector<MambaLayerDev> mlayers;
   float* xbc = nullptr; float* ybuf = nullptr; float* vss = nullptr;   // Mamba2 workspace
   int mpf_rows = 0; float* mpf_h = nullptr; float* mpf_t = nullptr; float* mpf_zx = nullptr; float* mpf_xbc = nullptr; float* mpf_y = nullptr; float* mpf_vss = nullptr;
@@ -1726,6 +1729,141 @@ static int prefill_dense(bz_model* m, const long long* d_tok, int S, const KvVie
   return BZ_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// DeepSeek-V2 batched prefill (BASELINE.json configs[4]: "prefill 512 (MFMA) + decode 128"): every projection of the prompt rows is one GEMM on
+// the matrix cores (k_gemm_nt), the MLA attention runs the decode kernel's arithmetic with one workgroup per (head, token) over the latent
+// cache that a row-wise kernel filled first, and the routed experts become per-expert GEMMs over gathered token rows
+// (docs/architecture.md:108-119: softmax -> top-k -> weighted sum + shared experts).  Same rounding points as the decode step, token for token.
+// ---------------------------------------------------------------------------------------------------------
+static bool dsv2_prefill_eligible(const bz_model* m, int S, int total_len, const KvView& view) {
+  const bz_model_config& c = m->cfg;
+  if (c.arch != BZ_ARCH_DEEPSEEK2 || S < prefill_min_rows() || (c.act_dtype != BZ_F16 && c.act_dtype != BZ_BF16) || c.mla_q_lora_rank > 0) return false;
+  if (c.hidden % 64 || (c.n_heads * c.mla_v_dim) % 64 || (c.moe_n_experts > 0 && c.moe_inter % 64) || view.dtype != c.act_dtype) return false;
+  for (const DsLayerDev& L : m->dlayers) {
+    for (const FusedLinear* F : {&L.qkva, &L.o}) if (F->parts.size() != 1 || F->parts[0].kind != LK_ROWS || F->parts[0].wdt != c.act_dtype) return false;
+    if (L.kv_b_dt != c.act_dtype) return false;
+    if (!L.is_moe) { for (const FusedLinear* F : {&L.gateup, &L.down}) if (F->parts.size() != 1 || F->parts[0].kind != LK_ROWS || F->parts[0].wdt != c.act_dtype || c.inter % 64) return false; }
+    else if (L.e_dt != c.act_dtype) return false;
+  }
+  MlaArgs probe{}; probe.rank = c.mla_kv_lora_rank; probe.rope = c.mla_rope_dim; probe.nope = c.mla_nope_dim; probe.vdim = c.mla_v_dim;
+  extern size_t bzk_mla_smem(const MlaArgs&, int);
+  if (bzk_mla_smem(probe, total_len) > 160 * 1024) return false;
+  return m->lm_head.parts.size() == 1 && m->lm_head.parts[0].kind == LK_ROWS && !m->lm_head.fix_out;
+}
+static int dsv2_prefill_ws(bz_model* m, int rows) {
+  if (m->dpf_rows >= rows) return BZ_OK;
+  const bz_model_config& c = m->cfg;
+  const int H = c.hidden, NH = c.n_heads, TK = std::max(c.moe_top_k, 1), MI = std::max(c.moe_inter, 1);
+  const size_t qn = (size_t)NH * (c.mla_nope_dim + c.mla_rope_dim) + c.mla_kv_lora_rank + c.mla_rope_dim;
+  const size_t xw = std::max<size_t>(std::max<size_t>(H, (size_t)NH * c.mla_v_dim), std::max<size_t>(c.inter, MI));
+  BZ_HIP(hipStreamSynchronize(m->dev->stream));
+  void* p;
+  BZ_TRY(dev_alloc(m, &p, (size_t)rows * H * 4)); m->pf_h = (float*)p;
+  BZ_TRY(dev_alloc(m, &p, (size_t)rows * H * 4)); m->pf_t = (float*)p;
+  BZ_TRY(dev_alloc(m, &p, (size_t)rows * qn * 4)); m->pf_qkv = (float*)p;
+  BZ_TRY(dev_alloc(m, &p, (size_t)rows * 2 * std::max(c.inter, 1) * 4)); m->pf_gu = (float*)p;
+  BZ_TRY(dev_alloc(m, &p, (size_t)rows * xw * 2)); m->pf_x16 = p;
+  BZ_TRY(dev_alloc(m, &p, (size_t)rows * NH * c.mla_v_dim * 4)); m->dpf_att = (float*)p;
+  if (c.moe_n_experts > 0) {
+    BZ_TRY(dev_alloc(m, &p, (size_t)rows * TK * H * 2)); m->dpf_xg16 = p;
+    BZ_TRY(dev_alloc(m, &p, (size_t)rows * TK * 2 * MI * 4)); m->dpf_gu = (float*)p;
+    BZ_TRY(dev_alloc(m, &p, (size_t)rows * TK * MI * 2)); m->dpf_a16 = p;
+    BZ_TRY(dev_alloc(m, &p, (size_t)rows * TK * H * 4)); m->dpf_ye = (float*)p;
+    BZ_TRY(dev_alloc(m, &p, (size_t)rows * H * 4)); m->dpf_ysh = (float*)p;
+    BZ_TRY(dev_alloc(m, &p, (size_t)rows * TK * 4)); m->dpf_sel = (int*)p;
+    BZ_TRY(dev_alloc(m, &p, (size_t)rows * TK * 4)); m->dpf_w = (float*)p;
+    BZ_TRY(dev_alloc(m, &p, (size_t)c.moe_n_experts * 4)); m->dpf_cnt = (int*)p;
+    BZ_TRY(dev_alloc(m, &p, (size_t)c.moe_n_experts * 4)); m->dpf_off = (int*)p;
+    BZ_TRY(dev_alloc(m, &p, (size_t)rows * TK * 4)); m->dpf_rowof = (int*)p;
+    BZ_TRY(dev_alloc(m, &p, (size_t)rows * TK * 4)); m->dpf_tokof = (int*)p;
+  }
+  m->dpf_rows = rows;
+  return BZ_OK;
+}
+__global__ void k_acc_rows(float* acc, const float* y, size_t n, int first) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) acc[i] = first ? y[i] : acc[i] + y[i];
+}
+static int dsv2_prefill(bz_model* m, const long long* d_tok, int S, const KvView& view, int pos0, bool all, bz_tensor* logits_out) {
+  const bz_model_config& c = m->cfg;
+  hipStream_t st = m->dev->stream;
+  const int H = c.hidden, NH = c.n_heads, R = c.mla_kv_lora_rank, DN = c.mla_nope_dim, DR = c.mla_rope_dim, DV = c.mla_v_dim, act = c.act_dtype, dt = c.act_dtype;
+  const int E = c.moe_n_experts, TK = c.moe_top_k, NS = c.moe_n_shared, MI = c.moe_inter;
+  const int NQ = NH * (DN + DR), QN = NQ + R + DR;
+  const size_t es = bz_dtype_size(dt);
+  const int CH = 512;
+  BZ_TRY(dsv2_prefill_ws(m, std::min(S, CH)));
+  std::vector<int> hcnt(std::max(E, 1));
+  for (int s0 = 0; s0 < S; s0 += CH) {
+    const int n = std::min(CH, S - s0), p0 = pos0 + s0;
+    BZ_TRY(bzk_pf_embed(st, m->embed, m->embed_dt, d_tok + s0, n, H, act, m->pf_h));
+    const float* prev = nullptr;
+    for (int l = 0; l < c.n_layers; l++) {
+      const DsLayerDev& L = m->dlayers[l];
+      BZ_TRY(bzk_pf_norm(st, dt, m->pf_h, prev, L.attn_norm, n, H, c.rms_eps, act, m->pf_x16));
+      const LinearDev& PQ = L.qkva.parts[0];
+      BZ_TRY(bzk_gemm_nt(st, dt, m->pf_x16, PQ.w, PQ.bias, n, QN, H, act, m->pf_qkv));
+      BZ_TRY(bzk_mla_append_rows(st, m->pf_qkv + NQ, QN, n, L.kv_norm, c.rms_eps, R, DR, m->cos_t, m->sin_t, p0, act, view, l));
+      MlaArgs ma{};
+      ma.qkv = VSrc{m->pf_qkv, 0}; ma.kv_norm = L.kv_norm; ma.eps = c.rms_eps; ma.wkvb = L.kv_b; ma.wdt = L.kv_b_dt; ma.cos_t = m->cos_t; ma.sin_t = m->sin_t; ma.pos = nullptr;
+      ma.n_heads = NH; ma.rank = R; ma.nope = DN; ma.rope = DR; ma.vdim = DV; ma.act = act; ma.kv = view; ma.layer = l; ma.out = m->dpf_att;
+      ma.scale = 1.0f / sqrtf((float)(DN + DR));
+      ma.batch = n; ma.pos0 = p0; ma.q_stride = QN; ma.out_stride = (long long)NH * DV;
+      BZ_TRY(bzk_mla_attn(st, ma, p0 + n));
+      BZ_TRY(bzk_pf_cvt16(st, dt, m->dpf_att, (size_t)n * NH * DV, m->pf_x16));
+      const LinearDev& PO = L.o.parts[0];
+      BZ_TRY(bzk_gemm_nt(st, dt, m->pf_x16, PO.w, PO.bias, n, H, NH * DV, act, m->pf_t));
+      BZ_TRY(bzk_pf_norm(st, dt, m->pf_h, m->pf_t, L.ffn_norm, n, H, c.rms_eps, act, m->pf_x16));
+      if (!L.is_moe) {
+        const LinearDev& PG = L.gateup.parts[0]; const LinearDev& PD = L.down.parts[0];
+        BZ_TRY(bzk_gemm_nt(st, dt, m->pf_x16, PG.w, PG.bias, n, 2 * c.inter, H, act, m->pf_gu));
+        BZ_TRY(bzk_pf_silu(st, dt, m->pf_gu, n, c.inter, act, m->pf_x16));
+        BZ_TRY(bzk_gemm_nt(st, dt, m->pf_x16, PD.w, PD.bias, n, H, c.inter, act, m->pf_t));
+      } else {
+        // routing, per-expert row lists (one small device -> host copy per layer: the row counts size the GEMM launches)
+        BZ_TRY(bzk_moe_route_rows(st, dt, m->pf_x16, n, H, L.router, L.router_dt, E, TK, c.moe_routed_scale, c.moe_norm_topk, m->dpf_sel, m->dpf_w));
+        BZ_TRY(bzk_moe_plan_rows(st, m->dpf_sel, n, TK, E, m->dpf_cnt, m->dpf_off, m->dpf_rowof, m->dpf_tokof));
+        BZ_HIP(hipMemcpyAsync(hcnt.data(), m->dpf_cnt, (size_t)E * 4, hipMemcpyDeviceToHost, st));
+        BZ_TRY(bzk_moe_gather_rows(st, m->pf_x16, m->dpf_tokof, n * TK, H, m->dpf_xg16));
+        BZ_HIP(hipStreamSynchronize(st));
+        const size_t gu_sz = (size_t)2 * MI * H * es, dn_sz = (size_t)H * MI * es;
+        int maxc = 0;
+        for (int e = 0; e < E; e++) maxc = std::max(maxc, hcnt[e]);
+        // all the experts of the layer in ONE grouped launch per projection (per-expert launches were weight-bandwidth-bound on 44 workgroups each:
+        // 126 launches x 43 us per layer, profiles/r02_dsv2_prefill_kernel_stats_before.csv)
+        BZ_TRY(bzk_gemm_nt_grouped(st, dt, m->dpf_xg16, L.e_gu, (long long)2 * MI * H, E, m->dpf_off, m->dpf_cnt, maxc, (long long)n * TK, 2 * MI, H, act, m->dpf_gu));
+        BZ_TRY(bzk_pf_silu(st, dt, m->dpf_gu, n * TK, MI, act, m->dpf_a16));
+        BZ_TRY(bzk_gemm_nt_grouped(st, dt, m->dpf_a16, L.e_dn, (long long)H * MI, E, m->dpf_off, m->dpf_cnt, maxc, (long long)n * TK, H, MI, act, m->dpf_ye));
+        // the shared experts: one MLP of width NS * moe_inter stored as NS expert-shaped slots; the slots' down products are summed unrounded
+        for (int j = 0; j < NS; j++) {
+          BZ_TRY(bzk_gemm_nt(st, dt, m->pf_x16, (const char*)L.e_gu + (size_t)(E + j) * gu_sz, nullptr, n, 2 * MI, H, act, m->dpf_gu));
+          BZ_TRY(bzk_pf_silu(st, dt, m->dpf_gu, n, MI, act, m->dpf_a16));
+          BZ_TRY(bzk_gemm_nt(st, dt, m->dpf_a16, (const char*)L.e_dn + (size_t)(E + j) * dn_sz, nullptr, n, H, MI, BZ_F32, j == 0 ? m->dpf_ysh : m->pf_t));
+          if (j > 0) hipLaunchKernelGGL(k_acc_rows, dim3(1024), dim3(256), 0, st, m->dpf_ysh, m->pf_t, (size_t)n * H, 0);
+        }
+        BZ_TRY(bzk_moe_combine_rows(st, m->dpf_ye, m->dpf_rowof, m->dpf_w, NS > 0 ? m->dpf_ysh : nullptr, n, TK, H, act, m->pf_t));
+      }
+      prev = m->pf_t;
+    }
+    const LinearDev& LH = m->lm_head.parts[0];
+    if (all && n > 1 && LH.wdt == act && LH.K % 64 == 0 && logits_out->nbytes >= (size_t)(s0 + n) * c.vocab * 4) {
+      BZ_TRY(bzk_pf_norm(st, dt, m->pf_h, prev, m->final_norm, n, H, c.rms_eps, act, m->pf_x16));
+      BZ_TRY(bzk_gemm_nt(st, act, m->pf_x16, LH.w, LH.bias, n, c.vocab, H, act, (float*)logits_out->ptr + (size_t)s0 * c.vocab));
+      continue;
+    }
+    for (int r = 0; r < n; r++) {
+      const int srow = s0 + r;
+      if (!all && srow != S - 1) continue;
+      Pro ph{}; ph.mode = PRO_NORM; ph.src = VSrc{prev + (size_t)r * H, 0}; ph.h_in = m->pf_h + (size_t)r * H; ph.h_out = nullptr; ph.norm_w = m->final_norm;
+      ph.eps = c.rms_eps; ph.H = H; ph.act = act;
+      GemvOut o{};
+      o.direct = m->logits; o.amax_val = m->pval; o.amax_idx = m->pidx;
+      BZ_TRY(bzk_gemv(st, m->lm_head.parts[0], ph, o, act));
+      BZ_TRY(emit_logits(m, logits_out, all ? srow : 0));
+    }
+  }
+  return BZ_OK;
+}
+
 // op-level: y[S,N] = x16[S,K] . W[N,K]^T on the matrix cores, x rounded to the weight dtype first, f32 accumulators returned unrounded
 extern "C" int bz_prefill_matmul(bz_model* m, const char* name, const bz_tensor* x, int S, bz_tensor* y) {
   BZ_API_BEGIN
@@ -1764,6 +1902,12 @@ extern "C" int bz_forward_kv(bz_model* m, const bz_tensor* tokens, int S, bz_kv*
     // prompt-sized inputs of dense 16-bit models: batched prefill, GEMMs on the matrix cores
     if (!logits_out || logits_out->dtype != BZ_F32 || logits_out->nbytes < (size_t)(all ? S : 1) * m->cfg.vocab * 4) BZ_FAIL(BZ_E_INVALID, "forward: logits_out too small");
     BZ_TRY(prefill_dense(m, (const long long*)tokens->ptr, S, view_of(kv), position, nullptr, all, logits_out));
+    kv->seq_len = position + S;
+    return BZ_OK;
+  }
+  if (dsv2_prefill_eligible(m, S, position + S, view_of(kv))) {
+    if (!logits_out || logits_out->dtype != BZ_F32 || logits_out->nbytes < (size_t)(all ? S : 1) * m->cfg.vocab * 4) BZ_FAIL(BZ_E_INVALID, "forward: logits_out too small");
+    BZ_TRY(dsv2_prefill(m, (const long long*)tokens->ptr, S, view_of(kv), position, all, logits_out));
     kv->seq_len = position + S;
     return BZ_OK;
   }

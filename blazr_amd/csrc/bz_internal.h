@@ -249,10 +249,22 @@ struct MlaArgs {
   const void* wkvb; int wdt;   // kv_b_proj [n_heads (nope+v)][rank]
   const float* cos_t; const float* sin_t; const int* pos;
   int n_heads, rank, nope, rope, vdim, act;
-  KvView kv; int layer;     // n_kv = 1, hd = rank + rope, contiguous
+  KvView kv; int layer;     // n_kv = 1, hd = rank + rope; contiguous or paged
   float* out;               // [n_heads vdim]
   float scale;
+  // batched form (prompt rows, grid.y = token): q rows are f32 at qkv.p + token * q_stride, the latent rows of ALL the tokens are already
+  // in the cache (bzk_mla_append_rows), token t attends over positions 0 .. pos0 + t, its output goes to out + t * out_stride
+  int batch; int pos0; long long q_stride; long long out_stride;
+  const float* kva;         // decode with q_lora_rank > 0: [latent | k_pe] of the current token when q comes from a separate projection (else nullptr)
 };
+// prompt rows: latent RMSNorm + k_pe RoPE of rows s = 0 .. S-1 (source row s at kva + s * stride), appended to the cache at position pos0 + s
+int bzk_mla_append_rows(hipStream_t s, const float* kva, long long stride, int S, const float* kv_norm, float eps, int rank, int rope, const float* cos_t, const float* sin_t,
+                        int pos0, int act, const KvView& kv, int layer);
+// MoE over prompt rows: routing (same arithmetic as the decode router), per-expert row lists, gather, combine
+int bzk_moe_route_rows(hipStream_t s, int dt, const void* x16, int S, int H, const void* wr, int wdt, int E, int top_k, float routed_scale, int norm_topk, int* sel, float* wsel);
+int bzk_moe_plan_rows(hipStream_t s, const int* sel, int S, int top_k, int E, int* counts, int* offsets, int* row_of, int* tok_of);
+int bzk_moe_gather_rows(hipStream_t s, const void* x16, const int* tok_of, int rows, int H, void* xg16);
+int bzk_moe_combine_rows(hipStream_t s, const float* ye, const int* row_of, const float* wsel, const float* ysh, int S, int top_k, int H, int act, float* out);
 struct MoeGemvArgs {
   const void* w; long long expert_stride;       // elements between experts
   const int* sel;                               // [n_slots] expert index per slot
@@ -269,6 +281,8 @@ int bzk_moe_combine(hipStream_t s, long long* acc, const float* wsel, int top_k,
 
 // batched prefill for dense 16-bit models (bz_prefill.hip): MFMA GEMM + row-wise norm / RoPE + KV append / causal attention / SiLU*up
 int bzk_gemm_nt(hipStream_t s, int dt, const void* x16, const void* w, const float* bias, int S, int N, int K, int act, float* y);
+int bzk_gemm_nt_grouped(hipStream_t s, int dt, const void* x16, const void* w, long long w_stride, int G, const int* g_off, const int* g_cnt, int max_rows, long long total_rows,
+                        int N, int K, int act, float* y);
 int bzk_pf_cvt16(hipStream_t s, int dt, const float* x, size_t n, void* y);
 int bzk_pf_embed(hipStream_t s, const void* table, int tdt, const long long* tok, int S, int H, int act, float* out);
 int bzk_pf_norm(hipStream_t s, int dt, float* hbuf, const float* prev, const float* w, int S, int H, float eps, int act, void* x16);

@@ -3693,7 +3693,7 @@ template <int NW> __device__ __forceinline__ float block_sum_nw(float v, float* 
   __syncthreads();
   return t;
 }
-template <int NCH, int DT, int NW>   // NCH: 512-column chunks of the latent, 1 (rank <= 512) or 2 (rank <= 1024); DT: dtype of kv_b and of the cache
+template <int NCH, int DT, int NW, int BATCH>   // NCH: 512-column chunks of the latent, 1 (rank <= 512) or 2 (rank <= 1024); DT: dtype of kv_b and of the cache; BATCH: prompt rows (grid.y = token)
 __global__ __launch_bounds__(NW * 64) void k_mla_attn(MlaArgs a) {
   constexpr int NTH = NW * 64;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -3701,8 +3701,19 @@ __global__ __launch_bounds__(NW * 64) void k_mla_attn(MlaArgs a) {
   float* ccur = lds; float* kcur = ccur + R; float* qn = kcur + DR; float* qp = qn + DN; float* qabs = qp + DR;
   float* part = qabs + R; float* red = part + NW * R; float* sc = red + 16;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hd = blockIdx.x;
-  const int pos = a.pos[0], len = pos + 1;
+  const int tok = BATCH ? blockIdx.y : 0;
+  const int pos = BATCH ? a.pos0 + tok : a.pos[0], len = pos + 1;
+  const int nc = BATCH ? len : pos;                 // positions read from the cache (the batched form finds the token's own row there too)
   const int QH = DN + DR, qoff = hd * QH, coff = a.n_heads * QH;
+  const float* qrow = BATCH ? (const float*)a.qkv.p + (size_t)tok * a.q_stride : nullptr;
+  auto qsrc = [&](int i) -> float { return BATCH ? qrow[i] : vsrc_get(a.qkv, i, a.act); };
+  auto csrc = [&](int i) -> float { return a.kva ? a.kva[i] : vsrc_get(a.qkv, coff + i, a.act); };   // latent | k_pe of the current token (decode)
+  const size_t rowbase = (size_t)a.layer * a.kv.layer_stride;
+  const int Wd = R + DR;
+  auto rowoff = [&](int p) -> size_t {
+    if (a.kv.paged) return rowbase + ((size_t)a.kv.block_table[p / a.kv.bs] * a.kv.bs + (p % a.kv.bs)) * Wd;
+    return rowbase + (size_t)p * Wd;
+  };
   const size_t wrow0 = (size_t)hd * (DN + DV);
   constexpr int RIF = (NW == 4 ? 16 : 8) / NCH, TIF = (NW == 4 ? 8 : 4) / NCH;   // weight rows / cache rows a wave keeps in flight
   bool con[NCH]; int colc[NCH];                      // this lane's 8 columns per chunk (clamped when beyond the rank)
@@ -3719,25 +3730,30 @@ __global__ __launch_bounds__(NW * 64) void k_mla_attn(MlaArgs a) {
   __builtin_amdgcn_sched_barrier(0);
 
   // ---- current token: latent norm, k_pe / q_pe rope, q_nope ----
-  float ss = 0.f;
-  for (int r = tid; r < R; r += NTH) { const float v = vsrc_get(a.qkv, coff + r, a.act); ccur[r] = v; ss += v * v; }
-  ss = block_sum_nw<NW>(ss, red);
-  const float rs = 1.0f / sqrtf(ss / (float)R + a.eps);
-  for (int r = tid; r < R; r += NTH) ccur[r] = round_act(a.kv_norm[r] * round_act(ccur[r] * rs, a.act), a.act);
   const float* cr = a.cos_t + (size_t)pos * (DR / 2); const float* sr = a.sin_t + (size_t)pos * (DR / 2);
+  if (!BATCH) {
+    float ss = 0.f;
+    for (int r = tid; r < R; r += NTH) { const float v = csrc(r); ccur[r] = v; ss += v * v; }
+    ss = block_sum_nw<NW>(ss, red);
+    const float rs = 1.0f / sqrtf(ss / (float)R + a.eps);
+    for (int r = tid; r < R; r += NTH) ccur[r] = round_act(a.kv_norm[r] * round_act(ccur[r] * rs, a.act), a.act);
+  }
   for (int j = tid; j < DR / 2; j += NTH) {
     const float c = cr[j], s = sr[j];
-    float x0 = vsrc_get(a.qkv, coff + R + 2 * j, a.act), x1 = vsrc_get(a.qkv, coff + R + 2 * j + 1, a.act);
-    kcur[2 * j] = round_act(x0 * c - x1 * s, a.act); kcur[2 * j + 1] = round_act(x1 * c + x0 * s, a.act);
-    x0 = vsrc_get(a.qkv, qoff + DN + 2 * j, a.act); x1 = vsrc_get(a.qkv, qoff + DN + 2 * j + 1, a.act);
+    if (!BATCH) {
+      const float k0 = csrc(R + 2 * j), k1 = csrc(R + 2 * j + 1);
+      kcur[2 * j] = round_act(k0 * c - k1 * s, a.act); kcur[2 * j + 1] = round_act(k1 * c + k0 * s, a.act);
+    }
+    const float x0 = qsrc(qoff + DN + 2 * j), x1 = qsrc(qoff + DN + 2 * j + 1);
     qp[2 * j] = round_act(x0 * c - x1 * s, a.act); qp[2 * j + 1] = round_act(x1 * c + x0 * s, a.act);
   }
-  for (int d = tid; d < DN; d += NTH) qn[d] = vsrc_get(a.qkv, qoff + d, a.act);
+  for (int d = tid; d < DN; d += NTH) qn[d] = qsrc(qoff + d);
   __syncthreads();
-  const size_t rowbase = (size_t)a.layer * a.kv.layer_stride;
-  const int Wd = R + DR;
-  if (hd == 0) {
-    for (int i = tid; i < Wd; i += NTH) kv_st(a.kv.k, rowbase + (size_t)pos * Wd + i, a.kv.dtype, i < R ? ccur[i] : kcur[i - R]);
+  if (!BATCH && hd == 0) {
+    size_t wo;
+    if (a.kv.paged) { const int slot = a.kv.slot ? a.kv.slot[0] : (a.kv.block_table[pos / a.kv.bs] * a.kv.bs + pos % a.kv.bs); wo = rowbase + (size_t)slot * Wd; }
+    else wo = rowbase + (size_t)pos * Wd;
+    for (int i = tid; i < Wd; i += NTH) kv_st(a.kv.k, wo + i, a.kv.dtype, i < R ? ccur[i] : kcur[i - R]);
   }
   {
     float acc[NCH][8];
@@ -3782,11 +3798,11 @@ __global__ __launch_bounds__(NW * 64) void k_mla_attn(MlaArgs a) {
   for (int c = 0; c < NCH; c++)
 #pragma unroll
     for (int e = 0; e < 8; e++) qa[c][e] = con[c] ? qabs[colc[c] + e] : 0.f;
-  for (int t0 = wave; t0 < pos; t0 += NW * TIF) {
+  for (int t0 = wave; t0 < nc; t0 += NW * TIF) {
     float cv[TIF][NCH][8], kp[TIF];
 #pragma unroll
     for (int u = 0; u < TIF; u++) {
-      const size_t ro = rowbase + (size_t)min(t0 + NW * u, pos - 1) * Wd;
+      const size_t ro = rowoff(min(t0 + NW * u, nc - 1));
 #pragma unroll
       for (int c = 0; c < NCH; c++) ld8t<DT>(a.kv.k, ro + colc[c], cv[u][c]);
       kp[u] = ld1t<DT>(a.kv.k, ro + R + min(lane, DR - 1));
@@ -3799,10 +3815,10 @@ __global__ __launch_bounds__(NW * 64) void k_mla_attn(MlaArgs a) {
 #pragma unroll
         for (int e = 0; e < 8; e++) dsum += qa[c][e] * cv[u][c][e];
       dsum = wave_sum(dsum);
-      if (lane == 0 && t0 + NW * u < pos) sc[t0 + NW * u] = dsum * a.scale;
+      if (lane == 0 && t0 + NW * u < nc) sc[t0 + NW * u] = dsum * a.scale;
     }
   }
-  if (wave == 0) {
+  if (!BATCH && wave == 0) {
     float dsum = (lane < DR) ? qpl * kcur[lane] : 0.f;
 #pragma unroll
     for (int c = 0; c < NCH; c++)
@@ -3840,22 +3856,24 @@ __global__ __launch_bounds__(NW * 64) void k_mla_attn(MlaArgs a) {
     for (int c = 0; c < NCH; c++)
 #pragma unroll
       for (int e = 0; e < 8; e++) acc[c][e] = 0.f;
-    for (int t0 = wave; t0 < pos; t0 += NW * TIF) {
+    for (int t0 = wave; t0 < nc; t0 += NW * TIF) {
       float cv[TIF][NCH][8];
 #pragma unroll
-      for (int u = 0; u < TIF; u++)
+      for (int u = 0; u < TIF; u++) {
+        const size_t ro = rowoff(min(t0 + NW * u, nc - 1));
 #pragma unroll
-        for (int c = 0; c < NCH; c++) ld8t<DT>(a.kv.k, rowbase + (size_t)min(t0 + NW * u, pos - 1) * Wd + colc[c], cv[u][c]);
+        for (int c = 0; c < NCH; c++) ld8t<DT>(a.kv.k, ro + colc[c], cv[u][c]);
+      }
 #pragma unroll
       for (int u = 0; u < TIF; u++) {
-        const float p = (t0 + NW * u < pos) ? sc[t0 + NW * u] : 0.f;
+        const float p = (t0 + NW * u < nc) ? sc[t0 + NW * u] : 0.f;
 #pragma unroll
         for (int c = 0; c < NCH; c++)
 #pragma unroll
           for (int e = 0; e < 8; e++) acc[c][e] += p * cv[u][c][e];
       }
     }
-    if (wave == (pos % NW)) {       // the current token, in the wave that would own it in token order
+    if (!BATCH && wave == (pos % NW)) {       // the current token, in the wave that would own it in token order
       const float p = sc[pos];
 #pragma unroll
       for (int c = 0; c < NCH; c++)
@@ -3897,37 +3915,90 @@ __global__ __launch_bounds__(NW * 64) void k_mla_attn(MlaArgs a) {
 #pragma unroll
         for (int e = 0; e < 8; e++) s += w0[u][c][e] * qa[c][e];
       s = wave_sum(s);
-      if (lane == 0 && d + u < v1) a.out[hd * DV + d + u] = round_act(s, a.act);
+      if (lane == 0 && d + u < v1) a.out[(BATCH ? (size_t)tok * a.out_stride : 0) + hd * DV + d + u] = round_act(s, a.act);
     }
   }
 }
 
 static int mla_waves(const MlaArgs& a) {
-  static const bool w4 = getenv("BZ_MLA_NW4") != nullptr;
-  return (!w4 && a.nope % 16 == 0 && a.vdim % 16 == 0) ? 16 : 4;
+  // decode: one workgroup per head, 16 waves hide each other's dependent chains.  Prompt rows: thousands of (head, token) workgroups -- four waves
+  // each, so that a CU runs several of these latency chains at once (16-wave workgroups ran one per CU: 621 us per layer at 512 tokens)
+  return (a.batch == 0 && a.nope % 16 == 0 && a.vdim % 16 == 0) ? 16 : 4;
 }
 size_t bzk_mla_smem(const MlaArgs& a, int max_len) { return (size_t)(a.rank * (2 + mla_waves(a)) + a.rope * 2 + a.nope + 16 + max_len) * 4 + 64; }
 
 int bzk_mla_attn(hipStream_t s, const MlaArgs& a, int max_len) {
-  if (a.rank % 8 || a.rank > 1024 || a.rope > 64 || (a.rope & 1) || a.nope % 4 || a.vdim % 4 || a.kv.paged || a.kv.n_kv != 1 || a.kv.hd != a.rank + a.rope)
+  if (a.rank % 8 || a.rank > 1024 || a.rope > 64 || (a.rope & 1) || a.nope % 4 || a.vdim % 4 || a.kv.n_kv != 1 || a.kv.hd != a.rank + a.rope)
     BZ_FAIL(BZ_E_UNSUPPORTED, "mla_attn: rank %d / rope %d / nope %d / v %d unsupported", a.rank, a.rope, a.nope, a.vdim);
   const size_t smem = bzk_mla_smem(a, max_len);
   if (smem > 160 * 1024) BZ_FAIL(BZ_E_UNSUPPORTED, "mla_attn: context %d too long for the single-pass kernel", max_len);
   if (a.wdt != a.kv.dtype) BZ_FAIL(BZ_E_UNSUPPORTED, "mla_attn: kv_b_proj dtype %d must equal the cache dtype %d", a.wdt, a.kv.dtype);
   const double bytes = (double)a.n_heads * (a.nope + a.vdim) * a.rank * bz_dtype_size(a.wdt);
   const int NWV = mla_waves(a);
-#define LAUNCH_MLA_W(NCH, DT, W_) do { \
+#define LAUNCH_MLA_WB(NCH, DT, W_, B_) do { \
     static bool attr_done = false; \
-    if (!attr_done) { BZ_HIP(hipFuncSetAttribute((const void*)k_mla_attn<NCH, DT, W_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_done = true; } \
-    BZ_LAUNCH("mla_attn", bytes, (k_mla_attn<NCH, DT, W_>), dim3(a.n_heads), dim3(W_ * 64), smem, s, a); } while (0)
+    if (!attr_done) { BZ_HIP(hipFuncSetAttribute((const void*)k_mla_attn<NCH, DT, W_, B_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_done = true; } \
+    BZ_LAUNCH(B_ ? "mla_attn<rows>" : "mla_attn", bytes, (k_mla_attn<NCH, DT, W_, B_>), dim3(a.n_heads, B_ ? a.batch : 1), dim3(W_ * 64), smem, s, a); } while (0)
+#define LAUNCH_MLA_W(NCH, DT, W_) do { if (a.batch > 0) LAUNCH_MLA_WB(NCH, DT, W_, 1); else LAUNCH_MLA_WB(NCH, DT, W_, 0); } while (0)
 #define LAUNCH_MLA(NCH, DT) do { if (NWV == 16) LAUNCH_MLA_W(NCH, DT, 16); else LAUNCH_MLA_W(NCH, DT, 4); } while (0)
 #define LAUNCH_MLA_DT(DT) do { if (a.rank <= 512) LAUNCH_MLA(1, DT); else LAUNCH_MLA(2, DT); } while (0)
   if (a.wdt == BZ_F16) LAUNCH_MLA_DT(BZ_F16); else if (a.wdt == BZ_BF16) LAUNCH_MLA_DT(BZ_BF16); else LAUNCH_MLA_DT(BZ_F32);
 #undef LAUNCH_MLA_DT
 #undef LAUNCH_MLA
 #undef LAUNCH_MLA_W
+#undef LAUNCH_MLA_WB
   BZ_HIP(hipGetLastError());
   return BZ_OK;
+}
+
+// one wave: f32 softmax over E logits (the oracle's sequential sum) + greedy top-k (ties -> lowest index); lane l owns experts l, l + 64, ... (E <= 1024).
+// Shared by the decode router and the prompt-row router, so a token is routed identically on both paths.
+__device__ __forceinline__ void moe_softmax_topk(const float* lg, int E, int top_k, int n_shared, float routed_scale, int norm_topk, int* sel, float* wsel, int lane) {
+    // wave-parallel softmax + greedy top-k; lane l owns experts l, l + 64, ... (E <= 1024)
+    float v[16];
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 16; j++) { const int ee = lane + 64 * j; v[j] = ee < E ? lg[ee] : -INFINITY; m = fmaxf(m, v[j]); }
+    m = wave_max(m);
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; j++) { const int ee = lane + 64 * j; v[j] = ee < E ? expf(v[j] - m) : 0.f; }
+    for (int ee = 0; ee < E; ee++) sum += expf(lg[ee] - m);      // the oracle's sequential order
+#pragma unroll
+    for (int j = 0; j < 16; j++) { const int ee = lane + 64 * j; v[j] = ee < E ? v[j] / sum : -1.f; }
+    float tsum = 0.f, myw = 0.f; int mysel = 0;
+    for (int k = 0; k < top_k; k++) {
+      float bv = -1.f; int bi = 0x7fffffff;
+#pragma unroll
+      for (int j = 0; j < 16; j++) { const int ee = lane + 64 * j; if (v[j] > bv) { bv = v[j]; bi = ee; } }   // ascending e within a lane: first max wins
+      // wave argmax (larger value, then smaller index) without the LDS permute network: every step is symmetric, so all lanes agree
+#define ROUTER_STEP(OV, OI) do { const float ov_ = (OV); const int oi_ = (OI); if (ov_ > bv || (ov_ == bv && oi_ < bi)) { bv = ov_; bi = oi_; } } while (0)
+      ROUTER_STEP(dpp_get<DPP_XOR1>(bv), dpp_get<DPP_XOR1>(bi));
+      ROUTER_STEP(dpp_get<DPP_XOR2>(bv), dpp_get<DPP_XOR2>(bi));
+      ROUTER_STEP(dpp_get<DPP_HMIRROR>(bv), dpp_get<DPP_HMIRROR>(bi));
+      ROUTER_STEP(dpp_get<DPP_MIRROR>(bv), dpp_get<DPP_MIRROR>(bi));
+      {
+        const bz_u2_t rv = __builtin_amdgcn_permlane16_swap(__float_as_uint(bv), __float_as_uint(bv), false, false);
+        const bz_u2_t ri = __builtin_amdgcn_permlane16_swap((unsigned)bi, (unsigned)bi, false, false);
+        const float v0 = __uint_as_float(rv.x), v1 = __uint_as_float(rv.y); const int i0 = (int)ri.x, i1 = (int)ri.y;
+        const bool first = v0 > v1 || (v0 == v1 && i0 < i1);
+        bv = first ? v0 : v1; bi = first ? i0 : i1;
+      }
+      {
+        const bz_u2_t rv = __builtin_amdgcn_permlane32_swap(__float_as_uint(bv), __float_as_uint(bv), false, false);
+        const bz_u2_t ri = __builtin_amdgcn_permlane32_swap((unsigned)bi, (unsigned)bi, false, false);
+        const float v0 = __uint_as_float(rv.x), v1 = __uint_as_float(rv.y); const int i0 = (int)ri.x, i1 = (int)ri.y;
+        const bool first = v0 > v1 || (v0 == v1 && i0 < i1);
+        bv = first ? v0 : v1; bi = first ? i0 : i1;
+      }
+#undef ROUTER_STEP
+      if (lane == k) { mysel = bi; myw = bv; }
+      tsum += bv;
+#pragma unroll
+      for (int j = 0; j < 16; j++) if (lane + 64 * j == bi) v[j] = -1.f;
+    }
+    if (lane < top_k) { sel[lane] = mysel; wsel[lane] = norm_topk ? myw / (tsum + 1e-20f) * routed_scale : myw * routed_scale; }
+    if (lane < n_shared) { sel[top_k + lane] = E + lane; wsel[top_k + lane] = 1.0f; }
 }
 
 // Router: one workgroup.  Residual add + RMSNorm (writes h' and the normalised x for the expert GEMVs), f32 logits over E
@@ -3978,53 +4049,7 @@ __global__ __launch_bounds__(256) void k_moe_router(Pro pro, const void* wr, int
   for (int i = tid; i < E; i += 256) lg[i] = __hip_atomic_load(lg_glob + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (tid == 0) *counter = 0;                    // ready for the next launch (stream order)
   __syncthreads();
-  if (wave == 0) {
-    // wave-parallel softmax + greedy top-k; lane l owns experts l, l + 64, ... (E <= 1024)
-    float v[16];
-    float m = -INFINITY;
-#pragma unroll
-    for (int j = 0; j < 16; j++) { const int ee = lane + 64 * j; v[j] = ee < E ? lg[ee] : -INFINITY; m = fmaxf(m, v[j]); }
-    m = wave_max(m);
-    float sum = 0.f;
-#pragma unroll
-    for (int j = 0; j < 16; j++) { const int ee = lane + 64 * j; v[j] = ee < E ? expf(v[j] - m) : 0.f; }
-    for (int ee = 0; ee < E; ee++) sum += expf(lg[ee] - m);      // the oracle's sequential order
-#pragma unroll
-    for (int j = 0; j < 16; j++) { const int ee = lane + 64 * j; v[j] = ee < E ? v[j] / sum : -1.f; }
-    float tsum = 0.f, myw = 0.f; int mysel = 0;
-    for (int k = 0; k < top_k; k++) {
-      float bv = -1.f; int bi = 0x7fffffff;
-#pragma unroll
-      for (int j = 0; j < 16; j++) { const int ee = lane + 64 * j; if (v[j] > bv) { bv = v[j]; bi = ee; } }   // ascending e within a lane: first max wins
-      // wave argmax (larger value, then smaller index) without the LDS permute network: every step is symmetric, so all lanes agree
-#define ROUTER_STEP(OV, OI) do { const float ov_ = (OV); const int oi_ = (OI); if (ov_ > bv || (ov_ == bv && oi_ < bi)) { bv = ov_; bi = oi_; } } while (0)
-      ROUTER_STEP(dpp_get<DPP_XOR1>(bv), dpp_get<DPP_XOR1>(bi));
-      ROUTER_STEP(dpp_get<DPP_XOR2>(bv), dpp_get<DPP_XOR2>(bi));
-      ROUTER_STEP(dpp_get<DPP_HMIRROR>(bv), dpp_get<DPP_HMIRROR>(bi));
-      ROUTER_STEP(dpp_get<DPP_MIRROR>(bv), dpp_get<DPP_MIRROR>(bi));
-      {
-        const bz_u2_t rv = __builtin_amdgcn_permlane16_swap(__float_as_uint(bv), __float_as_uint(bv), false, false);
-        const bz_u2_t ri = __builtin_amdgcn_permlane16_swap((unsigned)bi, (unsigned)bi, false, false);
-        const float v0 = __uint_as_float(rv.x), v1 = __uint_as_float(rv.y); const int i0 = (int)ri.x, i1 = (int)ri.y;
-        const bool first = v0 > v1 || (v0 == v1 && i0 < i1);
-        bv = first ? v0 : v1; bi = first ? i0 : i1;
-      }
-      {
-        const bz_u2_t rv = __builtin_amdgcn_permlane32_swap(__float_as_uint(bv), __float_as_uint(bv), false, false);
-        const bz_u2_t ri = __builtin_amdgcn_permlane32_swap((unsigned)bi, (unsigned)bi, false, false);
-        const float v0 = __uint_as_float(rv.x), v1 = __uint_as_float(rv.y); const int i0 = (int)ri.x, i1 = (int)ri.y;
-        const bool first = v0 > v1 || (v0 == v1 && i0 < i1);
-        bv = first ? v0 : v1; bi = first ? i0 : i1;
-      }
-#undef ROUTER_STEP
-      if (lane == k) { mysel = bi; myw = bv; }
-      tsum += bv;
-#pragma unroll
-      for (int j = 0; j < 16; j++) if (lane + 64 * j == bi) v[j] = -1.f;
-    }
-    if (lane < top_k) { sel[lane] = mysel; wsel[lane] = norm_topk ? myw / (tsum + 1e-20f) * routed_scale : myw * routed_scale; }
-    if (lane < n_shared) { sel[top_k + lane] = E + lane; wsel[top_k + lane] = 1.0f; }
-  }
+  if (wave == 0) moe_softmax_topk(lg, E, top_k, n_shared, routed_scale, norm_topk, sel, wsel, lane);
 }
 
 int bzk_moe_router(hipStream_t s, const Pro& pro, const void* wr, int wdt, int E, int top_k, int n_shared, float routed_scale, int norm_topk,
@@ -4072,6 +4097,140 @@ __global__ void k_moe_combine(long long* acc, const float* wsel, int top_k, int 
 }
 int bzk_moe_combine(hipStream_t s, long long* acc, const float* wsel, int top_k, int has_shared, int H, int act, float* out) {
   BZ_LAUNCH("moe_combine", 0.0, k_moe_combine, dim3((H + 255) / 256), dim3(256), 0, s, acc, wsel, top_k, has_shared, H, act, out);
+  BZ_HIP(hipGetLastError());
+  return BZ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// DeepSeek-V2 prompt rows (batched prefill): latent append, routing, per-expert row lists, gather, combine
+// ---------------------------------------------------------------------------------------------------------
+// row s: c = R(w R(kva[:rank] rs)), k_pe = R(rope(kva[rank:])) -> cache row pos0 + s (the decode kernel's arithmetic, row-wise).  grid = S
+__global__ __launch_bounds__(256) void k_mla_append_rows(const float* __restrict__ kva, long long stride, const float* __restrict__ kv_norm, float eps, int R, int DR,
+                                                         const float* __restrict__ cos_t, const float* __restrict__ sin_t, int pos0, int act, KvView kv, int layer) {
+  __shared__ float red[4];
+  const int s = blockIdx.x, tid = threadIdx.x, pos = pos0 + s;
+  const float* row = kva + (size_t)s * stride;
+  float ss = 0.f;
+  for (int r = tid; r < R; r += 256) { const float v = row[r]; ss += v * v; }
+  ss = wave_sum(ss);
+  if ((tid & 63) == 0) red[tid >> 6] = ss;
+  __syncthreads();
+  ss = (red[0] + red[1]) + (red[2] + red[3]);
+  const float rs = 1.0f / sqrtf(ss / (float)R + eps);
+  const int Wd = R + DR;
+  size_t wo = (size_t)layer * kv.layer_stride;
+  if (kv.paged) wo += ((size_t)kv.block_table[pos / kv.bs] * kv.bs + (pos % kv.bs)) * Wd; else wo += (size_t)pos * Wd;
+  for (int r = tid; r < R; r += 256) kv_st(kv.k, wo + r, kv.dtype, round_act(kv_norm[r] * round_act(row[r] * rs, act), act));
+  const float* cr = cos_t + (size_t)pos * (DR / 2); const float* sr = sin_t + (size_t)pos * (DR / 2);
+  for (int j = tid; j < DR / 2; j += 256) {
+    const float c = cr[j], sn = sr[j], x0 = row[R + 2 * j], x1 = row[R + 2 * j + 1];
+    kv_st(kv.k, wo + R + 2 * j, kv.dtype, round_act(x0 * c - x1 * sn, act));
+    kv_st(kv.k, wo + R + 2 * j + 1, kv.dtype, round_act(x1 * c + x0 * sn, act));
+  }
+}
+int bzk_mla_append_rows(hipStream_t s, const float* kva, long long stride, int S, const float* kv_norm, float eps, int rank, int rope, const float* cos_t, const float* sin_t,
+                        int pos0, int act, const KvView& kv, int layer) {
+  hipLaunchKernelGGL(k_mla_append_rows, dim3(S), dim3(256), 0, s, kva, stride, kv_norm, eps, rank, rope, cos_t, sin_t, pos0, act, kv, layer);
+  BZ_HIP(hipGetLastError());
+  return BZ_OK;
+}
+
+// routing of prompt rows: workgroup = one token; the logits are summed exactly as k_moe_router sums them (lane = 8 columns of every 512-column
+// chunk, then the wave tree), so a token gets the same experts and weights as on the decode path.  grid = S, 256 threads.
+template <int DT, int WDT>
+__global__ __launch_bounds__(256) void k_moe_route_rows(const unsigned short* __restrict__ x16, int H, const void* __restrict__ wr, int E, int top_k, float routed_scale,
+                                                        int norm_topk, int* __restrict__ sel, float* __restrict__ wsel) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* xs = lds; float* lg = xs + H;
+  const int t = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  for (int i = tid; i < H; i += 256) {
+    const unsigned short u = x16[(size_t)t * H + i];
+    xs[i] = DT == BZ_F16 ? __half2float(__ushort_as_half(u)) : __uint_as_float((unsigned)u << 16);
+  }
+  __syncthreads();
+  for (int e = wave; e < E; e += 4) {
+    float acc = 0.f;
+    for (int k0 = 0; k0 < H; k0 += 4096) {
+      float w[8][8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) { const int k = k0 + j * 512 + lane * 8; load8<WDT>(wr, (size_t)e * H + (k < H ? k : 0), true, w[j]); }
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int k = k0 + j * 512 + lane * 8;
+        if (k < H) {
+          const float4 xa = *(const float4*)(xs + k), xb = *(const float4*)(xs + k + 4);
+          acc += w[j][0] * xa.x + w[j][1] * xa.y + w[j][2] * xa.z + w[j][3] * xa.w + w[j][4] * xb.x + w[j][5] * xb.y + w[j][6] * xb.z + w[j][7] * xb.w;
+        }
+      }
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) lg[e] = acc;
+  }
+  __syncthreads();
+  if (wave == 0) moe_softmax_topk(lg, E, top_k, 0, routed_scale, norm_topk, sel + (size_t)t * top_k, wsel + (size_t)t * top_k, lane);
+}
+int bzk_moe_route_rows(hipStream_t s, int dt, const void* x16, int S, int H, const void* wr, int wdt, int E, int top_k, float routed_scale, int norm_topk, int* sel, float* wsel) {
+  if (E > 1024 || top_k > E || top_k > 64 || H % 8 || (dt != BZ_F16 && dt != BZ_BF16)) BZ_FAIL(BZ_E_UNSUPPORTED, "moe_route_rows: E %d / top_k %d unsupported", E, top_k);
+  const size_t smem = (size_t)(H + E) * 4 + 64;
+#define LAUNCH_RR(DT, WDT) hipLaunchKernelGGL((k_moe_route_rows<DT, WDT>), dim3(S), dim3(256), smem, s, (const unsigned short*)x16, H, wr, E, top_k, routed_scale, norm_topk, sel, wsel)
+#define LAUNCH_RR_W(DT) do { if (wdt == BZ_F16) LAUNCH_RR(DT, BZ_F16); else if (wdt == BZ_BF16) LAUNCH_RR(DT, BZ_BF16); else LAUNCH_RR(DT, BZ_F32); } while (0)
+  if (dt == BZ_F16) LAUNCH_RR_W(BZ_F16); else LAUNCH_RR_W(BZ_BF16);
+#undef LAUNCH_RR_W
+#undef LAUNCH_RR
+  BZ_HIP(hipGetLastError());
+  return BZ_OK;
+}
+
+// per-expert row lists of S x top_k (token, slot) pairs: counts, exclusive offsets, row_of[(t, k)] and tok_of[row].  One workgroup; the order of rows
+// inside an expert's list depends on the atomics, the results do not (rows are independent and scattered back by (t, k)).
+__global__ __launch_bounds__(1024) void k_moe_plan_rows(const int* __restrict__ sel, int n, int E, int* __restrict__ counts, int* __restrict__ offsets, int* __restrict__ row_of,
+                                                        int* __restrict__ tok_of, int top_k) {
+  __shared__ int cnt[1024], off[1024], fill[1024];
+  const int tid = threadIdx.x;
+  if (tid < E) { cnt[tid] = 0; fill[tid] = 0; }
+  __syncthreads();
+  for (int i = tid; i < n; i += 1024) atomicAdd(&cnt[sel[i]], 1);
+  __syncthreads();
+  if (tid == 0) { int a = 0; for (int e = 0; e < E; e++) { off[e] = a; a += cnt[e]; } }
+  __syncthreads();
+  if (tid < E) { counts[tid] = cnt[tid]; offsets[tid] = off[tid]; }
+  for (int i = tid; i < n; i += 1024) {
+    const int e = sel[i];
+    const int r = off[e] + atomicAdd(&fill[e], 1);
+    row_of[i] = r; tok_of[r] = i / top_k;
+  }
+}
+int bzk_moe_plan_rows(hipStream_t s, const int* sel, int S, int top_k, int E, int* counts, int* offsets, int* row_of, int* tok_of) {
+  if (E > 1024) BZ_FAIL(BZ_E_UNSUPPORTED, "moe_plan_rows: %d experts", E);
+  hipLaunchKernelGGL(k_moe_plan_rows, dim3(1), dim3(1024), 0, s, sel, S * top_k, E, counts, offsets, row_of, tok_of, top_k);
+  BZ_HIP(hipGetLastError());
+  return BZ_OK;
+}
+__global__ void k_moe_gather_rows(const uint4* __restrict__ x16, const int* __restrict__ tok_of, int H8, uint4* __restrict__ xg16) {
+  const int r = blockIdx.x;
+  const uint4* src = x16 + (size_t)tok_of[r] * H8;
+  for (int i = threadIdx.x; i < H8; i += blockDim.x) xg16[(size_t)r * H8 + i] = src[i];
+}
+int bzk_moe_gather_rows(hipStream_t s, const void* x16, const int* tok_of, int rows, int H, void* xg16) {
+  if (H % 8) BZ_FAIL(BZ_E_UNSUPPORTED, "moe_gather_rows: hidden %d", H);
+  hipLaunchKernelGGL(k_moe_gather_rows, dim3(rows), dim3(256), 0, s, (const uint4*)x16, tok_of, H / 8, (uint4*)xg16);
+  BZ_HIP(hipGetLastError());
+  return BZ_OK;
+}
+// out[t][i] = R(R(sum_k w[t][k] * ye[row_of[t][k]][i]) + R(ysh[t][i]))   -- k_moe_combine's expression, row-wise; ysh: unrounded sum of the shared slots (nullptr: none)
+__global__ void k_moe_combine_rows(const float* __restrict__ ye, const int* __restrict__ row_of, const float* __restrict__ wsel, const float* __restrict__ ysh, int top_k, int H,
+                                   int act, float* __restrict__ out) {
+  const int t = blockIdx.x;
+  for (int i = threadIdx.x; i < H; i += blockDim.x) {
+    float r = 0.f;
+    for (int k = 0; k < top_k; k++) r += wsel[(size_t)t * top_k + k] * ye[(size_t)row_of[(size_t)t * top_k + k] * H + i];
+    r = round_act(r, act);
+    if (ysh) r = round_act(r + round_act(ysh[(size_t)t * H + i], act), act);
+    out[(size_t)t * H + i] = r;
+  }
+}
+int bzk_moe_combine_rows(hipStream_t s, const float* ye, const int* row_of, const float* wsel, const float* ysh, int S, int top_k, int H, int act, float* out) {
+  hipLaunchKernelGGL(k_moe_combine_rows, dim3(S), dim3(256), 0, s, ye, row_of, wsel, ysh, top_k, H, act, out);
   BZ_HIP(hipGetLastError());
   return BZ_OK;
 }

@@ -52,8 +52,15 @@ __device__ __forceinline__ f32x16 mfma16(const uint4& a, const uint4& b, f32x16 
 constexpr int A_STRIDE = 144;   // bytes per LDS row: 64 k x 2 B + 16 B pad
 template <int DT, int MT, int NT>
 __global__ __launch_bounds__(256) void k_gemm_nt(const unsigned short* __restrict__ X, const unsigned short* __restrict__ W, const float* __restrict__ bias,
-                                                 int S, int N, int K, int act, float* __restrict__ Y) {
+                                                 int S, int N, int K, int act, float* __restrict__ Y, const int* __restrict__ g_off, const int* __restrict__ g_cnt,
+                                                 long long w_stride) {
   __shared__ __attribute__((aligned(16))) unsigned char sA[2][32 * MT * A_STRIDE];
+  if (g_cnt) {   // grouped form (MoE experts over gathered token rows): group blockIdx.z owns rows [g_off, g_off + g_cnt) of X / Y and the z-th weight matrix
+    const int z = blockIdx.z, off = g_off[z];
+    S = g_cnt[z];
+    if ((int)blockIdx.y * 32 * MT >= S) return;
+    X += (size_t)off * K; Y += (size_t)off * N; W += (size_t)z * w_stride;
+  }
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int n0 = (blockIdx.x * 4 + wave) * 32 * NT, m0 = blockIdx.y * 32 * MT;
   // B: lane (r,h) reads 64 contiguous bytes (k = 32 h .. 32 h + 31) of row n per 64-k tile
@@ -625,13 +632,33 @@ int bzk_gemm_nt(hipStream_t s, int dt, const void* x16, const void* w, const flo
   while (MT > 1 && waves(MT, NT) < 512) MT = MT == 3 ? 2 : MT / 2;
   const dim3 grid((N + 128 * NT - 1) / (128 * NT), (S + 32 * MT - 1) / (32 * MT));
   const double flops = 2.0 * S * (double)N * K;
-#define LAUNCH_GEMM(DT, M, NN) BZ_LAUNCH("gemm_nt_mfma", flops, (k_gemm_nt<DT, M, NN>), grid, dim3(256), 0, s, (const unsigned short*)x16, (const unsigned short*)w, bias, S, N, K, act, y)
+#define LAUNCH_GEMM(DT, M, NN) BZ_LAUNCH("gemm_nt_mfma", flops, (k_gemm_nt<DT, M, NN>), grid, dim3(256), 0, s, (const unsigned short*)x16, (const unsigned short*)w, bias, S, N, K, act, y, \
+                                         (const int*)nullptr, (const int*)nullptr, 0LL)
 #define LAUNCH_GEMM_N(DT, M) do { if (NT == 2) LAUNCH_GEMM(DT, M, 2); else LAUNCH_GEMM(DT, M, 1); } while (0)
 #define LAUNCH_GEMM_M(DT) do { if (MT == 4) LAUNCH_GEMM_N(DT, 4); else if (MT == 3) LAUNCH_GEMM_N(DT, 3); else if (MT == 2) LAUNCH_GEMM_N(DT, 2); else LAUNCH_GEMM_N(DT, 1); } while (0)
   if (dt == BZ_F16) LAUNCH_GEMM_M(BZ_F16); else LAUNCH_GEMM_M(BZ_BF16);
 #undef LAUNCH_GEMM_M
 #undef LAUNCH_GEMM_N
 #undef LAUNCH_GEMM
+  BZ_HIP(hipGetLastError());
+  return BZ_OK;
+}
+
+// Grouped form: G weight matrices [N][K] (w + g * w_stride elements), group g multiplies the rows [g_off[g], g_off[g] + g_cnt[g]) of x16 / y (device arrays);
+// max_rows = the largest group's row count (host copy), total_rows for the FLOP accounting.  One launch for all the experts of a MoE layer.
+int bzk_gemm_nt_grouped(hipStream_t s, int dt, const void* x16, const void* w, long long w_stride, int G, const int* g_off, const int* g_cnt, int max_rows, long long total_rows,
+                        int N, int K, int act, float* y) {
+  if (dt != BZ_F16 && dt != BZ_BF16) BZ_FAIL(BZ_E_UNSUPPORTED, "gemm_nt_grouped: 16-bit operands only");
+  if (K % 64 || K < 64 || N <= 0 || G <= 0) BZ_FAIL(BZ_E_UNSUPPORTED, "gemm_nt_grouped: K=%d must be a positive multiple of 64", K);
+  if (max_rows <= 0) return BZ_OK;
+  const int MT = max_rows > 32 ? 2 : 1;        // experts see tens of rows each: small row tiles, the grid is filled by the groups
+  const dim3 grid((N + 127) / 128, (max_rows + 32 * MT - 1) / (32 * MT), G);
+  const double flops = 2.0 * (double)total_rows * N * K;
+#define LAUNCH_GG(DT, M) BZ_LAUNCH("gemm_nt_mfma<grouped>", flops, (k_gemm_nt<DT, M, 1>), grid, dim3(256), 0, s, (const unsigned short*)x16, (const unsigned short*)w, (const float*)nullptr, \
+                                   0, N, K, act, y, g_off, g_cnt, w_stride)
+  if (dt == BZ_F16) { if (MT == 2) LAUNCH_GG(BZ_F16, 2); else LAUNCH_GG(BZ_F16, 1); }
+  else { if (MT == 2) LAUNCH_GG(BZ_BF16, 2); else LAUNCH_GG(BZ_BF16, 1); }
+#undef LAUNCH_GG
   BZ_HIP(hipGetLastError());
   return BZ_OK;
 }

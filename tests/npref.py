@@ -317,20 +317,22 @@ class NpDsv2:
     agree with the oracle's absorbed form to float precision (it validates the algebra, the RoPE convention, the router and the
     MoE combine); in bf16 the two forms round at different places and agree only to a few bf16 ulps."""
 
-    def __init__(self, model):
-        self.m, self.cfg = model, model["config"]
-        self.emb = dequant(dict(kind="dense", weight=model["embed"]))
-        self.lm = dequant(model["lm_head"])
+    def __init__(self, model, truth=False):
+        """truth=True: no rounding anywhere, every tensor and sum in float64 (what the oracle and the HIP path both approximate)"""
+        self.m, self.cfg, self.truth = model, model["config"], truth
+        dq = (lambda spec: dequant(spec).astype(np.float64)) if truth else dequant
+        self.emb = dq(dict(kind="dense", weight=model["embed"]))
+        self.lm = dq(model["lm_head"])
         self.W = []
         for lay in model["layers"]:
-            w = {k: dequant(lay[k]) for k in ("q_proj", "kv_a", "kv_b", "o")}
+            w = {k: dq(lay[k]) for k in ("q_proj", "kv_a", "kv_b", "o")}
             if lay["is_moe"]:
-                w["router"] = dequant(lay["router"])
-                w["experts"] = [{k: dequant(e[k]) for k in ("gate", "up", "down")} for e in lay["experts"]]
+                w["router"] = dq(lay["router"])
+                w["experts"] = [{k: dq(e[k]) for k in ("gate", "up", "down")} for e in lay["experts"]]
                 if "shared" in lay:
-                    w["shared"] = {k: dequant(lay["shared"][k]) for k in ("gate", "up", "down")}
+                    w["shared"] = {k: dq(lay["shared"][k]) for k in ("gate", "up", "down")}
             else:
-                w.update({k: dequant(lay[k]) for k in ("gate", "up", "down")})
+                w.update({k: dq(lay[k]) for k in ("gate", "up", "down")})
             self.W.append(w)
         self.lat = [[] for _ in model["layers"]]
 
@@ -339,7 +341,7 @@ class NpDsv2:
         half = c["rope_dim"] // 2
         inv = 1.0 / (np.float64(c["rope_theta"]) ** (np.arange(half, dtype=np.float64) * 2 / c["rope_dim"]))
         ang = pos * inv
-        cs, sn = np.cos(ang).astype(np.float32), np.sin(ang).astype(np.float32)
+        cs, sn = (np.cos(ang), np.sin(ang)) if self.truth else (np.cos(ang).astype(np.float32), np.sin(ang).astype(np.float32))
         x = v.reshape(-1, half, 2)
         out = np.empty_like(x)
         out[..., 0] = x[..., 0] * cs - x[..., 1] * sn
@@ -349,42 +351,45 @@ class NpDsv2:
     def step(self, token, pos):
         c = self.cfg
         act = c["act_dtype"]
-        R = lambda a: round_act(a, act)
+        truth = self.truth
+        R = (lambda a: a) if truth else (lambda a: round_act(a, act))
+        fdt = np.float64 if truth else np.float32
+        rms_norm_ = (lambda x, w, eps, _a: np.asarray(w, np.float64) * (x / np.sqrt(np.mean(x * x) + eps))) if truth else rms_norm
         NH, RK, DN, DR, DV = c["n_heads"], c["kv_lora_rank"], c["nope_dim"], c["rope_dim"], c["v_dim"]
         silu = lambda a: a / (1.0 + np.exp(-a))
         mlp = lambda w, x: R(R(R(silu(R(x @ w["gate"].T))) * R(x @ w["up"].T)) @ w["down"].T)
         h = R(self.emb[token])
         for l, lay in enumerate(self.m["layers"]):
             w = self.W[l]
-            xn = rms_norm(h, lay["attn_norm"], c["rms_eps"], act)
+            xn = rms_norm_(h, lay["attn_norm"], c["rms_eps"], act)
             q = R(xn @ w["q_proj"].T).reshape(NH, DN + DR)
             kva = R(xn @ w["kv_a"].T)
-            lat = rms_norm(kva[:RK], lay["kv_norm"], c["rms_eps"], act)
+            lat = rms_norm_(kva[:RK], lay["kv_norm"], c["rms_eps"], act)
             kpe = R(self._rope(kva[RK:], pos))
             self.lat[l].append(np.concatenate([lat, kpe]))
             Cm = np.stack(self.lat[l])                                   # [T, RK + DR]
             kv = R(Cm[:, :RK] @ w["kv_b"].T).reshape(-1, NH, DN + DV)      # naive expansion
             qpe = R(self._rope(q[:, DN:], pos))
-            sc = (np.einsum("hd,thd->ht", q[:, :DN], kv[:, :, :DN]) + qpe @ Cm[:, RK:].T) / np.sqrt(np.float32(DN + DR))
+            sc = (np.einsum("hd,thd->ht", q[:, :DN], kv[:, :, :DN]) + qpe @ Cm[:, RK:].T) / np.sqrt(fdt(DN + DR))
             p = np.exp(sc - sc.max(axis=1, keepdims=True))
             p = p / p.sum(axis=1, keepdims=True)
             att = R(np.einsum("ht,thd->hd", p, kv[:, :, DN:])).reshape(-1)
             h = R(h + R(att @ w["o"].T))
-            xn = rms_norm(h, lay["ffn_norm"], c["rms_eps"], act)
+            xn = rms_norm_(h, lay["ffn_norm"], c["rms_eps"], act)
             if not lay["is_moe"]:
                 out = mlp(w, xn)
             else:
-                lg = (xn @ w["router"].T).astype(np.float32)
+                lg = (xn @ w["router"].T).astype(fdt)
                 s = np.exp(lg - lg.max())
                 s = s / s.sum()
                 sel = np.argsort(-s, kind="stable")[:c["top_k"]]
                 wt = s[sel] / (s[sel].sum() + 1e-20) * c["routed_scale"] if c["norm_topk"] else s[sel] * c["routed_scale"]
                 routed = np.zeros_like(h)
                 for e, we in zip(sel, wt):
-                    routed = routed + np.float32(we) * mlp(w["experts"][int(e)], xn)
+                    routed = routed + fdt(we) * mlp(w["experts"][int(e)], xn)
                 out = R(routed)
                 if "shared" in w:
                     out = R(out + mlp(w["shared"], xn))
             h = R(h + out)
-        xn = rms_norm(h, self.m["final_norm"], c["rms_eps"], act)
+        xn = rms_norm_(h, self.m["final_norm"], c["rms_eps"], act)
         return R(xn @ self.lm.T)

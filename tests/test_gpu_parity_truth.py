@@ -45,3 +45,25 @@ def test_hip_is_as_close_to_the_unrounded_truth_as_the_oracle(device, preset, ov
     # a ratio says nothing -- there the absolute floor applies (three orders of magnitude under the 1e-3 bar)
     assert g2 <= max(1.25 * o2, FLOOR), msg
     assert gm <= max(1.25 * omx, 3 * FLOOR), msg
+
+
+def test_dsv2_full_width_against_the_unrounded_truth(device):
+    """DeepSeek-V2-Lite widths (bf16): token-by-token decode rows AND the batched-prefill rows of a second chunk, each held to 1.25x the oracle's own
+    distance from the float64 truth (naive HF form, no weight absorption, no rounding)"""
+    from fullwidth_cases import GpuRun, OrcRun, make
+    fam, model = make("deepseek-v2-lite-2l")
+    cfg = model["config"]
+    g, o, tm = GpuRun(device, fam, model), OrcRun(fam, model, cap=64), npref.NpDsv2(model, truth=True)
+    p = synth.prompt_tokens(6, cfg["vocab"], seed=2)
+    p2 = synth.prompt_tokens(20, cfg["vocab"], seed=9)
+    G = np.concatenate([g.forward(p, all_logits=True), g.forward(p2, all_logits=True)]).astype(np.float64)     # 6 decode-path rows + 20 prefill-path rows
+    O = np.concatenate([o.forward(p, all_logits=True), o.forward(p2, all_logits=True)]).astype(np.float64)
+    T = np.stack([tm.step(int(t), i) for i, t in enumerate(list(p) + list(p2))])
+    for name, sl in (("decode rows", slice(0, 6)), ("prefill rows", slice(6, 26))):
+        nT = np.linalg.norm(T[sl])
+        g2, o2 = np.linalg.norm(G[sl] - T[sl]) / nT, np.linalg.norm(O[sl] - T[sl]) / nT
+        gm, om = np.abs(G[sl] - T[sl]).max() / np.abs(T[sl]).max(), np.abs(O[sl] - T[sl]).max() / np.abs(T[sl]).max()
+        msg = "deepseek-v2-lite-2l %s: relative L2 to the f64 truth: hip %.3e, oracle %.3e; max-norm: hip %.3e, oracle %.3e; hip vs oracle L2 %.3e" % (
+            name, g2, o2, gm, om, np.linalg.norm(G[sl] - O[sl]) / np.linalg.norm(O[sl]))
+        print(msg)
+        assert g2 <= 1.25 * o2 and gm <= 1.5 * om, msg
