@@ -266,7 +266,8 @@ struct MambaLayerDev {
 
 struct DsLayerDev {
   float* attn_norm = nullptr; float* ffn_norm = nullptr; float* kv_norm = nullptr;
-  FusedLinear qkva, o;                       // [q_proj ; kv_a_proj_with_mqa], o_proj
+  FusedLinear qkva, o;                       // [q_proj ; kv_a_proj_with_mqa] (q_lora_rank > 0: [q_a_proj ; kv_a_proj_with_mqa]), o_proj
+  float* q_norm = nullptr; FusedLinear q_b;  // q_lora_rank > 0: q_a_layernorm, q_b_proj [n_heads (nope + rope)][q_lora_rank]
   void* kv_b = nullptr; int kv_b_dt = BZ_BF16;   // kv_b_proj [n_heads (nope+v)][rank], as stored
   bool is_moe = false;
   FusedLinear gateup, down;                  // dense layers
@@ -342,7 +343,7 @@ extern "C" int bz_model_create(bz_device* dev, const bz_model_config* cfg, bz_mo
     if (cfg->hidden <= 0 || cfg->n_layers <= 0 || cfg->n_heads <= 0 || cfg->vocab <= 0 || cfg->max_seq_len <= 0 || cfg->mla_kv_lora_rank <= 0 ||
         cfg->mla_nope_dim <= 0 || cfg->mla_rope_dim <= 0 || cfg->mla_v_dim <= 0 || cfg->moe_n_experts < 0 || cfg->moe_first_dense < 0)
       BZ_FAIL(BZ_E_INVALID, "config: non-positive deepseek2 dimension");
-    if (cfg->mla_q_lora_rank != 0) BZ_FAIL(BZ_E_UNSUPPORTED, "config: q_lora_rank > 0 (DeepSeek-V2 full) is not implemented; V2-Lite uses a plain q_proj");
+    if (cfg->mla_q_lora_rank < 0 || cfg->mla_q_lora_rank % 8) BZ_FAIL(BZ_E_INVALID, "config: q_lora_rank %d must be a non-negative multiple of 8", cfg->mla_q_lora_rank);
     if (cfg->hidden % 8 || cfg->mla_kv_lora_rank % 8 || cfg->mla_kv_lora_rank > 1024 || cfg->mla_rope_dim > 64 || (cfg->mla_rope_dim & 1) || cfg->mla_nope_dim % 4 ||
         cfg->mla_v_dim % 4)
       BZ_FAIL(BZ_E_UNSUPPORTED, "config: MLA dims unsupported (rank %% 8, rank <= 1024, rope <= 64 even, nope/v %% 4)");
@@ -932,9 +933,20 @@ static int finalize_dsv2(bz_model* m) {
     BZ_TRY(take_vector_f32(m, p + "input_layernorm.weight", H, &L.attn_norm));
     BZ_TRY(take_vector_f32(m, p + "post_attention_layernorm.weight", H, &L.ffn_norm));
     BZ_TRY(take_vector_f32(m, p + "self_attn.kv_a_layernorm.weight", R, &L.kv_norm));
-    BZ_TRY(build_fused(m, {p + "self_attn.q_proj", p + "self_attn.kv_a_proj_with_mqa"}, &L.qkva));
-    if (L.qkva.parts.size() != 1 || L.qkva.parts[0].kind != LK_ROWS || L.qkva.N != NH * (DN + DR) + R + DR || L.qkva.K != H)
-      BZ_FAIL(BZ_E_INVALID, "layer %d: q_proj / kv_a_proj_with_mqa must be dense tensors matching the config", l);
+    const int QL = c.mla_q_lora_rank;
+    if (QL > 0) {   // gguf.rs:188-196 (DeepSeek-V2 full): q = q_b_proj(q_a_layernorm(q_a_proj(x)))
+      BZ_TRY(build_fused(m, {p + "self_attn.q_a_proj", p + "self_attn.kv_a_proj_with_mqa"}, &L.qkva));
+      BZ_TRY(take_vector_f32(m, p + "self_attn.q_a_layernorm.weight", QL, &L.q_norm));
+      BZ_TRY(build_fused(m, {p + "self_attn.q_b_proj"}, &L.q_b));
+      if (L.q_b.parts.size() != 1 || L.q_b.parts[0].kind != LK_ROWS || L.q_b.N != NH * (DN + DR) || L.q_b.K != QL) BZ_FAIL(BZ_E_INVALID, "layer %d: q_b_proj must be dense [n_heads (nope + rope), q_lora_rank]", l);
+      force_direct(&L.q_b);
+      for (auto& P : L.q_b.parts) { m->resident += P.bytes; per_token += P.algo_bytes; }
+      per_token += (size_t)QL * act_b;
+    } else {
+      BZ_TRY(build_fused(m, {p + "self_attn.q_proj", p + "self_attn.kv_a_proj_with_mqa"}, &L.qkva));
+    }
+    if (L.qkva.parts.size() != 1 || L.qkva.parts[0].kind != LK_ROWS || L.qkva.N != (QL > 0 ? QL : NH * (DN + DR)) + R + DR || L.qkva.K != H)
+      BZ_FAIL(BZ_E_INVALID, "layer %d: q_proj (q_a_proj) / kv_a_proj_with_mqa must be dense tensors matching the config", l);
     force_direct(&L.qkva);
     size_t kvb_bytes = 0;
     BZ_TRY(take_dense(m, p + "self_attn.kv_b_proj.weight", (int64_t)NH * (DN + DV), R, &L.kv_b, &L.kv_b_dt, &kvb_bytes));
@@ -1014,7 +1026,7 @@ static int finalize_dsv2(bz_model* m) {
   void* p;
   BZ_TRY(dev_alloc(m, &p, cs.size() * 4)); m->cos_t = (float*)p; BZ_HIP(hipMemcpy(p, cs.data(), cs.size() * 4, hipMemcpyHostToDevice));
   BZ_TRY(dev_alloc(m, &p, sn.size() * 4)); m->sin_t = (float*)p; BZ_HIP(hipMemcpy(p, sn.data(), sn.size() * 4, hipMemcpyHostToDevice));
-  m->ring_n = std::max(ring_n, NH * (DN + DR) + R + DR);
+  m->ring_n = std::max(ring_n, NH * (DN + DR) + R + DR + c.mla_q_lora_rank);
   for (int i = 0; i < 3; i++) {
     BZ_TRY(dev_alloc(m, &p, (size_t)m->ring_n * 8)); m->ring[i] = (long long*)p; BZ_HIP(hipMemset(p, 0, (size_t)m->ring_n * 8));
     BZ_TRY(dev_alloc(m, &p, (size_t)m->ring_n * 4)); m->dring[i] = (float*)p; BZ_HIP(hipMemset(p, 0, (size_t)m->ring_n * 4));
@@ -1549,6 +1561,15 @@ static int dsv2_step(bz_model* m, const StepIO& io) {
     BZ_TRY(run_fused(m, L.qkva, pn, rs, &qkva));
     cur ^= 1;
     MlaArgs ma{};
+    if (c.mla_q_lora_rank > 0) {
+      // q = q_b_proj(q_a_layernorm(q_a)): a second GEMV whose prologue is the RMSNorm of the first one's leading q_lora_rank outputs (no residual);
+      // the latent | k_pe part of the first GEMV's output reaches the attention kernel through `kva`
+      Pro pq{}; pq.mode = PRO_NORM; pq.src = VSrc{nullptr, 0}; pq.h_in = (const float*)qkva.p; pq.h_out = nullptr; pq.norm_w = L.q_norm; pq.eps = c.rms_eps; pq.H = c.mla_q_lora_rank; pq.act = act;
+      VSrc qv;
+      BZ_TRY(run_fused(m, L.q_b, pq, rs, &qv));
+      ma.kva = (const float*)qkva.p + c.mla_q_lora_rank;
+      qkva = qv;
+    }
     ma.qkv = qkva; ma.kv_norm = L.kv_norm; ma.eps = c.rms_eps; ma.wkvb = L.kv_b; ma.wdt = L.kv_b_dt; ma.cos_t = m->cos_t; ma.sin_t = m->sin_t; ma.pos = io.d_pos;
     ma.n_heads = NH; ma.rank = R; ma.nope = DN; ma.rope = DR; ma.vdim = DV; ma.act = act; ma.kv = io.kv; ma.layer = l; ma.out = m->attn_out;
     ma.scale = 1.0f / sqrtf((float)(DN + DR));
@@ -1930,7 +1951,7 @@ extern "C" int bz_forward_paged(bz_model* m, const bz_tensor* tokens, int S, bz_
   BZ_API_BEGIN
   BZ_TRY(check_fwd(m, tokens, S));
   std::lock_guard<std::recursive_mutex> lock__(m->mu);
-  if (m->cfg.arch != BZ_ARCH_LLAMA) BZ_FAIL(BZ_E_UNSUPPORTED, "forward_paged: llama family only (Mamba2 has no KV cache; the MLA latent cache is contiguous in this build)");
+  if (m->cfg.arch == BZ_ARCH_MAMBA2) BZ_FAIL(BZ_E_UNSUPPORTED, "forward_paged: Mamba2 has no KV cache");   // MLA: the latent cache pages like any other (one 'head' of rank + rope values)
   if (!kv || kv->layers != m->cfg.n_layers || kv->n_kv != m->cfg.n_kv_heads || kv->hd != m->cfg.head_dim) BZ_FAIL(BZ_E_INVALID, "forward_paged: cache does not match the model");
   if (!slot_mapping || slot_mapping->dtype != BZ_I32 || slot_mapping->nbytes < (size_t)S * 4) BZ_FAIL(BZ_E_INVALID, "forward_paged: slot_mapping must be I32[S]");
   if (!block_table || block_table->dtype != BZ_I32 || block_table->nbytes < (size_t)n_table * 4) BZ_FAIL(BZ_E_INVALID, "forward_paged: block_table must be I32[n_table]");
@@ -1944,6 +1965,13 @@ extern "C" int bz_forward_paged(bz_model* m, const bz_tensor* tokens, int S, bz_
     kv->seq_len = seq_len_k;
     return BZ_OK;
   }
+  if (dsv2_prefill_eligible(m, S, seq_len_k, view_of(kv, (const int*)block_table->ptr, nullptr))) {
+    // (the rows' slots follow from the block table: slot = block_table[p / bs] * bs + p % bs, batch_decode.rs:81-88)
+    if (!logits_out || logits_out->dtype != BZ_F32 || logits_out->nbytes < (size_t)(all ? S : 1) * m->cfg.vocab * 4) BZ_FAIL(BZ_E_INVALID, "forward: logits_out too small");
+    BZ_TRY(dsv2_prefill(m, (const long long*)tokens->ptr, S, view_of(kv, (const int*)block_table->ptr, nullptr), start_pos, all, logits_out));
+    kv->seq_len = seq_len_k;
+    return BZ_OK;
+  }
   for (int s = 0; s < S; s++) {
     hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, m->dev->stream, m->pos_tmp, start_pos + s);
     StepIO io{};
@@ -1951,7 +1979,7 @@ extern "C" int bz_forward_paged(bz_model* m, const bz_tensor* tokens, int S, bz_
     io.d_tok = (const long long*)tokens->ptr + s; io.d_pos = m->pos_tmp;
     io.att_positions = att_positions_for(start_pos + s + 1);
     io.do_head = all || s == S - 1;
-    BZ_TRY(llama_step(m, io));
+    BZ_TRY(model_step(m, io));
     if (io.do_head) BZ_TRY(emit_logits(m, logits_out, all ? s : 0));
   }
   kv->seq_len = seq_len_k;
@@ -2544,7 +2572,8 @@ extern "C" int bz_decode_graph_capture_paged(bz_model* m, bz_paged_kv* kv, int m
   BZ_API_BEGIN
   if (!m || !m->finalized || !kv || !out || max_blocks <= 0) BZ_FAIL(BZ_E_INVALID, "graph capture: bad argument");
   std::lock_guard<std::recursive_mutex> lock__(m->mu);
-  if (m->cfg.arch != BZ_ARCH_LLAMA) BZ_FAIL(BZ_E_INVALID, "graph capture: model has no KV cache (use bz_decode_graph_capture_ssm)");
+  if (m->cfg.arch == BZ_ARCH_MAMBA2) BZ_FAIL(BZ_E_INVALID, "graph capture: model has no KV cache (use bz_decode_graph_capture_ssm)");
+  if (kv->layers != m->cfg.n_layers || kv->n_kv != m->cfg.n_kv_heads || kv->hd != m->cfg.head_dim) BZ_FAIL(BZ_E_INVALID, "graph capture: cache does not match the model");
   BZ_HIP(hipSetDevice(m->dev->id));
   bz_decode_graph* g = new bz_decode_graph();
   bz_dev_retain(m->dev); g->dev = m->dev;

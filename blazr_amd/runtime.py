@@ -239,8 +239,13 @@ class LoadedModel:
         self.add_dense(p + "input_layernorm.weight", f32(lay["attn_norm"]))
         self.add_dense(p + "post_attention_layernorm.weight", f32(lay["ffn_norm"]))
         self.add_dense(p + "self_attn.kv_a_layernorm.weight", f32(lay["kv_norm"]))
-        for short, hf in (("q_proj", "self_attn.q_proj"), ("kv_a", "self_attn.kv_a_proj_with_mqa"), ("kv_b", "self_attn.kv_b_proj"), ("o", "self_attn.o_proj")):
+        ql = "q_b" in lay     # q_lora_rank > 0: q_a_proj -> q_a_layernorm -> q_b_proj
+        for short, hf in (("q_proj", "self_attn.q_a_proj" if ql else "self_attn.q_proj"), ("kv_a", "self_attn.kv_a_proj_with_mqa"), ("kv_b", "self_attn.kv_b_proj"),
+                          ("o", "self_attn.o_proj")):
             self.add_linear(p + hf, lay[short])
+        if ql:
+            self.add_dense(p + "self_attn.q_a_layernorm.weight", f32(lay["q_norm"]))
+            self.add_linear(p + "self_attn.q_b_proj", lay["q_b"])
         if not lay["is_moe"]:
             for n in ("gate", "up", "down"):
                 self.add_linear(p + "mlp.%s_proj" % n, lay[n])

@@ -354,16 +354,19 @@ def _dsv2_mlp(prefix, H, I, act, seed):
 def dsv2_layer(cfg, i, seed=BASE_SEED):
     """HF DeepSeek-V2 tensor names: self_attn.{q_proj, kv_a_proj_with_mqa, kv_a_layernorm, kv_b_proj, o_proj}, mlp.{gate, experts.N, shared_experts}"""
     H, NH, R, DN, DR, DV, act = cfg["hidden"], cfg["n_heads"], cfg["kv_lora_rank"], cfg["nope_dim"], cfg["rope_dim"], cfg["v_dim"], cfg["act_dtype"]
-    if cfg.get("q_lora_rank"):
-        raise ValueError("synthetic q_lora_rank > 0 is not generated")
+    QL = int(cfg.get("q_lora_rank") or 0)
     p = "model.layers.%d." % i
     lay = dict(attn_norm=_repr(1.0 + _normal(_rng(p + "input_layernorm.weight", seed), (H,), 0.02), act),
                ffn_norm=_repr(1.0 + _normal(_rng(p + "post_attention_layernorm.weight", seed), (H,), 0.02), act),
                kv_norm=_repr(1.0 + _normal(_rng(p + "self_attn.kv_a_layernorm.weight", seed), (R,), 0.02), act),
-               q_proj=dense_linear(p + "self_attn.q_proj", NH * (DN + DR), H, act, seed=seed),
+               # q_lora_rank > 0 (DeepSeek-V2 full, gguf.rs:188-196): q = q_b_proj(q_a_layernorm(q_a_proj(x))); "q_proj" then holds q_a_proj
+               q_proj=dense_linear(p + ("self_attn.q_a_proj" if QL else "self_attn.q_proj"), QL if QL else NH * (DN + DR), H, act, seed=seed),
                kv_a=dense_linear(p + "self_attn.kv_a_proj_with_mqa", R + DR, H, act, seed=seed),
                kv_b=dense_linear(p + "self_attn.kv_b_proj", NH * (DN + DV), R, act, std=0.05, seed=seed),
                o=dense_linear(p + "self_attn.o_proj", H, NH * DV, act, seed=seed))
+    if QL:
+        lay["q_norm"] = _repr(1.0 + _normal(_rng(p + "self_attn.q_a_layernorm.weight", seed), (QL,), 0.02), act)
+        lay["q_b"] = dense_linear(p + "self_attn.q_b_proj", NH * (DN + DR), QL, act, std=0.05, seed=seed)
     lay["is_moe"] = i >= cfg["first_dense"] and cfg["n_experts"] > 0
     if not lay["is_moe"]:
         lay.update(_dsv2_mlp(p + "mlp.", H, cfg["inter"], act, seed))
@@ -393,10 +396,12 @@ def dsv2_bytes_per_token(cfg):
     """active weight bytes one decoded token streams (SURVEY.md 8d cfg 5: 4.90 GB for DeepSeek-V2-Lite); latent cache excluded"""
     H, NH, R, DN, DR, DV, V, L = (cfg[k] for k in ("hidden", "n_heads", "kv_lora_rank", "nope_dim", "rope_dim", "v_dim", "vocab", "n_layers"))
     b = {"f16": 2, "bf16": 2, "f32": 4}[cfg["act_dtype"]]
-    attn = NH * (DN + DR) * H + (R + DR) * H + NH * (DN + DV) * R + H * NH * DV
+    QL = int(cfg.get("q_lora_rank") or 0)
+    qp = (QL * H + NH * (DN + DR) * QL) if QL else NH * (DN + DR) * H
+    attn = qp + (R + DR) * H + NH * (DN + DV) * R + H * NH * DV
     dense = 3 * H * cfg["inter"]
     moe = cfg["n_experts"] * H + (cfg["top_k"] + cfg["n_shared"]) * 3 * H * cfg["moe_inter"]
     n_moe = sum(1 for i in range(L) if i >= cfg["first_dense"] and cfg["n_experts"] > 0)
     params = L * attn + (L - n_moe) * dense + n_moe * moe + V * H
-    norms = L * (2 * H + R) + H
+    norms = L * (2 * H + R + QL) + H
     return (params + norms + H) * b

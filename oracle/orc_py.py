@@ -490,6 +490,11 @@ class OrcDsv2:
                 setattr(Lr, name, _p(a))
             for name in ("q_proj", "kv_a", "kv_b", "o"):
                 setattr(Lr, name, lin(lay[name]))
+            if "q_b" in lay:                      # q_lora_rank > 0: q_proj holds q_a_proj
+                a = np.ascontiguousarray(lay["q_norm"], dtype=np.float32)
+                self.keep.append(a)
+                Lr.q_norm = _p(a)
+                Lr.q_b = lin(lay["q_b"])
             Lr.is_moe = int(lay["is_moe"])
             if not lay["is_moe"]:
                 for name in ("gate", "up", "down"):

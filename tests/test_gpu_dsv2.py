@@ -80,16 +80,15 @@ def test_error_behaviour(pair, device):
     wrong = runtime.LayeredKvCache(device, cfg["n_layers"], 1, 2, 8, 64, 64, lm.c.act_dtype)
     with pytest.raises(L.BlazrHipError):
         lm.forward_with_kv_cache([1, 2], wrong, 0)                     # not the latent-cache shape
+    bad = dict(cfg, q_lora_rank=63)
     with pytest.raises(L.BlazrHipError):
-        runtime.Executor(lm).generate([1, 2, 3], 4, paged=True)        # paged MLA cache: not in this build
-    bad = dict(cfg, q_lora_rank=64)
-    with pytest.raises(L.BlazrHipError):
-        runtime.LoadedModel(device, bad)
+        runtime.LoadedModel(device, bad)                               # not a multiple of 8
 
 
 @pytest.mark.parametrize("over", [dict(n_shared=0), dict(first_dense=0, n_layers=2), dict(top_k=8), dict(n_experts=0, first_dense=3),
-                                  dict(kv_lora_rank=64, nope_dim=32, v_dim=128, rope_dim=16), dict(act_dtype="f16")],
-                         ids=["no-shared", "all-moe", "topk-all", "dense-only", "odd-mla-dims", "f16"])
+                                  dict(kv_lora_rank=64, nope_dim=32, v_dim=128, rope_dim=16), dict(act_dtype="f16"), dict(q_lora_rank=96),
+                                  dict(q_lora_rank=64, act_dtype="f32")],
+                         ids=["no-shared", "all-moe", "topk-all", "dense-only", "odd-mla-dims", "f16", "q-lora", "q-lora-f32"])
 def test_config_variants(device, over):
     # edges of the MoE / MLA configuration space against the oracle (prefill rows + a few decode steps)
     model = synth.make_dsv2("tiny-dsv2", **over)
@@ -104,3 +103,39 @@ def test_config_variants(device, over):
         _check_logits(lm.forward_with_kv_cache([tok], kv, 6 + i).to_numpy(), lo, cfg["act_dtype"])
         tok = int(lo[0].argmax())
     orc_py.lib().orc_mla_cache_free(okc)
+
+
+@pytest.mark.parametrize("mode", ["paged", "paged-graph"])
+def test_paged_latent_cache_generation_equals_contiguous(pair, mode):
+    """executor_generate.rs:182-340: the paged branch applies to any KV model; the MLA latent cache pages as one 'head' of rank + rope values"""
+    model, lm, om = pair
+    cfg = model["config"]
+    p = synth.prompt_tokens(11, cfg["vocab"], seed=21)
+    ex = runtime.Executor(lm)
+    base = ex.generate(p, 20)
+    got = ex.generate(p, 20, paged=True, use_graph="graph" in mode)
+    assert got.tolist() == base.tolist(), mode
+
+
+def test_paged_latent_cache_forward_scattered_blocks(pair, device):
+    """prompt chunk (batched rows where the model has that path) + decode steps over a scattered block table == the contiguous cache, bit for bit"""
+    model, lm, om = pair
+    cfg = model["config"]
+    W = cfg["kv_lora_rank"] + cfg["rope_dim"]
+    p = synth.prompt_tokens(13, cfg["vocab"], seed=4)
+    kv = lm.new_kv_cache(32)
+    a = lm.forward_with_kv_cache(p, kv, 0, all_logits=True).to_numpy()
+    pk = runtime.LayeredPagedKvCache(device, cfg["n_layers"], 9, 4, 1, W, lm.c.act_dtype)
+    pk.set_blocks([7, 2, 5, 0, 8, 3, 1])
+    sm = pk.compute_slot_mapping(0, len(p))
+    pk.set_seq_len(len(p))
+    b = lm.forward_with_paged_kv_cache(p, pk, sm, pk.block_table_device_format(), len(p), 0, all_logits=True).to_numpy()
+    assert np.array_equal(a, b)
+    tok = int(a[-1].argmax())
+    for i in range(6):
+        n = len(p) + i + 1
+        pk.set_seq_len(n)
+        x = lm.forward_with_kv_cache([tok], kv, n - 1).to_numpy()
+        y = lm.forward_with_paged_kv_cache([tok], pk, pk.compute_slot_mapping(n - 1, 1), pk.block_table_device_format(), n, n - 1).to_numpy()
+        assert np.array_equal(x, y), i
+        tok = int(x[0].argmax())
