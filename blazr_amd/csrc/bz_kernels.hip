@@ -1267,6 +1267,57 @@ bool bzk_gemv_slim_ok(const LinearDev& L, const Pro& pro) {
 enum { GQ_Q80 = 0, GQ_Q4K = 1, GQ_Q6K = 2 };
 #define XQ_MAX 8355000.0f  // < 127*65536 + 127*256 + 127: the largest magnitude of three balanced int8 planes
 
+// one thread's octet (8 consecutive k of a 32-k chunk; the chunk's four octets sit in four consecutive lanes, quad-aligned) -> three int8 planes
+// + the chunk parameters.  e0 = index of the octet's first element in the slice; `on`: this thread takes part (its lanes' reductions run anyway)
+template <int FMT>
+__device__ __forceinline__ void quant8_x32(const float (&v)[8], int e0, bool on, int lane, unsigned* xh, unsigned* xm, unsigned* xl, int4* cpar) {
+  float am = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; i++) am = fmaxf(am, fabsf(v[i]));
+  am = grp_reduce<4, OpMax>(am);   // 4 lanes x 8 = one 32-k chunk
+  const float inv = am > 0.f ? XQ_MAX / am : 0.f;
+  unsigned wh[2] = {0, 0}, wm[2] = {0, 0}, wl[2] = {0, 0};
+  int sa[3] = {0, 0, 0}, sb[3] = {0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const int xi = (int)rintf(v[i] * inv);
+    const int lo = ((xi + 128) & 255) - 128;
+    const int r1 = (xi - lo) >> 8;
+    const int mid = ((r1 + 128) & 255) - 128;
+    const int hi = (r1 - mid) >> 8;
+    wh[i >> 2] |= ((unsigned)hi & 255u) << (8 * (i & 3));
+    wm[i >> 2] |= ((unsigned)mid & 255u) << (8 * (i & 3));
+    wl[i >> 2] |= ((unsigned)lo & 255u) << (8 * (i & 3));
+    if (FMT == GQ_Q4K) { sa[0] += hi; sa[1] += mid; sa[2] += lo; if (i >= 4) { sb[0] += hi; sb[1] += mid; sb[2] += lo; } }
+    if (FMT == GQ_Q6K) { sa[0] += hi; sa[1] += mid; sa[2] += lo; }   // per-thread sum; halves are separated below
+  }
+  if (FMT == GQ_Q6K) {
+    // lanes 0,1 of the 4-lane group hold k 0..15 (first half), lanes 2,3 hold k 16..31
+    const bool second = (lane & 2) != 0;
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      const int mine = sa[q] + dpp_get<DPP_XOR1>(sa[q]);          // sum of my half
+      const int other = dpp_get<DPP_XOR2>(mine);                  // the other half
+      sa[q] = second ? other : mine;                              // Sa = first half
+      sb[q] = second ? mine : other;                              // Sb = second half
+    }
+  } else if (FMT == GQ_Q4K) {
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      sa[q] = grp_reduce<4, OpAdd>(sa[q]);
+      sb[q] = grp_reduce<4, OpAdd>(sb[q]);
+    }
+  }
+  if (on) {
+    *(uint2*)(xh + e0 / 4) = make_uint2(wh[0], wh[1]);
+    *(uint2*)(xm + e0 / 4) = make_uint2(wm[0], wm[1]);
+    *(uint2*)(xl + e0 / 4) = make_uint2(wl[0], wl[1]);
+    if ((lane & 3) == 0) {
+      cpar[2 * (e0 >> 5)] = make_int4(__float_as_int(am * (1.0f / XQ_MAX)), sa[0], sa[1], sa[2]);
+      cpar[2 * (e0 >> 5) + 1] = make_int4(sb[0], sb[1], sb[2], 0);
+    }
+  }
+}
 template <int FMT>
 __device__ __forceinline__ void quant_x32(const float* xs, int KR, unsigned* xh, unsigned* xm, unsigned* xl, int4* cpar) {
   for (int base = 0; base < KR; base += 256 * 8) {
@@ -1280,52 +1331,7 @@ __device__ __forceinline__ void quant_x32(const float* xs, int KR, unsigned* xh,
 #pragma unroll
       for (int i = 0; i < 8; i++) v[i] = 0.f;
     }
-    float am = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; i++) am = fmaxf(am, fabsf(v[i]));
-    am = grp_reduce<4, OpMax>(am);   // 4 lanes x 8 = one 32-k chunk
-    const float inv = am > 0.f ? XQ_MAX / am : 0.f;
-    unsigned wh[2] = {0, 0}, wm[2] = {0, 0}, wl[2] = {0, 0};
-    int sa[3] = {0, 0, 0}, sb[3] = {0, 0, 0};
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const int xi = (int)rintf(v[i] * inv);
-      const int lo = ((xi + 128) & 255) - 128;
-      const int r1 = (xi - lo) >> 8;
-      const int mid = ((r1 + 128) & 255) - 128;
-      const int hi = (r1 - mid) >> 8;
-      wh[i >> 2] |= ((unsigned)hi & 255u) << (8 * (i & 3));
-      wm[i >> 2] |= ((unsigned)mid & 255u) << (8 * (i & 3));
-      wl[i >> 2] |= ((unsigned)lo & 255u) << (8 * (i & 3));
-      if (FMT == GQ_Q4K) { sa[0] += hi; sa[1] += mid; sa[2] += lo; if (i >= 4) { sb[0] += hi; sb[1] += mid; sb[2] += lo; } }
-      if (FMT == GQ_Q6K) { sa[0] += hi; sa[1] += mid; sa[2] += lo; }   // per-thread sum; halves are separated below
-    }
-    if (FMT == GQ_Q6K) {
-      // lanes 0,1 of the 4-lane group hold k 0..15 (first half), lanes 2,3 hold k 16..31
-      const bool second = (threadIdx.x & 2) != 0;
-#pragma unroll
-      for (int q = 0; q < 3; q++) {
-        const int mine = sa[q] + dpp_get<DPP_XOR1>(sa[q]);          // sum of my half
-        const int other = dpp_get<DPP_XOR2>(mine);                  // the other half
-        sa[q] = second ? other : mine;                              // Sa = first half
-        sb[q] = second ? mine : other;                              // Sb = second half
-      }
-    } else if (FMT == GQ_Q4K) {
-#pragma unroll
-      for (int q = 0; q < 3; q++) {
-        sa[q] = grp_reduce<4, OpAdd>(sa[q]);
-        sb[q] = grp_reduce<4, OpAdd>(sb[q]);
-      }
-    }
-    if (on) {
-      *(uint2*)(xh + e0 / 4) = make_uint2(wh[0], wh[1]);
-      *(uint2*)(xm + e0 / 4) = make_uint2(wm[0], wm[1]);
-      *(uint2*)(xl + e0 / 4) = make_uint2(wl[0], wl[1]);
-      if ((threadIdx.x & 3) == 0) {
-        cpar[2 * (e0 >> 5)] = make_int4(__float_as_int(am * (1.0f / XQ_MAX)), sa[0], sa[1], sa[2]);
-        cpar[2 * (e0 >> 5) + 1] = make_int4(sb[0], sb[1], sb[2], 0);
-      }
-    }
+    quant8_x32<FMT>(v, e0, on, (int)threadIdx.x, xh, xm, xl, cpar);
   }
 }
 
@@ -1518,6 +1524,8 @@ __global__ __launch_bounds__(256) void k_gemv_gq(const uint4* __restrict__ Wq, c
 //   MODE NORM: x = RMSNorm(h + prev) slice (full-H sum of squares per block)      MODE SILU: x = R(R(silu(gate)) * up) slice
 // grid = (K / 256) x ceil(N / 512), 512 threads
 // ---------------------------------------------------------------------------------------------------------
+// (a 12-wave role-split form of this kernel, as in k_gemv_q4g_slim, was built and measured on the Mistral-7B Q4_K_M shape: 539 vs 549 tok/s -- no gain; the f32
+// activations of the GGUF path make its prologue lighter (no 64-bit residual reads), and its big launches want many small workgroups in flight)
 template <int FMT, int MODE, int FIX, int NJ>     // NJ = H / 2048 (NORM only)
 __global__ __launch_bounds__(512) void k_gemv_gq_slim(const uint4* __restrict__ Wq, const uint2* __restrict__ Wh, const uint4* __restrict__ Hd,
                                                      const __half* __restrict__ Dd, const float* __restrict__ bias, int N, int K, Pro pro, long long* acc,
