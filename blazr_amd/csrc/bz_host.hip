@@ -1441,6 +1441,13 @@ static int llama_step(bz_model* m, const StepIO& io) {
       dn = VSrc{m->ring[rs.ri], 1};
       rs.dirty[rz] = 0; rs.dirty[rs.ri] = H; rs.ri = rz;
       cur ^= 1;
+    } else if (!no_mlp_fuse && Ld.gateup.parts.size() == 1 && Ld.down.parts.size() == 1 && bzk_mlp_gq_fusable(Ld.gateup.parts[0], Ld.down.parts[0], H, I, act)) {
+      // the GGUF form of the same fusion (Q4_K gate / up, Q4_K or Q6_K down, f32 activations)
+      const int rz = (rs.ri + 1) % 3;
+      BZ_TRY(bzk_mlp_gq(st, Ld.gateup.parts[0], Ld.down.parts[0], H, I, pf, m->ring[rs.ri], rs.dirty[rz] > 0 ? m->ring[rz] : nullptr, rs.dirty[rz]));
+      dn = VSrc{m->ring[rs.ri], 1};
+      rs.dirty[rz] = 0; rs.dirty[rs.ri] = H; rs.ri = rz;
+      cur ^= 1;
     } else {
       VSrc gu;
       BZ_TRY(run_fused(m, Ld.gateup, pf, rs, &gu));

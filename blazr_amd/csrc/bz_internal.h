@@ -177,6 +177,8 @@ bool bzk_gemm_q4g_mfma_ok(const LinearDev& L, int xdt, int rows);   // int4 weig
 int bzk_gemm_q4g_mfma(hipStream_t s, const LinearDev& L, const void* x16, int S, int act, float* y, float* ws = nullptr, size_t ws_bytes = 0);   // ws: split-K partials (short prompts)
 int bzk_gemm_q4g_rows(hipStream_t s, const LinearDev& L, int xdt, const void* x16, int rows, int act, long long* acc, float* y);
 int bzk_rows_choose_sk(int N, int K);
+bool bzk_mlp_gq_fusable(const LinearDev& gu, const LinearDev& dn, int H, int I, int act);   // GGUF Q4_K gate/up + Q4_K / Q6_K down, f32 activations
+int bzk_mlp_gq(hipStream_t s, const LinearDev& gu, const LinearDev& dn, int H, int I, const Pro& pro, long long* acc, long long* zero_buf, int zero_n);
 bool bzk_gemv_cols_ok(const LinearDev& L, const Pro& pro, int act);   // full-K int4 GEMV with direct output (q/k/v of the decode step)
 int bzk_gemv_cols(hipStream_t s, const LinearDev& L, const Pro& pro, float* out, long long* zero_buf, int zero_n);
 bool bzk_mlp_fusable(const LinearDev& gu, const LinearDev& dn, int H, int I);

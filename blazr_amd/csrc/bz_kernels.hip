@@ -1688,6 +1688,241 @@ __global__ __launch_bounds__(512) void k_gemv_gq_slim(const uint4* __restrict__ 
   atomicAdd((unsigned long long*)(acc + n), (unsigned long long)f2fix(y));
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Fused MLP for the GGUF block formats (Q4_K gate / up, Q4_K or Q6_K down: the Q4_K_M mix), the structure of k_mlp_q4g:
+//   acc_down += Wd[:, slab] . (silu(Wg[slice] x) * (Wu[slice] x)),   x = RMSNorm(h + prev)        (f32 activations: gguf.rs:305)
+// grid = I / 64 workgroups of NW = H / 256 waves: wave w owns superblock w (256 k) of the slice's gate tile and up tile, then 64 / NW ... output tiles
+// of the workgroup's 64-k slab of down_proj (two 32-k chunks of one superblock, with that superblock's header).  Wave roles as in k_mlp_q4g: the
+// first half requests its gate / up superblocks at entry, the second half holds the row, does the norm and publishes the int8 planes (three per
+// 32-k chunk, quant8_x32); LDS counters instead of barriers on that path.  One launch instead of two slim GEMVs: the SiLU * up vector never
+// leaves the CU, the down slab's loads fly under the gate / up dots.
+// ---------------------------------------------------------------------------------------------------------
+// one 32-k chunk of a Q4_K superblock: weight piece qc, chunk's planes at index pc, sub-block cs of the superblock header hw
+__device__ __forceinline__ float gq_chunk_q4k(const uint4& qc, int pc, int cs, const unsigned (&hw)[4], float d, float dmin, const uint4* xh4, const uint4* xm4, const uint4* xl4,
+                                               const int4* cpar) {
+  const unsigned ww[4] = {qc.x, qc.y, qc.z, qc.w};
+  unsigned w[8];
+#pragma unroll
+  for (int j = 0; j < 4; j++) { w[2 * j] = ww[j] & 0x0F0F0F0Fu; w[2 * j + 1] = ww[j] & 0xF0F0F0F0u; }
+  int ua_[3] = {0, 0, 0}, ub_[3] = {0, 0, 0};
+  const uint4 h0 = xh4[pc * 2], h1 = xh4[pc * 2 + 1], m0 = xm4[pc * 2], m1 = xm4[pc * 2 + 1], l0 = xl4[pc * 2], l1 = xl4[pc * 2 + 1];
+  const unsigned Xh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+  const unsigned Xm[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+  const unsigned Xl[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    ua_[0] = __builtin_amdgcn_sdot4((int)w[2 * j], (int)Xh[2 * j], ua_[0], false);
+    ua_[1] = __builtin_amdgcn_sdot4((int)w[2 * j], (int)Xm[2 * j], ua_[1], false);
+    ua_[2] = __builtin_amdgcn_sdot4((int)w[2 * j], (int)Xl[2 * j], ua_[2], false);
+    ub_[0] = __builtin_amdgcn_sdot4((int)w[2 * j + 1], (int)Xh[2 * j + 1], ub_[0], false);
+    ub_[1] = __builtin_amdgcn_sdot4((int)w[2 * j + 1], (int)Xm[2 * j + 1], ub_[1], false);
+    ub_[2] = __builtin_amdgcn_sdot4((int)w[2 * j + 1], (int)Xl[2 * j + 1], ub_[2], false);
+  }
+  const int4 p0 = cpar[2 * pc], p1 = cpar[2 * pc + 1];
+  const float qx = planes_f((ua_[0] << 4) + ub_[0] + 128 * p1.x, (ua_[1] << 4) + ub_[1] + 128 * p1.y, (ua_[2] << 4) + ub_[2] + 128 * p1.z) * (1.0f / 16.0f);
+  const float sx_ = planes_f(p0.y, p0.z, p0.w);
+  int sc, mn;
+  q4k_scale_min(hw, cs, sc, mn);
+  return __int_as_float(p0.x) * ((d * (float)sc) * qx - (dmin * (float)mn) * sx_);
+}
+// one 32-k chunk of a Q6_K superblock: low nibbles qc, 2-bit highs qhc, 16 int8 scales sw, chunk cs of the superblock
+__device__ __forceinline__ float gq_chunk_q6k(const uint4& qc, const uint2& qhc, int pc, int cs, const unsigned (&sw)[4], float d, const uint4* xh4, const uint4* xm4,
+                                               const uint4* xl4, const int4* cpar) {
+  const unsigned ww[4] = {qc.x, qc.y, qc.z, qc.w};
+  const unsigned hh[2] = {qhc.x, qhc.y};
+  unsigned w[8];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const unsigned lo_a = ww[j] & 0x0F0F0F0Fu, lo_b = (ww[j] >> 4) & 0x0F0F0F0Fu;
+    const int fa = 2 * j, fb = 2 * j + 1;
+    const unsigned hi_a = ((hh[fa >> 2] >> (2 * (fa & 3))) & 0x03030303u) << 4;
+    const unsigned hi_b = ((hh[fb >> 2] >> (2 * (fb & 3))) & 0x03030303u) << 4;
+    w[2 * j] = lo_a | hi_a;
+    w[2 * j + 1] = lo_b | hi_b;
+  }
+  const uint4 h0 = xh4[pc * 2], h1 = xh4[pc * 2 + 1], m0 = xm4[pc * 2], m1 = xm4[pc * 2 + 1], l0 = xl4[pc * 2], l1 = xl4[pc * 2 + 1];
+  const unsigned Xh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+  const unsigned Xm[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+  const unsigned Xl[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+  int u0[3] = {0, 0, 0}, u1[3] = {0, 0, 0};
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    u0[0] = __builtin_amdgcn_sdot4((int)w[j], (int)Xh[j], u0[0], false);
+    u0[1] = __builtin_amdgcn_sdot4((int)w[j], (int)Xm[j], u0[1], false);
+    u0[2] = __builtin_amdgcn_sdot4((int)w[j], (int)Xl[j], u0[2], false);
+    u1[0] = __builtin_amdgcn_sdot4((int)w[4 + j], (int)Xh[4 + j], u1[0], false);
+    u1[1] = __builtin_amdgcn_sdot4((int)w[4 + j], (int)Xm[4 + j], u1[1], false);
+    u1[2] = __builtin_amdgcn_sdot4((int)w[4 + j], (int)Xl[4 + j], u1[2], false);
+  }
+  const int4 p0 = cpar[2 * pc], p1 = cpar[2 * pc + 1];
+  const int s0 = (int)(signed char)((sw[(2 * cs) >> 2] >> (8 * ((2 * cs) & 3))) & 255u);
+  const int s1 = (int)(signed char)((sw[(2 * cs + 1) >> 2] >> (8 * ((2 * cs + 1) & 3))) & 255u);
+  const float f0 = planes_f(u0[0] - 32 * p0.y, u0[1] - 32 * p0.z, u0[2] - 32 * p0.w);
+  const float f1 = planes_f(u1[0] - 32 * p1.x, u1[1] - 32 * p1.y, u1[2] - 32 * p1.z);
+  return __int_as_float(p0.x) * ((d * (float)s0) * f0 + (d * (float)s1) * f1);
+}
+
+template <int FMTD, int FIX, int NW, int TPW>   // FMTD: down_proj format (GQ_Q4K / GQ_Q6K); NW = H / 256 waves; TPW = H / 64 / NW down tiles per wave
+__global__ __launch_bounds__(NW * 64) void k_mlp_gq(const uint4* __restrict__ Wgu, const uint4* __restrict__ Hgu, const float* __restrict__ bgu, const uint4* __restrict__ Wd,
+                                                const uint2* __restrict__ Whd, const uint4* __restrict__ Hdd, const __half* __restrict__ Ddd, const float* __restrict__ bd,
+                                                int H, int I, Pro pro, long long* acc, long long* zero_buf, int zero_n) {
+  constexpr int NP = NW / 2, NTH = NW * 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned* xh = (unsigned*)smem;             // [H/4] x 3
+  unsigned* xm = xh + H / 4;
+  unsigned* xl = xm + H / 4;
+  int4* cpar = (int4*)(xl + H / 4);           // [2 H/32]
+  float* part = (float*)(cpar + 2 * (H >> 5));  // [NW][128]
+  float* av = part + NW * 128;                // [64]
+  unsigned* ah = (unsigned*)(av + 64);        // [16] x 3
+  unsigned* am_ = ah + 16;
+  unsigned* al = am_ + 16;
+  int4* apar = (int4*)(al + 16);              // [4]
+  float* red = (float*)(apar + 4);            // [NP]
+  volatile unsigned* cnt = (volatile unsigned*)(red + NW);
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const bool prolog = wave >= NP;
+  const int sl = blockIdx.x, NTI = I >> 6, C32 = H >> 5, SBH = H >> 8;
+  asm volatile("" :: "s"(zero_buf), "s"(zero_n), "s"(acc), "s"(pro.h_in), "s"(pro.src.p), "s"(pro.norm_w), "s"(pro.h_out), "s"(pro.H), "s"(pro.act),
+               "s"(H), "s"(I), "s"(Wgu), "s"(Hgu), "s"(Wd), "s"(Whd), "s"(Hdd), "s"(Ddd));
+  const uint4* pg = Wgu + ((size_t)sl * C32 + (size_t)wave * 8) * 64 + lane;
+  const uint4* pu = Wgu + ((size_t)(NTI + sl) * C32 + (size_t)wave * 8) * 64 + lane;
+  uint4 qg[8], qu[8];
+  if (tid == 0) { cnt[0] = 0; cnt[1] = 0; }
+  if (prolog) {
+    const bool hasprev = pro.src.p != nullptr;
+    const void* prevp = hasprev ? pro.src.p : (const void*)pro.h_in;
+    const int oct = tid - NP * 64, i0 = oct * 8;
+    const float4 ha = *(const float4*)(pro.h_in + i0), hb = *(const float4*)(pro.h_in + i0 + 4);
+    typename RawT<FIX>::T pv[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) pv[e] = vraw<FIX>(prevp, (FIX || hasprev) ? i0 + e : 0);
+    const float4 na = *(const float4*)(pro.norm_w + i0), nb = *(const float4*)(pro.norm_w + i0 + 4);
+    __builtin_amdgcn_sched_barrier(0);
+    qg[0] = ldnt(pg); qu[0] = ldnt(pu);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();                     // counters zeroed; nobody waits for data here
+    float v[8] = {ha.x, ha.y, ha.z, ha.w, hb.x, hb.y, hb.z, hb.w};
+    float ss = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; e++) { if (hasprev) v[e] = round_act(v[e] + vcvt<FIX>(pv[e], pro.act), pro.act); ss += v[e] * v[e]; }
+    if (blockIdx.x == 0 && pro.h_out) { *(float4*)(pro.h_out + i0) = make_float4(v[0], v[1], v[2], v[3]); *(float4*)(pro.h_out + i0 + 4) = make_float4(v[4], v[5], v[6], v[7]); }
+    ss = wave_sum(ss);
+    if (lane == 0) { red[wave - NP] = ss; __builtin_amdgcn_s_waitcnt(0xc07f); atomicAdd((unsigned*)&cnt[0], 1u); }
+    lds_wait_count(&cnt[0], NP);
+    float tot = (red[0] + red[1]) + (red[2] + red[3]);
+    if (NP == 8) tot += (red[4] + red[5]) + (red[6] + red[7]);
+    const float rs = 1.0f / sqrtf(tot / (float)H + pro.eps);
+    const float nwv[8] = {na.x, na.y, na.z, na.w, nb.x, nb.y, nb.z, nb.w};
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) x[e] = round_act(nwv[e] * round_act(v[e] * rs, pro.act), pro.act);
+    quant8_x32<GQ_Q4K>(x, i0, true, lane, xh, xm, xl, cpar);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    if (lane == 0) atomicAdd((unsigned*)&cnt[1], 1u);
+#pragma unroll
+    for (int c = 1; c < 8; c++) { qg[c] = ldnt(pg + c * 64); qu[c] = ldnt(pu + c * 64); }
+  } else {
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 8; c++) { qg[c] = ldnt(pg + c * 64); qu[c] = ldnt(pu + c * 64); }
+    zero_duty<NP * 64>(zero_buf, zero_n);
+  }
+  const uint4 hg = Hgu[((size_t)sl * SBH + wave) * 64 + lane], hu = Hgu[((size_t)(NTI + sl) * SBH + wave) * 64 + lane];
+  lds_wait_count(&cnt[1], NP);
+  const uint4* xh4 = (const uint4*)xh;
+  const uint4* xm4 = (const uint4*)xm;
+  const uint4* xl4 = (const uint4*)xl;
+  float yg = 0.f, yu = 0.f;
+  {
+    const unsigned hwg[4] = {hg.x, hg.y, hg.z, hg.w}, hwu[4] = {hu.x, hu.y, hu.z, hu.w};
+    const float dg = __half2float(__ushort_as_half((unsigned short)(hwg[0] & 0xffffu))), dming = __half2float(__ushort_as_half((unsigned short)(hwg[0] >> 16)));
+    const float du = __half2float(__ushort_as_half((unsigned short)(hwu[0] & 0xffffu))), dminu = __half2float(__ushort_as_half((unsigned short)(hwu[0] >> 16)));
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+      yg += gq_chunk_q4k(qg[c], wave * 8 + c, c, hwg, dg, dming, xh4, xm4, xl4, cpar);
+      yu += gq_chunk_q4k(qu[c], wave * 8 + c, c, hwu, du, dminu, xh4, xm4, xl4, cpar);
+    }
+  }
+  // the down slab: chunks 2 sl, 2 sl + 1 of down's k range = chunks (2 sl) % 8, +1 of superblock sl / 4; TPW tiles per wave
+  const int C32D = I >> 5, SBD = I >> 8, sbd = sl >> 2, cs0 = (2 * sl) & 7;
+  uint4 D[TPW][2]; uint2 Dh[TPW][2]; uint4 hdd[TPW]; __half ddd[TPW];
+#pragma unroll
+  for (int q = 0; q < TPW; q++) {
+    const int t = wave * TPW + q;
+    const uint4* wp = Wd + ((size_t)t * C32D + 2 * sl) * 64 + lane;
+    D[q][0] = ldnt(wp); D[q][1] = ldnt(wp + 64);
+    hdd[q] = Hdd[((size_t)t * SBD + sbd) * 64 + lane];
+    if (FMTD == GQ_Q6K) {
+      const uint2* wh = Whd + ((size_t)t * C32D + 2 * sl) * 64 + lane;
+      Dh[q][0] = wh[0]; Dh[q][1] = wh[64];
+      ddd[q] = Ddd[((size_t)t * SBD + sbd) * 64 + lane];
+    }
+  }
+  part[wave * 128 + lane] = yg;
+  part[wave * 128 + 64 + lane] = yu;
+  __syncthreads();
+  if (tid < 64) {
+    float tg = 0.f, tu = 0.f;
+#pragma unroll
+    for (int w2 = 0; w2 < NW; w2++) { tg += part[w2 * 128 + tid]; tu += part[w2 * 128 + 64 + tid]; }
+    if (bgu) { tg += bgu[sl * 64 + tid]; tu += bgu[I + sl * 64 + tid]; }
+    tg = round_act(tg, pro.act); tu = round_act(tu, pro.act);
+    av[tid] = round_act(round_act(silu_f(tg), pro.act) * tu, pro.act);
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) x[e] = lane < 8 ? av[lane * 8 + e] : 0.f;
+    if (FMTD == GQ_Q6K) quant8_x32<GQ_Q6K>(x, lane * 8, lane < 8, lane, ah, am_, al, apar); else quant8_x32<GQ_Q4K>(x, lane * 8, lane < 8, lane, ah, am_, al, apar);
+  }
+  __syncthreads();
+  const uint4* ah4 = (const uint4*)ah;
+  const uint4* am4 = (const uint4*)am_;
+  const uint4* al4 = (const uint4*)al;
+#pragma unroll
+  for (int q = 0; q < TPW; q++) {
+    const unsigned hw[4] = {hdd[q].x, hdd[q].y, hdd[q].z, hdd[q].w};
+    float y = 0.f;
+    if (FMTD == GQ_Q4K) {
+      const float d = __half2float(__ushort_as_half((unsigned short)(hw[0] & 0xffffu))), dmin = __half2float(__ushort_as_half((unsigned short)(hw[0] >> 16)));
+      y += gq_chunk_q4k(D[q][0], 0, cs0, hw, d, dmin, ah4, am4, al4, apar);
+      y += gq_chunk_q4k(D[q][1], 1, cs0 + 1, hw, d, dmin, ah4, am4, al4, apar);
+    } else {
+      const float d = __half2float(ddd[q]);
+      y += gq_chunk_q6k(D[q][0], Dh[q][0], 0, cs0, hw, d, ah4, am4, al4, apar);
+      y += gq_chunk_q6k(D[q][1], Dh[q][1], 1, cs0 + 1, hw, d, ah4, am4, al4, apar);
+    }
+    const int n = (wave * TPW + q) * 64 + lane;
+    if (bd != nullptr && sl == 0) y += bd[n];
+    atomicAdd((unsigned long long*)(acc + n), (unsigned long long)f2fix(y));
+  }
+}
+static size_t mlp_gq_smem(int H) { return (size_t)H * 3 + (size_t)(H >> 5) * 32 + 16 * 128 * 4 + 64 * 4 + 48 * 4 + 64 + 16 * 4 + 16 + 64; }
+bool bzk_mlp_gq_fusable(const LinearDev& gu, const LinearDev& dn, int H, int I, int act) {
+  // opt-in: measured on the Mistral-7B Q4_K_M shape the fused launch takes 31.0 us against ~19 + ~11 us for the two slim launches (535.6 vs 549.0 tok/s, same
+  // box): the block formats cost ~2.5 VALU operations per weight (AND-unpack + three-plane V_DOT4 + a per-32-k epilogue of scale / min arithmetic), ~19 us
+  // of issue per CU when 224 workgroups carry all of it -- the fused form serialises that behind its stream, the slim launches spread it over 256 CUs
+  static const bool on = getenv("BZ_GGUF_MLP_FUSION") != nullptr && getenv("BZ_NO_MLP_FUSION") == nullptr;
+  return on && act == BZ_F32 && gu.kind == LK_Q4K && (dn.kind == LK_Q4K || dn.kind == LK_Q6K) && !gu.perm && !dn.perm && gu.N == 2 * I && gu.K == H && dn.N == H && dn.K == I &&
+         (H == 2048 || H == 4096) && I % 256 == 0 && I % 64 == 0;
+}
+int bzk_mlp_gq(hipStream_t s, const LinearDev& gu, const LinearDev& dn, int H, int I, const Pro& pro, long long* acc, long long* zero_buf, int zero_n) {
+  if (!bzk_mlp_gq_fusable(gu, dn, H, I, pro.act)) BZ_FAIL(BZ_E_INVALID, "fused GGUF MLP does not apply to this shape");
+  const size_t smem = mlp_gq_smem(H);
+  const double bytes = (double)gu.algo_bytes + (double)dn.algo_bytes;
+#define LAUNCH_MGQ(FD, FIX, NW_, TP) BZ_LAUNCH("mlp_gguf<norm+gate/up+silu+down>", bytes, (k_mlp_gq<FD, FIX, NW_, TP>), dim3(I / 64), dim3(NW_ * 64), smem, s, (const uint4*)gu.w, \
+    (const uint4*)gu.hdr, gu.bias, (const uint4*)dn.w, (const uint2*)dn.zeros, (const uint4*)dn.hdr, (const __half*)dn.scales, dn.bias, H, I, pro, acc, zero_buf, zero_n)
+#define LAUNCH_MGQ_F(FD, NW_, TP) do { if (pro.src.fix) LAUNCH_MGQ(FD, 1, NW_, TP); else LAUNCH_MGQ(FD, 0, NW_, TP); } while (0)
+  if (H == 4096) { if (dn.kind == LK_Q6K) LAUNCH_MGQ_F(GQ_Q6K, 16, 4); else LAUNCH_MGQ_F(GQ_Q4K, 16, 4); }
+  else { if (dn.kind == LK_Q6K) LAUNCH_MGQ_F(GQ_Q6K, 8, 4); else LAUNCH_MGQ_F(GQ_Q4K, 8, 4); }
+#undef LAUNCH_MGQ_F
+#undef LAUNCH_MGQ
+  BZ_HIP(hipGetLastError());
+  return BZ_OK;
+}
+
 bool bzk_gq_slim_ok(const LinearDev& L, const Pro& pro) {
   static const bool off = getenv("BZ_NO_GQ_SLIM") != nullptr;
   if (off || (L.kind != LK_Q4K && L.kind != LK_Q6K) || pro.perm != nullptr || pro.dbg || pro.stamps || L.N % 64 || L.K % 256) return false;

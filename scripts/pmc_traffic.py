@@ -6,6 +6,7 @@ usage: pmc_traffic.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> 
 """
 import csv
 import glob
+import hashlib
 import json
 import os
 import re
@@ -41,8 +42,12 @@ def main():
         w = sw / nw if nw else 0.0
         out[name] = {"dispatches": max(nf, nw), "FETCH_SIZE_KiB_avg": round(f, 2), "WRITE_SIZE_KiB_avg": round(w, 2),
                      "hbm_bytes_per_launch": round((2 * f + w) * 1024)}
-    json.dump({"formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024  (gfx950 correction, MI355X_MICROARCH.md HBM section)", "labels": LABELS, "kernels": out},
-              sys.stdout, indent=1)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for f in ("bz_kernels.hip", "bz_internal.h"):      # the same stamp bench.py computes: a pass taken on other kernel sources is refused there
+        h.update(open(os.path.join(root, "blazr_amd", "csrc", f), "rb").read())
+    json.dump({"formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024  (gfx950 correction, MI355X_MICROARCH.md HBM section)", "kernels_sha16": h.hexdigest()[:16],
+               "labels": LABELS, "kernels": out}, sys.stdout, indent=1)
 
 
 if __name__ == "__main__":

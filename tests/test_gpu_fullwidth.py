@@ -92,6 +92,8 @@ SWITCHES = [
     ("BZ_NO_ROWS_SPLITK=1", ["mamba2-2.7b-2l", "llama3.2-1b-bf16-2l"]),  # row GEMVs without split-K
     ("BZ_NO_MFMA_PREFILL=1", ["mamba2-2.7b-2l", "tiny-bf16"]),           # prompts token by token
     ("BZ_NO_Q4G_MFMA=1", ["llama3-8b-awq-2l"]),                          # int4 prompts through the multi-row dot4 kernel
+    ("BZ_GGUF_MLP_FUSION=1", ["mistral-7b-q4km-2l", "q4km-h2048"]),       # opt-in fused GGUF MLP (Q4_K gate/up + Q4_K / Q6_K down in one launch)
+    ("BZ_COLS_QKV=1", ["llama3-8b-awq-2l", "awq-h2048"]),                # opt-in full-K direct-output q/k/v kernel
     ("BZ_PREFILL_MIN=4", ["tiny-bf16", "tiny-awq"]),
     ("BZ_GEMV_TARGET_WGS=96", ["tiny-awq", "tiny-q4km"]),
 ]
