@@ -152,6 +152,7 @@ SYMBOLS = {
     "bz_forward_paged_batch": (C.c_int, [P, P, C.c_int, P, P, P, C.c_int, P, P]),
     "bz_forward_ssm": (C.c_int, [P, P, C.c_int, P, P, C.c_uint32]),
     "bz_decode_graph_capture_ssm": (C.c_int, [P, P, C.POINTER(P)]),
+    "bz_tune_rows": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "bz_tune_mlp": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     "bz_probe_hbm_read": (C.c_int, [P, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
     "bz_tune_gemv": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),

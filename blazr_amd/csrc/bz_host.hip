@@ -285,7 +285,7 @@ struct bz_model {
   int dpf_rows = 0; float* dpf_att = nullptr; void* dpf_xg16 = nullptr; float* dpf_gu = nullptr; void* dpf_a16 = nullptr; float* dpf_ye = nullptr; float* dpf_ysh = nullptr;
   int* dpf_sel = nullptr; float* dpf_w = nullptr; int* dpf_cnt = nullptr; int* dpf_off = nullptr; int* dpf_rowof = nullptr; int* dpf_tokof = nullptr;
   std::vector<MambaLayerDev> mlayers;
-  float* xbc = nullptr; float* ybuf = nullptr; float* vss = nullptr;   // Mamba2 workspace
+  float* ybuf = nullptr; float* vss = nullptr;   // Mamba2 workspace
   int mpf_rows = 0; float* mpf_h = nullptr; float* mpf_t = nullptr; float* mpf_zx = nullptr; float* mpf_xbc = nullptr; float* mpf_y = nullptr; float* mpf_vss = nullptr;
   void* mpf_x16 = nullptr;   // Mamba2 batched-prefill rows (allocated on first use)
   bz_device* dev = nullptr;
@@ -1078,10 +1078,9 @@ static int finalize_mamba2(bz_model* m) {
     BZ_TRY(take_vector_f32(m, p + "mixer.D", NH, &L.D, false));   // kept as stored (f32 in HF checkpoints)
     BZ_TRY(take_vector_f32(m, p + "mixer.norm.weight", DI, &L.gnorm));
     BZ_TRY(build_fused(m, {p + "mixer.in_proj"}, &L.in_proj));
-    force_direct(&L.in_proj);   // conv1d / SSM kernels read the projection as plain f32
     BZ_TRY(build_fused(m, {p + "mixer.out_proj"}, &L.out_proj));
     if (L.in_proj.N != d_in || L.in_proj.K != D || L.out_proj.N != D || L.out_proj.K != DI) BZ_FAIL(BZ_E_INVALID, "layer %d: in_proj/out_proj shapes do not match the config", l);
-    if (L.in_proj.fix_out || L.in_proj.parts[0].kind != LK_ROWS || L.out_proj.parts[0].kind != LK_ROWS)
+    if (L.in_proj.parts[0].kind != LK_ROWS || L.out_proj.parts[0].kind != LK_ROWS)
       BZ_FAIL(BZ_E_UNSUPPORTED, "mamba2: quantised projections are not implemented (dense f16/bf16/f32)");
   }
   BZ_TRY(take_vector_f32(m, "backbone.norm_f.weight", D, &m->final_norm));
@@ -1111,7 +1110,6 @@ static int finalize_mamba2(bz_model* m) {
     BZ_TRY(dev_alloc(m, &p, (size_t)m->ring_n * 4)); m->dring[i] = (float*)p; BZ_HIP(hipMemset(p, 0, (size_t)m->ring_n * 4));
   }
   for (int i = 0; i < 2; i++) { BZ_TRY(dev_alloc(m, &p, (size_t)D * 4)); m->hbuf[i] = (float*)p; }
-  BZ_TRY(dev_alloc(m, &p, (size_t)conv_dim * 4)); m->xbc = (float*)p;
   BZ_TRY(dev_alloc(m, &p, (size_t)DI * 4)); m->ybuf = (float*)p;
   BZ_TRY(dev_alloc(m, &p, (size_t)NH * 4)); m->vss = (float*)p;
   BZ_TRY(dev_alloc(m, &p, (size_t)V * 4)); m->logits = (float*)p;
@@ -1319,7 +1317,7 @@ struct StepIO {
 struct RingState { int ri = 0; int dirty[3] = {0, 0, 0}; };
 
 // Launch every part of a fused linear.  Returns the VSrc describing its output.
-static int run_fused(bz_model* m, const FusedLinear& F, Pro pro, RingState& rs, VSrc* out) {
+static int run_fused(bz_model* m, const FusedLinear& F, Pro pro, RingState& rs, VSrc* out, const ConvShift* shift = nullptr) {
   hipStream_t st = step_stream(m);
   const int act = m->cfg.act_dtype;
   const int ri = rs.ri, rz = (rs.ri + 1) % 3;
@@ -1339,6 +1337,7 @@ static int run_fused(bz_model* m, const FusedLinear& F, Pro pro, RingState& rs, 
     GemvOut o{};
     o.acc = acc + F.n_off[i]; o.direct = direct + F.n_off[i];
     o.zero_buf = (i == 0 && rs.dirty[rz] > 0) ? m->ring[rz] : nullptr; o.zero_n = rs.dirty[rz];
+    if (i == 0 && shift) o.shift = *shift;
     BZ_TRY(bzk_gemv(st, L, p, o, act));
   }
   rs.dirty[rz] = 0;
@@ -1498,8 +1497,8 @@ static int llama_step(bz_model* m, const StepIO& io) {
 }
 
 
-// Mamba2 decode step (forward_with_ssm_state, /root/reference/src/engine/executor_generate.rs:137,148), 4 launches per layer:
-//   in_proj GEMV (prologue: residual add + RMSNorm) -> conv1d step + SiLU -> SSM recurrence -> out_proj GEMV (prologue: gate + grouped RMSNorm)
+// Mamba2 decode step (forward_with_ssm_state, /root/reference/src/engine/executor_generate.rs:137,148), 3 launches per layer:
+//   in_proj GEMV (prologue: residual add + RMSNorm) -> [conv1d step + SiLU + SSM recurrence + gate] -> out_proj GEMV (prologue: grouped RMSNorm)
 static int mamba_step(bz_model* m, const StepIO& io) {
   const bz_model_config& c = m->cfg;
   hipStream_t st = step_stream(m);
@@ -1516,16 +1515,18 @@ static int mamba_step(bz_model* m, const StepIO& io) {
     VSrc zx;
     BZ_TRY(run_fused(m, L.in_proj, pn, rs, &zx));
     cur ^= 1;
-    const float* zxp = (const float*)zx.p;
-    BZ_TRY(bzk_conv_step(st, zxp, DI, conv_dim, KC, L.conv_w, L.conv_b, S->conv + (size_t)l * conv_dim * (KC - 1), act, m->xbc));
+    // conv1d step + SiLU + SSM recurrence + gate in one launch (reads the projection from the ring: f32 or fixed point)
     SsmArgs sa{};
-    sa.xbc = m->xbc; sa.zxbcdt = zxp; sa.dt_off = DI + conv_dim; sa.dt_bias = L.dt_bias; sa.A_log = L.A_log; sa.D = L.D;
+    sa.zx = zx; sa.z_off = 0; sa.x_off = DI; sa.dt_off = DI + conv_dim; sa.dt_bias = L.dt_bias; sa.A_log = L.A_log; sa.D = L.D;
+    sa.conv_w = L.conv_w; sa.conv_b = L.conv_b; sa.conv_state = S->conv + (size_t)l * conv_dim * (KC - 1); sa.conv_kernel = KC;
     sa.state = (char*)S->ssm + (size_t)l * NH * c.ssm_head_dim * NS * bz_dtype_size(S->dtype); sa.sdt = S->dtype;
-    sa.n_heads = NH; sa.head_dim = c.ssm_head_dim; sa.d_state = NS; sa.n_groups = G; sa.d_inner = DI; sa.act = act; sa.y = m->ybuf; sa.z = zxp; sa.vss = m->vss;
+    sa.n_heads = NH; sa.head_dim = c.ssm_head_dim; sa.d_state = NS; sa.n_groups = G; sa.d_inner = DI; sa.act = act; sa.y = m->ybuf; sa.gate = 1; sa.vss = m->vss;
     BZ_TRY(bzk_ssm_step(st, sa));
     Pro pg{}; pg.mode = PRO_GATED2; pg.src = VSrc{m->ybuf, 0}; pg.h_in = m->vss; pg.aux2 = NH; pg.norm_w = L.gnorm; pg.eps = c.rms_eps; pg.H = DI; pg.act = act; pg.aux = G;
     VSrc ov;
-    BZ_TRY(run_fused(m, L.out_proj, pg, rs, &ov));
+    // side duty of this launch: the B / C channels' conv state moves on by this step's projection (every head's SSM step has read the old one)
+    ConvShift shf{sa.conv_state, zx, DI, DI, 2 * G * NS, KC};
+    BZ_TRY(run_fused(m, L.out_proj, pg, rs, &ov, &shf));
     prev = ov;
   }
   // ring indices as in llama_step: rs.ri clean, (rs.ri+2)%3 holds `prev` when it is fixed point, (rs.ri+1)%3 stale
@@ -2350,6 +2351,58 @@ extern "C" int bz_tune_gemv(bz_device* dev, int N, int K, int gw, int mode, int 
       for (int w = 0; w < 12; w++) { fprintf(stderr, "   "); for (int i = 0; i < 8; i++) fprintf(stderr, " %6.2f", h[(b * 12 + w) * 8 + i] > 0 ? (h[(b * 12 + w) * 8 + i] - t0) / 100.0 : -1.0); fprintf(stderr, "\n"); }
     }
   }
+  double tot = 0; int n = 0;
+  for (auto& r : sink.recs) { float ms = 0.f; if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) { tot += ms; n++; } hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+  *avg_us = n ? 1e3 * tot / n : 0.0;
+  for (void* q : bufs) hipFree(q);
+  return rc;
+  BZ_API_END
+}
+
+// Tuning aid for the dense row GEMV (k_gemv_rows): [N,K] 16-bit weights in `nbuf` rotating buffers (cold HBM), the real launcher.
+// mode: 0 plain f32 x, 1 fused residual + RMSNorm prologue (fixed-point prev), 2 SiLU*up prologue (fixed-point gate/up); sk: split-K count
+// (0 = the loader's choice, bzk_rows_choose_sk).  Returns the mean dispatch time.
+extern "C" int bz_tune_rows(bz_device* dev, int N, int K, int wdt, int mode, int sk, int nbuf, int iters, double* avg_us) {
+  BZ_API_BEGIN
+  if (!dev || !avg_us || N <= 0 || K % 8 || K <= 0 || nbuf <= 0 || iters <= 0 || mode < 0 || mode > 2 || (wdt != BZ_F16 && wdt != BZ_BF16)) BZ_FAIL(BZ_E_INVALID, "tune_rows: bad argument");
+  BZ_HIP(hipSetDevice(dev->id));
+  hipStream_t st = dev->stream;
+  const size_t wb = (size_t)N * K * 2;
+  std::vector<void*> bufs;
+  int rc = BZ_OK;
+  auto alloc = [&](size_t bytes, void** p) { if (hipMalloc(p, bytes) != hipSuccess) { rc = BZ_E_OOM; *p = nullptr; } else bufs.push_back(*p); };
+  std::vector<LinearDev> Ls(nbuf);
+  const int SK = sk > 0 ? sk : bzk_rows_choose_sk(N, K);
+  for (int b = 0; b < nbuf && rc == BZ_OK; b++) {
+    void* w;
+    alloc(wb, &w);
+    if (rc != BZ_OK) break;
+    hipMemsetAsync(w, wdt == BZ_F16 ? 0x1c : 0x3b, wb, st);   // small finite values in either format
+    LinearDev& L = Ls[b];
+    L.kind = LK_ROWS; L.N = N; L.K = K; L.wdt = wdt; L.w = w; L.sk = SK; L.algo_bytes = wb;
+  }
+  const int KX = mode == 2 ? 2 * K : K;
+  void *xs, *acc, *hin, *hout, *nw, *src, *y;
+  alloc((size_t)KX * 8, &src); alloc((size_t)N * 8, &acc); alloc((size_t)K * 4, &hin); alloc((size_t)K * 4, &hout); alloc((size_t)K * 4, &nw); alloc((size_t)KX * 4, &xs);
+  alloc((size_t)N * 4, &y);
+  if (rc != BZ_OK) { for (void* p : bufs) hipFree(p); BZ_FAIL(BZ_E_OOM, "tune_rows: out of memory"); }
+  hipLaunchKernelGGL(k_fill_u32, dim3(64), dim3(256), 0, st, (uint32_t*)src, (size_t)KX * 2, 5u);
+  hipMemsetAsync(xs, 0x3c, (size_t)KX * 4, st); hipMemsetAsync(hin, 0x3c, (size_t)K * 4, st); hipMemsetAsync(nw, 0x3c, (size_t)K * 4, st);
+  hipMemsetAsync(acc, 0, (size_t)N * 8, st);
+  Pro p{};
+  p.act = wdt; p.eps = 1e-5f;
+  if (mode == 0) { p.mode = PRO_PLAIN; p.src = VSrc{xs, 0}; }
+  else if (mode == 1) { p.mode = PRO_NORM; p.src = VSrc{src, 1}; p.h_in = (float*)hin; p.h_out = (float*)hout; p.norm_w = (float*)nw; p.H = K; }
+  else { p.mode = PRO_SILU; p.src = VSrc{src, 1}; p.H = K; }
+  BzTimingSink sink;
+  for (int i = 0; i < iters + 2 && rc == BZ_OK; i++) {
+    GemvOut o{};
+    if (SK > 1) o.acc = (long long*)acc; else o.direct = (float*)y;
+    if (i == 2) bzk_set_timing_sink(&sink);
+    rc = bzk_gemv(st, Ls[i % nbuf], p, o, wdt);
+  }
+  bzk_set_timing_sink(nullptr);
+  hipStreamSynchronize(st);
   double tot = 0; int n = 0;
   for (auto& r : sink.recs) { float ms = 0.f; if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) { tot += ms; n++; } hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
   *avg_us = n ? 1e3 * tot / n : 0.0;

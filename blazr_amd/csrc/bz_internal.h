@@ -162,12 +162,16 @@ BzTimingSink* bzk_timing_sink();
 // ---------------------------------------------------------------------------------------------------------
 // kernel launchers (bz_kernels.hip)
 // ---------------------------------------------------------------------------------------------------------
+// Mamba2 side duty of the out_proj GEMV: shift the conv state of channels [ch0, ch0 + n) by this step's raw projection (see k_ssm_step)
+struct ConvShift { float* cs; VSrc src; int x_off, ch0, n, kc; };
+
 struct GemvOut {
   long long* acc;        // Q4G/K-quants: fixed-point accumulator [N] (must be zero on entry)
   float* direct;         // ROWS: direct store [N] (rounded to act)
   long long* zero_buf;   // buffer this launch zeroes for the NEXT accumulate launch (nullptr: none)
   int zero_n;
   float* amax_val; int* amax_idx; // ROWS argmax partials per block (nullptr: off)
+  ConvShift shift;       // ROWS: optional side duty (cs == nullptr: none)
 };
 
 int bzk_gemv(hipStream_t s, const LinearDev& L, const Pro& pro, const GemvOut& out, int act);
@@ -310,17 +314,15 @@ int bzk_sample(hipStream_t s, void** ws, const float* logits, long long V, const
 int bzk_sample_free(void* ws);
 
 // Mamba2 kernels
-int bzk_conv_step(hipStream_t s, const float* zxbcdt, int x_off, int conv_dim, int kc, const float* w, const float* b, float* conv_state, int act,
-                  float* xbc_out);
 struct SsmArgs {
-  const float* xbc;      // [d_inner | G*NS (B) | G*NS (C)] after conv + silu
-  const float* zxbcdt;   // raw in_proj output (dt at dt_off)
-  int dt_off;
+  VSrc zx;               // raw in_proj output [z | x B C | dt] (f32, or the fixed-point accumulator of a split GEMV)
+  int z_off, x_off, dt_off;
+  const float* conv_w; const float* conv_b; float* conv_state; int conv_kernel;   // this layer's depthwise conv1d: [conv_dim][kc], [conv_dim], [conv_dim][kc-1]
   const float* dt_bias; const float* A_log; const float* D;
   void* state; int sdt;  // this layer's [n_heads][head_dim][d_state]
   int n_heads, head_dim, d_state, n_groups, d_inner, act;
   float* y;              // [d_inner]
-  const float* z;        // optional gate input [d_inner]: y <- R(y * R(silu(z))) and vss[head] <- sum of y^2 (feeds PRO_GATED2)
+  int gate;              // != 0: y <- R(y * R(silu(z))) and vss[head] <- sum of y^2 (feeds PRO_GATED2)
   float* vss;            // [n_heads]
 };
 int bzk_ssm_step(hipStream_t s, const SsmArgs& a);

@@ -558,6 +558,7 @@ struct OpOr { __device__ __forceinline__ static int f(int a, int b) { return a |
 //  * the tail (sum of the waves' partials, SiLU * up, its 64-value quantisation) runs in ONE wave between two barriers instead of four.
 __device__ __forceinline__ void lds_wait_count(volatile unsigned* cnt, unsigned n) {
   while (*cnt < n) __builtin_amdgcn_s_sleep(1);
+  asm volatile("" ::: "memory");   // the LDS reads that follow stay behind the wait
 }
 template <int FIX, int GPW, int TPW, int NW, int ACT, int DIAG = 0>   // NW waves per block; GPW k-groups per wave (gate/up), TPW output tiles per wave (down); DIAG: stamp build
 __global__ __launch_bounds__(NW * 64) void k_mlp_q4g(const uint4* __restrict__ Wgu, const __half* __restrict__ Sgu, const unsigned char* __restrict__ Zgu,
@@ -2103,6 +2104,200 @@ __global__ __launch_bounds__(256) void k_gemv_rows(const void* __restrict__ W, c
   rows_body<WDT, SPLIT>(W, bias, N, K, rows_per_wg, pro, out, act, pval, pidx, zero_buf, zero_n, SK, accbuf, blockIdx.x);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Dense row GEMV, second form (16-bit weights, fixed-point output): balanced unit ranges + wave roles.
+//  * unit = (512-k chunk kc, group rg of four rows), ordered chunk-major: u = kc * NRG + rg.  Workgroup b owns units [U b / nb, U (b+1) / nb) and
+//    its eight tile waves split that range evenly again, so that any [N, K] loads the 256 CUs to within one unit (16-row x full-K workgroups
+//    left 35 % of the chip idle on N = 10576, and ran 1024 norm prologues against 32 MB of L2 reads on N = 16384).  A range lies in at most two
+//    chunks (nb >= K / 512), so a workgroup needs 1024 elements of x, eight per lane and chunk, held in REGISTERS by the tile waves.
+//  * roles (see k_mlp_q4g): waves 0-3 hold the activation row -- their loads go out first, then the rendezvous barrier, then the tile waves
+//    (4-11) request up to 16 KiB each and sit in the issue queue while the norm runs.  The halves meet through two LDS counters.
+//  * every unit ends in a 4-value transposed reduction (3 swaps + 4 DPP steps) and one 64-bit fixed-point atomic per row: N K / 512 atomics.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum4(float v0, float v1, float v2, float v3) {
+  // permlane32_swap(a, b): a's upper half <-> b's lower half; permlane16_swap(a, b): a's odd rows <-> b's even rows.  Result: the total of
+  // v0 in every lane of row 0 (lanes 0-15), v2 in row 1, v1 in row 2, v3 in row 3
+  bz_u2_t r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v0), __float_as_uint(v1), false, false);
+  const float s01 = __uint_as_float(r.x) + __uint_as_float(r.y);
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v2), __float_as_uint(v3), false, false);
+  const float s23 = __uint_as_float(r.x) + __uint_as_float(r.y);
+  r = __builtin_amdgcn_permlane16_swap(__float_as_uint(s01), __float_as_uint(s23), false, false);
+  return grp_reduce<16, OpAdd>(__uint_as_float(r.x) + __uint_as_float(r.y));
+}
+
+// Mamba2: the B / C channels' conv state is shifted by the launch AFTER the SSM step (every head has read the old state by then): a side duty of
+// the out_proj GEMV, like the ring's zeroing duty
+__device__ __forceinline__ void conv_shift_one(const ConvShift& c, int i, int act) {
+  const int ch = c.ch0 + i;
+  float* cs = c.cs + (size_t)ch * (c.kc - 1);
+  const float xr = vsrc_get(c.src, c.x_off + ch, act);
+  for (int j = 0; j + 1 < c.kc - 1; j++) cs[j] = cs[j + 1];
+  cs[c.kc - 2] = xr;
+}
+__global__ void k_conv_shift(ConvShift c, int act) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < c.n) conv_shift_one(c, i, act);
+}
+
+template <int WDT, int MODE, bool FIX>
+__global__ __launch_bounds__(768) void k_gemv_rows2(const void* __restrict__ W, const float* __restrict__ bias, int N, int K, Pro pro,
+                                                    long long* __restrict__ acc, long long* zero_buf, int zero_n, ConvShift shift) {
+  __shared__ __attribute__((aligned(16))) float xs[1024];   // x[k0, k0 + 1024): the (at most) two chunks of this workgroup
+  __shared__ double dred[4];
+  __shared__ float grs[4][8];
+  __shared__ unsigned cnt[2];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int NRG = (N + 3) >> 2, KCall = (K + 511) >> 9;
+  const long long U = (long long)NRG * KCall;
+  const int u0 = (int)(U * blockIdx.x / gridDim.x), u1 = (int)(U * (blockIdx.x + 1) / gridDim.x);
+  const int kcA = u0 / NRG;
+  const int k0 = kcA * 512;                       // first k of the slice
+  const int ub = (kcA + 1) * NRG;                 // first unit of the second chunk
+  const int act = pro.act;
+  if (tid == 0) { cnt[0] = 0; cnt[1] = 0; }
+  if (wave < 4) {
+    // ---- row waves: x[k0, k0 + 1024) -> LDS -------------------------------------------------------------
+    const int sk = k0 + tid * 4;                   // this thread's four slice elements
+    const int skc = min(sk, K - 4);                // clamped for addressing (K % 8 == 0)
+    const bool son = sk < K;
+    if (MODE == PRO_NORM) {
+      const int H = pro.H;
+      const bool hasprev = pro.src.p != nullptr;
+      const void* prevp = hasprev ? pro.src.p : (const void*)pro.h_in;
+      const float4 nw = *(const float4*)(pro.norm_w + skc);
+      double ssd = 0.0;
+      bool first = true;
+      for (int base = 0; base < H; base += 4096) {
+        float4 ha[2], hb[2];
+        typename SrcRaw<FIX>::T pv[2][8];
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          const int i0 = min(base + (j * 256 + tid) * 8, H - 8);
+          ha[j] = *(const float4*)(pro.h_in + i0); hb[j] = *(const float4*)(pro.h_in + i0 + 4);
+#pragma unroll
+          for (int e = 0; e < 8; e++) pv[j][e] = src_raw<FIX>(prevp, (FIX || hasprev) ? i0 + e : 0);
+        }
+        if (first) { __builtin_amdgcn_sched_barrier(0); __syncthreads(); first = false; }   // rendezvous: these loads are ahead of the weight stream
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          const int i0 = base + (j * 256 + tid) * 8;
+          float v[8] = {ha[j].x, ha[j].y, ha[j].z, ha[j].w, hb[j].x, hb[j].y, hb[j].z, hb[j].w};
+          if (hasprev) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = round_act(v[e] + src_cvt<FIX>(pv[j][e], act), act);
+          }
+          if (i0 < H) {
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) ssd += (double)(v[e] * v[e]) + (double)(v[e + 1] * v[e + 1]);
+            if (blockIdx.x == 0 && pro.h_out) { *(float4*)(pro.h_out + i0) = make_float4(v[0], v[1], v[2], v[3]); *(float4*)(pro.h_out + i0 + 4) = make_float4(v[4], v[5], v[6], v[7]); }
+            if (i0 >= k0 && i0 < k0 + 1024) { *(float4*)(xs + (i0 - k0)) = make_float4(v[0], v[1], v[2], v[3]); *(float4*)(xs + (i0 - k0) + 4) = make_float4(v[4], v[5], v[6], v[7]); }
+          }
+        }
+      }
+      ssd = wave_sum_d(ssd);
+      if (lane == 0) dred[wave] = ssd;
+      __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): the parked slice and the partial are in LDS
+      if (lane == 0) atomicAdd(&cnt[0], 1u);
+      lds_wait_count(&cnt[0], 4);
+      const float ss = (float)((dred[0] + dred[1]) + (dred[2] + dred[3]));   // the rounded exact sum of squares (oracle: orc_rms_norm)
+      const float rs = 1.0f / sqrtf(ss / (float)H + pro.eps);
+      float4 v = *(const float4*)(xs + tid * 4);
+      const float nwv[4] = {nw.x, nw.y, nw.z, nw.w};
+      float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int e = 0; e < 4; e++) x[e] = son ? round_act(nwv[e] * round_act(x[e] * rs, act), act) : 0.f;
+      *(float4*)(xs + tid * 4) = make_float4(x[0], x[1], x[2], x[3]);
+    } else if (MODE == PRO_GATED2) {
+      // gated RMSNorm with the gate and the per-head sums of squares already applied / reduced by the SSM kernel (see build_x_simple)
+      const int G = pro.aux > 0 ? pro.aux : 1, gsz = pro.H / G, hpg = pro.aux2 / G;
+      const float4 vv = *(const float4*)((const float*)pro.src.p + skc);
+      const float4 nw = *(const float4*)(pro.norm_w + skc);
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+      for (int g = 0; g < G && g < 8; g++) {        // every row wave keeps its own copy of the (<= 8) group factors
+        double t = 0.0;
+        for (int h = lane; h < hpg; h += 64) t += (double)pro.h_in[g * hpg + h];
+        t = wave_sum_d(t);
+        if (lane == 0) grs[wave][g] = 1.0f / sqrtf((float)t / (float)gsz + pro.eps);
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      const float rs = grs[wave][min(skc / gsz, 7)];
+      const float vs[4] = {vv.x, vv.y, vv.z, vv.w}, nwv[4] = {nw.x, nw.y, nw.z, nw.w};
+      float x[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) x[e] = son ? round_act(nwv[e] * round_act(vs[e] * rs, act), act) : 0.f;
+      *(float4*)(xs + tid * 4) = make_float4(x[0], x[1], x[2], x[3]);
+    } else {
+      typename SrcRaw<FIX>::T a[4], b[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        a[e] = src_raw<FIX>(pro.src.p, skc + e);
+        if (MODE == PRO_SILU) b[e] = src_raw<FIX>(pro.src.p, pro.H + skc + e);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+      float x[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        float v = src_cvt<FIX>(a[e], act);
+        if (MODE == PRO_SILU) v = round_act(round_act(silu_f(v), act) * src_cvt<FIX>(b[e], act), act);
+        x[e] = son ? v : 0.f;
+      }
+      *(float4*)(xs + tid * 4) = make_float4(x[0], x[1], x[2], x[3]);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): this wave's part of x is in LDS
+    if (lane == 0) atomicAdd(&cnt[1], 1u);
+    if (shift.cs)                                  // the row waves are done: they take the side duty
+      for (int i = blockIdx.x * 256 + tid; i < shift.n; i += gridDim.x * 256) conv_shift_one(shift, i, act);
+    return;
+  }
+  // ---- tile waves ---------------------------------------------------------------------------------------
+  const int tw = wave - 4;
+  const int ua = u0 + (int)((long long)(u1 - u0) * tw / 8), ue = u0 + (int)((long long)(u1 - u0) * (tw + 1) / 8);
+  struct Stage { RowPiece<WDT> p[4]; };
+  auto issue = [&](Stage& S, int u) {
+    const int kc = kcA + (u >= ub ? 1 : 0);
+    const int rg = u - kc * NRG;
+    const int k = kc * 512 + lane * 8;
+    const int ko = k < K ? k : 0;                 // x is 0 beyond K
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) S.p[rr] = piece_load<WDT>(W, (size_t)min(4 * rg + rr, N - 1) * K + ko);
+  };
+  __syncthreads();                                 // rendezvous: the row waves' loads are in the queue
+  Stage st[4];
+  if (ua < ue) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) if (ua + q < ue) issue(st[q], ua + q);
+  }
+  if (zero_buf)                                   // the ring protocol's zeroing duty, by the 512 tile threads
+    for (int i = blockIdx.x * 512 + (tid - 256); i < zero_n; i += gridDim.x * 512) zero_buf[i] = 0;
+  lds_wait_count(&cnt[1], 4);
+  const float4 xa0 = *(const float4*)(xs + lane * 8), xa1 = *(const float4*)(xs + lane * 8 + 4);
+  const float4 xb0 = *(const float4*)(xs + 512 + lane * 8), xb1 = *(const float4*)(xs + 512 + lane * 8 + 4);
+  const int jrow = ((lane >> 4) & 1) * 2 + (lane >> 5);   // wave_sum4: row (of 16 lanes) -> value index
+  for (int uc = ua; uc < ue; uc += 4) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int u = uc + q;
+      if (u < ue) {
+        const bool second = u >= ub;
+        const float4 xa = second ? xb0 : xa0, xb = second ? xb1 : xa1;
+        const float d0 = piece_dot<WDT>(st[q].p[0], xa, xb), d1 = piece_dot<WDT>(st[q].p[1], xa, xb);
+        const float d2 = piece_dot<WDT>(st[q].p[2], xa, xb), d3 = piece_dot<WDT>(st[q].p[3], xa, xb);
+        if (u + 4 < ue) issue(st[q], u + 4);
+        float v = wave_sum4(d0, d1, d2, d3);
+        const int kc = kcA + (second ? 1 : 0);
+        const int row = 4 * (u - kc * NRG) + jrow;
+        if ((lane & 15) == 0 && row < N) {
+          if (bias && kc == 0) v += bias[row];
+          atomicAdd((unsigned long long*)(acc + row), (unsigned long long)f2fix(v));
+        }
+      }
+    }
+  }
+}
+
 // MoE grouped GEMV: blockIdx.y = expert slot.  The expert id comes from the router's device-side selection, so the whole MoE
 // layer stays capturable in a hipGraph.  Stacked weights [E + n_shared][N][K]; per-slot prologue source / output offsets.
 template <int WDT, bool SPLIT>
@@ -2125,14 +2320,26 @@ static int rows_per_wg_for(int N) {
   while (r < 256 && (N + r - 1) / r > 1024) r <<= 1;
   return r;
 }
+static bool rows2_enabled() { static const bool off = getenv("BZ_NO_ROWS2") != nullptr; return !off; }
 // split count for a dense [N,K] GEMV: enough (16-row x K-slice) workgroups to fill the chip when N alone is too small
 int bzk_rows_choose_sk(int N, int K) {
   const int rbs = (N + 15) / 16, KC = (K + 511) / 512;
-  if (rbs >= 512 || KC < 8) return 1;
+  if (rows2_enabled() && K % 8 == 0 && K <= 131072) {   // fixed-point output whatever the shape: k_gemv_rows2 balances any [N, K] over the chip
+    if (rbs >= 512 || KC < 8) return 2;                // (the value only matters to the fallback kernel)
+  } else if (rbs >= 512 || KC < 8) return 1;
   int sk = std::min((512 + rbs - 1) / rbs, KC / 4);   // a slice keeps >= 4 chunks (2048 k): below that the prologue dominates
   const int kcs = (KC + sk - 1) / sk;
   sk = (KC + kcs - 1) / kcs;
   return sk;
+}
+// the balanced role kernel (k_gemv_rows2) takes every fixed-point-output dense GEMV with 16-bit weights
+static bool bzk_rows2_ok(const LinearDev& L, const Pro& pro, const GemvOut& out) {
+  if (!rows2_enabled() || L.kind != LK_ROWS || L.sk <= 1 || !out.acc || out.amax_val) return false;
+  if (L.wdt != BZ_F16 && L.wdt != BZ_BF16) return false;
+  if (L.K % 8 || L.K > 131072 || pro.perm) return false;
+  if (pro.mode == PRO_NORM) return pro.H == L.K && pro.H % 8 == 0;
+  if (pro.mode == PRO_GATED2) return !pro.src.fix && (pro.aux <= 8) && pro.H == L.K && (pro.H / (pro.aux > 0 ? pro.aux : 1)) % 4 == 0;
+  return pro.mode == PRO_PLAIN || pro.mode == PRO_SILU;
 }
 int bzk_gemv_rows_blocks(const LinearDev& L) { int r = rows_per_wg_for(L.N); return (L.N + r - 1) / r; }
 
@@ -2319,8 +2526,28 @@ int bzk_gemv(hipStream_t s, const LinearDev& L, const Pro& pro, const GemvOut& o
     BZ_HIP(hipGetLastError());
     return BZ_OK;
   }
+  if (L.kind == LK_ROWS && bzk_rows2_ok(L, pro, out)) {
+    static const int forced = getenv("BZ_ROWS2_WGS") ? atoi(getenv("BZ_ROWS2_WGS")) : 0;
+    const long long U = (long long)((L.N + 3) / 4) * ((L.K + 511) / 512);
+    const int KC = (L.K + 511) / 512;
+    int nb = forced > 0 ? forced : 256;
+    nb = (int)std::max<long long>(std::min<long long>(nb, U), KC);
+    const char* lbl = pro.mode == PRO_NORM ? "gemv_rows2<norm>" : pro.mode == PRO_GATED2 ? "gemv_rows2<gated>" : pro.mode == PRO_SILU ? "gemv_rows2<silu>" : "gemv_rows2";
+#define LAUNCH_R2(DT, MODE, FIX) BZ_LAUNCH(lbl, L.algo_bytes, (k_gemv_rows2<DT, MODE, FIX>), dim3(nb), dim3(768), 0, s, (const void*)L.w, L.bias, L.N, L.K, pro, \
+    out.acc, out.zero_buf, out.zero_n, out.shift)
+#define LAUNCH_R2_F(DT, MODE) do { if (pro.src.fix) LAUNCH_R2(DT, MODE, true); else LAUNCH_R2(DT, MODE, false); } while (0)
+#define LAUNCH_R2_M(DT) do { if (pro.mode == PRO_NORM) LAUNCH_R2_F(DT, PRO_NORM); else if (pro.mode == PRO_SILU) LAUNCH_R2_F(DT, PRO_SILU); \
+    else if (pro.mode == PRO_GATED2) LAUNCH_R2(DT, PRO_GATED2, false); else LAUNCH_R2_F(DT, PRO_PLAIN); } while (0)
+    if (L.wdt == BZ_F16) LAUNCH_R2_M(BZ_F16); else LAUNCH_R2_M(BZ_BF16);
+#undef LAUNCH_R2_M
+#undef LAUNCH_R2_F
+#undef LAUNCH_R2
+    BZ_HIP(hipGetLastError());
+    return BZ_OK;
+  }
   if (L.kind == LK_ROWS) {
     const int SK = L.sk > 1 ? L.sk : 1;
+    if (out.shift.cs) { hipLaunchKernelGGL(k_conv_shift, dim3((out.shift.n + 255) / 256), dim3(256), 0, s, out.shift, act); BZ_HIP(hipGetLastError()); }   // (k_gemv_rows2 does it in-launch)
     if (SK == 1 && !out.direct) BZ_FAIL(BZ_E_INVALID, "rows gemv needs a direct output");
     if (SK > 1 && (!out.acc || out.amax_val)) BZ_FAIL(BZ_E_INVALID, "split-K rows gemv needs a fixed-point accumulator");
     const int rpw = SK > 1 ? 16 : rows_per_wg_for(L.N);
@@ -3795,57 +4022,64 @@ int bzk_silu_mul(hipStream_t s, const float* g, const float* u, long long n, int
 // ---------------------------------------------------------------------------------------------------------
 // Mamba2 single-token kernels: causal conv1d step, SSM state update + readout
 // ---------------------------------------------------------------------------------------------------------
-__global__ void k_conv_step(const float* zx, int x_off, int conv_dim, int kc, const float* w, const float* b, float* cs, int act, float* out) {
-  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ch >= conv_dim) return;
-  float* st = cs + (size_t)ch * (kc - 1);
-  const float xr = zx[x_off + ch];
-  float a = 0.f;
-  for (int j = 0; j < kc - 1; j++) a += st[j] * w[(size_t)ch * kc + j];
-  a += xr * w[(size_t)ch * kc + kc - 1];
-  a = round_act(a + b[ch], act);
-  out[ch] = round_act(silu_f(a), act);
-  for (int j = 0; j + 1 < kc - 1; j++) st[j] = st[j + 1];
-  st[kc - 2] = xr;
-}
-int bzk_conv_step(hipStream_t s, const float* zxbcdt, int x_off, int conv_dim, int kc, const float* w, const float* b, float* conv_state, int act,
-                  float* xbc_out) {
-  BZ_LAUNCH("mamba2_conv_step", (double)conv_dim * (kc * 2 + 2) * 4, k_conv_step, dim3((conv_dim + 255) / 256), dim3(256), 0, s, zxbcdt, x_off, conv_dim, kc,
-            w, b, conv_state, act, xbc_out);
-  BZ_HIP(hipGetLastError());
-  return BZ_OK;
-}
-
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
 
 // grid = n_heads; 256 threads = 64 rows (p) x 4 state quarters.  h = R(h * dA + (dt x) B); y = R(sum_n h C + D x)
+// The causal conv1d step (+ SiLU) runs in front, inside the same launch: a head's workgroup convolves its own head_dim x channels (and shifts
+// their conv state, which nobody else touches) and -- redundantly, 2 d_state channels -- its group's B and C from the OLD state.  The B / C
+// state is shifted by the NEXT launch (the out_proj GEMV's ConvShift duty), when every head has read it.  All global loads of the step (state
+// piece, conv taps, dt) are issued before the first use: one L2 round trip instead of four.
 template <int SDT, int PARTS>   // PARTS threads share a state row: 4 (256-thread blocks) or 16 (1024 threads: 4 waves per SIMD, one 16-byte piece per thread)
 __global__ __launch_bounds__(64 * PARTS) void k_ssm_step(SsmArgs a) {
   constexpr int NTH = 64 * PARTS;
-  __shared__ float sB[256], sC[256], sred[PARTS];
+  __shared__ float sB[256], sC[256], sX[256], sred[PARTS];
   const int hd = blockIdx.x, tid = threadIdx.x;
-  const int NS = a.d_state, HD = a.head_dim;
-  const int g = hd / (a.n_heads / a.n_groups);
-  for (int i = tid; i < NS; i += NTH) { sB[i] = a.xbc[a.d_inner + g * NS + i]; sC[i] = a.xbc[a.d_inner + a.n_groups * NS + g * NS + i]; }
-  const float dt = round_act(softplus_f(round_act(a.zxbcdt[a.dt_off + hd] + a.dt_bias[hd], a.act)), a.act);
-  const float dA = expf(dt * -expf(a.A_log[hd]));
-  const float Dh = a.D[hd];
-  __syncthreads();
+  const int NS = a.d_state, HD = a.head_dim, KC = a.conv_kernel;
+  const int hpg = a.n_heads / a.n_groups;
+  const int g = hd / hpg;
   const int q = tid % PARTS, nq = NS / PARTS;      // this thread's part of the state row
+  const bool vec = (SDT != BZ_F32) && (nq & 7) == 0;
+  // (0) the first state piece of this thread, and dt
+  uint4 pre = make_uint4(0, 0, 0, 0);
+  if (SDT != BZ_F32) { if (vec && tid / PARTS < HD) pre = *(const uint4*)((const unsigned short*)a.state + ((size_t)hd * HD + tid / PARTS) * NS + q * nq); }
+  const float dtraw = vsrc_get(a.zx, a.dt_off + hd, a.act);
+  const float dtb = a.dt_bias[hd], alog = a.A_log[hd], Dh = a.D[hd];
+  // (1) conv1d step + SiLU: B, C of the group (old state, read only) and this head's x channels (state shifted here)
+  for (int t = tid; t < 2 * NS + HD; t += NTH) {
+    const int ch = t < NS ? a.d_inner + g * NS + t : (t < 2 * NS ? a.d_inner + a.n_groups * NS + g * NS + (t - NS) : hd * HD + (t - 2 * NS));
+    float* cs = a.conv_state + (size_t)ch * (KC - 1);
+    const float xr = vsrc_get(a.zx, a.x_off + ch, a.act);
+    float c = 0.f;
+    if (KC == 4) {
+      const float c0 = cs[0], c1 = cs[1], c2 = cs[2];
+      const float4 w = *(const float4*)(a.conv_w + (size_t)ch * 4);
+      c += c0 * w.x; c += c1 * w.y; c += c2 * w.z; c += xr * w.w;
+      if (t >= 2 * NS) { cs[0] = c1; cs[1] = c2; cs[2] = xr; }
+    } else {
+      for (int j = 0; j < KC - 1; j++) c += cs[j] * a.conv_w[(size_t)ch * KC + j];
+      c += xr * a.conv_w[(size_t)ch * KC + KC - 1];
+      if (t >= 2 * NS) { for (int j = 0; j + 1 < KC - 1; j++) cs[j] = cs[j + 1]; cs[KC - 2] = xr; }
+    }
+    c = round_act(c + a.conv_b[ch], a.act);
+    c = round_act(silu_f(c), a.act);
+    if (t < NS) sB[t] = c; else if (t < 2 * NS) sC[t - NS] = c; else sX[t - 2 * NS] = c;
+  }
+  const float dt = round_act(softplus_f(round_act(dtraw + dtb, a.act)), a.act);
+  const float dA = expf(dt * -expf(alog));
+  __syncthreads();
   float vsq = 0.f;
   for (int p0 = 0; p0 < HD; p0 += 64) {
     const int p = p0 + tid / PARTS;
     float acc = 0.f, xv = 0.f;
     if (p < HD) {
-      xv = a.xbc[hd * HD + p];
+      xv = sX[p];
       const float dtx = dt * xv;
       const size_t off = ((size_t)hd * HD + p) * NS + q * nq;
-      const bool vec = (SDT != BZ_F32) && (nq & 7) == 0;
       if (vec) {
         // 16-bit state: 8 elements per 16-byte load / store
         if constexpr (SDT != BZ_F32) for (int n = 0; n < nq; n += 8) {
           uint4* sp = (uint4*)((unsigned short*)a.state + off + n);
-          const uint4 raw = *sp;
+          const uint4 raw = (p0 == 0 && n == 0) ? pre : *sp;
           unsigned u[4] = {raw.x, raw.y, raw.z, raw.w};
 #pragma unroll
           for (int j = 0; j < 4; j++) {
@@ -3876,11 +4110,11 @@ __global__ __launch_bounds__(64 * PARTS) void k_ssm_step(SsmArgs a) {
     acc = grp_reduce<PARTS, OpAdd>(acc);
     if (p < HD && q == 0) {
       float yv = round_act(acc + Dh * xv, a.act);
-      if (a.z) { yv = round_act(yv * round_act(silu_f(a.z[hd * HD + p]), a.act), a.act); vsq += yv * yv; }
+      if (a.gate) { yv = round_act(yv * round_act(silu_f(vsrc_get(a.zx, a.z_off + hd * HD + p, a.act)), a.act), a.act); vsq += yv * yv; }
       a.y[hd * HD + p] = yv;
     }
   }
-  if (a.z) {
+  if (a.gate) {
     vsq = wave_sum(vsq);             // fixed tree: the per-head sum is deterministic
     if ((tid & 63) == 0) sred[tid >> 6] = vsq;
     __syncthreads();
@@ -3893,6 +4127,7 @@ __global__ __launch_bounds__(64 * PARTS) void k_ssm_step(SsmArgs a) {
   }
 }
 int bzk_ssm_step(hipStream_t s, const SsmArgs& a) {
+  if (a.head_dim > 256 || a.conv_kernel < 2) BZ_FAIL(BZ_E_UNSUPPORTED, "ssm_step: head_dim %d / conv kernel %d unsupported", a.head_dim, a.conv_kernel);
   if (a.d_state > 256 || (a.d_state & 3) || a.n_heads % a.n_groups) BZ_FAIL(BZ_E_UNSUPPORTED, "ssm_step: d_state %d / groups %d unsupported", a.d_state, a.n_groups);
   const double bytes = 2.0 * a.n_heads * a.head_dim * a.d_state * (a.sdt == BZ_F32 ? 4 : 2);
   // 16 threads per state row when a part is then a whole number of 16-byte pieces (d_state 128 with a 16-bit state) or the state is f32

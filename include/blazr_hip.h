@@ -284,6 +284,10 @@ int bz_tune_gemv(bz_device* dev, int N, int K, int groups_per_wg, int mode, int 
  * diagnostic build's per-wave phase stamps in 10 ns units */
 int bz_tune_mlp(bz_device* dev, int H, int I, int nbuf, int iters, int flags, double* avg_us, long long* stamps_out);
 
+/* the same for the dense row GEMV (16-bit weights [N,K], wdt BZ_F16 / BZ_BF16); mode 0 plain, 1 residual + RMSNorm prologue, 2 SiLU*up prologue;
+ * sk = split-K count (0: the loader's choice) */
+int bz_tune_rows(bz_device* dev, int N, int K, int wdt, int mode, int sk, int nbuf, int iters, double* avg_us);
+
 /* Measured HBM read ceiling of this device, GB/s: a streaming read of `bytes` (rotating buffers beyond the Infinity Cache) with the decode
  * kernels' load pattern and no arithmetic.  bench.py reports roofline fractions against the 8 TB/s spec peak AND against this number
  * (SURVEY.md 8d "record the measured peak on the box and report against both"). */
