@@ -280,6 +280,8 @@ struct bz_model {
   // concurrent generate() calls on one model (engine/scheduler.rs:67, startup.rs:234-236) interleave whole steps, never kernels.
   std::recursive_mutex mu;
   std::vector<DsLayerDev> dlayers;
+  float* mla_ws = nullptr; int mla_nsplit = 1;   // MLA decode over context slices: partials [n_heads][nsplit][rank + 2]
+  long long* moe_gu_acc = nullptr;   // fixed-point gate / up of the MoE slots (k_gemv_rows2's MoE form); zeroed by the combine launch
   float* moe_xn = nullptr; float* moe_gu = nullptr; float* moe_out = nullptr; long long* moe_acc = nullptr; int* moe_sel = nullptr; float* moe_w = nullptr; float* moe_lg = nullptr; unsigned* moe_cnt = nullptr;
   // DeepSeek-V2 batched-prefill rows (allocated on first use for dpf_rows prompt rows)
   int dpf_rows = 0; float* dpf_att = nullptr; void* dpf_xg16 = nullptr; float* dpf_gu = nullptr; void* dpf_a16 = nullptr; float* dpf_ye = nullptr; float* dpf_ysh = nullptr;
@@ -939,7 +941,6 @@ static int finalize_dsv2(bz_model* m) {
       BZ_TRY(take_vector_f32(m, p + "self_attn.q_a_layernorm.weight", QL, &L.q_norm));
       BZ_TRY(build_fused(m, {p + "self_attn.q_b_proj"}, &L.q_b));
       if (L.q_b.parts.size() != 1 || L.q_b.parts[0].kind != LK_ROWS || L.q_b.N != NH * (DN + DR) || L.q_b.K != QL) BZ_FAIL(BZ_E_INVALID, "layer %d: q_b_proj must be dense [n_heads (nope + rope), q_lora_rank]", l);
-      force_direct(&L.q_b);
       for (auto& P : L.q_b.parts) { m->resident += P.bytes; per_token += P.algo_bytes; }
       per_token += (size_t)QL * act_b;
     } else {
@@ -947,7 +948,7 @@ static int finalize_dsv2(bz_model* m) {
     }
     if (L.qkva.parts.size() != 1 || L.qkva.parts[0].kind != LK_ROWS || L.qkva.N != (QL > 0 ? QL : NH * (DN + DR)) + R + DR || L.qkva.K != H)
       BZ_FAIL(BZ_E_INVALID, "layer %d: q_proj (q_a_proj) / kv_a_proj_with_mqa must be dense tensors matching the config", l);
-    force_direct(&L.qkva);
+    if (QL > 0) force_direct(&L.qkva);   // q_b_proj's norm prologue and the attention kernel's `kva` read q_a / the latent as plain f32
     size_t kvb_bytes = 0;
     BZ_TRY(take_dense(m, p + "self_attn.kv_b_proj.weight", (int64_t)NH * (DN + DV), R, &L.kv_b, &L.kv_b_dt, &kvb_bytes));
     BZ_TRY(build_fused(m, {p + "self_attn.o_proj"}, &L.o));
@@ -1033,10 +1034,13 @@ static int finalize_dsv2(bz_model* m) {
   }
   for (int i = 0; i < 2; i++) { BZ_TRY(dev_alloc(m, &p, (size_t)H * 4)); m->hbuf[i] = (float*)p; }
   BZ_TRY(dev_alloc(m, &p, (size_t)NH * DV * 4)); m->attn_out = (float*)p;
+  m->mla_nsplit = bzk_mla_nsplit(NH);
+  BZ_TRY(dev_alloc(m, &p, (size_t)NH * m->mla_nsplit * (R + 2) * 4)); m->mla_ws = (float*)p;
   BZ_TRY(dev_alloc(m, &p, (size_t)V * 4)); m->logits = (float*)p;
   if (E > 0) {
     BZ_TRY(dev_alloc(m, &p, (size_t)H * 4)); m->moe_xn = (float*)p;
     BZ_TRY(dev_alloc(m, &p, (size_t)(TK + NS) * 2 * MI * 4)); m->moe_gu = (float*)p;
+    BZ_TRY(dev_alloc(m, &p, (size_t)(TK + NS) * 2 * MI * 8)); m->moe_gu_acc = (long long*)p; BZ_HIP(hipMemset(p, 0, (size_t)(TK + NS) * 2 * MI * 8));
     BZ_TRY(dev_alloc(m, &p, (size_t)H * 4)); m->moe_out = (float*)p;
     BZ_TRY(dev_alloc(m, &p, (size_t)(TK + 1) * H * 8)); m->moe_acc = (long long*)p; BZ_HIP(hipMemset(p, 0, (size_t)(TK + 1) * H * 8));
     BZ_TRY(dev_alloc(m, &p, (size_t)(TK + NS + 4) * 4)); m->moe_sel = (int*)p; BZ_HIP(hipMemset(p, 0, (size_t)(TK + NS + 4) * 4));
@@ -1581,6 +1585,7 @@ static int dsv2_step(bz_model* m, const StepIO& io) {
     ma.qkv = qkva; ma.kv_norm = L.kv_norm; ma.eps = c.rms_eps; ma.wkvb = L.kv_b; ma.wdt = L.kv_b_dt; ma.cos_t = m->cos_t; ma.sin_t = m->sin_t; ma.pos = io.d_pos;
     ma.n_heads = NH; ma.rank = R; ma.nope = DN; ma.rope = DR; ma.vdim = DV; ma.act = act; ma.kv = io.kv; ma.layer = l; ma.out = m->attn_out;
     ma.scale = 1.0f / sqrtf((float)(DN + DR));
+    ma.ws = m->mla_ws; ma.nsplit = m->mla_nsplit;
     BZ_TRY(bzk_mla_attn(st, ma, c.max_seq_len));
     Pro pp{}; pp.mode = PRO_PLAIN; pp.src = VSrc{m->attn_out, 0}; pp.act = act; pp.H = 0;
     VSrc ov;
@@ -1598,17 +1603,21 @@ static int dsv2_step(bz_model* m, const StepIO& io) {
       cur ^= 1;
       const int slots = TK + NS;
       const size_t es = bz_dtype_size(L.e_dt);
+      // gate / up of the selected + shared experts in ONE launch, down in one more.  Balanced role kernel (fixed-point accumulators both times) when the
+      // expert weights are 16-bit; else the 16-row workgroup form with a direct f32 gate / up
+      const bool r2 = bzk_moe_rows2_ok(L.e_dt, H) && bzk_moe_rows2_ok(L.e_dt, MI);
       MoeGemvArgs g1{};
       g1.w = L.e_gu; g1.expert_stride = (long long)2 * MI * H; g1.sel = m->moe_sel; g1.N = 2 * MI; g1.K = H; g1.src_stride = 0;
       g1.out = m->moe_gu; g1.out_stride = 2 * MI;
+      if (r2) { g1.acc = m->moe_gu_acc; g1.acc_stride = 2 * MI; g1.acc_slots = slots; }
       Pro p1{}; p1.mode = PRO_PLAIN; p1.src = VSrc{m->moe_xn, 0}; p1.act = act;
-      BZ_TRY(bzk_moe_gemv(st, g1, L.e_dt, slots, p1, act, false, (double)slots * 2 * MI * H * es));
+      BZ_TRY(bzk_moe_gemv(st, g1, L.e_dt, slots, p1, act, r2, (double)slots * 2 * MI * H * es));
       MoeGemvArgs g2{};
       g2.w = L.e_dn; g2.expert_stride = (long long)H * MI; g2.sel = m->moe_sel; g2.N = H; g2.K = MI; g2.src_stride = 2 * MI;
       g2.acc = m->moe_acc; g2.acc_stride = H; g2.acc_slots = TK + 1;
-      Pro p2{}; p2.mode = PRO_SILU; p2.src = VSrc{m->moe_gu, 0}; p2.H = MI; p2.act = act;
+      Pro p2{}; p2.mode = PRO_SILU; p2.src = r2 ? VSrc{m->moe_gu_acc, 1} : VSrc{m->moe_gu, 0}; p2.H = MI; p2.act = act;
       BZ_TRY(bzk_moe_gemv(st, g2, L.e_dt, slots, p2, act, true, (double)slots * H * MI * es));
-      BZ_TRY(bzk_moe_combine(st, m->moe_acc, m->moe_w, TK, NS > 0, H, act, m->moe_out));
+      BZ_TRY(bzk_moe_combine(st, m->moe_acc, m->moe_w, TK, NS > 0, H, act, m->moe_out, r2 ? m->moe_gu_acc : nullptr, slots * 2 * MI));
       prev = VSrc{m->moe_out, 0};
     }
   }

@@ -165,6 +165,9 @@ BzTimingSink* bzk_timing_sink();
 // Mamba2 side duty of the out_proj GEMV: shift the conv state of channels [ch0, ch0 + n) by this step's raw projection (see k_ssm_step)
 struct ConvShift { float* cs; VSrc src; int x_off, ch0, n, kc; };
 
+// MoE form of k_gemv_rows2: n slots, slot s -> expert sel[s] (sel == nullptr: the one dense matrix), its input row and its accumulator row
+struct MoeSlots { const int* sel; long long expert_stride; int n; long long src_stride; long long acc_stride; int acc_slots; };
+
 struct GemvOut {
   long long* acc;        // Q4G/K-quants: fixed-point accumulator [N] (must be zero on entry)
   float* direct;         // ROWS: direct store [N] (rounded to act)
@@ -262,7 +265,9 @@ struct MlaArgs {
   // in the cache (bzk_mla_append_rows), token t attends over positions 0 .. pos0 + t, its output goes to out + t * out_stride
   int batch; int pos0; long long q_stride; long long out_stride;
   const float* kva;         // decode with q_lora_rank > 0: [latent | k_pe] of the current token when q comes from a separate projection (else nullptr)
+  float* ws; int nsplit;    // decode over context slices (nsplit > 1): [n_heads][nsplit][rank + 2] partials (k_mla_attn<SPLIT> -> k_mla_merge)
 };
+int bzk_mla_nsplit(int n_heads);
 // prompt rows: latent RMSNorm + k_pe RoPE of rows s = 0 .. S-1 (source row s at kva + s * stride), appended to the cache at position pos0 + s
 int bzk_mla_append_rows(hipStream_t s, const float* kva, long long stride, int S, const float* kv_norm, float eps, int rank, int rope, const float* cos_t, const float* sin_t,
                         int pos0, int act, const KvView& kv, int layer);
@@ -283,7 +288,8 @@ int bzk_moe_gemv(hipStream_t s, const MoeGemvArgs& g, int wdt, int n_slots, cons
 int bzk_mla_attn(hipStream_t s, const MlaArgs& a, int max_len);
 int bzk_moe_router(hipStream_t s, const Pro& pro, const void* wr, int wdt, int E, int top_k, int n_shared, float routed_scale, int norm_topk,
                    float* xn_out, int* sel, float* wsel, float* lg_glob, unsigned* counter);
-int bzk_moe_combine(hipStream_t s, long long* acc, const float* wsel, int top_k, int has_shared, int H, int act, float* out);
+int bzk_moe_combine(hipStream_t s, long long* acc, const float* wsel, int top_k, int has_shared, int H, int act, float* out, long long* zero_buf = nullptr, int zero_n = 0);
+bool bzk_moe_rows2_ok(int wdt, int K);   // the balanced role kernel takes the grouped expert GEMVs (16-bit weights)
 
 // batched prefill for dense 16-bit models (bz_prefill.hip): MFMA GEMM + row-wise norm / RoPE + KV append / causal attention / SiLU*up
 int bzk_gemm_nt(hipStream_t s, int dt, const void* x16, const void* w, const float* bias, int S, int N, int K, int act, float* y);

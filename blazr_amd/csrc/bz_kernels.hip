@@ -2139,28 +2139,35 @@ __global__ void k_conv_shift(ConvShift c, int act) {
   if (i < c.n) conv_shift_one(c, i, act);
 }
 
+// MoE form (slots.n > 1): the same launch covers the selected experts' matrices -- slot s multiplies W[sel[s]] ([N, K] each, expert_stride elements apart) with
+// ITS input row (src_stride elements apart; 0: one shared row) into ITS accumulator row.  A segment is then a (chunk, slot) pair, seg = kc n_slots + slot,
+// units are ordered (segment, row group), and a workgroup's range still lies in at most two segments (nb >= n_slots K / 512).
 template <int WDT, int MODE, bool FIX>
 __global__ __launch_bounds__(768) void k_gemv_rows2(const void* __restrict__ W, const float* __restrict__ bias, int N, int K, Pro pro,
-                                                    long long* __restrict__ acc, long long* zero_buf, int zero_n, ConvShift shift) {
-  __shared__ __attribute__((aligned(16))) float xs[1024];   // x[k0, k0 + 1024): the (at most) two chunks of this workgroup
+                                                    long long* __restrict__ acc, long long* zero_buf, int zero_n, ConvShift shift, MoeSlots slots) {
+  __shared__ __attribute__((aligned(16))) float xs[1024];   // x of the (at most) two segments of this workgroup, 512 each
   __shared__ double dred[4];
   __shared__ float grs[4][8];
   __shared__ unsigned cnt[2];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int NRG = (N + 3) >> 2, KCall = (K + 511) >> 9;
-  const long long U = (long long)NRG * KCall;
+  const int NRG = (N + 3) >> 2, KCall = (K + 511) >> 9, NSL = slots.n;
+  const int nseg = KCall * NSL;
+  const long long U = (long long)NRG * nseg;
   const int u0 = (int)(U * blockIdx.x / gridDim.x), u1 = (int)(U * (blockIdx.x + 1) / gridDim.x);
-  const int kcA = u0 / NRG;
-  const int k0 = kcA * 512;                       // first k of the slice
-  const int ub = (kcA + 1) * NRG;                 // first unit of the second chunk
+  const int segA = u0 / NRG, segB = min(segA + 1, nseg - 1);
+  const int kcA = segA / NSL, slA = segA - kcA * NSL, kcB = segB / NSL, slB = segB - kcB * NSL;
+  const int k0 = kcA * 512;                       // first k of the slice (dense form: segment B is the next chunk)
+  const int ub = (segA + 1) * NRG;                // first unit of the second segment
   const int act = pro.act;
   if (tid == 0) { cnt[0] = 0; cnt[1] = 0; }
   if (wave < 4) {
-    // ---- row waves: x[k0, k0 + 1024) -> LDS -------------------------------------------------------------
-    const int sk = k0 + tid * 4;                   // this thread's four slice elements
+    // ---- row waves: x of segments A | B -> LDS ------------------------------------------------------------
+    const int hb = tid >> 7;                                      // this thread's segment (0: A, 1: B) and its four elements there
+    const int sk = (hb ? kcB : kcA) * 512 + (tid & 127) * 4;
     const int skc = min(sk, K - 4);                // clamped for addressing (K % 8 == 0)
-    const bool son = sk < K;
+    const bool son = sk < K && (hb == 0 || segA + 1 < nseg);
+    const size_t soff = (size_t)(hb ? slB : slA) * (size_t)slots.src_stride;   // this slot's input row
     if (MODE == PRO_NORM) {
       const int H = pro.H;
       const bool hasprev = pro.src.p != nullptr;
@@ -2232,8 +2239,8 @@ __global__ __launch_bounds__(768) void k_gemv_rows2(const void* __restrict__ W, 
       typename SrcRaw<FIX>::T a[4], b[4];
 #pragma unroll
       for (int e = 0; e < 4; e++) {
-        a[e] = src_raw<FIX>(pro.src.p, skc + e);
-        if (MODE == PRO_SILU) b[e] = src_raw<FIX>(pro.src.p, pro.H + skc + e);
+        a[e] = src_raw<FIX>(pro.src.p, soff + skc + e);
+        if (MODE == PRO_SILU) b[e] = src_raw<FIX>(pro.src.p, soff + pro.H + skc + e);
       }
       __builtin_amdgcn_sched_barrier(0);
       __syncthreads();
@@ -2256,13 +2263,15 @@ __global__ __launch_bounds__(768) void k_gemv_rows2(const void* __restrict__ W, 
   const int tw = wave - 4;
   const int ua = u0 + (int)((long long)(u1 - u0) * tw / 8), ue = u0 + (int)((long long)(u1 - u0) * (tw + 1) / 8);
   struct Stage { RowPiece<WDT> p[4]; };
+  const size_t eoffA = slots.sel ? (size_t)slots.sel[slA] * (size_t)slots.expert_stride : 0, eoffB = slots.sel ? (size_t)slots.sel[slB] * (size_t)slots.expert_stride : 0;
   auto issue = [&](Stage& S, int u) {
-    const int kc = kcA + (u >= ub ? 1 : 0);
-    const int rg = u - kc * NRG;
-    const int k = kc * 512 + lane * 8;
+    const bool second = u >= ub;
+    const int rg = u - (second ? ub : ub - NRG);
+    const int k = (second ? kcB : kcA) * 512 + lane * 8;
     const int ko = k < K ? k : 0;                 // x is 0 beyond K
+    const size_t eo = second ? eoffB : eoffA;
 #pragma unroll
-    for (int rr = 0; rr < 4; rr++) S.p[rr] = piece_load<WDT>(W, (size_t)min(4 * rg + rr, N - 1) * K + ko);
+    for (int rr = 0; rr < 4; rr++) S.p[rr] = piece_load<WDT>(W, eo + (size_t)min(4 * rg + rr, N - 1) * K + ko);
   };
   __syncthreads();                                 // rendezvous: the row waves' loads are in the queue
   Stage st[4];
@@ -2287,11 +2296,11 @@ __global__ __launch_bounds__(768) void k_gemv_rows2(const void* __restrict__ W, 
         const float d2 = piece_dot<WDT>(st[q].p[2], xa, xb), d3 = piece_dot<WDT>(st[q].p[3], xa, xb);
         if (u + 4 < ue) issue(st[q], u + 4);
         float v = wave_sum4(d0, d1, d2, d3);
-        const int kc = kcA + (second ? 1 : 0);
-        const int row = 4 * (u - kc * NRG) + jrow;
+        const int row = 4 * (u - (second ? ub : ub - NRG)) + jrow;
         if ((lane & 15) == 0 && row < N) {
-          if (bias && kc == 0) v += bias[row];
-          atomicAdd((unsigned long long*)(acc + row), (unsigned long long)f2fix(v));
+          if (bias && (second ? kcB : kcA) == 0) v += bias[row];
+          long long* ap = acc + (size_t)min(second ? slB : slA, slots.acc_slots - 1) * (size_t)slots.acc_stride;
+          atomicAdd((unsigned long long*)(ap + row), (unsigned long long)f2fix(v));
         }
       }
     }
@@ -2534,7 +2543,7 @@ int bzk_gemv(hipStream_t s, const LinearDev& L, const Pro& pro, const GemvOut& o
     nb = (int)std::max<long long>(std::min<long long>(nb, U), KC);
     const char* lbl = pro.mode == PRO_NORM ? "gemv_rows2<norm>" : pro.mode == PRO_GATED2 ? "gemv_rows2<gated>" : pro.mode == PRO_SILU ? "gemv_rows2<silu>" : "gemv_rows2";
 #define LAUNCH_R2(DT, MODE, FIX) BZ_LAUNCH(lbl, L.algo_bytes, (k_gemv_rows2<DT, MODE, FIX>), dim3(nb), dim3(768), 0, s, (const void*)L.w, L.bias, L.N, L.K, pro, \
-    out.acc, out.zero_buf, out.zero_n, out.shift)
+    out.acc, out.zero_buf, out.zero_n, out.shift, MoeSlots{nullptr, 0, 1, 0, 0, 1})
 #define LAUNCH_R2_F(DT, MODE) do { if (pro.src.fix) LAUNCH_R2(DT, MODE, true); else LAUNCH_R2(DT, MODE, false); } while (0)
 #define LAUNCH_R2_M(DT) do { if (pro.mode == PRO_NORM) LAUNCH_R2_F(DT, PRO_NORM); else if (pro.mode == PRO_SILU) LAUNCH_R2_F(DT, PRO_SILU); \
     else if (pro.mode == PRO_GATED2) LAUNCH_R2(DT, PRO_GATED2, false); else LAUNCH_R2_F(DT, PRO_PLAIN); } while (0)
@@ -4171,7 +4180,11 @@ template <int NW> __device__ __forceinline__ float block_sum_nw(float v, float* 
   __syncthreads();
   return t;
 }
-template <int NCH, int DT, int NW, int BATCH>   // NCH: 512-column chunks of the latent, 1 (rank <= 512) or 2 (rank <= 1024); DT: dtype of kv_b and of the cache; BATCH: prompt rows (grid.y = token)
+// SPLIT (decode): grid.y = context slice.  Sixteen one-per-head workgroups each walked the whole cache twice (40 us per layer at 650 positions, 16 CUs
+// busy): slice s of head h now takes positions [s ts, (s+1) ts) (the last slice also the current token), runs the same q absorption, scores and
+// softmax over ITS positions, and leaves (unnormalised latent sum, local max, local sum) in the workspace; k_mla_merge rescales and sums the
+// slices in slice order, normalises once, rounds, and applies Wuv.
+template <int NCH, int DT, int NW, int BATCH, int SPLIT = 0>   // NCH: 512-column chunks of the latent, 1 (rank <= 512) or 2 (rank <= 1024); DT: dtype of kv_b and of the cache; BATCH: prompt rows (grid.y = token)
 __global__ __launch_bounds__(NW * 64) void k_mla_attn(MlaArgs a) {
   constexpr int NTH = NW * 64;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -4182,6 +4195,10 @@ __global__ __launch_bounds__(NW * 64) void k_mla_attn(MlaArgs a) {
   const int tok = BATCH ? blockIdx.y : 0;
   const int pos = BATCH ? a.pos0 + tok : a.pos[0], len = pos + 1;
   const int nc = BATCH ? len : pos;                 // positions read from the cache (the batched form finds the token's own row there too)
+  const int ts = SPLIT ? (nc + a.nsplit - 1) / a.nsplit : nc;                      // cached positions per slice
+  const int tlo = SPLIT ? min((int)blockIdx.y * ts, nc) : 0, thi = SPLIT ? min(tlo + ts, nc) : nc;
+  const bool own_cur = !BATCH && (!SPLIT || (int)blockIdx.y == a.nsplit - 1);      // the slice that holds the current token
+  const int nloc = thi - tlo + (own_cur ? 1 : 0);   // scores of this workgroup: sc[t - tlo], the current token last
   const int QH = DN + DR, qoff = hd * QH, coff = a.n_heads * QH;
   const float* qrow = BATCH ? (const float*)a.qkv.p + (size_t)tok * a.q_stride : nullptr;
   auto qsrc = [&](int i) -> float { return BATCH ? qrow[i] : vsrc_get(a.qkv, i, a.act); };
@@ -4227,7 +4244,7 @@ __global__ __launch_bounds__(NW * 64) void k_mla_attn(MlaArgs a) {
   }
   for (int d = tid; d < DN; d += NTH) qn[d] = qsrc(qoff + d);
   __syncthreads();
-  if (!BATCH && hd == 0) {
+  if (!BATCH && hd == 0 && (!SPLIT || blockIdx.y == 0)) {
     size_t wo;
     if (a.kv.paged) { const int slot = a.kv.slot ? a.kv.slot[0] : (a.kv.block_table[pos / a.kv.bs] * a.kv.bs + pos % a.kv.bs); wo = rowbase + (size_t)slot * Wd; }
     else wo = rowbase + (size_t)pos * Wd;
@@ -4276,11 +4293,13 @@ __global__ __launch_bounds__(NW * 64) void k_mla_attn(MlaArgs a) {
   for (int c = 0; c < NCH; c++)
 #pragma unroll
     for (int e = 0; e < 8; e++) qa[c][e] = con[c] ? qabs[colc[c] + e] : 0.f;
-  for (int t0 = wave; t0 < nc; t0 += NW * TIF) {
-    float cv[TIF][NCH][8], kp[TIF];
+  float cv[TIF][NCH][8];                              // (kept for the latent sum when the slice is a single batch of NW * TIF positions)
+  const bool single = SPLIT && thi - tlo <= NW * TIF;
+  for (int t0 = tlo + wave; t0 < thi; t0 += NW * TIF) {
+    float kp[TIF];
 #pragma unroll
     for (int u = 0; u < TIF; u++) {
-      const size_t ro = rowoff(min(t0 + NW * u, nc - 1));
+      const size_t ro = rowoff(min(t0 + NW * u, thi - 1));
 #pragma unroll
       for (int c = 0; c < NCH; c++) ld8t<DT>(a.kv.k, ro + colc[c], cv[u][c]);
       kp[u] = ld1t<DT>(a.kv.k, ro + R + min(lane, DR - 1));
@@ -4293,10 +4312,10 @@ __global__ __launch_bounds__(NW * 64) void k_mla_attn(MlaArgs a) {
 #pragma unroll
         for (int e = 0; e < 8; e++) dsum += qa[c][e] * cv[u][c][e];
       dsum = wave_sum(dsum);
-      if (lane == 0 && t0 + NW * u < nc) sc[t0 + NW * u] = dsum * a.scale;
+      if (lane == 0 && t0 + NW * u < thi) sc[t0 + NW * u - tlo] = dsum * a.scale;
     }
   }
-  if (!BATCH && wave == 0) {
+  if (own_cur && wave == 0) {
     float dsum = (lane < DR) ? qpl * kcur[lane] : 0.f;
 #pragma unroll
     for (int c = 0; c < NCH; c++)
@@ -4304,18 +4323,20 @@ __global__ __launch_bounds__(NW * 64) void k_mla_attn(MlaArgs a) {
 #pragma unroll
         for (int e = 0; e < 8; e++) dsum += qa[c][e] * ccur[colc[c] + e];
     dsum = wave_sum(dsum);
-    if (lane == 0) sc[pos] = dsum * a.scale;
+    if (lane == 0) sc[thi - tlo] = dsum * a.scale;
   }
   // first rows of Wuv for the output phase: in flight during the softmax and the latent sum
   const int v0 = wave * (DV / NW), v1 = v0 + DV / NW;
+  if (!SPLIT) {
 #pragma unroll
-  for (int u = 0; u < RIF; u++)
+    for (int u = 0; u < RIF; u++)
 #pragma unroll
-    for (int c = 0; c < NCH; c++) ld8t<DT>(a.wkvb, (wrow0 + DN + (size_t)min(v0 + u, v1 - 1)) * R + colc[c], w0[u][c]);
+      for (int c = 0; c < NCH; c++) ld8t<DT>(a.wkvb, (wrow0 + DN + (size_t)min(v0 + u, v1 - 1)) * R + colc[c], w0[u][c]);
+  }
   __builtin_amdgcn_sched_barrier(0);
   __syncthreads();
   float mx = -INFINITY;
-  for (int t = tid; t < len; t += NTH) mx = fmaxf(mx, sc[t]);
+  for (int t = tid; t < nloc; t += NTH) mx = fmaxf(mx, sc[t]);
   mx = wave_max(mx);
   if (lane == 0) red[wave] = mx;
   __syncthreads();
@@ -4324,7 +4345,7 @@ __global__ __launch_bounds__(NW * 64) void k_mla_attn(MlaArgs a) {
   for (int w = 1; w < NW; w++) mx = fmaxf(mx, red[w]);
   __syncthreads();
   float psum = 0.f;
-  for (int t = tid; t < len; t += NTH) { const float p = expf(sc[t] - mx); sc[t] = p; psum += p; }
+  for (int t = tid; t < nloc; t += NTH) { const float p = expf(sc[t] - mx); sc[t] = p; psum += p; }
   psum = block_sum_nw<NW>(psum, red);
   const float inv = 1.0f / psum;
   // ---- olat = R(sum_t p_t c_t * inv) ----
@@ -4334,25 +4355,26 @@ __global__ __launch_bounds__(NW * 64) void k_mla_attn(MlaArgs a) {
     for (int c = 0; c < NCH; c++)
 #pragma unroll
       for (int e = 0; e < 8; e++) acc[c][e] = 0.f;
-    for (int t0 = wave; t0 < nc; t0 += NW * TIF) {
-      float cv[TIF][NCH][8];
+    for (int t0 = tlo + wave; t0 < thi; t0 += NW * TIF) {
+      if (!single) {
 #pragma unroll
-      for (int u = 0; u < TIF; u++) {
-        const size_t ro = rowoff(min(t0 + NW * u, nc - 1));
+        for (int u = 0; u < TIF; u++) {
+          const size_t ro = rowoff(min(t0 + NW * u, thi - 1));
 #pragma unroll
-        for (int c = 0; c < NCH; c++) ld8t<DT>(a.kv.k, ro + colc[c], cv[u][c]);
+          for (int c = 0; c < NCH; c++) ld8t<DT>(a.kv.k, ro + colc[c], cv[u][c]);
+        }
       }
 #pragma unroll
       for (int u = 0; u < TIF; u++) {
-        const float p = (t0 + NW * u < nc) ? sc[t0 + NW * u] : 0.f;
+        const float p = (t0 + NW * u < thi) ? sc[t0 + NW * u - tlo] : 0.f;
 #pragma unroll
         for (int c = 0; c < NCH; c++)
 #pragma unroll
           for (int e = 0; e < 8; e++) acc[c][e] += p * cv[u][c][e];
       }
     }
-    if (!BATCH && wave == (pos % NW)) {       // the current token, in the wave that would own it in token order
-      const float p = sc[pos];
+    if (own_cur && wave == ((thi - tlo) % NW)) {       // the current token, in the wave that would own it in token order
+      const float p = sc[thi - tlo];
 #pragma unroll
       for (int c = 0; c < NCH; c++)
         if (con[c])
@@ -4366,6 +4388,18 @@ __global__ __launch_bounds__(NW * 64) void k_mla_attn(MlaArgs a) {
         for (int e = 0; e < 8; e++) part[wave * R + colc[c] + e] = acc[c][e];
   }
   __syncthreads();
+  if (SPLIT) {
+    // this slice's share: sum_t exp(s_t - mx) c_t (unrounded), mx, sum_t exp(s_t - mx); an empty slice leaves (0, -inf, 0)
+    float* wsp = a.ws + ((size_t)hd * a.nsplit + blockIdx.y) * (R + 2);
+    for (int r = tid; r < R; r += NTH) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; w += 2) t += part[w * R + r] + part[(w + 1) * R + r];
+      wsp[r] = nloc > 0 ? t : 0.f;
+    }
+    if (tid == 0) { wsp[R] = nloc > 0 ? mx : -INFINITY; wsp[R + 1] = nloc > 0 ? psum : 0.f; }
+    return;
+  }
   for (int r = tid; r < R; r += NTH) {   // qabs now holds olat
     float t = 0.f;
 #pragma unroll
@@ -4398,12 +4432,91 @@ __global__ __launch_bounds__(NW * 64) void k_mla_attn(MlaArgs a) {
   }
 }
 
+// Merge of the context slices + Wuv.  grid = (n_heads, 4): workgroup (h, q) rebuilds olat_h = R(sum_s e^{m_s - M} part_s / sum_s e^{m_s - M} l_s) (slice
+// order) and computes rows [q DV/4, (q+1) DV/4) of out_h = R(Wuv_h olat_h), 8 weight rows per wave in flight.
+template <int NCH, int DT>
+__global__ __launch_bounds__(256) void k_mla_merge(MlaArgs a) {
+  __shared__ float olat[1024];
+  __shared__ float wgt[64];
+  const int R = a.rank, DN = a.nope, DV = a.vdim, NSP = a.nsplit;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hd = blockIdx.x;
+  const int rows = DV / 4, v0 = blockIdx.y * rows + wave * (rows / 4), v1 = v0 + rows / 4;
+  const size_t wrow0 = (size_t)hd * (DN + DV);
+  bool con[NCH]; int colc[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; c++) { const int col = c * 512 + lane * 8; con[c] = col < R; colc[c] = con[c] ? col : 0; }
+  constexpr int RIF = 8 / NCH;
+  float w0[RIF][NCH][8];
+#pragma unroll
+  for (int u = 0; u < RIF; u++)
+#pragma unroll
+    for (int c = 0; c < NCH; c++) ld8t<DT>(a.wkvb, (wrow0 + DN + (size_t)min(v0 + u, v1 - 1)) * R + colc[c], w0[u][c]);
+  __builtin_amdgcn_sched_barrier(0);
+  const float* wsp = a.ws + (size_t)hd * NSP * (R + 2);
+  {
+    // slice weights e^{m_s - M} and 1 / L: lane s holds slice s (NSP <= 62), every wave computes the same values (fixed reduction trees)
+    const int sl = min(lane, NSP - 1);
+    const float ms = wsp[(size_t)sl * (R + 2) + R], ls = wsp[(size_t)sl * (R + 2) + R + 1];
+    const bool on = lane < NSP && ls > 0.f;
+    const float M = wave_max(on ? ms : -INFINITY);
+    const float wv = on ? expf(ms - M) : 0.f;
+    const float L = wave_sum(wv * ls);
+    if (wave == 0) { wgt[lane] = wv; if (lane == 63) wgt[63] = 1.0f / L; }
+  }
+  __syncthreads();
+  const float inv = wgt[63];
+  for (int r = tid; r < R; r += 256) {
+    float t = 0.f;
+    for (int s0 = 0; s0 < NSP; s0 += 8) {        // eight slices' loads in flight (clamped index, zero weight beyond the last slice)
+      float pv[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) pv[j] = wsp[(size_t)min(s0 + j, NSP - 1) * (R + 2) + r];
+#pragma unroll
+      for (int j = 0; j < 8; j++) t += (s0 + j < NSP ? wgt[s0 + j] : 0.f) * pv[j];
+    }
+    olat[r] = round_act(t * inv, a.act);
+  }
+  __syncthreads();
+  float qa[NCH][8];
+#pragma unroll
+  for (int c = 0; c < NCH; c++)
+#pragma unroll
+    for (int e = 0; e < 8; e++) qa[c][e] = con[c] ? olat[colc[c] + e] : 0.f;
+  for (int d = v0; d < v1; d += RIF) {
+    if (d > v0) {
+#pragma unroll
+      for (int u = 0; u < RIF; u++)
+#pragma unroll
+        for (int c = 0; c < NCH; c++) ld8t<DT>(a.wkvb, (wrow0 + DN + (size_t)min(d + u, v1 - 1)) * R + colc[c], w0[u][c]);
+    }
+#pragma unroll
+    for (int u = 0; u < RIF; u++) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int c = 0; c < NCH; c++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) sacc += w0[u][c][e] * qa[c][e];
+      sacc = wave_sum(sacc);
+      if (lane == 0 && d + u < v1) a.out[hd * DV + d + u] = round_act(sacc, a.act);
+    }
+  }
+}
+
+static bool mla_split_on(const MlaArgs& a) {
+  static const bool off = getenv("BZ_NO_MLA_SPLIT") != nullptr;
+  return !off && a.batch == 0 && a.ws != nullptr && a.nsplit > 1 && a.nsplit <= 62 && a.vdim % 16 == 0 && a.nope % 16 == 0;
+}
+int bzk_mla_nsplit(int n_heads) { return std::max(1, std::min(32, 256 / std::max(n_heads, 1))); }
+
 static int mla_waves(const MlaArgs& a) {
   // decode: one workgroup per head, 16 waves hide each other's dependent chains.  Prompt rows: thousands of (head, token) workgroups -- four waves
   // each, so that a CU runs several of these latency chains at once (16-wave workgroups ran one per CU: 621 us per layer at 512 tokens)
   return (a.batch == 0 && a.nope % 16 == 0 && a.vdim % 16 == 0) ? 16 : 4;
 }
-size_t bzk_mla_smem(const MlaArgs& a, int max_len) { return (size_t)(a.rank * (2 + mla_waves(a)) + a.rope * 2 + a.nope + 16 + max_len) * 4 + 64; }
+size_t bzk_mla_smem(const MlaArgs& a, int max_len) {
+  const int nsc = mla_split_on(a) ? (max_len + a.nsplit - 1) / a.nsplit + 1 : max_len;   // scores held by one workgroup
+  return (size_t)(a.rank * (2 + mla_waves(a)) + a.rope * 2 + a.nope + 16 + nsc) * 4 + 64;
+}
 
 int bzk_mla_attn(hipStream_t s, const MlaArgs& a, int max_len) {
   if (a.rank % 8 || a.rank > 1024 || a.rope > 64 || (a.rope & 1) || a.nope % 4 || a.vdim % 4 || a.kv.n_kv != 1 || a.kv.hd != a.rank + a.rope)
@@ -4417,13 +4530,19 @@ int bzk_mla_attn(hipStream_t s, const MlaArgs& a, int max_len) {
     static bool attr_done = false; \
     if (!attr_done) { BZ_HIP(hipFuncSetAttribute((const void*)k_mla_attn<NCH, DT, W_, B_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_done = true; } \
     BZ_LAUNCH(B_ ? "mla_attn<rows>" : "mla_attn", bytes, (k_mla_attn<NCH, DT, W_, B_>), dim3(a.n_heads, B_ ? a.batch : 1), dim3(W_ * 64), smem, s, a); } while (0)
-#define LAUNCH_MLA_W(NCH, DT, W_) do { if (a.batch > 0) LAUNCH_MLA_WB(NCH, DT, W_, 1); else LAUNCH_MLA_WB(NCH, DT, W_, 0); } while (0)
+#define LAUNCH_MLA_SP(NCH, DT) do { \
+    static bool attr_done = false; \
+    if (!attr_done) { BZ_HIP(hipFuncSetAttribute((const void*)k_mla_attn<NCH, DT, 16, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_done = true; } \
+    BZ_LAUNCH("mla_attn<split>", bytes, (k_mla_attn<NCH, DT, 16, 0, 1>), dim3(a.n_heads, a.nsplit), dim3(1024), smem, s, a); \
+    BZ_LAUNCH("mla_merge", bytes * a.vdim / (a.nope + a.vdim), (k_mla_merge<NCH, DT>), dim3(a.n_heads, 4), dim3(256), 0, s, a); } while (0)
+#define LAUNCH_MLA_W(NCH, DT, W_) do { if (a.batch > 0) LAUNCH_MLA_WB(NCH, DT, W_, 1); else if (W_ == 16 && mla_split_on(a)) LAUNCH_MLA_SP(NCH, DT); else LAUNCH_MLA_WB(NCH, DT, W_, 0); } while (0)
 #define LAUNCH_MLA(NCH, DT) do { if (NWV == 16) LAUNCH_MLA_W(NCH, DT, 16); else LAUNCH_MLA_W(NCH, DT, 4); } while (0)
 #define LAUNCH_MLA_DT(DT) do { if (a.rank <= 512) LAUNCH_MLA(1, DT); else LAUNCH_MLA(2, DT); } while (0)
   if (a.wdt == BZ_F16) LAUNCH_MLA_DT(BZ_F16); else if (a.wdt == BZ_BF16) LAUNCH_MLA_DT(BZ_BF16); else LAUNCH_MLA_DT(BZ_F32);
 #undef LAUNCH_MLA_DT
 #undef LAUNCH_MLA
 #undef LAUNCH_MLA_W
+#undef LAUNCH_MLA_SP
 #undef LAUNCH_MLA_WB
   BZ_HIP(hipGetLastError());
   return BZ_OK;
@@ -4543,7 +4662,29 @@ int bzk_moe_router(hipStream_t s, const Pro& pro, const void* wr, int wdt, int E
   return BZ_OK;
 }
 
+bool bzk_moe_rows2_ok(int wdt, int K) { return rows2_enabled() && (wdt == BZ_F16 || wdt == BZ_BF16) && K % 8 == 0 && K <= 131072; }
+
 int bzk_moe_gemv(hipStream_t s, const MoeGemvArgs& g, int wdt, int n_slots, const Pro& pro, int act, bool split, double bytes) {
+  if (split && g.acc && bzk_moe_rows2_ok(wdt, g.K) && (pro.mode == PRO_PLAIN || pro.mode == PRO_SILU)) {
+    // the balanced role kernel over all slots at once (fixed-point accumulators: slot s -> acc[min(s, acc_slots - 1)])
+    const int KC = (g.K + 511) / 512;
+    const long long U = (long long)((g.N + 3) / 4) * KC * n_slots;
+    static const int forced = getenv("BZ_ROWS2_WGS") ? atoi(getenv("BZ_ROWS2_WGS")) : 0;
+    int nb = forced > 0 ? forced : 256;
+    nb = (int)std::max<long long>(std::min<long long>(nb, U), (long long)KC * n_slots);
+    const MoeSlots ms{g.sel, g.expert_stride, n_slots, g.src_stride, g.acc_stride, g.acc_slots};
+    const char* lbl = pro.mode == PRO_SILU ? "moe_rows2<down>" : "moe_rows2<gate_up>";
+#define LAUNCH_MR2(DT, MODE, FIX) BZ_LAUNCH(lbl, bytes, (k_gemv_rows2<DT, MODE, FIX>), dim3(nb), dim3(768), 0, s, g.w, (const float*)nullptr, g.N, g.K, pro, g.acc, \
+    (long long*)nullptr, 0, ConvShift{}, ms)
+#define LAUNCH_MR2_F(DT, MODE) do { if (pro.src.fix) LAUNCH_MR2(DT, MODE, true); else LAUNCH_MR2(DT, MODE, false); } while (0)
+#define LAUNCH_MR2_M(DT) do { if (pro.mode == PRO_SILU) LAUNCH_MR2_F(DT, PRO_SILU); else LAUNCH_MR2_F(DT, PRO_PLAIN); } while (0)
+    if (wdt == BZ_F16) LAUNCH_MR2_M(BZ_F16); else LAUNCH_MR2_M(BZ_BF16);
+#undef LAUNCH_MR2_M
+#undef LAUNCH_MR2_F
+#undef LAUNCH_MR2
+    BZ_HIP(hipGetLastError());
+    return BZ_OK;
+  }
   const int KP = (g.K + 511) & ~511;
   const size_t smem = (size_t)KP * 4 + 64;
   if (g.K % 8 || smem > 160 * 1024) BZ_FAIL(BZ_E_UNSUPPORTED, "moe_gemv: K=%d unsupported", g.K);
@@ -4558,8 +4699,9 @@ int bzk_moe_gemv(hipStream_t s, const MoeGemvArgs& g, int wdt, int n_slots, cons
 }
 
 // routed = R(sum_k w_k * R(y_k)) (selection order, f32) ; out = R(routed + R(y_shared)) ; the accumulators are zeroed for the next layer
-__global__ void k_moe_combine(long long* acc, const float* wsel, int top_k, int has_shared, int H, int act, float* out) {
+__global__ void k_moe_combine(long long* acc, const float* wsel, int top_k, int has_shared, int H, int act, float* out, long long* zero_buf, int zero_n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (zero_buf) for (int j = i; j < zero_n; j += gridDim.x * blockDim.x) zero_buf[j] = 0;   // the gate / up accumulators of this layer (read by the down launch)
   if (i >= H) return;
   float r = 0.f;
   for (int k = 0; k < top_k; k++) {
@@ -4573,8 +4715,8 @@ __global__ void k_moe_combine(long long* acc, const float* wsel, int top_k, int 
   }
   out[i] = r;
 }
-int bzk_moe_combine(hipStream_t s, long long* acc, const float* wsel, int top_k, int has_shared, int H, int act, float* out) {
-  BZ_LAUNCH("moe_combine", 0.0, k_moe_combine, dim3((H + 255) / 256), dim3(256), 0, s, acc, wsel, top_k, has_shared, H, act, out);
+int bzk_moe_combine(hipStream_t s, long long* acc, const float* wsel, int top_k, int has_shared, int H, int act, float* out, long long* zero_buf, int zero_n) {
+  BZ_LAUNCH("moe_combine", 0.0, k_moe_combine, dim3((H + 255) / 256), dim3(256), 0, s, acc, wsel, top_k, has_shared, H, act, out, zero_buf, zero_n);
   BZ_HIP(hipGetLastError());
   return BZ_OK;
 }
