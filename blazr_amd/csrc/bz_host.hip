@@ -965,6 +965,7 @@ static int finalize_dsv2(bz_model* m) {
     } else {
       size_t rb = 0;
       BZ_TRY(take_dense(m, p + "mlp.gate.weight", E, H, &L.router, &L.router_dt, &rb));
+      ring_n = std::max(ring_n, E);   // the router logits pass through the ring (fixed point)
       auto it = m->raw.find(p + "mlp.experts.0.gate_proj.weight");
       if (it == m->raw.end()) BZ_FAIL(BZ_E_NOTFOUND, "finalize: layer %d has no expert tensors", l);
       L.e_dt = it->second.dtype;
@@ -1599,10 +1600,42 @@ static int dsv2_step(bz_model* m, const StepIO& io) {
       BZ_TRY(run_fused(m, L.down, ps, rs, &dn));
       prev = dn;
     } else {
-      BZ_TRY(bzk_moe_router(st, pf, L.router, L.router_dt, E, TK, NS, c.moe_routed_scale, c.moe_norm_topk, m->moe_xn, m->moe_sel, m->moe_w, m->moe_lg, m->moe_cnt));
-      cur ^= 1;
       const int slots = TK + NS;
       const size_t es = bz_dtype_size(L.e_dt);
+      static const bool no_fr = getenv("BZ_NO_MOE_ROUTE_FUSION") != nullptr;
+      if (!no_fr && bzk_moe_rows2_ok(L.e_dt, H) && bzk_moe_rows2_ok(L.e_dt, MI) && bzk_moe_rows2_ok(L.router_dt, H) && E <= 1024 && slots <= 128) {
+        // router logits = one more fixed-point GEMV of the ring (norm prologue: writes h'); the top-k runs in the prologue of the gate / up launch, which
+        // repeats the norm for its own x (the same inputs: h and the o_proj accumulator, both still in place)
+        LinearDev RL; RL.kind = LK_ROWS; RL.N = E; RL.K = H; RL.wdt = L.router_dt; RL.w = L.router; RL.sk = 2; RL.owned = false; RL.algo_bytes = (size_t)E * H * bz_dtype_size(L.router_dt);
+        FusedLinear RF; RF.parts.push_back(RL); RF.n_off.push_back(0); RF.N = E; RF.K = H; RF.fix_out = true;
+        VSrc lg;
+        BZ_TRY(run_fused(m, RF, pf, rs, &lg));
+        cur ^= 1;
+        Pro pg = pf; pg.h_out = nullptr;
+        MoeGemvArgs g1{};
+        g1.w = L.e_gu; g1.expert_stride = (long long)2 * MI * H; g1.sel = nullptr; g1.N = 2 * MI; g1.K = H; g1.src_stride = 0;
+        g1.acc = m->moe_gu_acc; g1.acc_stride = 2 * MI; g1.acc_slots = slots;
+        g1.route = RouteArgs{(const long long*)lg.p, E, TK, NS, c.moe_routed_scale, c.moe_norm_topk, m->moe_sel, m->moe_w};
+        static const bool moe_stamps = getenv("BZ_MOE_STAMPS") != nullptr;   // diagnostic: phase stamps of the route + gate/up launch (layer 2, printed once)
+        static long long* stamp_buf = nullptr; static int stamp_prints = 0;
+        if (moe_stamps && l == 2 && stamp_prints < 3 && !tl_capture_stream) { if (!stamp_buf) { hipMalloc(&stamp_buf, 64); } hipMemsetAsync(stamp_buf, 0, 64, st); pg.stamps = stamp_buf; }
+        BZ_TRY(bzk_moe_gemv(st, g1, L.e_dt, slots, pg, act, true, (double)slots * 2 * MI * H * es));
+        if (pg.stamps) {
+          long long hs[8]; hipStreamSynchronize(st); hipMemcpy(hs, stamp_buf, 64, hipMemcpyDeviceToHost); stamp_prints++;
+          fprintf(stderr, "[bz] route+gate/up stamps (us since entry): rendezvous %.2f, x published %.2f, top-k done %.2f | tile wave: range 0 done %.2f, ids seen %.2f, end %.2f\n",
+                  (hs[1] - hs[0]) / 100.0, (hs[2] - hs[0]) / 100.0, (hs[3] - hs[0]) / 100.0, (hs[4] - hs[0]) / 100.0, (hs[5] - hs[0]) / 100.0, (hs[6] - hs[0]) / 100.0);
+        }
+        MoeGemvArgs g2{};
+        g2.w = L.e_dn; g2.expert_stride = (long long)H * MI; g2.sel = m->moe_sel; g2.N = H; g2.K = MI; g2.src_stride = 2 * MI;
+        g2.acc = m->moe_acc; g2.acc_stride = H; g2.acc_slots = TK + 1;
+        Pro p2{}; p2.mode = PRO_SILU; p2.src = VSrc{m->moe_gu_acc, 1}; p2.H = MI; p2.act = act;
+        BZ_TRY(bzk_moe_gemv(st, g2, L.e_dt, slots, p2, act, true, (double)slots * H * MI * es));
+        BZ_TRY(bzk_moe_combine(st, m->moe_acc, m->moe_w, TK, NS > 0, H, act, m->moe_out, m->moe_gu_acc, slots * 2 * MI));
+        prev = VSrc{m->moe_out, 0};
+        continue;
+      }
+      BZ_TRY(bzk_moe_router(st, pf, L.router, L.router_dt, E, TK, NS, c.moe_routed_scale, c.moe_norm_topk, m->moe_xn, m->moe_sel, m->moe_w, m->moe_lg, m->moe_cnt));
+      cur ^= 1;
       // gate / up of the selected + shared experts in ONE launch, down in one more.  Balanced role kernel (fixed-point accumulators both times) when the
       // expert weights are 16-bit; else the 16-row workgroup form with a direct f32 gate / up
       const bool r2 = bzk_moe_rows2_ok(L.e_dt, H) && bzk_moe_rows2_ok(L.e_dt, MI);

@@ -168,6 +168,9 @@ struct ConvShift { float* cs; VSrc src; int x_off, ch0, n, kc; };
 // MoE form of k_gemv_rows2: n slots, slot s -> expert sel[s] (sel == nullptr: the one dense matrix), its input row and its accumulator row
 struct MoeSlots { const int* sel; long long expert_stride; int n; long long src_stride; long long acc_stride; int acc_slots; };
 
+// in-launch MoE routing (k_gemv_rows2<NORM, ROUTE>): lg = the router logits as the fixed-point output of the previous launch
+struct RouteArgs { const long long* lg; int E, top_k, n_shared; float routed_scale; int norm_topk; int* sel_out; float* w_out; };
+
 struct GemvOut {
   long long* acc;        // Q4G/K-quants: fixed-point accumulator [N] (must be zero on entry)
   float* direct;         // ROWS: direct store [N] (rounded to act)
@@ -283,6 +286,7 @@ struct MoeGemvArgs {
   long long src_stride;                         // prologue source: floats between slots (0: shared input)
   float* out; long long out_stride;             // direct output (SPLIT == false)
   long long* acc; long long acc_stride; int acc_slots;   // SPLIT: slot s accumulates into acc[min(s, acc_slots-1)]
+  RouteArgs route;                                       // gate / up with in-launch routing (route.lg != nullptr; prologue mode NORM)
 };
 int bzk_moe_gemv(hipStream_t s, const MoeGemvArgs& g, int wdt, int n_slots, const Pro& pro, int act, bool split, double bytes);
 int bzk_mla_attn(hipStream_t s, const MlaArgs& a, int max_len);

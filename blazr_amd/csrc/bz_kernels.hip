@@ -2142,54 +2142,101 @@ __global__ void k_conv_shift(ConvShift c, int act) {
 // MoE form (slots.n > 1): the same launch covers the selected experts' matrices -- slot s multiplies W[sel[s]] ([N, K] each, expert_stride elements apart) with
 // ITS input row (src_stride elements apart; 0: one shared row) into ITS accumulator row.  A segment is then a (chunk, slot) pair, seg = kc n_slots + slot,
 // units are ordered (segment, row group), and a workgroup's range still lies in at most two segments (nb >= n_slots K / 512).
-template <int WDT, int MODE, bool FIX>
-__global__ __launch_bounds__(768) void k_gemv_rows2(const void* __restrict__ W, const float* __restrict__ bias, int N, int K, Pro pro,
-                                                    long long* __restrict__ acc, long long* zero_buf, int zero_n, ConvShift shift, MoeSlots slots) {
-  __shared__ __attribute__((aligned(16))) float xs[1024];   // x of the (at most) two segments of this workgroup, 512 each
+// ROUTE (DeepSeek MoE gate / up): the router's logits arrive as the fixed-point output of the previous launch (a plain k_gemv_rows2<norm> over the
+// router matrix); row wave 0 turns them into the top-k selection (moe_softmax_topk) while the tile waves wait for the expert ids, workgroup 0
+// publishes selection and weights for the down / combine launches.  One 5 us GEMV + ~3 us in front of this stream instead of a 14 us router launch
+// whose last workgroup ran the top-k behind a device-scope counter.
+__device__ void moe_softmax_topk(const float* lg, int E, int top_k, int n_shared, float routed_scale, int norm_topk, int* sel, float* wsel, int lane);
+template <int WDT, int MODE, bool FIX, int ROUTE = 0>
+__global__ __launch_bounds__(ROUTE ? 832 : 768) void k_gemv_rows2(const void* __restrict__ W, const float* __restrict__ bias, int N, int K, Pro pro,
+                                                    long long* __restrict__ acc, long long* zero_buf, int zero_n, ConvShift shift, MoeSlots slots, RouteArgs route) {
+  // NR unit ranges per workgroup.  ROUTE: range 0 = the shared experts' slots [top_k, top_k + n_shared) (ids known: the stream starts at entry),
+  // range 1 = the routed slots [0, top_k) (ids from the top-k, a few us later); otherwise one range over all slots.
+  constexpr int NR = ROUTE ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) float xs[NR * 1024];   // x of the (at most) two segments of each range, 512 each
   __shared__ double dred[4];
   __shared__ float grs[4][8];
-  __shared__ unsigned cnt[2];
+  __shared__ unsigned cnt[4];
+  __shared__ float lgs[ROUTE ? 1024 : 1];
+  __shared__ int ssel[ROUTE ? 128 : 1];
+  __shared__ float swgt[ROUTE ? 128 : 1];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int NRG = (N + 3) >> 2, KCall = (K + 511) >> 9, NSL = slots.n;
-  const int nseg = KCall * NSL;
-  const long long U = (long long)NRG * nseg;
-  const int u0 = (int)(U * blockIdx.x / gridDim.x), u1 = (int)(U * (blockIdx.x + 1) / gridDim.x);
-  const int segA = u0 / NRG, segB = min(segA + 1, nseg - 1);
-  const int kcA = segA / NSL, slA = segA - kcA * NSL, kcB = segB / NSL, slB = segB - kcB * NSL;
-  const int k0 = kcA * 512;                       // first k of the slice (dense form: segment B is the next chunk)
-  const int ub = (segA + 1) * NRG;                // first unit of the second segment
+  const int NRG = (N + 3) >> 2, KCall = (K + 511) >> 9;
+  int u0[NR], u1[NR], ub[NR], kcA[NR], slA[NR], kcB[NR], slB[NR], sbase[NR];
+  bool hasB[NR];
+#pragma unroll
+  for (int r = 0; r < NR; r++) {
+    sbase[r] = ROUTE ? (r == 0 ? route.top_k : 0) : 0;
+    const int nsl = ROUTE ? (r == 0 ? route.n_shared : route.top_k) : slots.n;
+    const int nseg = KCall * nsl;
+    const long long U = (long long)NRG * nseg;
+    u0[r] = (int)(U * blockIdx.x / gridDim.x); u1[r] = (int)(U * (blockIdx.x + 1) / gridDim.x);
+    const int segA = u0[r] / NRG, segB = min(segA + 1, max(nseg - 1, 0));
+    hasB[r] = segA + 1 < nseg;
+    const int nd = max(nsl, 1);
+    kcA[r] = segA / nd; slA[r] = segA - kcA[r] * nd; kcB[r] = segB / nd; slB[r] = segB - kcB[r] * nd;
+    ub[r] = (segA + 1) * NRG;                      // first unit of the second segment
+  }
   const int act = pro.act;
-  if (tid == 0) { cnt[0] = 0; cnt[1] = 0; }
+  // diagnostic only (BZ_MOE_STAMPS): s_memrealtime (100 MHz) of workgroup 0 -- row wave 0: entry, rendezvous, x published, top-k done; tile wave 4: range 0 done, ids seen, end
+#define RSTAMP(i) do { if (ROUTE && pro.stamps && blockIdx.x == 0 && lane == 0) pro.stamps[i] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+  if (tid == 0) { cnt[0] = 0; cnt[1] = 0; cnt[2] = 0; cnt[3] = 0; }
+  if (wave == 0) RSTAMP(0);
+  if (ROUTE && wave == 12) {
+    // ---- the routing wave (13th): logits -> softmax + top-k -> expert ids for the tile waves' second range; nobody waits for it before that
+    __builtin_amdgcn_s_setprio(3);
+    for (int j = lane; j < route.E; j += 64) lgs[j] = fix2f(route.lg[j]);
+    __syncthreads();                               // (the rendezvous barrier: every wave passes it once)
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    moe_softmax_topk(lgs, route.E, route.top_k, route.n_shared, route.routed_scale, route.norm_topk, ssel, swgt, lane);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    if (lane == 0) atomicAdd(&cnt[2], 1u);
+    RSTAMP(3);
+    if (blockIdx.x == 0)
+      for (int j = lane; j < route.top_k + route.n_shared; j += 64) { route.sel_out[j] = ssel[j]; route.w_out[j] = swgt[j]; }
+    return;
+  }
   if (wave < 4) {
-    // ---- row waves: x of segments A | B -> LDS ------------------------------------------------------------
+    // ---- row waves: x of segments A | B (of every range) -> LDS --------------------------------------------
+    __builtin_amdgcn_s_setprio(3);                                // everybody waits for these four waves
     const int hb = tid >> 7;                                      // this thread's segment (0: A, 1: B) and its four elements there
-    const int sk = (hb ? kcB : kcA) * 512 + (tid & 127) * 4;
-    const int skc = min(sk, K - 4);                // clamped for addressing (K % 8 == 0)
-    const bool son = sk < K && (hb == 0 || segA + 1 < nseg);
-    const size_t soff = (size_t)(hb ? slB : slA) * (size_t)slots.src_stride;   // this slot's input row
+    int sk[NR], skc[NR]; bool son[NR];
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+      sk[r] = (hb ? kcB[r] : kcA[r]) * 512 + (tid & 127) * 4;
+      skc[r] = min(sk[r], K - 4);                  // clamped for addressing (K % 8 == 0)
+      son[r] = sk[r] < K && (hb == 0 || hasB[r]);
+    }
     if (MODE == PRO_NORM) {
       const int H = pro.H;
       const bool hasprev = pro.src.p != nullptr;
       const void* prevp = hasprev ? pro.src.p : (const void*)pro.h_in;
-      const float4 nw = *(const float4*)(pro.norm_w + skc);
+      float4 nw[NR];
+#pragma unroll
+      for (int r = 0; r < NR; r++) nw[r] = *(const float4*)(pro.norm_w + skc[r]);
       double ssd = 0.0;
       bool first = true;
       for (int base = 0; base < H; base += 4096) {
-        float4 ha[2], hb[2];
+        float4 ha[2], hb4[2];
         typename SrcRaw<FIX>::T pv[2][8];
 #pragma unroll
         for (int j = 0; j < 2; j++) {
           const int i0 = min(base + (j * 256 + tid) * 8, H - 8);
-          ha[j] = *(const float4*)(pro.h_in + i0); hb[j] = *(const float4*)(pro.h_in + i0 + 4);
+          ha[j] = *(const float4*)(pro.h_in + i0); hb4[j] = *(const float4*)(pro.h_in + i0 + 4);
 #pragma unroll
           for (int e = 0; e < 8; e++) pv[j][e] = src_raw<FIX>(prevp, (FIX || hasprev) ? i0 + e : 0);
         }
-        if (first) { __builtin_amdgcn_sched_barrier(0); __syncthreads(); first = false; }   // rendezvous: these loads are ahead of the weight stream
+        if (first) {
+          __builtin_amdgcn_sched_barrier(0);
+          __syncthreads();                         // rendezvous: these loads are ahead of the weight stream
+          first = false;
+          if (wave == 0) RSTAMP(1);
+        }
 #pragma unroll
         for (int j = 0; j < 2; j++) {
           const int i0 = base + (j * 256 + tid) * 8;
-          float v[8] = {ha[j].x, ha[j].y, ha[j].z, ha[j].w, hb[j].x, hb[j].y, hb[j].z, hb[j].w};
+          float v[8] = {ha[j].x, ha[j].y, ha[j].z, ha[j].w, hb4[j].x, hb4[j].y, hb4[j].z, hb4[j].w};
           if (hasprev) {
 #pragma unroll
             for (int e = 0; e < 8; e++) v[e] = round_act(v[e] + src_cvt<FIX>(pv[j][e], act), act);
@@ -2198,28 +2245,36 @@ __global__ __launch_bounds__(768) void k_gemv_rows2(const void* __restrict__ W, 
 #pragma unroll
             for (int e = 0; e < 8; e += 2) ssd += (double)(v[e] * v[e]) + (double)(v[e + 1] * v[e + 1]);
             if (blockIdx.x == 0 && pro.h_out) { *(float4*)(pro.h_out + i0) = make_float4(v[0], v[1], v[2], v[3]); *(float4*)(pro.h_out + i0 + 4) = make_float4(v[4], v[5], v[6], v[7]); }
-            if (i0 >= k0 && i0 < k0 + 1024) { *(float4*)(xs + (i0 - k0)) = make_float4(v[0], v[1], v[2], v[3]); *(float4*)(xs + (i0 - k0) + 4) = make_float4(v[4], v[5], v[6], v[7]); }
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+              float* xr = xs + r * 1024;
+              if ((i0 >> 9) == kcA[r]) { *(float4*)(xr + (i0 & 511)) = make_float4(v[0], v[1], v[2], v[3]); *(float4*)(xr + (i0 & 511) + 4) = make_float4(v[4], v[5], v[6], v[7]); }
+              if ((i0 >> 9) == kcB[r]) { *(float4*)(xr + 512 + (i0 & 511)) = make_float4(v[0], v[1], v[2], v[3]); *(float4*)(xr + 512 + (i0 & 511) + 4) = make_float4(v[4], v[5], v[6], v[7]); }
+            }
           }
         }
       }
       ssd = wave_sum_d(ssd);
       if (lane == 0) dred[wave] = ssd;
-      __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): the parked slice and the partial are in LDS
+      __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): the parked slices and the partial are in LDS
       if (lane == 0) atomicAdd(&cnt[0], 1u);
       lds_wait_count(&cnt[0], 4);
       const float ss = (float)((dred[0] + dred[1]) + (dred[2] + dred[3]));   // the rounded exact sum of squares (oracle: orc_rms_norm)
       const float rs = 1.0f / sqrtf(ss / (float)H + pro.eps);
-      float4 v = *(const float4*)(xs + tid * 4);
-      const float nwv[4] = {nw.x, nw.y, nw.z, nw.w};
-      float x[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-      for (int e = 0; e < 4; e++) x[e] = son ? round_act(nwv[e] * round_act(x[e] * rs, act), act) : 0.f;
-      *(float4*)(xs + tid * 4) = make_float4(x[0], x[1], x[2], x[3]);
+      for (int r = 0; r < NR; r++) {
+        float4 v = *(const float4*)(xs + r * 1024 + tid * 4);
+        const float nwv[4] = {nw[r].x, nw[r].y, nw[r].z, nw[r].w};
+        float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) x[e] = son[r] ? round_act(nwv[e] * round_act(x[e] * rs, act), act) : 0.f;
+        *(float4*)(xs + r * 1024 + tid * 4) = make_float4(x[0], x[1], x[2], x[3]);
+      }
     } else if (MODE == PRO_GATED2) {
       // gated RMSNorm with the gate and the per-head sums of squares already applied / reduced by the SSM kernel (see build_x_simple)
       const int G = pro.aux > 0 ? pro.aux : 1, gsz = pro.H / G, hpg = pro.aux2 / G;
-      const float4 vv = *(const float4*)((const float*)pro.src.p + skc);
-      const float4 nw = *(const float4*)(pro.norm_w + skc);
+      const float4 vv = *(const float4*)((const float*)pro.src.p + skc[0]);
+      const float4 nw = *(const float4*)(pro.norm_w + skc[0]);
       __builtin_amdgcn_sched_barrier(0);
       __syncthreads();
       for (int g = 0; g < G && g < 8; g++) {        // every row wave keeps its own copy of the (<= 8) group factors
@@ -2229,18 +2284,19 @@ __global__ __launch_bounds__(768) void k_gemv_rows2(const void* __restrict__ W, 
         if (lane == 0) grs[wave][g] = 1.0f / sqrtf((float)t / (float)gsz + pro.eps);
       }
       __builtin_amdgcn_s_waitcnt(0xc07f);
-      const float rs = grs[wave][min(skc / gsz, 7)];
+      const float rs = grs[wave][min(skc[0] / gsz, 7)];
       const float vs[4] = {vv.x, vv.y, vv.z, vv.w}, nwv[4] = {nw.x, nw.y, nw.z, nw.w};
       float x[4];
 #pragma unroll
-      for (int e = 0; e < 4; e++) x[e] = son ? round_act(nwv[e] * round_act(vs[e] * rs, act), act) : 0.f;
+      for (int e = 0; e < 4; e++) x[e] = son[0] ? round_act(nwv[e] * round_act(vs[e] * rs, act), act) : 0.f;
       *(float4*)(xs + tid * 4) = make_float4(x[0], x[1], x[2], x[3]);
     } else {
+      const size_t soff = (size_t)(hb ? slB[0] : slA[0]) * (size_t)slots.src_stride;   // this slot's input row
       typename SrcRaw<FIX>::T a[4], b[4];
 #pragma unroll
       for (int e = 0; e < 4; e++) {
-        a[e] = src_raw<FIX>(pro.src.p, soff + skc + e);
-        if (MODE == PRO_SILU) b[e] = src_raw<FIX>(pro.src.p, soff + pro.H + skc + e);
+        a[e] = src_raw<FIX>(pro.src.p, soff + skc[0] + e);
+        if (MODE == PRO_SILU) b[e] = src_raw<FIX>(pro.src.p, soff + pro.H + skc[0] + e);
       }
       __builtin_amdgcn_sched_barrier(0);
       __syncthreads();
@@ -2249,62 +2305,77 @@ __global__ __launch_bounds__(768) void k_gemv_rows2(const void* __restrict__ W, 
       for (int e = 0; e < 4; e++) {
         float v = src_cvt<FIX>(a[e], act);
         if (MODE == PRO_SILU) v = round_act(round_act(silu_f(v), act) * src_cvt<FIX>(b[e], act), act);
-        x[e] = son ? v : 0.f;
+        x[e] = son[0] ? v : 0.f;
       }
       *(float4*)(xs + tid * 4) = make_float4(x[0], x[1], x[2], x[3]);
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): this wave's part of x is in LDS
     if (lane == 0) atomicAdd(&cnt[1], 1u);
+    if (wave == 0) RSTAMP(2);
     if (shift.cs)                                  // the row waves are done: they take the side duty
       for (int i = blockIdx.x * 256 + tid; i < shift.n; i += gridDim.x * 256) conv_shift_one(shift, i, act);
     return;
   }
   // ---- tile waves ---------------------------------------------------------------------------------------
   const int tw = wave - 4;
-  const int ua = u0 + (int)((long long)(u1 - u0) * tw / 8), ue = u0 + (int)((long long)(u1 - u0) * (tw + 1) / 8);
   struct Stage { RowPiece<WDT> p[4]; };
-  const size_t eoffA = slots.sel ? (size_t)slots.sel[slA] * (size_t)slots.expert_stride : 0, eoffB = slots.sel ? (size_t)slots.sel[slB] * (size_t)slots.expert_stride : 0;
-  auto issue = [&](Stage& S, int u) {
-    const bool second = u >= ub;
-    const int rg = u - (second ? ub : ub - NRG);
-    const int k = (second ? kcB : kcA) * 512 + lane * 8;
-    const int ko = k < K ? k : 0;                 // x is 0 beyond K
-    const size_t eo = second ? eoffB : eoffA;
-#pragma unroll
-    for (int rr = 0; rr < 4; rr++) S.p[rr] = piece_load<WDT>(W, eo + (size_t)min(4 * rg + rr, N - 1) * K + ko);
-  };
-  __syncthreads();                                 // rendezvous: the row waves' loads are in the queue
-  Stage st[4];
-  if (ua < ue) {
-#pragma unroll
-    for (int q = 0; q < 4; q++) if (ua + q < ue) issue(st[q], ua + q);
-  }
-  if (zero_buf)                                   // the ring protocol's zeroing duty, by the 512 tile threads
-    for (int i = blockIdx.x * 512 + (tid - 256); i < zero_n; i += gridDim.x * 512) zero_buf[i] = 0;
-  lds_wait_count(&cnt[1], 4);
-  const float4 xa0 = *(const float4*)(xs + lane * 8), xa1 = *(const float4*)(xs + lane * 8 + 4);
-  const float4 xb0 = *(const float4*)(xs + 512 + lane * 8), xb1 = *(const float4*)(xs + 512 + lane * 8 + 4);
   const int jrow = ((lane >> 4) & 1) * 2 + (lane >> 5);   // wave_sum4: row (of 16 lanes) -> value index
-  for (int uc = ua; uc < ue; uc += 4) {
+  __syncthreads();                                 // rendezvous: the row waves' loads are in the queue
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int u = uc + q;
-      if (u < ue) {
-        const bool second = u >= ub;
-        const float4 xa = second ? xb0 : xa0, xb = second ? xb1 : xa1;
-        const float d0 = piece_dot<WDT>(st[q].p[0], xa, xb), d1 = piece_dot<WDT>(st[q].p[1], xa, xb);
-        const float d2 = piece_dot<WDT>(st[q].p[2], xa, xb), d3 = piece_dot<WDT>(st[q].p[3], xa, xb);
-        if (u + 4 < ue) issue(st[q], u + 4);
-        float v = wave_sum4(d0, d1, d2, d3);
-        const int row = 4 * (u - (second ? ub : ub - NRG)) + jrow;
-        if ((lane & 15) == 0 && row < N) {
-          if (bias && (second ? kcB : kcA) == 0) v += bias[row];
-          long long* ap = acc + (size_t)min(second ? slB : slA, slots.acc_slots - 1) * (size_t)slots.acc_stride;
-          atomicAdd((unsigned long long*)(ap + row), (unsigned long long)f2fix(v));
+  for (int r = 0; r < NR; r++) {
+    const int ua = u0[r] + (int)((long long)(u1[r] - u0[r]) * tw / 8), ue = u0[r] + (int)((long long)(u1[r] - u0[r]) * (tw + 1) / 8);
+    size_t eoffA = 0, eoffB = 0;
+    if (ROUTE) {
+      if (r == 0) { eoffA = (size_t)(route.E + slA[0]) * (size_t)slots.expert_stride; eoffB = (size_t)(route.E + slB[0]) * (size_t)slots.expert_stride; }
+      else { if (tw == 0) RSTAMP(4); lds_wait_count(&cnt[2], 1); if (tw == 0) RSTAMP(5); eoffA = (size_t)ssel[slA[1]] * (size_t)slots.expert_stride; eoffB = (size_t)ssel[slB[1]] * (size_t)slots.expert_stride; }
+    } else if (slots.sel) { eoffA = (size_t)slots.sel[slA[0]] * (size_t)slots.expert_stride; eoffB = (size_t)slots.sel[slB[0]] * (size_t)slots.expert_stride; }
+    const int ubr = ub[r], kA = kcA[r], kB = kcB[r];
+    auto issue = [&](Stage& S, int u) {
+      const bool second = u >= ubr;
+      const int rg = u - (second ? ubr : ubr - NRG);
+      const int k = (second ? kB : kA) * 512 + lane * 8;
+      const int ko = k < K ? k : 0;                 // x is 0 beyond K
+      const size_t eo = second ? eoffB : eoffA;
+#pragma unroll
+      for (int rr = 0; rr < 4; rr++) S.p[rr] = piece_load<WDT>(W, eo + (size_t)min(4 * rg + rr, N - 1) * K + ko);
+    };
+    Stage st[4];
+    if (ua < ue) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) if (ua + q < ue) issue(st[q], ua + q);
+    }
+    if (r == 0) {
+      if (zero_buf)                                   // the ring protocol's zeroing duty, by the 512 tile threads
+        for (int i = blockIdx.x * 512 + (tid - 256); i < zero_n; i += gridDim.x * 512) zero_buf[i] = 0;
+      lds_wait_count(&cnt[1], 4);
+    }
+    const float* xr = xs + r * 1024;
+    const float4 xa0 = *(const float4*)(xr + lane * 8), xa1 = *(const float4*)(xr + lane * 8 + 4);
+    const float4 xb0 = *(const float4*)(xr + 512 + lane * 8), xb1 = *(const float4*)(xr + 512 + lane * 8 + 4);
+    long long* apA = acc + (size_t)min(sbase[r] + slA[r], slots.acc_slots - 1) * (size_t)slots.acc_stride;
+    long long* apB = acc + (size_t)min(sbase[r] + slB[r], slots.acc_slots - 1) * (size_t)slots.acc_stride;
+    for (int uc = ua; uc < ue; uc += 4) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int u = uc + q;
+        if (u < ue) {
+          const bool second = u >= ubr;
+          const float4 xa = second ? xb0 : xa0, xb = second ? xb1 : xa1;
+          const float d0 = piece_dot<WDT>(st[q].p[0], xa, xb), d1 = piece_dot<WDT>(st[q].p[1], xa, xb);
+          const float d2 = piece_dot<WDT>(st[q].p[2], xa, xb), d3 = piece_dot<WDT>(st[q].p[3], xa, xb);
+          if (u + 4 < ue) issue(st[q], u + 4);
+          float v = wave_sum4(d0, d1, d2, d3);
+          const int row = 4 * (u - (second ? ubr : ubr - NRG)) + jrow;
+          if ((lane & 15) == 0 && row < N) {
+            if (bias && (second ? kB : kA) == 0) v += bias[row];
+            atomicAdd((unsigned long long*)((second ? apB : apA) + row), (unsigned long long)f2fix(v));
+          }
         }
       }
     }
   }
+  if (tw == 0) RSTAMP(6);
+#undef RSTAMP
 }
 
 // MoE grouped GEMV: blockIdx.y = expert slot.  The expert id comes from the router's device-side selection, so the whole MoE
@@ -2543,7 +2614,7 @@ int bzk_gemv(hipStream_t s, const LinearDev& L, const Pro& pro, const GemvOut& o
     nb = (int)std::max<long long>(std::min<long long>(nb, U), KC);
     const char* lbl = pro.mode == PRO_NORM ? "gemv_rows2<norm>" : pro.mode == PRO_GATED2 ? "gemv_rows2<gated>" : pro.mode == PRO_SILU ? "gemv_rows2<silu>" : "gemv_rows2";
 #define LAUNCH_R2(DT, MODE, FIX) BZ_LAUNCH(lbl, L.algo_bytes, (k_gemv_rows2<DT, MODE, FIX>), dim3(nb), dim3(768), 0, s, (const void*)L.w, L.bias, L.N, L.K, pro, \
-    out.acc, out.zero_buf, out.zero_n, out.shift, MoeSlots{nullptr, 0, 1, 0, 0, 1})
+    out.acc, out.zero_buf, out.zero_n, out.shift, MoeSlots{nullptr, 0, 1, 0, 0, 1}, RouteArgs{})
 #define LAUNCH_R2_F(DT, MODE) do { if (pro.src.fix) LAUNCH_R2(DT, MODE, true); else LAUNCH_R2(DT, MODE, false); } while (0)
 #define LAUNCH_R2_M(DT) do { if (pro.mode == PRO_NORM) LAUNCH_R2_F(DT, PRO_NORM); else if (pro.mode == PRO_SILU) LAUNCH_R2_F(DT, PRO_SILU); \
     else if (pro.mode == PRO_GATED2) LAUNCH_R2(DT, PRO_GATED2, false); else LAUNCH_R2_F(DT, PRO_PLAIN); } while (0)
@@ -4550,24 +4621,33 @@ int bzk_mla_attn(hipStream_t s, const MlaArgs& a, int max_len) {
 
 // one wave: f32 softmax over E logits (the oracle's sequential sum) + greedy top-k (ties -> lowest index); lane l owns experts l, l + 64, ... (E <= 1024).
 // Shared by the decode router and the prompt-row router, so a token is routed identically on both paths.
-__device__ __forceinline__ void moe_softmax_topk(const float* lg, int E, int top_k, int n_shared, float routed_scale, int norm_topk, int* sel, float* wsel, int lane) {
-    // wave-parallel softmax + greedy top-k; lane l owns experts l, l + 64, ... (E <= 1024)
-    float v[16];
+// NJM = slots per lane the code is unrolled for (1: E <= 64, 4: E <= 256, 16: E <= 1024) -- the routing runs ONCE per workgroup, from a cold instruction
+// cache: the 16-slot form is ~5000 instructions and took 6-8 us for DeepSeek-V2-Lite's 64 experts, the 1-slot form a few hundred
+template <int NJM>
+__device__ __forceinline__ void moe_softmax_topk_n(const float* lg, int E, int top_k, int n_shared, float routed_scale, int norm_topk, int* sel, float* wsel, int lane) {
+    // wave-parallel softmax + greedy top-k; lane l owns experts l, l + 64, ... (E <= 1024): NJ = ceil(E / 64) live slots per lane
+    const int NJ = (E + 63) >> 6;
+    float v[NJM];
     float m = -INFINITY;
 #pragma unroll
-    for (int j = 0; j < 16; j++) { const int ee = lane + 64 * j; v[j] = ee < E ? lg[ee] : -INFINITY; m = fmaxf(m, v[j]); }
+    for (int j = 0; j < NJM; j++) { v[j] = -INFINITY; if (j < NJ) { const int ee = lane + 64 * j; v[j] = ee < E ? lg[ee] : -INFINITY; m = fmaxf(m, v[j]); } }
     m = wave_max(m);
-    float sum = 0.f;
 #pragma unroll
-    for (int j = 0; j < 16; j++) { const int ee = lane + 64 * j; v[j] = ee < E ? expf(v[j] - m) : 0.f; }
-    for (int ee = 0; ee < E; ee++) sum += expf(lg[ee] - m);      // the oracle's sequential order
+    for (int j = 0; j < NJM; j++) if (j < NJ) { const int ee = lane + 64 * j; v[j] = ee < E ? expf(v[j] - m) : 0.f; }
+    float sum = 0.f;                                   // the oracle's sequential order e = 0 .. E-1 (lanes beyond E hold 0: adding them changes nothing)
 #pragma unroll
-    for (int j = 0; j < 16; j++) { const int ee = lane + 64 * j; v[j] = ee < E ? v[j] / sum : -1.f; }
+    for (int j = 0; j < NJM; j++)
+      if (j < NJ) {
+#pragma unroll
+        for (int l = 0; l < 64; l++) sum += __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v[j]), l));
+      }
+#pragma unroll
+    for (int j = 0; j < NJM; j++) { const int ee = lane + 64 * j; v[j] = (j < NJ && ee < E) ? v[j] / sum : -1.f; }
     float tsum = 0.f, myw = 0.f; int mysel = 0;
     for (int k = 0; k < top_k; k++) {
       float bv = -1.f; int bi = 0x7fffffff;
 #pragma unroll
-      for (int j = 0; j < 16; j++) { const int ee = lane + 64 * j; if (v[j] > bv) { bv = v[j]; bi = ee; } }   // ascending e within a lane: first max wins
+      for (int j = 0; j < NJM; j++) if (j < NJ) { const int ee = lane + 64 * j; if (v[j] > bv) { bv = v[j]; bi = ee; } }   // ascending e within a lane: first max wins
       // wave argmax (larger value, then smaller index) without the LDS permute network: every step is symmetric, so all lanes agree
 #define ROUTER_STEP(OV, OI) do { const float ov_ = (OV); const int oi_ = (OI); if (ov_ > bv || (ov_ == bv && oi_ < bi)) { bv = ov_; bi = oi_; } } while (0)
       ROUTER_STEP(dpp_get<DPP_XOR1>(bv), dpp_get<DPP_XOR1>(bi));
@@ -4592,10 +4672,15 @@ __device__ __forceinline__ void moe_softmax_topk(const float* lg, int E, int top
       if (lane == k) { mysel = bi; myw = bv; }
       tsum += bv;
 #pragma unroll
-      for (int j = 0; j < 16; j++) if (lane + 64 * j == bi) v[j] = -1.f;
+      for (int j = 0; j < NJM; j++) if (j < NJ && lane + 64 * j == bi) v[j] = -1.f;
     }
     if (lane < top_k) { sel[lane] = mysel; wsel[lane] = norm_topk ? myw / (tsum + 1e-20f) * routed_scale : myw * routed_scale; }
     if (lane < n_shared) { sel[top_k + lane] = E + lane; wsel[top_k + lane] = 1.0f; }
+}
+__device__ void moe_softmax_topk(const float* lg, int E, int top_k, int n_shared, float routed_scale, int norm_topk, int* sel, float* wsel, int lane) {
+  if (E <= 64) moe_softmax_topk_n<1>(lg, E, top_k, n_shared, routed_scale, norm_topk, sel, wsel, lane);
+  else if (E <= 256) moe_softmax_topk_n<4>(lg, E, top_k, n_shared, routed_scale, norm_topk, sel, wsel, lane);
+  else moe_softmax_topk_n<16>(lg, E, top_k, n_shared, routed_scale, norm_topk, sel, wsel, lane);
 }
 
 // Router: one workgroup.  Residual add + RMSNorm (writes h' and the normalised x for the expert GEMVs), f32 logits over E
@@ -4665,7 +4750,7 @@ int bzk_moe_router(hipStream_t s, const Pro& pro, const void* wr, int wdt, int E
 bool bzk_moe_rows2_ok(int wdt, int K) { return rows2_enabled() && (wdt == BZ_F16 || wdt == BZ_BF16) && K % 8 == 0 && K <= 131072; }
 
 int bzk_moe_gemv(hipStream_t s, const MoeGemvArgs& g, int wdt, int n_slots, const Pro& pro, int act, bool split, double bytes) {
-  if (split && g.acc && bzk_moe_rows2_ok(wdt, g.K) && (pro.mode == PRO_PLAIN || pro.mode == PRO_SILU)) {
+  if (split && g.acc && bzk_moe_rows2_ok(wdt, g.K) && (pro.mode == PRO_PLAIN || pro.mode == PRO_SILU || (pro.mode == PRO_NORM && g.route.lg))) {
     // the balanced role kernel over all slots at once (fixed-point accumulators: slot s -> acc[min(s, acc_slots - 1)])
     const int KC = (g.K + 511) / 512;
     const long long U = (long long)((g.N + 3) / 4) * KC * n_slots;
@@ -4673,11 +4758,12 @@ int bzk_moe_gemv(hipStream_t s, const MoeGemvArgs& g, int wdt, int n_slots, cons
     int nb = forced > 0 ? forced : 256;
     nb = (int)std::max<long long>(std::min<long long>(nb, U), (long long)KC * n_slots);
     const MoeSlots ms{g.sel, g.expert_stride, n_slots, g.src_stride, g.acc_stride, g.acc_slots};
-    const char* lbl = pro.mode == PRO_SILU ? "moe_rows2<down>" : "moe_rows2<gate_up>";
-#define LAUNCH_MR2(DT, MODE, FIX) BZ_LAUNCH(lbl, bytes, (k_gemv_rows2<DT, MODE, FIX>), dim3(nb), dim3(768), 0, s, g.w, (const float*)nullptr, g.N, g.K, pro, g.acc, \
-    (long long*)nullptr, 0, ConvShift{}, ms)
-#define LAUNCH_MR2_F(DT, MODE) do { if (pro.src.fix) LAUNCH_MR2(DT, MODE, true); else LAUNCH_MR2(DT, MODE, false); } while (0)
-#define LAUNCH_MR2_M(DT) do { if (pro.mode == PRO_SILU) LAUNCH_MR2_F(DT, PRO_SILU); else LAUNCH_MR2_F(DT, PRO_PLAIN); } while (0)
+    if (pro.mode == PRO_NORM && (g.route.E > 1024 || g.route.top_k + g.route.n_shared > 128 || pro.H != g.K || g.src_stride != 0)) BZ_FAIL(BZ_E_UNSUPPORTED, "moe gate/up with in-launch routing: E %d unsupported", g.route.E);
+    const char* lbl = pro.mode == PRO_SILU ? "moe_rows2<down>" : (pro.mode == PRO_NORM ? "moe_rows2<route+gate_up>" : "moe_rows2<gate_up>");
+#define LAUNCH_MR2(DT, MODE, FIX, RT) BZ_LAUNCH(lbl, bytes, (k_gemv_rows2<DT, MODE, FIX, RT>), dim3(nb), dim3(RT ? 832 : 768), 0, s, g.w, (const float*)nullptr, g.N, g.K, pro, g.acc, \
+    (long long*)nullptr, 0, ConvShift{}, ms, g.route)
+#define LAUNCH_MR2_F(DT, MODE, RT) do { if (pro.src.fix) LAUNCH_MR2(DT, MODE, true, RT); else LAUNCH_MR2(DT, MODE, false, RT); } while (0)
+#define LAUNCH_MR2_M(DT) do { if (pro.mode == PRO_SILU) LAUNCH_MR2_F(DT, PRO_SILU, 0); else if (pro.mode == PRO_NORM) LAUNCH_MR2_F(DT, PRO_NORM, 1); else LAUNCH_MR2_F(DT, PRO_PLAIN, 0); } while (0)
     if (wdt == BZ_F16) LAUNCH_MR2_M(BZ_F16); else LAUNCH_MR2_M(BZ_BF16);
 #undef LAUNCH_MR2_M
 #undef LAUNCH_MR2_F
@@ -4755,8 +4841,9 @@ int bzk_mla_append_rows(hipStream_t s, const float* kva, long long stride, int S
   return BZ_OK;
 }
 
-// routing of prompt rows: workgroup = one token; the logits are summed exactly as k_moe_router sums them (lane = 8 columns of every 512-column
-// chunk, then the wave tree), so a token gets the same experts and weights as on the decode path.  grid = S, 256 threads.
+// routing of prompt rows: workgroup = one token; the logits are summed exactly as the decode path sums them (k_gemv_rows2 over the router matrix:
+// lane = 8 columns of a 512-column chunk, the 32 / 16 / DPP tree, fixed-point sum over the chunks), so a token gets the same experts and weights
+// on both paths.  grid = S, 256 threads.
 template <int DT, int WDT>
 __global__ __launch_bounds__(256) void k_moe_route_rows(const unsigned short* __restrict__ x16, int H, const void* __restrict__ wr, int E, int top_k, float routed_scale,
                                                         int norm_topk, int* __restrict__ sel, float* __restrict__ wsel) {
@@ -4769,22 +4856,23 @@ __global__ __launch_bounds__(256) void k_moe_route_rows(const unsigned short* __
   }
   __syncthreads();
   for (int e = wave; e < E; e += 4) {
-    float acc = 0.f;
+    long long accf = 0;                     // per 512-k chunk: the lane's 8-term dot, k_gemv_rows2's reduction tree, 2^-32 fixed point
     for (int k0 = 0; k0 < H; k0 += 4096) {
-      float w[8][8];
+      RowPiece<WDT> w[8];
 #pragma unroll
-      for (int j = 0; j < 8; j++) { const int k = k0 + j * 512 + lane * 8; load8<WDT>(wr, (size_t)e * H + (k < H ? k : 0), true, w[j]); }
+      for (int j = 0; j < 8; j++) { const int k = k0 + j * 512 + lane * 8; w[j] = piece_load<WDT>(wr, (size_t)e * H + (k < H ? k : 0)); }
 #pragma unroll
       for (int j = 0; j < 8; j++) {
         const int k = k0 + j * 512 + lane * 8;
-        if (k < H) {
-          const float4 xa = *(const float4*)(xs + k), xb = *(const float4*)(xs + k + 4);
-          acc += w[j][0] * xa.x + w[j][1] * xa.y + w[j][2] * xa.z + w[j][3] * xa.w + w[j][4] * xb.x + w[j][5] * xb.y + w[j][6] * xb.z + w[j][7] * xb.w;
+        if (k0 + j * 512 < H) {
+          const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+          const float4 xa = k < H ? *(const float4*)(xs + k) : z4, xb = k < H ? *(const float4*)(xs + k + 4) : z4;
+          const float d = piece_dot<WDT>(w[j], xa, xb);
+          accf += f2fix(grp_reduce<16, OpAdd>(xrow16<OpAdd>(xrow32<OpAdd>(d))));
         }
       }
     }
-    acc = wave_sum(acc);
-    if (lane == 0) lg[e] = acc;
+    if (lane == 0) lg[e] = fix2f(accf);
   }
   __syncthreads();
   if (wave == 0) moe_softmax_topk(lg, E, top_k, 0, routed_scale, norm_topk, sel + (size_t)t * top_k, wsel + (size_t)t * top_k, lane);

@@ -91,6 +91,8 @@ SWITCHES = [
     ("BZ_SPLIT_MIN=4", ["llama3-8b-awq-2l", "tiny-bf16"]),               # split-KV attention from position 4 on
     ("BZ_NO_ROWS_SPLITK=1", ["mamba2-2.7b-2l", "llama3.2-1b-bf16-2l"]),  # row GEMVs without split-K
     ("BZ_NO_ROWS2=1", ["mamba2-2.7b-2l", "llama3.2-1b-bf16-2l", "deepseek-v2-lite-2l"]),   # 16-row workgroup GEMV (k_gemv_rows) instead of the balanced role kernel
+    ("BZ_NO_MLA_SPLIT=1", ["deepseek-v2-lite-2l"]),                      # MLA decode: one workgroup per head over the whole context
+    ("BZ_NO_MOE_ROUTE_FUSION=1", ["deepseek-v2-lite-2l"]),               # router launch (last-workgroup top-k) + plain grouped gate/up
     ("BZ_NO_MFMA_PREFILL=1", ["mamba2-2.7b-2l", "tiny-bf16"]),           # prompts token by token
     ("BZ_NO_Q4G_MFMA=1", ["llama3-8b-awq-2l"]),                          # int4 prompts through the multi-row dot4 kernel
     ("BZ_GGUF_MLP_FUSION=1", ["mistral-7b-q4km-2l", "q4km-h2048"]),       # opt-in fused GGUF MLP (Q4_K gate/up + Q4_K / Q6_K down in one launch)
