@@ -1525,6 +1525,8 @@ __global__ __launch_bounds__(256) void k_gemv_gq(const uint4* __restrict__ Wq, c
 //   MODE NORM: x = RMSNorm(h + prev) slice (full-H sum of squares per block)      MODE SILU: x = R(R(silu(gate)) * up) slice
 // grid = (K / 256) x ceil(N / 512), 512 threads
 // ---------------------------------------------------------------------------------------------------------
+// (several tiles per wave -- one norm prologue per ~256 workgroups instead of 896 on gate/up, the next tile's superblock prefetched under the current dots --
+// was built and measured too: 132 / 169 registers instead of 77-115, one workgroup per CU, 527 vs 539 tok/s.  The kernel is bound by its dot issue, not its prologues.)
 // (a 12-wave role-split form of this kernel, as in k_gemv_q4g_slim, was built and measured on the Mistral-7B Q4_K_M shape: 539 vs 549 tok/s -- no gain; the f32
 // activations of the GGUF path make its prologue lighter (no 64-bit residual reads), and its big launches want many small workgroups in flight)
 template <int FMT, int MODE, int FIX, int NJ>     // NJ = H / 2048 (NORM only)
@@ -2394,8 +2396,6 @@ __global__ __launch_bounds__(256) void k_moe_rows(MoeGemvArgs g, Pro pro, int ac
 
 static int rows_per_wg_for(int N) {
   // ~1000 workgroups when N is large, at least 16 rows (4 per wave) per workgroup
-  static const int forced = getenv("BZ_ROWS_RPW") ? atoi(getenv("BZ_ROWS_RPW")) : 0;
-  if (forced > 0 && N < 40000) return forced;
   int r = 16;
   while (r < 256 && (N + r - 1) / r > 1024) r <<= 1;
   return r;
@@ -2607,11 +2607,9 @@ int bzk_gemv(hipStream_t s, const LinearDev& L, const Pro& pro, const GemvOut& o
     return BZ_OK;
   }
   if (L.kind == LK_ROWS && bzk_rows2_ok(L, pro, out)) {
-    static const int forced = getenv("BZ_ROWS2_WGS") ? atoi(getenv("BZ_ROWS2_WGS")) : 0;
     const long long U = (long long)((L.N + 3) / 4) * ((L.K + 511) / 512);
     const int KC = (L.K + 511) / 512;
-    int nb = forced > 0 ? forced : 256;
-    nb = (int)std::max<long long>(std::min<long long>(nb, U), KC);
+    const int nb = (int)std::max<long long>(std::min<long long>(256, U), KC);   // one workgroup per CU; a range lies in <= 2 chunks when nb >= K / 512
     const char* lbl = pro.mode == PRO_NORM ? "gemv_rows2<norm>" : pro.mode == PRO_GATED2 ? "gemv_rows2<gated>" : pro.mode == PRO_SILU ? "gemv_rows2<silu>" : "gemv_rows2";
 #define LAUNCH_R2(DT, MODE, FIX) BZ_LAUNCH(lbl, L.algo_bytes, (k_gemv_rows2<DT, MODE, FIX>), dim3(nb), dim3(768), 0, s, (const void*)L.w, L.bias, L.N, L.K, pro, \
     out.acc, out.zero_buf, out.zero_n, out.shift, MoeSlots{nullptr, 0, 1, 0, 0, 1}, RouteArgs{})
@@ -3529,10 +3527,8 @@ static size_t attn2_smem(int nw) { return (size_t)(64 * 3 + 2 * nw + nw * 128 + 
 static int attn_oproj_plan(const AttnArgs& a, const LinearDev& L, int& NW) {
   NW = 0;
   if (a.hd != 128 || L.kind != LK_Q4G || L.perm != nullptr || L.K != a.nq * 128 || a.q_only) return 0;
-  static const bool nw4 = getenv("BZ_ATTN_NW4") != nullptr;
   const int NT = L.N / 64;
-  const int nw0 = nw4 ? 4 : 8;
-  for (int nw = nw0; nw >= 4; nw >>= 1) {
+  for (int nw = 8; nw >= 4; nw >>= 1) {
     const int ow = nw > 8 ? 8 : nw;
     for (int cs = 8; cs >= 1; cs >>= 1)
       if (NT % (cs * ow) == 0 && NT / (cs * ow) <= 2 && a.nq * cs <= 1024) { NW = nw; return cs; }
@@ -4211,8 +4207,7 @@ int bzk_ssm_step(hipStream_t s, const SsmArgs& a) {
   if (a.d_state > 256 || (a.d_state & 3) || a.n_heads % a.n_groups) BZ_FAIL(BZ_E_UNSUPPORTED, "ssm_step: d_state %d / groups %d unsupported", a.d_state, a.n_groups);
   const double bytes = 2.0 * a.n_heads * a.head_dim * a.d_state * (a.sdt == BZ_F32 ? 4 : 2);
   // 16 threads per state row when a part is then a whole number of 16-byte pieces (d_state 128 with a 16-bit state) or the state is f32
-  static const bool p4 = getenv("BZ_SSM_PARTS4") != nullptr;
-  const bool wide = !p4 && a.d_state % 16 == 0 && (a.sdt == BZ_F32 || (a.d_state / 16) % 8 == 0);
+  const bool wide = a.d_state % 16 == 0 && (a.sdt == BZ_F32 || (a.d_state / 16) % 8 == 0);
 #define LAUNCH_SSM(SDT) do { if (wide) BZ_LAUNCH("mamba2_ssm_step", bytes, (k_ssm_step<SDT, 16>), dim3(a.n_heads), dim3(1024), 0, s, a); \
                              else BZ_LAUNCH("mamba2_ssm_step", bytes, (k_ssm_step<SDT, 4>), dim3(a.n_heads), dim3(256), 0, s, a); } while (0)
   if (a.sdt == BZ_F32) LAUNCH_SSM(BZ_F32); else if (a.sdt == BZ_F16) LAUNCH_SSM(BZ_F16); else LAUNCH_SSM(BZ_BF16);
@@ -4754,9 +4749,7 @@ int bzk_moe_gemv(hipStream_t s, const MoeGemvArgs& g, int wdt, int n_slots, cons
     // the balanced role kernel over all slots at once (fixed-point accumulators: slot s -> acc[min(s, acc_slots - 1)])
     const int KC = (g.K + 511) / 512;
     const long long U = (long long)((g.N + 3) / 4) * KC * n_slots;
-    static const int forced = getenv("BZ_ROWS2_WGS") ? atoi(getenv("BZ_ROWS2_WGS")) : 0;
-    int nb = forced > 0 ? forced : 256;
-    nb = (int)std::max<long long>(std::min<long long>(nb, U), (long long)KC * n_slots);
+    const int nb = (int)std::max<long long>(std::min<long long>(256, U), (long long)KC * n_slots);
     const MoeSlots ms{g.sel, g.expert_stride, n_slots, g.src_stride, g.acc_stride, g.acc_slots};
     if (pro.mode == PRO_NORM && (g.route.E > 1024 || g.route.top_k + g.route.n_shared > 128 || pro.H != g.K || g.src_stride != 0)) BZ_FAIL(BZ_E_UNSUPPORTED, "moe gate/up with in-launch routing: E %d unsupported", g.route.E);
     const char* lbl = pro.mode == PRO_SILU ? "moe_rows2<down>" : (pro.mode == PRO_NORM ? "moe_rows2<route+gate_up>" : "moe_rows2<gate_up>");

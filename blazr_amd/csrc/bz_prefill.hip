@@ -672,9 +672,7 @@ int bzk_gemm_q4g_mfma(hipStream_t s, const LinearDev& L, const void* x16, int S,
   if (!bzk_gemm_q4g_mfma_ok(L, BZ_F16, S)) BZ_FAIL(BZ_E_UNSUPPORTED, "gemm_q4g_mfma: unsupported weight / activation format");
   // one wave per block (measured faster than four at every prompt length, 32..2000 tokens): the A rows are shared through L1 / L2 either
   // way, and single-wave blocks spread a small grid (o_proj / down at a few hundred rows: 64 x 8 tiles) over the whole chip
-  static const char* wpb_env = getenv("BZ_Q4G_MFMA_WPB");
   static const bool no_ks = getenv("BZ_Q4G_MFMA_NO_KSPLIT") != nullptr;
-  const int wpb = wpb_env ? atoi(wpb_env) : 1;
   const double flops = 2.0 * S * (double)L.N * L.K;
   const int G = L.K / 128, rt = (S + 63) / 64;
   // short prompts / decode batches: too few 64 x 64 tiles to fill the chip -> split K over blockIdx.z into partials (summed in a fixed order)
@@ -687,11 +685,7 @@ int bzk_gemm_q4g_mfma(hipStream_t s, const LinearDev& L, const void* x16, int S,
     if (KS < 2 || (size_t)KS * S * L.N * 4 > ws_bytes) { KS = 1; GPB = G; }
   }
   float* part = KS > 1 ? ws : nullptr;
-  if (wpb == 4) {
-    const dim3 grid((L.N / 64 + 3) / 4, rt, KS);
-    BZ_LAUNCH("gemm_q4g_mfma", flops, k_gemm_q4g_mfma<4>, grid, dim3(256), 0, s, (const uint4*)L.w, (const __half*)L.scales,
-              (const unsigned char*)L.zeros, L.bias, L.N, L.K, (const unsigned short*)x16, S, act, y, GPB, part);
-  } else {
+  {
     const dim3 grid(L.N / 64, rt, KS);
     BZ_LAUNCH("gemm_q4g_mfma", flops, k_gemm_q4g_mfma<1>, grid, dim3(64), 0, s, (const uint4*)L.w, (const __half*)L.scales,
               (const unsigned char*)L.zeros, L.bias, L.N, L.K, (const unsigned short*)x16, S, act, y, GPB, part);

@@ -487,7 +487,7 @@ def test_split_attention_decode_matches_oracle(device, split_min, case):
     okv = om.new_kv(256)
     want = om.forward_kv(p, okv, 0, all_logits=True)
     # token-by-token decode of this 150-token fixture sits at 1.0-1.3e-3 relative L2 against the oracle on BOTH attention paths (measured:
-    # mean 1.126e-3 single-launch, 1.125e-3 split; scripts/dbg_split.py) -- rounding-flip noise of two correct f16 pipelines, see REL above
+    # mean 1.126e-3 single-launch, 1.125e-3 split) -- rounding-flip noise of two correct f16 pipelines, see REL above
     factor = 1.5 if preset.startswith("llama3") else TINY
     for i in range(n):   # token by token: every step is a decode step
         lg = lm.forward_with_kv_cache([int(p[i])], kv, i)
