@@ -234,7 +234,10 @@ def main():
             top2 = np.partition(row, -2)[-2:]
             return float(top2[1] - top2[0]) / max(float(np.abs(row).max()), 1e-30)
         gaps = [gap_of(r) for r in cpu_rows]
-        fair_prefix = next((i for i, g in enumerate(gaps) if g < 4e-3), len(gaps))
+        # near-tie guard = 8 rounding units of the activation dtype: 4e-3 for f16 (2^-11; also used for f32 models), 3.1e-2 for bf16 (2^-8) -- two correct
+        # pipelines in that dtype differ by about that much after a few layers (tests/test_gpu_parity_truth.py, scripts/parity_depth.py)
+        guard = 8.0 * 2.0 ** -8 if cfg["act_dtype"] == "bf16" else 4e-3
+        fair_prefix = next((i for i, g in enumerate(gaps) if g < guard), len(gaps))
         n_same = next((i for i, (a, g) in enumerate(zip(cpu_tokens, tokens)) if a != g), min(len(cpu_tokens), len(tokens)))
         # (2) teacher forcing: the CPU's ids are fed through bz_forward_kv one by one on a fresh cache (the prompt row comes from the prefill
         #     above), so EVERY step is comparable whatever happened before it: per-step logit errors, and the argmax wherever the step is fair
@@ -245,7 +248,7 @@ def main():
             gpu_rows.append(lm.forward_with_kv_cache([cpu_tokens[i]], kv2, args.prompt_len + i).to_numpy().reshape(-1).copy())
         l2 = [float(np.linalg.norm(g.astype(np.float64) - c) / np.linalg.norm(c)) for g, c in zip(gpu_rows, cpu_rows)]
         mx = [float(np.abs(g.astype(np.float64) - c).max() / np.abs(c).max()) for g, c in zip(gpu_rows, cpu_rows)]
-        fair = [g >= 4e-3 for g in gaps]
+        fair = [g >= guard for g in gaps]
         same = [int(g.argmax()) == t for g, t in zip(gpu_rows, cpu_tokens)]
         n_cmp = sum(fair)
         n_eq = sum(1 for f, e in zip(fair, same) if f and e)
@@ -254,8 +257,9 @@ def main():
                          "teacher_forced": {"rel_l2_max": round(max(l2), 6), "rel_l2_mean": round(float(np.mean(l2)), 6), "max_norm_max": round(max(mx), 6),
                                             "rel_l2_per_step": [round(v, 6) for v in l2], "max_norm_per_step": [round(v, 6) for v in mx],
                                             "top2_gap_per_step": [round(g, 5) for g in gaps], "argmax_equal_per_step": same},
-                         "note": "ids compared on every step whose oracle top-2 gap is >= 4e-3 of max|logit| (a rounding-level tie below that); "
-                                 "logit errors relative to the CPU row (L2) and to its largest magnitude (max-norm); bar: 1e-3 relative L2"}
+                         "gap_guard": guard,
+                         "note": "ids compared on every step whose oracle top-2 gap is >= gap_guard of max|logit| (8 rounding units of the activation dtype: a rounding-level "
+                                 "tie below that); logit errors relative to the CPU row (L2) and to its largest magnitude (max-norm); bar: 1e-3 relative L2 (f16 / f32 activations)"}
 
     if rank == 0:
         print(json.dumps(out))
