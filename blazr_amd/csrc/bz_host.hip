@@ -1336,6 +1336,16 @@ static int run_fused(bz_model* m, const FusedLinear& F, Pro pro, RingState& rs, 
     out->fix = 0; out->p = (const void*)direct;
     return BZ_OK;
   }
+  static const bool no_mix = getenv("BZ_NO_GQ_MIX") != nullptr;
+  if (!no_mix && F.parts.size() == 2 && F.fix_out && F.n_off[1] == F.parts[0].N && bzk_gq_mix_ok(F.parts[0], F.parts[1], pro)) {
+    // GGUF Q4_K_M q/k/v: the Q4_K part (q, k) and the Q6_K part (v) in one launch
+    GemvOut o{};
+    o.acc = acc; o.zero_buf = rs.dirty[rz] > 0 ? m->ring[rz] : nullptr; o.zero_n = rs.dirty[rz];
+    BZ_TRY(bzk_gemv_gq_mix(st, F.parts[0], F.parts[1], pro, o));
+    rs.dirty[rz] = 0; rs.dirty[ri] = F.N; rs.ri = rz;
+    out->fix = 1; out->p = (const void*)acc;
+    return BZ_OK;
+  }
   for (size_t i = 0; i < F.parts.size(); i++) {
     const LinearDev& L = F.parts[i];
     Pro p = pro; p.perm = L.perm;

@@ -171,6 +171,11 @@ struct MoeSlots { const int* sel; long long expert_stride; int n; long long src_
 // in-launch MoE routing (k_gemv_rows2<NORM, ROUTE>): lg = the router logits as the fixed-point output of the previous launch
 struct RouteArgs { const long long* lg; int E, top_k, n_shared; float routed_scale; int norm_topk; int* sel_out; float* w_out; };
 
+// second (Q6_K) tile range of a mixed-format slim GGUF launch: tiles [nt4, ...) read these arrays with the tile index restarting at 0
+struct GqMix { const uint4* Wq6; const uint2* Wh6; const uint4* Hd6; const __half* Dd6; int nt4; };
+bool bzk_gq_mix_ok(const LinearDev& A, const LinearDev& B, const Pro& pro);
+int bzk_gemv_gq_mix(hipStream_t s, const LinearDev& A, const LinearDev& B, const Pro& pro, const struct GemvOut& out);
+
 struct GemvOut {
   long long* acc;        // Q4G/K-quants: fixed-point accumulator [N] (must be zero on entry)
   float* direct;         // ROWS: direct store [N] (rounded to act)

@@ -1265,20 +1265,21 @@ bool bzk_gemv_slim_ok(const LinearDev& L, const Pro& pro) {
 //   Q4_K: Sa = sum over the chunk, Sb = sum over k%8 >= 4 (for the signed high-nibble trick);  Q6_K: Sa / Sb = sums over the
 //   first / second 16;  Q8_0: unused.
 // =========================================================================================================
-enum { GQ_Q80 = 0, GQ_Q4K = 1, GQ_Q6K = 2 };
+enum { GQ_Q80 = 0, GQ_Q4K = 1, GQ_Q6K = 2, GQ_MIX = 3 };   // MIX: Q4_K tiles followed by Q6_K tiles in one launch (the Q4_K_M q/k + v split)
 #define XQ_MAX 8355000.0f  // < 127*65536 + 127*256 + 127: the largest magnitude of three balanced int8 planes
 
 // one thread's octet (8 consecutive k of a 32-k chunk; the chunk's four octets sit in four consecutive lanes, quad-aligned) -> three int8 planes
 // + the chunk parameters.  e0 = index of the octet's first element in the slice; `on`: this thread takes part (its lanes' reductions run anyway)
 template <int FMT>
-__device__ __forceinline__ void quant8_x32(const float (&v)[8], int e0, bool on, int lane, unsigned* xh, unsigned* xm, unsigned* xl, int4* cpar) {
+__device__ __forceinline__ void quant8_x32(const float (&v)[8], int e0, bool on, int lane, unsigned* xh, unsigned* xm, unsigned* xl, int4* cpar, int4* cpar6 = nullptr) {
   float am = 0.f;
 #pragma unroll
   for (int i = 0; i < 8; i++) am = fmaxf(am, fabsf(v[i]));
   am = grp_reduce<4, OpMax>(am);   // 4 lanes x 8 = one 32-k chunk
   const float inv = am > 0.f ? XQ_MAX / am : 0.f;
   unsigned wh[2] = {0, 0}, wm[2] = {0, 0}, wl[2] = {0, 0};
-  int sa[3] = {0, 0, 0}, sb[3] = {0, 0, 0};
+  int sa[3] = {0, 0, 0}, sb[3] = {0, 0, 0};     // Q4_K: sums over the chunk / over k % 8 >= 4 ; Q6_K (and the second set of MIX): first / second 16
+  int ta[3] = {0, 0, 0}, tb[3] = {0, 0, 0};
 #pragma unroll
   for (int i = 0; i < 8; i++) {
     const int xi = (int)rintf(v[i] * inv);
@@ -1289,20 +1290,25 @@ __device__ __forceinline__ void quant8_x32(const float (&v)[8], int e0, bool on,
     wh[i >> 2] |= ((unsigned)hi & 255u) << (8 * (i & 3));
     wm[i >> 2] |= ((unsigned)mid & 255u) << (8 * (i & 3));
     wl[i >> 2] |= ((unsigned)lo & 255u) << (8 * (i & 3));
-    if (FMT == GQ_Q4K) { sa[0] += hi; sa[1] += mid; sa[2] += lo; if (i >= 4) { sb[0] += hi; sb[1] += mid; sb[2] += lo; } }
+    if (FMT == GQ_Q4K || FMT == GQ_MIX) { sa[0] += hi; sa[1] += mid; sa[2] += lo; if (i >= 4) { sb[0] += hi; sb[1] += mid; sb[2] += lo; } }
     if (FMT == GQ_Q6K) { sa[0] += hi; sa[1] += mid; sa[2] += lo; }   // per-thread sum; halves are separated below
   }
-  if (FMT == GQ_Q6K) {
+  if (FMT == GQ_Q6K || FMT == GQ_MIX) {
     // lanes 0,1 of the 4-lane group hold k 0..15 (first half), lanes 2,3 hold k 16..31
     const bool second = (lane & 2) != 0;
 #pragma unroll
     for (int q = 0; q < 3; q++) {
-      const int mine = sa[q] + dpp_get<DPP_XOR1>(sa[q]);          // sum of my half
+      const int mine = sa[q] + dpp_get<DPP_XOR1>(sa[q]);          // sum of my half (MIX: sa is still the per-thread sum here)
       const int other = dpp_get<DPP_XOR2>(mine);                  // the other half
-      sa[q] = second ? other : mine;                              // Sa = first half
-      sb[q] = second ? mine : other;                              // Sb = second half
+      ta[q] = second ? other : mine;                              // first half
+      tb[q] = second ? mine : other;                              // second half
     }
-  } else if (FMT == GQ_Q4K) {
+    if (FMT == GQ_Q6K) {
+#pragma unroll
+      for (int q = 0; q < 3; q++) { sa[q] = ta[q]; sb[q] = tb[q]; }
+    }
+  }
+  if (FMT == GQ_Q4K || FMT == GQ_MIX) {
 #pragma unroll
     for (int q = 0; q < 3; q++) {
       sa[q] = grp_reduce<4, OpAdd>(sa[q]);
@@ -1316,11 +1322,15 @@ __device__ __forceinline__ void quant8_x32(const float (&v)[8], int e0, bool on,
     if ((lane & 3) == 0) {
       cpar[2 * (e0 >> 5)] = make_int4(__float_as_int(am * (1.0f / XQ_MAX)), sa[0], sa[1], sa[2]);
       cpar[2 * (e0 >> 5) + 1] = make_int4(sb[0], sb[1], sb[2], 0);
+      if (FMT == GQ_MIX) {
+        cpar6[2 * (e0 >> 5)] = make_int4(__float_as_int(am * (1.0f / XQ_MAX)), ta[0], ta[1], ta[2]);
+        cpar6[2 * (e0 >> 5) + 1] = make_int4(tb[0], tb[1], tb[2], 0);
+      }
     }
   }
 }
 template <int FMT>
-__device__ __forceinline__ void quant_x32(const float* xs, int KR, unsigned* xh, unsigned* xm, unsigned* xl, int4* cpar) {
+__device__ __forceinline__ void quant_x32(const float* xs, int KR, unsigned* xh, unsigned* xm, unsigned* xl, int4* cpar, int4* cpar6 = nullptr) {
   for (int base = 0; base < KR; base += 256 * 8) {
     const int e0 = base + threadIdx.x * 8;
     const bool on = e0 < KR;
@@ -1332,7 +1342,7 @@ __device__ __forceinline__ void quant_x32(const float* xs, int KR, unsigned* xh,
 #pragma unroll
       for (int i = 0; i < 8; i++) v[i] = 0.f;
     }
-    quant8_x32<FMT>(v, e0, on, (int)threadIdx.x, xh, xm, xl, cpar);
+    quant8_x32<FMT>(v, e0, on, (int)threadIdx.x, xh, xm, xl, cpar, cpar6);
   }
 }
 
@@ -1532,16 +1542,23 @@ __global__ __launch_bounds__(256) void k_gemv_gq(const uint4* __restrict__ Wq, c
 template <int FMT, int MODE, int FIX, int NJ>     // NJ = H / 2048 (NORM only)
 __global__ __launch_bounds__(512) void k_gemv_gq_slim(const uint4* __restrict__ Wq, const uint2* __restrict__ Wh, const uint4* __restrict__ Hd,
                                                      const __half* __restrict__ Dd, const float* __restrict__ bias, int N, int K, Pro pro, long long* acc,
-                                                     long long* zero_buf, int zero_n) {
+                                                     long long* zero_buf, int zero_n, GqMix mix) {
   __shared__ __attribute__((aligned(16))) float xs[256];
   __shared__ __attribute__((aligned(16))) unsigned xh[64], xm[64], xl[64];
   __shared__ int4 cpar[16];
+  __shared__ int4 cpar6[FMT == GQ_MIX ? 16 : 1];
   __shared__ float red[8];
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int SB = K >> 8, C32 = K >> 5;
   const int ksl = blockIdx.x % SB, tq = (blockIdx.x / SB) * 8 + wave;
   const bool q_on = tq * 64 < N;
-  const int tqc = q_on ? tq : 0;
+  // MIX: tiles [0, mix.nt4) are Q4_K (the kernel's primary pointers), the rest Q6_K (mix pointers, tile index restarting at 0); wave-uniform
+  const bool is6 = FMT == GQ_Q6K || (FMT == GQ_MIX && q_on && tq >= mix.nt4);
+  const int tqc = q_on ? (FMT == GQ_MIX && is6 ? tq - mix.nt4 : tq) : 0;
+  const uint4* Wq_ = (FMT == GQ_MIX && is6) ? mix.Wq6 : Wq;
+  const uint4* Hd_ = (FMT == GQ_MIX && is6) ? mix.Hd6 : Hd;
+  const uint2* Wh_ = FMT == GQ_MIX ? mix.Wh6 : Wh;
+  const __half* Dd_ = FMT == GQ_MIX ? mix.Dd6 : Dd;
   asm volatile("" :: "s"(zero_buf), "s"(zero_n), "s"(acc), "s"(pro.h_in), "s"(pro.src.p), "s"(pro.norm_w), "s"(pro.h_out), "s"(pro.H),
                "s"(pro.act), "s"(K), "s"(N), "s"(Wq), "s"(Wh), "s"(Hd), "s"(Dd), "s"(bias));   // one scalar-load batch for all arguments
   zero_duty<512>(zero_buf, zero_n);
@@ -1570,15 +1587,16 @@ __global__ __launch_bounds__(512) void k_gemv_gq_slim(const uint4* __restrict__ 
   // (2) this wave's superblock: 8 x 16 B of nibbles (+ Q6_K: 8 x 8 B of high bits), header, all in flight now
   uint4 q[8]; uint2 qh[8]; uint4 hd; __half dsb = __float2half(0.f);
   {
-    const uint4* p = Wq + ((size_t)tqc * C32 + (size_t)ksl * 8) * 64 + lane;
+    const uint4* p = Wq_ + ((size_t)tqc * C32 + (size_t)ksl * 8) * 64 + lane;
 #pragma unroll
     for (int i = 0; i < 8; i++) q[i] = ldnt(p + i * 64);
-    hd = Hd[((size_t)tqc * SB + ksl) * 64 + lane];
-    if (FMT == GQ_Q6K) {
-      const uint2* ph = Wh + ((size_t)tqc * C32 + (size_t)ksl * 8) * 64 + lane;
+    hd = Hd_[((size_t)tqc * SB + ksl) * 64 + lane];
+    if (FMT == GQ_Q6K || FMT == GQ_MIX) {
+      const int t6 = is6 ? tqc : 0;              // (MIX, Q4_K wave: harmless loads of tile 0)
+      const uint2* ph = Wh_ + ((size_t)t6 * C32 + (size_t)ksl * 8) * 64 + lane;
 #pragma unroll
       for (int i = 0; i < 8; i++) qh[i] = ph[i * 64];
-      dsb = Dd[((size_t)tqc * SB + ksl) * 64 + lane];
+      dsb = Dd_[((size_t)t6 * SB + ksl) * 64 + lane];
     }
   }
   // (3) the activation slice
@@ -1609,14 +1627,15 @@ __global__ __launch_bounds__(512) void k_gemv_gq_slim(const uint4* __restrict__ 
     if (tid < 256) xs[tid] = round_act(round_act(silu_f(vcvt<FIX>(ga, pro.act)), pro.act) * vcvt<FIX>(ua, pro.act), pro.act);
   }
   __syncthreads();
-  quant_x32<FMT>(xs, 256, xh, xm, xl, cpar);
+  quant_x32<FMT>(xs, 256, xh, xm, xl, cpar, cpar6);
   __syncthreads();
   if (!q_on) return;
+  const int4* cp6 = FMT == GQ_MIX ? cpar6 : cpar;   // the chunk parameters in the Q6_K convention
   const uint4* xh4 = (const uint4*)xh;
   const uint4* xm4 = (const uint4*)xm;
   const uint4* xl4 = (const uint4*)xl;
   float y = 0.f;
-  if (FMT == GQ_Q4K) {
+  if (!is6) {
     const unsigned hw[4] = {hd.x, hd.y, hd.z, hd.w};
     const float d = __half2float(__ushort_as_half((unsigned short)(hw[0] & 0xffffu)));
     const float dmin = __half2float(__ushort_as_half((unsigned short)(hw[0] >> 16)));
@@ -1678,7 +1697,7 @@ __global__ __launch_bounds__(512) void k_gemv_gq_slim(const uint4* __restrict__ 
         u1[1] = __builtin_amdgcn_sdot4((int)w[4 + j], (int)Xm[4 + j], u1[1], false);
         u1[2] = __builtin_amdgcn_sdot4((int)w[4 + j], (int)Xl[4 + j], u1[2], false);
       }
-      const int4 p0 = cpar[2 * c], p1 = cpar[2 * c + 1];
+      const int4 p0 = cp6[2 * c], p1 = cp6[2 * c + 1];
       const int s0 = (int)(signed char)((sw[(2 * c) >> 2] >> (8 * ((2 * c) & 3))) & 255u);
       const int s1 = (int)(signed char)((sw[(2 * c + 1) >> 2] >> (8 * ((2 * c + 1) & 3))) & 255u);
       const float f0 = planes_f(u0[0] - 32 * p0.y, u0[1] - 32 * p0.z, u0[2] - 32 * p0.w);
@@ -1934,6 +1953,25 @@ bool bzk_gq_slim_ok(const LinearDev& L, const Pro& pro) {
   return false;
 }
 
+
+// Q4_K tiles followed by Q6_K tiles (one K, one prologue) in ONE slim launch: the Q4_K_M rule stores q / k as Q4_K and v as Q6_K, which made q/k/v two launches
+bool bzk_gq_mix_ok(const LinearDev& A, const LinearDev& B, const Pro& pro) {
+  return A.kind == LK_Q4K && B.kind == LK_Q6K && A.K == B.K && !A.bias && !B.bias && pro.mode == PRO_NORM && bzk_gq_slim_ok(A, pro) && bzk_gq_slim_ok(B, pro);
+}
+int bzk_gemv_gq_mix(hipStream_t s, const LinearDev& A, const LinearDev& B, const Pro& pro, const GemvOut& out) {
+  if (!bzk_gq_mix_ok(A, B, pro) || !out.acc) BZ_FAIL(BZ_E_INVALID, "mixed Q4_K / Q6_K slim launch does not apply");
+  const int N = A.N + B.N, K = A.K, nsb = K / 256, ntg = (N / 64 + 7) / 8;
+  const GqMix mix{(const uint4*)B.w, (const uint2*)B.zeros, (const uint4*)B.hdr, (const __half*)B.scales, A.N / 64};
+  const double bytes = (double)A.algo_bytes + (double)B.algo_bytes;
+#define LAUNCH_GQM(FIX, NJ) BZ_LAUNCH("gemv_q4_K+q6_K<slim>", bytes, (k_gemv_gq_slim<GQ_MIX, PRO_NORM, FIX, NJ>), dim3(nsb * ntg), dim3(512), 0, s, (const uint4*)A.w, \
+    (const uint2*)nullptr, (const uint4*)A.hdr, (const __half*)nullptr, (const float*)nullptr, N, K, pro, out.acc, out.zero_buf, out.zero_n, mix)
+#define LAUNCH_GQM_NJ(FIX) do { if (K == 2048) LAUNCH_GQM(FIX, 1); else if (K == 4096) LAUNCH_GQM(FIX, 2); else LAUNCH_GQM(FIX, 4); } while (0)
+  if (pro.src.fix) LAUNCH_GQM_NJ(1); else LAUNCH_GQM_NJ(0);
+#undef LAUNCH_GQM_NJ
+#undef LAUNCH_GQM
+  BZ_HIP(hipGetLastError());
+  return BZ_OK;
+}
 
 static size_t gq_smem(int SBW) { size_t KR = (size_t)SBW * 256; return KR * 4 + KR * 3 + KR + 64; }
 
@@ -2649,7 +2687,7 @@ int bzk_gemv(hipStream_t s, const LinearDev& L, const Pro& pro, const GemvOut& o
     const int nsb = L.K / 256, ntg = (L.N / 64 + 7) / 8;
     const char* label = L.kind == LK_Q4K ? "gemv_q4_K<slim>" : "gemv_q6_K<slim>";
 #define LAUNCH_GQS(FMT, MODE, FIX, NJ) BZ_LAUNCH(label, L.algo_bytes, (k_gemv_gq_slim<FMT, MODE, FIX, NJ>), dim3(nsb * ntg), dim3(512), 0, s, (const uint4*)L.w, \
-    (const uint2*)L.zeros, (const uint4*)L.hdr, (const __half*)L.scales, L.bias, L.N, L.K, pro, out.acc, out.zero_buf, out.zero_n)
+    (const uint2*)L.zeros, (const uint4*)L.hdr, (const __half*)L.scales, L.bias, L.N, L.K, pro, out.acc, out.zero_buf, out.zero_n, GqMix{})
 #define LAUNCH_GQS_NJ(FMT, FIX) do { if (pro.mode == PRO_SILU) LAUNCH_GQS(FMT, PRO_SILU, FIX, 1); else if (L.K == 2048) LAUNCH_GQS(FMT, PRO_NORM, FIX, 1); \
     else if (L.K == 4096) LAUNCH_GQS(FMT, PRO_NORM, FIX, 2); else LAUNCH_GQS(FMT, PRO_NORM, FIX, 4); } while (0)
 #define LAUNCH_GQS_F(FMT) do { if (pro.src.fix) LAUNCH_GQS_NJ(FMT, 1); else LAUNCH_GQS_NJ(FMT, 0); } while (0)

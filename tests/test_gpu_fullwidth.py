@@ -84,6 +84,7 @@ SWITCHES = [
     # (env, cases whose kernels the switch changes)
     ("BZ_NO_GQ_SLIM=1", ["mistral-7b-q4km-2l", "tiny-q4km"]),            # generic k_gemv_gq instead of the slim one: cross-checks the slim kernels
     ("BZ_NO_ATTN_F32=1", ["mistral-7b-q4km-2l"]),                        # generic attention instead of k_attn2f
+    ("BZ_NO_GQ_MIX=1", ["mistral-7b-q4km-2l"]),                          # q/k (Q4_K) and v (Q6_K) as two slim launches instead of the mixed-format one
     ("BZ_NO_SLIM_QKV=1", ["llama3-8b-awq-2l", "tiny-awq"]),              # k_gemv_q4g instead of k_gemv_q4g_slim
     ("BZ_NO_MLP_FUSION=1", ["llama3-8b-awq-2l", "tiny-awq"]),            # gate/up and down as two launches
     ("BZ_NO_ATTN_FUSION=1", ["llama3-8b-awq-2l", "tiny-awq"]),           # attention and o_proj as two launches
