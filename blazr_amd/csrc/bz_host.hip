@@ -1420,7 +1420,9 @@ static int llama_step(bz_model* m, const StepIO& io) {
     }
     VSrc ov;
     static const bool no_fuse = getenv("BZ_NO_ATTN_FUSION") != nullptr;
-    const bool fuse_o = !no_fuse && Ld.o.parts.size() == 1 && Ld.o.fix_out && bzk_attn_oproj_slices(aa, Ld.o.parts[0]) > 0;
+    // (the f32-cache form has no split-KV partner: beyond the single-launch contexts it stays unfused)
+    const bool fuse_o = !no_fuse && Ld.o.parts.size() == 1 && Ld.o.fix_out && bzk_attn_oproj_slices(aa, Ld.o.parts[0]) > 0 &&
+                        (aa.kv.dtype != BZ_F32 || io.att_positions == 0);
     static const bool no_split = getenv("BZ_NO_ATTN_SPLIT") != nullptr;
     const bool split = !no_split && io.att_positions > 0 && m->att_ws && bzk_attn_split_ok(aa) && (!fuse_o || bzk_attn_merge_oproj_ok(aa, Ld.o.parts[0]));
     int SPL = 0, nsplit = 0;

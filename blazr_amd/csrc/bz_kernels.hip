@@ -3410,19 +3410,24 @@ __global__ __launch_bounds__(NW * 64) void k_attn2(AttnArgs a, const uint4* __re
 // attention decode, head_dim 128, F32 cache (GGUF models keep f32 activations and an f32 cache): k_attn2's structure and prologue
 // discipline -- 8 waves, lane = (row l >> 4, 8-element piece l & 15), in-register PV, online merge of 256-position chunks, dead waves
 // skipped -- with 32-byte row pieces and plain FMAs.  Replaces the one-thread-per-position kernel (14 us per layer on the Mistral shape).
-// grid = n_heads, 512 threads; not fused with o_proj.
+// grid = n_heads, 512 threads.  FUSE: + a Q4_K o_proj, as k_attn2 does for the int4 one: grid = n_heads x CS column slices, wave w of slice cs owns output
+// tile cs * 8 + w and the head's 128 k of it -- four 32-k chunks of superblock hq / 2 (a 256-k superblock spans two heads) with that superblock's
+// header --, requested at entry; the head output is quantised per 32-k chunk (quant8_x32) and the tile's partial goes to the fixed-point ring.
 // ---------------------------------------------------------------------------------------------------------
-template <int PAGED>
-__global__ __launch_bounds__(512) void k_attn2f(AttnArgs a) {
+template <int PAGED, int FUSE = 0>
+__global__ __launch_bounds__(512) void k_attn2f(AttnArgs a, const uint4* __restrict__ Wq, const uint4* __restrict__ Hd, const float* __restrict__ bias, int CS, long long* acc) {
   constexpr int HD = 128, half = 64, NW = 8, PW = 256 / NW, NL = PW / 4, NTH = NW * 64;
   __shared__ __attribute__((aligned(16))) float qf[HD], kf[HD], vf[HD];
   __shared__ float wred[2 * NW];
   __shared__ __attribute__((aligned(16))) float pout[NW * 128];
+  __shared__ __attribute__((aligned(16))) float outh[FUSE ? HD : 4];
+  __shared__ __attribute__((aligned(16))) unsigned xh[FUSE ? 32 : 4], xm[FUSE ? 32 : 4], xl[FUSE ? 32 : 4];
+  __shared__ int4 cpar[FUSE ? 8 : 1];
   asm volatile("" :: "s"(a.zero_buf), "s"(a.zero_n), "s"(a.kv.k), "s"(a.kv.v), "s"(a.kv.cap), "s"(a.kv.layer_stride), "s"(a.layer), "s"(a.act),
                "s"(a.interleaved), "s"(a.rope_cur), "s"(a.qkv.p), "s"(a.qkv.fix), "s"(a.nq), "s"(a.nkv), "s"(a.q_only), "s"(a.pos), "s"(a.out),
-               "s"(a.kv.bs), "s"(a.kv.n_kv));
+               "s"(a.kv.bs), "s"(a.kv.n_kv), "s"(Wq), "s"(Hd), "s"(bias), "s"(CS), "s"(acc));
   const int rep = a.nq / a.nkv;
-  const int hq = blockIdx.x, kvh = hq / rep;
+  const int hq = FUSE ? blockIdx.x / CS : blockIdx.x, cs = FUSE ? blockIdx.x % CS : 0, kvh = hq / rep;
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int piece = lane & 15, rsub = lane >> 4;
   const KvView& kv = a.kv;
@@ -3445,7 +3450,18 @@ __global__ __launch_bounds__(512) void k_attn2f(AttnArgs a) {
   const float* rc = a.q_only ? (const float*)a.qkv.p : a.rope_cur;
   const float pc = rc[tid % half], ps = rc[half + tid % half];
   if (a.zero_buf)
-    for (int i = blockIdx.x * NTH + tid; i < a.zero_n; i += a.nq * NTH) a.zero_buf[i] = 0;
+    for (int i = blockIdx.x * NTH + tid; i < a.zero_n; i += (FUSE ? a.nq * CS : a.nq) * NTH) a.zero_buf[i] = 0;
+  // o_proj slab of this wave (FUSE): does not depend on the position; in flight through the whole attention
+  uint4 Wb[4]; uint4 hdw = make_uint4(0, 0, 0, 0);
+  const int t0 = cs * NW + wave;
+  if (FUSE) {
+    const int K = a.nq * HD;
+    const uint4* wp = Wq + ((size_t)t0 * (K >> 5) + hq * 4) * 64 + lane;
+#pragma unroll
+    for (int c = 0; c < 4; c++) Wb[c] = ldnt(wp + c * 64);
+    hdw = Hd[((size_t)t0 * (K >> 8) + (hq >> 1)) * 64 + lane];
+  }
+  __builtin_amdgcn_sched_barrier(0);
   const int pos = __builtin_amdgcn_readfirstlane(pos_v);
   const int pmax = pos > 0 ? pos - 1 : 0;
   const int len = a.q_only ? pos : pos + 1;
@@ -3474,7 +3490,7 @@ __global__ __launch_bounds__(512) void k_attn2f(AttnArgs a) {
       vf[2 * (tid - 2 * half)] = px0; vf[2 * (tid - 2 * half) + 1] = px1;
     }
     __syncthreads();
-    if (hq % rep == 0 && tid < HD) {     // KV append, once per kv head
+    if (hq % rep == 0 && cs == 0 && tid < HD) {     // KV append, once per kv head
       size_t woff;
       if (PAGED) woff = kv_slot_off(kv, a.layer, kvh, kv.slot ? slot_v : (kv.block_table[pos / kv.bs] * kv.bs + pos % kv.bs));
       else woff = kv_row_off_t<0>(kv, a.layer, kvh, pos);
@@ -3555,7 +3571,30 @@ __global__ __launch_bounds__(512) void k_attn2f(AttnArgs a) {
       Mrun = Mn;
     }
   }
-  if (tid < 128) a.out[(size_t)hq * HD + tid] = round_act(Orun / Lrun, a.act);
+  if (!FUSE) {
+    if (tid < 128) a.out[(size_t)hq * HD + tid] = round_act(Orun / Lrun, a.act);
+    return;
+  }
+  if (tid < 128) outh[tid] = round_act(Orun / Lrun, a.act);
+  __syncthreads();
+  quant_x32<GQ_Q4K>(outh, HD, xh, xm, xl, cpar);
+  __syncthreads();
+  {
+    const unsigned hw[4] = {hdw.x, hdw.y, hdw.z, hdw.w};
+    const float d = __half2float(__ushort_as_half((unsigned short)(hw[0] & 0xffffu)));
+    const float dmin = __half2float(__ushort_as_half((unsigned short)(hw[0] >> 16)));
+    float y = 0.f;
+    if (hq & 1) {     // (compile-time chunk indices for the sub-scale extraction: two copies)
+#pragma unroll
+      for (int c = 0; c < 4; c++) y += gq_chunk_q4k(Wb[c], c, 4 + c, hw, d, dmin, (const uint4*)xh, (const uint4*)xm, (const uint4*)xl, cpar);
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; c++) y += gq_chunk_q4k(Wb[c], c, c, hw, d, dmin, (const uint4*)xh, (const uint4*)xm, (const uint4*)xl, cpar);
+    }
+    const int n = t0 * 64 + lane;
+    if (bias != nullptr && hq == 0) y += bias[n];
+    atomicAdd((unsigned long long*)(acc + n), (unsigned long long)f2fix(y));
+  }
 }
 
 static size_t attn2_smem(int nw) { return (size_t)(64 * 3 + 2 * nw + nw * 128 + 128 + 96 + 8) * 4; }
@@ -3573,9 +3612,27 @@ static int attn_oproj_plan(const AttnArgs& a, const LinearDev& L, int& NW) {
   }
   return 0;
 }
-int bzk_attn_oproj_slices(const AttnArgs& a, const LinearDev& L) { int nw; return attn_oproj_plan(a, L, nw); }
+// the f32-cache form (GGUF models): Q4_K o_proj, one tile per wave, CS = N / 512 column slices; single-launch contexts only (no split-KV path for the f32 cache)
+static int attn2f_oproj_slices(const AttnArgs& a, const LinearDev& L) {
+  static const bool off = getenv("BZ_NO_ATTN_F32") != nullptr;
+  if (off || a.hd != 128 || a.kv.dtype != BZ_F32 || a.rope_cur == nullptr || a.q_only || L.kind != LK_Q4K || L.K != a.nq * 128 || L.N % 512 || L.K % 256) return 0;
+  const int cs = L.N / 512;
+  return a.nq * cs <= 2048 ? cs : 0;
+}
+int bzk_attn_oproj_slices(const AttnArgs& a, const LinearDev& L) {
+  if (a.kv.dtype == BZ_F32) return attn2f_oproj_slices(a, L);
+  int nw; return attn_oproj_plan(a, L, nw);
+}
 
 int bzk_attn_oproj(hipStream_t s, const AttnArgs& a, const LinearDev& L, long long* acc) {
+  if (a.kv.dtype == BZ_F32) {
+    const int CS = attn2f_oproj_slices(a, L);
+    if (CS <= 0) BZ_FAIL(BZ_E_INVALID, "attn+o_proj fusion (f32 cache) does not apply to this shape");
+    if (a.kv.paged) BZ_LAUNCH("attn+o_proj<q4_K>", L.algo_bytes, (k_attn2f<1, 1>), dim3(a.nq * CS), dim3(512), 0, s, a, (const uint4*)L.w, (const uint4*)L.hdr, L.bias, CS, acc);
+    else BZ_LAUNCH("attn+o_proj<q4_K>", L.algo_bytes, (k_attn2f<0, 1>), dim3(a.nq * CS), dim3(512), 0, s, a, (const uint4*)L.w, (const uint4*)L.hdr, L.bias, CS, acc);
+    BZ_HIP(hipGetLastError());
+    return BZ_OK;
+  }
   int NW;
   const int CS = attn_oproj_plan(a, L, NW);
   if (CS <= 0) BZ_FAIL(BZ_E_INVALID, "attn+o_proj fusion does not apply to this shape");
@@ -3947,8 +4004,8 @@ int bzk_attn_decode(hipStream_t s, const AttnArgs& a) {
 #undef LAUNCH_A2
   }
   else if (a.hd == 128 && a.kv.dtype == BZ_F32 && a.rope_cur != nullptr && getenv("BZ_NO_ATTN_F32") == nullptr) {
-    if (a.kv.paged) BZ_LAUNCH("attn_decode", 0.0, k_attn2f<1>, dim3(a.nq), dim3(512), 0, s, a);
-    else BZ_LAUNCH("attn_decode", 0.0, k_attn2f<0>, dim3(a.nq), dim3(512), 0, s, a);
+    if (a.kv.paged) BZ_LAUNCH("attn_decode", 0.0, (k_attn2f<1, 0>), dim3(a.nq), dim3(512), 0, s, a, (const uint4*)nullptr, (const uint4*)nullptr, (const float*)nullptr, 1, (long long*)nullptr);
+    else BZ_LAUNCH("attn_decode", 0.0, (k_attn2f<0, 0>), dim3(a.nq), dim3(512), 0, s, a, (const uint4*)nullptr, (const uint4*)nullptr, (const float*)nullptr, 1, (long long*)nullptr);
   }
   else if (a.hd == 64) LAUNCH_ATT_DT(64);
   else if (a.hd == 128) LAUNCH_ATT_DT(128);
