@@ -143,6 +143,13 @@ SYMBOLS = {
     "bz_decode_graph_read_token": (C.c_int, [P, C.c_int64, C.POINTER(C.c_int64)]),
     "bz_decode_graph_read_logits": (C.c_int, [P, P, C.c_size_t]),
     "bz_decode_graph_free": (C.c_int, [P]),
+    "bz_decode_batch_graph_capture": (C.c_int, [P, P, C.c_int, C.c_int, C.POINTER(P)]),
+    "bz_decode_batch_graph_seed": (C.c_int, [P, P, P, P]),
+    "bz_decode_batch_graph_set_block_table": (C.c_int, [P, P]),
+    "bz_decode_batch_graph_replay": (C.c_int, [P]),
+    "bz_decode_batch_graph_read_tokens": (C.c_int, [P, C.c_int64, P]),
+    "bz_decode_batch_graph_logits": (C.c_int, [P, C.POINTER(P)]),
+    "bz_decode_batch_graph_free": (C.c_int, [P]),
     "bz_generate": (C.c_int, [P, P, C.c_int, C.POINTER(GenConfig), P, C.POINTER(GenStats)]),
     "bz_profile_step": (C.c_int, [P, P, C.c_int64, C.c_int, C.c_int, C.POINTER(KernelTime), C.c_int, C.POINTER(C.c_int)]),
     "bz_profile_step_ssm": (C.c_int, [P, P, C.c_int64, C.c_int, C.POINTER(KernelTime), C.c_int, C.POINTER(C.c_int)]),

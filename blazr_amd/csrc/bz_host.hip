@@ -1750,7 +1750,7 @@ static int prefill_ws(bz_model* m, int rows) {
 
 // Y[n][N] = R(X16[n][K] . W^T): dense 16-bit weights on the matrix cores, int4 weights through the multi-row dot4 GEMM
 static int pf_gemm(bz_model* m, const LinearDev& P, const void* x16, int n, float* y) {
-  hipStream_t st = m->dev->stream;
+  hipStream_t st = step_stream(m);
   const int act = m->cfg.act_dtype;
   if (P.kind == LK_ROWS) return bzk_gemm_nt(st, act, x16, P.w, P.bias, n, P.N, P.K, act, y);
   if (bzk_gemm_q4g_mfma_ok(P, act, n)) return bzk_gemm_q4g_mfma(st, P, x16, n, act, y, m->pf_ws, m->pf_ws_bytes);
@@ -1764,7 +1764,7 @@ struct RowsCtx { const int* row_pos = nullptr; int table_stride = 0; int max_len
 static int prefill_dense(bz_model* m, const long long* d_tok, int S, const KvView& view, int pos0, const int* slots, bool all, bz_tensor* logits_out,
                          const RowsCtx& rc = RowsCtx()) {
   const bz_model_config& c = m->cfg;
-  hipStream_t st = m->dev->stream;
+  hipStream_t st = step_stream(m);     // (a batched decode graph records this function on its capture stream)
   const int H = c.hidden, I = c.inter, nq = c.n_heads, nkv = c.n_kv_heads, hd = c.head_dim, act = c.act_dtype, dt = c.act_dtype;
   const int CH = 512;
   BZ_TRY(prefill_ws(m, std::min(S, CH)));
@@ -2715,6 +2715,156 @@ extern "C" int bz_decode_graph_capture_ssm(bz_model* m, bz_ssm_state* st, bz_dec
   return BZ_OK;
   BZ_API_END
 }
+// ---------------------------------------------------------------------------------------------------------
+// Batched decode graph (cuda_graphs_batched.rs:43-257): ONE hipGraph decodes one token for N sequences over a shared paged cache -- the
+// weight-sharing multi-row step of bz_forward_paged_batch between two bookkeeping kernels.  Stable-address device buffers, as the reference's
+// BatchedGraphState: token_buf [N], slot_mapping [N], block_table [N, max_blocks], next_token_buf [N]; beyond the reference (one shared
+// seq_len_k), every sequence has its own device-resident position, the argmax is fed back on the device and the slot comes from the block table,
+// so consecutive replays need no host work until a sequence crosses into a block the table does not hold yet.
+// ---------------------------------------------------------------------------------------------------------
+struct bz_batch_graph {
+  bz_model* m = nullptr; bz_device* dev = nullptr; bz_paged_kv* kv = nullptr;
+  hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+  int N = 0, max_blocks = 0, capacity = 0;
+  long long* tok = nullptr; long long* next = nullptr; int* pos = nullptr; int* slot = nullptr; int* table = nullptr; int* step = nullptr;
+  bz_tensor* logits = nullptr;        // [N, vocab] of the last replay
+  long long* log = nullptr;           // pinned host [LOGCAP][N]
+  std::vector<int> host_pos;          // host copy of the positions (limit checks, cache bookkeeping)
+  long long replays = 0;
+  static const int LOGCAP = 1024;
+};
+extern "C" int bz_decode_batch_graph_free(bz_batch_graph* g) {
+  if (!g) return BZ_OK;
+  if (g->dev) hipSetDevice(g->dev->id);
+  hipDeviceSynchronize();
+  if (g->exec) hipGraphExecDestroy(g->exec);
+  if (g->graph) hipGraphDestroy(g->graph);
+  for (void* p : {(void*)g->tok, (void*)g->next, (void*)g->pos, (void*)g->slot, (void*)g->table, (void*)g->step}) if (p) hipFree(p);
+  if (g->log) hipHostFree(g->log);
+  if (g->logits) bz_tensor_free(g->logits);
+  if (g->dev) bz_dev_release(g->dev);
+  delete g;
+  return BZ_OK;
+}
+extern "C" int bz_decode_batch_graph_capture(bz_model* m, bz_paged_kv* kv, int N, int max_blocks, bz_batch_graph** out) {
+  BZ_API_BEGIN
+  if (!m || !m->finalized || !kv || !out || N < 2 || N > 512 || max_blocks <= 0) BZ_FAIL(BZ_E_INVALID, "batch graph capture: bad argument (2 <= N <= 512)");
+  std::lock_guard<std::recursive_mutex> lock__(m->mu);
+  if (m->cfg.arch != BZ_ARCH_LLAMA) BZ_FAIL(BZ_E_UNSUPPORTED, "batch graph capture: llama family only");
+  if (kv->layers != m->cfg.n_layers || kv->n_kv != m->cfg.n_kv_heads || kv->hd != m->cfg.head_dim) BZ_FAIL(BZ_E_INVALID, "batch graph capture: cache does not match the model");
+  const int capacity = std::min(max_blocks * kv->block_size, m->cfg.max_seq_len);
+  const LinearDev& LH = m->lm_head.parts[0];
+  if (!prefill_eligible(m, std::max(N, prefill_min_rows()), capacity) || LH.wdt != m->cfg.act_dtype || LH.K % 64)
+    BZ_FAIL(BZ_E_UNSUPPORTED, "batch graph capture: the model does not take the weight-sharing multi-row step (int4 without act-order or dense 16-bit weights, 16-bit lm_head)");
+  BZ_HIP(hipSetDevice(m->dev->id));
+  BZ_TRY(prefill_ws(m, N));                      // workspace before the capture (allocation synchronises)
+  bz_batch_graph* g = new bz_batch_graph();
+  bz_dev_retain(m->dev); g->dev = m->dev;
+  g->m = m; g->kv = kv; g->N = N; g->max_blocks = max_blocks; g->capacity = capacity; g->host_pos.assign(N, -1);
+  int rc = BZ_OK;
+  auto fail = [&](int code) { bz_decode_batch_graph_free(g); return code; };
+  if (hipMalloc(&g->tok, (size_t)N * 8) != hipSuccess || hipMalloc(&g->next, (size_t)N * 8) != hipSuccess || hipMalloc(&g->pos, (size_t)N * 4) != hipSuccess ||
+      hipMalloc(&g->slot, (size_t)N * 4) != hipSuccess || hipMalloc(&g->table, (size_t)N * max_blocks * 4) != hipSuccess || hipMalloc(&g->step, 64) != hipSuccess ||
+      hipHostMalloc(&g->log, sizeof(long long) * bz_batch_graph::LOGCAP * N, hipHostMallocDefault) != hipSuccess)
+    return fail(BZ_E_OOM);
+  hipMemset(g->tok, 0, (size_t)N * 8); hipMemset(g->next, 0, (size_t)N * 8); hipMemset(g->pos, 0, (size_t)N * 4); hipMemset(g->slot, 0, (size_t)N * 4);
+  hipMemset(g->table, 0, (size_t)N * max_blocks * 4); hipMemset(g->step, 0, 64);
+  memset(g->log, 0xff, sizeof(long long) * bz_batch_graph::LOGCAP * N);
+  const int64_t shp[2] = {N, m->cfg.vocab};
+  rc = bz_tensor_zeros(m->dev, BZ_F32, shp, 2, &g->logits);
+  if (rc != BZ_OK) return fail(rc);
+  BZ_HIP(hipDeviceSynchronize());
+  hipStream_t cap = nullptr;
+  BZ_HIP(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
+  hipError_t eb = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal);
+  if (eb != hipSuccess) { hipStreamDestroy(cap); bz_decode_batch_graph_free(g); BZ_FAIL(BZ_E_HIP, "hipStreamBeginCapture failed: %s", hipGetErrorString(eb)); }
+  tl_capture_stream = cap;
+  rc = bzk_batch_advance(cap, g->tok, g->next, g->pos, g->slot, g->table, max_blocks, kv->block_size, N);
+  if (rc == BZ_OK) {
+    RowsCtx rcx; rcx.row_pos = g->pos; rcx.table_stride = max_blocks; rcx.max_len = capacity;
+    rc = prefill_dense(m, g->tok, N, view_of(kv, g->table, nullptr), 0, g->slot, true, g->logits, rcx);
+  }
+  if (rc == BZ_OK) rc = bzk_batch_argmax(cap, (const float*)g->logits->ptr, m->cfg.vocab, g->next, g->log, g->step, bz_batch_graph::LOGCAP, N);
+  tl_capture_stream = nullptr;
+  hipGraph_t graph = nullptr;
+  hipError_t e = hipStreamEndCapture(cap, &graph);
+  hipStreamDestroy(cap);
+  if (rc != BZ_OK) { if (graph) hipGraphDestroy(graph); return fail(rc); }
+  if (e != hipSuccess) { bz_decode_batch_graph_free(g); BZ_FAIL(BZ_E_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e)); }
+  g->graph = graph;
+  if (hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0) != hipSuccess) { bz_decode_batch_graph_free(g); BZ_FAIL(BZ_E_HIP, "hipGraphInstantiate failed"); }
+  *out = g;
+  return BZ_OK;
+  BZ_API_END
+}
+// State BEFORE the first replay: tokens[i] = the token sequence i feeds next, seq_lens[i] = its length INCLUDING that token (its position is
+// seq_lens[i] - 1), block_table = [N, max_blocks] rows (every block a sequence will reach before the next set_block_table call).
+extern "C" int bz_decode_batch_graph_seed(bz_batch_graph* g, const int64_t* tokens, const int32_t* seq_lens, const int32_t* block_table) {
+  BZ_API_BEGIN
+  if (!g || !tokens || !seq_lens || !block_table) BZ_FAIL(BZ_E_INVALID, "batch graph seed: null argument");
+  std::lock_guard<std::recursive_mutex> lock__(g->m->mu);
+  std::vector<int> p0(g->N);
+  for (int i = 0; i < g->N; i++) {
+    if (seq_lens[i] <= 0 || seq_lens[i] > g->capacity) BZ_FAIL(BZ_E_INVALID, "batch graph seed: sequence %d has length %d (capacity %d)", i, seq_lens[i], g->capacity);
+    p0[i] = seq_lens[i] - 2;                   // the advance kernel in front of the forward adds 1
+    g->host_pos[i] = seq_lens[i] - 2;
+  }
+  hipStream_t st = g->m->dev->stream;
+  int z = 0;
+  BZ_HIP(hipMemcpyAsync(g->next, tokens, (size_t)g->N * 8, hipMemcpyHostToDevice, st));
+  BZ_HIP(hipMemcpyAsync(g->pos, p0.data(), (size_t)g->N * 4, hipMemcpyHostToDevice, st));
+  BZ_HIP(hipMemcpyAsync(g->table, block_table, (size_t)g->N * g->max_blocks * 4, hipMemcpyHostToDevice, st));
+  BZ_HIP(hipMemcpyAsync(g->step, &z, 4, hipMemcpyHostToDevice, st));
+  BZ_HIP(hipStreamSynchronize(st));
+  g->replays = 0;
+  return BZ_OK;
+  BZ_API_END
+}
+extern "C" int bz_decode_batch_graph_set_block_table(bz_batch_graph* g, const int32_t* block_table) {
+  BZ_API_BEGIN
+  if (!g || !block_table) BZ_FAIL(BZ_E_INVALID, "batch graph set_block_table: null argument");
+  hipStream_t st = g->m->dev->stream;
+  BZ_HIP(hipMemcpyAsync(g->table, block_table, (size_t)g->N * g->max_blocks * 4, hipMemcpyHostToDevice, st));
+  BZ_HIP(hipStreamSynchronize(st));
+  return BZ_OK;
+  BZ_API_END
+}
+// one decode step for all N sequences: feeds back the previous argmax (or the seeded tokens), advances the positions, leaves the new argmax per sequence
+extern "C" int bz_decode_batch_graph_replay(bz_batch_graph* g) {
+  BZ_API_BEGIN
+  if (!g || !g->exec) BZ_FAIL(BZ_E_INVALID, "null batch graph");
+  std::lock_guard<std::recursive_mutex> lock__(g->m->mu);
+  int maxlen = 0;
+  for (int i = 0; i < g->N; i++) {
+    if (g->host_pos[i] + 1 >= g->capacity) BZ_FAIL(BZ_E_INVALID, "batch graph replay: sequence %d would reach position %d, beyond the capacity %d the step was captured over", i, g->host_pos[i] + 1, g->capacity);
+    maxlen = std::max(maxlen, g->host_pos[i] + 2);
+  }
+  BZ_HIP(hipGraphLaunch(g->exec, g->m->dev->stream));
+  for (int i = 0; i < g->N; i++) g->host_pos[i]++;
+  if (g->kv->seq_len < maxlen) g->kv->seq_len = maxlen;
+  g->replays++;
+  return BZ_OK;
+  BZ_API_END
+}
+// tokens produced by replay number `step` (0-based since the seed), host [N]; waits for the device
+extern "C" int bz_decode_batch_graph_read_tokens(bz_batch_graph* g, int64_t step, int64_t* tokens_out) {
+  BZ_API_BEGIN
+  if (!g || !tokens_out || step < 0 || step >= g->replays || step < g->replays - bz_batch_graph::LOGCAP) BZ_FAIL(BZ_E_INVALID, "batch graph read_tokens: step out of range");
+  BZ_HIP(hipStreamSynchronize(g->m->dev->stream));
+  const long long* row = g->log + (size_t)(step % bz_batch_graph::LOGCAP) * g->N;
+  for (int i = 0; i < g->N; i++) tokens_out[i] = row[i];
+  return BZ_OK;
+  BZ_API_END
+}
+// logits [N, vocab] of the last replay (device tensor owned by the graph)
+extern "C" int bz_decode_batch_graph_logits(bz_batch_graph* g, bz_tensor** logits_out) {
+  BZ_API_BEGIN
+  if (!g || !logits_out) BZ_FAIL(BZ_E_INVALID, "batch graph logits: null argument");
+  *logits_out = g->logits;
+  return BZ_OK;
+  BZ_API_END
+}
+
 extern "C" int bz_decode_graph_set_block_table(bz_decode_graph* g, const int32_t* bt, int n) {
   BZ_API_BEGIN
   if (!g || !g->block_table || !bt || n < 0 || n > g->max_blocks) BZ_FAIL(BZ_E_INVALID, "set_block_table: bad argument");

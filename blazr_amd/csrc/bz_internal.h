@@ -341,6 +341,8 @@ struct SsmArgs {
   float* vss;            // [n_heads]
 };
 int bzk_ssm_step(hipStream_t s, const SsmArgs& a);
+int bzk_batch_advance(hipStream_t s, long long* tok, const long long* next, int* pos, int* slot, const int* table, int stride, int bs, int N);
+int bzk_batch_argmax(hipStream_t s, const float* logits, int V, long long* next, long long* log, int* step, int logcap, int N);
 
 #if defined(__HIPCC__)
 // ---------------------------------------------------------------------------------------------------------

@@ -4072,6 +4072,49 @@ __global__ __launch_bounds__(256) void k_argmax_final(FinalArgs a) {
   }
   if (a.zero_buf) for (int i = threadIdx.x; i < a.zero_n; i += 256) a.zero_buf[i] = 0;
 }
+// ---- batched decode graph (cuda_graphs_batched.rs:43-257): the step's bookkeeping on the device ----------------------------------------------------
+// before the forward: feed back last step's argmax, advance every sequence's position, derive its slot from its block-table row
+__global__ void k_batch_advance(long long* tok, const long long* next, int* pos, int* slot, const int* table, int stride, int bs, int N) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  tok[i] = next[i];
+  const int p = pos[i] + 1;
+  pos[i] = p;
+  slot[i] = table[(size_t)i * stride + p / bs] * bs + p % bs;
+}
+// after the forward: row-wise argmax (larger value, then smaller index -- batch_argmax_to_buf) -> next[row] and the pinned token log
+__global__ __launch_bounds__(256) void k_batch_argmax(const float* __restrict__ logits, int V, long long* next, long long* log, int* step, int logcap, int N) {
+  __shared__ float sv[4]; __shared__ int si[4];
+  const int row = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const float* lg = logits + (size_t)row * V;
+  float bv = -INFINITY; int bi = 0x7fffffff;
+  for (int i = tid; i < V; i += 256) { const float v = lg[i]; if (v > bv) { bv = v; bi = i; } }   // ascending i per thread: first maximum wins
+  for (int off = 32; off >= 1; off >>= 1) {
+    const float ov = __shfl_xor(bv, off); const int oi = __shfl_xor(bi, off);
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+  }
+  if (lane == 0) { sv[wave] = bv; si[wave] = bi; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 4; w++) if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) { bv = sv[w]; bi = si[w]; }
+    next[row] = bi;
+    const int st = *step;
+    log[(size_t)(st % logcap) * N + row] = bi;
+  }
+}
+__global__ void k_batch_step_inc(int* step) { *step = *step + 1; }
+int bzk_batch_advance(hipStream_t s, long long* tok, const long long* next, int* pos, int* slot, const int* table, int stride, int bs, int N) {
+  hipLaunchKernelGGL(k_batch_advance, dim3((N + 63) / 64), dim3(64), 0, s, tok, next, pos, slot, table, stride, bs, N);
+  BZ_HIP(hipGetLastError());
+  return BZ_OK;
+}
+int bzk_batch_argmax(hipStream_t s, const float* logits, int V, long long* next, long long* log, int* step, int logcap, int N) {
+  hipLaunchKernelGGL(k_batch_argmax, dim3(N), dim3(256), 0, s, logits, V, next, log, step, logcap, N);
+  hipLaunchKernelGGL(k_batch_step_inc, dim3(1), dim3(1), 0, s, step);
+  BZ_HIP(hipGetLastError());
+  return BZ_OK;
+}
+
 int bzk_argmax_final(hipStream_t s, const FinalArgs& a) {
   BZ_LAUNCH("argmax_final", 0.0, k_argmax_final, dim3(1), dim3(256), 0, s, a);
   BZ_HIP(hipGetLastError());

@@ -640,6 +640,54 @@ def logits_to_token(dev, logits, ids, cnts, repeat_penalty=1.0, frequency_penalt
     return out
 
 
+class BatchDecodeGraph:
+    """Executor::capture_batched_graph / replay_batched_graph + BatchedGraphState (cuda_graphs_batched.rs:43-257): one hipGraph per decode step of N
+    sequences over a shared paged cache; tokens, positions and slots live on the device between replays."""
+
+    def __init__(self, model, cache, n, max_blocks):
+        h = C.c_void_p()
+        L.check(L.lib().bz_decode_batch_graph_capture(model.h, cache.h, int(n), int(max_blocks), C.byref(h)))
+        self.h, self.model, self.cache, self.n, self.max_blocks = h, model, cache, int(n), int(max_blocks)
+
+    def __del__(self):
+        try:
+            if self.h and L.alive:
+                L.lib().bz_decode_batch_graph_free(self.h)
+        except Exception:
+            pass
+
+    def _table(self, block_tables):
+        bt = np.zeros((self.n, self.max_blocks), dtype=np.int32)
+        for i, row in enumerate(block_tables):
+            bt[i, :len(row)] = row
+        return bt
+
+    def seed(self, tokens, seq_lens, block_tables):
+        t = np.ascontiguousarray(tokens, dtype=np.int64)
+        sl = np.ascontiguousarray(seq_lens, dtype=np.int32)
+        bt = self._table(block_tables)
+        L.check(L.lib().bz_decode_batch_graph_seed(self.h, _ptr(t), _ptr(sl), _ptr(bt)))
+
+    def set_block_table(self, block_tables):
+        bt = self._table(block_tables)
+        L.check(L.lib().bz_decode_batch_graph_set_block_table(self.h, _ptr(bt)))
+
+    def replay(self):
+        L.check(L.lib().bz_decode_batch_graph_replay(self.h))
+
+    def read_tokens(self, step):
+        out = np.empty(self.n, dtype=np.int64)
+        L.check(L.lib().bz_decode_batch_graph_read_tokens(self.h, int(step), _ptr(out)))
+        return out
+
+    def read_logits(self):
+        t = C.c_void_p()
+        L.check(L.lib().bz_decode_batch_graph_logits(self.h, C.byref(t)))
+        out = np.empty((self.n, self.model.c.vocab), dtype=np.float32)
+        L.check(L.lib().bz_tensor_to_host(t, _ptr(out), out.nbytes))
+        return out
+
+
 class DecodeGraph:
     """inference::decode_graph::DecodeGraph (cuda_graphs.rs:97-189) as a hipGraph."""
 

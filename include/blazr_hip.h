@@ -227,6 +227,26 @@ int bz_decode_graph_read_token(bz_decode_graph* g, int64_t step, int64_t* token_
 int bz_decode_graph_read_logits(bz_decode_graph* g, float* host, size_t n);
 int bz_decode_graph_free(bz_decode_graph* g);
 
+/* ---- batched decode graph (Executor::capture_batched_graph / replay_batched_graph + BatchedGraphState, cuda_graphs_batched.rs:43-257) --------
+ * ONE hipGraph decodes one token for N sequences over a shared paged cache: the weight-sharing multi-row step of bz_forward_paged_batch between
+ * two bookkeeping kernels.  Stable-address device buffers as in BatchedGraphState (token_buf [N], slot_mapping [N], block_table [N, max_blocks],
+ * next_token_buf [N]); beyond the reference (one shared seq_len_k) every sequence keeps its own device-resident position, the argmax
+ * (batch_argmax_to_buf) is fed back on the device and the slot is derived from the block table, so consecutive replays need no host work.
+ * Llama-family models that take the multi-row step (int4 without act-order, or dense 16-bit; 16-bit lm_head); 2 <= N <= 512. */
+typedef struct bz_batch_graph bz_batch_graph;
+int bz_decode_batch_graph_capture(bz_model* m, bz_paged_kv* kv, int N, int max_blocks, bz_batch_graph** out);
+/* state before the first replay: tokens[i] = the token sequence i feeds next, seq_lens[i] = its length INCLUDING that token (batch_decode.rs:79-88),
+ * block_table = host I32 [N, max_blocks] */
+int bz_decode_batch_graph_seed(bz_batch_graph* g, const int64_t* tokens, const int32_t* seq_lens, const int32_t* block_table);
+/* new block-table rows (a sequence is about to cross into a block the device table does not hold yet) */
+int bz_decode_batch_graph_set_block_table(bz_batch_graph* g, const int32_t* block_table);
+int bz_decode_batch_graph_replay(bz_batch_graph* g);
+/* the N greedy tokens produced by replay `step` (0-based since the seed); waits for the device */
+int bz_decode_batch_graph_read_tokens(bz_batch_graph* g, int64_t step, int64_t* tokens_out);
+/* logits F32 [N, vocab] of the last replay: a device tensor owned by the graph (do not free) */
+int bz_decode_batch_graph_logits(bz_batch_graph* g, bz_tensor** logits_out);
+int bz_decode_batch_graph_free(bz_batch_graph* g);
+
 /* ---- host decode loop (Executor::generate contiguous branch, executor_generate.rs:341-410) ---------------- */
 typedef struct {
   int32_t max_tokens;

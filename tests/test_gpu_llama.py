@@ -366,6 +366,65 @@ def test_batched_paged_decode_matches_per_sequence_oracle(device, preset, nseq):
         lm.forward_paged_batch([1, 2], pool, [0, 1], [[0], [1]], [40, 2])      # 40 tokens do not fit one block
 
 
+@pytest.mark.parametrize("preset,nseq", [("tiny-awq", 4), ("tiny-awq", 10), ("tiny-bf16", 3)])
+def test_batched_decode_graph_matches_eager_batch_and_oracle(device, preset, nseq):
+    """cuda_graphs_batched.rs:43-257: one hipGraph per decode step of N sequences.  The replayed step must equal the eager bz_forward_paged_batch
+    step bit for bit (same kernels, same rows), its device-side argmax / position / slot bookkeeping must follow the sequences across block
+    boundaries for 24 steps without host input, and the ids must be the per-sequence oracle's on the fair prefix."""
+    model = synth.make_llama(preset)
+    cfg = model["config"]
+    lm, om = runtime.LoadedModel.from_synth(device, model), orc_py.OrcLlama(model)
+    bs, per, steps = 16, 5, 24
+    def fresh_pool():
+        return runtime.LayeredPagedKvCache(device, cfg["n_layers"], nseq * per, bs, cfg["n_kv_heads"], cfg["head_dim"], _kv_dt(cfg))
+    tables = [[i + nseq * j for j in range(per)] for i in range(nseq)]            # interleaved physical blocks
+    plens = [3 + (13 * i) % 30 for i in range(nseq)]
+    prompts = [synth.prompt_tokens(n, cfg["vocab"], seed=70 + i) for i, n in enumerate(plens)]
+
+    def prefill(pool):
+        first = []
+        for p, tb in zip(prompts, tables):
+            slots = [tb[i // bs] * bs + i % bs for i in range(len(p))]
+            lg = lm.forward_with_paged_kv_cache(p, pool, slots, tb, len(p), 0).to_numpy()
+            first.append(int(lg[0].argmax()))
+        return first
+
+    # (a) eager reference run: the batched step fed with its own argmax
+    pool_a = fresh_pool()
+    toks = prefill(pool_a)
+    lens = list(plens)
+    eager_ids, eager_logits = [], []
+    for _ in range(steps):
+        lens = [n + 1 for n in lens]
+        slots = [tb[(n - 1) // bs] * bs + (n - 1) % bs for n, tb in zip(lens, tables)]
+        lg = lm.forward_paged_batch(toks, pool_a, slots, tables, lens).to_numpy()
+        toks = [int(r.argmax()) for r in lg]
+        eager_ids.append(list(toks)); eager_logits.append(lg)
+    # (b) the graph: seeded once, replayed `steps` times, nothing from the host in between
+    pool_b = fresh_pool()
+    first = prefill(pool_b)
+    g = runtime.BatchDecodeGraph(lm, pool_b, nseq, per)
+    g.seed(first, [n + 1 for n in plens], tables)
+    for s in range(steps):
+        g.replay()
+        if s in (0, 7, steps - 1):
+            assert np.array_equal(g.read_logits(), eager_logits[s]), "graph step %d differs from the eager batched step" % s
+    for s in range(steps):
+        assert g.read_tokens(s).tolist() == eager_ids[s], s
+    # (c) per-sequence oracle on the fair prefix
+    for i in range(nseq):
+        want, trace = om.generate(prompts[i], steps + 1, trace=True)
+        n = _fair_prefix(trace)
+        got = [first[i]] + [eager_ids[s][i] for s in range(steps)]
+        assert got[:n] == want[:n].tolist(), (i, got, want.tolist(), n)
+    # beyond the captured capacity: refused, not a fault
+    g2 = runtime.BatchDecodeGraph(lm, pool_b, nseq, 1)
+    g2.seed(first, [bs] * nseq, [[t[0]] for t in tables])
+    g2.replay()                                    # position bs - 1: the last one of the block
+    with pytest.raises(L.BlazrHipError):
+        g2.replay()
+
+
 def test_batched_paged_decode_beyond_one_512_row_chunk(device):
     """the multi-row pipeline works in 512-row chunks; sequence 512 + s of the second chunk must read ITS block-table row (it read
     row s before: another sequence's K/V).  520 one-block sequences, every sequence a different prompt, against per-sequence results."""
