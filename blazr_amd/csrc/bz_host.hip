@@ -2734,6 +2734,7 @@ struct bz_batch_graph {
   static const int LOGCAP = 1024;
 };
 extern "C" int bz_decode_batch_graph_free(bz_batch_graph* g) {
+  BZ_API_BEGIN
   if (!g) return BZ_OK;
   if (g->dev) hipSetDevice(g->dev->id);
   hipDeviceSynchronize();
@@ -2745,6 +2746,7 @@ extern "C" int bz_decode_batch_graph_free(bz_batch_graph* g) {
   if (g->dev) bz_dev_release(g->dev);
   delete g;
   return BZ_OK;
+  BZ_API_END
 }
 extern "C" int bz_decode_batch_graph_capture(bz_model* m, bz_paged_kv* kv, int N, int max_blocks, bz_batch_graph** out) {
   BZ_API_BEGIN
