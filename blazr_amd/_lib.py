@@ -25,7 +25,7 @@ OK, E_INVALID, E_NODEVICE, E_HIP, E_UNSUPPORTED, E_NOTFOUND, E_OOM = 0, -1, -2, 
 F32, F16, BF16, I64, I32, U32, U8 = range(7)
 ABI_VERSION = 3
 FWD_ALL_LOGITS = 1
-ROPE_NONE, ROPE_LINEAR, ROPE_LLAMA3 = 0, 1, 2
+ROPE_NONE, ROPE_LINEAR, ROPE_LLAMA3, ROPE_YARN = 0, 1, 2, 3
 ARCH_LLAMA = 0
 ARCH_MAMBA2 = 1
 ARCH_DEEPSEEK2 = 2
@@ -49,7 +49,8 @@ class ModelConfig(C.Structure):
                 ("mla_kv_lora_rank", C.c_int32), ("mla_q_lora_rank", C.c_int32), ("mla_nope_dim", C.c_int32), ("mla_rope_dim", C.c_int32),
                 ("mla_v_dim", C.c_int32), ("moe_n_experts", C.c_int32), ("moe_top_k", C.c_int32), ("moe_n_shared", C.c_int32),
                 ("moe_inter", C.c_int32), ("moe_first_dense", C.c_int32), ("moe_norm_topk", C.c_int32), ("moe_routed_scale", C.c_float),
-                ("reserved", C.c_int32 * 8)]
+                ("rope_beta_fast", C.c_float), ("rope_beta_slow", C.c_float), ("rope_attn_factor", C.c_float), ("mla_softmax_mscale", C.c_float),
+                ("reserved", C.c_int32 * 4)]
 
 
 class GenConfig(C.Structure):

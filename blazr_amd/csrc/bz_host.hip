@@ -754,8 +754,23 @@ static void rope_tables_host(const bz_model_config& c, std::vector<float>& cs, s
   const int half = c.head_dim / 2;
   cs.resize((size_t)c.max_seq_len * half); sn.resize((size_t)c.max_seq_len * half);
   const double PI2 = 6.283185307179586476925286766559;
+  // YaRN (HF _compute_yarn_parameters): NTK-by-parts blend of the interpolated and the original frequencies between the dims that make beta_fast and
+  // beta_slow rotations over the original context; cos / sin scaled by the attention factor
+  double ylow = 0.0, yhigh = 0.0; float af = 1.0f;
+  if (c.rope_scaling == BZ_ROPE_YARN) {
+    const double bf = c.rope_beta_fast > 0.f ? c.rope_beta_fast : 32.0, bsl = c.rope_beta_slow > 0.f ? c.rope_beta_slow : 1.0;
+    const double dim = c.head_dim, base = c.rope_theta, omax = c.rope_original_max_pos;
+    auto corr = [&](double rot) { return dim * log(omax / (rot * PI2)) / (2.0 * log(base)); };
+    ylow = std::max(floor(corr(bf)), 0.0); yhigh = std::min(ceil(corr(bsl)), dim - 1.0);
+    if (ylow == yhigh) yhigh += 0.001;
+    af = c.rope_attn_factor > 0.f ? c.rope_attn_factor : (c.rope_factor <= 1.f ? 1.0f : (float)(0.1 * log((double)c.rope_factor) + 1.0));
+  }
   for (int i = 0; i < half; i++) {
     double inv = 1.0 / pow((double)c.rope_theta, (double)(2 * i) / (double)c.head_dim);
+    if (c.rope_scaling == BZ_ROPE_YARN) {
+      const double ramp = std::min(std::max(((double)i - ylow) / (yhigh - ylow), 0.0), 1.0), ext = 1.0 - ramp;
+      inv = (inv / (double)c.rope_factor) * (1.0 - ext) + inv * ext;
+    }
     if (c.rope_scaling == BZ_ROPE_LINEAR) inv /= (double)c.rope_factor;
     else if (c.rope_scaling == BZ_ROPE_LLAMA3) {
       double low_wl = (double)c.rope_original_max_pos / (double)c.rope_low_freq_factor;
@@ -771,10 +786,14 @@ static void rope_tables_host(const bz_model_config& c, std::vector<float>& cs, s
     const float invf = (float)inv;
     for (int p = 0; p < c.max_seq_len; p++) {
       float ang = (float)p * invf;
-      cs[(size_t)p * half + i] = (float)cos((double)ang);
-      sn[(size_t)p * half + i] = (float)sin((double)ang);
+      cs[(size_t)p * half + i] = (float)cos((double)ang) * af;
+      sn[(size_t)p * half + i] = (float)sin((double)ang) * af;
     }
   }
+}
+static float mla_softmax_scale(const bz_model_config& c) {
+  const float ms = c.mla_softmax_mscale > 0.f ? c.mla_softmax_mscale : 1.0f;
+  return 1.0f / sqrtf((float)(c.mla_nope_dim + c.mla_rope_dim)) * ms * ms;     // HF DeepseekV2Attention: softmax_scale * mscale * mscale
 }
 
 static int finalize_mamba2(bz_model* m);
@@ -1597,7 +1616,7 @@ static int dsv2_step(bz_model* m, const StepIO& io) {
     }
     ma.qkv = qkva; ma.kv_norm = L.kv_norm; ma.eps = c.rms_eps; ma.wkvb = L.kv_b; ma.wdt = L.kv_b_dt; ma.cos_t = m->cos_t; ma.sin_t = m->sin_t; ma.pos = io.d_pos;
     ma.n_heads = NH; ma.rank = R; ma.nope = DN; ma.rope = DR; ma.vdim = DV; ma.act = act; ma.kv = io.kv; ma.layer = l; ma.out = m->attn_out;
-    ma.scale = 1.0f / sqrtf((float)(DN + DR));
+    ma.scale = mla_softmax_scale(c);
     ma.ws = m->mla_ws; ma.nsplit = m->mla_nsplit;
     BZ_TRY(bzk_mla_attn(st, ma, c.max_seq_len));
     Pro pp{}; pp.mode = PRO_PLAIN; pp.src = VSrc{m->attn_out, 0}; pp.act = act; pp.H = 0;
@@ -1889,7 +1908,7 @@ static int dsv2_prefill(bz_model* m, const long long* d_tok, int S, const KvView
       MlaArgs ma{};
       ma.qkv = VSrc{m->pf_qkv, 0}; ma.kv_norm = L.kv_norm; ma.eps = c.rms_eps; ma.wkvb = L.kv_b; ma.wdt = L.kv_b_dt; ma.cos_t = m->cos_t; ma.sin_t = m->sin_t; ma.pos = nullptr;
       ma.n_heads = NH; ma.rank = R; ma.nope = DN; ma.rope = DR; ma.vdim = DV; ma.act = act; ma.kv = view; ma.layer = l; ma.out = m->dpf_att;
-      ma.scale = 1.0f / sqrtf((float)(DN + DR));
+      ma.scale = mla_softmax_scale(c);
       ma.batch = n; ma.pos0 = p0; ma.q_stride = QN; ma.out_stride = (long long)NH * DV;
       BZ_TRY(bzk_mla_attn(st, ma, p0 + n));
       BZ_TRY(bzk_pf_cvt16(st, dt, m->dpf_att, (size_t)n * NH * DV, m->pf_x16));

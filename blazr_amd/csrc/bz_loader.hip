@@ -335,6 +335,17 @@ int hf_config_to_pod(const JVal& j, bz_model_config* c, QuantInfo* q) {
       c->rope_original_max_pos = (int)rs->i64("original_max_position_embeddings", 8192);
       if (ty == "llama3") c->rope_scaling = BZ_ROPE_LLAMA3;
       else if (ty == "linear") c->rope_scaling = BZ_ROPE_LINEAR;
+      else if (ty == "yarn") {
+        // HF _compute_yarn_parameters / DeepseekV2YarnRotaryEmbedding: beta_fast / beta_slow (0 = defaults 32 / 1), the cos / sin factor, and -- DeepSeek-V2 --
+        // the softmax mscale from mscale_all_dim
+        c->rope_scaling = BZ_ROPE_YARN;
+        c->rope_beta_fast = (float)rs->f64("beta_fast", 0.0); c->rope_beta_slow = (float)rs->f64("beta_slow", 0.0);
+        auto mscale = [&](double ms) { return c->rope_factor <= 1.0f ? 1.0 : 0.1 * ms * log((double)c->rope_factor) + 1.0; };
+        const double ms = rs->f64("mscale", 0.0), msa = rs->f64("mscale_all_dim", 0.0);
+        if (rs->get("attention_factor")) c->rope_attn_factor = (float)rs->f64("attention_factor", 0.0);
+        else if (ms > 0.0 && msa > 0.0) c->rope_attn_factor = (float)(mscale(ms) / mscale(msa));
+        if (lower.find("deepseek") != std::string::npos && msa > 0.0) c->mla_softmax_mscale = (float)mscale(msa);
+      }
       else if (ty == "default" || ty.empty()) c->rope_scaling = BZ_ROPE_NONE;
       else BZ_FAIL(BZ_E_UNSUPPORTED, "config.json: rope_scaling type '%s' is not implemented", ty.c_str());
     }

@@ -137,7 +137,7 @@ def make_config(cfg):
         c.tie_embeddings = int(bool(cfg.get("tie_embeddings")))
         c.rope_theta = cfg["rope_theta"]
         c.rope_interleaved = 1
-        c.rope_scaling, c.rope_factor, c.rope_low_freq_factor, c.rope_high_freq_factor, c.rope_original_max_pos = L.ROPE_NONE, 1.0, 1.0, 4.0, 8192
+        _rope_scaling_to_config(cfg, c)
         return c
     c.arch = L.ARCH_LLAMA
     for k in ("hidden", "n_layers", "n_heads", "n_kv_heads", "head_dim", "inter", "vocab", "max_seq_len"):
@@ -147,13 +147,33 @@ def make_config(cfg):
     c.tie_embeddings = int(bool(cfg.get("tie_embeddings")))
     c.rope_theta = cfg["rope_theta"]
     c.rope_interleaved = int(cfg.get("rope_interleaved", 0))
+    _rope_scaling_to_config(cfg, c)
+    return c
+
+
+def yarn_mscale(factor, mscale=1.0):
+    """HF yarn_get_mscale"""
+    import math
+    return 1.0 if factor <= 1.0 else 0.1 * mscale * math.log(factor) + 1.0
+
+
+def _rope_scaling_to_config(cfg, c):
+    """rope_scaling dict (HF config.json names) -> the bz_model_config fields (loader/safetensors/config.rs:83-95)"""
     rs = cfg.get("rope_scaling") or {}
-    c.rope_scaling = {"none": L.ROPE_NONE, "linear": L.ROPE_LINEAR, "llama3": L.ROPE_LLAMA3}[rs.get("type", "none")]
+    c.rope_scaling = {"none": L.ROPE_NONE, "linear": L.ROPE_LINEAR, "llama3": L.ROPE_LLAMA3, "yarn": L.ROPE_YARN}[rs.get("type", "none")]
     c.rope_factor = rs.get("factor", 1.0)
     c.rope_low_freq_factor = rs.get("low_freq_factor", 1.0)
     c.rope_high_freq_factor = rs.get("high_freq_factor", 4.0)
     c.rope_original_max_pos = rs.get("original_max_position_embeddings", 8192)
-    return c
+    c.rope_beta_fast, c.rope_beta_slow = rs.get("beta_fast", 0.0), rs.get("beta_slow", 0.0)
+    c.rope_attn_factor, c.mla_softmax_mscale = 0.0, 0.0
+    if rs.get("type") == "yarn":
+        if "attention_factor" in rs:
+            c.rope_attn_factor = rs["attention_factor"]
+        elif "mscale" in rs and "mscale_all_dim" in rs:      # DeepSeek-V2: cos / sin by mscale / mscale_all_dim, softmax scale by mscale_all_dim^2
+            c.rope_attn_factor = yarn_mscale(c.rope_factor, rs["mscale"]) / yarn_mscale(c.rope_factor, rs["mscale_all_dim"])
+        if cfg.get("arch") == "deepseek2" and rs.get("mscale_all_dim"):
+            c.mla_softmax_mscale = yarn_mscale(c.rope_factor, rs["mscale_all_dim"])
 
 
 _AWQ_SHIFTS = np.array([0, 16, 4, 20, 8, 24, 12, 28], dtype=np.uint32)  # awq.rs:32

@@ -46,7 +46,7 @@ enum { BZ_F32 = 0, BZ_F16 = 1, BZ_BF16 = 2, BZ_I64 = 3, BZ_I32 = 4, BZ_U32 = 5, 
 enum { BZ_GGML_F32 = 0, BZ_GGML_F16 = 1, BZ_GGML_Q8_0 = 8, BZ_GGML_Q4_K = 12, BZ_GGML_Q6_K = 14, BZ_GGML_BF16 = 30 };
 
 enum { BZ_ARCH_LLAMA = 0, BZ_ARCH_MAMBA2 = 1, BZ_ARCH_DEEPSEEK2 = 2 };
-enum { BZ_ROPE_NONE = 0, BZ_ROPE_LINEAR = 1, BZ_ROPE_LLAMA3 = 2 };
+enum { BZ_ROPE_NONE = 0, BZ_ROPE_LINEAR = 1, BZ_ROPE_LLAMA3 = 2, BZ_ROPE_YARN = 3 };
 
 typedef struct bz_device bz_device;
 typedef struct bz_tensor bz_tensor;
@@ -79,7 +79,11 @@ typedef struct {
   int32_t mla_kv_lora_rank, mla_q_lora_rank, mla_nope_dim, mla_rope_dim, mla_v_dim;
   int32_t moe_n_experts, moe_top_k, moe_n_shared, moe_inter, moe_first_dense, moe_norm_topk;
   float   moe_routed_scale;
-  int32_t reserved[8];
+  /* BZ_ROPE_YARN (RopeScalingConfig beta_fast / beta_slow / attention_factor, loader/safetensors/config.rs:83-95 -- the reference maps them to None = the
+   * defaults): 0 means default (beta_fast 32, beta_slow 1, attention_factor 0.1 ln(factor) + 1).  cos / sin are multiplied by the attention factor.
+   * mla_softmax_mscale (DeepSeek-V2 YaRN, mscale_all_dim): the MLA softmax scale is multiplied by its square; 0 = 1. */
+  float   rope_beta_fast, rope_beta_slow, rope_attn_factor, mla_softmax_mscale;
+  int32_t reserved[4];
 } bz_model_config;
 
 /* ---- errors / device ------------------------------------------------------------------------------- */

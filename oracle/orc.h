@@ -83,9 +83,10 @@ void orc_rms_norm(const float* x, const float* w, int n, float eps, int act, flo
 typedef struct {
   int   head_dim, max_pos;
   float theta;
-  int   scaling_type;        /* 0 none, 1 linear, 2 llama3 */
+  int   scaling_type;        /* 0 none, 1 linear, 2 llama3, 3 yarn */
   float factor, low_freq_factor, high_freq_factor;
   int   original_max_pos;
+  float beta_fast, beta_slow, attn_factor;   /* yarn: 0 = defaults (32, 1, 0.1 ln(factor) + 1); cos / sin are multiplied by attn_factor */
 } orc_rope_cfg;
 /* cos/sin tables [max_pos][head_dim/2] f32 */
 void orc_rope_tables(const orc_rope_cfg* c, float* cos_t, float* sin_t);
@@ -210,6 +211,7 @@ typedef struct {
   float routed_scale; int norm_topk;
   float rms_eps; int act_dtype;
   orc_rope_cfg rope;                                          /* head_dim / max_pos filled by orc_dsv2_new */
+  float softmax_mscale;                                       /* YaRN (HF DeepseekV2Attention: softmax_scale * mscale^2, mscale from mscale_all_dim); 0 = 1 */
 } orc_dsv2_cfg;
 typedef struct {
   const float* attn_norm; const float* ffn_norm; const float* kv_norm; const float* q_norm;

@@ -102,7 +102,8 @@ int orc_dsv2_forward(const orc_dsv2* m, const int64_t* tokens, int S, orc_mla_ca
   const int H = c->hidden, NH = c->n_heads, R = c->kv_lora_rank, DN = c->nope_dim, DR = c->rope_dim, DV = c->v_dim, act = c->act_dtype, V = c->vocab;
   const int QH = DN + DR, W = R + DR;
   if (position + S > kc->capacity || position + S > c->max_seq_len) return -1;
-  const float scale = 1.0f / sqrtf((float)QH);
+  const float msc = c->softmax_mscale > 0.f ? c->softmax_mscale : 1.0f;
+  const float scale = 1.0f / sqrtf((float)QH) * msc * msc;
   const int imax = c->inter > c->n_shared * c->moe_inter ? c->inter : c->n_shared * c->moe_inter;
   float* h = (float*)malloc(sizeof(float) * H); float* xn = (float*)malloc(sizeof(float) * H); float* o = (float*)malloc(sizeof(float) * H);
   float* q = (float*)malloc(sizeof(float) * (size_t)NH * QH); float* kva = (float*)malloc(sizeof(float) * W);

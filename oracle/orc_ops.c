@@ -25,8 +25,28 @@ void orc_rms_norm(const float* x, const float* w, int n, float eps, int act, flo
 void orc_rope_tables(const orc_rope_cfg* c, float* cos_t, float* sin_t) {
   const int half = c->head_dim / 2;
   const double PI2 = 6.283185307179586476925286766559;
+  /* yarn: HF modeling_rope_utils._compute_yarn_parameters (the reference carries beta_fast / beta_slow / attention_factor as None = defaults,
+     loader/safetensors/config.rs:83-95): correction range [low, high] in dims, linear ramp, blend of interpolated and original inv_freq */
+  double ylow = 0.0, yhigh = 0.0; float af = 1.0f;
+  if (c->scaling_type == 3) {
+    const double bf = c->beta_fast > 0.f ? c->beta_fast : 32.0, bs = c->beta_slow > 0.f ? c->beta_slow : 1.0;
+    const double dim = c->head_dim, lb = log((double)c->theta), omax = c->original_max_pos;
+    ylow = floor(dim * log(omax / (bf * PI2)) / (2.0 * lb));
+    yhigh = ceil(dim * log(omax / (bs * PI2)) / (2.0 * lb));
+    if (ylow < 0.0) ylow = 0.0;
+    if (yhigh > dim - 1.0) yhigh = dim - 1.0;
+    if (ylow == yhigh) yhigh += 0.001;
+    af = c->attn_factor > 0.f ? c->attn_factor : (c->factor <= 1.f ? 1.0f : (float)(0.1 * log((double)c->factor) + 1.0));
+  }
   for (int i = 0; i < half; i++) {
     double inv = 1.0 / pow((double)c->theta, (double)(2 * i) / (double)c->head_dim);
+    if (c->scaling_type == 3) {
+      double ramp = ((double)i - ylow) / (yhigh - ylow);
+      if (ramp < 0.0) ramp = 0.0;
+      if (ramp > 1.0) ramp = 1.0;
+      const double ext = 1.0 - ramp;                      /* weight of the original (extrapolated) frequency */
+      inv = (inv / (double)c->factor) * (1.0 - ext) + inv * ext;
+    }
     if (c->scaling_type == 1) {
       inv /= (double)c->factor;
     } else if (c->scaling_type == 2) { /* llama3 (config.rs:83-95 field mapping; HF _compute_llama3_parameters) */
@@ -43,8 +63,8 @@ void orc_rope_tables(const orc_rope_cfg* c, float* cos_t, float* sin_t) {
     const float invf = (float)inv;
     for (int p = 0; p < c->max_pos; p++) {
       float ang = (float)p * invf;
-      cos_t[(size_t)p * half + i] = (float)cos((double)ang);
-      sin_t[(size_t)p * half + i] = (float)sin((double)ang);
+      cos_t[(size_t)p * half + i] = (float)cos((double)ang) * af;
+      sin_t[(size_t)p * half + i] = (float)sin((double)ang) * af;
     }
   }
 }

@@ -31,7 +31,7 @@ class Linear(C.Structure):
 class RopeCfg(C.Structure):
     _fields_ = [("head_dim", C.c_int), ("max_pos", C.c_int), ("theta", C.c_float), ("scaling_type", C.c_int),
                 ("factor", C.c_float), ("low_freq_factor", C.c_float), ("high_freq_factor", C.c_float),
-                ("original_max_pos", C.c_int)]
+                ("original_max_pos", C.c_int), ("beta_fast", C.c_float), ("beta_slow", C.c_float), ("attn_factor", C.c_float)]
 
 
 class LlamaCfg(C.Structure):
@@ -71,7 +71,7 @@ class Dsv2Cfg(C.Structure):
                 ("kv_lora_rank", C.c_int), ("q_lora_rank", C.c_int), ("nope_dim", C.c_int), ("rope_dim", C.c_int), ("v_dim", C.c_int),
                 ("inter", C.c_int), ("n_experts", C.c_int), ("top_k", C.c_int), ("n_shared", C.c_int), ("moe_inter", C.c_int),
                 ("first_dense", C.c_int), ("routed_scale", C.c_float), ("norm_topk", C.c_int), ("rms_eps", C.c_float),
-                ("act_dtype", C.c_int), ("rope", RopeCfg)]
+                ("act_dtype", C.c_int), ("rope", RopeCfg), ("softmax_mscale", C.c_float)]
 
 
 class Dsv2Layer(C.Structure):
@@ -297,13 +297,7 @@ class OrcLlama:
         c.act_dtype = _DT[cfg["act_dtype"]]
         c.rope_interleaved = int(cfg.get("rope_interleaved", 0))
         c.max_seq_len = cfg["max_seq_len"]
-        rs = cfg.get("rope_scaling") or {}
-        c.rope.theta = cfg["rope_theta"]
-        c.rope.scaling_type = {"none": 0, "linear": 1, "llama3": 2}[rs.get("type", "none")]
-        c.rope.factor = rs.get("factor", 1.0)
-        c.rope.low_freq_factor = rs.get("low_freq_factor", 1.0)
-        c.rope.high_freq_factor = rs.get("high_freq_factor", 4.0)
-        c.rope.original_max_pos = rs.get("original_max_position_embeddings", 8192)
+        _rope_cfg(cfg, c.rope)
         self.cfg = c
         self.h = lib().orc_llama_new(C.byref(c))
         self.keep = []
@@ -452,6 +446,31 @@ class OrcMamba2:
         return (out[:n], tr[:n]) if trace else out[:n]
 
 
+def _yarn_mscale(factor, mscale=1.0):
+    return 1.0 if factor <= 1.0 else 0.1 * mscale * float(np.log(factor)) + 1.0
+
+
+def _rope_cfg(cfg, r):
+    """rope_scaling dict (HF names) -> orc_rope_cfg; returns the MLA softmax mscale (DeepSeek-V2 YaRN: mscale_all_dim), 0 = none"""
+    rs = cfg.get("rope_scaling") or {}
+    r.theta = cfg["rope_theta"]
+    r.scaling_type = {"none": 0, "linear": 1, "llama3": 2, "yarn": 3}[rs.get("type", "none")]
+    r.factor = rs.get("factor", 1.0)
+    r.low_freq_factor = rs.get("low_freq_factor", 1.0)
+    r.high_freq_factor = rs.get("high_freq_factor", 4.0)
+    r.original_max_pos = rs.get("original_max_position_embeddings", 8192)
+    r.beta_fast, r.beta_slow, r.attn_factor = rs.get("beta_fast", 0.0), rs.get("beta_slow", 0.0), 0.0
+    sm = 0.0
+    if rs.get("type") == "yarn":
+        if "attention_factor" in rs:
+            r.attn_factor = rs["attention_factor"]
+        elif "mscale" in rs and "mscale_all_dim" in rs:
+            r.attn_factor = _yarn_mscale(r.factor, rs["mscale"]) / _yarn_mscale(r.factor, rs["mscale_all_dim"])
+        if cfg.get("arch") == "deepseek2" and rs.get("mscale_all_dim"):
+            sm = _yarn_mscale(r.factor, rs["mscale_all_dim"])
+    return sm
+
+
 class OrcDsv2:
     """Oracle DeepSeek-V2 (MLA + MoE) model built from a blazr_amd.synth.make_dsv2 dict."""
 
@@ -463,7 +482,7 @@ class OrcDsv2:
             setattr(c, k, int(cfg[k]))
         c.routed_scale, c.norm_topk = float(cfg["routed_scale"]), int(bool(cfg["norm_topk"]))
         c.rms_eps, c.act_dtype = cfg["rms_eps"], _DT[cfg["act_dtype"]]
-        c.rope.theta, c.rope.scaling_type, c.rope.factor = cfg["rope_theta"], 0, 1.0
+        c.softmax_mscale = _rope_cfg(cfg, c.rope)
         self.cfg = c
         self.h = lib().orc_dsv2_new(C.byref(c))
         self.keep = []

@@ -85,10 +85,13 @@ def test_error_behaviour(pair, device):
         runtime.LoadedModel(device, bad)                               # not a multiple of 8
 
 
-@pytest.mark.parametrize("over", [dict(n_shared=0), dict(first_dense=0, n_layers=2), dict(top_k=8), dict(n_experts=0, first_dense=3),
+_YARN = dict(type="yarn", factor=40, original_max_position_embeddings=48, beta_fast=32, beta_slow=1, mscale=0.707, mscale_all_dim=0.707)
+
+
+@pytest.mark.parametrize("over", [dict(n_shared=0), dict(first_dense=0, n_layers=2), dict(top_k=8), dict(n_experts=0, first_dense=3), dict(rope_scaling=_YARN),
                                   dict(kv_lora_rank=64, nope_dim=32, v_dim=128, rope_dim=16), dict(act_dtype="f16"), dict(q_lora_rank=96),
                                   dict(q_lora_rank=64, act_dtype="f32")],
-                         ids=["no-shared", "all-moe", "topk-all", "dense-only", "odd-mla-dims", "f16", "q-lora", "q-lora-f32"])
+                         ids=["no-shared", "all-moe", "topk-all", "dense-only", "yarn-mscale", "odd-mla-dims", "f16", "q-lora", "q-lora-f32"])
 def test_config_variants(device, over):
     # edges of the MoE / MLA configuration space against the oracle (prefill rows + a few decode steps)
     model = synth.make_dsv2("tiny-dsv2", **over)

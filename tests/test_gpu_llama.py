@@ -76,6 +76,33 @@ def test_prefill_all_logits(pair, device):
     orc_py.lib().orc_kv_free(okv)
 
 
+def test_yarn_rope_scaling(device):
+    """rope_scaling type "yarn" (RopeScalingConfig, config.rs:83-95; rejected in round 1): the product's RoPE tables equal the oracle's bit for bit
+    (both restate HF's _compute_yarn_parameters; the oracle's tables are pinned against an independent numpy form in tests/test_oracle.py), and
+    prompt + decode logits of a model that runs far beyond its original context agree with the oracle"""
+    rs = dict(type="yarn", factor=4.0, original_max_position_embeddings=32)
+    model = synth.make_llama("tiny-awq", rope_scaling=rs)
+    cfg = model["config"]
+    lm, om = runtime.LoadedModel.from_synth(device, model), orc_py.OrcLlama(model)
+    cos, sin = lm.rope_caches()
+    rc = orc_py.RopeCfg()
+    orc_py._rope_cfg(cfg, rc)
+    rc.head_dim, rc.max_pos = cfg["head_dim"], cfg["max_seq_len"]
+    wc, ws = np.empty_like(cos), np.empty_like(sin)
+    orc_py.lib().orc_rope_tables(orc_py.C.byref(rc), wc.ctypes.data_as(orc_py.C.c_void_p), ws.ctypes.data_as(orc_py.C.c_void_p))
+    assert np.array_equal(cos, wc) and np.array_equal(sin, ws)
+    plain = synth.make_llama("tiny-awq")
+    pc, _ = runtime.LoadedModel.from_synth(device, plain).rope_caches()
+    assert not np.array_equal(pc, cos)                       # (the scaling is not a no-op)
+    p = synth.prompt_tokens(70, cfg["vocab"], seed=3)         # positions well past original_max_position_embeddings
+    kv = runtime.LayeredKvCache(device, cfg["n_layers"], 1, cfg["n_kv_heads"], 96, cfg["max_seq_len"], cfg["head_dim"], _kv_dt(cfg))
+    okv = om.new_kv(96)
+    _check_logits(lm.forward_with_kv_cache(p, kv, 0, all_logits=True).to_numpy(), om.forward_kv(p, okv, 0, all_logits=True), cfg["act_dtype"])
+    for i in range(4):
+        _check_logits(lm.forward_with_kv_cache([7 + i], kv, 70 + i).to_numpy(), om.forward_kv([7 + i], okv, 70 + i), cfg["act_dtype"])
+    orc_py.lib().orc_kv_free(okv)
+
+
 def test_decode_steps_and_cache_growth(pair, device):
     model, lm, om = pair
     cfg = model["config"]

@@ -160,6 +160,22 @@ def test_huggingface_config_rope_scaling():
     assert q["quant_method"] is None and c.act_dtype == L.F16        # config.rs:27: no torch_dtype -> "f16"
 
 
+def test_huggingface_config_rope_scaling_yarn():
+    """YaRN (RopeScalingConfig scaling_type "yarn", config.rs:83-95): the Llama form (default betas / attention factor) and DeepSeek-V2's
+    (mscale / mscale_all_dim: cos / sin factor = their mscale ratio, softmax mscale from mscale_all_dim)"""
+    base = dict(vocab_size=10, hidden_size=256, num_hidden_layers=2, num_attention_heads=4, intermediate_size=512)
+    c, _ = runtime.config_from_hf_json(json.dumps(dict(base, model_type="llama", rope_scaling=dict(rope_type="yarn", factor=4.0, original_max_position_embeddings=2048))))
+    assert c.rope_scaling == L.ROPE_YARN and c.rope_factor == 4.0 and c.rope_original_max_pos == 2048
+    assert c.rope_beta_fast == 0.0 and c.rope_beta_slow == 0.0 and c.rope_attn_factor == 0.0 and c.mla_softmax_mscale == 0.0      # 0 = defaults
+    ds = dict(base, model_type="deepseek_v2", architectures=["DeepseekV2ForCausalLM"], kv_lora_rank=64, qk_nope_head_dim=32, qk_rope_head_dim=16, v_head_dim=32,
+              n_routed_experts=4, num_experts_per_tok=2, moe_intermediate_size=64,
+              rope_scaling=dict(type="yarn", factor=40, original_max_position_embeddings=4096, beta_fast=32, beta_slow=1, mscale=0.707, mscale_all_dim=0.707))
+    c, _ = runtime.config_from_hf_json(json.dumps(ds))
+    want = 0.1 * 0.707 * np.log(40.0) + 1.0
+    assert c.rope_scaling == L.ROPE_YARN and c.rope_factor == 40.0 and c.rope_beta_fast == 32.0 and c.rope_beta_slow == 1.0
+    assert abs(c.rope_attn_factor - 1.0) < 1e-6 and abs(c.mla_softmax_mscale - want) < 1e-6
+
+
 def test_hf_config_defaults_dtype_and_quantization():
     # model/config.rs:119-145 defaults; config.rs:15-28 torch_dtype; detect_arch.rs:79-90 quantization_config; awq.rs:69-71 forces f16
     c, q = runtime.config_from_hf_json(json.dumps(dict(model_type="llama", vocab_size=10, hidden_size=256, num_hidden_layers=2, num_attention_heads=4,
@@ -172,7 +188,7 @@ def test_hf_config_defaults_dtype_and_quantization():
     with pytest.raises(L.BlazrHipError):
         runtime.config_from_hf_json("{not json")
     with pytest.raises(L.BlazrHipError):
-        runtime.config_from_hf_json(json.dumps(dict(model_type="llama", hidden_size=8, rope_scaling=dict(rope_type="yarn", factor=40))))
+        runtime.config_from_hf_json(json.dumps(dict(model_type="llama", hidden_size=8, rope_scaling=dict(rope_type="longrope", factor=40))))
 
 
 @pytest.mark.parametrize("preset", ["tiny-bf16", "tiny-awq", "tiny-mamba2", "tiny-dsv2", "deepseek-v2-lite", "llama3.2-1b-bf16"])
