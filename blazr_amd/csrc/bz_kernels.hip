@@ -3161,12 +3161,12 @@ __device__ __forceinline__ size_t kv_row_off_t(const KvView& kv, int layer, int 
   return (size_t)layer * kv.layer_stride + ((size_t)kvh * kv.cap + p) * kv.hd;
 }
 
-template <int KVDT, int FUSE, int TPW, int NW, int PAGED>   // NW waves per block: each owns 256/NW positions of a chunk
+template <int KVDT, int FUSE, int TPW, int NW, int PAGED, int HD = 128>   // NW waves per block: each owns 256/NW positions of a chunk; HD = 128 or 64 (64: not fused)
 __global__ __launch_bounds__(NW * 64) void k_attn2(AttnArgs a, const uint4* __restrict__ W, const __half* __restrict__ S,
                                                const unsigned char* __restrict__ Z, const float* __restrict__ bias, int CS, long long* acc) {
-  // Mapping: a chunk is 256 positions, wave w owns positions c0 + PW w .. +PW-1 (PW = 256/NW).  One wave-wide 16-byte load fetches 4 whole
-  // rows (1 KiB contiguous in the contiguous cache): lane l holds piece (l & 15) = elements 8*(l&15)..+7 of row 4 i + (l >> 4)
-  // for load i = 0..PW/4-1.  A row's score is a 4-DOT2 partial per lane reduced over its 16 lanes -- and lands exactly in the
+  // Mapping: a chunk is 256 positions, wave w owns positions c0 + PW w .. +PW-1 (PW = 256/NW).  One wave-wide 16-byte load fetches RPL = 512 / HD whole
+  // rows (1 KiB contiguous in the contiguous cache; 4 rows of 128 elements, 8 rows of 64): lane l holds piece (l % NPC) = elements 8 piece .. +7 of row
+  // RPL i + l / NPC for load i = 0..PW/RPL-1 (NPC = HD / 8 pieces per row).  A row's score is a 4-DOT2 partial per lane reduced over its 16 lanes -- and lands exactly in the
   // lanes that hold that row's V pieces, so P.V accumulates in registers (8 outputs per lane) with no LDS image.
   //
   // Prologue discipline (measured with s_memrealtime stamps per wave):
@@ -3176,7 +3176,8 @@ __global__ __launch_bounds__(NW * 64) void k_attn2(AttnArgs a, const uint4* __re
   //  * cos/sin come from a row staged at a fixed address by the embed kernel, so RoPE does not wait for position -> table;
   //  * the CU's vector-memory path moves 64 B/clk, so a full 256-row K/V chunk (128 KiB per block) is ~1 us of issue at ANY context length:
   //    waves whose positions lie beyond the context skip their loads and their score / PV work.
-  constexpr int HD = 128, half = 64, PW = 256 / NW, NL = PW / 4, OW = NW > 8 ? 8 : NW, NTH = NW * 64;   // OW waves carry o_proj tiles
+  static_assert(HD == 128 || (HD == 64 && !FUSE), "head_dim 128, or 64 without the fused o_proj");
+  constexpr int half = HD / 2, NPC = HD / 8, RPL = 64 / NPC, PW = 256 / NW, NL = PW / RPL, OW = NW > 8 ? 8 : NW, NTH = NW * 64;   // OW waves carry o_proj tiles
   asm volatile("" :: "s"(a.zero_buf), "s"(a.zero_n), "s"(a.kv.k), "s"(a.kv.v), "s"(a.kv.cap), "s"(a.kv.layer_stride), "s"(a.layer), "s"(a.act),
                "s"(a.interleaved), "s"(a.rope_cur), "s"(a.qkv.p), "s"(a.qkv.fix), "s"(a.nq), "s"(a.nkv), "s"(a.q_only), "s"(a.pos), "s"(W), "s"(S),
                "s"(Z), "s"(bias), "s"(CS), "s"(acc), "s"(a.out), "s"(a.stamps), "s"(a.kv.bs), "s"(a.kv.n_kv));   // one scalar-load batch for all arguments
@@ -3192,7 +3193,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn2(AttnArgs a, const uint4* __re
   const int rep = a.nq / a.nkv;
   const int hq = FUSE ? blockIdx.x / CS : blockIdx.x, cs = FUSE ? blockIdx.x % CS : 0, kvh = hq / rep;
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const int piece = lane & 15, rsub = lane >> 4;
+  const int piece = lane % NPC, rsub = lane / NPC;
 #define STAMP(i) do { if (a.stamps && blockIdx.x == 0 && tid == 0) a.stamps[i] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
   STAMP(0);
   const KvView& kv = a.kv;
@@ -3251,17 +3252,17 @@ __global__ __launch_bounds__(NW * 64) void k_attn2(AttnArgs a, const uint4* __re
       const int r0 = wave * PW + rsub;
 #pragma unroll
       for (int i = 0; i < NL; i++) {
-        const unsigned off = (unsigned)min(r0 + 4 * i, pmax) * HD + piece * 8;
+        const unsigned off = (unsigned)min(r0 + RPL * i, pmax) * HD + piece * 8;
         kr[i] = *(const uint4*)(kb + off);
         vr[i] = *(const uint4*)(vb + off);
       }
     } else {
       int blk[NL];
 #pragma unroll
-      for (int i = 0; i < NL; i++) blk[i] = kv.block_table[min(wave * PW + 4 * i + rsub, pmax) / kv.bs];
+      for (int i = 0; i < NL; i++) blk[i] = kv.block_table[min(wave * PW + RPL * i + rsub, pmax) / kv.bs];
 #pragma unroll
       for (int i = 0; i < NL; i++) {
-        const int pp = min(wave * PW + 4 * i + rsub, pmax);
+        const int pp = min(wave * PW + RPL * i + rsub, pmax);
         const size_t off = (((size_t)blk[i] * kv.n_kv + kvh) * kv.bs + (pp % kv.bs)) * HD + piece * 8;
         kr[i] = *(const uint4*)(kb0 + off);
         vr[i] = *(const uint4*)(vb0 + off);
@@ -3280,11 +3281,11 @@ __global__ __launch_bounds__(NW * 64) void k_attn2(AttnArgs a, const uint4* __re
       const unsigned p0 = pack2<KVDT>(y0, y1);
       dst[ia] = (unsigned short)(p0 & 0xffffu);
       dst[ib] = (unsigned short)(p0 >> 16);
-    } else if (tid < 2 * half + 64) {
+    } else if (tid < 3 * half) {
       v2[tid - 2 * half] = pack2<KVDT>(px0, px1);
     }
     __syncthreads();
-    if (hq % rep == 0 && cs == 0 && tid < 64) {   // KV append, once per kv head: 64 threads x 4-byte pairs
+    if (hq % rep == 0 && cs == 0 && tid < half) {   // KV append, once per kv head: HD / 2 threads x 4-byte pairs
       size_t woff;
       if (PAGED) woff = kv_slot_off(kv, a.layer, kvh, kv.slot ? slot_v : (kv.block_table[pos / kv.bs] * kv.bs + pos % kv.bs));
       else woff = kv_row_off_t<0>(kv, a.layer, kvh, pos);
@@ -3292,7 +3293,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn2(AttnArgs a, const uint4* __re
       ((unsigned*)((unsigned short*)kv.v + woff))[tid] = v2[tid];
     }
   } else {
-    if (tid < 64) q2[tid] = pack2<KVDT>(px0, px1);
+    if (tid < half) q2[tid] = pack2<KVDT>(px0, px1);
     __syncthreads();
   }
   STAMP(2);
@@ -3307,7 +3308,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn2(AttnArgs a, const uint4* __re
       if (won) {
 #pragma unroll
         for (int i = 0; i < NL; i++) {
-          const size_t off = kv_row_off_t<PAGED>(kv, 0, kvh, min(c0 + wave * PW + 4 * i + rsub, pmax)) + piece * 8;
+          const size_t off = kv_row_off_t<PAGED>(kv, 0, kvh, min(c0 + wave * PW + RPL * i + rsub, pmax)) + piece * 8;
           kr[i] = *(const uint4*)(kb0 + off);
           vr[i] = *(const uint4*)(vb0 + off);
         }
@@ -3319,12 +3320,12 @@ __global__ __launch_bounds__(NW * 64) void k_attn2(AttnArgs a, const uint4* __re
     if (won) {
 #pragma unroll
       for (int i = 0; i < NL; i++) {
-        const int p = c0 + wave * PW + 4 * i + rsub;
+        const int p = c0 + wave * PW + RPL * i + rsub;
         uint4 kk = kr[i];
         if (!a.q_only && p == pos) { kk = ((const uint4*)k2)[piece]; vr[i] = ((const uint4*)v2)[piece]; }
         float d = dot2acc<KVDT>(kk.x, qq.x, 0.f);
         d = dot2acc<KVDT>(kk.y, qq.y, d); d = dot2acc<KVDT>(kk.z, qq.z, d); d = dot2acc<KVDT>(kk.w, qq.w, d);
-        d = grp_reduce<16, OpAdd>(d);
+        d = grp_reduce<NPC, OpAdd>(d);
         sc_[i] = (p < len) ? d * scale : -INFINITY;
         mloc = fmaxf(mloc, sc_[i]);
       }
@@ -3349,23 +3350,27 @@ __global__ __launch_bounds__(NW * 64) void k_attn2(AttnArgs a, const uint4* __re
 #pragma unroll
         for (int q = 0; q < 8; q++) accv[q] = fmaf(e, v[q], accv[q]);
       }
-      // rows of the wave: the 4 lane groups hold different rows -> reduce over xor 16, 32 (the 16 lanes of a group are replicas for lsum)
+      // rows of the wave: the RPL lane groups hold different rows -> reduce over xor (8,) 16, 32 (the lanes of a group are replicas for lsum)
+      if (NPC == 8) lsum += dpp_get<DPP_ROR8>(lsum);
       lsum = xrow32<OpAdd>(xrow16<OpAdd>(lsum));
 #pragma unroll
-      for (int q = 0; q < 8; q++) accv[q] = xrow32<OpAdd>(xrow16<OpAdd>(accv[q]));
+      for (int q = 0; q < 8; q++) {
+        if (NPC == 8) accv[q] += dpp_get<DPP_ROR8>(accv[q]);
+        accv[q] = xrow32<OpAdd>(xrow16<OpAdd>(accv[q]));
+      }
     }
     STAMP(4);
-    if (lane < 16) {
-      *(float4*)(pout + wave * 128 + piece * 8) = make_float4(accv[0], accv[1], accv[2], accv[3]);
-      *(float4*)(pout + wave * 128 + piece * 8 + 4) = make_float4(accv[4], accv[5], accv[6], accv[7]);
+    if (lane < NPC) {
+      *(float4*)(pout + wave * HD + piece * 8) = make_float4(accv[0], accv[1], accv[2], accv[3]);
+      *(float4*)(pout + wave * HD + piece * 8 + 4) = make_float4(accv[4], accv[5], accv[6], accv[7]);
     }
     if (lane == 0) wred[NW + wave] = lsum;
     __syncthreads();
     STAMP(5);
-    if (tid < 128) {
+    if (tid < HD) {
       float oc = 0.f, Lc = 0.f;
 #pragma unroll
-      for (int w = 0; w < NW; w += 2) { oc += pout[w * 128 + tid] + pout[(w + 1) * 128 + tid]; Lc += wred[NW + w] + wred[NW + w + 1]; }
+      for (int w = 0; w < NW; w += 2) { oc += pout[w * HD + tid] + pout[(w + 1) * HD + tid]; Lc += wred[NW + w] + wred[NW + w + 1]; }
       const float Mn = fmaxf(Mrun, Mc);
       const float fa = (Mrun == -INFINITY) ? 0.f : expf(Mrun - Mn), fb = expf(Mc - Mn);
       Orun = Orun * fa + oc * fb;
@@ -3374,10 +3379,10 @@ __global__ __launch_bounds__(NW * 64) void k_attn2(AttnArgs a, const uint4* __re
     }
   }
   if (!FUSE) {
-    if (tid < 128) a.out[(size_t)hq * HD + tid] = round_act(Orun / Lrun, a.act);
+    if (tid < HD) a.out[(size_t)hq * HD + tid] = round_act(Orun / Lrun, a.act);
     return;
   }
-  if (tid < 128) outh[tid] = round_act(Orun / Lrun, a.act);
+  if (tid < HD) outh[tid] = round_act(Orun / Lrun, a.act);
   // slab scales / zero points (L2-resident, tiny): fetched now, used after the quantisation
   float sc[FUSE ? TPW : 1]; int zp[FUSE ? TPW : 1];
   {
@@ -3996,11 +4001,16 @@ int bzk_attn_decode(hipStream_t s, const AttnArgs& a) {
 #define LAUNCH_ATT(HD, DT) BZ_LAUNCH("attn_decode", 0.0, (k_attn_decode<HD, DT>), dim3(a.nq), dim3(256), smem, s, a)
 #define LAUNCH_ATT_DT(HD) do { if (a.kv.dtype == BZ_F16) LAUNCH_ATT(HD, BZ_F16); else if (a.kv.dtype == BZ_BF16) LAUNCH_ATT(HD, BZ_BF16); \
                                else LAUNCH_ATT(HD, BZ_F32); } while (0)
-  if (a.hd == 128 && a.kv.dtype != BZ_F32) {
-#define LAUNCH_A2(DT, PG) BZ_LAUNCH("attn_decode", 0.0, (k_attn2<DT, 0, 1, 8, PG>), dim3(a.nq), dim3(512), attn2_smem(8), s, a, (const uint4*)nullptr, \
+  static const bool no_a64 = getenv("BZ_NO_ATTN2_HD64") != nullptr;
+  if ((a.hd == 128 || (a.hd == 64 && a.rope_cur != nullptr && !no_a64)) && a.kv.dtype != BZ_F32) {
+    // the 8-wave lane = (row, 8-element piece) kernel: head_dim 128, and 64 (Llama-3.2-1B) with 8 rows per wave-wide load
+#define LAUNCH_A2(DT, PG, HDV) BZ_LAUNCH("attn_decode", 0.0, (k_attn2<DT, 0, 1, 8, PG, HDV>), dim3(a.nq), dim3(512), attn2_smem(8), s, a, (const uint4*)nullptr, \
     (const __half*)nullptr, (const unsigned char*)nullptr, (const float*)nullptr, 1, (long long*)nullptr)
-    if (a.kv.dtype == BZ_F16) { if (a.kv.paged) LAUNCH_A2(BZ_F16, 1); else LAUNCH_A2(BZ_F16, 0); }
-    else { if (a.kv.paged) LAUNCH_A2(BZ_BF16, 1); else LAUNCH_A2(BZ_BF16, 0); }
+#define LAUNCH_A2_P(DT, HDV) do { if (a.kv.paged) LAUNCH_A2(DT, 1, HDV); else LAUNCH_A2(DT, 0, HDV); } while (0)
+#define LAUNCH_A2_H(DT) do { if (a.hd == 128) LAUNCH_A2_P(DT, 128); else LAUNCH_A2_P(DT, 64); } while (0)
+    if (a.kv.dtype == BZ_F16) LAUNCH_A2_H(BZ_F16); else LAUNCH_A2_H(BZ_BF16);
+#undef LAUNCH_A2_H
+#undef LAUNCH_A2_P
 #undef LAUNCH_A2
   }
   else if (a.hd == 128 && a.kv.dtype == BZ_F32 && a.rope_cur != nullptr && getenv("BZ_NO_ATTN_F32") == nullptr) {

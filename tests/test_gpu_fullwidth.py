@@ -91,6 +91,7 @@ SWITCHES = [
     ("BZ_NO_ATTN_SPLIT=1 BZ_SPLIT_MIN=4", ["tiny-bf16"]),                # long-context split disabled
     ("BZ_SPLIT_MIN=4", ["llama3-8b-awq-2l", "tiny-bf16"]),               # split-KV attention from position 4 on
     ("BZ_NO_ROWS_SPLITK=1", ["mamba2-2.7b-2l", "llama3.2-1b-bf16-2l"]),  # row GEMVs without split-K
+    ("BZ_NO_ATTN2_HD64=1", ["llama3.2-1b-bf16-2l", "tiny-bf16"]),         # one-thread-per-position attention instead of k_attn2<head_dim 64>
     ("BZ_NO_ROWS2=1", ["mamba2-2.7b-2l", "llama3.2-1b-bf16-2l", "deepseek-v2-lite-2l"]),   # 16-row workgroup GEMV (k_gemv_rows) instead of the balanced role kernel
     ("BZ_NO_MLA_SPLIT=1", ["deepseek-v2-lite-2l"]),                      # MLA decode: one workgroup per head over the whole context
     ("BZ_NO_MOE_ROUTE_FUSION=1", ["deepseek-v2-lite-2l"]),               # router launch (last-workgroup top-k) + plain grouped gate/up
