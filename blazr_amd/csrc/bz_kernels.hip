@@ -1535,6 +1535,9 @@ __global__ __launch_bounds__(256) void k_gemv_gq(const uint4* __restrict__ Wq, c
 //   MODE NORM: x = RMSNorm(h + prev) slice (full-H sum of squares per block)      MODE SILU: x = R(R(silu(gate)) * up) slice
 // grid = (K / 256) x ceil(N / 512), 512 threads
 // ---------------------------------------------------------------------------------------------------------
+// (the balanced role form of k_gemv_rows2 on these layouts -- 256 workgroups of 4 row + 8 tile waves, units = (superblock slice, tile), 512 activations quantised
+// once per workgroup, Q4_K one unit ahead -- was built, is parity-clean, and is slower on every Mistral-7B launch: gate/up / down 15.1 vs 13.9 us, Q6_K 15.6 vs 13.4,
+// q/k/v mix 10.3 vs 9.5: eight tile waves per CU cannot keep the dot / epilogue chains of this arithmetic busy; the slim kernel's 16 computing waves per CU can.)
 // (several tiles per wave -- one norm prologue per ~256 workgroups instead of 896 on gate/up, the next tile's superblock prefetched under the current dots --
 // was built and measured too: 132 / 169 registers instead of 77-115, one workgroup per CU, 527 vs 539 tok/s.  The kernel is bound by its dot issue, not its prologues.)
 // (a 12-wave role-split form of this kernel, as in k_gemv_q4g_slim, was built and measured on the Mistral-7B Q4_K_M shape: 539 vs 549 tok/s -- no gain; the f32
