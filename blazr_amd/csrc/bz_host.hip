@@ -1440,10 +1440,14 @@ static int llama_step(bz_model* m, const StepIO& io) {
     VSrc ov;
     static const bool no_fuse = getenv("BZ_NO_ATTN_FUSION") != nullptr;
     // (the f32-cache form has no split-KV partner: beyond the single-launch contexts it stays unfused)
-    const bool fuse_o = !no_fuse && Ld.o.parts.size() == 1 && Ld.o.fix_out && bzk_attn_oproj_slices(aa, Ld.o.parts[0]) > 0 &&
-                        (aa.kv.dtype != BZ_F32 || io.att_positions == 0);
+    const bool fuse_cap = !no_fuse && Ld.o.parts.size() == 1 && Ld.o.fix_out && bzk_attn_oproj_slices(aa, Ld.o.parts[0]) > 0;
     static const bool no_split = getenv("BZ_NO_ATTN_SPLIT") != nullptr;
-    const bool split = !no_split && io.att_positions > 0 && m->att_ws && bzk_attn_split_ok(aa) && (!fuse_o || bzk_attn_merge_oproj_ok(aa, Ld.o.parts[0]));
+    const bool split_wanted = !no_split && io.att_positions > 0 && m->att_ws && bzk_attn_split_ok(aa);
+    const bool merge_fused = fuse_cap && Ld.o.parts[0].kind == LK_Q4G && bzk_attn_merge_oproj_ok(aa, Ld.o.parts[0]);
+    // long contexts: split-KV attention merged with the o_proj where that form exists (int4); otherwise attention (split or not) and a separate o_proj launch --
+    // the fused single-launch kernel reads the context once per column slice, which only pays while the context is short
+    const bool fuse_o = fuse_cap && (io.att_positions == 0 || (split_wanted && merge_fused));
+    const bool split = split_wanted && (!fuse_o || merge_fused);
     int SPL = 0, nsplit = 0;
     if (split) {
       // long context: split-KV partials (all query heads of a group share the K/V rows), then merge (+ o_proj)

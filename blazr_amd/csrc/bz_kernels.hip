@@ -3179,7 +3179,9 @@ __global__ __launch_bounds__(NW * 64) void k_attn2(AttnArgs a, const uint4* __re
   //  * cos/sin come from a row staged at a fixed address by the embed kernel, so RoPE does not wait for position -> table;
   //  * the CU's vector-memory path moves 64 B/clk, so a full 256-row K/V chunk (128 KiB per block) is ~1 us of issue at ANY context length:
   //    waves whose positions lie beyond the context skip their loads and their score / PV work.
-  static_assert(HD == 128 || (HD == 64 && !FUSE), "head_dim 128, or 64 without the fused o_proj");
+  // FUSE: 0 attention only; 1 + int4 (AWQ / GPTQ) o_proj; 2 + dense 16-bit o_proj (weights [N][K] in the cache dtype: the head's HD k of an output row are one
+  // 16-byte piece per lane, RPL output rows per wave-wide load -- the K/V row mapping again)
+  static_assert(HD == 128 || (HD == 64 && FUSE != 1), "head_dim 128, or 64 without the int4 o_proj");
   constexpr int half = HD / 2, NPC = HD / 8, RPL = 64 / NPC, PW = 256 / NW, NL = PW / RPL, OW = NW > 8 ? 8 : NW, NTH = NW * 64;   // OW waves carry o_proj tiles
   asm volatile("" :: "s"(a.zero_buf), "s"(a.zero_n), "s"(a.kv.k), "s"(a.kv.v), "s"(a.kv.cap), "s"(a.kv.layer_stride), "s"(a.layer), "s"(a.act),
                "s"(a.interleaved), "s"(a.rope_cur), "s"(a.qkv.p), "s"(a.qkv.fix), "s"(a.nq), "s"(a.nkv), "s"(a.q_only), "s"(a.pos), "s"(W), "s"(S),
@@ -3225,9 +3227,18 @@ __global__ __launch_bounds__(NW * 64) void k_attn2(AttnArgs a, const uint4* __re
     for (int i = blockIdx.x * NTH + tid; i < a.zero_n; i += nblk * NTH) a.zero_buf[i] = 0;
   }
   // (1) o_proj slab of this wave (FUSE): does not depend on the position; in flight through the whole attention
-  uint4 Wb[FUSE ? TPW : 1][4];
+  uint4 Wb[FUSE == 1 ? TPW : 1][4];
   const int t0 = (cs * OW + wave % OW) * TPW;   // waves >= OW mirror a slab (L2 hits) and skip the atomics
-  if (FUSE) {
+  constexpr int DLD = FUSE == 2 ? TPW : 1;       // FUSE 2: TPW = wave-wide loads of RPL output rows each
+  uint4 Wd[DLD];
+  const int nd0 = (cs * NW + wave) * DLD * RPL;  // first output row of this wave
+  if (FUSE == 2) {
+    const int K = a.nq * HD;
+    const unsigned short* wd = (const unsigned short*)W;
+#pragma unroll
+    for (int t = 0; t < DLD; t++) Wd[t] = ldnt((const uint4*)(wd + (size_t)(nd0 + t * RPL + rsub) * K + hq * HD + piece * 8));
+  }
+  if (FUSE == 1) {
     const int K = a.nq * HD;
 #pragma unroll
     for (int t = 0; t < TPW; t++) {
@@ -3386,12 +3397,30 @@ __global__ __launch_bounds__(NW * 64) void k_attn2(AttnArgs a, const uint4* __re
     return;
   }
   if (tid < HD) outh[tid] = round_act(Orun / Lrun, a.act);
+  if (FUSE == 2) {
+    // dense o_proj: this lane's 8 weights of each output row against its 8 head outputs, reduced over the row's NPC lanes, one fixed-point atomic per (head, row)
+    __syncthreads();
+    const float4 oa = *(const float4*)(outh + piece * 8), ob = *(const float4*)(outh + piece * 8 + 4);
+#pragma unroll
+    for (int t = 0; t < DLD; t++) {
+      float w8[8];
+      unpack2<KVDT>(Wd[t].x, w8[0], w8[1]); unpack2<KVDT>(Wd[t].y, w8[2], w8[3]); unpack2<KVDT>(Wd[t].z, w8[4], w8[5]); unpack2<KVDT>(Wd[t].w, w8[6], w8[7]);
+      float d = w8[0] * oa.x + w8[1] * oa.y + w8[2] * oa.z + w8[3] * oa.w + w8[4] * ob.x + w8[5] * ob.y + w8[6] * ob.z + w8[7] * ob.w;
+      d = grp_reduce<NPC, OpAdd>(d);
+      const int n = nd0 + t * RPL + rsub;
+      if (piece == 0) {
+        if (bias != nullptr && hq == 0) d += bias[n];
+        atomicAdd((unsigned long long*)(acc + n), (unsigned long long)f2fix(d));
+      }
+    }
+    return;
+  }
   // slab scales / zero points (L2-resident, tiny): fetched now, used after the quantisation
-  float sc[FUSE ? TPW : 1]; int zp[FUSE ? TPW : 1];
+  float sc[FUSE == 1 ? TPW : 1]; int zp[FUSE == 1 ? TPW : 1];
   {
     const int G = (a.nq * HD) >> 7;
 #pragma unroll
-    for (int t = 0; t < (FUSE ? TPW : 1); t++) {
+    for (int t = 0; t < (FUSE == 1 ? TPW : 1); t++) {
       sc[t] = __half2float(S[((size_t)(t0 + t) * G + hq) * 64 + lane]);
       zp[t] = Z[((size_t)(t0 + t) * G + hq) * 64 + lane];
     }
@@ -3402,7 +3431,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn2(AttnArgs a, const uint4* __re
   __syncthreads();
   STAMP(7);
 #pragma unroll
-  for (int t = 0; t < (FUSE ? TPW : 1); t++) {
+  for (int t = 0; t < (FUSE == 1 ? TPW : 1); t++) {
     double y = 0.0;
     q4g_consume(Wb[t], 0, xpl, gpar, sc[t], zp[t], y);
     const int n = (t0 + t) * 64 + lane;
@@ -3627,8 +3656,19 @@ static int attn2f_oproj_slices(const AttnArgs& a, const LinearDev& L) {
   const int cs = L.N / 512;
   return a.nq * cs <= 2048 ? cs : 0;
 }
+// dense 16-bit o_proj in the cache dtype (Llama-3.2-1B: head_dim 64, N 2048): 8 column slices, RPL rows per wave-wide load, 1..4 loads per wave
+static int attn_dense_oproj_loads(const AttnArgs& a, const LinearDev& L) {
+  static const bool off = getenv("BZ_NO_ATTN2_HD64") != nullptr;
+  if (off || L.kind != LK_ROWS || L.wdt != a.kv.dtype || (a.kv.dtype != BZ_F16 && a.kv.dtype != BZ_BF16) || (a.hd != 64 && a.hd != 128) || a.q_only || a.rope_cur == nullptr) return 0;
+  if (L.K != a.nq * a.hd || a.nq * 8 > 2048) return 0;
+  const int rpl = 512 / a.hd, per_wave = L.N / 64;          // 8 slices x 8 waves
+  if (L.N % 64 || per_wave % rpl) return 0;
+  const int loads = per_wave / rpl;
+  return (loads == 1 || loads == 2 || loads == 4) ? loads : 0;
+}
 int bzk_attn_oproj_slices(const AttnArgs& a, const LinearDev& L) {
   if (a.kv.dtype == BZ_F32) return attn2f_oproj_slices(a, L);
+  if (L.kind == LK_ROWS) return attn_dense_oproj_loads(a, L) > 0 ? 8 : 0;
   int nw; return attn_oproj_plan(a, L, nw);
 }
 
@@ -3638,6 +3678,22 @@ int bzk_attn_oproj(hipStream_t s, const AttnArgs& a, const LinearDev& L, long lo
     if (CS <= 0) BZ_FAIL(BZ_E_INVALID, "attn+o_proj fusion (f32 cache) does not apply to this shape");
     if (a.kv.paged) BZ_LAUNCH("attn+o_proj<q4_K>", L.algo_bytes, (k_attn2f<1, 1>), dim3(a.nq * CS), dim3(512), 0, s, a, (const uint4*)L.w, (const uint4*)L.hdr, L.bias, CS, acc);
     else BZ_LAUNCH("attn+o_proj<q4_K>", L.algo_bytes, (k_attn2f<0, 1>), dim3(a.nq * CS), dim3(512), 0, s, a, (const uint4*)L.w, (const uint4*)L.hdr, L.bias, CS, acc);
+    BZ_HIP(hipGetLastError());
+    return BZ_OK;
+  }
+  if (L.kind == LK_ROWS) {
+    const int DL = attn_dense_oproj_loads(a, L);
+    if (DL <= 0) BZ_FAIL(BZ_E_INVALID, "attn+o_proj fusion (dense) does not apply to this shape");
+#define LAUNCH_AD(DT, T, PG, HDV) BZ_LAUNCH("attn+o_proj<dense>", L.algo_bytes, (k_attn2<DT, 2, T, 8, PG, HDV>), dim3(a.nq * 8), dim3(512), attn2_smem(8), s, a, \
+    (const uint4*)L.w, (const __half*)nullptr, (const unsigned char*)nullptr, L.bias, 8, acc)
+#define LAUNCH_AD_P(DT, T, HDV) do { if (a.kv.paged) LAUNCH_AD(DT, T, 1, HDV); else LAUNCH_AD(DT, T, 0, HDV); } while (0)
+#define LAUNCH_AD_T(DT, HDV) do { if (DL == 1) LAUNCH_AD_P(DT, 1, HDV); else if (DL == 2) LAUNCH_AD_P(DT, 2, HDV); else LAUNCH_AD_P(DT, 4, HDV); } while (0)
+#define LAUNCH_AD_H(DT) do { if (a.hd == 64) LAUNCH_AD_T(DT, 64); else LAUNCH_AD_T(DT, 128); } while (0)
+    if (a.kv.dtype == BZ_F16) LAUNCH_AD_H(BZ_F16); else LAUNCH_AD_H(BZ_BF16);
+#undef LAUNCH_AD_H
+#undef LAUNCH_AD_T
+#undef LAUNCH_AD_P
+#undef LAUNCH_AD
     BZ_HIP(hipGetLastError());
     return BZ_OK;
   }
