@@ -360,23 +360,23 @@ __device__ __forceinline__ uint4 q4_frag_f16(unsigned w, f16x2 mz) {   // mz = -
   return r;
 }
 
-template <int WPB>   // waves per block, side by side along N
+template <int WPB, int MT = 2>   // waves per block, side by side along N; MT 32-row tiles per wave (1: decode batches / prompts of <= 32 rows -- half the MFMAs and half the activation loads)
 __global__ __launch_bounds__(WPB * 64) void k_gemm_q4g_mfma(const uint4* __restrict__ W, const __half* __restrict__ Sc, const unsigned char* __restrict__ Z,
                                                        const float* __restrict__ bias, int N, int K, const unsigned short* __restrict__ X, int S, int act,
                                                        float* __restrict__ Y, int GPB, float* __restrict__ part) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
   const int tile = blockIdx.x * WPB + wave;            // 64-column tile of this wave
   if (tile * 64 >= N) return;
-  const int r0 = blockIdx.y * 64;
+  const int r0 = blockIdx.y * 32 * MT;
   const int G = K >> 7, C32 = K >> 5;
   const uint4* wp = W + (size_t)tile * C32 * 64 + lane;
   const unsigned short* xa0 = X + (size_t)min(r0 + c, S - 1) * K + 8 * h;        // rows r0 + c and r0 + 32 + c (clamped; masked at the store)
   const unsigned short* xa1 = X + (size_t)min(r0 + 32 + c, S - 1) * K + 8 * h;
   const __half* sp = Sc + (size_t)tile * G * 64 + c;
   const unsigned char* zp = Z + (size_t)tile * G * 64 + c;
-  f32x16 tot[2][2], grp[2][2];
+  f32x16 tot[MT][2], grp[MT][2];
 #pragma unroll
-  for (int a = 0; a < 2; a++)
+  for (int a = 0; a < MT; a++)
 #pragma unroll
     for (int b = 0; b < 2; b++)
 #pragma unroll
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(WPB * 64) void k_gemm_q4g_mfma(const uint4* __restr
   u32x4 wn = __builtin_nontemporal_load((const u32x4*)(wp + (size_t)kc0 * 64));
   uint4 an[2][2];
   an[0][0] = *(const uint4*)(xa0 + kc0 * 32); an[0][1] = *(const uint4*)(xa0 + kc0 * 32 + 16);
-  an[1][0] = *(const uint4*)(xa1 + kc0 * 32); an[1][1] = *(const uint4*)(xa1 + kc0 * 32 + 16);
+  if (MT == 2) { an[1][0] = *(const uint4*)(xa1 + kc0 * 32); an[1][1] = *(const uint4*)(xa1 + kc0 * 32 + 16); }
   // K split (small S): block z owns groups [z GPB, (z+1) GPB) and writes an unrounded partial; k_q4g_mfma_reduce sums them in a fixed order
   const int g_beg = blockIdx.z * GPB, g_end = min(G, g_beg + GPB);
   for (int g = g_beg; g < g_end; g++) {
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(WPB * 64) void k_gemm_q4g_mfma(const uint4* __restr
     const _Float16 m0 = (_Float16)(-(1024.0f + (float)zp[(size_t)g * 64])), m1 = (_Float16)(-(1024.0f + (float)zp[(size_t)g * 64 + 32]));
     const f16x2 mz0 = {m0, m0}, mz1 = {m1, m1};
 #pragma unroll
-    for (int a = 0; a < 2; a++)
+    for (int a = 0; a < MT; a++)
 #pragma unroll
       for (int b = 0; b < 2; b++)
 #pragma unroll
@@ -404,19 +404,20 @@ __global__ __launch_bounds__(WPB * 64) void k_gemm_q4g_mfma(const uint4* __restr
       const int kc = g * 4 + cc;
       const u32x4 w = wn;
       uint4 a[2][2];
-      a[0][0] = an[0][0]; a[0][1] = an[0][1]; a[1][0] = an[1][0]; a[1][1] = an[1][1];
+      a[0][0] = an[0][0]; a[0][1] = an[0][1];
+      if (MT == 2) { a[1][0] = an[1][0]; a[1][1] = an[1][1]; }
       {
         const int kn = min(kc + 1, C32 - 1);            // last chunk: a harmless re-load
         wn = __builtin_nontemporal_load((const u32x4*)(wp + (size_t)kn * 64));
         an[0][0] = *(const uint4*)(xa0 + kn * 32); an[0][1] = *(const uint4*)(xa0 + kn * 32 + 16);
-        an[1][0] = *(const uint4*)(xa1 + kn * 32); an[1][1] = *(const uint4*)(xa1 + kn * 32 + 16);
+        if (MT == 2) { an[1][0] = *(const uint4*)(xa1 + kn * 32); an[1][1] = *(const uint4*)(xa1 + kn * 32 + 16); }
       }
       const u32x2 r01 = __builtin_amdgcn_permlane32_swap(w.x, w.y, false, false);   // .x: columns 0-31 {k 0-7 | k 8-15}; .y: columns 32-63
       const u32x2 r23 = __builtin_amdgcn_permlane32_swap(w.z, w.w, false, false);   // same for k 16-31
       const uint4 b00 = q4_frag_f16(r01.x, mz0), b01 = q4_frag_f16(r01.y, mz1);
       const uint4 b10 = q4_frag_f16(r23.x, mz0), b11 = q4_frag_f16(r23.y, mz1);
 #pragma unroll
-      for (int mt = 0; mt < 2; mt++) {
+      for (int mt = 0; mt < MT; mt++) {
         grp[mt][0] = mfma16<BZ_F16>(a[mt][0], b00, grp[mt][0]);
         grp[mt][1] = mfma16<BZ_F16>(a[mt][0], b01, grp[mt][1]);
         grp[mt][0] = mfma16<BZ_F16>(a[mt][1], b10, grp[mt][0]);
@@ -424,7 +425,7 @@ __global__ __launch_bounds__(WPB * 64) void k_gemm_q4g_mfma(const uint4* __restr
       }
     }
 #pragma unroll
-    for (int mt = 0; mt < 2; mt++)
+    for (int mt = 0; mt < MT; mt++)
 #pragma unroll
       for (int i = 0; i < 16; i++) { tot[mt][0][i] = fmaf(s0, grp[mt][0][i], tot[mt][0][i]); tot[mt][1][i] = fmaf(s1, grp[mt][1][i], tot[mt][1][i]); }
   }
@@ -434,7 +435,7 @@ __global__ __launch_bounds__(WPB * 64) void k_gemm_q4g_mfma(const uint4* __restr
     const int n = tile * 64 + 32 * T + c;
     const float bv = bias ? bias[n] : 0.f;
 #pragma unroll
-    for (int mt = 0; mt < 2; mt++)
+    for (int mt = 0; mt < MT; mt++)
 #pragma unroll
       for (int i = 0; i < 16; i++) {
         const int m = r0 + 32 * mt + (i & 3) + 8 * (i >> 2) + 4 * h;
@@ -459,7 +460,7 @@ __global__ void k_q4g_mfma_reduce(const float* __restrict__ part, int KS, size_t
 // Mamba2 batched prefill: the prompt's rows go through the GEMMs together (in_proj / out_proj on the matrix cores); the depthwise conv is
 // a parallel map over (token, channel); the SSM recurrence is a scan INSIDE one kernel -- one workgroup per head keeps its state in
 // registers and walks the tokens, so a prompt costs one pass over the state instead of a read-modify-write of it per token.
-// Arithmetic and rounding points are those of the decode-step kernels (k_conv_step, k_ssm_step, the GATED2 prologue).
+// Arithmetic and rounding points are those of the decode-step kernels (k_ssm_step with its in-launch conv1d step, the GATED2 prologue).
 // ---------------------------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float pf_silu(float x) { return x / (1.0f + expf(-x)); }
 __device__ __forceinline__ float pf_softplus(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
@@ -674,7 +675,8 @@ int bzk_gemm_q4g_mfma(hipStream_t s, const LinearDev& L, const void* x16, int S,
   // way, and single-wave blocks spread a small grid (o_proj / down at a few hundred rows: 64 x 8 tiles) over the whole chip
   static const bool no_ks = getenv("BZ_Q4G_MFMA_NO_KSPLIT") != nullptr;
   const double flops = 2.0 * S * (double)L.N * L.K;
-  const int G = L.K / 128, rt = (S + 63) / 64;
+  const bool small = S <= 32;                    // decode batches / short prompts: one 32-row tile per wave
+  const int G = L.K / 128, rt = small ? 1 : (S + 63) / 64;
   // short prompts / decode batches: too few 64 x 64 tiles to fill the chip -> split K over blockIdx.z into partials (summed in a fixed order)
   const long long tiles = (long long)(L.N / 64) * rt;
   int KS = 1, GPB = G;
@@ -687,8 +689,10 @@ int bzk_gemm_q4g_mfma(hipStream_t s, const LinearDev& L, const void* x16, int S,
   float* part = KS > 1 ? ws : nullptr;
   {
     const dim3 grid(L.N / 64, rt, KS);
-    BZ_LAUNCH("gemm_q4g_mfma", flops, k_gemm_q4g_mfma<1>, grid, dim3(64), 0, s, (const uint4*)L.w, (const __half*)L.scales,
-              (const unsigned char*)L.zeros, L.bias, L.N, L.K, (const unsigned short*)x16, S, act, y, GPB, part);
+    if (small) BZ_LAUNCH("gemm_q4g_mfma<32 rows>", flops, (k_gemm_q4g_mfma<1, 1>), grid, dim3(64), 0, s, (const uint4*)L.w, (const __half*)L.scales,
+                         (const unsigned char*)L.zeros, L.bias, L.N, L.K, (const unsigned short*)x16, S, act, y, GPB, part);
+    else BZ_LAUNCH("gemm_q4g_mfma", flops, (k_gemm_q4g_mfma<1, 2>), grid, dim3(64), 0, s, (const uint4*)L.w, (const __half*)L.scales,
+                   (const unsigned char*)L.zeros, L.bias, L.N, L.K, (const unsigned short*)x16, S, act, y, GPB, part);
   }
   BZ_HIP(hipGetLastError());
   if (KS > 1) {
