@@ -254,8 +254,8 @@ def main():
         n_eq = sum(1 for f, e in zip(fair, same) if f and e)
         out["parity"] = {"greedy_ids_match": bool(n_eq == n_cmp and n_same >= fair_prefix), "n_compared": n_cmp, "n_equal": n_eq, "n_tokens": n_cpu,
                          "free_running": {"n_identical_prefix": n_same, "fair_prefix": fair_prefix, "cpu": cpu_tokens[:n_cpu], "gpu": tokens[:n_cpu]},
-                         "teacher_forced": {"rel_l2_max": round(max(l2), 6), "rel_l2_mean": round(float(np.mean(l2)), 6), "max_norm_max": round(max(mx), 6),
-                                            "rel_l2_per_step": [round(v, 6) for v in l2], "max_norm_per_step": [round(v, 6) for v in mx],
+                         "teacher_forced": {"rel_l2_max": round(max(l2), 9), "rel_l2_mean": round(float(np.mean(l2)), 9), "max_norm_max": round(max(mx), 9),
+                                            "rel_l2_per_step": [round(v, 9) for v in l2], "max_norm_per_step": [round(v, 9) for v in mx],
                                             "top2_gap_per_step": [round(g, 5) for g in gaps], "argmax_equal_per_step": same},
                          "gap_guard": guard,
                          "note": "ids compared on every step whose oracle top-2 gap is >= gap_guard of max|logit| (8 rounding units of the activation dtype: a rounding-level "
