@@ -323,3 +323,20 @@ def test_full_size_repack_and_gemv_properties(device):
     for r, k in enumerate(ks):      # (q*1 - z*1) * s evaluated as q*s' - z*s' in the kernel: one f32 rounding of difference at most
         assert np.abs(y[r] - W[:, k]).max() <= 2 ** -22 * np.abs(W[:, k]).max(), r
     assert np.abs(y[4] - (W[:, ks[0]] + W[:, ks[1]])).max() <= 2 ** -23 * np.abs(W).max() * 2
+
+
+def test_tuning_entry_points_run_and_reject_bad_arguments(device):
+    """bz_tune_gemv / bz_tune_rows / bz_tune_mlp / bz_probe_hbm_read (the per-kernel timing aids behind scripts/tune_*.py and bench.py's measured peak): one
+    short call each returns a plausible time, a bad shape is an error code, not a fault"""
+    us = C.c_double()
+    L.check(L.lib().bz_tune_rows(device.h, 256, 1024, L.BF16, 1, 0, 2, 2, C.byref(us)))
+    assert 0.5 < us.value < 1e4
+    L.check(L.lib().bz_tune_gemv(device.h, 512, 1024, 2, 1, 2, 2, 0, C.byref(us)))
+    assert 0.5 < us.value < 1e4
+    L.check(L.lib().bz_tune_mlp(device.h, 2048, 1024, 2, 2, 0, C.byref(us), None))
+    assert 0.5 < us.value < 1e4
+    gbs = C.c_double()
+    L.check(L.lib().bz_probe_hbm_read(device.h, 64 << 20, 2, C.byref(gbs)))
+    assert 100.0 < gbs.value < 9000.0
+    assert L.lib().bz_tune_rows(device.h, 256, 1001, L.BF16, 1, 0, 2, 2, C.byref(us)) != 0      # K not a multiple of 8
+    assert L.lib().bz_tune_mlp(device.h, 1000, 1024, 2, 2, 0, C.byref(us), None) != 0          # hidden size the fused kernel is not built for
