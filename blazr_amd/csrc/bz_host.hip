@@ -256,6 +256,7 @@ struct FusedLinear {
 struct LayerDev {
   float* attn_norm = nullptr; float* ffn_norm = nullptr;
   FusedLinear qkv, o, gateup, down;
+  void* down_slabs = nullptr;   // dense 16-bit down_proj, slab-major copy [I / 32][H][32] for the fused MLP (k_mlp_dense); nullptr: not built
 };
 
 struct MambaLayerDev {
@@ -824,7 +825,17 @@ extern "C" int bz_model_finalize(bz_model* m) {
     if (Ld.o.N != H || Ld.o.K != nq * hd) BZ_FAIL(BZ_E_INVALID, "layer %d: o_proj shape does not match the config", l);
     if (Ld.gateup.N != 2 * I || Ld.gateup.K != H) BZ_FAIL(BZ_E_INVALID, "layer %d: gate/up shapes do not match the config", l);
     if (Ld.down.N != H || Ld.down.K != I) BZ_FAIL(BZ_E_INVALID, "layer %d: down_proj shape does not match the config", l);
+    // dense 16-bit MLP of the Llama-3.2-1B class: a slab-major copy of down_proj for the fused MLP launch (the row-major one stays for prefill / fallbacks)
+    if (Ld.gateup.parts.size() == 1 && Ld.down.parts.size() == 1 && Ld.down.parts[0].kind == LK_ROWS) {
+      char dummy = 0;
+      if (bzk_mlp_dense_fusable(Ld.gateup.parts[0], Ld.down.parts[0], &dummy, H, I, c.act_dtype)) {
+        BZ_TRY(dev_alloc(m, &Ld.down_slabs, (size_t)H * I * 2));
+        BZ_TRY(bzk_repack_down_slabs(m->dev->stream, Ld.down.parts[0].w, H, I, Ld.down_slabs));
+        m->resident += (size_t)H * I * 2;
+      }
+    }
   }
+  BZ_HIP(hipStreamSynchronize(m->dev->stream));
   BZ_TRY(take_vector_f32(m, "model.norm.weight", H, &m->final_norm));
   // embeddings stay in their storage dtype (rows are gathered); tied lm_head reads the same buffer
   {
@@ -1477,6 +1488,13 @@ static int llama_step(bz_model* m, const StepIO& io) {
       // norm + gate/up + SiLU*up + down in one launch (same ring protocol as one GEMV launch)
       const int rz = (rs.ri + 1) % 3;
       BZ_TRY(bzk_mlp_q4g(st, Ld.gateup.parts[0], Ld.down.parts[0], H, I, pf, m->ring[rs.ri], rs.dirty[rz] > 0 ? m->ring[rz] : nullptr, rs.dirty[rz]));
+      dn = VSrc{m->ring[rs.ri], 1};
+      rs.dirty[rz] = 0; rs.dirty[rs.ri] = H; rs.ri = rz;
+      cur ^= 1;
+    } else if (!no_mlp_fuse && Ld.gateup.parts.size() == 1 && Ld.down.parts.size() == 1 && bzk_mlp_dense_fusable(Ld.gateup.parts[0], Ld.down.parts[0], Ld.down_slabs, H, I, act)) {
+      // the dense 16-bit form of the same fusion (slab-major down_proj copy)
+      const int rz = (rs.ri + 1) % 3;
+      BZ_TRY(bzk_mlp_dense(st, Ld.gateup.parts[0], Ld.down.parts[0], Ld.down_slabs, H, I, pf, m->ring[rs.ri], rs.dirty[rz] > 0 ? m->ring[rz] : nullptr, rs.dirty[rz]));
       dn = VSrc{m->ring[rs.ri], 1};
       rs.dirty[rz] = 0; rs.dirty[rs.ri] = H; rs.ri = rz;
       cur ^= 1;

@@ -196,6 +196,10 @@ bool bzk_mlp_gq_fusable(const LinearDev& gu, const LinearDev& dn, int H, int I, 
 int bzk_mlp_gq(hipStream_t s, const LinearDev& gu, const LinearDev& dn, int H, int I, const Pro& pro, long long* acc, long long* zero_buf, int zero_n);
 bool bzk_gemv_cols_ok(const LinearDev& L, const Pro& pro, int act);   // full-K int4 GEMV with direct output (q/k/v of the decode step)
 int bzk_gemv_cols(hipStream_t s, const LinearDev& L, const Pro& pro, float* out, long long* zero_buf, int zero_n);
+// dense 16-bit form (k_mlp_dense): down_proj additionally stored slab-major [I / 32][H][32] (bzk_repack_down_slabs at finalize)
+int bzk_repack_down_slabs(hipStream_t s, const void* w, int H, int I, void* out);
+bool bzk_mlp_dense_fusable(const LinearDev& gu, const LinearDev& dn, const void* down_slabs, int H, int I, int act);
+int bzk_mlp_dense(hipStream_t s, const LinearDev& gu, const LinearDev& dn, const void* down_slabs, int H, int I, const Pro& pro, long long* acc, long long* zero_buf, int zero_n);
 bool bzk_mlp_fusable(const LinearDev& gu, const LinearDev& dn, int H, int I);
 int bzk_mlp_q4g(hipStream_t s, const LinearDev& gu, const LinearDev& dn, int H, int I, const Pro& pro, long long* acc, long long* zero_buf, int zero_n);   // number of workgroups the ROWS kernel uses (argmax partial count)
 int bzk_repack_awq(hipStream_t s, const uint32_t* d_qweight, const float* d_scales, const float* d_zeros, int N, int K, int gs,

@@ -2421,6 +2421,178 @@ __global__ __launch_bounds__(ROUTE ? 832 : 768) void k_gemv_rows2(const void* __
 #undef RSTAMP
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Fused MLP for dense 16-bit weights (Llama-3.2-1B shape): acc_down += Wd[:, slab] . (silu(Wg[slab] x) * (Wu[slab] x)),  x = RMSNorm(h + prev).
+// grid = I / 32 workgroups (256 at I = 8192) of 4 row waves + 8 tile waves.  A workgroup owns 32 columns of gate and of up over the FULL K (no split, no
+// intermediate round trip): tile wave w streams gate rows 4w..4w+3 and up rows 4w..4w+3 of the slab, 512 k at a time, two chunks of loads in flight, x from LDS;
+// its eight sums (wave_sum4 twice) become four activations without leaving the wave.  Then the 32-k slab of down_proj -- stored slab-major at load,
+// [I / 32][H][32 k], so that a workgroup's slab is 128 KiB contiguous -- four lanes per output row (16 bytes = 8 k each), 16 rows per wave-wide load, reduced
+// over the four lanes, one fixed-point atomic per output row.  One launch instead of two row GEMVs: 16.3 + 9.1 us -> see DESIGN.
+// ---------------------------------------------------------------------------------------------------------
+template <int WDT>
+__global__ void k_repack_down_slabs(const unsigned short* __restrict__ W, int H, int I, unsigned short* __restrict__ out) {   // W [H][I] -> out [I/32][H][32]
+  const size_t n = (size_t)H * I;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int row = (int)(i / I), k = (int)(i % I);
+    out[((size_t)(k >> 5) * H + row) * 32 + (k & 31)] = W[i];
+  }
+}
+int bzk_repack_down_slabs(hipStream_t s, const void* w, int H, int I, void* out) {
+  hipLaunchKernelGGL(k_repack_down_slabs<BZ_F16>, dim3(2048), dim3(256), 0, s, (const unsigned short*)w, H, I, (unsigned short*)out);
+  BZ_HIP(hipGetLastError());
+  return BZ_OK;
+}
+
+template <int WDT, bool FIX>
+__global__ __launch_bounds__(768) void k_mlp_dense(const void* __restrict__ Wgu, const float* __restrict__ bgu, const void* __restrict__ Wds, const float* __restrict__ bd,
+                                                   int H, int I, Pro pro, long long* __restrict__ acc, long long* zero_buf, int zero_n) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* xs = (float*)smem;                      // [H] normalised activations
+  float* actl = xs + H;                          // [32] the slab's activations
+  double* dred = (double*)(actl + 32);           // [4]
+  unsigned* cnt = (unsigned*)(dred + 4);         // [0] sum of squares complete, [1] x published, [2] activations published
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int slab = blockIdx.x;
+  const int act = pro.act;
+  if (tid == 0) { cnt[0] = 0; cnt[1] = 0; cnt[2] = 0; }
+  if (wave < 4) {
+    // ---- row waves: x = R(w R(h' rs)), h' = R(h + prev), the whole row -> LDS (the structure of k_gemv_rows2's norm prologue) ----
+    __builtin_amdgcn_s_setprio(3);
+    const bool hasprev = pro.src.p != nullptr;
+    const void* prevp = hasprev ? pro.src.p : (const void*)pro.h_in;
+    double ssd = 0.0;
+    bool first = true;
+    for (int base = 0; base < H; base += 2048) {
+      const int i0 = min(base + tid * 8, H - 8);
+      const float4 ha = *(const float4*)(pro.h_in + i0), hb = *(const float4*)(pro.h_in + i0 + 4);
+      const float4 na = *(const float4*)(pro.norm_w + i0), nb = *(const float4*)(pro.norm_w + i0 + 4);
+      typename SrcRaw<FIX>::T pv[8];
+#pragma unroll
+      for (int e = 0; e < 8; e++) pv[e] = src_raw<FIX>(prevp, (FIX || hasprev) ? i0 + e : 0);
+      if (first) { __builtin_amdgcn_sched_barrier(0); __syncthreads(); first = false; }   // rendezvous: these loads are ahead of the weight stream
+      float v[8] = {ha.x, ha.y, ha.z, ha.w, hb.x, hb.y, hb.z, hb.w};
+      if (hasprev) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] = round_act(v[e] + src_cvt<FIX>(pv[e], act), act);
+      }
+      if (base + tid * 8 < H) {
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) ssd += (double)(v[e] * v[e]) + (double)(v[e + 1] * v[e + 1]);
+        if (blockIdx.x == 0 && pro.h_out) { *(float4*)(pro.h_out + i0) = make_float4(v[0], v[1], v[2], v[3]); *(float4*)(pro.h_out + i0 + 4) = make_float4(v[4], v[5], v[6], v[7]); }
+        // parked as v * w-independent halves: the weight is applied after rs is known (both factors kept: v here, w in registers of the same thread)
+        *(float4*)(xs + i0) = make_float4(v[0], v[1], v[2], v[3]); *(float4*)(xs + i0 + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      }
+      if (base + 2048 >= H) {                      // last (usually only) batch: finish here, this thread still holds its norm weights
+        ssd = wave_sum_d(ssd);
+        if (lane == 0) dred[wave] = ssd;
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        if (lane == 0) atomicAdd(&cnt[0], 1u);
+        lds_wait_count(&cnt[0], 4);
+        const float ss = (float)((dred[0] + dred[1]) + (dred[2] + dred[3]));
+        const float rs = 1.0f / sqrtf(ss / (float)H + pro.eps);
+        for (int b2 = 0; b2 < H; b2 += 2048) {     // every batch of this thread (H <= 2048: exactly the values above)
+          const int j0 = b2 + tid * 8;
+          if (j0 < H) {
+            float4 wa = na, wb = nb;
+            if (b2 != base) { wa = *(const float4*)(pro.norm_w + j0); wb = *(const float4*)(pro.norm_w + j0 + 4); }
+            const float4 va = *(const float4*)(xs + j0), vb = *(const float4*)(xs + j0 + 4);
+            *(float4*)(xs + j0) = make_float4(round_act(wa.x * round_act(va.x * rs, act), act), round_act(wa.y * round_act(va.y * rs, act), act),
+                                              round_act(wa.z * round_act(va.z * rs, act), act), round_act(wa.w * round_act(va.w * rs, act), act));
+            *(float4*)(xs + j0 + 4) = make_float4(round_act(wb.x * round_act(vb.x * rs, act), act), round_act(wb.y * round_act(vb.y * rs, act), act),
+                                                  round_act(wb.z * round_act(vb.z * rs, act), act), round_act(wb.w * round_act(vb.w * rs, act), act));
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    if (lane == 0) atomicAdd(&cnt[1], 1u);
+    return;
+  }
+  // ---- tile waves -----------------------------------------------------------------------------------------------------
+  const int tw = wave - 4;
+  const unsigned short* wg = (const unsigned short*)Wgu;
+  const int KC = H >> 9;                            // 512-k chunks (H % 512 == 0)
+  const int c0 = slab * 32 + tw * 4;                // this wave's four columns: gate rows c0.., up rows I + c0..
+  struct Stage { RowPiece<WDT> g[4], u[4]; };
+  auto issue = [&](Stage& S, int kc) {
+    const size_t ko = (size_t)kc * 512 + lane * 8;
+#pragma unroll
+    for (int r = 0; r < 4; r++) { S.g[r] = piece_load<WDT>(wg, (size_t)(c0 + r) * H + ko); S.u[r] = piece_load<WDT>(wg, (size_t)(I + c0 + r) * H + ko); }
+  };
+  __syncthreads();                                  // rendezvous: the row waves' loads are in the queue
+  Stage st[2];
+  issue(st[0], 0);
+  if (KC > 1) issue(st[1], 1);
+  if (zero_buf)
+    for (int i = blockIdx.x * 512 + (tid - 256); i < zero_n; i += gridDim.x * 512) zero_buf[i] = 0;
+  lds_wait_count(&cnt[1], 4);
+  float ag[4] = {0.f, 0.f, 0.f, 0.f}, au[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int kc = 0; kc < KC; kc += 2) {
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      if (kc + q < KC) {
+        const float4 xa = *(const float4*)(xs + (kc + q) * 512 + lane * 8), xb = *(const float4*)(xs + (kc + q) * 512 + lane * 8 + 4);
+#pragma unroll
+        for (int r = 0; r < 4; r++) { ag[r] += piece_dot<WDT>(st[q].g[r], xa, xb); au[r] += piece_dot<WDT>(st[q].u[r], xa, xb); }
+        if (kc + q + 2 < KC) issue(st[q], kc + q + 2);
+      }
+    }
+  }
+  // the down slab's loads go out now: rows 256 tw .. 256 tw + 255 of the output (H = 2048: 16 wave-wide loads of 16 rows), under the reductions below.
+  // (Requesting them earlier -- behind the last two gate / up chunks, with the stage registers still live -- was measured: 30.6 vs 23.8 us.)
+  const unsigned short* wd = (const unsigned short*)Wds + (size_t)slab * H * 32;
+  const int NLD = H / (8 * 16);                     // loads per wave: H rows / 8 waves / 16 rows per load
+  const int n0 = tw * (H / 8) + (lane >> 2), ksub = (lane & 3) * 8;
+  uint4 D[16];
+#pragma unroll
+  for (int t = 0; t < 16; t++) if (t < NLD) D[t] = ldnt((const uint4*)(wd + (size_t)(n0 + t * 16) * 32 + ksub));
+  {
+    const float sg = wave_sum4(ag[0], ag[1], ag[2], ag[3]), su = wave_sum4(au[0], au[1], au[2], au[3]);   // value j in 16-lane row [0, 2, 1, 3][j]
+    const int j = ((lane >> 4) & 1) * 2 + (lane >> 5);
+    float g = sg, u = su;
+    if (bgu) { g += bgu[c0 + j]; u += bgu[I + c0 + j]; }
+    const float a = round_act(round_act(silu_f(round_act(g, act)), act) * round_act(u, act), act);
+    if ((lane & 15) == 0) actl[tw * 4 + j] = a;
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  if (lane == 0) atomicAdd(&cnt[2], 1u);
+  lds_wait_count(&cnt[2], 8);
+  const float4 aa = *(const float4*)(actl + ksub), ab = *(const float4*)(actl + ksub + 4);
+#pragma unroll
+  for (int t = 0; t < 16; t++) {
+    if (t < NLD) {
+      RowPiece<WDT> pc; pc.a = D[t];
+      float d = piece_dot<WDT>(pc, aa, ab);
+      d = grp_reduce<4, OpAdd>(d);
+      const int n = n0 + t * 16;
+      if ((lane & 3) == 0) {
+        if (bd != nullptr && slab == 0) d += bd[n];
+        atomicAdd((unsigned long long*)(acc + n), (unsigned long long)f2fix(d));
+      }
+    }
+  }
+}
+
+bool bzk_mlp_dense_fusable(const LinearDev& gu, const LinearDev& dn, const void* down_slabs, int H, int I, int act) {
+  static const bool off = getenv("BZ_NO_MLP_FUSION") != nullptr;
+  return !off && down_slabs != nullptr && gu.kind == LK_ROWS && dn.kind == LK_ROWS && gu.wdt == dn.wdt && (gu.wdt == BZ_F16 || gu.wdt == BZ_BF16) && gu.N == 2 * I &&
+         gu.K == H && dn.N == H && dn.K == I && H % 512 == 0 && H >= 1024 && H <= 2048 && I % 32 == 0 && I / 32 >= 128 && gu.sk > 1 && dn.sk > 1 && (act == BZ_F16 || act == BZ_BF16 || act == BZ_F32);
+}
+int bzk_mlp_dense(hipStream_t s, const LinearDev& gu, const LinearDev& dn, const void* down_slabs, int H, int I, const Pro& pro, long long* acc, long long* zero_buf, int zero_n) {
+  if (!bzk_mlp_dense_fusable(gu, dn, down_slabs, H, I, pro.act) || pro.mode != PRO_NORM || pro.H != H) BZ_FAIL(BZ_E_INVALID, "dense fused MLP does not apply to this shape");
+  const size_t smem = (size_t)H * 4 + 32 * 4 + 4 * 8 + 64;
+  const double bytes = (double)gu.algo_bytes + (double)dn.algo_bytes;
+#define LAUNCH_MD(DT, FX) BZ_LAUNCH("mlp_dense<norm+gate/up+silu+down>", bytes, (k_mlp_dense<DT, FX>), dim3(I / 32), dim3(768), smem, s, gu.w, gu.bias, down_slabs, dn.bias, H, I, pro, \
+    acc, zero_buf, zero_n)
+#define LAUNCH_MD_F(DT) do { if (pro.src.fix) LAUNCH_MD(DT, true); else LAUNCH_MD(DT, false); } while (0)
+  if (gu.wdt == BZ_F16) LAUNCH_MD_F(BZ_F16); else LAUNCH_MD_F(BZ_BF16);
+#undef LAUNCH_MD_F
+#undef LAUNCH_MD
+  BZ_HIP(hipGetLastError());
+  return BZ_OK;
+}
+
 // MoE grouped GEMV: blockIdx.y = expert slot.  The expert id comes from the router's device-side selection, so the whole MoE
 // layer stays capturable in a hipGraph.  Stacked weights [E + n_shared][N][K]; per-slot prologue source / output offsets.
 template <int WDT, bool SPLIT>

@@ -86,7 +86,7 @@ SWITCHES = [
     ("BZ_NO_ATTN_F32=1", ["mistral-7b-q4km-2l"]),                        # generic attention instead of k_attn2f
     ("BZ_NO_GQ_MIX=1", ["mistral-7b-q4km-2l"]),                          # q/k (Q4_K) and v (Q6_K) as two slim launches instead of the mixed-format one
     ("BZ_NO_SLIM_QKV=1", ["llama3-8b-awq-2l", "tiny-awq"]),              # k_gemv_q4g instead of k_gemv_q4g_slim
-    ("BZ_NO_MLP_FUSION=1", ["llama3-8b-awq-2l", "tiny-awq"]),            # gate/up and down as two launches
+    ("BZ_NO_MLP_FUSION=1", ["llama3-8b-awq-2l", "tiny-awq", "llama3.2-1b-bf16-2l"]),   # gate/up and down as two launches
     ("BZ_NO_ATTN_FUSION=1", ["llama3-8b-awq-2l", "tiny-awq", "mistral-7b-q4km-2l", "llama3.2-1b-bf16-2l"]),   # attention and o_proj as two launches
     ("BZ_NO_ATTN_SPLIT=1 BZ_SPLIT_MIN=4", ["tiny-bf16"]),                # long-context split disabled
     ("BZ_SPLIT_MIN=4", ["llama3-8b-awq-2l", "tiny-bf16"]),               # split-KV attention from position 4 on
