@@ -2184,7 +2184,7 @@ static int mamba_prefill(bz_model* m, const long long* d_tok, int S, bz_ssm_stat
     BZ_TRY(dev_alloc(m, &p, (size_t)rows * ld * 4)); m->mpf_zx = (float*)p;
     BZ_TRY(dev_alloc(m, &p, (size_t)rows * conv_dim * 4)); m->mpf_xbc = (float*)p;
     BZ_TRY(dev_alloc(m, &p, (size_t)rows * DI * 4)); m->mpf_y = (float*)p;
-    BZ_TRY(dev_alloc(m, &p, (size_t)rows * NH * 4)); m->mpf_vss = (float*)p;
+    BZ_TRY(dev_alloc(m, &p, (size_t)rows * NH * bzk_ssm_scan_pieces(c.ssm_head_dim) * 4)); m->mpf_vss = (float*)p;
     BZ_TRY(dev_alloc(m, &p, (size_t)rows * std::max(D, DI) * 2)); m->mpf_x16 = p;
     m->mpf_rows = rows;
   }
@@ -2203,7 +2203,7 @@ static int mamba_prefill(bz_model* m, const long long* d_tok, int S, bz_ssm_stat
       sc.state = (char*)state->ssm + (size_t)l * NH * c.ssm_head_dim * NS * bz_dtype_size(state->dtype);
       sc.n_heads = NH; sc.head_dim = c.ssm_head_dim; sc.d_state = NS; sc.n_groups = G; sc.d_inner = DI; sc.act = act; sc.S = n; sc.y = m->mpf_y; sc.vss = m->mpf_vss;
       BZ_TRY(bzk_ssm_scan(st, sc, state->dtype));
-      BZ_TRY(bzk_pf_gnorm(st, dt, m->mpf_y, m->mpf_vss, L.gnorm, n, DI, G, NH, c.rms_eps, act, m->mpf_x16));
+      BZ_TRY(bzk_pf_gnorm(st, dt, m->mpf_y, m->mpf_vss, L.gnorm, n, DI, G, NH * bzk_ssm_scan_pieces(c.ssm_head_dim), c.rms_eps, act, m->mpf_x16));
       BZ_TRY(bzk_gemm_nt(st, act, m->mpf_x16, Pout.w, Pout.bias, n, Pout.N, Pout.K, act, m->mpf_t));
       prev = m->mpf_t;
     }

@@ -321,6 +321,7 @@ struct BzSsmScan {
   int n_heads, head_dim, d_state, n_groups, d_inner, act, S; float* y; float* vss;
 };
 bool bzk_ssm_scan_ok(int head_dim, int d_state, int n_groups, int kc);
+int bzk_ssm_scan_pieces(int head_dim);   // vss holds [S][n_heads][pieces]; k_pf_gnorm takes n_heads * pieces
 int bzk_pf_conv(hipStream_t s, const float* zx, int ld, int x_off, int conv_dim, int kc, const float* w, const float* b, float* conv_state, int S, int act, float* out);
 int bzk_ssm_scan(hipStream_t s, const BzSsmScan& b, int state_dtype);
 int bzk_pf_gnorm(hipStream_t s, int dt, const float* v, const float* vss, const float* w, int S, int DI, int G, int NH, float eps, int act, void* x16);

@@ -26,12 +26,12 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ float pf_round(float x, int act) {
   if (act == BZ_F16) return __half2float(__float2half_rn(x));
-  if (act == BZ_BF16) { unsigned u = __float_as_uint(x); if ((u & 0x7f800000u) != 0x7f800000u) u += 0x7fffu + ((u >> 16) & 1u); return __uint_as_float(u & 0xffff0000u); }
+  if (act == BZ_BF16) return (float)(__bf16)x;     // v_cvt_pk_bf16_f32 (round to nearest even) + shift
   return x;
 }
 template <int DT> __device__ __forceinline__ unsigned short to16(float x) {
   if (DT == BZ_F16) return __half_as_ushort(__float2half_rn(x));
-  unsigned u = __float_as_uint(x); if ((u & 0x7f800000u) != 0x7f800000u) u += 0x7fffu + ((u >> 16) & 1u); return (unsigned short)(u >> 16);
+  const __bf16 b = (__bf16)x; return __builtin_bit_cast(unsigned short, b);
 }
 template <int DT> __device__ __forceinline__ float from16(unsigned short b) {
   if (DT == BZ_F16) return __half2float(__ushort_as_half(b));
@@ -518,30 +518,40 @@ template <int SDT> __device__ __forceinline__ float st_round(float v) {     // w
   return from16<BZ_BF16>(to16<BZ_BF16>(v));
 }
 
-// grid = n_heads; 256 threads = 64 rows (p) x 4 state quarters (as k_ssm_step); NQ = d_state / 4 state values per thread in registers;
-// tokens in chunks of 8 (B, C, dt, dA staged in LDS once per chunk; x and z of the chunk prefetched into registers)
-template <int SDT, int NQ, int PARTS>   // PARTS threads share a state row (NQ = d_state / PARTS values each); 64 rows x PARTS threads per block
-__global__ __launch_bounds__(64 * PARTS) void k_ssm_scan(SsmScanArgs a) {
-  constexpr int TC = 8, NS = NQ * PARTS, NP = NQ + 1, NTH = 64 * PARTS, NWV = PARTS;   // NP: padded part stride (the parts of a row would otherwise share banks)
-  __shared__ float sB[TC][PARTS * NP], sC[TC][PARTS * NP], sdt[TC], sdA[TC], sred[TC][NWV];
+// compile-time rounding to the activation dtype (bf16: v_cvt_pk_bf16_f32 + shift, two instructions on gfx950)
+template <int ACT> __device__ __forceinline__ float rnd(float x) {
+  if constexpr (ACT == BZ_F16) return __half2float(__float2half_rn(x));
+  else if constexpr (ACT == BZ_BF16) return (float)(__bf16)x;
+  else return x;
+}
+
+// The recurrence is sequential in t (the state is rounded at every token, as the decode step stores it), so the kernel is bound by the instructions one
+// CU issues per token.  What keeps that count low: rounding is compile-time (ACT); a head's rows are split over ceil(head_dim / 16) workgroups; B / C
+// come out of LDS as 16-byte reads; per token only the state update, the C dot and its 16-lane reduction run (dt * x comes staged from LDS) -- the
+// gate / SiLU / y epilogue runs once per CHUNK with lane q of a row serving token q (it used to run per token on one lane in 16); the next chunk's
+// rows are requested before the current chunk's arithmetic, and a chunk's stores are issued one chunk late, ahead of that request.
+// grid = (n_heads, ceil(head_dim / 16)); 256 threads = 16 rows (p) x 16 state parts (q); NQ = d_state / 16 state values per thread in registers;
+// tokens in chunks of 8.  vss rows are [S][n_heads][gridDim.y] (k_pf_gnorm adds the pieces)
+template <int SDT, int ACT, int NQ>
+__global__ __launch_bounds__(256) void k_ssm_scan(SsmScanArgs a) {
+  constexpr int TC = 8, PARTS = 16, NS = NQ * PARTS, NP = NQ == 8 ? 12 : NQ, NTH = 256, NWV = 4;   // NP: part stride in LDS (16-byte aligned for NQ >= 4)
+  constexpr int NBC = (TC * NS + NTH - 1) / NTH;     // B and C elements per thread per chunk
+  __shared__ __attribute__((aligned(16))) float sB[TC][PARTS * NP], sC[TC][PARTS * NP];
+  __shared__ float sdA[TC], sdtx[TC][16], sred[TC][NWV];
   const int hd = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int HD = a.head_dim;
   const int g = hd / (a.n_heads / a.n_groups);
-  const int p = tid / PARTS, q = tid % PARTS;
+  const int pl = tid / PARTS, p = blockIdx.y * 16 + pl, q = tid % PARTS, tq = q & (TC - 1);   // tq: the token of a chunk this lane serves in the epilogue
   const bool on = p < HD;
+  const int pc = on ? p : 0;
   const float Dh = a.D[hd], Aneg = -expf(a.A_log[hd]), dtb = a.dt_bias[hd];
-  const bool same = a.act == SDT;          // state dtype == activation dtype: the activation rounding already is the storage rounding
-  const size_t soff = ((size_t)hd * HD + (on ? p : 0)) * NS + q * NQ;
+  const size_t soff = ((size_t)hd * HD + pc) * NS + q * NQ;
   float h[NQ];
 #pragma unroll
   for (int n = 0; n < NQ; n++) h[n] = on ? st_load<SDT>(a.state, soff + n) : 0.f;
-  for (int t0 = 0; t0 < a.S; t0 += TC) {
-    const int nt = min(TC, a.S - t0);
-    __syncthreads();                       // the previous chunk's LDS reads are done
-    // every global load of the chunk is unconditional (clamped rows / channels) and issued before anything waits: a load under a divergent
-    // branch drains vmcnt each time, which made this staging cost 20 us per chunk
-    constexpr int NBC = (TC * NS + NTH - 1) / NTH;     // B and C elements per thread per chunk
-    float bv[NBC], cv[NBC];
+  // every global load of a chunk is unconditional (clamped rows / channels): a load under a divergent branch drains vmcnt each time
+  float bv[NBC], cv[NBC], dtraw, xn, zn;
+  auto request = [&](int t0) {
 #pragma unroll
     for (int k = 0; k < NBC; k++) {
       const int i = min(k * NTH + tid, TC * NS - 1), tt = i / NS, n = i % NS;
@@ -549,57 +559,83 @@ __global__ __launch_bounds__(64 * PARTS) void k_ssm_scan(SsmScanArgs a) {
       bv[k] = row[a.d_inner + g * NS + n];
       cv[k] = row[a.d_inner + a.n_groups * NS + g * NS + n];
     }
-    const float dtraw = a.zx[(size_t)min(t0 + (tid & (TC - 1)), a.S - 1) * a.ld + a.dt_off + hd];
-    float xv[TC], zv[TC], vsq[TC];
-    const int pc = on ? p : 0;
-#pragma unroll
-    for (int tt = 0; tt < TC; tt++) {
-      const int t = min(t0 + tt, a.S - 1);
-      xv[tt] = a.xbc[(size_t)t * a.conv_dim + hd * HD + pc];
-      zv[tt] = a.zx[(size_t)t * a.ld + hd * HD + pc];
-      vsq[tt] = 0.f;
-    }
+    const size_t t = (size_t)min(t0 + tq, a.S - 1);
+    dtraw = a.zx[t * a.ld + a.dt_off + hd];
+    xn = a.xbc[t * a.conv_dim + hd * HD + pc];
+    zn = a.zx[t * a.ld + hd * HD + pc];
+  };
+  request(0);
+  float yprev = 0.f, vssv = 0.f;
+  int tprev = -1, ntprev = 0;
+  auto flush = [&]() {     // (stores and loads share vmcnt on gfx9: a store right before the wait for the prefetched rows would put its round trip into every chunk)
+    if (tprev < 0) return;
+    if (on && q < ntprev) a.y[(size_t)(tprev + q) * a.d_inner + hd * HD + p] = yprev;
+    if (tid < ntprev) a.vss[((size_t)(tprev + tid) * a.n_heads + hd) * gridDim.y + blockIdx.y] = vssv;
+  };
+  for (int t0 = 0; t0 < a.S; t0 += TC) {
+    const int nt = min(TC, a.S - t0);
+    // (no barrier here: every wave passed the one after the sred writes, i.e. is done with the previous chunk's sB / sC / sdA / sdtx)
 #pragma unroll
     for (int k = 0; k < NBC; k++) {
       const int i = k * NTH + tid, tt = i / NS, n = i % NS;
       if (i < TC * NS) { sB[tt][(n / NQ) * NP + n % NQ] = bv[k]; sC[tt][(n / NQ) * NP + n % NQ] = cv[k]; }
     }
-    if (tid < TC) {
-      const float dt = pf_round(pf_softplus(pf_round(dtraw + dtb, a.act)), a.act);
-      sdt[tid] = dt; sdA[tid] = expf(dt * Aneg);
+    const float xc = xn, zc = zn;
+    {
+      const float dt = rnd<ACT>(pf_softplus(rnd<ACT>(dtraw + dtb)));     // token tq
+      if (q < TC) sdtx[q][pl] = dt * xc;
+      if (tid < TC) sdA[tid] = expf(dt * Aneg);
     }
     __syncthreads();
+    flush();
+    if (t0 + TC < a.S) request(t0 + TC);   // uniform branch; the loads land under this chunk's arithmetic
+    float accs[TC];
 #pragma unroll
     for (int tt = 0; tt < TC; tt++) {
+      accs[tt] = 0.f;
       if (tt < nt) {
-        const float dt = sdt[tt], dA = sdA[tt], dtx = dt * xv[tt];
+        const float dA = sdA[tt], dtx = sdtx[tt][pl];
+        float Bq[NQ], Cq[NQ];
+        if constexpr (NQ % 4 == 0) {
+#pragma unroll
+          for (int n = 0; n < NQ; n += 4) {
+            const float4 b4 = *(const float4*)&sB[tt][q * NP + n], c4 = *(const float4*)&sC[tt][q * NP + n];
+            Bq[n] = b4.x; Bq[n + 1] = b4.y; Bq[n + 2] = b4.z; Bq[n + 3] = b4.w; Cq[n] = c4.x; Cq[n + 1] = c4.y; Cq[n + 2] = c4.z; Cq[n + 3] = c4.w;
+          }
+        } else {
+#pragma unroll
+          for (int n = 0; n < NQ; n++) { Bq[n] = sB[tt][q * NP + n]; Cq[n] = sC[tt][q * NP + n]; }
+        }
         float acc = 0.f;
 #pragma unroll
         for (int n = 0; n < NQ; n++) {
-          const float hn = pf_round(h[n] * dA + dtx * sB[tt][q * NP + n], a.act);
-          acc += hn * sC[tt][q * NP + n];     // (the step kernel multiplies the activation-rounded value and stores the state-dtype one)
-          h[n] = same ? hn : st_round<SDT>(hn);
+          const float hn = rnd<ACT>(h[n] * dA + dtx * Bq[n]);
+          acc += hn * Cq[n];                   // (the step kernel multiplies the activation-rounded value and stores the state-dtype one)
+          h[n] = ACT == SDT ? hn : st_round<SDT>(hn);
         }
-        acc = grp_reduce<PARTS, OpAdd>(acc);
-        if (on && q == 0) {
-          float yv = pf_round(acc + Dh * xv[tt], a.act);
-          yv = pf_round(yv * pf_round(pf_silu(zv[tt]), a.act), a.act);
-          vsq[tt] = yv * yv;
-          a.y[(size_t)(t0 + tt) * a.d_inner + hd * HD + p] = yv;
-        }
+        accs[tt] = grp_reduce<PARTS, OpAdd>(acc);
       }
     }
-    // per-token sums of squares over the head: eight block reductions at once (same fixed tree as block_sum256)
+    // epilogue, once per chunk: lane q < nt of row p finishes token t0 + q
+    float am = accs[0];
 #pragma unroll
-    for (int tt = 0; tt < TC; tt++) { const float s = wave_sum(vsq[tt]); if (lane == 0) sred[tt][wave] = s; }
-    __syncthreads();
-    if (tid < nt) {
-      float v = 0.f;
-#pragma unroll
-      for (int w = 0; w < NWV; w += 2) v += sred[tid][w] + sred[tid][w + 1];     // fixed order
-      a.vss[(size_t)(t0 + tid) * a.n_heads + hd] = v;
+    for (int tt = 1; tt < TC; tt++) am = tq == tt ? accs[tt] : am;
+    float y = 0.f;
+    if (on && q < nt) {
+      const float y0 = rnd<ACT>(am + Dh * xc);
+      y = rnd<ACT>(y0 * rnd<ACT>(pf_silu(zc)));
     }
+    yprev = y;
+    // per-token sums of squares over this workgroup's rows: the wave's 4 rows by two lane exchanges, the 4 waves through LDS (fixed tree)
+    float sq = y * y;
+    sq += __shfl_xor(sq, 16, 64);
+    sq += __shfl_xor(sq, 32, 64);
+    if (lane < TC) sred[lane][wave] = sq;
+    __syncthreads();
+    if (tid < TC) vssv = (sred[tid][0] + sred[tid][1]) + (sred[tid][2] + sred[tid][3]);
+    tprev = t0; ntprev = nt;
   }
+  flush();
   if (on) {
 #pragma unroll
     for (int n = 0; n < NQ; n++) st_store<SDT>(a.state, soff + n, h[n]);
@@ -612,10 +648,11 @@ __global__ __launch_bounds__(256) void k_pf_gnorm(const float* __restrict__ v, c
                                                   float eps, int act, unsigned short* __restrict__ x16) {
   __shared__ float rs[64];
   const int t = blockIdx.x, gsz = DI / G, hpg = NH / G;
-  if (threadIdx.x < G) {
+  for (int g = threadIdx.x >> 6; g < G; g += 4) {     // one wave per group: lanes stride over the group's pieces, fixed tree
     float ss = 0.f;
-    for (int h = 0; h < hpg; h++) ss += vss[(size_t)t * NH + threadIdx.x * hpg + h];
-    rs[threadIdx.x] = 1.0f / sqrtf(ss / (float)gsz + eps);
+    for (int h = threadIdx.x & 63; h < hpg; h += 64) ss += vss[(size_t)t * NH + g * hpg + h];
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) rs[g] = 1.0f / sqrtf(ss / (float)gsz + eps);
   }
   __syncthreads();
   for (int i = threadIdx.x; i < DI; i += 256)
@@ -703,6 +740,7 @@ int bzk_gemm_q4g_mfma(hipStream_t s, const LinearDev& L, const void* x16, int S,
   return BZ_OK;
 }
 
+int bzk_ssm_scan_pieces(int head_dim) { return (head_dim + 15) / 16; }     // workgroups per head = vss pieces per (token, head)
 bool bzk_ssm_scan_ok(int head_dim, int d_state, int n_groups, int kc) {
   return head_dim <= 64 && (d_state == 16 || d_state == 64 || d_state == 128) && n_groups <= 64 && kc >= 2 && kc <= 9;
 }
@@ -717,9 +755,11 @@ int bzk_ssm_scan(hipStream_t s, const BzSsmScan& b, int sdt) {
   SsmScanArgs a;
   a.xbc = b.xbc; a.conv_dim = b.conv_dim; a.zx = b.zx; a.ld = b.ld; a.dt_off = b.dt_off; a.dt_bias = b.dt_bias; a.A_log = b.A_log; a.D = b.D; a.state = b.state;
   a.n_heads = b.n_heads; a.head_dim = b.head_dim; a.d_state = b.d_state; a.n_groups = b.n_groups; a.d_inner = b.d_inner; a.act = b.act; a.S = b.S; a.y = b.y; a.vss = b.vss;
-#define LAUNCH_SCAN(SDT, NQ) BZ_LAUNCH("mamba2_ssm_scan", 0.0, (k_ssm_scan<SDT, NQ, 16>), dim3(b.n_heads), dim3(1024), 0, s, a)
-#define LAUNCH_SCAN_N(SDT) do { if (b.d_state == 16) LAUNCH_SCAN(SDT, 1); else if (b.d_state == 64) LAUNCH_SCAN(SDT, 4); else LAUNCH_SCAN(SDT, 8); } while (0)
-  if (sdt == BZ_F32) LAUNCH_SCAN_N(BZ_F32); else if (sdt == BZ_F16) LAUNCH_SCAN_N(BZ_F16); else LAUNCH_SCAN_N(BZ_BF16);
+#define LAUNCH_SCAN(SDT, ACT, NQ) BZ_LAUNCH("mamba2_ssm_scan", 0.0, (k_ssm_scan<SDT, ACT, NQ>), dim3(b.n_heads, bzk_ssm_scan_pieces(b.head_dim)), dim3(256), 0, s, a)
+#define LAUNCH_SCAN_N(SDT, ACT) do { if (b.d_state == 16) LAUNCH_SCAN(SDT, ACT, 1); else if (b.d_state == 64) LAUNCH_SCAN(SDT, ACT, 4); else LAUNCH_SCAN(SDT, ACT, 8); } while (0)
+#define LAUNCH_SCAN_A(SDT) do { if (b.act == BZ_F32) LAUNCH_SCAN_N(SDT, BZ_F32); else if (b.act == BZ_F16) LAUNCH_SCAN_N(SDT, BZ_F16); else LAUNCH_SCAN_N(SDT, BZ_BF16); } while (0)
+  if (sdt == BZ_F32) LAUNCH_SCAN_A(BZ_F32); else if (sdt == BZ_F16) LAUNCH_SCAN_A(BZ_F16); else LAUNCH_SCAN_A(BZ_BF16);
+#undef LAUNCH_SCAN_A
 #undef LAUNCH_SCAN_N
 #undef LAUNCH_SCAN
   BZ_HIP(hipGetLastError());
