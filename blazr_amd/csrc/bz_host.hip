@@ -1772,6 +1772,15 @@ static bool prefill_eligible(const bz_model* m, int S, int total_len) {
     }
   return m->lm_head.parts.size() == 1 && m->lm_head.parts[0].kind == LK_ROWS && !m->lm_head.fix_out;
 }
+// split-K partials of the prefill GEMMs (bzk_gemm_nt / bzk_gemm_q4g_mfma)
+static int ensure_pf_ws(bz_model* m) {
+  if (m->pf_ws) return BZ_OK;
+  void* p;
+  m->pf_ws_bytes = (size_t)48 << 20;
+  BZ_TRY(dev_alloc(m, &p, m->pf_ws_bytes));
+  m->pf_ws = (float*)p;
+  return BZ_OK;
+}
 static int prefill_ws(bz_model* m, int rows) {
   if (m->pf_rows >= rows) return BZ_OK;
   const bz_model_config& c = m->cfg;
@@ -1784,7 +1793,7 @@ static int prefill_ws(bz_model* m, int rows) {
   BZ_TRY(dev_alloc(m, &p, (size_t)rows * 2 * c.inter * 4)); m->pf_gu = (float*)p;
   BZ_TRY(dev_alloc(m, &p, (size_t)rows * xw * 2)); m->pf_x16 = p;
   if (!m->pf_acc) { const size_t an = 8 * std::max<size_t>(std::max<size_t>(qn, 2 * (size_t)c.inter), c.hidden); BZ_TRY(dev_alloc(m, &p, an * 8)); m->pf_acc = (long long*)p; BZ_HIP(hipMemset(p, 0, an * 8)); }
-  if (!m->pf_ws) { m->pf_ws_bytes = (size_t)48 << 20; BZ_TRY(dev_alloc(m, &p, m->pf_ws_bytes)); m->pf_ws = (float*)p; }
+  BZ_TRY(ensure_pf_ws(m));
   m->pf_rows = rows;
   return BZ_OK;
 }
@@ -1793,7 +1802,7 @@ static int prefill_ws(bz_model* m, int rows) {
 static int pf_gemm(bz_model* m, const LinearDev& P, const void* x16, int n, float* y) {
   hipStream_t st = step_stream(m);
   const int act = m->cfg.act_dtype;
-  if (P.kind == LK_ROWS) return bzk_gemm_nt(st, act, x16, P.w, P.bias, n, P.N, P.K, act, y);
+  if (P.kind == LK_ROWS) return bzk_gemm_nt(st, act, x16, P.w, P.bias, n, P.N, P.K, act, y, m->pf_ws, m->pf_ws_bytes);
   if (bzk_gemm_q4g_mfma_ok(P, act, n)) return bzk_gemm_q4g_mfma(st, P, x16, n, act, y, m->pf_ws, m->pf_ws_bytes);
   return bzk_gemm_q4g_rows(st, P, act, x16, n, act, m->pf_acc, y);
 }
@@ -1836,7 +1845,7 @@ static int prefill_dense(bz_model* m, const long long* d_tok, int S, const KvVie
     const LinearDev& LH = m->lm_head.parts[0];
     if (all && n > 1 && LH.wdt == act && LH.K % 64 == 0 && logits_out->nbytes >= (size_t)(s0 + n) * c.vocab * 4) {
       BZ_TRY(bzk_pf_norm(st, dt, m->pf_h, prev, m->final_norm, n, H, c.rms_eps, act, m->pf_x16));
-      BZ_TRY(bzk_gemm_nt(st, act, m->pf_x16, LH.w, LH.bias, n, c.vocab, H, act, (float*)logits_out->ptr + (size_t)s0 * c.vocab));
+      BZ_TRY(bzk_gemm_nt(st, act, m->pf_x16, LH.w, LH.bias, n, c.vocab, H, act, (float*)logits_out->ptr + (size_t)s0 * c.vocab, m->pf_ws, m->pf_ws_bytes));
       continue;
     }
     for (int r = 0; r < n; r++) {
@@ -1916,6 +1925,7 @@ static int dsv2_prefill(bz_model* m, const long long* d_tok, int S, const KvView
   const size_t es = bz_dtype_size(dt);
   const int CH = 512;
   BZ_TRY(dsv2_prefill_ws(m, std::min(S, CH)));
+  BZ_TRY(ensure_pf_ws(m));
   std::vector<int> hcnt(std::max(E, 1));
   for (int s0 = 0; s0 < S; s0 += CH) {
     const int n = std::min(CH, S - s0), p0 = pos0 + s0;
@@ -1925,7 +1935,7 @@ static int dsv2_prefill(bz_model* m, const long long* d_tok, int S, const KvView
       const DsLayerDev& L = m->dlayers[l];
       BZ_TRY(bzk_pf_norm(st, dt, m->pf_h, prev, L.attn_norm, n, H, c.rms_eps, act, m->pf_x16));
       const LinearDev& PQ = L.qkva.parts[0];
-      BZ_TRY(bzk_gemm_nt(st, dt, m->pf_x16, PQ.w, PQ.bias, n, QN, H, act, m->pf_qkv));
+      BZ_TRY(bzk_gemm_nt(st, dt, m->pf_x16, PQ.w, PQ.bias, n, QN, H, act, m->pf_qkv, m->pf_ws, m->pf_ws_bytes));
       BZ_TRY(bzk_mla_append_rows(st, m->pf_qkv + NQ, QN, n, L.kv_norm, c.rms_eps, R, DR, m->cos_t, m->sin_t, p0, act, view, l));
       MlaArgs ma{};
       ma.qkv = VSrc{m->pf_qkv, 0}; ma.kv_norm = L.kv_norm; ma.eps = c.rms_eps; ma.wkvb = L.kv_b; ma.wdt = L.kv_b_dt; ma.cos_t = m->cos_t; ma.sin_t = m->sin_t; ma.pos = nullptr;
@@ -1935,13 +1945,13 @@ static int dsv2_prefill(bz_model* m, const long long* d_tok, int S, const KvView
       BZ_TRY(bzk_mla_attn(st, ma, p0 + n));
       BZ_TRY(bzk_pf_cvt16(st, dt, m->dpf_att, (size_t)n * NH * DV, m->pf_x16));
       const LinearDev& PO = L.o.parts[0];
-      BZ_TRY(bzk_gemm_nt(st, dt, m->pf_x16, PO.w, PO.bias, n, H, NH * DV, act, m->pf_t));
+      BZ_TRY(bzk_gemm_nt(st, dt, m->pf_x16, PO.w, PO.bias, n, H, NH * DV, act, m->pf_t, m->pf_ws, m->pf_ws_bytes));
       BZ_TRY(bzk_pf_norm(st, dt, m->pf_h, m->pf_t, L.ffn_norm, n, H, c.rms_eps, act, m->pf_x16));
       if (!L.is_moe) {
         const LinearDev& PG = L.gateup.parts[0]; const LinearDev& PD = L.down.parts[0];
-        BZ_TRY(bzk_gemm_nt(st, dt, m->pf_x16, PG.w, PG.bias, n, 2 * c.inter, H, act, m->pf_gu));
+        BZ_TRY(bzk_gemm_nt(st, dt, m->pf_x16, PG.w, PG.bias, n, 2 * c.inter, H, act, m->pf_gu, m->pf_ws, m->pf_ws_bytes));
         BZ_TRY(bzk_pf_silu(st, dt, m->pf_gu, n, c.inter, act, m->pf_x16));
-        BZ_TRY(bzk_gemm_nt(st, dt, m->pf_x16, PD.w, PD.bias, n, H, c.inter, act, m->pf_t));
+        BZ_TRY(bzk_gemm_nt(st, dt, m->pf_x16, PD.w, PD.bias, n, H, c.inter, act, m->pf_t, m->pf_ws, m->pf_ws_bytes));
       } else {
         // routing, per-expert row lists (one small device -> host copy per layer: the row counts size the GEMM launches)
         BZ_TRY(bzk_moe_route_rows(st, dt, m->pf_x16, n, H, L.router, L.router_dt, E, TK, c.moe_routed_scale, c.moe_norm_topk, m->dpf_sel, m->dpf_w));
@@ -1959,9 +1969,9 @@ static int dsv2_prefill(bz_model* m, const long long* d_tok, int S, const KvView
         BZ_TRY(bzk_gemm_nt_grouped(st, dt, m->dpf_a16, L.e_dn, (long long)H * MI, E, m->dpf_off, m->dpf_cnt, maxc, (long long)n * TK, H, MI, act, m->dpf_ye));
         // the shared experts: one MLP of width NS * moe_inter stored as NS expert-shaped slots; the slots' down products are summed unrounded
         for (int j = 0; j < NS; j++) {
-          BZ_TRY(bzk_gemm_nt(st, dt, m->pf_x16, (const char*)L.e_gu + (size_t)(E + j) * gu_sz, nullptr, n, 2 * MI, H, act, m->dpf_gu));
+          BZ_TRY(bzk_gemm_nt(st, dt, m->pf_x16, (const char*)L.e_gu + (size_t)(E + j) * gu_sz, nullptr, n, 2 * MI, H, act, m->dpf_gu, m->pf_ws, m->pf_ws_bytes));
           BZ_TRY(bzk_pf_silu(st, dt, m->dpf_gu, n, MI, act, m->dpf_a16));
-          BZ_TRY(bzk_gemm_nt(st, dt, m->dpf_a16, (const char*)L.e_dn + (size_t)(E + j) * dn_sz, nullptr, n, H, MI, BZ_F32, j == 0 ? m->dpf_ysh : m->pf_t));
+          BZ_TRY(bzk_gemm_nt(st, dt, m->dpf_a16, (const char*)L.e_dn + (size_t)(E + j) * dn_sz, nullptr, n, H, MI, BZ_F32, j == 0 ? m->dpf_ysh : m->pf_t, m->pf_ws, m->pf_ws_bytes));
           if (j > 0) hipLaunchKernelGGL(k_acc_rows, dim3(1024), dim3(256), 0, st, m->dpf_ysh, m->pf_t, (size_t)n * H, 0);
         }
         BZ_TRY(bzk_moe_combine_rows(st, m->dpf_ye, m->dpf_rowof, m->dpf_w, NS > 0 ? m->dpf_ysh : nullptr, n, TK, H, act, m->pf_t));
@@ -1971,7 +1981,7 @@ static int dsv2_prefill(bz_model* m, const long long* d_tok, int S, const KvView
     const LinearDev& LH = m->lm_head.parts[0];
     if (all && n > 1 && LH.wdt == act && LH.K % 64 == 0 && logits_out->nbytes >= (size_t)(s0 + n) * c.vocab * 4) {
       BZ_TRY(bzk_pf_norm(st, dt, m->pf_h, prev, m->final_norm, n, H, c.rms_eps, act, m->pf_x16));
-      BZ_TRY(bzk_gemm_nt(st, act, m->pf_x16, LH.w, LH.bias, n, c.vocab, H, act, (float*)logits_out->ptr + (size_t)s0 * c.vocab));
+      BZ_TRY(bzk_gemm_nt(st, act, m->pf_x16, LH.w, LH.bias, n, c.vocab, H, act, (float*)logits_out->ptr + (size_t)s0 * c.vocab, m->pf_ws, m->pf_ws_bytes));
       continue;
     }
     for (int r = 0; r < n; r++) {
@@ -2176,6 +2186,7 @@ static int mamba_prefill(bz_model* m, const long long* d_tok, int S, bz_ssm_stat
   const int conv_dim = DI + 2 * G * NS, ld = DI + conv_dim + NH;
   const int CH = 512;
   const int rows = std::min(S, CH);
+  BZ_TRY(ensure_pf_ws(m));
   if (m->mpf_rows < rows) {
     BZ_HIP(hipStreamSynchronize(st));
     void* p;
@@ -2196,7 +2207,7 @@ static int mamba_prefill(bz_model* m, const long long* d_tok, int S, bz_ssm_stat
       const MambaLayerDev& L = m->mlayers[l];
       const LinearDev& Pin = L.in_proj.parts[0]; const LinearDev& Pout = L.out_proj.parts[0];
       BZ_TRY(bzk_pf_norm(st, dt, m->mpf_h, prev, L.norm, n, D, c.rms_eps, act, m->mpf_x16));
-      BZ_TRY(bzk_gemm_nt(st, act, m->mpf_x16, Pin.w, Pin.bias, n, Pin.N, Pin.K, act, m->mpf_zx));
+      BZ_TRY(bzk_gemm_nt(st, act, m->mpf_x16, Pin.w, Pin.bias, n, Pin.N, Pin.K, act, m->mpf_zx, m->pf_ws, m->pf_ws_bytes));
       BZ_TRY(bzk_pf_conv(st, m->mpf_zx, ld, DI, conv_dim, KC, L.conv_w, L.conv_b, state->conv + (size_t)l * conv_dim * (KC - 1), n, act, m->mpf_xbc));
       BzSsmScan sc{};
       sc.xbc = m->mpf_xbc; sc.conv_dim = conv_dim; sc.zx = m->mpf_zx; sc.ld = ld; sc.dt_off = DI + conv_dim; sc.dt_bias = L.dt_bias; sc.A_log = L.A_log; sc.D = L.D;
@@ -2204,7 +2215,7 @@ static int mamba_prefill(bz_model* m, const long long* d_tok, int S, bz_ssm_stat
       sc.n_heads = NH; sc.head_dim = c.ssm_head_dim; sc.d_state = NS; sc.n_groups = G; sc.d_inner = DI; sc.act = act; sc.S = n; sc.y = m->mpf_y; sc.vss = m->mpf_vss;
       BZ_TRY(bzk_ssm_scan(st, sc, state->dtype));
       BZ_TRY(bzk_pf_gnorm(st, dt, m->mpf_y, m->mpf_vss, L.gnorm, n, DI, G, NH * bzk_ssm_scan_pieces(c.ssm_head_dim), c.rms_eps, act, m->mpf_x16));
-      BZ_TRY(bzk_gemm_nt(st, act, m->mpf_x16, Pout.w, Pout.bias, n, Pout.N, Pout.K, act, m->mpf_t));
+      BZ_TRY(bzk_gemm_nt(st, act, m->mpf_x16, Pout.w, Pout.bias, n, Pout.N, Pout.K, act, m->mpf_t, m->pf_ws, m->pf_ws_bytes));
       prev = m->mpf_t;
     }
     for (int r = 0; r < n; r++) {

@@ -305,7 +305,7 @@ int bzk_moe_combine(hipStream_t s, long long* acc, const float* wsel, int top_k,
 bool bzk_moe_rows2_ok(int wdt, int K);   // the balanced role kernel takes the grouped expert GEMVs (16-bit weights)
 
 // batched prefill for dense 16-bit models (bz_prefill.hip): MFMA GEMM + row-wise norm / RoPE + KV append / causal attention / SiLU*up
-int bzk_gemm_nt(hipStream_t s, int dt, const void* x16, const void* w, const float* bias, int S, int N, int K, int act, float* y);
+int bzk_gemm_nt(hipStream_t s, int dt, const void* x16, const void* w, const float* bias, int S, int N, int K, int act, float* y, float* ws = nullptr, size_t ws_bytes = 0);   // ws: split-K partials (optional)
 int bzk_gemm_nt_grouped(hipStream_t s, int dt, const void* x16, const void* w, long long w_stride, int G, const int* g_off, const int* g_cnt, int max_rows, long long total_rows,
                         int N, int K, int act, float* y);
 int bzk_pf_cvt16(hipStream_t s, int dt, const float* x, size_t n, void* y);

@@ -132,6 +132,95 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const unsigned short* __restric
   }
 }
 
+// LDS-DMA form (every plain GEMM of the prefill paths; scripts/gemm_probe.hip holds the same kernel with a reference check and the timings behind
+// these choices).  Workgroup tile 128 x 128 x 64, 2 x 2 waves of 64 x 64 (2 x 2 MFMA 32x32x16 tiles each).  BOTH operands go global -> LDS with
+// global_load_lds_dwordx4 (no staging registers, no ds_write pass): one wave-instruction fills 8 rows x 128 B = 1 KB, lane-linear, so the LDS rows are
+// un-padded and the 16-byte pieces of a row are XOR-swizzled by (row & 7) -- on the SOURCE address and on the fragment read (conflict-free
+// ds_read_b128).  Two 32 KB buffers: tile i+1 is in flight under the MFMAs of tile i; the wait is a counted vmcnt and the barrier a raw s_barrier, so
+// nothing drains early; two workgroups share a CU.  Measured against the register-staged wave-tile kernel above (k_gemm_nt): Mamba2 in_proj at 512 rows
+// (10576 x 2560) 176 -> 48 us (572 TFLOP/s), out_proj 114 -> 35 us; 2048 x 4096 x 4096 845 TFLOP/s.
+// K can be split over KS workgroups (unrounded f32 partials in `part`, summed in a fixed order by k_q4g_mfma_reduce): a few hundred rows give only tens of
+// tiles.  XCD-aware tile order: consecutive workgroups of one XCD (blockIdx.x % 8) walk the row tiles and K splits of ONE column tile, so a weight tile
+// crosses HBM -> L2 once.                                grid = 8 ceil(ntiles / 8) * mtiles * KS (1-D); LDS = 64 KB
+#define BZ_GLDS16(gsrc, ldst) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc), (__attribute__((address_space(3))) void*)(ldst), 16, 0, 0)
+template <int DT>
+__global__ __launch_bounds__(256) void k_gemm_nt2(const unsigned short* __restrict__ X, const unsigned short* __restrict__ W, const float* __restrict__ bias,
+                                                  int S, int N, int K, int act, float* __restrict__ Y, float* __restrict__ part, int KS, int mtiles, int ntiles) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem2[];   // the ONLY LDS object of this kernel (a second one makes hipcc drain vmcnt per k-step)
+  const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+  const int mt = jj % mtiles, rest = jj / mtiles, ks = rest % KS, nt = (rest / KS) * 8 + xcd;
+  if (nt >= ntiles) return;                                  // (whole workgroup: no barrier is skipped by part of it)
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
+  const int m0 = mt * 128, n0 = nt * 128;
+  const int nk = K >> 6, k_beg = (int)((long long)ks * nk / KS), k_end = (int)((long long)(ks + 1) * nk / KS), nsteps = k_end - k_beg;
+  // staging: wave w fills row groups 4 w .. 4 w + 3 (8 rows x 128 B each) of A and of B; lane -> (row lane / 8, slot lane % 8), the slot holds piece slot ^ row
+  const int lrow = lane >> 3, piece = (lane & 7) ^ lrow;
+  unsigned xo[4], wo[4];                                     // element offsets (S K and N K < 2^32 on this path); rows past the edge are clamped, their results dropped
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int row = (wave * 4 + i) * 8 + lrow;
+    xo[i] = (unsigned)min(m0 + row, S - 1) * (unsigned)K + 8u * piece;
+    wo[i] = (unsigned)min(n0 + row, N - 1) * (unsigned)K + 8u * piece;
+  }
+  auto issue = [&](int kt, int buf) {
+    unsigned char* base = smem2 + buf * 32768 + wave * 4096;
+#pragma unroll
+    for (int i = 0; i < 4; i++) BZ_GLDS16(X + xo[i] + (size_t)kt * 64, base + i * 1024);
+#pragma unroll
+    for (int i = 0; i < 4; i++) BZ_GLDS16(W + wo[i] + (size_t)kt * 64, base + 16384 + i * 1024);
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int t = 0; t < 2; t++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int i = 0; i < 16; i++) acc[t][j][i] = 0.f;
+  if (nsteps > 0) {
+    issue(k_beg, 0);
+    const int aoff = (wm * 64 + r) * 128, boff = 16384 + (wn * 64 + r) * 128, sw = r & 7;
+    for (int it = 0; it < nsteps; it++) {
+      // this wave's pieces of tile `it` have landed; after the barrier everyone's have, and everyone is done reading the buffer the next issue overwrites
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      issue(min(k_beg + it + 1, k_end - 1), (it + 1) & 1);   // clamped: one redundant reload at the tail, never a branch around a load
+      const unsigned char* tb = smem2 + (it & 1) * 32768;
+#pragma unroll
+      for (int sidx = 0; sidx < 4; sidx++) {
+        const int po = ((4 * h + sidx) ^ sw) * 16;           // lane (r, h) takes k = 32 h + 8 sidx .. + 7 of its row for MFMA step sidx (A and B alike)
+        uint4 af[2], bf[2];
+#pragma unroll
+        for (int t = 0; t < 2; t++) af[t] = *(const uint4*)(tb + aoff + t * 32 * 128 + po);
+#pragma unroll
+        for (int j = 0; j < 2; j++) bf[j] = *(const uint4*)(tb + boff + j * 32 * 128 + po);
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+          for (int j = 0; j < 2; j++) acc[t][j] = mfma16<DT>(af[t], bf[j], acc[t][j]);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the tail's redundant LDS-DMA lands before the LDS allocation is released
+  }
+  // C layout: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const int n = n0 + wn * 64 + 32 * j + r;
+    if (n < N) {
+      const float bv = (!part && bias) ? bias[n] : 0.f;
+#pragma unroll
+      for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+          const int m = m0 + wm * 64 + 32 * t + (i & 3) + 8 * (i >> 2) + 4 * h;
+          if (m < S) {
+            if (part) part[((size_t)ks * S + m) * N + n] = acc[t][j][i];
+            else Y[(size_t)m * N + n] = pf_round(acc[t][j][i] + bv, act);
+          }
+        }
+    }
+  }
+}
+
 // row s: h <- R(h + prev) (prev optional) ; x16 <- to16(R(w * R(h * rs)))        grid = S
 template <int DT>
 __global__ __launch_bounds__(256) void k_pf_norm(float* hbuf, const float* prev, const float* w, int H, float eps, int act, unsigned short* x16) {
@@ -660,16 +749,42 @@ __global__ __launch_bounds__(256) void k_pf_gnorm(const float* __restrict__ v, c
 }
 
 // ---- launchers ---------------------------------------------------------------------------------------------------------------------------
-int bzk_gemm_nt(hipStream_t s, int dt, const void* x16, const void* w, const float* bias, int S, int N, int K, int act, float* y) {
+int bzk_gemm_nt(hipStream_t s, int dt, const void* x16, const void* w, const float* bias, int S, int N, int K, int act, float* y, float* ws, size_t ws_bytes) {
   if (dt != BZ_F16 && dt != BZ_BF16) BZ_FAIL(BZ_E_UNSUPPORTED, "gemm_nt: 16-bit operands only");
   if (K % 64 || K < 64 || S <= 0 || N <= 0) BZ_FAIL(BZ_E_UNSUPPORTED, "gemm_nt: K=%d must be a positive multiple of 64", K);
+  if ((unsigned long long)S * K >= (1ull << 32) || (unsigned long long)N * K >= (1ull << 32)) BZ_FAIL(BZ_E_UNSUPPORTED, "gemm_nt: operand of 2^32 elements or more");
+  static const bool old_kernel = getenv("BZ_GEMM_NT_WAVE_TILES") != nullptr;     // the round-1 kernel (weights straight to registers), kept for A/B runs and the grouped form
+  const double flops = 2.0 * S * (double)N * K;
+  if (!old_kernel) {
+    // 128 x 128 tiles; K split (a power of two) so that the chip sees about 256-320 workgroups, partials summed in a fixed order
+    const int mtiles = (S + 127) / 128, ntiles = (N + 127) / 128, nk = K / 64;
+    const long long tiles = (long long)mtiles * ntiles;
+    int KS = 1;
+    if (ws) {
+      while (KS * 2 * tiles <= 320 && KS * 2 <= nk / 2 && KS < 16 && (size_t)KS * 2 * S * N * 4 <= ws_bytes) KS *= 2;
+    }
+    float* part = KS > 1 ? ws : nullptr;
+    const unsigned grid = 8u * (unsigned)((ntiles + 7) / 8) * (unsigned)mtiles * (unsigned)KS;
+#define LAUNCH_G2(DT) do { \
+      static bool attr_done = false; \
+      if (!attr_done) { BZ_HIP(hipFuncSetAttribute((const void*)k_gemm_nt2<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536)); attr_done = true; } \
+      BZ_LAUNCH("gemm_nt_mfma", flops, (k_gemm_nt2<DT>), dim3(grid), dim3(256), 65536, s, (const unsigned short*)x16, (const unsigned short*)w, bias, S, N, K, act, y, part, KS, mtiles, ntiles); } while (0)
+    if (dt == BZ_F16) LAUNCH_G2(BZ_F16); else LAUNCH_G2(BZ_BF16);
+#undef LAUNCH_G2
+    BZ_HIP(hipGetLastError());
+    if (KS > 1) {
+      const size_t SN = (size_t)S * N;
+      hipLaunchKernelGGL(k_q4g_mfma_reduce, dim3((unsigned)std::min<size_t>((SN + 255) / 256, 2048)), dim3(256), 0, s, (const float*)ws, KS, SN, N, bias, act, y);
+      BZ_HIP(hipGetLastError());
+    }
+    return BZ_OK;
+  }
   // wave tile (32 MT) x (32 NT): as large as the problem allows while still giving the chip >= 512 waves
   int MT = S > 96 ? 4 : (S > 64 ? 3 : (S > 32 ? 2 : 1)), NT = 2;
   auto waves = [&](int mt, int nt) { return (long long)((S + 32 * mt - 1) / (32 * mt)) * ((N + 32 * nt - 1) / (32 * nt)); };
   if (waves(MT, NT) < 512) NT = 1;
   while (MT > 1 && waves(MT, NT) < 512) MT = MT == 3 ? 2 : MT / 2;
   const dim3 grid((N + 128 * NT - 1) / (128 * NT), (S + 32 * MT - 1) / (32 * MT));
-  const double flops = 2.0 * S * (double)N * K;
 #define LAUNCH_GEMM(DT, M, NN) BZ_LAUNCH("gemm_nt_mfma", flops, (k_gemm_nt<DT, M, NN>), grid, dim3(256), 0, s, (const unsigned short*)x16, (const unsigned short*)w, bias, S, N, K, act, y, \
                                          (const int*)nullptr, (const int*)nullptr, 0LL)
 #define LAUNCH_GEMM_N(DT, M) do { if (NT == 2) LAUNCH_GEMM(DT, M, 2); else LAUNCH_GEMM(DT, M, 1); } while (0)
