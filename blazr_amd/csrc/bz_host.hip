@@ -1761,7 +1761,8 @@ static bool prefill_eligible(const bz_model* m, int S, int total_len) {
   if (c.arch != BZ_ARCH_LLAMA || S < prefill_min_rows() || (c.act_dtype != BZ_F16 && c.act_dtype != BZ_BF16)) return false;
   if (c.hidden % 64 || (c.n_heads * c.head_dim) % 64 || c.inter % 64 || c.head_dim % 8 || 256 % (c.head_dim / 8)) return false;
   const int rep = c.n_heads / c.n_kv_heads;
-  if ((rep != 1 && rep != 2 && rep != 4 && rep != 8) || bzk_pf_attn_smem(c.n_heads, c.n_kv_heads, c.head_dim, total_len) > 160 * 1024) return false;
+  if (rep != 1 && rep != 2 && rep != 4 && rep != 8) return false;
+  if (!bzk_pf_attn_mfma_ok(c.head_dim, rep) && bzk_pf_attn_smem(c.n_heads, c.n_kv_heads, c.head_dim, total_len) > 160 * 1024) return false;   // (the scalar kernel keeps scores in LDS)
   // every projection either dense in the activation dtype (MFMA GEMM) or int4 without act-order (multi-row dot4 GEMM)
   for (const LayerDev& L : m->layers)
     for (const FusedLinear* F : {&L.qkv, &L.o, &L.gateup, &L.down}) {

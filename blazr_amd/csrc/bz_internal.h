@@ -327,6 +327,7 @@ int bzk_ssm_scan(hipStream_t s, const BzSsmScan& b, int state_dtype);
 int bzk_pf_gnorm(hipStream_t s, int dt, const float* v, const float* vss, const float* w, int S, int DI, int G, int NH, float eps, int act, void* x16);
 int bzk_pf_silu(hipStream_t s, int dt, const float* gu, int S, int I, int act, void* a16);
 size_t bzk_pf_attn_smem(int nq, int nkv, int hd, int len);
+bool bzk_pf_attn_mfma_ok(int hd, int rep);
 
 // non-greedy sampling (bz_sample.hip)
 int bzk_sample(hipStream_t s, void** ws, const float* logits, long long V, const long long* ids, const int* cnts, int n, float rp, float fp, float pp,

@@ -337,6 +337,36 @@ def test_batched_prefill_full_width_1b_shape(device):
     orc_py.lib().orc_kv_free(okv)
 
 
+@pytest.mark.parametrize("act", ["bf16", "f16"])
+@pytest.mark.parametrize("hd,nq,nkv", [(64, 4, 4), (64, 4, 2), (64, 8, 2), (64, 8, 1), (128, 4, 1), (128, 2, 2)])
+def test_prefill_attention_on_the_matrix_cores(device, act, hd, nq, nkv):
+    """k_pf_attn_mfma (head_dim 64 / 128; group sizes 1, 2, 4, 8 = 4, 2, 1 query tiles per workgroup and the two-half form): a 150-token prompt
+    (5 query tiles, 3 key tiles, ragged tails) and a second 45-token chunk at position 150 (keys before the chunk + the causal part), contiguous
+    and paged (scattered 16-token blocks), every row of logits against the oracle at the fixture bar"""
+    model = synth.make_llama("tiny-bf16", n_heads=nq, n_kv_heads=nkv, head_dim=hd, act_dtype=act, n_layers=1, max_seq_len=256)
+    cfg = model["config"]
+    lm, om = runtime.LoadedModel.from_synth(device, model), orc_py.OrcLlama(model)
+    p, p2 = synth.prompt_tokens(150, cfg["vocab"], seed=5), synth.prompt_tokens(45, cfg["vocab"], seed=6)
+    kv = runtime.LayeredKvCache(device, 1, 1, nkv, 200, cfg["max_seq_len"], hd, _kv_dt(cfg))
+    okv = om.new_kv(200)
+    w1, w2 = om.forward_kv(p, okv, 0, all_logits=True), om.forward_kv(p2, okv, 150, all_logits=True)
+    g1 = lm.forward_with_kv_cache(p, kv, 0, all_logits=True).to_numpy()
+    g2 = lm.forward_with_kv_cache(p2, kv, 150, all_logits=True).to_numpy()
+    _check_logits(g1, w1, act)
+    _check_logits(g2, w2, act)
+    orc_py.lib().orc_kv_free(okv)
+    # paged: same arithmetic through the block table -> bit-identical to the contiguous run
+    pk = runtime.LayeredPagedKvCache(device, 1, 16, 16, nkv, hd, _kv_dt(cfg))
+    pk.set_blocks([7, 2, 15, 0, 8, 3, 1, 11, 4, 13, 6, 9, 14])
+    sm = pk.compute_slot_mapping(0, 150)
+    pk.set_seq_len(150)
+    b1 = lm.forward_with_paged_kv_cache(p, pk, sm, pk.block_table_device_format(), 150, 0, all_logits=True).to_numpy()
+    sm2 = pk.compute_slot_mapping(150, 45)
+    pk.set_seq_len(195)
+    b2 = lm.forward_with_paged_kv_cache(p2, pk, sm2, pk.block_table_device_format(), 195, 150, all_logits=True).to_numpy()
+    assert np.array_equal(b1, g1) and np.array_equal(b2, g2)
+
+
 def test_generate_with_host_side_sampler_options(device):
     # sampling.rs:393-437: DRY / typical / logit bias / dynatemp / mirostat run on a host copy of the logits row, as in the reference
     lm = runtime.LoadedModel.from_synth(device, synth.make_llama("tiny-awq"))
