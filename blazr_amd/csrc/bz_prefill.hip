@@ -143,58 +143,66 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const unsigned short* __restric
 // tiles.  XCD-aware tile order: consecutive workgroups of one XCD (blockIdx.x % 8) walk the row tiles and K splits of ONE column tile, so a weight tile
 // crosses HBM -> L2 once.                                grid = 8 ceil(ntiles / 8) * mtiles * KS (1-D); LDS = 64 KB
 #define BZ_GLDS16(gsrc, ldst) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc), (__attribute__((address_space(3))) void*)(ldst), 16, 0, 0)
-template <int DT>
+// TM = 2: 128-row tiles; TM = 1: 64-row tiles (2 x 2 waves of 32 x 64) for <= 64 rows and for the grouped form, where an expert sees tens of rows
+// and a 128-row A tile would spend half of the CU's load slots on clamped duplicates
+template <int DT, int TM>
 __global__ __launch_bounds__(256) void k_gemm_nt2(const unsigned short* __restrict__ X, const unsigned short* __restrict__ W, const float* __restrict__ bias,
-                                                  int S, int N, int K, int act, float* __restrict__ Y, float* __restrict__ part, int KS, int mtiles, int ntiles) {
+                                                  int S, int N, int K, int act, float* __restrict__ Y, float* __restrict__ part, int KS, int mtiles, int ntiles,
+                                                  const int* __restrict__ g_off, const int* __restrict__ g_cnt, long long w_stride) {
+  constexpr int BM = 64 * TM, TILE = (BM + 128) * 128;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem2[];   // the ONLY LDS object of this kernel (a second one makes hipcc drain vmcnt per k-step)
   const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
   const int mt = jj % mtiles, rest = jj / mtiles, ks = rest % KS, nt = (rest / KS) * 8 + xcd;
   if (nt >= ntiles) return;                                  // (whole workgroup: no barrier is skipped by part of it)
+  if (g_cnt) {   // grouped form (MoE experts over gathered token rows): group blockIdx.y owns rows [g_off, g_off + g_cnt) of X / Y and the y-th weight matrix
+    const int z = blockIdx.y, off = g_off[z];
+    S = g_cnt[z];
+    if (mt * BM >= S) return;
+    X += (size_t)off * K; Y += (size_t)off * N; W += (size_t)z * w_stride;
+  }
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
-  const int m0 = mt * 128, n0 = nt * 128;
+  const int m0 = mt * BM, n0 = nt * 128;
   const int nk = K >> 6, k_beg = (int)((long long)ks * nk / KS), k_end = (int)((long long)(ks + 1) * nk / KS), nsteps = k_end - k_beg;
   // staging: wave w fills row groups 4 w .. 4 w + 3 (8 rows x 128 B each) of A and of B; lane -> (row lane / 8, slot lane % 8), the slot holds piece slot ^ row
   const int lrow = lane >> 3, piece = (lane & 7) ^ lrow;
-  unsigned xo[4], wo[4];                                     // element offsets (S K and N K < 2^32 on this path); rows past the edge are clamped, their results dropped
+  unsigned xo[2 * TM], wo[4];                                // element offsets (S K and N K < 2^32 on this path); rows past the edge are clamped, their results dropped
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const int row = (wave * 4 + i) * 8 + lrow;
-    xo[i] = (unsigned)min(m0 + row, S - 1) * (unsigned)K + 8u * piece;
-    wo[i] = (unsigned)min(n0 + row, N - 1) * (unsigned)K + 8u * piece;
-  }
+  for (int i = 0; i < 2 * TM; i++) xo[i] = (unsigned)min(m0 + (wave * 2 * TM + i) * 8 + lrow, S - 1) * (unsigned)K + 8u * piece;
+#pragma unroll
+  for (int i = 0; i < 4; i++) wo[i] = (unsigned)min(n0 + (wave * 4 + i) * 8 + lrow, N - 1) * (unsigned)K + 8u * piece;
   auto issue = [&](int kt, int buf) {
-    unsigned char* base = smem2 + buf * 32768 + wave * 4096;
+    unsigned char* base = smem2 + buf * TILE;
 #pragma unroll
-    for (int i = 0; i < 4; i++) BZ_GLDS16(X + xo[i] + (size_t)kt * 64, base + i * 1024);
+    for (int i = 0; i < 2 * TM; i++) BZ_GLDS16(X + xo[i] + (size_t)kt * 64, base + (wave * 2 * TM + i) * 1024);
 #pragma unroll
-    for (int i = 0; i < 4; i++) BZ_GLDS16(W + wo[i] + (size_t)kt * 64, base + 16384 + i * 1024);
+    for (int i = 0; i < 4; i++) BZ_GLDS16(W + wo[i] + (size_t)kt * 64, base + BM * 128 + (wave * 4 + i) * 1024);
   };
-  f32x16 acc[2][2];
+  f32x16 acc[TM][2];
 #pragma unroll
-  for (int t = 0; t < 2; t++)
+  for (int t = 0; t < TM; t++)
 #pragma unroll
     for (int j = 0; j < 2; j++)
 #pragma unroll
       for (int i = 0; i < 16; i++) acc[t][j][i] = 0.f;
   if (nsteps > 0) {
     issue(k_beg, 0);
-    const int aoff = (wm * 64 + r) * 128, boff = 16384 + (wn * 64 + r) * 128, sw = r & 7;
+    const int aoff = (wm * 32 * TM + r) * 128, boff = BM * 128 + (wn * 64 + r) * 128, sw = r & 7;
     for (int it = 0; it < nsteps; it++) {
       // this wave's pieces of tile `it` have landed; after the barrier everyone's have, and everyone is done reading the buffer the next issue overwrites
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       issue(min(k_beg + it + 1, k_end - 1), (it + 1) & 1);   // clamped: one redundant reload at the tail, never a branch around a load
-      const unsigned char* tb = smem2 + (it & 1) * 32768;
+      const unsigned char* tb = smem2 + (it & 1) * TILE;
 #pragma unroll
       for (int sidx = 0; sidx < 4; sidx++) {
         const int po = ((4 * h + sidx) ^ sw) * 16;           // lane (r, h) takes k = 32 h + 8 sidx .. + 7 of its row for MFMA step sidx (A and B alike)
-        uint4 af[2], bf[2];
+        uint4 af[TM], bf[2];
 #pragma unroll
-        for (int t = 0; t < 2; t++) af[t] = *(const uint4*)(tb + aoff + t * 32 * 128 + po);
+        for (int t = 0; t < TM; t++) af[t] = *(const uint4*)(tb + aoff + t * 32 * 128 + po);
 #pragma unroll
         for (int j = 0; j < 2; j++) bf[j] = *(const uint4*)(tb + boff + j * 32 * 128 + po);
 #pragma unroll
-        for (int t = 0; t < 2; t++)
+        for (int t = 0; t < TM; t++)
 #pragma unroll
           for (int j = 0; j < 2; j++) acc[t][j] = mfma16<DT>(af[t], bf[j], acc[t][j]);
       }
@@ -208,10 +216,10 @@ __global__ __launch_bounds__(256) void k_gemm_nt2(const unsigned short* __restri
     if (n < N) {
       const float bv = (!part && bias) ? bias[n] : 0.f;
 #pragma unroll
-      for (int t = 0; t < 2; t++)
+      for (int t = 0; t < TM; t++)
 #pragma unroll
         for (int i = 0; i < 16; i++) {
-          const int m = m0 + wm * 64 + 32 * t + (i & 3) + 8 * (i >> 2) + 4 * h;
+          const int m = m0 + wm * 32 * TM + 32 * t + (i & 3) + 8 * (i >> 2) + 4 * h;
           if (m < S) {
             if (part) part[((size_t)ks * S + m) * N + n] = acc[t][j][i];
             else Y[(size_t)m * N + n] = pf_round(acc[t][j][i] + bv, act);
@@ -909,8 +917,9 @@ int bzk_gemm_nt(hipStream_t s, int dt, const void* x16, const void* w, const flo
   static const bool old_kernel = getenv("BZ_GEMM_NT_WAVE_TILES") != nullptr;     // the round-1 kernel (weights straight to registers), kept for A/B runs and the grouped form
   const double flops = 2.0 * S * (double)N * K;
   if (!old_kernel) {
-    // 128 x 128 tiles; K split (a power of two) so that the chip sees about 256-320 workgroups, partials summed in a fixed order
-    const int mtiles = (S + 127) / 128, ntiles = (N + 127) / 128, nk = K / 64;
+    // 128 x 128 tiles (64 x 128 for <= 64 rows); K split (a power of two) so that the chip sees about 256-320 workgroups, partials summed in a fixed order
+    const int TM = S <= 64 ? 1 : 2, BM = 64 * TM;
+    const int mtiles = (S + BM - 1) / BM, ntiles = (N + 127) / 128, nk = K / 64;
     const long long tiles = (long long)mtiles * ntiles;
     int KS = 1;
     if (ws) {
@@ -918,11 +927,13 @@ int bzk_gemm_nt(hipStream_t s, int dt, const void* x16, const void* w, const flo
     }
     float* part = KS > 1 ? ws : nullptr;
     const unsigned grid = 8u * (unsigned)((ntiles + 7) / 8) * (unsigned)mtiles * (unsigned)KS;
-#define LAUNCH_G2(DT) do { \
+#define LAUNCH_G2(DT, M) do { \
       static bool attr_done = false; \
-      if (!attr_done) { BZ_HIP(hipFuncSetAttribute((const void*)k_gemm_nt2<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536)); attr_done = true; } \
-      BZ_LAUNCH("gemm_nt_mfma", flops, (k_gemm_nt2<DT>), dim3(grid), dim3(256), 65536, s, (const unsigned short*)x16, (const unsigned short*)w, bias, S, N, K, act, y, part, KS, mtiles, ntiles); } while (0)
-    if (dt == BZ_F16) LAUNCH_G2(BZ_F16); else LAUNCH_G2(BZ_BF16);
+      if (!attr_done) { BZ_HIP(hipFuncSetAttribute((const void*)k_gemm_nt2<DT, M>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536)); attr_done = true; } \
+      BZ_LAUNCH("gemm_nt_mfma", flops, (k_gemm_nt2<DT, M>), dim3(grid), dim3(256), 2 * (64 * M + 128) * 128, s, (const unsigned short*)x16, (const unsigned short*)w, bias, S, N, K, act, y, part, KS, \
+                mtiles, ntiles, (const int*)nullptr, (const int*)nullptr, 0LL); } while (0)
+    if (dt == BZ_F16) { if (TM == 1) LAUNCH_G2(BZ_F16, 1); else LAUNCH_G2(BZ_F16, 2); }
+    else { if (TM == 1) LAUNCH_G2(BZ_BF16, 1); else LAUNCH_G2(BZ_BF16, 2); }
 #undef LAUNCH_G2
     BZ_HIP(hipGetLastError());
     if (KS > 1) {
@@ -957,6 +968,21 @@ int bzk_gemm_nt_grouped(hipStream_t s, int dt, const void* x16, const void* w, l
   if (dt != BZ_F16 && dt != BZ_BF16) BZ_FAIL(BZ_E_UNSUPPORTED, "gemm_nt_grouped: 16-bit operands only");
   if (K % 64 || K < 64 || N <= 0 || G <= 0) BZ_FAIL(BZ_E_UNSUPPORTED, "gemm_nt_grouped: K=%d must be a positive multiple of 64", K);
   if (max_rows <= 0) return BZ_OK;
+  static const bool old_kernel = getenv("BZ_GEMM_NT_WAVE_TILES") != nullptr;
+  if (!old_kernel) {   // LDS-DMA kernel, one grid row per group; experts see tens of rows each, so the launch is bound by the weight stream, not by the padded row tiles
+    const int mtiles = (max_rows + 63) / 64, ntiles = (N + 127) / 128;
+    const dim3 grid2(8u * (unsigned)((ntiles + 7) / 8) * (unsigned)mtiles, G);
+    const double flops2 = 2.0 * (double)total_rows * N * K;
+#define LAUNCH_GG2(DT) do { \
+      static bool attr_done = false; \
+      if (!attr_done) { BZ_HIP(hipFuncSetAttribute((const void*)k_gemm_nt2<DT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536)); attr_done = true; } \
+      BZ_LAUNCH("gemm_nt_mfma<grouped>", flops2, (k_gemm_nt2<DT, 1>), grid2, dim3(256), 2 * (64 + 128) * 128, s, (const unsigned short*)x16, (const unsigned short*)w, (const float*)nullptr, 0, N, K, act, y, \
+                (float*)nullptr, 1, mtiles, ntiles, g_off, g_cnt, w_stride); } while (0)
+    if (dt == BZ_F16) LAUNCH_GG2(BZ_F16); else LAUNCH_GG2(BZ_BF16);
+#undef LAUNCH_GG2
+    BZ_HIP(hipGetLastError());
+    return BZ_OK;
+  }
   const int MT = max_rows > 32 ? 2 : 1;        // experts see tens of rows each: small row tiles, the grid is filled by the groups
   const dim3 grid((N + 127) / 128, (max_rows + 32 * MT - 1) / (32 * MT), G);
   const double flops = 2.0 * (double)total_rows * N * K;
@@ -965,6 +991,44 @@ int bzk_gemm_nt_grouped(hipStream_t s, int dt, const void* x16, const void* w, l
   if (dt == BZ_F16) { if (MT == 2) LAUNCH_GG(BZ_F16, 2); else LAUNCH_GG(BZ_F16, 1); }
   else { if (MT == 2) LAUNCH_GG(BZ_BF16, 2); else LAUNCH_GG(BZ_BF16, 1); }
 #undef LAUNCH_GG
+  BZ_HIP(hipGetLastError());
+  return BZ_OK;
+}
+
+// int4 group-quantised weights (the layout above) -> f16 [N][K] rows, for long prompts: past a few hundred rows the prompt GEMM is cheaper as
+// one dequantisation pass (N K / 2 bytes in, 2 N K out) + the LDS-DMA f16 GEMM than as k_gemm_q4g_mfma, whose weight fragments are rebuilt per row tile.
+// w = R16((q - z) * s): the product is exact in f32 (4 x 11 bits) and rounded once.    thread = (column, pair of 32-k chunks): 2 x 16 B in, 128 B out
+__global__ __launch_bounds__(256) void k_q4g_dequant_f16(const uint4* __restrict__ W, const __half* __restrict__ Sc, const unsigned char* __restrict__ Z, int N, int K,
+                                                         __half* __restrict__ out) {
+  const int tile = blockIdx.x, lane = threadIdx.x & 63, pi = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int G = K >> 7, C32 = K >> 5;
+  if (2 * pi >= C32) return;
+  const int n = tile * 64 + lane;
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const int kc = 2 * pi + j, g = kc >> 2;
+    const uint4 w = W[((size_t)tile * C32 + kc) * 64 + lane];
+    const float sc = __half2float(Sc[((size_t)tile * G + g) * 64 + lane]), z = (float)Z[((size_t)tile * G + g) * 64 + lane];
+    const unsigned ww[4] = {w.x ^ 0x88888888u, w.y ^ 0x88888888u, w.z ^ 0x88888888u, w.w ^ 0x88888888u};
+    __half* o = out + (size_t)n * K + kc * 32;
+#pragma unroll
+    for (int jw = 0; jw < 4; jw++) {
+      unsigned short v[8];
+#pragma unroll
+      for (int b = 0; b < 4; b++) {
+        v[b] = __half_as_ushort(__float2half_rn(((float)((ww[jw] >> (8 * b)) & 15u) - z) * sc));
+        v[4 + b] = __half_as_ushort(__float2half_rn(((float)((ww[jw] >> (8 * b + 4)) & 15u) - z) * sc));
+      }
+      uint4 pk;
+      pk.x = v[0] | ((unsigned)v[1] << 16); pk.y = v[2] | ((unsigned)v[3] << 16); pk.z = v[4] | ((unsigned)v[5] << 16); pk.w = v[6] | ((unsigned)v[7] << 16);
+      *(uint4*)(o + 8 * jw) = pk;
+    }
+  }
+}
+int bzk_q4g_dequant_f16(hipStream_t s, const LinearDev& L, void* out) {
+  if (L.kind != LK_Q4G || L.perm || L.K % 128 || L.N % 64 || (L.gs && L.gs != 128)) BZ_FAIL(BZ_E_UNSUPPORTED, "q4g_dequant: unsupported weight format");
+  const dim3 grid(L.N / 64, (L.K / 64 + 3) / 4);
+  BZ_LAUNCH("q4g_dequant_f16", (double)L.N * L.K * 2.5, k_q4g_dequant_f16, grid, dim3(256), 0, s, (const uint4*)L.w, (const __half*)L.scales, (const unsigned char*)L.zeros, L.N, L.K, (__half*)out);
   BZ_HIP(hipGetLastError());
   return BZ_OK;
 }

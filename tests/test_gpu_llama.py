@@ -367,6 +367,26 @@ def test_prefill_attention_on_the_matrix_cores(device, act, hd, nq, nkv):
     assert np.array_equal(b1, g1) and np.array_equal(b2, g2)
 
 
+def test_long_prompt_on_int4_weights_dequantises_once(device):
+    """prompts of >= 384 rows on AWQ weights: k_q4g_dequant_f16 + the f16 LDS-DMA GEMM instead of k_gemm_q4g_mfma (pf_gemm); 400-token prompt,
+    every row of logits against the oracle, then decode steps on the cache it wrote"""
+    model = synth.make_llama("tiny-awq", max_seq_len=512)
+    cfg = model["config"]
+    lm, om = runtime.LoadedModel.from_synth(device, model), orc_py.OrcLlama(model)
+    p = synth.prompt_tokens(400, cfg["vocab"], seed=17)
+    kv = runtime.LayeredKvCache(device, cfg["n_layers"], 1, cfg["n_kv_heads"], 410, cfg["max_seq_len"], cfg["head_dim"], _kv_dt(cfg))
+    okv = om.new_kv(416)
+    want = om.forward_kv(p, okv, 0, all_logits=True)
+    got = lm.forward_with_kv_cache(p, kv, 0, all_logits=True).to_numpy()
+    _check_logits(got, want, cfg["act_dtype"])
+    tok = int(want[-1].argmax())
+    for i in range(4):
+        lg, lo = lm.forward_with_kv_cache([tok], kv, 400 + i).to_numpy(), om.forward_kv([tok], okv, 400 + i)
+        _check_logits(lg, lo, cfg["act_dtype"])
+        tok = int(lo[0].argmax())
+    orc_py.lib().orc_kv_free(okv)
+
+
 def test_generate_with_host_side_sampler_options(device):
     # sampling.rs:393-437: DRY / typical / logit bias / dynatemp / mirostat run on a host copy of the logits row, as in the reference
     lm = runtime.LoadedModel.from_synth(device, synth.make_llama("tiny-awq"))
