@@ -311,7 +311,6 @@ struct bz_model {
   int* row_pos = nullptr; int row_pos_n = 0;   // device copy of a decode batch's per-row positions
   long long* pf_acc = nullptr;   // int4 multi-row GEMM scratch: 8 rows x widest N, fixed point, kept zero between launches
   float* pf_ws = nullptr; size_t pf_ws_bytes = 0;   // W4A16 MFMA GEMM: split-K partials for short prompts / decode batches
-  void* pf_wdq = nullptr; size_t pf_wdq_bytes = 0;  // long prompts on int4 weights: one linear dequantised to f16 [N][K] (the largest of the model)
   long long* ring[3] = {nullptr, nullptr, nullptr};
   float* dring[3] = {nullptr, nullptr, nullptr};   // direct-output twins of the ring (ROWS kernels)
   int ring_n = 0;
@@ -1805,26 +1804,9 @@ static int pf_gemm(bz_model* m, const LinearDev& P, const void* x16, int n, floa
   hipStream_t st = step_stream(m);
   const int act = m->cfg.act_dtype;
   if (P.kind == LK_ROWS) return bzk_gemm_nt(st, act, x16, P.w, P.bias, n, P.N, P.K, act, y, m->pf_ws, m->pf_ws_bytes);
-  if (bzk_gemm_q4g_mfma_ok(P, act, n)) {
-    // long prompts: dequantise the linear once (N K / 2 bytes in, 2 N K out) and run the LDS-DMA f16 GEMM; BZ_Q4G_DEQUANT_MIN rows (default 384), 0 = never
-    static const int deq_min = getenv("BZ_Q4G_DEQUANT_MIN") ? atoi(getenv("BZ_Q4G_DEQUANT_MIN")) : 384;
-    if (deq_min > 0 && n >= deq_min && (!P.gs || P.gs == 128)) {
-      if (!m->pf_wdq) {
-        size_t mx = 0;
-        for (const LayerDev& L : m->layers)
-          for (const FusedLinear* F : {&L.qkv, &L.o, &L.gateup, &L.down})
-            for (const LinearDev& Q : F->parts) if (Q.kind == LK_Q4G) mx = std::max(mx, (size_t)Q.N * Q.K * 2);
-        void* p;
-        BZ_TRY(dev_alloc(m, &p, mx));
-        m->pf_wdq = p; m->pf_wdq_bytes = mx;
-      }
-      if ((size_t)P.N * P.K * 2 <= m->pf_wdq_bytes) {
-        BZ_TRY(bzk_q4g_dequant_f16(st, P, m->pf_wdq));
-        return bzk_gemm_nt(st, BZ_F16, x16, m->pf_wdq, P.bias, n, P.N, P.K, act, y, m->pf_ws, m->pf_ws_bytes);
-      }
-    }
-    return bzk_gemm_q4g_mfma(st, P, x16, n, act, y, m->pf_ws, m->pf_ws_bytes);
-  }
+  // (dequantising an int4 linear to f16 once per chunk and running the f16 LDS-DMA GEMM was built and measured: 2048-token prompt 90 -> 65 ms, but
+  //  R16((q - z) s) costs 1.4e-4 relative per GEMM and put awq 8B-width logits at 1.40e-3 against the 1e-3 bar -- removed)
+  if (bzk_gemm_q4g_mfma_ok(P, act, n)) return bzk_gemm_q4g_mfma(st, P, x16, n, act, y, m->pf_ws, m->pf_ws_bytes);
   return bzk_gemm_q4g_rows(st, P, act, x16, n, act, m->pf_acc, y);
 }
 
@@ -1837,7 +1819,7 @@ static int prefill_dense(bz_model* m, const long long* d_tok, int S, const KvVie
   const bz_model_config& c = m->cfg;
   hipStream_t st = step_stream(m);     // (a batched decode graph records this function on its capture stream)
   const int H = c.hidden, I = c.inter, nq = c.n_heads, nkv = c.n_kv_heads, hd = c.head_dim, act = c.act_dtype, dt = c.act_dtype;
-  const int CH = rc.row_pos ? 512 : 2048;      // prompts: 2048-row chunks (larger GEMMs; an int4 linear is dequantised once per chunk)
+  const int CH = rc.row_pos ? 512 : 2048;      // prompts: 2048-row chunks (larger GEMMs: 8B AWQ 2048-token prompt 105 -> 90 ms)
   BZ_TRY(prefill_ws(m, std::min(S, CH)));
   for (int s0 = 0; s0 < S; s0 += CH) {
     const int n = std::min(CH, S - s0), p0 = pos0 + s0;

@@ -188,7 +188,6 @@ struct GemvOut {
 int bzk_gemv(hipStream_t s, const LinearDev& L, const Pro& pro, const GemvOut& out, int act);
 int bzk_gemv_rows_blocks(const LinearDev& L);
 bool bzk_gemm_q4g_rows_ok(const LinearDev& L);
-int bzk_q4g_dequant_f16(hipStream_t s, const LinearDev& L, void* out_f16);   // int4 groups -> f16 [N][K] (long prompts: dequantise once, then the f16 GEMM)
 bool bzk_gemm_q4g_mfma_ok(const LinearDev& L, int xdt, int rows);   // int4 weights x f16 activations on the matrix cores (rows >= 9)
 int bzk_gemm_q4g_mfma(hipStream_t s, const LinearDev& L, const void* x16, int S, int act, float* y, float* ws = nullptr, size_t ws_bytes = 0);   // ws: split-K partials (short prompts)
 int bzk_gemm_q4g_rows(hipStream_t s, const LinearDev& L, int xdt, const void* x16, int rows, int act, long long* acc, float* y);

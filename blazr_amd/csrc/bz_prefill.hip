@@ -142,7 +142,16 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const unsigned short* __restric
 // K can be split over KS workgroups (unrounded f32 partials in `part`, summed in a fixed order by k_q4g_mfma_reduce): a few hundred rows give only tens of
 // tiles.  XCD-aware tile order: consecutive workgroups of one XCD (blockIdx.x % 8) walk the row tiles and K splits of ONE column tile, so a weight tile
 // crosses HBM -> L2 once.                                grid = 8 ceil(ntiles / 8) * mtiles * KS (1-D); LDS = 64 KB
-#define BZ_GLDS16(gsrc, ldst) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc), (__attribute__((address_space(3))) void*)(ldst), 16, 0, 0)
+// One 1 KB LDS-DMA: lane i's 16 bytes at `gsrc` land at LDS byte address ldst + 16 i (ldst wave-uniform).  Inline asm, not __builtin_amdgcn_global_load_lds:
+// with the builtin hipcc (ROCm 7.2) put an s_waitcnt vmcnt(0) between the DMAs of tile i+1 and the first fragment read of tile i in these kernels (its
+// LDS-DMA alias tracking; the same source in scripts/gemm_probe.hip compiled without it), i.e. one memory round trip per k-step.  An asm DMA is outside its
+// bookkeeping: the counted waits in the kernels are the only ones.  M0 (the DMA's LDS base) is saved and restored inside the statement.
+__device__ __forceinline__ void glds16(const void* gsrc, const unsigned char* ldst) {
+  const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(const __attribute__((address_space(3))) unsigned char*)ldst);
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+#define BZ_GLDS16(gsrc, ldst) glds16((gsrc), (ldst))
 // TM = 2: 128-row tiles; TM = 1: 64-row tiles (2 x 2 waves of 32 x 64) for <= 64 rows and for the grouped form, where an expert sees tens of rows
 // and a 128-row A tile would spend half of the CU's load slots on clamped duplicates
 template <int DT, int TM>
@@ -697,6 +706,125 @@ __global__ __launch_bounds__(WPB * 64) void k_gemm_q4g_mfma(const uint4* __restr
   }
 }
 
+// The same arithmetic with both operands shared through LDS (prompts of more than 64 rows): workgroup tile 128 rows x 128 columns (two 64-column weight
+// tiles) x 64 k, 2 x 2 waves of 64 x 64.  Activations go global -> LDS by LDS-DMA exactly as in k_gemm_nt2 (128-byte rows, pieces XOR-swizzled by row & 7);
+// the int4 weights are DMA'd as they lie in memory -- a (tile, 32-k chunk) is 64 lanes x 16 B = one 1 KB wave-instruction -- and each wave rebuilds its four
+// B fragments per chunk from ONE 16-byte LDS read per lane (two V_PERMLANE32_SWAPs + the V_PERM nibble trick above).  The activation rows are fetched once
+// per workgroup instead of once per wave (k_gemm_q4g_mfma re-reads them for every 64-column tile: 4 x the weight bytes at f16), the weight chunk once per
+// 128 rows.  A group (128 k) is two k-steps: the group accumulator is folded into the total with the f32 scale after the second one; the next group's
+// scales / zero points are ordinary loads issued a whole step ahead of their use (they are complete at the counted wait of the step that needs them).
+// Two 20 KB buffers; K may be split in units of groups (partials summed by k_q4g_mfma_reduce).     grid = 8 ceil(ntiles / 8) * mtiles * KS, 256 threads
+__device__ __forceinline__ unsigned ld_u16_asm(const void* p) { unsigned v; asm volatile("global_load_ushort %0, %1, off" : "=v"(v) : "v"(p) : "memory"); return v; }
+__device__ __forceinline__ unsigned ld_u8_asm(const void* p) { unsigned v; asm volatile("global_load_ubyte %0, %1, off" : "=v"(v) : "v"(p) : "memory"); return v; }
+__global__ __launch_bounds__(256) void k_gemm_q4g_lds(const uint4* __restrict__ W, const __half* __restrict__ Sc, const unsigned char* __restrict__ Z,
+                                                      const float* __restrict__ bias, int N, int K, const unsigned short* __restrict__ X, int S, int act,
+                                                      float* __restrict__ Y, float* __restrict__ part, int KS, int mtiles, int ntiles) {
+  constexpr int TILE = 16384 + 4096;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem3[];   // the only LDS object
+  const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+  const int mt = jj % mtiles, rest = jj / mtiles, ks = rest % KS, nt = (rest / KS) * 8 + xcd;
+  if (nt >= ntiles) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
+  const int m0 = mt * 128;
+  const int G = K >> 7, C32 = K >> 5, ncol = N >> 6;
+  const int g_beg = (int)((long long)ks * G / KS), g_end = (int)((long long)(ks + 1) * G / KS), nsteps = 2 * (g_end - g_beg);
+  const int ctile = min(nt * 2 + wn, ncol - 1);               // this wave's 64-column tile (N % 128 == 64: the last workgroup's second tile is a masked duplicate)
+  const bool cols_on = nt * 2 + wn < ncol;
+  // staging: every wave fills 4 row groups of A (8 rows x 128 B each) and ONE weight chunk: (column tile wave >> 1, chunk wave & 1) of the step
+  const int lrow = lane >> 3, piece = (lane & 7) ^ lrow;
+  unsigned xo[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) xo[i] = (unsigned)min(m0 + (wave * 4 + i) * 8 + lrow, S - 1) * (unsigned)K + 8u * piece;
+  const uint4* wsrc = W + (size_t)min(nt * 2 + (wave >> 1), ncol - 1) * C32 * 64 + lane;
+  auto issue = [&](int step, int buf) {                       // step = absolute 64-k step index
+    unsigned char* base = smem3 + buf * TILE;
+#pragma unroll
+    for (int i = 0; i < 4; i++) BZ_GLDS16(X + xo[i] + (size_t)step * 64, base + (wave * 4 + i) * 1024);
+    BZ_GLDS16(wsrc + (size_t)(2 * step + (wave & 1)) * 64, base + 16384 + wave * 1024);
+  };
+  const __half* sp = Sc + (size_t)ctile * G * 64 + r;
+  const unsigned char* zp = Z + (size_t)ctile * G * 64 + r;
+  f32x16 tot[2][2], grp[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int b = 0; b < 2; b++)
+#pragma unroll
+      for (int i = 0; i < 16; i++) { tot[a][b][i] = 0.f; grp[a][b][i] = 0.f; }
+  if (nsteps > 0) {
+    const int st0 = 2 * g_beg;
+    issue(st0, 0);
+    // (inline-asm loads: beside LDS-DMA hipcc puts a vmcnt(0) in front of LDS reads for any ordinary load still pending -- seen in the .s: one full
+    //  round trip per k-step; an asm load is outside its bookkeeping, and the counted wait at the top of the loop, tied to these registers, covers it)
+    unsigned sn0 = ld_u16_asm(sp + (size_t)g_beg * 64), sn1 = ld_u16_asm(sp + (size_t)g_beg * 64 + 32);
+    unsigned zn0 = ld_u8_asm(zp + (size_t)g_beg * 64), zn1 = ld_u8_asm(zp + (size_t)g_beg * 64 + 32);
+    float s0 = 0.f, s1 = 0.f;
+    f16x2 mz0 = {0, 0}, mz1 = {0, 0};
+    const int aoff = (wm * 64 + r) * 128, sw = r & 7;
+    for (int it = 0; it < nsteps; it++) {
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(sn0), "+v"(sn1), "+v"(zn0), "+v"(zn1) :: "memory");   // this wave's pieces of step `it` and the scale loads have landed
+      __builtin_amdgcn_s_barrier();
+      if (!(it & 1)) {                                        // first step of a group: take its scales BEFORE the next LDS-DMAs go out (hipcc waits vmcnt(0) at
+        s0 = __half2float(__ushort_as_half((unsigned short)sn0)); s1 = __half2float(__ushort_as_half((unsigned short)sn1));   // the use of an ordinary load beside LDS-DMA: here nothing is outstanding, so the wait is free)
+        const _Float16 a0 = (_Float16)(-(1024.0f + (float)zn0)), a1 = (_Float16)(-(1024.0f + (float)zn1));
+        mz0 = f16x2{a0, a0}; mz1 = f16x2{a1, a1};
+      }
+      issue(st0 + min(it + 1, nsteps - 1), (it + 1) & 1);
+      if (!(it & 1)) {                                        // ... and request the next group's, a whole group ahead of their use
+        const int gn = min(g_beg + (it >> 1) + 1, g_end - 1);
+        sn0 = ld_u16_asm(sp + (size_t)gn * 64); sn1 = ld_u16_asm(sp + (size_t)gn * 64 + 32);
+        zn0 = ld_u8_asm(zp + (size_t)gn * 64); zn1 = ld_u8_asm(zp + (size_t)gn * 64 + 32);
+      }
+      const unsigned char* tb = smem3 + (it & 1) * TILE;
+#pragma unroll
+      for (int cc = 0; cc < 2; cc++) {
+        const u32x4 w = *(const u32x4*)(tb + 16384 + (wn * 2 + cc) * 1024 + lane * 16);
+        const u32x2 r01 = __builtin_amdgcn_permlane32_swap(w.x, w.y, false, false);   // .x: columns 0-31 {k 0-7 | k 8-15}; .y: columns 32-63
+        const u32x2 r23 = __builtin_amdgcn_permlane32_swap(w.z, w.w, false, false);   // same for k 16-31
+        const uint4 b00 = q4_frag_f16(r01.x, mz0), b01 = q4_frag_f16(r01.y, mz1);
+        const uint4 b10 = q4_frag_f16(r23.x, mz0), b11 = q4_frag_f16(r23.y, mz1);
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+          // row (wm 64 + 32 t + r), k = 32 cc + 16 step + 8 h .. + 7 of the 64-k tile: piece 4 cc + 2 step + h
+          const uint4 a0 = *(const uint4*)(tb + aoff + t * 32 * 128 + (((4 * cc + h) ^ sw) * 16));
+          const uint4 a1 = *(const uint4*)(tb + aoff + t * 32 * 128 + (((4 * cc + 2 + h) ^ sw) * 16));
+          grp[t][0] = mfma16<BZ_F16>(a0, b00, grp[t][0]);
+          grp[t][1] = mfma16<BZ_F16>(a0, b01, grp[t][1]);
+          grp[t][0] = mfma16<BZ_F16>(a1, b10, grp[t][0]);
+          grp[t][1] = mfma16<BZ_F16>(a1, b11, grp[t][1]);
+        }
+      }
+      if (it & 1) {
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+          for (int i = 0; i < 16; i++) {
+            tot[t][0][i] = fmaf(s0, grp[t][0][i], tot[t][0][i]); tot[t][1][i] = fmaf(s1, grp[t][1][i], tot[t][1][i]);
+            grp[t][0][i] = 0.f; grp[t][1][i] = 0.f;
+          }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  if (cols_on) {
+#pragma unroll
+    for (int T = 0; T < 2; T++) {
+      const int n = ctile * 64 + 32 * T + r;
+      const float bv = (!part && bias) ? bias[n] : 0.f;
+#pragma unroll
+      for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+          const int m = m0 + wm * 64 + 32 * t + (i & 3) + 8 * (i >> 2) + 4 * h;
+          if (m < S) {
+            if (part) part[((size_t)ks * S + m) * N + n] = tot[t][T][i];
+            else Y[(size_t)m * N + n] = pf_round(tot[t][T][i] + bv, act);
+          }
+        }
+    }
+  }
+}
+
 __global__ void k_q4g_mfma_reduce(const float* __restrict__ part, int KS, size_t SN, int N, const float* __restrict__ bias, int act, float* __restrict__ Y) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < SN; i += (size_t)gridDim.x * 256) {
     float v = 0.f;
@@ -995,44 +1123,6 @@ int bzk_gemm_nt_grouped(hipStream_t s, int dt, const void* x16, const void* w, l
   return BZ_OK;
 }
 
-// int4 group-quantised weights (the layout above) -> f16 [N][K] rows, for long prompts: past a few hundred rows the prompt GEMM is cheaper as
-// one dequantisation pass (N K / 2 bytes in, 2 N K out) + the LDS-DMA f16 GEMM than as k_gemm_q4g_mfma, whose weight fragments are rebuilt per row tile.
-// w = R16((q - z) * s): the product is exact in f32 (4 x 11 bits) and rounded once.    thread = (column, pair of 32-k chunks): 2 x 16 B in, 128 B out
-__global__ __launch_bounds__(256) void k_q4g_dequant_f16(const uint4* __restrict__ W, const __half* __restrict__ Sc, const unsigned char* __restrict__ Z, int N, int K,
-                                                         __half* __restrict__ out) {
-  const int tile = blockIdx.x, lane = threadIdx.x & 63, pi = blockIdx.y * 4 + (threadIdx.x >> 6);
-  const int G = K >> 7, C32 = K >> 5;
-  if (2 * pi >= C32) return;
-  const int n = tile * 64 + lane;
-#pragma unroll
-  for (int j = 0; j < 2; j++) {
-    const int kc = 2 * pi + j, g = kc >> 2;
-    const uint4 w = W[((size_t)tile * C32 + kc) * 64 + lane];
-    const float sc = __half2float(Sc[((size_t)tile * G + g) * 64 + lane]), z = (float)Z[((size_t)tile * G + g) * 64 + lane];
-    const unsigned ww[4] = {w.x ^ 0x88888888u, w.y ^ 0x88888888u, w.z ^ 0x88888888u, w.w ^ 0x88888888u};
-    __half* o = out + (size_t)n * K + kc * 32;
-#pragma unroll
-    for (int jw = 0; jw < 4; jw++) {
-      unsigned short v[8];
-#pragma unroll
-      for (int b = 0; b < 4; b++) {
-        v[b] = __half_as_ushort(__float2half_rn(((float)((ww[jw] >> (8 * b)) & 15u) - z) * sc));
-        v[4 + b] = __half_as_ushort(__float2half_rn(((float)((ww[jw] >> (8 * b + 4)) & 15u) - z) * sc));
-      }
-      uint4 pk;
-      pk.x = v[0] | ((unsigned)v[1] << 16); pk.y = v[2] | ((unsigned)v[3] << 16); pk.z = v[4] | ((unsigned)v[5] << 16); pk.w = v[6] | ((unsigned)v[7] << 16);
-      *(uint4*)(o + 8 * jw) = pk;
-    }
-  }
-}
-int bzk_q4g_dequant_f16(hipStream_t s, const LinearDev& L, void* out) {
-  if (L.kind != LK_Q4G || L.perm || L.K % 128 || L.N % 64 || (L.gs && L.gs != 128)) BZ_FAIL(BZ_E_UNSUPPORTED, "q4g_dequant: unsupported weight format");
-  const dim3 grid(L.N / 64, (L.K / 64 + 3) / 4);
-  BZ_LAUNCH("q4g_dequant_f16", (double)L.N * L.K * 2.5, k_q4g_dequant_f16, grid, dim3(256), 0, s, (const uint4*)L.w, (const __half*)L.scales, (const unsigned char*)L.zeros, L.N, L.K, (__half*)out);
-  BZ_HIP(hipGetLastError());
-  return BZ_OK;
-}
-
 bool bzk_gemm_q4g_mfma_ok(const LinearDev& L, int xdt, int rows) {
   static const bool off = getenv("BZ_NO_Q4G_MFMA") != nullptr;
   return !off && L.kind == LK_Q4G && !L.perm && L.K % 128 == 0 && L.N % 64 == 0 && xdt == BZ_F16 && rows >= 9;   // 9+: the multi-row dot4 kernel would need a second pass over the weights
@@ -1044,6 +1134,24 @@ int bzk_gemm_q4g_mfma(hipStream_t s, const LinearDev& L, const void* x16, int S,
   // way, and single-wave blocks spread a small grid (o_proj / down at a few hundred rows: 64 x 8 tiles) over the whole chip
   static const bool no_ks = getenv("BZ_Q4G_MFMA_NO_KSPLIT") != nullptr;
   const double flops = 2.0 * S * (double)L.N * L.K;
+  static const bool no_lds = getenv("BZ_Q4G_MFMA_NO_LDS") != nullptr;
+  if (!no_lds && S > 64) {                       // prompts: both operands through LDS (k_gemm_q4g_lds)
+    const int mtiles = (S + 127) / 128, ntiles = (L.N + 127) / 128, Gn = L.K / 128;
+    const long long tiles2 = (long long)mtiles * ntiles;
+    int KS2 = 1;
+    if (!no_ks && ws) while (KS2 * 2 * tiles2 <= 320 && KS2 * 2 <= Gn / 2 && KS2 < 16 && (size_t)KS2 * 2 * S * L.N * 4 <= ws_bytes) KS2 *= 2;
+    float* part2 = KS2 > 1 ? ws : nullptr;
+    const unsigned grid2 = 8u * (unsigned)((ntiles + 7) / 8) * (unsigned)mtiles * (unsigned)KS2;
+    BZ_LAUNCH("gemm_q4g_mfma<lds>", flops, k_gemm_q4g_lds, dim3(grid2), dim3(256), 2 * (16384 + 4096), s, (const uint4*)L.w, (const __half*)L.scales, (const unsigned char*)L.zeros, L.bias,
+              L.N, L.K, (const unsigned short*)x16, S, act, y, part2, KS2, mtiles, ntiles);
+    BZ_HIP(hipGetLastError());
+    if (KS2 > 1) {
+      const size_t SN = (size_t)S * L.N;
+      hipLaunchKernelGGL(k_q4g_mfma_reduce, dim3((unsigned)std::min<size_t>((SN + 255) / 256, 2048)), dim3(256), 0, s, (const float*)ws, KS2, SN, L.N, L.bias, act, y);
+      BZ_HIP(hipGetLastError());
+    }
+    return BZ_OK;
+  }
   const bool small = S <= 32;                    // decode batches / short prompts: one 32-row tile per wave
   const int G = L.K / 128, rt = small ? 1 : (S + 63) / 64;
   // short prompts / decode batches: too few 64 x 64 tiles to fill the chip -> split K over blockIdx.z into partials (summed in a fixed order)

@@ -367,9 +367,9 @@ def test_prefill_attention_on_the_matrix_cores(device, act, hd, nq, nkv):
     assert np.array_equal(b1, g1) and np.array_equal(b2, g2)
 
 
-def test_long_prompt_on_int4_weights_dequantises_once(device):
-    """prompts of >= 384 rows on AWQ weights: k_q4g_dequant_f16 + the f16 LDS-DMA GEMM instead of k_gemm_q4g_mfma (pf_gemm); 400-token prompt,
-    every row of logits against the oracle, then decode steps on the cache it wrote"""
+def test_long_prompt_on_int4_weights(device):
+    """400-token prompt on AWQ weights (k_gemm_q4g_mfma at 64-row tiles, flash attention over 7 key tiles): every row of logits against the oracle,
+    then decode steps on the cache it wrote"""
     model = synth.make_llama("tiny-awq", max_seq_len=512)
     cfg = model["config"]
     lm, om = runtime.LoadedModel.from_synth(device, model), orc_py.OrcLlama(model)
