@@ -152,6 +152,11 @@ __device__ __forceinline__ void glds16(const void* gsrc, const unsigned char* ld
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
 }
 #define BZ_GLDS16(gsrc, ldst) glds16((gsrc), (ldst))
+__device__ __forceinline__ void glds4(const void* gsrc, const unsigned char* ldst) {      // 64 lanes x 4 bytes -> 256 contiguous LDS bytes
+  const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(const __attribute__((address_space(3))) unsigned char*)ldst);
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
 // TM = 2: 128-row tiles; TM = 1: 64-row tiles (2 x 2 waves of 32 x 64) for <= 64 rows and for the grouped form, where an expert sees tens of rows
 // and a 128-row A tile would spend half of the CU's load slots on clamped duplicates
 template <int DT, int TM>
@@ -711,11 +716,10 @@ __global__ __launch_bounds__(WPB * 64) void k_gemm_q4g_mfma(const uint4* __restr
 // the int4 weights are DMA'd as they lie in memory -- a (tile, 32-k chunk) is 64 lanes x 16 B = one 1 KB wave-instruction -- and each wave rebuilds its four
 // B fragments per chunk from ONE 16-byte LDS read per lane (two V_PERMLANE32_SWAPs + the V_PERM nibble trick above).  The activation rows are fetched once
 // per workgroup instead of once per wave (k_gemm_q4g_mfma re-reads them for every 64-column tile: 4 x the weight bytes at f16), the weight chunk once per
-// 128 rows.  A group (128 k) is two k-steps: the group accumulator is folded into the total with the f32 scale after the second one; the next group's
-// scales / zero points are ordinary loads issued a whole step ahead of their use (they are complete at the counted wait of the step that needs them).
-// Two 20 KB buffers; K may be split in units of groups (partials summed by k_q4g_mfma_reduce).     grid = 8 ceil(ntiles / 8) * mtiles * KS, 256 threads
-__device__ __forceinline__ unsigned ld_u16_asm(const void* p) { unsigned v; asm volatile("global_load_ushort %0, %1, off" : "=v"(v) : "v"(p) : "memory"); return v; }
-__device__ __forceinline__ unsigned ld_u8_asm(const void* p) { unsigned v; asm volatile("global_load_ubyte %0, %1, off" : "=v"(v) : "v"(p) : "memory"); return v; }
+// 128 rows.  A group (128 k) is two k-steps: the group accumulator (started from the constant 0 by the group's first MFMA) is folded into the total with the f32
+// scale after the second one; the next group's scales / zero points come by LDS-DMA too, a whole group ahead of their use.
+// Three 20 KB buffers (prefetch distance two steps; occupancy is bound by registers, not LDS); K may be split in units of groups (partials summed by
+// k_q4g_mfma_reduce).     grid = 8 ceil(ntiles / 8) * mtiles * KS, 256 threads
 __global__ __launch_bounds__(256) void k_gemm_q4g_lds(const uint4* __restrict__ W, const __half* __restrict__ Sc, const unsigned char* __restrict__ Z,
                                                       const float* __restrict__ bias, int N, int K, const unsigned short* __restrict__ X, int S, int act,
                                                       float* __restrict__ Y, float* __restrict__ part, int KS, int mtiles, int ntiles) {
@@ -742,8 +746,6 @@ __global__ __launch_bounds__(256) void k_gemm_q4g_lds(const uint4* __restrict__ 
     for (int i = 0; i < 4; i++) BZ_GLDS16(X + xo[i] + (size_t)step * 64, base + (wave * 4 + i) * 1024);
     BZ_GLDS16(wsrc + (size_t)(2 * step + (wave & 1)) * 64, base + 16384 + wave * 1024);
   };
-  const __half* sp = Sc + (size_t)ctile * G * 64 + r;
-  const unsigned char* zp = Z + (size_t)ctile * G * 64 + r;
   f32x16 tot[2][2], grp[2][2];
 #pragma unroll
   for (int a = 0; a < 2; a++)
@@ -752,59 +754,64 @@ __global__ __launch_bounds__(256) void k_gemm_q4g_lds(const uint4* __restrict__ 
 #pragma unroll
       for (int i = 0; i < 16; i++) { tot[a][b][i] = 0.f; grp[a][b][i] = 0.f; }
   if (nsteps > 0) {
+    // three buffers, prefetch distance two steps.  EVERY load of the loop is an LDS-DMA -- the group scales / zero points too (one 4-byte-per-lane DMA per
+    // wave and group into a 256-byte slot: lanes 0-31 two f16 scales each, lanes 32-47 four zero points each) -- because the counted waits rely on loads
+    // retiring in issue order, which held among LDS-DMAs but NOT between LDS-DMAs and ordinary VGPR loads (a version with register scale loads returned
+    // sparse wrong tiles).  Order of issue: tile 0, group g_beg's scales, tile 1 | step it: tile it + 2 (+ on even steps the scales of step it + 2's group).
+    // "tile `it` (and, on even steps, its group's scales) landed" = vmcnt(5) on even steps (only tile it + 1's 5 DMAs may be out), vmcnt(6) on odd ones.
     const int st0 = 2 * g_beg;
+    unsigned char* sslot = smem3 + 3 * TILE + wave * 256;      // + 1024 for odd groups
+    const unsigned char* ssrc = lane < 32 ? (const unsigned char*)(Sc + (size_t)ctile * G * 64) + 4 * lane : (const unsigned char*)(Z + (size_t)ctile * G * 64) + 4 * (lane & 15);
+    const size_t sstep = lane < 32 ? 128 : 64;                  // bytes per group in the scale / zero arrays
     issue(st0, 0);
-    // (inline-asm loads: beside LDS-DMA hipcc puts a vmcnt(0) in front of LDS reads for any ordinary load still pending -- seen in the .s: one full
-    //  round trip per k-step; an asm load is outside its bookkeeping, and the counted wait at the top of the loop, tied to these registers, covers it)
-    unsigned sn0 = ld_u16_asm(sp + (size_t)g_beg * 64), sn1 = ld_u16_asm(sp + (size_t)g_beg * 64 + 32);
-    unsigned zn0 = ld_u8_asm(zp + (size_t)g_beg * 64), zn1 = ld_u8_asm(zp + (size_t)g_beg * 64 + 32);
-    float s0 = 0.f, s1 = 0.f;
-    f16x2 mz0 = {0, 0}, mz1 = {0, 0};
+    glds4(ssrc + (size_t)g_beg * sstep, sslot);
+    issue(st0 + min(1, nsteps - 1), 1);
     const int aoff = (wm * 64 + r) * 128, sw = r & 7;
-    for (int it = 0; it < nsteps; it++) {
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(sn0), "+v"(sn1), "+v"(zn0), "+v"(zn1) :: "memory");   // this wave's pieces of step `it` and the scale loads have landed
-      __builtin_amdgcn_s_barrier();
-      if (!(it & 1)) {                                        // first step of a group: take its scales BEFORE the next LDS-DMAs go out (hipcc waits vmcnt(0) at
-        s0 = __half2float(__ushort_as_half((unsigned short)sn0)); s1 = __half2float(__ushort_as_half((unsigned short)sn1));   // the use of an ordinary load beside LDS-DMA: here nothing is outstanding, so the wait is free)
-        const _Float16 a0 = (_Float16)(-(1024.0f + (float)zn0)), a1 = (_Float16)(-(1024.0f + (float)zn1));
-        mz0 = f16x2{a0, a0}; mz1 = f16x2{a1, a1};
-      }
-      issue(st0 + min(it + 1, nsteps - 1), (it + 1) & 1);
-      if (!(it & 1)) {                                        // ... and request the next group's, a whole group ahead of their use
-        const int gn = min(g_beg + (it >> 1) + 1, g_end - 1);
-        sn0 = ld_u16_asm(sp + (size_t)gn * 64); sn1 = ld_u16_asm(sp + (size_t)gn * 64 + 32);
-        zn0 = ld_u8_asm(zp + (size_t)gn * 64); zn1 = ld_u8_asm(zp + (size_t)gn * 64 + 32);
-      }
-      const unsigned char* tb = smem3 + (it & 1) * TILE;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int gi = 0; gi < g_end - g_beg; gi++) {
+      float s0 = 0.f, s1 = 0.f;
+      f16x2 mz0 = {0, 0}, mz1 = {0, 0};
 #pragma unroll
-      for (int cc = 0; cc < 2; cc++) {
-        const u32x4 w = *(const u32x4*)(tb + 16384 + (wn * 2 + cc) * 1024 + lane * 16);
-        const u32x2 r01 = __builtin_amdgcn_permlane32_swap(w.x, w.y, false, false);   // .x: columns 0-31 {k 0-7 | k 8-15}; .y: columns 32-63
-        const u32x2 r23 = __builtin_amdgcn_permlane32_swap(w.z, w.w, false, false);   // same for k 16-31
-        const uint4 b00 = q4_frag_f16(r01.x, mz0), b01 = q4_frag_f16(r01.y, mz1);
-        const uint4 b10 = q4_frag_f16(r23.x, mz0), b11 = q4_frag_f16(r23.y, mz1);
+      for (int hs = 0; hs < 2; hs++) {
+        const int it = 2 * gi + hs;
+        if (hs == 0) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                        // everyone's pieces of tile `it` have landed; everyone is done reading the buffer the next issue overwrites
+        if (hs == 0) {
+          const unsigned char* sb = sslot + (gi & 1) * 1024;
+          s0 = __half2float(*(const __half*)(sb + 2 * r)); s1 = __half2float(*(const __half*)(sb + 2 * (r + 32)));
+          const _Float16 a0 = (_Float16)(-(1024.0f + (float)sb[128 + r])), a1 = (_Float16)(-(1024.0f + (float)sb[128 + 32 + r]));
+          mz0 = f16x2{a0, a0}; mz1 = f16x2{a1, a1};
+        }
+        issue(st0 + min(it + 2, nsteps - 1), (it + 2) % 3);   // clamped: redundant reloads at the tail, never a branch around a load
+        if (hs == 0) glds4(ssrc + (size_t)min(g_beg + gi + 1, g_end - 1) * sstep, sslot + ((gi + 1) & 1) * 1024);   // the next group's scales, a whole group ahead of their use
+        const unsigned char* tb = smem3 + (it % 3) * TILE;
 #pragma unroll
-        for (int t = 0; t < 2; t++) {
-          // row (wm 64 + 32 t + r), k = 32 cc + 16 step + 8 h .. + 7 of the 64-k tile: piece 4 cc + 2 step + h
-          const uint4 a0 = *(const uint4*)(tb + aoff + t * 32 * 128 + (((4 * cc + h) ^ sw) * 16));
-          const uint4 a1 = *(const uint4*)(tb + aoff + t * 32 * 128 + (((4 * cc + 2 + h) ^ sw) * 16));
-          grp[t][0] = mfma16<BZ_F16>(a0, b00, grp[t][0]);
-          grp[t][1] = mfma16<BZ_F16>(a0, b01, grp[t][1]);
-          grp[t][0] = mfma16<BZ_F16>(a1, b10, grp[t][0]);
-          grp[t][1] = mfma16<BZ_F16>(a1, b11, grp[t][1]);
+        for (int cc = 0; cc < 2; cc++) {
+          const u32x4 w = *(const u32x4*)(tb + 16384 + (wn * 2 + cc) * 1024 + lane * 16);
+          const u32x2 r01 = __builtin_amdgcn_permlane32_swap(w.x, w.y, false, false);   // .x: columns 0-31 {k 0-7 | k 8-15}; .y: columns 32-63
+          const u32x2 r23 = __builtin_amdgcn_permlane32_swap(w.z, w.w, false, false);   // same for k 16-31
+          const uint4 b00 = q4_frag_f16(r01.x, mz0), b01 = q4_frag_f16(r01.y, mz1);
+          const uint4 b10 = q4_frag_f16(r23.x, mz0), b11 = q4_frag_f16(r23.y, mz1);
+#pragma unroll
+          for (int t = 0; t < 2; t++) {
+            // row (wm 64 + 32 t + r), k = 32 cc + 16 step + 8 h .. + 7 of the 64-k tile: piece 4 cc + 2 step + h
+            const uint4 a0 = *(const uint4*)(tb + aoff + t * 32 * 128 + (((4 * cc + h) ^ sw) * 16));
+            const uint4 a1 = *(const uint4*)(tb + aoff + t * 32 * 128 + (((4 * cc + 2 + h) ^ sw) * 16));
+            const bool first = hs == 0 && cc == 0;            // compile time: a group's first MFMA takes the constant 0 as C (no zeroing pass)
+            grp[t][0] = mfma16<BZ_F16>(a0, b00, first ? zero16 : grp[t][0]);
+            grp[t][1] = mfma16<BZ_F16>(a0, b01, first ? zero16 : grp[t][1]);
+            grp[t][0] = mfma16<BZ_F16>(a1, b10, grp[t][0]);
+            grp[t][1] = mfma16<BZ_F16>(a1, b11, grp[t][1]);
+          }
         }
       }
-      if (it & 1) {
 #pragma unroll
-        for (int t = 0; t < 2; t++)
+      for (int t = 0; t < 2; t++)
 #pragma unroll
-          for (int i = 0; i < 16; i++) {
-            tot[t][0][i] = fmaf(s0, grp[t][0][i], tot[t][0][i]); tot[t][1][i] = fmaf(s1, grp[t][1][i], tot[t][1][i]);
-            grp[t][0][i] = 0.f; grp[t][1][i] = 0.f;
-          }
-      }
+        for (int i = 0; i < 16; i++) { tot[t][0][i] = fmaf(s0, grp[t][0][i], tot[t][0][i]); tot[t][1][i] = fmaf(s1, grp[t][1][i], tot[t][1][i]); }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the tail's redundant LDS-DMAs land before the LDS allocation is released
   }
   if (cols_on) {
 #pragma unroll
@@ -1135,14 +1142,15 @@ int bzk_gemm_q4g_mfma(hipStream_t s, const LinearDev& L, const void* x16, int S,
   static const bool no_ks = getenv("BZ_Q4G_MFMA_NO_KSPLIT") != nullptr;
   const double flops = 2.0 * S * (double)L.N * L.K;
   static const bool no_lds = getenv("BZ_Q4G_MFMA_NO_LDS") != nullptr;
-  if (!no_lds && S > 64) {                       // prompts: both operands through LDS (k_gemm_q4g_lds)
+  static const int lds_min = getenv("BZ_Q4G_LDS_MIN") ? atoi(getenv("BZ_Q4G_LDS_MIN")) : 65;
+  if (!no_lds && S >= lds_min) {                 // prompts: both operands through LDS (k_gemm_q4g_lds)
     const int mtiles = (S + 127) / 128, ntiles = (L.N + 127) / 128, Gn = L.K / 128;
     const long long tiles2 = (long long)mtiles * ntiles;
     int KS2 = 1;
     if (!no_ks && ws) while (KS2 * 2 * tiles2 <= 320 && KS2 * 2 <= Gn / 2 && KS2 < 16 && (size_t)KS2 * 2 * S * L.N * 4 <= ws_bytes) KS2 *= 2;
     float* part2 = KS2 > 1 ? ws : nullptr;
     const unsigned grid2 = 8u * (unsigned)((ntiles + 7) / 8) * (unsigned)mtiles * (unsigned)KS2;
-    BZ_LAUNCH("gemm_q4g_mfma<lds>", flops, k_gemm_q4g_lds, dim3(grid2), dim3(256), 2 * (16384 + 4096), s, (const uint4*)L.w, (const __half*)L.scales, (const unsigned char*)L.zeros, L.bias,
+    BZ_LAUNCH("gemm_q4g_mfma<lds>", flops, k_gemm_q4g_lds, dim3(grid2), dim3(256), 3 * (16384 + 4096) + 2048, s, (const uint4*)L.w, (const __half*)L.scales, (const unsigned char*)L.zeros, L.bias,
               L.N, L.K, (const unsigned short*)x16, S, act, y, part2, KS2, mtiles, ntiles);
     BZ_HIP(hipGetLastError());
     if (KS2 > 1) {

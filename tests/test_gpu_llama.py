@@ -281,7 +281,7 @@ def test_prefill_matmul_q4g_mfma(device, S):
     rng = np.random.default_rng(100 + S)
     cases = [("tiny-awq", {}, [("model.layers.1.mlp.down_proj.weight", "down"), ("model.layers.0.mlp.gate_proj.weight", "gate")]),
              ("tiny-gptq", dict(bias=True), [("model.layers.1.self_attn.q_proj.weight", "q")])]
-    if S in (33, 130):
+    if S in (33, 130, 300):
         cases.append(("llama3-8b-awq-2l", {}, [("model.layers.1.mlp.down_proj.weight", "down"), ("model.layers.0.self_attn.k_proj.weight", "k")]))
     for preset, over, names in cases:
         model = synth.make_llama(preset, **over)
