@@ -261,6 +261,26 @@ def main():
                          "note": "ids compared on every step whose oracle top-2 gap is >= gap_guard of max|logit| (8 rounding units of the activation dtype: a rounding-level "
                                  "tie below that); logit errors relative to the CPU row (L2) and to its largest magnitude (max-norm); bar: 1e-3 relative L2 (f16 / f32 activations)"}
 
+    # the prompt phase on its own (outside the timed decode region): a 512-token prompt through the batched prefill (matrix-core GEMMs + flash attention),
+    # 1 warm-up + 2 timed passes, best of the two; 2 FLOP per linear weight per token against the dense 16-bit MFMA peak
+    if cfg["act_dtype"] in ("f16", "bf16") and cfg["max_seq_len"] >= 520:
+        pf_len = 512
+        kv2 = runtime.LayeredKvCache(dev, cfg["n_layers"], 1, cfg["n_kv_heads"], pf_len + 8, cfg["max_seq_len"], cfg["head_dim"], kv_dt)
+        p2 = synth.prompt_tokens(pf_len, cfg["vocab"], seed=11)
+        ptimer = hip_events(C.c_void_p(dev.stream()))
+        pf_ms = []
+        for _ in range(3):
+            dev.synchronize()
+            ptimer.start()
+            lm.forward_with_kv_cache(p2, kv2, 0)
+            ptimer.stop()
+            pf_ms.append(ptimer.ms())
+        H, I, nq, nkv, hd = cfg["hidden"], cfg["inter"], cfg["n_heads"], cfg["n_kv_heads"], cfg["head_dim"]
+        lin = cfg["n_layers"] * (H * nq * hd + 2 * H * nkv * hd + nq * hd * H + 3 * H * I)
+        best = min(pf_ms[1:])
+        out["prefill"] = {"tokens": pf_len, "ms": round(best, 3), "tokens_per_s": round(pf_len / (best / 1e3), 1), "gemm_tflops": round(2.0 * lin * pf_len / (best / 1e3) / 1e12, 2),
+                          "mfma_peak_tflops": 2500.0, "frac_of_mfma_peak": round(2.0 * lin * pf_len / (best / 1e3) / 2.5e15, 4), "runs_ms": [round(v, 3) for v in pf_ms],
+                          "note": "whole prompt phase of a 512-token prompt (norms, GEMMs on the matrix cores, RoPE / cache append, flash attention), not part of `value`"}
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
