@@ -2014,13 +2014,16 @@ extern "C" int bz_prefill_matmul(bz_model* m, const char* name, const bz_tensor*
     BZ_FAIL(BZ_E_INVALID, "prefill_matmul: x must be F32 [S,%d], y F32 [S,%d]", L.K, L.N);
   BZ_HIP(hipSetDevice(m->dev->id));
   hipStream_t st = m->dev->stream;
-  void* x16 = nullptr;
+  void* x16 = nullptr; void* ws = nullptr;
+  const size_t ws_bytes = (size_t)48 << 20;      // split-K partials, as the prefill paths pass them
   BZ_HIP(hipMalloc(&x16, (size_t)S * L.K * 2));
+  if (hipMalloc(&ws, ws_bytes) != hipSuccess) { hipFree(x16); BZ_FAIL(BZ_E_OOM, "prefill_matmul: workspace"); }
   const int xdt = q4 ? BZ_F16 : L.wdt;
   int rc = bzk_pf_cvt16(st, xdt, (const float*)x->ptr, (size_t)S * L.K, x16);
-  if (rc == BZ_OK) rc = q4 ? bzk_gemm_q4g_mfma(st, L, x16, S, BZ_F32, (float*)y->ptr) : bzk_gemm_nt(st, L.wdt, x16, L.w, L.bias, S, L.N, L.K, BZ_F32, (float*)y->ptr);
+  if (rc == BZ_OK) rc = q4 ? bzk_gemm_q4g_mfma(st, L, x16, S, BZ_F32, (float*)y->ptr, (float*)ws, ws_bytes)
+                           : bzk_gemm_nt(st, L.wdt, x16, L.w, L.bias, S, L.N, L.K, BZ_F32, (float*)y->ptr, (float*)ws, ws_bytes);
   hipStreamSynchronize(st);
-  hipFree(x16);
+  hipFree(x16); hipFree(ws);
   return rc;
   BZ_API_END
 }

@@ -429,7 +429,7 @@ template <int DT> __device__ __forceinline__ uint4 pack8(const float* v) {
   o.z = (unsigned)to16<DT>(v[4]) | ((unsigned)to16<DT>(v[5]) << 16); o.w = (unsigned)to16<DT>(v[6]) | ((unsigned)to16<DT>(v[7]) << 16);
   return o;
 }
-template <int DT, int HD, int REP>
+template <int DT, int HD, int REP, bool PAGED>
 __global__ __launch_bounds__(256) void k_pf_attn_mfma(const float* __restrict__ qkv, int S, int nq, int nkv, int pos0, int act, KvView kv, int layer, float scale,
                                                       unsigned short* __restrict__ out16) {
   constexpr int HW = REP < 4 ? REP : 4, QT = 4 / HW, PR = HD / 8, PK = HD * 2 + 16, PV = 64 * 2 + 8, NC = HD / 16, NDB = HD / 32, KPT = PR / 4;
@@ -451,45 +451,40 @@ __global__ __launch_bounds__(256) void k_pf_attn_mfma(const float* __restrict__ 
       qf[c] = pack8<DT>(v);
     }
   }
-  auto row_off = [&](int p) -> size_t {
-    if (kv.paged) { const int blk = kv.block_table[p / kv.bs]; return (size_t)layer * kv.layer_stride + (((size_t)blk * kv.n_kv + kvh) * kv.bs + p % kv.bs) * kv.hd; }
-    return (size_t)layer * kv.layer_stride + ((size_t)kvh * kv.cap + p) * kv.hd;
+  auto row_off = [&](int p) -> size_t {     // (PAGED is compile time: a run-time branch around each load made hipcc wait for them one by one and spill the prefetch registers)
+    if constexpr (PAGED) { const int blk = kv.block_table[p / kv.bs]; return (size_t)layer * kv.layer_stride + (((size_t)blk * kv.n_kv + kvh) * kv.bs + p % kv.bs) * kv.hd; }
+    else return (size_t)layer * kv.layer_stride + ((size_t)kvh * kv.cap + p) * kv.hd;
   };
+  // (macros, not lambdas: with the prefetch registers captured by reference hipcc kept one of the two arrays in scratch, reloaded and re-stored every tile)
   uint4 kr[KPT], vr[KPT];
-  auto gload = [&](int kt0) {
-#pragma unroll
-    for (int i = 0; i < KPT; i++) {
-      const int idx = tid + 256 * i, row = idx / PR, col = idx % PR;                                 // K: a row's pieces on consecutive lanes
-      kr[i] = *(const uint4*)((const unsigned short*)kv.k + row_off(min(kt0 + row, kmax - 1)) + 8 * col);
-      vr[i] = *(const uint4*)((const unsigned short*)kv.v + row_off(min(kt0 + lane, kmax - 1)) + 8 * (wave + 4 * i));   // V: 64 keys on the 64 lanes, piece wave + 4 i
-    }
-  };
-  auto lstore = [&]() {
-#pragma unroll
-    for (int i = 0; i < KPT; i++) {
-      const int idx = tid + 256 * i, row = idx / PR, col = idx % PR;
-      *(uint4*)(Ks + row * PK + col * 16) = kr[i];
-      const unsigned u[4] = {vr[i].x, vr[i].y, vr[i].z, vr[i].w};
-      unsigned char* vb = Vt + (8 * (wave + 4 * i)) * PV + lane * 2;
-#pragma unroll
-      for (int e = 0; e < 4; e++) {
-        *(unsigned short*)(vb + (2 * e) * PV) = (unsigned short)(u[e] & 0xffffu);
-        *(unsigned short*)(vb + (2 * e + 1) * PV) = (unsigned short)(u[e] >> 16);
-      }
-    }
-  };
+#define PFA_GLOAD(KT0)                                                                                                                        \
+  _Pragma("unroll") for (int i = 0; i < KPT; i++) {                                                                                           \
+    const int idx = tid + 256 * i, row = idx / PR, col = idx % PR;                                 /* K: a row's pieces on consecutive lanes */ \
+    kr[i] = *(const uint4*)((const unsigned short*)kv.k + row_off(min((KT0) + row, kmax - 1)) + 8 * col);                                      \
+    vr[i] = *(const uint4*)((const unsigned short*)kv.v + row_off(min((KT0) + lane, kmax - 1)) + 8 * (wave + 4 * i));   /* V: 64 keys on the 64 lanes, piece wave + 4 i */ \
+  }
   f32x16 o[NDB];
 #pragma unroll
   for (int d = 0; d < NDB; d++)
 #pragma unroll
     for (int i = 0; i < 16; i++) o[d][i] = 0.f;
   float m = -INFINITY, l = 0.f;
-  gload(0);
+  PFA_GLOAD(0)
   for (int kt0 = 0; kt0 < kmax; kt0 += 64) {
     __syncthreads();                                          // the previous tile's fragment reads are done
-    lstore();
+#pragma unroll
+    for (int i = 0; i < KPT; i++) {
+      const int idx = tid + 256 * i, row = idx / PR, col = idx % PR;
+      *(uint4*)(Ks + row * PK + col * 16) = kr[i];
+      unsigned char* vb = Vt + (8 * (wave + 4 * i)) * PV + lane * 2;
+      const uint4 vv = vr[i];
+      *(unsigned short*)(vb + 0 * PV) = (unsigned short)(vv.x & 0xffffu); *(unsigned short*)(vb + 1 * PV) = (unsigned short)(vv.x >> 16);
+      *(unsigned short*)(vb + 2 * PV) = (unsigned short)(vv.y & 0xffffu); *(unsigned short*)(vb + 3 * PV) = (unsigned short)(vv.y >> 16);
+      *(unsigned short*)(vb + 4 * PV) = (unsigned short)(vv.z & 0xffffu); *(unsigned short*)(vb + 5 * PV) = (unsigned short)(vv.z >> 16);
+      *(unsigned short*)(vb + 6 * PV) = (unsigned short)(vv.w & 0xffffu); *(unsigned short*)(vb + 7 * PV) = (unsigned short)(vv.w >> 16);
+    }
     __syncthreads();
-    if (kt0 + 64 < kmax) gload(kt0 + 64);                     // uniform; lands under this tile's arithmetic
+    { const int ktn = kt0 + 64 < kmax ? kt0 + 64 : kt0; PFA_GLOAD(ktn) }                  // lands under this tile's arithmetic (last tile: a redundant reload, never a branch around the loads -- under one, hipcc kept the prefetch registers in scratch)
     if (kt0 <= my_last) {                                     // wave-uniform: later tiles are fully masked for this wave
       f32x16 st[2];
 #pragma unroll
@@ -566,15 +561,20 @@ __global__ __launch_bounds__(256) void k_pf_attn_mfma(const float* __restrict__ 
   }
 }
 
+#undef PFA_GLOAD
 // a16[s][i] = to16(R(R(silu(g)) * u)),  gu rows = [gate (I) | up (I)]
 template <int DT>
-__global__ void k_pf_silu(const float* gu, int S, int I, int act, unsigned short* a16) {
-  const size_t n = (size_t)S * I;
-  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
-    const size_t s = idx / I, i = idx % I;
-    const float g = gu[s * 2 * I + i], u = gu[s * 2 * I + I + i];
-    a16[idx] = to16<DT>(pf_round(pf_round(g / (1.0f + expf(-g)), act) * u, act));
-  }
+__global__ __launch_bounds__(256) void k_pf_silu(const float* __restrict__ gu, int S, int I, int act, unsigned short* __restrict__ a16) {   // grid = (ceil(I / 1024), S): 4 columns per thread
+  const int s = blockIdx.y, i = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= I) return;
+  const float* row = gu + (size_t)s * 2 * I;
+  const float4 g = *(const float4*)(row + i), u = *(const float4*)(row + I + i);
+  const float gv[4] = {g.x, g.y, g.z, g.w}, uv[4] = {u.x, u.y, u.z, u.w};
+  unsigned short o[4];
+#pragma unroll
+  for (int e = 0; e < 4; e++) o[e] = to16<DT>(pf_round(pf_round(gv[e] / (1.0f + expf(-gv[e])), act) * uv[e], act));
+  uint2 w; w.x = o[0] | ((unsigned)o[1] << 16); w.y = o[2] | ((unsigned)o[3] << 16);
+  *(uint2*)(a16 + (size_t)s * I + i) = w;
 }
 
 template <int DT>
@@ -1261,7 +1261,8 @@ int bzk_pf_attn(hipStream_t s, int dt, const float* qkv, int S, int nq, int nkv,
     const int HW = REP < 4 ? REP : 4, QT = 4 / HW;
     const dim3 grid((S + 32 * QT - 1) / (32 * QT), nkv, REP / HW);
     const double flops = 4.0 * nq * hd * ((double)S * pos0 + 0.5 * (double)S * S);
-#define LAUNCH_PFM(DT, HD, R) BZ_LAUNCH("pf_attn_mfma", flops, (k_pf_attn_mfma<DT, HD, R>), grid, dim3(256), 0, s, qkv, S, nq, nkv, pos0, act, kv, layer, scale_m, (unsigned short*)out16)
+#define LAUNCH_PFM(DT, HD, R) do { if (kv.paged) BZ_LAUNCH("pf_attn_mfma", flops, (k_pf_attn_mfma<DT, HD, R, true>), grid, dim3(256), 0, s, qkv, S, nq, nkv, pos0, act, kv, layer, scale_m, (unsigned short*)out16); \
+                                   else BZ_LAUNCH("pf_attn_mfma", flops, (k_pf_attn_mfma<DT, HD, R, false>), grid, dim3(256), 0, s, qkv, S, nq, nkv, pos0, act, kv, layer, scale_m, (unsigned short*)out16); } while (0)
 #define LAUNCH_PFM_R(DT, HD) do { if (REP == 1) LAUNCH_PFM(DT, HD, 1); else if (REP == 2) LAUNCH_PFM(DT, HD, 2); else if (REP == 4) LAUNCH_PFM(DT, HD, 4); else LAUNCH_PFM(DT, HD, 8); } while (0)
 #define LAUNCH_PFM_H(DT) do { if (hd == 64) LAUNCH_PFM_R(DT, 64); else LAUNCH_PFM_R(DT, 128); } while (0)
     if (dt == BZ_F16) LAUNCH_PFM_H(BZ_F16); else LAUNCH_PFM_H(BZ_BF16);
@@ -1287,8 +1288,10 @@ int bzk_pf_attn(hipStream_t s, int dt, const float* qkv, int S, int nq, int nkv,
   return BZ_OK;
 }
 int bzk_pf_silu(hipStream_t s, int dt, const float* gu, int S, int I, int act, void* a16) {
-  if (dt == BZ_F16) hipLaunchKernelGGL(k_pf_silu<BZ_F16>, dim3(512), dim3(256), 0, s, gu, S, I, act, (unsigned short*)a16);
-  else hipLaunchKernelGGL(k_pf_silu<BZ_BF16>, dim3(512), dim3(256), 0, s, gu, S, I, act, (unsigned short*)a16);
+  if (I % 4) BZ_FAIL(BZ_E_UNSUPPORTED, "pf_silu: intermediate size %d is not a multiple of 4", I);
+  const dim3 grid((I + 1023) / 1024, S);
+  if (dt == BZ_F16) hipLaunchKernelGGL(k_pf_silu<BZ_F16>, grid, dim3(256), 0, s, gu, S, I, act, (unsigned short*)a16);
+  else hipLaunchKernelGGL(k_pf_silu<BZ_BF16>, grid, dim3(256), 0, s, gu, S, I, act, (unsigned short*)a16);
   BZ_HIP(hipGetLastError());
   return BZ_OK;
 }

@@ -301,6 +301,38 @@ def test_prefill_matmul_q4g_mfma(device, S):
             assert np.abs(got - want).max() <= 3e-6 * np.abs(want).max(), (preset, name, S, float(np.abs(got - want).max()), float(np.abs(want).max()))
 
 
+def test_prefill_gemms_are_deterministic_run_to_run(device):
+    """race screen for the LDS-DMA kernels (k_gemm_nt2, k_gemm_q4g_lds): their LDS hand-off rests on counted vmcnt waits + raw barriers, and a wrong count
+    shows as RARE wrong tiles (one was caught this way during bring-up: ordinary loads retire out of order with LDS-DMAs).  The same product 12 times at
+    the 8B / 1B layer widths and ragged row counts: bit-identical every time, and equal to the f64 reference"""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    import npref
+    rng = np.random.default_rng(77)
+    for preset, over, name, short, dt in (("llama3-8b-awq-2l", {}, "model.layers.0.mlp.down_proj.weight", "down", "f16"),
+                                          ("llama3-8b-awq-2l", {}, "model.layers.1.self_attn.q_proj.weight", "q", "f16"),
+                                          ("llama3.2-1b-bf16", dict(n_layers=1, vocab=4096), "model.layers.0.mlp.gate_proj.weight", "gate", "bf16")):
+        model = synth.make_llama(preset, **over)
+        lm = runtime.LoadedModel.from_synth(device, model)
+        layer = int(name.split(".")[2])
+        W = npref.dequant(model["layers"][layer][short]).astype(np.float64)
+        N, K = W.shape
+        for S in (130, 513):
+            x = rng.standard_normal((S, K)).astype(np.float32)
+            tx = device.tensor(x)
+            want = _np16(x, dt).astype(np.float64) @ W.T
+            first = None
+            for rep in range(12):
+                ty = device.zeros((S, N))
+                L.check(L.lib().bz_prefill_matmul(lm.h, name.encode(), tx.h, S, ty.h))
+                got = ty.to_numpy()
+                if first is None:
+                    first = got
+                    assert np.abs(got - want).max() <= 3e-6 * np.abs(want).max(), (preset, name, S)
+                else:
+                    assert np.array_equal(got, first), (preset, name, S, rep, int((got != first).sum()))
+
+
 def test_batched_prefill_then_decode_matches_oracle(device):
     # 24-token prompt -> MFMA prefill path; the following decode steps read the cache it wrote
     for preset in ("tiny-bf16",):
