@@ -720,31 +720,38 @@ __global__ __launch_bounds__(WPB * 64) void k_gemm_q4g_mfma(const uint4* __restr
 // scale after the second one; the next group's scales / zero points come by LDS-DMA too, a whole group ahead of their use.
 // Three 20 KB buffers (prefetch distance two steps; occupancy is bound by registers, not LDS); K may be split in units of groups (partials summed by
 // k_q4g_mfma_reduce).     grid = 8 ceil(ntiles / 8) * mtiles * KS, 256 threads
+// WIDE (<= 64 rows: decode batches, short prompts): the four waves sit side by side on FOUR column tiles and share ONE 64-row activation tile -- 8 KB of
+// activations per 8 KB of weights and step, where the square tile moves 16 KB of (half clamped) activation rows per 4 KB of weights
+template <bool WIDE>
 __global__ __launch_bounds__(256) void k_gemm_q4g_lds(const uint4* __restrict__ W, const __half* __restrict__ Sc, const unsigned char* __restrict__ Z,
                                                       const float* __restrict__ bias, int N, int K, const unsigned short* __restrict__ X, int S, int act,
                                                       float* __restrict__ Y, float* __restrict__ part, int KS, int mtiles, int ntiles) {
-  constexpr int TILE = 16384 + 4096;
+  constexpr int BM = WIDE ? 64 : 128, CT = WIDE ? 4 : 2, ABYTES = BM * 128, WBYTES = CT * 2048, TILE = ABYTES + WBYTES, NA = BM / 32, NW = CT / 2;   // NA / NW: A row groups / weight chunks per wave and step
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem3[];   // the only LDS object
   const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
   const int mt = jj % mtiles, rest = jj / mtiles, ks = rest % KS, nt = (rest / KS) * 8 + xcd;
   if (nt >= ntiles) return;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
-  const int m0 = mt * 128;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5, wm = WIDE ? 0 : wave >> 1, wn = WIDE ? wave : wave & 1;
+  const int m0 = mt * BM;
   const int G = K >> 7, C32 = K >> 5, ncol = N >> 6;
   const int g_beg = (int)((long long)ks * G / KS), g_end = (int)((long long)(ks + 1) * G / KS), nsteps = 2 * (g_end - g_beg);
-  const int ctile = min(nt * 2 + wn, ncol - 1);               // this wave's 64-column tile (N % 128 == 64: the last workgroup's second tile is a masked duplicate)
-  const bool cols_on = nt * 2 + wn < ncol;
+  const int ctile = min(nt * CT + wn, ncol - 1);              // this wave's 64-column tile (past the edge: a masked duplicate of the last one)
+  const bool cols_on = nt * CT + wn < ncol;
   // staging: every wave fills 4 row groups of A (8 rows x 128 B each) and ONE weight chunk: (column tile wave >> 1, chunk wave & 1) of the step
   const int lrow = lane >> 3, piece = (lane & 7) ^ lrow;
-  unsigned xo[4];
+  unsigned xo[NA];
 #pragma unroll
-  for (int i = 0; i < 4; i++) xo[i] = (unsigned)min(m0 + (wave * 4 + i) * 8 + lrow, S - 1) * (unsigned)K + 8u * piece;
-  const uint4* wsrc = W + (size_t)min(nt * 2 + (wave >> 1), ncol - 1) * C32 * 64 + lane;
+  for (int i = 0; i < NA; i++) xo[i] = (unsigned)min(m0 + (wave * NA + i) * 8 + lrow, S - 1) * (unsigned)K + 8u * piece;
+  // weight chunks: square form -- wave w stages (column tile w >> 1, chunk w & 1); wide form -- wave w stages both chunks of its own column tile
+  const uint4* wsrc = W + (size_t)min(nt * CT + (WIDE ? wave : wave >> 1), ncol - 1) * C32 * 64 + lane;
   auto issue = [&](int step, int buf) {                       // step = absolute 64-k step index
     unsigned char* base = smem3 + buf * TILE;
 #pragma unroll
-    for (int i = 0; i < 4; i++) BZ_GLDS16(X + xo[i] + (size_t)step * 64, base + (wave * 4 + i) * 1024);
-    BZ_GLDS16(wsrc + (size_t)(2 * step + (wave & 1)) * 64, base + 16384 + wave * 1024);
+    for (int i = 0; i < NA; i++) BZ_GLDS16(X + xo[i] + (size_t)step * 64, base + (wave * NA + i) * 1024);
+    if constexpr (WIDE) {
+      BZ_GLDS16(wsrc + (size_t)(2 * step) * 64, base + ABYTES + wave * 2048);
+      BZ_GLDS16(wsrc + (size_t)(2 * step + 1) * 64, base + ABYTES + wave * 2048 + 1024);
+    } else BZ_GLDS16(wsrc + (size_t)(2 * step + (wave & 1)) * 64, base + ABYTES + wave * 1024);
   };
   f32x16 tot[2][2], grp[2][2];
 #pragma unroll
@@ -774,8 +781,9 @@ __global__ __launch_bounds__(256) void k_gemm_q4g_lds(const uint4* __restrict__ 
 #pragma unroll
       for (int hs = 0; hs < 2; hs++) {
         const int it = 2 * gi + hs;
-        if (hs == 0) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        // DMAs per tile and wave: 4 + 1 (square), 2 + 2 (wide)
+        if constexpr (WIDE) { if (hs == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }
+        else { if (hs == 0) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
         __builtin_amdgcn_s_barrier();                        // everyone's pieces of tile `it` have landed; everyone is done reading the buffer the next issue overwrites
         if (hs == 0) {
           const unsigned char* sb = sslot + (gi & 1) * 1024;
@@ -788,7 +796,7 @@ __global__ __launch_bounds__(256) void k_gemm_q4g_lds(const uint4* __restrict__ 
         const unsigned char* tb = smem3 + (it % 3) * TILE;
 #pragma unroll
         for (int cc = 0; cc < 2; cc++) {
-          const u32x4 w = *(const u32x4*)(tb + 16384 + (wn * 2 + cc) * 1024 + lane * 16);
+          const u32x4 w = *(const u32x4*)(tb + ABYTES + (wn * 2 + cc) * 1024 + lane * 16);
           const u32x2 r01 = __builtin_amdgcn_permlane32_swap(w.x, w.y, false, false);   // .x: columns 0-31 {k 0-7 | k 8-15}; .y: columns 32-63
           const u32x2 r23 = __builtin_amdgcn_permlane32_swap(w.z, w.w, false, false);   // same for k 16-31
           const uint4 b00 = q4_frag_f16(r01.x, mz0), b01 = q4_frag_f16(r01.y, mz1);
@@ -1144,14 +1152,17 @@ int bzk_gemm_q4g_mfma(hipStream_t s, const LinearDev& L, const void* x16, int S,
   static const bool no_lds = getenv("BZ_Q4G_MFMA_NO_LDS") != nullptr;
   static const int lds_min = getenv("BZ_Q4G_LDS_MIN") ? atoi(getenv("BZ_Q4G_LDS_MIN")) : 33;   // measured: 64 rows 6.57 -> 6.25 ms per batched step; at 32 rows the single-wave kernel wins (4.7 vs 5.7 ms)
   if (!no_lds && S >= lds_min) {                 // prompts: both operands through LDS (k_gemm_q4g_lds)
-    const int mtiles = (S + 127) / 128, ntiles = (L.N + 127) / 128, Gn = L.K / 128;
+    const bool wide = S <= 64;
+    const int mtiles = wide ? 1 : (S + 127) / 128, ntiles = wide ? (L.N + 255) / 256 : (L.N + 127) / 128, Gn = L.K / 128;
     const long long tiles2 = (long long)mtiles * ntiles;
     int KS2 = 1;
     if (!no_ks && ws) while (KS2 * 2 * tiles2 <= 320 && KS2 * 2 <= Gn / 2 && KS2 < 16 && (size_t)KS2 * 2 * S * L.N * 4 <= ws_bytes) KS2 *= 2;
     float* part2 = KS2 > 1 ? ws : nullptr;
     const unsigned grid2 = 8u * (unsigned)((ntiles + 7) / 8) * (unsigned)mtiles * (unsigned)KS2;
-    BZ_LAUNCH("gemm_q4g_mfma<lds>", flops, k_gemm_q4g_lds, dim3(grid2), dim3(256), 3 * (16384 + 4096) + 2048, s, (const uint4*)L.w, (const __half*)L.scales, (const unsigned char*)L.zeros, L.bias,
-              L.N, L.K, (const unsigned short*)x16, S, act, y, part2, KS2, mtiles, ntiles);
+    if (wide) BZ_LAUNCH("gemm_q4g_mfma<lds 64x256>", flops, k_gemm_q4g_lds<true>, dim3(grid2), dim3(256), 3 * (8192 + 8192) + 2048, s, (const uint4*)L.w, (const __half*)L.scales,
+                        (const unsigned char*)L.zeros, L.bias, L.N, L.K, (const unsigned short*)x16, S, act, y, part2, KS2, mtiles, ntiles);
+    else BZ_LAUNCH("gemm_q4g_mfma<lds>", flops, k_gemm_q4g_lds<false>, dim3(grid2), dim3(256), 3 * (16384 + 4096) + 2048, s, (const uint4*)L.w, (const __half*)L.scales,
+                   (const unsigned char*)L.zeros, L.bias, L.N, L.K, (const unsigned short*)x16, S, act, y, part2, KS2, mtiles, ntiles);
     BZ_HIP(hipGetLastError());
     if (KS2 > 1) {
       const size_t SN = (size_t)S * L.N;
