@@ -1150,7 +1150,7 @@ int bzk_gemm_q4g_mfma(hipStream_t s, const LinearDev& L, const void* x16, int S,
   static const bool no_ks = getenv("BZ_Q4G_MFMA_NO_KSPLIT") != nullptr;
   const double flops = 2.0 * S * (double)L.N * L.K;
   static const bool no_lds = getenv("BZ_Q4G_MFMA_NO_LDS") != nullptr;
-  static const int lds_min = getenv("BZ_Q4G_LDS_MIN") ? atoi(getenv("BZ_Q4G_LDS_MIN")) : 33;   // measured: 64 rows 6.57 -> 6.25 ms per batched step; at 32 rows the single-wave kernel wins (4.7 vs 5.7 ms)
+  static const int lds_min = getenv("BZ_Q4G_LDS_MIN") ? atoi(getenv("BZ_Q4G_LDS_MIN")) : 17;   // measured with the wide form (batched decode steps): 24 rows 4.49 -> 4.28 ms, 32 rows 4.66 -> 4.39 ms, 9-16 rows equal
   if (!no_lds && S >= lds_min) {                 // prompts: both operands through LDS (k_gemm_q4g_lds)
     const bool wide = S <= 64;
     const int mtiles = wide ? 1 : (S + 127) / 128, ntiles = wide ? (L.N + 255) / 256 : (L.N + 127) / 128, Gn = L.K / 128;
