@@ -97,7 +97,8 @@ SWITCHES = [
     ("BZ_NO_MOE_ROUTE_FUSION=1", ["deepseek-v2-lite-2l"]),               # router launch (last-workgroup top-k) + plain grouped gate/up
     ("BZ_NO_MFMA_PREFILL=1", ["mamba2-2.7b-2l", "tiny-bf16"]),           # prompts token by token
     ("BZ_NO_Q4G_MFMA=1", ["llama3-8b-awq-2l"]),                          # int4 prompts through the multi-row dot4 kernel
-    ("BZ_Q4G_LDS_MIN=9", ["llama3-8b-awq-2l", "awq-h2048", "tiny-awq"]),  # the 20-row prompt chunk through k_gemm_q4g_lds (default: from 33 rows) at the real widths
+    ("BZ_Q4G_MFMA_NO_LDS=1", ["llama3-8b-awq-2l", "awq-h2048"]),          # the 20-row prompt chunk on the single-wave k_gemm_q4g_mfma (default from 17 rows: the LDS kernel)
+    ("BZ_Q4G_LDS_MIN=9", ["llama3-8b-awq-2l", "awq-h2048", "tiny-awq"]),  # k_gemm_q4g_lds (wide form) from 9 rows instead of 17
     ("BZ_NO_PF_ATTN_MFMA=1", ["llama3.2-1b-bf16-2l", "tiny-bf16"]),      # prompt attention on the scalar kernel (scores in LDS) instead of k_pf_attn_mfma
     ("BZ_GEMM_NT_WAVE_TILES=1", ["llama3.2-1b-bf16-2l", "mamba2-2.7b-2l", "deepseek-v2-lite-2l"]),   # prefill GEMMs on the register-staged wave-tile kernel instead of the LDS-DMA one
     ("BZ_GGUF_MLP_FUSION=1", ["mistral-7b-q4km-2l", "q4km-h2048"]),       # opt-in fused GGUF MLP (Q4_K gate/up + Q4_K / Q6_K down in one launch)
