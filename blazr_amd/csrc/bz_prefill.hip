@@ -1,15 +1,20 @@
-// bz_prefill.hip -- batched prefill for dense f16 / bf16 Llama-family models ("MFMA for prefill only").
+// bz_prefill.hip -- the prompt phase on the matrix cores ("MFMA for prefill only"): batched prefill of the Llama family (dense 16-bit and
+// int4 group-quantised weights), Mamba2 and DeepSeek-V2, and the multi-row steps of batched decode.
 //
 //   Y[S,N] = R(X[S,K] . W[N,K]^T)  on the matrix cores: v_mfma_f32_32x32x16_{bf16,f16}, f32 accumulate.
 //
 // Both operands are K-contiguous ("NT"), which is exactly the MFMA fragment order: lane (r = l & 31, h = l >> 5) of a 32x32x16 step owns
 // 8 consecutive k of row r of A and of column r of B.  K is a reduction index, so any permutation of k applied to both operands is allowed:
-// within a 64-k tile, step s of lane half h takes k = 32 h + 8 s + j.  A lane then reads 64 contiguous bytes of its row per tile (four 16-byte
-// loads), lanes (r,0) and (r,1) together one 128-byte line -- fragments come straight from global memory, no LDS and no transposes.
-// A wave owns 32 output columns and up to 128 rows (MT = 1..4 accumulator tiles); weights are streamed once per 128-row chunk of the prompt.
-// Register double buffering keeps one 64-k tile of loads in flight under the MFMAs of the previous one.
+// within a 64-k tile, step s of lane half h takes k = 32 h + 8 s + j -- a lane reads 64 contiguous bytes of its row per tile; no transposes.
 //
-// Around the GEMM: row-wise residual + RMSNorm (16-bit output = GEMM input), RoPE + KV append, causal attention over the cache, SiLU*up.
+//   k_gemm_nt2        dense 16-bit GEMM, both operands global -> LDS by LDS-DMA (128 x 128 x 64 / 64 x 128 x 64 tiles, split-K, grouped MoE form)
+//   k_gemm_nt         the round-1 form (weights straight to registers, A through LDS), kept for A/B runs (BZ_GEMM_NT_WAVE_TILES)
+//   k_gemm_q4g_lds    W4A16: raw int4 chunks by LDS-DMA, exact (q - z) f16 fragments rebuilt per wave, f32 group scales (square and 64 x 256 wide form)
+//   k_gemm_q4g_mfma   W4A16 single-wave form (<= 16 rows)
+//   k_pf_attn_mfma    flash-style causal attention for prompts;  k_pf_attn: scalar form with scores in LDS (decode batches)
+//   k_ssm_scan        Mamba2 recurrence over the prompt's tokens (sequential in t: the state is rounded per token as the decode step stores it)
+//
+// Around them: row-wise residual + RMSNorm (16-bit output = GEMM input), RoPE + KV append, SiLU*up, depthwise conv, gated norm.
 // Every tensor is rounded to the activation dtype at the same op boundaries as the decode path and the oracle (oracle/orc_llama.c).
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
