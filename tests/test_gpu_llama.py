@@ -301,6 +301,29 @@ def test_prefill_matmul_q4g_mfma(device, S):
             assert np.abs(got - want).max() <= 3e-6 * np.abs(want).max(), (preset, name, S, float(np.abs(got - want).max()), float(np.abs(want).max()))
 
 
+@pytest.mark.parametrize("S", [20, 64, 70, 200])
+def test_prefill_matmul_q4g_ragged_column_tiles(device, S):
+    """k_gemm_q4g_lds at N = 64 = ONE column tile: the wide form (<= 64 rows, 4 tiles per workgroup) and the square form (2 per workgroup) both run a
+    workgroup whose extra waves are masked duplicates of the last tile"""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    import npref
+    rng = np.random.default_rng(300 + S)
+    model = synth.make_llama("tiny-awq", n_kv_heads=1)
+    lm = runtime.LoadedModel.from_synth(device, model)
+    for name, short in (("model.layers.0.self_attn.k_proj.weight", "k"), ("model.layers.1.self_attn.v_proj.weight", "v")):
+        layer = int(name.split(".")[2])
+        W = npref.dequant(model["layers"][layer][short]).astype(np.float64)
+        N, K = W.shape
+        assert N == 64
+        x = rng.standard_normal((S, K)).astype(np.float32)
+        tx, ty = device.tensor(x), device.zeros((S, N))
+        L.check(L.lib().bz_prefill_matmul(lm.h, name.encode(), tx.h, S, ty.h))
+        want = _np16(x, "f16").astype(np.float64) @ W.T
+        got = ty.to_numpy()
+        assert np.abs(got - want).max() <= 3e-6 * np.abs(want).max(), (name, S, float(np.abs(got - want).max()))
+
+
 def test_prefill_gemms_are_deterministic_run_to_run(device):
     """race screen for the LDS-DMA kernels (k_gemm_nt2, k_gemm_q4g_lds): their LDS hand-off rests on counted vmcnt waits + raw barriers, and a wrong count
     shows as RARE wrong tiles (one was caught this way during bring-up: ordinary loads retire out of order with LDS-DMAs).  The same product 12 times at
