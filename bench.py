@@ -98,6 +98,9 @@ def main():
     ap.add_argument("--reps", type=int, default=3)           # timed runs of exactly --steps steps each; the median is reported
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=32)    # ~10 s of CPU work on the GPU box's host cores (bounded sample)
+    # OpenMP threads of the CPU baseline; 0 = min(logical CPUs, 64) -- the GEMVs are memory-bound on the host, more threads than memory channels
+    # buy nothing (SURVEY 8d planned OMP_NUM_THREADS = nproc; the count actually used is what `cpu_baseline.cores` reports)
+    ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -195,7 +198,7 @@ def main():
 
     out = {"metric": "decode tokens/sec, Llama-3-8B AWQ-INT4 seq=1 on MI355X (and HBM-roofline fraction)", "value": round(tok_s, 2),
            "unit": "tokens/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(wall_ms / args.steps, 5),
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i8", "data": "synthetic",
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i4", "data": "synthetic",
            "config": {"workload": "%s greedy decode, batch 1, seq=1, prompt %d (seed %d), whole step as one hipGraph; N>1 = independent replicas"
                                   % (args.preset, args.prompt_len, args.prompt_seed), "algorithmic_bytes_per_token": algo_bytes,
                       "resident_weight_bytes": resident, "context_at_end": pos},
@@ -208,6 +211,7 @@ def main():
     if want_cpu:
         # CPU baseline: the oracle (a port -- BASELINE.md 4), same weights, same prompt, bounded sample; and the parity gate
         from oracle import orc_py
+        orc_py.set_threads(args.cpu_threads if args.cpu_threads > 0 else min(os.cpu_count() or 1, 64))
         model = dict(config=cfg, embed=emb, final_norm=fnorm, lm_head=lmh, layers=host_layers)
         om = orc_py.OrcLlama(model)
         n_cpu = max(2, args.cpu_tokens)
@@ -238,12 +242,16 @@ def main():
         # pipelines in that dtype differ by about that much after a few layers (tests/test_gpu_parity_truth.py, scripts/parity_depth.py)
         guard = 8.0 * 2.0 ** -8 if cfg["act_dtype"] == "bf16" else 4e-3
         fair_prefix = next((i for i, g in enumerate(gaps) if g < guard), len(gaps))
-        n_same = next((i for i, (a, g) in enumerate(zip(cpu_tokens, tokens)) if a != g), min(len(cpu_tokens), len(tokens)))
+        n_both = min(len(cpu_tokens), len(tokens))          # the graph ran warmup + steps tokens, the CPU --cpu-tokens: compare what both have
+        n_same = next((i for i, (a, g) in enumerate(zip(cpu_tokens, tokens)) if a != g), n_both)
         # (2) teacher forcing: the CPU's ids are fed through bz_forward_kv one by one on a fresh cache (the prompt row comes from the prefill
         #     above), so EVERY step is comparable whatever happened before it: per-step logit errors, and the argmax wherever the step is fair
         kv2 = runtime.LayeredKvCache(dev, cfg["n_layers"], 1, cfg["n_kv_heads"], args.prompt_len + n_cpu + 1, cfg["max_seq_len"], cfg["head_dim"], kv_dt)
-        lm.forward_with_kv_cache(prompt, kv2, 0)
-        gpu_rows = [prefill_row]
+        # (the prompt goes through the single-token decode path too, as the oracle's does: the kernels under test from the first position on; the batched
+        #  prompt path -- MFMA GEMMs whose f32 sums differ from the exact sums in the last bit -- is compared with the oracle in tests/ and in "prefill" below)
+        for i, t in enumerate(prompt):
+            row = lm.forward_with_kv_cache([int(t)], kv2, i)
+        gpu_rows = [row.to_numpy().reshape(-1).copy()]
         for i in range(n_cpu - 1):
             gpu_rows.append(lm.forward_with_kv_cache([cpu_tokens[i]], kv2, args.prompt_len + i).to_numpy().reshape(-1).copy())
         l2 = [float(np.linalg.norm(g.astype(np.float64) - c) / np.linalg.norm(c)) for g, c in zip(gpu_rows, cpu_rows)]
@@ -252,8 +260,9 @@ def main():
         same = [int(g.argmax()) == t for g, t in zip(gpu_rows, cpu_tokens)]
         n_cmp = sum(fair)
         n_eq = sum(1 for f, e in zip(fair, same) if f and e)
-        out["parity"] = {"greedy_ids_match": bool(n_eq == n_cmp and n_same >= fair_prefix), "n_compared": n_cmp, "n_equal": n_eq, "n_tokens": n_cpu,
-                         "free_running": {"n_identical_prefix": n_same, "fair_prefix": fair_prefix, "cpu": cpu_tokens[:n_cpu], "gpu": tokens[:n_cpu]},
+        out["parity"] = {"greedy_ids_match": bool(n_eq == n_cmp and n_same >= min(fair_prefix, n_both)), "n_compared": n_cmp, "n_equal": n_eq, "n_tokens": n_cpu,
+                         "free_running": {"n_identical_prefix": n_same, "fair_prefix": fair_prefix, "n_available": n_both, "cpu": cpu_tokens[:n_cpu], "gpu": tokens[:n_cpu]},
+                         "prefill_row_rel_l2": round(float(np.linalg.norm(prefill_row.astype(np.float64) - cpu_rows[0]) / np.linalg.norm(cpu_rows[0])), 9),
                          "teacher_forced": {"rel_l2_max": round(max(l2), 9), "rel_l2_mean": round(float(np.mean(l2)), 9), "max_norm_max": round(max(mx), 9),
                                             "rel_l2_per_step": [round(v, 9) for v in l2], "max_norm_per_step": [round(v, 9) for v in mx],
                                             "top2_gap_per_step": [round(g, 5) for g in gaps], "argmax_equal_per_step": same},

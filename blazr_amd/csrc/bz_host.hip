@@ -3248,6 +3248,14 @@ extern "C" int bz_dequant(bz_model* m, const char* name, float* host) {
   BZ_API_END
 }
 
+extern "C" int bz_expf_spec(const float* x, int n, float* y) {
+  BZ_API_BEGIN
+  if (!x || !y || n < 0) BZ_FAIL(BZ_E_INVALID, "bad argument");
+  for (int i = 0; i < n; i++) y[i] = bz_expf(x[i]);   // the host compilation of the device function (bz_internal.h)
+  return BZ_OK;
+  BZ_API_END
+}
+
 extern "C" int bz_rms_norm(bz_device* dev, const bz_tensor* x, const bz_tensor* prev, const bz_tensor* w, int rows, int n, float eps, int act,
                            bz_tensor* y, bz_tensor* h_out) {
   BZ_API_BEGIN

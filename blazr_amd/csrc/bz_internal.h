@@ -409,6 +409,12 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   }
   return v;
 }
+// sum of a double over aligned groups of N = 8 or 16 lanes (result in every lane of the group)
+template <int N> __device__ __forceinline__ double grp_sum_d(double v) {
+  v += dpp_get<DPP_XOR1>(v); v += dpp_get<DPP_XOR2>(v); v += dpp_get<DPP_HMIRROR>(v);
+  if (N >= 16) v += dpp_get<DPP_MIRROR>(v);
+  return v;
+}
 // deterministic block sum of a double over NW waves (own LDS words; two barriers)
 template <int NW> __device__ __forceinline__ double block_sum_d(double v) {
   __shared__ double dred__[NW];
@@ -422,4 +428,46 @@ template <int NW> __device__ __forceinline__ double block_sum_d(double v) {
   return t;
 }
 __device__ __forceinline__ float wave_max(float v) { return xrow32<OpMax>(xrow16<OpMax>(grp_reduce<16, OpMax>(v))); }
+// lane l with l ^ 16 / l ^ 32 for a double (the attention sums are carried in double: exact products, order-independent to ~1e-16)
+__device__ __forceinline__ double xrow16_d(double v) {
+  const long long b = __double_as_longlong(v);
+  const bz_u2_t l = __builtin_amdgcn_permlane16_swap((unsigned)b, (unsigned)b, false, false), h = __builtin_amdgcn_permlane16_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
+  return __longlong_as_double(((long long)h.x << 32) | l.x) + __longlong_as_double(((long long)h.y << 32) | l.y);
+}
+__device__ __forceinline__ double xrow32_d(double v) {
+  const long long b = __double_as_longlong(v);
+  const bz_u2_t l = __builtin_amdgcn_permlane32_swap((unsigned)b, (unsigned)b, false, false), h = __builtin_amdgcn_permlane32_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
+  return __longlong_as_double(((long long)h.x << 32) | l.x) + __longlong_as_double(((long long)h.y << 32) | l.y);
+}
+
+// exp, SPECIFIED: one fixed sequence of IEEE operations (Cephes expf: Cody-Waite reduction by ln2 in two fma steps, degree-5 Horner polynomial,
+// exact scaling by 2^n) -- the CPU oracle evaluates the same sequence (oracle/orc_ops.c: orc_expf restates it independently), so SiLU and the
+// softmax weights are the same BITS on both sides and a comparison measures structure and rounding points, not two libms (round 2: device
+// libm vs glibc flipped ~one f16 rounding per layer, which a layer later is ~2000 one-ulp differences).  < 1 ulp from the true exp;
+// 0 below -86 (results stay normal numbers), +inf above 88.  Every multiply-add is an explicit fma: nothing here for a compiler to contract.
+__host__ __device__ __forceinline__ float bz_expf(float x) {
+  if (x != x) return x;
+  if (x < -86.0f) return 0.0f;
+  if (x > 88.0f) return __builtin_inff();
+  const float n = __builtin_rintf(x * 1.44269504088896341f);
+  float r = __builtin_fmaf(n, -0.693145751953125f, x);
+  r = __builtin_fmaf(n, -1.42860682030941723212e-6f, r);
+  float p = 1.9875691500e-4f;
+  p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+  p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+  p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+  p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+  p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+  const float r2 = r * r;
+  float y = __builtin_fmaf(p, r2, r);
+  y = y + 1.0f;
+  const unsigned sb = (unsigned)((int)n + 127) << 23;   // 2^n, n in [-125, 127]
+  float sc;
+  __builtin_memcpy(&sc, &sb, 4);
+  return y * sc;
+}
+// RoPE pair: the products are exact in double (x: <= 24 significant bits, table entry: 24), one rounding of their difference / sum in double and
+// one to f32 -- the same bits whatever gets contracted (oracle: orc_rope_apply)
+__device__ __forceinline__ float rope_lo(float x0, float x1, float c, float s) { return (float)((double)x0 * (double)c - (double)x1 * (double)s); }
+__device__ __forceinline__ float rope_hi(float x0, float x1, float c, float s) { return (float)((double)x1 * (double)c + (double)x0 * (double)s); }
 #endif  // __HIPCC__

@@ -11,7 +11,7 @@
 //     instruction: six dots per eight weights, no unpacking.  All group arithmetic is exact integer arithmetic and
 //     the groups are summed in double: the kernel computes the exactly rounded dot product (as the oracle defines it).
 //     The GGUF block formats (f32 activations) run on V_DOT4_I32_I8 over three int8 planes per 32-k chunk.
-//   * Split-K partial sums are added with 64-bit INTEGER atomics in 2^-32 fixed point: integer addition is
+//   * Split-K partial sums are added with 64-bit INTEGER atomics in 2^-44 fixed point: integer addition is
 //     associative, so the result is bit-reproducible regardless of block scheduling.  The consumer kernel
 //     converts and rounds in its prologue -- there are no separate reduce / norm / activation launches.
 //   * Each GEMV's prologue rebuilds its activation slice from the previous kernel's output (residual add,
@@ -56,21 +56,25 @@ __device__ __forceinline__ float round_act(float x, int act) {
   if (act == BZ_BF16) return bf16_round(x);
   return x;
 }
-// 2^-32 fixed point
+// 2^-44 fixed point (round 2: 2^-32).  A workgroup rounds its partial sum to the grid once (d2fix), so a sum over a few hundred workgroups carries ~1e-12 of
+// absolute error at 2^-44 against ~4e-9 at 2^-32 -- the latter is 1e-5 of an f16 rounding interval of a value near 0.1, i.e. about one flipped f16 rounding
+// per ten thousand outputs, and one flip in a layer's input is ~2000 one-ulp differences in its output.  Range: +-2^19 = 524288 (f16 ends at 65504).
+#define BZ_FIX_SCALE 17592186044416.0          /* 2^44 */
+#define BZ_FIX_INV 5.6843418860808015e-14      /* 2^-44 */
 __device__ __forceinline__ float fix2f(long long a) {
   // ONE rounding of the exact fixed-point sum to f32 (the oracle rounds its double sum to f32 once): both 32-bit halves are exact in
-  // double, so is their join below 2^53, and the cast rounds to nearest even
+  // double, so is their join below 2^53 (|value| < 512; above, the join itself rounds to 53 bits first), and the cast rounds to nearest even
   const unsigned long long m = a < 0 ? (unsigned long long)(-a) : (unsigned long long)a;
-  const double d = fma((double)(unsigned)(m >> 32), 4294967296.0, (double)(unsigned)(m & 0xffffffffull)) * 2.3283064365386963e-10;
+  const double d = fma((double)(unsigned)(m >> 32), 4294967296.0, (double)(unsigned)(m & 0xffffffffull)) * BZ_FIX_INV;
   const float r = (float)d;
   return a < 0 ? -r : r;
 }
-__device__ __forceinline__ long long f2fix(float p) { return __float2ll_rn(p * 4294967296.0f); }
+__device__ __forceinline__ long long f2fix(float p) { return __float2ll_rn(p * (float)BZ_FIX_SCALE); }
 __device__ __forceinline__ float vsrc_get(const VSrc& s, int i, int act) {
   if (s.fix) return round_act(fix2f(((const long long*)s.p)[i]), act);
   return ((const float*)s.p)[i];
 }
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + bz_expf(-x)); }
 
 // deterministic block sum over 256 threads; red: LDS float[4]
 __device__ __forceinline__ float block_sum256(float v, float* red) {
@@ -526,8 +530,8 @@ __device__ __forceinline__ void q4g_consume_n(const uint4 (&w)[NCH], int co, int
   y += q4_term(D, gpar[gp], gpar[gp + 1], s, z);
 }
 
-// 2^-32 fixed point from the double a lane accumulated over its groups
-__device__ __forceinline__ long long d2fix(double p) { return __double2ll_rn(p * 4294967296.0); }
+// 2^-44 fixed point from the double a lane accumulated over its groups
+__device__ __forceinline__ long long d2fix(double p) { return __double2ll_rn(p * BZ_FIX_SCALE); }
 
 // ---------------------------------------------------------------------------------------------------------
 // Fused MLP (INT4):  acc_down += Wd[:, slice] . R(R(silu(R(Wg[slice] x))) * R(Wu[slice] x)),  x = RMSNorm(R(h + prev))
@@ -3209,7 +3213,7 @@ __global__ __launch_bounds__(256) void k_attn_decode(AttnArgs a) {
       const int ia = a.interleaved ? 2 * i : i, ib = a.interleaved ? 2 * i + 1 : i + half;
       const float x0 = vsrc_get(a.qkv, base + ia, a.act), x1 = vsrc_get(a.qkv, base + ib, a.act);
       const float c = cr[i], s = sr[i];
-      const float y0 = round_act(x0 * c - x1 * s, a.act), y1 = round_act(x1 * c + x0 * s, a.act);
+      const float y0 = round_act(rope_lo(x0, x1, c, s), a.act), y1 = round_act(rope_hi(x0, x1, c, s), a.act);
       if (hh == 0) { qs[ia] = y0; qs[ib] = y1; }
       else { knew[ia] = y0; knew[ib] = y1; }
     }
@@ -3251,7 +3255,7 @@ __global__ __launch_bounds__(256) void k_attn_decode(AttnArgs a) {
       for (int i = 0; i < HD; i++) o[i] = vr.get(i);
     } else {
       const float mn = fmaxf(m, s);
-      const float alpha = expf(m - mn), e = expf(s - mn);
+      const float alpha = bz_expf(m - mn), e = bz_expf(s - mn);
       l = l * alpha + e;
       m = mn;
 #pragma unroll
@@ -3263,7 +3267,7 @@ __global__ __launch_bounds__(256) void k_attn_decode(AttnArgs a) {
   if (lane == 0) wred[wave] = wm;
   __syncthreads();
   const float M = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
-  const float w = (m == -INFINITY) ? 0.f : expf(m - M);
+  const float w = (m == -INFINITY) ? 0.f : bz_expf(m - M);
   const float ws = wave_sum(l * w);
   if (lane == 0) wred[4 + wave] = ws;
   const int nrows = min(len, 256);
@@ -3362,9 +3366,10 @@ __global__ __launch_bounds__(NW * 64) void k_attn2(AttnArgs a, const uint4* __re
   unsigned* q2 = (unsigned*)smem;             // [64] packed q pairs
   unsigned* k2 = q2 + 64;                     // [64] packed new key
   unsigned* v2 = k2 + 64;                     // [64] packed new value
-  float* wred = (float*)(v2 + 64);            // [2 NW]
-  float* pout = wred + 2 * NW;                // [NW][128] PV partials of the waves
-  float* outh = pout + NW * 128;              // [128] head output (FUSE)
+  double* pout = (double*)(v2 + 64);          // [NW][128] PV partials of the waves (double: see the sums below)
+  double* lred = pout + NW * 128;             // [NW] the waves' sums of the softmax weights
+  float* wred = (float*)(lred + NW);          // [2 NW] the waves' maxima
+  float* outh = wred + 2 * NW;                // [128] head output (FUSE)
   uint4* xpl = (uint4*)(outh + 128);          // [4 chunks][6 planes]: 384 B (as the three int8 planes before)
   int4* gpar = (int4*)(xpl + 4 * XQ_NP);      // [2]
   const int rep = a.nq / a.nkv;
@@ -3462,7 +3467,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn2(AttnArgs a, const uint4* __re
     if (tid < 2 * half) {
       const int hh = tid / half, i = tid % half;
       const int ia = a.interleaved ? 2 * i : i, ib = a.interleaved ? 2 * i + 1 : i + half;
-      const float y0 = round_act(px0 * pc - px1 * ps, a.act), y1 = round_act(px1 * pc + px0 * ps, a.act);
+      const float y0 = round_act(rope_lo(px0, px1, pc, ps), a.act), y1 = round_act(rope_hi(px0, px1, pc, ps), a.act);
       unsigned short* dst = (unsigned short*)(hh == 0 ? q2 : k2);
       const unsigned p0 = pack2<KVDT>(y0, y1);
       dst[ia] = (unsigned short)(p0 & 0xffffu);
@@ -3484,85 +3489,97 @@ __global__ __launch_bounds__(NW * 64) void k_attn2(AttnArgs a, const uint4* __re
   }
   STAMP(2);
 
+  // Exact sums, two passes (the oracle's definition, oracle/orc_ops.c: orc_attn_decode): score = f32(sum q k) * scale with the sum carried in double over exact
+  // products; the maximum over ALL positions first, then p = exp(score - max) (bz_expf), L = f32(sum p), O = f32(sum p v), both sums in double -- order-independent
+  // to ~1e-16, so the result does not depend on the chunk / wave / lane decomposition and equals the oracle's bits (round 2 merged 256-position chunks online
+  // with f32 sums: ~1e-7 of order-dependent error, i.e. about one flipped f16 rounding per layer).  A context of up to 256 positions keeps its rows and scores in
+  // registers between the passes; longer ones re-read K (L2 hits) in pass 2.
   const float scale = 1.0f / sqrtf((float)HD);
   const uint4 qq = ((const uint4*)q2)[piece];
-  float Mrun = -INFINITY, Lrun = 0.f, Orun = 0.f;   // running state (threads < 128 own output d = tid)
+  float qf[8];
+  unpack2<KVDT>(qq.x, qf[0], qf[1]); unpack2<KVDT>(qq.y, qf[2], qf[3]); unpack2<KVDT>(qq.z, qf[4], qf[5]); unpack2<KVDT>(qq.w, qf[6], qf[7]);
+  const bool single = len <= 256;
+  float sc_[NL];
+  float Mw = -INFINITY;
+#define ATT_SCORES(c0_)                                                                                                    \
+  _Pragma("unroll") for (int i = 0; i < NL; i++) {                                                                         \
+    const int p = (c0_) + wave * PW + RPL * i + rsub;                                                                      \
+    uint4 kk = kr[i];                                                                                                      \
+    if (!a.q_only && p == pos) { kk = ((const uint4*)k2)[piece]; vr[i] = ((const uint4*)v2)[piece]; }                      \
+    float kf[8];                                                                                                           \
+    unpack2<KVDT>(kk.x, kf[0], kf[1]); unpack2<KVDT>(kk.y, kf[2], kf[3]); unpack2<KVDT>(kk.z, kf[4], kf[5]); unpack2<KVDT>(kk.w, kf[6], kf[7]); \
+    double d = 0.0;                                                                                                        \
+    _Pragma("unroll") for (int e = 0; e < 8; e++) d = fma((double)kf[e], (double)qf[e], d);                                \
+    d = grp_sum_d<NPC>(d);                                                                                                 \
+    sc_[i] = (p < len) ? (float)d * scale : -INFINITY;                                                                     \
+  }
   for (int c0 = 0; c0 < len; c0 += 256) {
     const bool won = c0 + wave * PW < len;   // wave-uniform: this wave has live positions in the chunk
+    if (!won) continue;
     if (c0 > 0) {
-      __syncthreads();   // the previous chunk's pout / wred reads are done
-      if (won) {
 #pragma unroll
-        for (int i = 0; i < NL; i++) {
-          const size_t off = kv_row_off_t<PAGED>(kv, 0, kvh, min(c0 + wave * PW + RPL * i + rsub, pmax)) + piece * 8;
-          kr[i] = *(const uint4*)(kb0 + off);
-          vr[i] = *(const uint4*)(vb0 + off);
-        }
-      }
+      for (int i = 0; i < NL; i++) kr[i] = *(const uint4*)(kb0 + kv_row_off_t<PAGED>(kv, 0, kvh, min(c0 + wave * PW + RPL * i + rsub, pmax)) + piece * 8);
     }
-    // the token being appended (position pos == ncache) comes from LDS
-    float sc_[NL];
-    float mloc = -INFINITY;
-    if (won) {
+    ATT_SCORES(c0)
+#pragma unroll
+    for (int i = 0; i < NL; i++) Mw = fmaxf(Mw, sc_[i]);
+  }
+  Mw = wave_max(Mw);
+  STAMP(3);
+  if (lane == 0) wred[wave] = Mw;
+  __syncthreads();
+  float Mall = wred[0];
+#pragma unroll
+  for (int w = 1; w < NW; w++) Mall = fmaxf(Mall, wred[w]);
+  double accv[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  double lsum = 0.0;
+  for (int c0 = 0; c0 < len; c0 += 256) {
+    const bool won = c0 + wave * PW < len;
+    if (!won) continue;
+    if (!single) {
 #pragma unroll
       for (int i = 0; i < NL; i++) {
-        const int p = c0 + wave * PW + RPL * i + rsub;
-        uint4 kk = kr[i];
-        if (!a.q_only && p == pos) { kk = ((const uint4*)k2)[piece]; vr[i] = ((const uint4*)v2)[piece]; }
-        float d = dot2acc<KVDT>(kk.x, qq.x, 0.f);
-        d = dot2acc<KVDT>(kk.y, qq.y, d); d = dot2acc<KVDT>(kk.z, qq.z, d); d = dot2acc<KVDT>(kk.w, qq.w, d);
-        d = grp_reduce<NPC, OpAdd>(d);
-        sc_[i] = (p < len) ? d * scale : -INFINITY;
-        mloc = fmaxf(mloc, sc_[i]);
+        const size_t off = kv_row_off_t<PAGED>(kv, 0, kvh, min(c0 + wave * PW + RPL * i + rsub, pmax)) + piece * 8;
+        kr[i] = *(const uint4*)(kb0 + off);
+        vr[i] = *(const uint4*)(vb0 + off);
       }
-      mloc = wave_max(mloc);
+      ATT_SCORES(c0)
     }
-    STAMP(3);
-    if (lane == 0) wred[wave] = mloc;
-    __syncthreads();
-    float Mc = wred[0];
 #pragma unroll
-    for (int w = 1; w < NW; w++) Mc = fmaxf(Mc, wred[w]);
-    float accv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    float lsum = 0.f;
-    if (won) {
+    for (int i = 0; i < NL; i++) {
+      const float e = (sc_[i] == -INFINITY) ? 0.f : bz_expf(sc_[i] - Mall);
+      const double ed = (double)e;
+      lsum += ed;
+      float v[8];
+      unpack2<KVDT>(vr[i].x, v[0], v[1]); unpack2<KVDT>(vr[i].y, v[2], v[3]);
+      unpack2<KVDT>(vr[i].z, v[4], v[5]); unpack2<KVDT>(vr[i].w, v[6], v[7]);
 #pragma unroll
-      for (int i = 0; i < NL; i++) {
-        const float e = (sc_[i] == -INFINITY) ? 0.f : expf(sc_[i] - Mc);
-        lsum += e;
-        float v[8];
-        unpack2<KVDT>(vr[i].x, v[0], v[1]); unpack2<KVDT>(vr[i].y, v[2], v[3]);
-        unpack2<KVDT>(vr[i].z, v[4], v[5]); unpack2<KVDT>(vr[i].w, v[6], v[7]);
-#pragma unroll
-        for (int q = 0; q < 8; q++) accv[q] = fmaf(e, v[q], accv[q]);
-      }
-      // rows of the wave: the RPL lane groups hold different rows -> reduce over xor (8,) 16, 32 (the lanes of a group are replicas for lsum)
-      if (NPC == 8) lsum += dpp_get<DPP_ROR8>(lsum);
-      lsum = xrow32<OpAdd>(xrow16<OpAdd>(lsum));
-#pragma unroll
-      for (int q = 0; q < 8; q++) {
-        if (NPC == 8) accv[q] += dpp_get<DPP_ROR8>(accv[q]);
-        accv[q] = xrow32<OpAdd>(xrow16<OpAdd>(accv[q]));
-      }
+      for (int q = 0; q < 8; q++) accv[q] = fma(ed, (double)v[q], accv[q]);
     }
-    STAMP(4);
-    if (lane < NPC) {
-      *(float4*)(pout + wave * HD + piece * 8) = make_float4(accv[0], accv[1], accv[2], accv[3]);
-      *(float4*)(pout + wave * HD + piece * 8 + 4) = make_float4(accv[4], accv[5], accv[6], accv[7]);
-    }
-    if (lane == 0) wred[NW + wave] = lsum;
-    __syncthreads();
-    STAMP(5);
-    if (tid < HD) {
-      float oc = 0.f, Lc = 0.f;
+  }
+#undef ATT_SCORES
+  // rows of the wave: the RPL lane groups hold different rows -> reduce over xor (8,) 16, 32 (the lanes of a group are replicas for lsum)
+  if (NPC == 8) lsum += dpp_get<DPP_ROR8>(lsum);
+  lsum = xrow32_d(xrow16_d(lsum));
 #pragma unroll
-      for (int w = 0; w < NW; w += 2) { oc += pout[w * HD + tid] + pout[(w + 1) * HD + tid]; Lc += wred[NW + w] + wred[NW + w + 1]; }
-      const float Mn = fmaxf(Mrun, Mc);
-      const float fa = (Mrun == -INFINITY) ? 0.f : expf(Mrun - Mn), fb = expf(Mc - Mn);
-      Orun = Orun * fa + oc * fb;
-      Lrun = Lrun * fa + Lc * fb;
-      Mrun = Mn;
-    }
+  for (int q = 0; q < 8; q++) {
+    if (NPC == 8) accv[q] += dpp_get<DPP_ROR8>(accv[q]);
+    accv[q] = xrow32_d(xrow16_d(accv[q]));
+  }
+  STAMP(4);
+  if (lane < NPC) {
+#pragma unroll
+    for (int q = 0; q < 8; q++) pout[wave * HD + piece * 8 + q] = accv[q];
+  }
+  if (lane == 0) lred[wave] = lsum;
+  __syncthreads();
+  STAMP(5);
+  float Orun = 0.f, Lrun = 1.f;
+  if (tid < HD) {
+    double oc = 0.0, Lc = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) { oc += pout[w * HD + tid]; Lc += lred[w]; }
+    Orun = (float)oc; Lrun = (float)Lc;
   }
   if (!FUSE) {
     if (tid < HD) a.out[(size_t)hq * HD + tid] = round_act(Orun / Lrun, a.act);
@@ -3693,8 +3710,8 @@ __global__ __launch_bounds__(512) void k_attn2f(AttnArgs a, const uint4* __restr
       const int hh = tid / half, i = tid % half;
       const int ia = a.interleaved ? 2 * i : i, ib = a.interleaved ? 2 * i + 1 : i + half;
       float* dst = hh == 0 ? qf : kf;
-      dst[ia] = round_act(px0 * pc - px1 * ps, a.act);
-      dst[ib] = round_act(px1 * pc + px0 * ps, a.act);
+      dst[ia] = round_act(rope_lo(px0, px1, pc, ps), a.act);
+      dst[ib] = round_act(rope_hi(px0, px1, pc, ps), a.act);
     } else if (tid < 2 * half + 64) {
       vf[2 * (tid - 2 * half)] = px0; vf[2 * (tid - 2 * half) + 1] = px1;
     }
@@ -3754,7 +3771,7 @@ __global__ __launch_bounds__(512) void k_attn2f(AttnArgs a, const uint4* __restr
     if (won) {
 #pragma unroll
       for (int i = 0; i < NL; i++) {
-        const float e = (sc_[i] == -INFINITY) ? 0.f : expf(sc_[i] - Mc);
+        const float e = (sc_[i] == -INFINITY) ? 0.f : bz_expf(sc_[i] - Mc);
         lsum += e;
         accv[0] = fmaf(e, vr[i][0].x, accv[0]); accv[1] = fmaf(e, vr[i][0].y, accv[1]); accv[2] = fmaf(e, vr[i][0].z, accv[2]); accv[3] = fmaf(e, vr[i][0].w, accv[3]);
         accv[4] = fmaf(e, vr[i][1].x, accv[4]); accv[5] = fmaf(e, vr[i][1].y, accv[5]); accv[6] = fmaf(e, vr[i][1].z, accv[6]); accv[7] = fmaf(e, vr[i][1].w, accv[7]);
@@ -3774,7 +3791,7 @@ __global__ __launch_bounds__(512) void k_attn2f(AttnArgs a, const uint4* __restr
 #pragma unroll
       for (int w = 0; w < NW; w += 2) { oc += pout[w * 128 + tid] + pout[(w + 1) * 128 + tid]; Lc += wred[NW + w] + wred[NW + w + 1]; }
       const float Mn = fmaxf(Mrun, Mc);
-      const float fa = (Mrun == -INFINITY) ? 0.f : expf(Mrun - Mn), fb = expf(Mc - Mn);
+      const float fa = (Mrun == -INFINITY) ? 0.f : bz_expf(Mrun - Mn), fb = bz_expf(Mc - Mn);
       Orun = Orun * fa + oc * fb;
       Lrun = Lrun * fa + Lc * fb;
       Mrun = Mn;
@@ -3806,7 +3823,7 @@ __global__ __launch_bounds__(512) void k_attn2f(AttnArgs a, const uint4* __restr
   }
 }
 
-static size_t attn2_smem(int nw) { return (size_t)(64 * 3 + 2 * nw + nw * 128 + 128 + 96 + 8) * 4; }
+static size_t attn2_smem(int nw) { return (size_t)(64 * 3 + 2 * nw + 128 + 96 + 8) * 4 + (size_t)(nw * 128 + nw) * 8; }
 
 // picks the column-slice count so that nq * CS ~ 256 workgroups, and the wave count (8 waves halve the per-wave attention chain);
 // returns 0 when the fused form does not apply
@@ -3944,14 +3961,14 @@ __global__ __launch_bounds__(REP == 8 ? 512 : 256) void k_attn_split(AttnArgs a,
   const bool owner = p1 == len;             // this block's range holds the new position
   {
     const float x0 = vsrc_finish(a.qkv.fix, q0l, q0h, a.act), x1 = vsrc_finish(a.qkv.fix, q1l, q1h, a.act);
-    const unsigned pk = pack2<KVDT>(round_act(x0 * pc - x1 * ps, a.act), round_act(x1 * pc + x0 * ps, a.act));
+    const unsigned pk = pack2<KVDT>(round_act(rope_lo(x0, x1, pc, ps), a.act), round_act(rope_hi(x0, x1, pc, ps), a.act));
     ((unsigned short*)q2[hl])[ia] = (unsigned short)(pk & 0xffffu);
     ((unsigned short*)q2[hl])[ib] = (unsigned short)(pk >> 16);
   }
   if (owner && tid < 2 * half) {
     const float x0 = vsrc_finish(a.qkv.fix, n0l, n0h, a.act), x1 = vsrc_finish(a.qkv.fix, n1l, n1h, a.act);
     if (tid < half) {
-      const unsigned pk = pack2<KVDT>(round_act(x0 * pc - x1 * ps, a.act), round_act(x1 * pc + x0 * ps, a.act));
+      const unsigned pk = pack2<KVDT>(round_act(rope_lo(x0, x1, pc, ps), a.act), round_act(rope_hi(x0, x1, pc, ps), a.act));
       ((unsigned short*)k2)[ia] = (unsigned short)(pk & 0xffffu);
       ((unsigned short*)k2)[ib] = (unsigned short)(pk >> 16);
     } else {
@@ -4034,7 +4051,7 @@ __global__ __launch_bounds__(REP == 8 ? 512 : 256) void k_attn_split(AttnArgs a,
         unpack2<KVDT>(vr[r].z, v[4], v[5]); unpack2<KVDT>(vr[r].w, v[6], v[7]);
 #pragma unroll
         for (int h = 0; h < REP; h++) {
-          const float e = (sc_[h][r] == -INFINITY) ? 0.f : expf(sc_[h][r] - Mc[h]);
+          const float e = (sc_[h][r] == -INFINITY) ? 0.f : bz_expf(sc_[h][r] - Mc[h]);
           lsum[h] += e;
 #pragma unroll
           for (int q = 0; q < 8; q++) accv[h][q] = fmaf(e, v[q], accv[h][q]);
@@ -4072,7 +4089,7 @@ __global__ __launch_bounds__(REP == 8 ? 512 : 256) void k_attn_split(AttnArgs a,
 #pragma unroll
         for (int w = 0; w < NW; w++) { oc += pout[w][h][tid]; Lc += lred[h][w]; }
         const float Mn = fmaxf(Mrun[h], Mc[h]);
-        const float fa = (Mrun[h] == -INFINITY) ? 0.f : expf(Mrun[h] - Mn), fb = expf(Mc[h] - Mn);
+        const float fa = (Mrun[h] == -INFINITY) ? 0.f : bz_expf(Mrun[h] - Mn), fb = bz_expf(Mc[h] - Mn);
         Orun[h] = Orun[h] * fa + oc * fb;
         Lrun[h] = Lrun[h] * fa + Lc * fb;
         Mrun[h] = Mn;
@@ -4103,7 +4120,7 @@ __device__ __forceinline__ void att_merge_512(const float* __restrict__ ws, int 
   float M = red[0];
 #pragma unroll
   for (int w = 1; w < 8; w++) M = fmaxf(M, red[w]);
-  const float wgt = (m == -INFINITY) ? 0.f : expf(m - M);
+  const float wgt = (m == -INFINITY) ? 0.f : bz_expf(m - M);
   if (tid < 128) wS[tid] = wgt;
   const float wl = wave_sum(wgt * l);
   if (lane == 0) red[8 + wave] = wl;
@@ -4452,8 +4469,8 @@ __global__ void k_rope(float* x, int S, int nh, int hd, int position, const floa
     const int ia = interleaved ? 2 * i : i, ib = interleaved ? 2 * i + 1 : i + half;
     const float c = cos_t[(size_t)(position + sidx) * half + i], sn = sin_t[(size_t)(position + sidx) * half + i];
     const float x0 = v[ia], x1 = v[ib];
-    v[ia] = round_act(x0 * c - x1 * sn, act);
-    v[ib] = round_act(x1 * c + x0 * sn, act);
+    v[ia] = round_act(rope_lo(x0, x1, c, sn), act);
+    v[ib] = round_act(rope_hi(x0, x1, c, sn), act);
   }
 }
 int bzk_rope(hipStream_t s, float* x, int S, int nh, int hd, int position, const float* cos_t, const float* sin_t, int interleaved,
@@ -4477,7 +4494,7 @@ int bzk_silu_mul(hipStream_t s, const float* g, const float* u, long long n, int
 // ---------------------------------------------------------------------------------------------------------
 // Mamba2 single-token kernels: causal conv1d step, SSM state update + readout
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float softplus_f(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.0f ? x : log1pf(bz_expf(x)); }
 
 // grid = n_heads; 256 threads = 64 rows (p) x 4 state quarters.  h = R(h * dA + (dt x) B); y = R(sum_n h C + D x)
 // The causal conv1d step (+ SiLU) runs in front, inside the same launch: a head's workgroup convolves its own head_dim x channels (and shifts
@@ -4520,7 +4537,7 @@ __global__ __launch_bounds__(64 * PARTS) void k_ssm_step(SsmArgs a) {
     if (t < NS) sB[t] = c; else if (t < 2 * NS) sC[t - NS] = c; else sX[t - 2 * NS] = c;
   }
   const float dt = round_act(softplus_f(round_act(dtraw + dtb, a.act)), a.act);
-  const float dA = expf(dt * -expf(alog));
+  const float dA = bz_expf(dt * -bz_expf(alog));
   __syncthreads();
   float vsq = 0.f;
   for (int p0 = 0; p0 < HD; p0 += 64) {
@@ -4682,10 +4699,10 @@ __global__ __launch_bounds__(NW * 64) void k_mla_attn(MlaArgs a) {
     const float c = cr[j], s = sr[j];
     if (!BATCH) {
       const float k0 = csrc(R + 2 * j), k1 = csrc(R + 2 * j + 1);
-      kcur[2 * j] = round_act(k0 * c - k1 * s, a.act); kcur[2 * j + 1] = round_act(k1 * c + k0 * s, a.act);
+      kcur[2 * j] = round_act(rope_lo(k0, k1, c, s), a.act); kcur[2 * j + 1] = round_act(rope_hi(k0, k1, c, s), a.act);
     }
     const float x0 = qsrc(qoff + DN + 2 * j), x1 = qsrc(qoff + DN + 2 * j + 1);
-    qp[2 * j] = round_act(x0 * c - x1 * s, a.act); qp[2 * j + 1] = round_act(x1 * c + x0 * s, a.act);
+    qp[2 * j] = round_act(rope_lo(x0, x1, c, s), a.act); qp[2 * j + 1] = round_act(rope_hi(x0, x1, c, s), a.act);
   }
   for (int d = tid; d < DN; d += NTH) qn[d] = qsrc(qoff + d);
   __syncthreads();
@@ -4790,7 +4807,7 @@ __global__ __launch_bounds__(NW * 64) void k_mla_attn(MlaArgs a) {
   for (int w = 1; w < NW; w++) mx = fmaxf(mx, red[w]);
   __syncthreads();
   float psum = 0.f;
-  for (int t = tid; t < nloc; t += NTH) { const float p = expf(sc[t] - mx); sc[t] = p; psum += p; }
+  for (int t = tid; t < nloc; t += NTH) { const float p = bz_expf(sc[t] - mx); sc[t] = p; psum += p; }
   psum = block_sum_nw<NW>(psum, red);
   const float inv = 1.0f / psum;
   // ---- olat = R(sum_t p_t c_t * inv) ----
@@ -4904,7 +4921,7 @@ __global__ __launch_bounds__(256) void k_mla_merge(MlaArgs a) {
     const float ms = wsp[(size_t)sl * (R + 2) + R], ls = wsp[(size_t)sl * (R + 2) + R + 1];
     const bool on = lane < NSP && ls > 0.f;
     const float M = wave_max(on ? ms : -INFINITY);
-    const float wv = on ? expf(ms - M) : 0.f;
+    const float wv = on ? bz_expf(ms - M) : 0.f;
     const float L = wave_sum(wv * ls);
     if (wave == 0) { wgt[lane] = wv; if (lane == 63) wgt[63] = 1.0f / L; }
   }
@@ -5007,7 +5024,7 @@ __device__ __forceinline__ void moe_softmax_topk_n(const float* lg, int E, int t
     for (int j = 0; j < NJM; j++) { v[j] = -INFINITY; if (j < NJ) { const int ee = lane + 64 * j; v[j] = ee < E ? lg[ee] : -INFINITY; m = fmaxf(m, v[j]); } }
     m = wave_max(m);
 #pragma unroll
-    for (int j = 0; j < NJM; j++) if (j < NJ) { const int ee = lane + 64 * j; v[j] = ee < E ? expf(v[j] - m) : 0.f; }
+    for (int j = 0; j < NJM; j++) if (j < NJ) { const int ee = lane + 64 * j; v[j] = ee < E ? bz_expf(v[j] - m) : 0.f; }
     float sum = 0.f;                                   // the oracle's sequential order e = 0 .. E-1 (lanes beyond E hold 0: adding them changes nothing)
 #pragma unroll
     for (int j = 0; j < NJM; j++)
@@ -5202,8 +5219,8 @@ __global__ __launch_bounds__(256) void k_mla_append_rows(const float* __restrict
   const float* cr = cos_t + (size_t)pos * (DR / 2); const float* sr = sin_t + (size_t)pos * (DR / 2);
   for (int j = tid; j < DR / 2; j += 256) {
     const float c = cr[j], sn = sr[j], x0 = row[R + 2 * j], x1 = row[R + 2 * j + 1];
-    kv_st(kv.k, wo + R + 2 * j, kv.dtype, round_act(x0 * c - x1 * sn, act));
-    kv_st(kv.k, wo + R + 2 * j + 1, kv.dtype, round_act(x1 * c + x0 * sn, act));
+    kv_st(kv.k, wo + R + 2 * j, kv.dtype, round_act(rope_lo(x0, x1, c, sn), act));
+    kv_st(kv.k, wo + R + 2 * j + 1, kv.dtype, round_act(rope_hi(x0, x1, c, sn), act));
   }
 }
 int bzk_mla_append_rows(hipStream_t s, const float* kva, long long stride, int S, const float* kv_norm, float eps, int rank, int rope, const float* cos_t, const float* sin_t,

@@ -279,8 +279,8 @@ __global__ __launch_bounds__(64) void k_pf_rope_kv(float* qkv, int nq, int nkv, 
     for (int i = threadIdx.x; i < half; i += 64) {
       const int a = interleaved ? 2 * i : i, b = interleaved ? 2 * i + 1 : i + half;
       const float x0 = v[a], x1 = v[b];
-      v[a] = pf_round(x0 * cr[i] - x1 * sr[i], act);
-      v[b] = pf_round(x1 * cr[i] + x0 * sr[i], act);
+      v[a] = pf_round(rope_lo(x0, x1, cr[i], sr[i]), act);
+      v[b] = pf_round(rope_hi(x0, x1, cr[i], sr[i]), act);
     }
   }
   __syncthreads();
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256) void k_pf_attn(const float* qkv, int nq, int n
   for (int h = 0; h < REP; h++) {
     const float m = fmaxf(fmaxf(red[h * 4], red[h * 4 + 1]), fmaxf(red[h * 4 + 2], red[h * 4 + 3]));
     float sum = 0.f;
-    for (int p = tid; p < len; p += 256) { const float e = expf(sc[h * len + p] - m); sc[h * len + p] = e; sum += e; }
+    for (int p = tid; p < len; p += 256) { const float e = bz_expf(sc[h * len + p] - m); sc[h * len + p] = e; sum += e; }
     sum = wave_sum(sum);
     if (lane == 0) red[4 * REP + h * 4 + wave] = sum;
   }
@@ -513,12 +513,12 @@ __global__ __launch_bounds__(256) void k_pf_attn_mfma(const float* __restrict__ 
         }
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float mn = fmaxf(m, mx);                          // finite: key 0 is visible to every query and sits in the first tile
-      const float alpha = expf(m - mn);
+      const float alpha = bz_expf(m - mn);
       float ps = 0.f;
 #pragma unroll
       for (int kb = 0; kb < 2; kb++)
 #pragma unroll
-        for (int i = 0; i < 16; i++) { const float e = expf(st[kb][i] - mn); st[kb][i] = e; ps += e; }
+        for (int i = 0; i < 16; i++) { const float e = bz_expf(st[kb][i] - mn); st[kb][i] = e; ps += e; }
       ps += __shfl_xor(ps, 32, 64);
       l = l * alpha + ps; m = mn;
 #pragma unroll
@@ -577,7 +577,7 @@ __global__ __launch_bounds__(256) void k_pf_silu(const float* __restrict__ gu, i
   const float gv[4] = {g.x, g.y, g.z, g.w}, uv[4] = {u.x, u.y, u.z, u.w};
   unsigned short o[4];
 #pragma unroll
-  for (int e = 0; e < 4; e++) o[e] = to16<DT>(pf_round(pf_round(gv[e] / (1.0f + expf(-gv[e])), act) * uv[e], act));
+  for (int e = 0; e < 4; e++) o[e] = to16<DT>(pf_round(pf_round(gv[e] / (1.0f + bz_expf(-gv[e])), act) * uv[e], act));
   uint2 w; w.x = o[0] | ((unsigned)o[1] << 16); w.y = o[2] | ((unsigned)o[3] << 16);
   *(uint2*)(a16 + (size_t)s * I + i) = w;
 }
@@ -860,8 +860,8 @@ __global__ void k_q4g_mfma_reduce(const float* __restrict__ part, int KS, size_t
 // registers and walks the tokens, so a prompt costs one pass over the state instead of a read-modify-write of it per token.
 // Arithmetic and rounding points are those of the decode-step kernels (k_ssm_step with its in-launch conv1d step, the GATED2 prologue).
 // ---------------------------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float pf_silu(float x) { return x / (1.0f + expf(-x)); }
-__device__ __forceinline__ float pf_softplus(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+__device__ __forceinline__ float pf_silu(float x) { return x / (1.0f + bz_expf(-x)); }
+__device__ __forceinline__ float pf_softplus(float x) { return x > 20.0f ? x : log1pf(bz_expf(x)); }
 
 // out[t][ch] = R(silu(R(conv window + bias))): window = the kc-1 inputs before t (from the rows, or from the carried conv state) and in[t]
 __global__ void k_pf_conv(const float* __restrict__ zx, int ld, int x_off, int conv_dim, int kc, const float* __restrict__ w, const float* __restrict__ b,
@@ -942,7 +942,7 @@ __global__ __launch_bounds__(256) void k_ssm_scan(SsmScanArgs a) {
   const int pl = tid / PARTS, p = blockIdx.y * 16 + pl, q = tid % PARTS, tq = q & (TC - 1);   // tq: the token of a chunk this lane serves in the epilogue
   const bool on = p < HD;
   const int pc = on ? p : 0;
-  const float Dh = a.D[hd], Aneg = -expf(a.A_log[hd]), dtb = a.dt_bias[hd];
+  const float Dh = a.D[hd], Aneg = -bz_expf(a.A_log[hd]), dtb = a.dt_bias[hd];
   const size_t soff = ((size_t)hd * HD + pc) * NS + q * NQ;
   float h[NQ];
 #pragma unroll
@@ -982,7 +982,7 @@ __global__ __launch_bounds__(256) void k_ssm_scan(SsmScanArgs a) {
     {
       const float dt = rnd<ACT>(pf_softplus(rnd<ACT>(dtraw + dtb)));     // token tq
       if (q < TC) sdtx[q][pl] = dt * xc;
-      if (tid < TC) sdA[tid] = expf(dt * Aneg);
+      if (tid < TC) sdA[tid] = bz_expf(dt * Aneg);
     }
     __syncthreads();
     flush();

@@ -3,7 +3,7 @@
 //
 // The reference's kernel (and its RNG) is in the absent boostr crate; only the argument list is visible.  This build fixes
 // the semantics in oracle/orc_ops.c (orc_logits_to_token) and implements exactly those:
-//   l_i = penalised logit / temperature ; p_i = (float)(expf(l_i - max) / sum_double)
+//   l_i = penalised logit / temperature ; p_i = (float)(bz_expf(l_i - max) / sum_double)
 //   candidates sorted by p descending, ties by ascending id ; keep = top_k ; cut after the first prefix with mass >= top_p ;
 //   cut at the first p_i < min_p * p_0 ; u = splitmix64(seed) * 2^-53 * mass(kept) ; token = first i with u < cumulative mass.
 // The descending sort is rocPRIM's stable radix sort on the f32 bit patterns (p >= 0, so the bit order is the value order; stability on
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void k_samp_exp(float* l2, long long V, const 
   for (int b = 0; b < NB; b++) m = fmaxf(m, pmax[b]);
   double s = 0.0;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < V; i += (long long)gridDim.x * 256) {
-    const float e = expf(l2[i] - m);
+    const float e = bz_expf(l2[i] - m);
     l2[i] = e;
     s += (double)e;
   }

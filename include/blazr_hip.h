@@ -339,6 +339,11 @@ int bz_paged_attn_decode(bz_model* m, const bz_tensor* q, bz_paged_kv* kv, int l
                          bz_tensor* out);
 /* kv_insert kernel (cuda_graphs.rs:5): write k,v F32 [n_kv_heads, head_dim] at `position` (contiguous) */
 int bz_kv_insert(bz_model* m, bz_kv* kv, int layer, int position, const bz_tensor* k, const bz_tensor* v);
+/* The exponential every kernel of this library uses (SiLU, softmax weights, sampling): ONE specified sequence of IEEE operations (range reduction by ln2
+ * in two fma steps, degree-5 polynomial, exact 2^n scaling; < 1 ulp), evaluated here on the HOST for n values -- the same function body the device code
+ * compiles, so a CPU-only test can pin it bit for bit against an independent restatement.  boostr's own exp (ActivationOps / softmax behind
+ * executor.rs:67-80) is not visible; any faithful expf is "the" exp, and a specified one makes both sides of a parity test compute the same bits. */
+int bz_expf_spec(const float* x, int n, float* y);
 /* rope_caches() -> (cos, sin) F32 [max_pos, head_dim/2] copied to host */
 int bz_rope_caches(bz_model* m, float* cos_host, float* sin_host);
 

@@ -97,6 +97,7 @@ void orc_rope_apply(float* v, int head_dim, int rot_dim, const float* cos_row, c
 void orc_attn_decode(const float* q, int n_q_per_kv, int head_dim, const float* kcache, const float* vcache,
                      size_t pos_stride, int len, float scale, float* out /*[n_q_per_kv][head_dim]*/);
 float orc_silu(float x);
+float orc_expf(float x);   /* the specified exp (orc_ops.c) */
 int64_t orc_argmax(const float* v, int64_t n); /* lowest index wins ties */
 
 /* sampling.rs:445-460 logits_to_token. ASSUMPTION: llama.cpp-style repeat penalty

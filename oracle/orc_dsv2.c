@@ -81,7 +81,7 @@ void orc_moe_route(const float* logits, int E, int top_k, float routed_scale, in
   float m = -INFINITY, sum = 0.0f;
   float* s = (float*)malloc(sizeof(float) * (size_t)E);
   for (int e = 0; e < E; e++) if (logits[e] > m) m = logits[e];
-  for (int e = 0; e < E; e++) { s[e] = expf(logits[e] - m); sum += s[e]; }
+  for (int e = 0; e < E; e++) { s[e] = orc_expf(logits[e] - m); sum += s[e]; }
   for (int e = 0; e < E; e++) s[e] = s[e] / sum;
   float tsum = 0.0f;
   for (int k = 0; k < top_k; k++) {
@@ -159,7 +159,7 @@ int orc_dsv2_forward(const orc_dsv2* m, const int64_t* tokens, int S, orc_mla_ca
           if (sc[t] > mx) mx = sc[t];
         }
         float sum = 0.0f;
-        for (int t = 0; t < len; t++) { sc[t] = expf(sc[t] - mx); sum += sc[t]; }
+        for (int t = 0; t < len; t++) { sc[t] = orc_expf(sc[t] - mx); sum += sc[t]; }
         const float inv = 1.0f / sum;
         for (int r = 0; r < R; r++) olat[r] = 0.0f;
         for (int t = 0; t < len; t++) { const float* ct = lat + (size_t)t * W; const float p = sc[t]; for (int r = 0; r < R; r++) olat[r] += p * ct[r]; }

@@ -23,7 +23,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-static float softplus_f(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+static float softplus_f(float x) { return x > 20.0f ? x : log1pf(orc_expf(x)); }
 
 orc_mamba2* orc_mamba2_new(const orc_mamba2_cfg* cfg) {
   orc_mamba2* m = (orc_mamba2*)calloc(1, sizeof(orc_mamba2));
@@ -76,7 +76,7 @@ int orc_mamba2_forward(const orc_mamba2* m, const int64_t* tokens, int S, orc_ss
       for (int hd = 0; hd < NH; hd++) {
         const int g = hd / (NH / G);
         const float dt = orc_round(softplus_f(orc_round(dtr[hd] + L->dt_bias[hd], act)), act);
-        const float dA = expf(dt * -expf(L->A_log[hd]));
+        const float dA = orc_expf(dt * -orc_expf(L->A_log[hd]));
         for (int p = 0; p < HD; p++) {
           const float xv = x[hd * HD + p];
           float* hs = ss + ((size_t)hd * HD + p) * NS;

@@ -69,45 +69,78 @@ void orc_rope_tables(const orc_rope_cfg* c, float* cos_t, float* sin_t) {
   }
 }
 
+/* RoPE of one head.  The products x * cos are exact in double (x carries <= 24 significant bits, the table entries 24), so each output is the
+   double-rounded difference / sum of two exact products, rounded once more to f32: the same bits whatever the compiler contracts. */
 void orc_rope_apply(float* v, int head_dim, int rot_dim, const float* c, const float* s, int interleaved) {
   const int half = rot_dim / 2;
   (void)head_dim;
   for (int i = 0; i < half; i++) {
     int a = interleaved ? 2 * i : i, b = interleaved ? 2 * i + 1 : i + half;
-    float x0 = v[a], x1 = v[b];
-    v[a] = x0 * c[i] - x1 * s[i];
-    v[b] = x1 * c[i] + x0 * s[i];
+    const double x0 = v[a], x1 = v[b], ci = c[i], si = s[i];
+    v[a] = (float)(x0 * ci - x1 * si);
+    v[b] = (float)(x1 * ci + x0 * si);
   }
 }
 
+/* exp, SPECIFIED (ASSUMPTION: the reference's expf lives in boostr / libm and is not visible; any faithful expf is "the" exp).  The oracle and
+   the HIP kernels evaluate this one sequence of IEEE operations (Cephes expf: Cody-Waite reduction by ln2 in two fmaf steps, degree-5 polynomial
+   in Horner form with fmaf, exact scaling by 2^n), so a comparison of the two sides measures structure and rounding points, not two libms.
+   Range: 0 below -86 (the smallest result stays a normal f32), +inf above 88; NaN propagates.  Max error vs the true exp: < 1 ulp. */
+float orc_expf(float x) {
+  if (x != x) return x;
+  if (x < -86.0f) return 0.0f;
+  if (x > 88.0f) return INFINITY;
+  const float n = rintf(x * 1.44269504088896341f);
+  float r = fmaf(n, -0.693145751953125f, x);
+  r = fmaf(n, -1.42860682030941723212e-6f, r);
+  float p = 1.9875691500e-4f;
+  p = fmaf(p, r, 1.3981999507e-3f);
+  p = fmaf(p, r, 8.3334519073e-3f);
+  p = fmaf(p, r, 4.1665795894e-2f);
+  p = fmaf(p, r, 1.6666665459e-1f);
+  p = fmaf(p, r, 5.0000001201e-1f);
+  const float r2 = r * r;
+  float y = fmaf(p, r2, r);
+  y = y + 1.0f;
+  union { uint32_t u; float f; } sc;
+  sc.u = (uint32_t)((int)n + 127) << 23;      /* 2^n, n in [-125, 127] */
+  return y * sc.f;
+}
+
+/* One kv head's group of query heads over `len` cached positions.  Every sum is DEFINED as the exactly rounded sum (the linear layers' rule,
+   orc_quant.c): products of 16-bit values are exact in double, so are products of an f32 probability and a 16-bit value; the sums are carried in
+   double (order-independent to ~1e-16) and rounded to f32 once.  score = f32(sum q k) * scale; p = exp(score - max) (orc_expf);
+   out = f32(sum p v) / f32(sum p).  An implementation that accumulates in f32 in some order approximates exactly this. */
 void orc_attn_decode(const float* q, int n_q_per_kv, int head_dim, const float* kc, const float* vc,
                      size_t stride, int len, float scale, float* out) {
   float* sc = (float*)malloc(sizeof(float) * (size_t)len);
+  double* od = (double*)malloc(sizeof(double) * (size_t)head_dim);
   for (int h = 0; h < n_q_per_kv; h++) {
     const float* qh = q + (size_t)h * head_dim;
     float m = -INFINITY;
     for (int p = 0; p < len; p++) {
       const float* kr = kc + (size_t)p * stride;
-      float d = 0.0f;
-      for (int i = 0; i < head_dim; i++) d += qh[i] * kr[i];
-      sc[p] = d * scale;
+      double d = 0.0;
+      for (int i = 0; i < head_dim; i++) d += (double)qh[i] * (double)kr[i];
+      sc[p] = (float)d * scale;
       if (sc[p] > m) m = sc[p];
     }
-    float sum = 0.0f;
-    for (int p = 0; p < len; p++) { sc[p] = expf(sc[p] - m); sum += sc[p]; }
-    float inv = 1.0f / sum;
+    double sum = 0.0;
+    for (int p = 0; p < len; p++) { sc[p] = orc_expf(sc[p] - m); sum += (double)sc[p]; }
+    const float l = (float)sum;
     float* o = out + (size_t)h * head_dim;
-    for (int i = 0; i < head_dim; i++) o[i] = 0.0f;
+    for (int i = 0; i < head_dim; i++) od[i] = 0.0;
     for (int p = 0; p < len; p++) {
       const float* vr = vc + (size_t)p * stride;
-      for (int i = 0; i < head_dim; i++) o[i] += sc[p] * vr[i];
+      const double e = (double)sc[p];
+      for (int i = 0; i < head_dim; i++) od[i] += e * (double)vr[i];
     }
-    for (int i = 0; i < head_dim; i++) o[i] *= inv;
+    for (int i = 0; i < head_dim; i++) o[i] = (float)od[i] / l;
   }
-  free(sc);
+  free(sc); free(od);
 }
 
-float orc_silu(float x) { return x / (1.0f + expf(-x)); }
+float orc_silu(float x) { return x / (1.0f + orc_expf(-x)); }
 
 int64_t orc_argmax(const float* v, int64_t n) {
   int64_t best = 0; float bv = v[0];
@@ -170,7 +203,7 @@ int64_t orc_logits_to_token(const float* logits, int64_t V, const int64_t* ids, 
     float m = -INFINITY;
     for (int64_t i = 0; i < V; i++) { l[i] /= temperature; if (l[i] > m) m = l[i]; }
     double sum = 0.0;
-    for (int64_t i = 0; i < V; i++) { c[i].p = expf(l[i] - m); c[i].id = i; sum += c[i].p; }
+    for (int64_t i = 0; i < V; i++) { c[i].p = orc_expf(l[i] - m); c[i].id = i; sum += c[i].p; }
     for (int64_t i = 0; i < V; i++) c[i].p = (float)(c[i].p / sum);
     qsort(c, (size_t)V, sizeof(cand), cand_cmp);
     int64_t keep = V;

@@ -139,6 +139,8 @@ def lib():
                                       C.c_float, C.c_void_p]
         L.orc_silu.restype = C.c_float
         L.orc_silu.argtypes = [C.c_float]
+        L.orc_expf.restype = C.c_float
+        L.orc_expf.argtypes = [C.c_float]
         L.orc_argmax.restype = C.c_int64
         L.orc_argmax.argtypes = [C.c_void_p, C.c_int64]
         L.orc_logits_to_token.restype = C.c_int64
@@ -194,6 +196,11 @@ def lib():
         L.orc_num_threads.restype = C.c_int
         _LIB = L
     return _LIB
+
+
+def set_threads(n):
+    """OpenMP team size of the oracle's GEMVs (bench.py --cpu-threads); the default team is min(16, CPU share) -- see lib()."""
+    lib().orc_set_num_threads(int(n))
 
 
 def _p(a):

@@ -12,6 +12,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "watchdog(seconds): per-test limit of the hang watchdog (default 150 s; the workload-size tests wait for the CPU oracle)")
 
 
 @pytest.fixture(scope="session")
@@ -30,7 +31,9 @@ def _watchdog(request):
     if request.node.get_closest_marker("gpu") is None:
         yield
         return
-    faulthandler.dump_traceback_later(int(os.environ.get("BZ_TEST_WATCHDOG_S", "150")), exit=True)
+    wd = request.node.get_closest_marker("watchdog")
+    limit = int(wd.args[0]) if wd is not None and wd.args else int(os.environ.get("BZ_TEST_WATCHDOG_S", "150"))
+    faulthandler.dump_traceback_later(limit, exit=True)
     try:
         yield
     finally:

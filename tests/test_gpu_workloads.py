@@ -1,0 +1,197 @@
+"""BASELINE.json configs at their STATED workloads, through the C ABI against the CPU oracle:
+
+  * DeepSeek-V2-Lite (configs[4]: "prefill 512 + decode 128") at its real widths, 2 layers: the 512-row batched prefill (per-expert row lists through
+    the grouped MFMA GEMM, the MLA prompt kernel at 512 keys), then decode at contexts 512 .. 650 (k_mla_attn<SPLIT> with more than one batch per
+    context slice, k_mla_merge over 16 live slices) -- contiguous and paged latent cache.  Reference call sites:
+    /root/reference/src/engine/executor_generate.rs:259-262,289-292,357,372; MLA / MoE semantics /root/reference/docs/architecture.md:87-119.
+  * Llama-3-8B AWQ widths, 2 layers: decode across 512 -> 650 positions (the fused attention + o_proj launch below 512, split-KV + merge above).
+  * Llama-3-8B AWQ-INT4 at its FULL depth (32 layers, configs[1], the headline): the oracle's ids teacher-forced through bz_forward_kv, logits held to the
+    north-star bar (1e-3 relative) at every step.  The prompt goes through the decode path token by token on both sides (the batched prompt path
+    has its own tests: its MFMA sums differ from the exact sums in the last f32 bit by construction).
+"""
+import numpy as np
+import pytest
+
+from blazr_amd import _lib as L
+from blazr_amd import runtime, synth
+from fullwidth_cases import make
+from oracle import orc_py
+from test_gpu_llama import _check_logits, _fair_prefix
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel_l2(got, want):
+    got, want = np.asarray(got, np.float64).reshape(-1), np.asarray(want, np.float64).reshape(-1)
+    return float(np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-30))
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------------
+# DeepSeek-V2-Lite: prefill 512 + decode to context 650
+# ------------------------------------------------------------------------------------------------------------------------------------------
+DS_PROMPT, DS_STEPS = 512, 138
+
+
+@pytest.fixture(scope="module")
+def dsv2_oracle():
+    """one oracle pass shared by the contiguous and the paged run: all 512 prompt rows, then 138 greedy decode steps (ids + logits + latent cache)"""
+    fam, model = make("deepseek-v2-lite-2l")
+    cfg = model["config"]
+    om = orc_py.OrcDsv2(model)
+    cap = DS_PROMPT + DS_STEPS + 8
+    okc = om.new_cache(cap)
+    p = synth.prompt_tokens(DS_PROMPT, cfg["vocab"], seed=2)
+    rows = om.forward(p, okc, 0, all_logits=True).copy()
+    ids, dec = [int(rows[-1].argmax())], []
+    for i in range(DS_STEPS):
+        lo = om.forward([ids[-1]], okc, DS_PROMPT + i).reshape(-1).copy()
+        dec.append(lo)
+        ids.append(int(lo.argmax()))
+    W = cfg["kv_lora_rank"] + cfg["rope_dim"]
+    lat = np.ctypeslib.as_array((orc_py.C.c_float * (cfg["n_layers"] * cap * W)).from_address(okc.contents.lat)).reshape(cfg["n_layers"], cap, W).copy()
+    orc_py.lib().orc_mla_cache_free(okc)
+    return model, p, rows, ids, np.stack(dec), lat
+
+
+@pytest.mark.watchdog(900)
+@pytest.mark.parametrize("mode", ["contiguous", "paged"])
+def test_deepseek_v2_lite_prefill_512_then_decode_to_650(dsv2_oracle, device, mode):
+    model, p, rows, ids, dec, lat = dsv2_oracle
+    cfg = model["config"]
+    act = cfg["act_dtype"]
+    f = 1.25 if act == "bf16" else 1.0          # as tests/test_gpu_fullwidth.py::_factor
+    lm = runtime.LoadedModel.from_synth(device, model)
+    W = cfg["kv_lora_rank"] + cfg["rope_dim"]
+    n_tot = DS_PROMPT + DS_STEPS
+    if mode == "contiguous":
+        kv = lm.new_kv_cache(n_tot + 8)
+        got = lm.forward_with_kv_cache(p, kv, 0, all_logits=True).to_numpy()
+    else:
+        bs = 16
+        nb = (n_tot + bs - 1) // bs + 3
+        pk = runtime.LayeredPagedKvCache(device, cfg["n_layers"], nb, bs, 1, W, lm.c.act_dtype)
+        order = list(np.random.default_rng(3).permutation(nb))          # scattered physical blocks
+        pk.set_blocks([int(b) for b in order])
+        pk.set_seq_len(DS_PROMPT)
+        got = lm.forward_with_paged_kv_cache(p, pk, pk.compute_slot_mapping(0, DS_PROMPT), pk.block_table_device_format(), DS_PROMPT, 0, all_logits=True).to_numpy()
+    # (1) every prompt row: the 512-row batched prefill (dsv2_prefill)
+    assert got.shape == rows.shape
+    _check_logits(got, rows, act, factor=f)
+    worst = max(_rel_l2(got[i], rows[i]) for i in range(0, DS_PROMPT, 7))
+    assert worst <= 2.0 * f * {"bf16": 2 ** -7, "f16": 1e-3, "f32": 1e-3}[act], worst    # no single row hides behind the aggregate
+    if mode == "contiguous":
+        # (2) the latent cache the prompt left behind: normalised latents | roped k_pe of every layer (rounded to the cache dtype)
+        for layer in range(cfg["n_layers"]):
+            g = kv.read(layer, 0, 0, DS_PROMPT)
+            assert np.abs(g - lat[layer, :DS_PROMPT]).max() <= 2 * 2 ** -7 * np.abs(lat[layer, :DS_PROMPT]).max(), layer
+    # (3) decode at contexts 512 .. 650, teacher-forced with the oracle's ids: every logits row, ids on the fair steps
+    n_cmp = n_eq = 0
+    gap = _fair_prefix  # noqa: F841  (ids are compared per step below, not as a prefix)
+    for i in range(DS_STEPS):
+        pos = DS_PROMPT + i
+        if mode == "contiguous":
+            lg = lm.forward_with_kv_cache([ids[i]], kv, pos).to_numpy().reshape(-1)
+        else:
+            pk.set_seq_len(pos + 1)
+            lg = lm.forward_with_paged_kv_cache([ids[i]], pk, pk.compute_slot_mapping(pos, 1), pk.block_table_device_format(), pos + 1, pos).to_numpy().reshape(-1)
+        _check_logits(lg, dec[i], act, factor=f)
+        srt = np.sort(dec[i])
+        if srt[-1] - srt[-2] >= 8 * 2.0 ** -8 * np.abs(dec[i]).max():      # 8 rounding units of bf16: a fair step
+            n_cmp += 1
+            n_eq += int(lg.argmax()) == ids[i + 1]
+    assert n_cmp >= DS_STEPS // 3 and n_eq == n_cmp, (n_eq, n_cmp)
+    if mode == "contiguous":
+        g = kv.read(cfg["n_layers"] - 1, 0, 0, n_tot)
+        assert np.abs(g - lat[-1, :n_tot]).max() <= 2 * 2 ** -7 * np.abs(lat[-1, :n_tot]).max()
+
+
+@pytest.mark.watchdog(600)
+def test_deepseek_v2_lite_graph_decode_at_long_context_equals_eager(dsv2_oracle, device):
+    """the decode graph (one hipGraph per step) at contexts 512 .. 560 replays the eager step bit for bit (ids and the last logits row)"""
+    model, p, rows, ids, dec, lat = dsv2_oracle
+    lm = runtime.LoadedModel.from_synth(device, model)
+    ex = runtime.Executor(lm)
+    a = ex.generate(p, 48)
+    b = ex.generate(p, 48, use_graph=True)
+    assert a.tolist() == b.tolist()
+    n = 0
+    while n < 48 and n < len(ids) and ids[n] == int(a[n]):
+        n += 1
+    fair = 0
+    for i in range(min(48, len(dec))):
+        srt = np.sort(dec[i])
+        if srt[-1] - srt[-2] < 8 * 2.0 ** -8 * np.abs(dec[i]).max():
+            break
+        fair += 1
+    assert n >= min(fair + 1, 48), (n, fair, a.tolist()[:12], ids[:12])
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------------
+# Llama-3-8B AWQ widths: decode across 512 -> 650
+# ------------------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.watchdog(900)
+def test_llama_awq_decode_across_512_to_650(device):
+    model = synth.make_llama("llama3-8b-awq-2l", max_seq_len=704)
+    cfg = model["config"]
+    lm, om = runtime.LoadedModel.from_synth(device, model), orc_py.OrcLlama(model)
+    P, N = 500, 150
+    p = synth.prompt_tokens(P, cfg["vocab"], seed=4)
+    kv = runtime.LayeredKvCache(device, cfg["n_layers"], 1, cfg["n_kv_heads"], P + N + 8, cfg["max_seq_len"], cfg["head_dim"], L.F16)
+    okv = om.new_kv(P + N + 8)
+    want = om.forward_kv(p, okv, 0)
+    got = lm.forward_with_kv_cache(p, kv, 0).to_numpy()                  # batched prefill (W4A16 MFMA GEMMs + flash attention)
+    _check_logits(got.reshape(-1), np.asarray(want).reshape(-1), "f16", factor=1.0)
+    tok = int(np.asarray(want).reshape(-1).argmax())
+    worst = 0.0
+    for i in range(N):                                                  # contexts 501 .. 650: single launch up to 512, split-KV + merge beyond
+        lo = np.asarray(om.forward_kv([tok], okv, P + i)).reshape(-1)
+        lg = lm.forward_with_kv_cache([tok], kv, P + i).to_numpy().reshape(-1)
+        _check_logits(lg, lo, "f16", factor=1.0)
+        worst = max(worst, _rel_l2(lg, lo))
+        tok = int(lo.argmax())
+    print("decode 501..650, 2 layers at 8B widths: worst relative L2 %.3e" % worst)
+    # the graph path over the same boundary: ids equal the eager path's, bit for bit
+    ex = runtime.Executor(lm)
+    a = ex.generate(p, 40)
+    b = ex.generate(p, 40, use_graph=True)
+    assert a.tolist() == b.tolist()
+    orc_py.lib().orc_kv_free(okv)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------------
+# the headline config at full depth
+# ------------------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.watchdog(1100)
+def test_llama3_8b_awq_full_depth_teacher_forced(device):
+    """32 layers, every weight at its real size (5.75 GB resident): 16 prompt tokens + 10 decode steps, all through the single-token decode path, the
+    oracle's greedy ids teacher-forced.  Bar: the north-star's 1e-3 relative (L2 over the vocabulary) at EVERY step; greedy ids equal on every fair step."""
+    cfg = synth.make_config("llama3-8b-awq")
+    cfg["max_seq_len"] = 64
+    lm = runtime.LoadedModel(device, cfg)
+    layers = []
+    for i in range(cfg["n_layers"]):
+        lay = synth.llama_layer(cfg, i)
+        lm.add_llama_layer(i, lay)
+        layers.append(lay)
+    emb, fnorm, lmh = synth.llama_head(cfg)
+    lm.add_llama_head(emb, fnorm, lmh)
+    lm.finalize()
+    om = orc_py.OrcLlama(dict(config=cfg, embed=emb, final_norm=fnorm, lm_head=lmh, layers=layers))
+    P, N = 16, 10
+    p = [int(t) for t in synth.prompt_tokens(P, cfg["vocab"], seed=26)]
+    kv = runtime.LayeredKvCache(device, cfg["n_layers"], 1, cfg["n_kv_heads"], P + N + 2, cfg["max_seq_len"], cfg["head_dim"], L.F16)
+    okv = om.new_kv(P + N + 2)
+    l2, fair, same = [], [], []
+    tok = p[0]
+    for i in range(P + N):
+        lo = np.asarray(om.forward_kv([tok], okv, i)).reshape(-1)
+        lg = lm.forward_with_kv_cache([tok], kv, i).to_numpy().reshape(-1)
+        l2.append(_rel_l2(lg, lo))
+        srt = np.sort(lo)
+        fair.append(bool(srt[-1] - srt[-2] >= 4e-3 * np.abs(lo).max()))
+        same.append(int(lg.argmax()) == int(lo.argmax()))
+        tok = p[i + 1] if i + 1 < P else int(lo.argmax())
+    orc_py.lib().orc_kv_free(okv)
+    print("32-layer teacher-forced relative L2 per step:", " ".join("%.2e" % v for v in l2))
+    assert all(s for s, f in zip(same, fair) if f), (same, fair)
+    assert max(l2) <= 1e-3, "full-depth logits: worst step %.3e > 1e-3 (per step: %s)" % (max(l2), l2)
