@@ -164,6 +164,11 @@ SYMBOLS = {
     "bz_tune_mlp": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     "bz_probe_hbm_read": (C.c_int, [P, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
     "bz_expf_spec": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "bz_conv1d_step": (C.c_int, [P, C.c_int, P, P, P]),
+    "bz_ssm_step": (C.c_int, [P, C.c_int, P, P, P]),
+    "bz_ssm_state_read": (C.c_int, [P, C.c_int, C.c_int, C.c_void_p, C.c_size_t]),
+    "bz_moe_route": (C.c_int, [P, C.c_int, P, P, P, P]),
+    "bz_moe_grouped_gemv": (C.c_int, [P, C.c_int, C.c_int, P, C.c_int, P, P]),
     "bz_tune_gemv": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "bz_compute_dynamic_temperature": (C.c_float, [P, C.c_int64, C.c_float, C.c_float, C.c_float]),
     "bz_apply_dry_penalty": (C.c_int, [P, C.c_int64, P, C.c_int64, C.c_float, C.c_int, C.c_int]),

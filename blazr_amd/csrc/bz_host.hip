@@ -3248,6 +3248,158 @@ extern "C" int bz_dequant(bz_model* m, const char* name, float* host) {
   BZ_API_END
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// op-level entry points for the Mamba2 mixer and the MoE block (bz_ssm_step, bz_conv1d_step, bz_moe_route, bz_moe_grouped_gemv).
+// Each runs the kernel the decode step uses, on caller-provided rows, so that the state update / router / grouped GEMV can be compared with
+// the oracle on their own (ConvOps and the MoE ops of the trait bound at /root/reference/src/engine/executor.rs:67-80).
+// ---------------------------------------------------------------------------------------------------------
+static int ssm_op_args(bz_model* m, int layer, bz_ssm_state* st, const bz_tensor* zx, SsmArgs* sa, int* conv_dim_out) {
+  if (!m || !m->finalized || m->cfg.arch != BZ_ARCH_MAMBA2) BZ_FAIL(BZ_E_INVALID, "ssm op: not a finalized Mamba2 model");
+  BZ_TRY(check_ssm(m, st));
+  const bz_model_config& c = m->cfg;
+  if (layer < 0 || layer >= c.n_layers) BZ_FAIL(BZ_E_INVALID, "ssm op: layer %d out of range", layer);
+  const int DI = c.ssm_d_inner, NH = c.ssm_n_heads, NS = c.ssm_d_state, G = c.ssm_n_groups, KC = c.ssm_conv_kernel;
+  const int conv_dim = DI + 2 * G * NS, d_in = 2 * DI + 2 * G * NS + NH;
+  if (!zx || zx->dtype != BZ_F32 || zx->nbytes < (size_t)d_in * 4) BZ_FAIL(BZ_E_INVALID, "ssm op: zx must be an F32 tensor of %d values ([z | x B C | dt], the in_proj row)", d_in);
+  BZ_HIP(hipSetDevice(m->dev->id));
+  const MambaLayerDev& L = m->mlayers[layer];
+  SsmArgs a{};
+  a.zx = VSrc{zx->ptr, 0}; a.z_off = 0; a.x_off = DI; a.dt_off = DI + conv_dim; a.dt_bias = L.dt_bias; a.A_log = L.A_log; a.D = L.D;
+  a.conv_w = L.conv_w; a.conv_b = L.conv_b; a.conv_state = st->conv + (size_t)layer * conv_dim * (KC - 1); a.conv_kernel = KC;
+  a.state = (char*)st->ssm + (size_t)layer * NH * c.ssm_head_dim * NS * bz_dtype_size(st->dtype); a.sdt = st->dtype;
+  a.n_heads = NH; a.head_dim = c.ssm_head_dim; a.d_state = NS; a.n_groups = G; a.d_inner = DI; a.act = c.act_dtype; a.y = m->ybuf; a.gate = 1; a.vss = m->vss;
+  *sa = a; *conv_dim_out = conv_dim;
+  return BZ_OK;
+}
+
+extern "C" int bz_conv1d_step(bz_model* m, int layer, bz_ssm_state* state, const bz_tensor* zx, bz_tensor* xbc_out) {
+  BZ_API_BEGIN
+  SsmArgs a; int conv_dim = 0;
+  BZ_TRY(ssm_op_args(m, layer, state, zx, &a, &conv_dim));
+  if (!xbc_out || xbc_out->dtype != BZ_F32 || xbc_out->nbytes < (size_t)conv_dim * 4) BZ_FAIL(BZ_E_INVALID, "conv1d_step: xbc_out must hold %d F32 values", conv_dim);
+  std::lock_guard<std::recursive_mutex> lk(m->mu);
+  hipStream_t st = m->dev->stream;
+  a.conv_out = (float*)xbc_out->ptr; a.conv_only = 1;
+  BZ_TRY(bzk_ssm_step(st, a));                        // the x channels' window moves inside the launch ...
+  const ConvShift shf{a.conv_state, a.zx, a.x_off, a.d_inner, conv_dim - a.d_inner, a.conv_kernel};
+  BZ_TRY(bzk_conv_shift(st, shf, a.act));             // ... the B / C channels' behind it (the decode step: a side duty of the out_proj launch)
+  BZ_HIP(hipStreamSynchronize(st));
+  return BZ_OK;
+  BZ_API_END
+}
+
+extern "C" int bz_ssm_step(bz_model* m, int layer, bz_ssm_state* state, const bz_tensor* zx, bz_tensor* y_out) {
+  BZ_API_BEGIN
+  SsmArgs a; int conv_dim = 0;
+  BZ_TRY(ssm_op_args(m, layer, state, zx, &a, &conv_dim));
+  if (!y_out || y_out->dtype != BZ_F32 || y_out->nbytes < (size_t)a.d_inner * 4) BZ_FAIL(BZ_E_INVALID, "ssm_step: y_out must hold %d F32 values", a.d_inner);
+  std::lock_guard<std::recursive_mutex> lk(m->mu);
+  hipStream_t st = m->dev->stream;
+  a.y = (float*)y_out->ptr;
+  BZ_TRY(bzk_ssm_step(st, a));
+  const ConvShift shf{a.conv_state, a.zx, a.x_off, a.d_inner, conv_dim - a.d_inner, a.conv_kernel};
+  BZ_TRY(bzk_conv_shift(st, shf, a.act));
+  BZ_HIP(hipStreamSynchronize(st));
+  return BZ_OK;
+  BZ_API_END
+}
+
+extern "C" int bz_ssm_state_read(const bz_ssm_state* st, int layer, int which, float* host, size_t n) {
+  BZ_API_BEGIN
+  if (!st || !host || layer < 0 || layer >= st->layers || (which != 0 && which != 1)) BZ_FAIL(BZ_E_INVALID, "ssm_state_read: bad argument");
+  BZ_HIP(hipSetDevice(st->dev->id));
+  BZ_HIP(hipStreamSynchronize(st->dev->stream));
+  if (which == 1) {
+    const size_t per = (size_t)st->conv_dim * (st->kc - 1);
+    if (n != per) BZ_FAIL(BZ_E_INVALID, "ssm_state_read: the conv window of a layer has %zu values", per);
+    BZ_HIP(hipMemcpy(host, st->conv + (size_t)layer * per, per * 4, hipMemcpyDeviceToHost));
+    return BZ_OK;
+  }
+  const size_t per = (size_t)st->n_heads * st->head_dim * st->d_state, es = bz_dtype_size(st->dtype);
+  if (n != per) BZ_FAIL(BZ_E_INVALID, "ssm_state_read: the SSM state of a layer has %zu values", per);
+  if (st->dtype == BZ_F32) { BZ_HIP(hipMemcpy(host, (const char*)st->ssm + (size_t)layer * per * 4, per * 4, hipMemcpyDeviceToHost)); return BZ_OK; }
+  std::vector<uint16_t> raw(per);
+  BZ_HIP(hipMemcpy(raw.data(), (const char*)st->ssm + (size_t)layer * per * es, per * es, hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < per; i++) {
+    if (st->dtype == BZ_BF16) { const uint32_t u = (uint32_t)raw[i] << 16; memcpy(&host[i], &u, 4); }
+    else host[i] = __half2float(__ushort_as_half(raw[i]));
+  }
+  return BZ_OK;
+  BZ_API_END
+}
+
+static int moe_op_layer(bz_model* m, int layer, const DsLayerDev** L) {
+  if (!m || !m->finalized || m->cfg.arch != BZ_ARCH_DEEPSEEK2) BZ_FAIL(BZ_E_INVALID, "moe op: not a finalized DeepSeek-V2 model");
+  if (layer < 0 || layer >= m->cfg.n_layers || !m->dlayers[layer].is_moe) BZ_FAIL(BZ_E_INVALID, "moe op: layer %d is not a MoE layer", layer);
+  BZ_HIP(hipSetDevice(m->dev->id));
+  *L = &m->dlayers[layer];
+  return BZ_OK;
+}
+
+extern "C" int bz_moe_route(bz_model* m, int layer, const bz_tensor* hidden, bz_tensor* sel_out, bz_tensor* w_out, bz_tensor* xn_out) {
+  BZ_API_BEGIN
+  const DsLayerDev* L = nullptr;
+  BZ_TRY(moe_op_layer(m, layer, &L));
+  const bz_model_config& c = m->cfg;
+  const int H = c.hidden, slots = c.moe_top_k + c.moe_n_shared;
+  if (!hidden || hidden->dtype != BZ_F32 || hidden->nbytes < (size_t)H * 4) BZ_FAIL(BZ_E_INVALID, "moe_route: hidden must be F32 [%d]", H);
+  if (!sel_out || sel_out->dtype != BZ_I32 || sel_out->nbytes < (size_t)slots * 4 || !w_out || w_out->dtype != BZ_F32 || w_out->nbytes < (size_t)slots * 4)
+    BZ_FAIL(BZ_E_INVALID, "moe_route: sel_out I32 / w_out F32 must hold top_k + n_shared = %d values", slots);
+  if (xn_out && (xn_out->dtype != BZ_F32 || xn_out->nbytes < (size_t)H * 4)) BZ_FAIL(BZ_E_INVALID, "moe_route: xn_out must be F32 [%d]", H);
+  std::lock_guard<std::recursive_mutex> lk(m->mu);
+  hipStream_t st = m->dev->stream;
+  Pro pf{}; pf.mode = PRO_NORM; pf.src = VSrc{nullptr, 0}; pf.h_in = (const float*)hidden->ptr; pf.h_out = nullptr; pf.norm_w = L->ffn_norm; pf.eps = c.rms_eps; pf.H = H; pf.act = c.act_dtype;
+  BZ_TRY(bzk_moe_router(st, pf, L->router, L->router_dt, c.moe_n_experts, c.moe_top_k, c.moe_n_shared, c.moe_routed_scale, c.moe_norm_topk, m->moe_xn, m->moe_sel, m->moe_w,
+                        m->moe_lg, m->moe_cnt));
+  BZ_HIP(hipMemcpyAsync(sel_out->ptr, m->moe_sel, (size_t)slots * 4, hipMemcpyDeviceToDevice, st));
+  BZ_HIP(hipMemcpyAsync(w_out->ptr, m->moe_w, (size_t)slots * 4, hipMemcpyDeviceToDevice, st));
+  if (xn_out) BZ_HIP(hipMemcpyAsync(xn_out->ptr, m->moe_xn, (size_t)H * 4, hipMemcpyDeviceToDevice, st));
+  BZ_HIP(hipStreamSynchronize(st));
+  return BZ_OK;
+  BZ_API_END
+}
+
+extern "C" int bz_moe_grouped_gemv(bz_model* m, int layer, int which, const bz_tensor* sel, int n_slots, const bz_tensor* x, bz_tensor* y) {
+  BZ_API_BEGIN
+  const DsLayerDev* L = nullptr;
+  BZ_TRY(moe_op_layer(m, layer, &L));
+  const bz_model_config& c = m->cfg;
+  const int H = c.hidden, MI = c.moe_inter, act = c.act_dtype;
+  if (which != 0 && which != 1) BZ_FAIL(BZ_E_INVALID, "moe_grouped_gemv: which must be 0 (gate/up) or 1 (down)");
+  if (n_slots <= 0 || n_slots > 128 || !sel || sel->dtype != BZ_I32 || sel->nbytes < (size_t)n_slots * 4) BZ_FAIL(BZ_E_INVALID, "moe_grouped_gemv: sel must be I32 [n_slots <= 128]");
+  const int N = which == 0 ? 2 * MI : H, K = which == 0 ? H : MI;
+  const size_t xin = which == 0 ? (size_t)H : (size_t)n_slots * 2 * MI;
+  if (!x || x->dtype != BZ_F32 || x->nbytes < xin * 4) BZ_FAIL(BZ_E_INVALID, "moe_grouped_gemv: x must hold %zu F32 values", xin);
+  if (!y || y->dtype != BZ_F32 || y->nbytes < (size_t)n_slots * N * 4) BZ_FAIL(BZ_E_INVALID, "moe_grouped_gemv: y must hold n_slots x %d F32 values", N);
+  {
+    std::vector<int> hs(n_slots);
+    BZ_HIP(hipMemcpy(hs.data(), sel->ptr, (size_t)n_slots * 4, hipMemcpyDeviceToHost));
+    for (int e : hs) if (e < 0 || e >= c.moe_n_experts + c.moe_n_shared) BZ_FAIL(BZ_E_INVALID, "moe_grouped_gemv: expert index %d out of range", e);
+  }
+  std::lock_guard<std::recursive_mutex> lk(m->mu);
+  hipStream_t st = m->dev->stream;
+  const size_t es = bz_dtype_size(L->e_dt);
+  const bool r2 = bzk_moe_rows2_ok(L->e_dt, K);
+  long long* acc = nullptr;
+  BZ_HIP(hipMalloc((void**)&acc, (size_t)n_slots * N * 8));
+  hipError_t e0 = hipMemsetAsync(acc, 0, (size_t)n_slots * N * 8, st);
+  int rc = e0 == hipSuccess ? BZ_OK : BZ_E_HIP;
+  MoeGemvArgs g{};
+  g.w = which == 0 ? L->e_gu : L->e_dn; g.expert_stride = (long long)N * K; g.sel = (const int*)sel->ptr; g.N = N; g.K = K;
+  g.src_stride = which == 0 ? 0 : 2 * MI;
+  g.out = (float*)y->ptr; g.out_stride = N;
+  g.acc = acc; g.acc_stride = N; g.acc_slots = n_slots;
+  Pro p{}; p.mode = which == 0 ? PRO_PLAIN : PRO_SILU; p.src = VSrc{x->ptr, 0}; p.H = which == 0 ? 0 : MI; p.act = act;
+  // the decode step's form: the balanced role kernel into fixed-point accumulators (16-bit experts), converted with one rounding; else the 16-row workgroup form
+  const bool split = r2 || which == 1;
+  if (rc == BZ_OK) rc = bzk_moe_gemv(st, g, L->e_dt, n_slots, p, act, split, (double)n_slots * N * K * es);
+  if (rc == BZ_OK && split) rc = bzk_fix_to_f32(st, acc, n_slots * N, act, (float*)y->ptr);
+  hipStreamSynchronize(st);
+  hipFree(acc);
+  return rc;
+  BZ_API_END
+}
+
 extern "C" int bz_expf_spec(const float* x, int n, float* y) {
   BZ_API_BEGIN
   if (!x || !y || n < 0) BZ_FAIL(BZ_E_INVALID, "bad argument");

@@ -345,8 +345,11 @@ struct SsmArgs {
   float* y;              // [d_inner]
   int gate;              // != 0: y <- R(y * R(silu(z))) and vss[head] <- sum of y^2 (feeds PRO_GATED2)
   float* vss;            // [n_heads]
+  float* conv_out;       // op-level entry points only (nullptr in the forward path): the conv1d step's output [x | B | C] (after SiLU, rounded)
+  int conv_only;         // op-level bz_conv1d_step: stop after the conv (the SSM state is not touched)
 };
 int bzk_ssm_step(hipStream_t s, const SsmArgs& a);
+int bzk_conv_shift(hipStream_t s, const ConvShift& c, int act);   // shifts the conv state of channels [ch0, ch0 + n) by the projection (the forward path does this inside out_proj's launch)
 int bzk_batch_advance(hipStream_t s, long long* tok, const long long* next, int* pos, int* slot, const int* table, int stride, int bs, int N);
 int bzk_batch_argmax(hipStream_t s, const float* logits, int V, long long* next, long long* log, int* step, int logcap, int N);
 

@@ -56,22 +56,25 @@ __device__ __forceinline__ float round_act(float x, int act) {
   if (act == BZ_BF16) return bf16_round(x);
   return x;
 }
-// 2^-44 fixed point (round 2: 2^-32).  A workgroup rounds its partial sum to the grid once (d2fix), so a sum over a few hundred workgroups carries ~1e-12 of
-// absolute error at 2^-44 against ~4e-9 at 2^-32 -- the latter is 1e-5 of an f16 rounding interval of a value near 0.1, i.e. about one flipped f16 rounding
-// per ten thousand outputs, and one flip in a layer's input is ~2000 one-ulp differences in its output.  Range: +-2^19 = 524288 (f16 ends at 65504).
-#define BZ_FIX_SCALE 17592186044416.0          /* 2^44 */
-#define BZ_FIX_INV 5.6843418860808015e-14      /* 2^-44 */
-__device__ __forceinline__ float fix2f(long long a) {
+// Fixed point of the split-K accumulators: 2^-44 units when the activations are f16, 2^-32 otherwise.  A workgroup rounds its partial sum to the grid once
+// (d2fix / f2fix), so a sum over a few hundred workgroups carries ~1e-12 of absolute error at 2^-44 against ~4e-9 at 2^-32 -- the latter is 1e-5 of an f16
+// rounding interval of a value near 0.1, i.e. about one flipped f16 rounding per ten thousand outputs, and one flip in a layer's input is ~2000 one-ulp
+// differences in its output.  Range at 2^-44: +-2^19 = 524288, enough where every value that is ever stored ends at 65504 (f16); bf16 / f32 activations have
+// no such bound (the synthetic Mistral Q4_K_M weights drive intermediate values past 5e5), so they keep 2^-32 (+-2^31).  Producer and consumer of an
+// accumulator belong to the same model and pass the same activation dtype.
+__device__ __forceinline__ double fix_scale(int act) { return act == BZ_F16 ? 17592186044416.0 : 4294967296.0; }            // 2^44 : 2^32
+__device__ __forceinline__ double fix_inv(int act) { return act == BZ_F16 ? 5.6843418860808015e-14 : 2.3283064365386963e-10; }
+__device__ __forceinline__ float fix2f(long long a, int act) {
   // ONE rounding of the exact fixed-point sum to f32 (the oracle rounds its double sum to f32 once): both 32-bit halves are exact in
-  // double, so is their join below 2^53 (|value| < 512; above, the join itself rounds to 53 bits first), and the cast rounds to nearest even
+  // double, so is their join below 2^53 (above, the join itself rounds to 53 bits first), and the cast rounds to nearest even
   const unsigned long long m = a < 0 ? (unsigned long long)(-a) : (unsigned long long)a;
-  const double d = fma((double)(unsigned)(m >> 32), 4294967296.0, (double)(unsigned)(m & 0xffffffffull)) * BZ_FIX_INV;
+  const double d = fma((double)(unsigned)(m >> 32), 4294967296.0, (double)(unsigned)(m & 0xffffffffull)) * fix_inv(act);
   const float r = (float)d;
   return a < 0 ? -r : r;
 }
-__device__ __forceinline__ long long f2fix(float p) { return __float2ll_rn(p * (float)BZ_FIX_SCALE); }
+__device__ __forceinline__ long long f2fix(float p, int act) { return __float2ll_rn(p * (float)fix_scale(act)); }
 __device__ __forceinline__ float vsrc_get(const VSrc& s, int i, int act) {
-  if (s.fix) return round_act(fix2f(((const long long*)s.p)[i]), act);
+  if (s.fix) return round_act(fix2f(((const long long*)s.p)[i], act), act);
   return ((const float*)s.p)[i];
 }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + bz_expf(-x)); }
@@ -115,7 +118,7 @@ __device__ __forceinline__ typename SrcRaw<FIX>::T src_raw(const void* p, int i)
 }
 template <bool FIX>
 __device__ __forceinline__ float src_cvt(typename SrcRaw<FIX>::T r, int act) {
-  if constexpr (FIX) return round_act(fix2f(r), act); else return r;
+  if constexpr (FIX) return round_act(fix2f(r, act), act); else return r;
 }
 
 // NORM pass 1: v = R(h + prev) for the whole row -> sum of squares; slice elements [k0, k0+KR) are parked in xs
@@ -255,7 +258,7 @@ __device__ void build_x_simple(const Pro& p, int k0, int KR, float* xs, float* r
 // below is statically indexed and stays in registers.
 template <int FIX>
 __device__ __forceinline__ float vget(const void* p, int i, int act) {
-  if (FIX) return round_act(fix2f(((const long long*)p)[i]), act);
+  if (FIX) return round_act(fix2f(((const long long*)p)[i], act), act);
   return ((const float*)p)[i];
 }
 
@@ -270,7 +273,7 @@ __device__ __forceinline__ typename RawT<FIX>::T vraw(const void* p, int i) {
 }
 template <int FIX>
 __device__ __forceinline__ float vcvt(typename RawT<FIX>::T r, int act) {
-  if (FIX) return round_act(fix2f((long long)r), act);
+  if (FIX) return round_act(fix2f((long long)r, act), act);
   return (float)r;
 }
 
@@ -362,45 +365,64 @@ __device__ __forceinline__ void xfinish(const Pro& p, int KR, const XRegs<MODE, 
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// activation slice -> six signed-nibble planes + per-group parameters   (QG = 128 k per group, 16 lanes x 8 each)
-//   x = c * xi exactly, c = 2^-e with am * 2^e in [2^21, 2^22) (am = the group's maximum magnitude): a power-of-two scale, so xi is the
-//   activation itself (f16 values carry 11 bits; every element within 2^-11 of the group maximum is represented exactly, smaller ones to
-//   2^-22 of the maximum).  xi = sum_p 16^p n_p with balanced nibbles n_p in [-8, 7]: the weights are signed nibbles (q - 8) as well, so a
-//   32-bit weight word meets a 32-bit plane word in ONE V_DOT8_I32_I4 -- six per eight weights, no unpacking at all (round 1: three int8
-//   planes on V_DOT4_I32_I8 = six dots + two ANDs per eight weights).
-//   LDS image: pl[(g*4 + c)*6 + p] = uint4, the four plane-p words for the four weight words of 32-k chunk c of group g; nibble i of a word
+// activation slice -> signed-nibble planes + per-group parameters   (QG = 128 k per group, 16 lanes x 8 each)
+//   x = c * xi exactly, c = 2^-e with am * 2^e in [2^29, 2^30) (am = the group's maximum magnitude): a power-of-two scale, so xi is the
+//   activation itself.  xi is a 32-bit code = EIGHT balanced nibbles n_p in [-8, 7], xi = sum_p 16^p n_p.  f16 values carry 11 significant bits, so an
+//   element within 2^-11 of the group maximum has nothing below bit 8: the two LOW planes (nibbles 0, 1) are zero for almost every group and are only
+//   multiplied when a group's flag says they are not (wave-uniform branch; ~10 % of the groups of a normalised row).  Round 2 stopped at 24 bits (six
+//   planes): elements below 2^-11.5 of their group maximum lost their last bits -- 3 elements of a 4096 row, an error of ~5e-9 of the output, i.e. one
+//   flipped f16 rounding per ~70 k outputs: about one per layer, and one flip in a layer's input is ~2000 one-ulp differences in its output
+//   (profiles/r03_parity_depth_*.txt).  With eight planes every f16 element down to 2^-19.5 of its group maximum is exact.
+//   The weights are signed nibbles (q - 8) as well, so a 32-bit weight word meets a 32-bit plane word in ONE V_DOT8_I32_I4 -- six per eight weights
+//   (eight in a flagged group), no unpacking at all (round 1: three int8 planes on V_DOT4_I32_I8 = six dots + two ANDs per eight weights).
+//   Plane order in LDS and in registers: index 0..5 = the MAIN planes (nibbles 2..7 of the code), index 6, 7 = the LOW planes (nibbles 0, 1).
+//   LDS image: pl[(g*4 + c)*8 + p] = uint4, the four plane-p words for the four weight words of 32-k chunk c of group g; nibble i of a word
 //   is k offset (i >> 1) + 4 (i & 1), the order of the weight words (repack kernels below).
-//   gpar[2g] = { c (float bits), S_0, S_1, S_2 }   gpar[2g+1] = { S_3, S_4, S_5, 0 }     S_p = sum of n_p over the group
-//   sum_k (q_k - z) x_k = c * sum_p 16^p (D_p + (8 - z) S_p),  D_p = sum_k (q_k - 8) n_p,k   -- all of it exact integer arithmetic.
+//   gpar[2g] = { c (float bits), S_0, S_1, S_2 }   gpar[2g+1] = { S_3, S_4, S_5, low }     S_p = sum of plane p over the group (main planes),
+//   low = S_6 (12 bits) | S_7 (12 bits) << 12 | flag << 24   (flag: some low-plane nibble of the group is not zero)
+//   sum_k (q_k - z) x_k = c * [ 256 * sum_{p<6} 16^p (D_p + (8 - z) S_p) + (D_6 + (8 - z) S_6) + 16 (D_7 + (8 - z) S_7) ],  D_p = sum_k (q_k - 8) n_p,k
+//   -- all of it exact integer arithmetic.
 // ---------------------------------------------------------------------------------------------------------
-#define XQ_NP 6
+#define XQ_NP 8   // planes stored per chunk
+#define XQ_NM 6   // main planes (always multiplied)
+struct OpOr { __device__ __forceinline__ static int f(int a, int b) { return a | b; } };
+__device__ __forceinline__ int xq_pack_low(int s6, int s7, int flag) { return (s6 & 0xFFF) | ((s7 & 0xFFF) << 12) | (flag ? (1 << 24) : 0); }
+// wave-uniform: does group `gi` (index of its gpar pair) have non-zero low planes?  (every lane reads the same LDS word)
+__device__ __forceinline__ bool xq_low(const int4* gpar, int gi) { return __builtin_amdgcn_readfirstlane(gpar[gi + 1].w >> 24) != 0; }
 
 // one thread: 8 consecutive activations -> one word per plane (+ the plane sums); am = group maximum (already reduced).
-// The balanced digits of xi are the unsigned base-16 digits of xi + 0x888888 minus 8, i.e. in two's complement simply
-// code = (xi + 0x888888) ^ 0x888888: nibble p of the 24-bit code IS the stored nibble of plane p.  What remains is an 8 x 6 nibble
+// The balanced digits of xi are the unsigned base-16 digits of xi + 0x88888888 minus 8, i.e. in two's complement simply
+// code = (xi + 0x88888888) ^ 0x88888888: nibble p of the 32-bit code IS the stored nibble of plane p.  What remains is an 8 x 8 nibble
 // transpose: pairs (k, k + 4) are interleaved into bytes with three mask ops, the bytes gathered per plane with V_PERM_B32.
 __device__ __forceinline__ void xq_split8(const float (&v)[8], float am, unsigned (&w)[XQ_NP], int (&sp)[XQ_NP], float& cscale) {
   const unsigned eb = (__float_as_uint(am) >> 23) & 255u;               // biased exponent of the group maximum
-  const bool live = eb >= 24u && eb < 255u;
-  const float inv = live ? __uint_as_float((275u - eb) << 23) : 0.f;    // 2^(21 - (eb - 127))
-  cscale = live ? __uint_as_float((eb - 21u) << 23) : 0.f;              // its reciprocal
+  const bool live = eb >= 32u && eb < 255u;
+  const float inv = live ? __uint_as_float((283u - eb) << 23) : 0.f;    // 2^(29 - (eb - 127))
+  cscale = live ? __uint_as_float((eb - 29u) << 23) : 0.f;              // its reciprocal
   unsigned code[8];
 #pragma unroll
-  for (int i = 0; i < 8; i++) code[i] = ((unsigned)((int)rintf(v[i] * inv) + 0x888888)) ^ 0x888888u;
-  unsigned E[4], O[4];          // byte k of E[i] / O[i]: plane 2k / 2k + 1, k offsets i (low nibble) and i + 4 (high nibble)
+  for (int i = 0; i < 8; i++) code[i] = ((unsigned)(int)rintf(v[i] * inv) + 0x88888888u) ^ 0x88888888u;
+  unsigned E[4], O[4];          // byte k of E[i] / O[i]: nibble 2k / 2k + 1 of the codes, k offsets i (low nibble of the byte) and i + 4 (high nibble)
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    E[i] = ((code[i + 4] & 0x0F0F0Fu) << 4) | (code[i] & 0x0F0F0Fu);
-    O[i] = ((code[i] >> 4) & 0x0F0F0Fu) | (code[i + 4] & 0xF0F0F0u);
+    E[i] = ((code[i + 4] & 0x0F0F0F0Fu) << 4) | (code[i] & 0x0F0F0F0Fu);
+    O[i] = ((code[i] >> 4) & 0x0F0F0F0Fu) | (code[i + 4] & 0xF0F0F0F0u);
   }
 #pragma unroll
-  for (int k = 0; k < 3; k++) {
+  for (int k = 0; k < 4; k++) {
     const unsigned sel = 0x0c0c0000u | ((4u + k) << 8) | (unsigned)k;   // [lo.byte k, hi.byte k, 0, 0]
-    w[2 * k] = __builtin_amdgcn_perm(E[1], E[0], sel) | (__builtin_amdgcn_perm(E[3], E[2], sel) << 16);
-    w[2 * k + 1] = __builtin_amdgcn_perm(O[1], O[0], sel) | (__builtin_amdgcn_perm(O[3], O[2], sel) << 16);
+    const int pe = k == 0 ? 6 : 2 * k - 2, po = k == 0 ? 7 : 2 * k - 1; // nibbles 0, 1 are the low planes (index 6, 7); nibble n >= 2 is main plane n - 2
+    w[pe] = __builtin_amdgcn_perm(E[1], E[0], sel) | (__builtin_amdgcn_perm(E[3], E[2], sel) << 16);
+    w[po] = __builtin_amdgcn_perm(O[1], O[0], sel) | (__builtin_amdgcn_perm(O[3], O[2], sel) << 16);
   }
 #pragma unroll
   for (int p = 0; p < XQ_NP; p++) sp[p] = __builtin_amdgcn_sdot8((int)w[p], 0x11111111, 0, false);   // sum of the eight signed nibbles
+}
+// the second parameter word of a group from one lane's reduced sums (the flag: OR over the group's lanes of "my low words are not zero")
+template <int NL>
+__device__ __forceinline__ int4 xq_gpar_hi(const unsigned (&w)[XQ_NP], const int (&sp)[XQ_NP]) {
+  const int fl = grp_reduce<NL, OpOr>((int)((w[6] | w[7]) != 0u));
+  return make_int4(sp[3], sp[4], sp[5], xq_pack_low(sp[6], sp[7], fl));
 }
 
 template <int NTH>
@@ -425,13 +447,14 @@ __device__ __forceinline__ void quant_x128(const float* xs, int KR, uint4* pl, i
     xq_split8(v, am, w, sp, cs);
 #pragma unroll
     for (int p = 0; p < XQ_NP; p++) sp[p] = grp_reduce<16, OpAdd>(sp[p]);
+    const int4 g2w = xq_gpar_hi<16>(w, sp);
     if (on) {
       const int word = ((e0 >> 5) * XQ_NP) * 4 + ((e0 >> 3) & 3);       // chunk e0 / 32, weight word (e0 / 8) % 4
 #pragma unroll
       for (int p = 0; p < XQ_NP; p++) plw[word + p * 4] = w[p];
       if ((threadIdx.x & 15) == 0) {
         gpar[2 * (e0 >> 7)] = make_int4(__float_as_int(cs), sp[0], sp[1], sp[2]);
-        gpar[2 * (e0 >> 7) + 1] = make_int4(sp[3], sp[4], sp[5], 0);
+        gpar[2 * (e0 >> 7) + 1] = g2w;
       }
     }
   }
@@ -453,6 +476,7 @@ __device__ __forceinline__ void quant_x64(const float* a, uint4* pl, int4* gpar)
   xq_split8(v, am, w, sp, cs);
 #pragma unroll
   for (int p = 0; p < XQ_NP; p++) sp[p] = grp_reduce<8, OpAdd>(sp[p]);
+  const int4 g2w = xq_gpar_hi<8>(w, sp);
   if (on) {
     unsigned* plw = (unsigned*)pl;
     const int word = ((t >> 2) * XQ_NP) * 4 + (t & 3);
@@ -460,7 +484,7 @@ __device__ __forceinline__ void quant_x64(const float* a, uint4* pl, int4* gpar)
     for (int p = 0; p < XQ_NP; p++) plw[word + p * 4] = w[p];
     if (t == 0) {
       gpar[0] = make_int4(__float_as_int(cs), sp[0], sp[1], sp[2]);
-      gpar[1] = make_int4(sp[3], sp[4], sp[5], 0);
+      gpar[1] = g2w;
     }
   }
 }
@@ -470,23 +494,32 @@ __device__ __forceinline__ void quant_x64(const float* a, uint4* pl, int4* gpar)
 // ---------------------------------------------------------------------------------------------------------
 #define Q4G_E 8  // slice elements per thread (KR <= 2048)
 
-// one 32-k chunk: the lane's 16-byte weight piece against the six planes (24 V_DOT8_I32_I4, 6 broadcast ds_read_b128)
-__device__ __forceinline__ void q4_chunk(const uint4& w, const uint4* pl6, int (&D)[XQ_NP]) {
+// one 32-k chunk: the lane's 16-byte weight piece against the six main planes (24 V_DOT8_I32_I4, 6 broadcast ds_read_b128), + the two low planes of a flagged group
+__device__ __forceinline__ void q4_chunk(const uint4& w, const uint4* pl8, int (&D)[XQ_NP], bool low) {
   const unsigned W[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
-  for (int p = 0; p < XQ_NP; p++) {
-    const uint4 P = pl6[p];
+  for (int p = 0; p < XQ_NM; p++) {
+    const uint4 P = pl8[p];
     const unsigned X[4] = {P.x, P.y, P.z, P.w};
 #pragma unroll
     for (int j = 0; j < 4; j++) D[p] = __builtin_amdgcn_sdot8((int)W[j], (int)X[j], D[p], false);
   }
+  if (low) {
+#pragma unroll
+    for (int p = XQ_NM; p < XQ_NP; p++) {
+      const uint4 P = pl8[p];
+      const unsigned X[4] = {P.x, P.y, P.z, P.w};
+#pragma unroll
+      for (int j = 0; j < 4; j++) D[p] = __builtin_amdgcn_sdot8((int)W[j], (int)X[j], D[p], false);
+    }
+  }
 }
 // the same planes against two weight pieces (gate and up of the fused MLP): the planes are read from LDS once
-__device__ __forceinline__ void q4_chunk2(const uint4& wa, const uint4& wb, const uint4* pl6, int (&Da)[XQ_NP], int (&Db)[XQ_NP]) {
+__device__ __forceinline__ void q4_chunk2(const uint4& wa, const uint4& wb, const uint4* pl8, int (&Da)[XQ_NP], int (&Db)[XQ_NP], bool low) {
   const unsigned Wa[4] = {wa.x, wa.y, wa.z, wa.w}, Wb[4] = {wb.x, wb.y, wb.z, wb.w};
 #pragma unroll
-  for (int p = 0; p < XQ_NP; p++) {
-    const uint4 P = pl6[p];
+  for (int p = 0; p < XQ_NM; p++) {
+    const uint4 P = pl8[p];
     const unsigned X[4] = {P.x, P.y, P.z, P.w};
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -494,29 +527,46 @@ __device__ __forceinline__ void q4_chunk2(const uint4& wa, const uint4& wb, cons
       Db[p] = __builtin_amdgcn_sdot8((int)Wb[j], (int)X[j], Db[p], false);
     }
   }
+  if (low) {
+#pragma unroll
+    for (int p = XQ_NM; p < XQ_NP; p++) {
+      const uint4 P = pl8[p];
+      const unsigned X[4] = {P.x, P.y, P.z, P.w};
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        Da[p] = __builtin_amdgcn_sdot8((int)Wa[j], (int)X[j], Da[p], false);
+        Db[p] = __builtin_amdgcn_sdot8((int)Wb[j], (int)X[j], Db[p], false);
+      }
+    }
+  }
 }
-// group epilogue: s * c * sum_p 16^p (D_p + (8 - z) S_p), exact -- |V_p| <= 2^14, the two three-plane halves fit int32, their join
-// (< 2^36) and the product with the f32 factor s c are exact in double
+// group epilogue: s * c * [256 * sum_{p<6} 16^p (D_p + (8 - z) S_p) + low part], exact -- |V_p| <= 2^14, the two three-plane halves fit int32, their join
+// (< 2^36), its shift by 8 bits plus the low part (< 2^19) and the product with the f32 factor s c are exact in double.  An unflagged group has
+// D_6 = D_7 = S_6 = S_7 = 0: the low part vanishes without a branch.
 __device__ __forceinline__ double q4_term(const int (&D)[XQ_NP], const int4 g1, const int4 g2, float s, int z) {
   const int zz = 8 - z;
   const int V0 = D[0] + zz * g1.y, V1 = D[1] + zz * g1.z, V2 = D[2] + zz * g1.w, V3 = D[3] + zz * g2.x, V4 = D[4] + zz * g2.y, V5 = D[5] + zz * g2.z;
   const int lo = V0 + (V1 << 4) + (V2 << 8), hi = V3 + (V4 << 4) + (V5 << 8);
-  return (double)(s * __int_as_float(g1.x)) * fma((double)hi, 4096.0, (double)lo);
+  const int s6 = (g2.w << 20) >> 20, s7 = (g2.w << 8) >> 20;
+  const int lw = (D[6] + zz * s6) + ((D[7] + zz * s7) << 4);
+  return (double)(s * __int_as_float(g1.x)) * fma(fma((double)hi, 4096.0, (double)lo), 256.0, (double)lw);
 }
 
 // one 128-k group (four chunks) of one tile
 __device__ __forceinline__ void q4g_consume(const uint4 (&w)[4], int g, const uint4* pl, const int4* gpar, float s, int z, double& y) {
-  int D[XQ_NP] = {0, 0, 0, 0, 0, 0};
+  int D[XQ_NP] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const bool low = xq_low(gpar, 2 * g);
 #pragma unroll
-  for (int c = 0; c < 4; c++) q4_chunk(w[c], pl + (g * 4 + c) * XQ_NP, D);
+  for (int c = 0; c < 4; c++) q4_chunk(w[c], pl + (g * 4 + c) * XQ_NP, D, low);
   y += q4_term(D, gpar[2 * g], gpar[2 * g + 1], s, z);
 }
 // two weight tiles against the SAME activation group (gate and up of the fused MLP)
 __device__ __forceinline__ void q4g_consume2(const uint4 (&wa)[4], const uint4 (&wb)[4], int g, const uint4* pl, const int4* gpar, float sa, int za, float sb, int zb,
                                              double& ya, double& yb) {
-  int Da[XQ_NP] = {0, 0, 0, 0, 0, 0}, Db[XQ_NP] = {0, 0, 0, 0, 0, 0};
+  int Da[XQ_NP] = {0, 0, 0, 0, 0, 0, 0, 0}, Db[XQ_NP] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const bool low = xq_low(gpar, 2 * g);
 #pragma unroll
-  for (int c = 0; c < 4; c++) q4_chunk2(wa[c], wb[c], pl + (g * 4 + c) * XQ_NP, Da, Db);
+  for (int c = 0; c < 4; c++) q4_chunk2(wa[c], wb[c], pl + (g * 4 + c) * XQ_NP, Da, Db, low);
   const int4 g1 = gpar[2 * g], g2 = gpar[2 * g + 1];
   ya += q4_term(Da, g1, g2, sa, za);
   yb += q4_term(Db, g1, g2, sb, zb);
@@ -524,14 +574,15 @@ __device__ __forceinline__ void q4g_consume2(const uint4 (&wa)[4], const uint4 (
 // the same arithmetic over NCH 32-k chunks whose planes start at chunk index co; group parameters at gpar[gp], gpar[gp + 1]
 template <int NCH>
 __device__ __forceinline__ void q4g_consume_n(const uint4 (&w)[NCH], int co, int gp, const uint4* pl, const int4* gpar, float s, int z, double& y) {
-  int D[XQ_NP] = {0, 0, 0, 0, 0, 0};
+  int D[XQ_NP] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const bool low = xq_low(gpar, gp);
 #pragma unroll
-  for (int c = 0; c < NCH; c++) q4_chunk(w[c], pl + (co + c) * XQ_NP, D);
+  for (int c = 0; c < NCH; c++) q4_chunk(w[c], pl + (co + c) * XQ_NP, D, low);
   y += q4_term(D, gpar[gp], gpar[gp + 1], s, z);
 }
 
-// 2^-44 fixed point from the double a lane accumulated over its groups
-__device__ __forceinline__ long long d2fix(double p) { return __double2ll_rn(p * BZ_FIX_SCALE); }
+// fixed point from the double a lane accumulated over its groups
+__device__ __forceinline__ long long d2fix(double p, int act) { return __double2ll_rn(p * fix_scale(act)); }
 
 // ---------------------------------------------------------------------------------------------------------
 // Fused MLP (INT4):  acc_down += Wd[:, slice] . R(R(silu(R(Wg[slice] x))) * R(Wu[slice] x)),  x = RMSNorm(R(h + prev))
@@ -547,7 +598,6 @@ template <int ACT> __device__ __forceinline__ float round_t(float x) {
 }
 #define DPP_ROR4 0x124   // row_ror:4 / row_ror:8: rotate within a 16-lane row (sums that must not mix even and odd lanes)
 #define DPP_ROR8 0x128
-struct OpOr { __device__ __forceinline__ static int f(int a, int b) { return a | b; } };
 
 // Structure of the launch (per-wave stamps of the diagnostic build, profiles/r02_mlp_stamps_*.txt):
 //  * a CU keeps ~40 KiB of HBM loads in flight; a wave that asks for more STALLS AT ISSUE -- in program order, so whatever it would do
@@ -623,7 +673,7 @@ __global__ __launch_bounds__(NW * 64) void k_mlp_q4g(const uint4* __restrict__ W
     float v[8] = {ha.x, ha.y, ha.z, ha.w, hb.x, hb.y, hb.z, hb.w};
     if (hasprev) {
 #pragma unroll
-      for (int e = 0; e < 8; e++) v[e] = round_t<ACT>(v[e] + round_t<ACT>(FIX ? fix2f((long long)pv[e]) : (float)pv[e]));
+      for (int e = 0; e < 8; e++) v[e] = round_t<ACT>(v[e] + round_t<ACT>(FIX ? fix2f((long long)pv[e], ACT) : (float)pv[e]));
     }
     if (blockIdx.x == 0 && pro.h_out) { *(float4*)(pro.h_out + i0) = make_float4(v[0], v[1], v[2], v[3]); *(float4*)(pro.h_out + i0 + 4) = make_float4(v[4], v[5], v[6], v[7]); }
     double ssd = 0.0;
@@ -648,13 +698,14 @@ __global__ __launch_bounds__(NW * 64) void k_mlp_q4g(const uint4* __restrict__ W
     xq_split8(x, am, w, sp, cs);
 #pragma unroll
     for (int p = 0; p < XQ_NP; p++) sp[p] = grp_reduce<16, OpAdd>(sp[p]);
+    const int4 g2w = xq_gpar_hi<16>(w, sp);
     const int oct = tid - NP * 64;                                        // octet index in the row: chunk oct >> 2, weight word oct & 3
     unsigned* plw = (unsigned*)xpl + ((oct >> 2) * XQ_NP) * 4 + (oct & 3);
 #pragma unroll
     for (int p = 0; p < XQ_NP; p++) plw[p * 4] = w[p];
     if ((lane & 15) == 0) {
       gpar[2 * (oct >> 4)] = make_int4(__float_as_int(cs), sp[0], sp[1], sp[2]);
-      gpar[2 * (oct >> 4) + 1] = make_int4(sp[3], sp[4], sp[5], 0);
+      gpar[2 * (oct >> 4) + 1] = g2w;
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);                                   // lgkmcnt(0): this wave's LDS stores are done
     if (lane == 0) atomicAdd((unsigned*)&cnt[1], 1u);
@@ -687,9 +738,10 @@ __global__ __launch_bounds__(NW * 64) void k_mlp_q4g(const uint4* __restrict__ W
   for (int b = 0; b < 2; b++) {
     if (b == 0) MSTAMP(5);
     if (b == 1) MSTAMP(7);
-    int Da[XQ_NP] = {0, 0, 0, 0, 0, 0}, Db[XQ_NP] = {0, 0, 0, 0, 0, 0};
+    int Da[XQ_NP] = {0, 0, 0, 0, 0, 0, 0, 0}, Db[XQ_NP] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool low = xq_low(gpar, 2 * (gbeg + b));
 #pragma unroll
-    for (int c = 0; c < 4; c++) q4_chunk2(Ag[b * 4 + c], Au[b * 4 + c], xpl + ((gbeg + b) * 4 + c) * XQ_NP, Da, Db);
+    for (int c = 0; c < 4; c++) q4_chunk2(Ag[b * 4 + c], Au[b * 4 + c], xpl + ((gbeg + b) * 4 + c) * XQ_NP, Da, Db, low);
     const int4 g1 = gpar[2 * (gbeg + b)], g2 = gpar[2 * (gbeg + b) + 1];
     yg += q4_term(Da, g1, g2, sg[b], zg[b]);
     yu += q4_term(Db, g1, g2, su[b], zu[b]);
@@ -721,15 +773,17 @@ __global__ __launch_bounds__(NW * 64) void k_mlp_q4g(const uint4* __restrict__ W
     const float a = round_t<ACT>(round_t<ACT>(silu_f(round_t<ACT>(fg))) * round_t<ACT>(fu));
     const float am = wave_max(fabsf(a));
     const unsigned eb = (__float_as_uint(am) >> 23) & 255u;
-    const bool live = eb >= 24u && eb < 255u;
-    const float inv = live ? __uint_as_float((275u - eb) << 23) : 0.f;
-    const float cs = live ? __uint_as_float((eb - 21u) << 23) : 0.f;
-    const unsigned code = ((unsigned)((int)rintf(a * inv) + 0x888888)) ^ 0x888888u;
+    const bool live = eb >= 32u && eb < 255u;
+    const float inv = live ? __uint_as_float((283u - eb) << 23) : 0.f;
+    const float cs = live ? __uint_as_float((eb - 29u) << 23) : 0.f;
+    const unsigned code = ((unsigned)(int)rintf(a * inv) + 0x88888888u) ^ 0x88888888u;
+    const int lowfl = __builtin_amdgcn_ballot_w64((code & 0xFFu) != 0u) != 0ull;                  // some value of the 64 has bits in the low planes
     const int o = lane & 7, sh = 4 * (2 * (o & 3) + (o >> 2));                // k offset o -> nibble 2 (o & 3) + (o >> 2)
     int sp[XQ_NP];
 #pragma unroll
     for (int p = 0; p < XQ_NP; p++) {
-      const int wv = grp_reduce<8, OpOr>((int)(((code >> (4 * p)) & 15u) << sh));   // the octet's word of plane p, in all of its lanes
+      const int nib = p < XQ_NM ? p + 2 : p - XQ_NM;                                // plane index -> nibble of the code (xq_split8's order)
+      const int wv = grp_reduce<8, OpOr>((int)(((code >> (4 * nib)) & 15u) << sh));   // the octet's word of plane p, in all of its lanes
       if (o == 0) ((unsigned*)apl)[((lane >> 5) * XQ_NP + p) * 4 + ((lane >> 3) & 3)] = (unsigned)wv;
       int t = __builtin_amdgcn_sdot8(wv, 0x11111111, 0, false);                    // the octet's sum (the same in its 8 lanes)
       t += dpp_get<DPP_ROR8>(t);                                                   // + the other octet of the 16-lane row
@@ -738,7 +792,7 @@ __global__ __launch_bounds__(NW * 64) void k_mlp_q4g(const uint4* __restrict__ W
       const bz_u2_t r2 = __builtin_amdgcn_permlane32_swap((unsigned)t, (unsigned)t, false, false);
       sp[p] = (int)r2.x + (int)r2.y;
     }
-    if (lane == 0) { apar[0] = make_int4(__float_as_int(cs), sp[0], sp[1], sp[2]); apar[1] = make_int4(sp[3], sp[4], sp[5], 0); }
+    if (lane == 0) { apar[0] = make_int4(__float_as_int(cs), sp[0], sp[1], sp[2]); apar[1] = make_int4(sp[3], sp[4], sp[5], xq_pack_low(sp[6], sp[7], lowfl)); }
   }
   __syncthreads();
   MSTAMP(11);
@@ -750,7 +804,7 @@ __global__ __launch_bounds__(NW * 64) void k_mlp_q4g(const uint4* __restrict__ W
     const int n = (tbeg + q) * 64 + lane;
     if (bd != nullptr && sl == 0) y += (double)bd[n];
     if (q == 0) MSTAMP(12);
-    atomicAdd((unsigned long long*)(acc + n), (unsigned long long)d2fix(y));
+    atomicAdd((unsigned long long*)(acc + n), (unsigned long long)d2fix(y, ACT));
   }
   MSTAMP(13);
   if (DIAG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -762,7 +816,7 @@ __global__ __launch_bounds__(NW * 64) void k_mlp_q4g(const uint4* __restrict__ W
 #undef MSTAMP
 }
 
-static size_t mlp_smem(int H) { return (size_t)H * 3 + (size_t)(H >> 7) * 32 + 16 * 128 * 8 + 2 * XQ_NP * 16 + 32 + 16 * 8 + 64; }   // planes, gpar, part, apl, apar, dred, counters
+static size_t mlp_smem(int H) { return (size_t)(H >> 5) * XQ_NP * 16 + (size_t)(H >> 7) * 32 + 16 * 128 * 8 + 2 * XQ_NP * 16 + 32 + 16 * 8 + 64; }   // planes, gpar, part, apl, apar, dred, counters
 
 bool bzk_mlp_fusable(const LinearDev& gu, const LinearDev& dn, int H, int I) {
   return gu.kind == LK_Q4G && dn.kind == LK_Q4G && !gu.perm && !dn.perm && gu.N == 2 * I && gu.K == H && dn.N == H && dn.K == I &&
@@ -875,8 +929,8 @@ __global__ __launch_bounds__(256) void k_gemv_q4g(const uint4* __restrict__ W, c
   QSTAMP(4);
   const int n = nt * 64 + lane;
   if (bias != nullptr && ks == 0) y += (double)bias[n];
-  if (pro.dbg & 1) acc[n] = d2fix(y);
-  else atomicAdd((unsigned long long*)(acc + n), (unsigned long long)d2fix(y));
+  if (pro.dbg & 1) acc[n] = d2fix(y, pro.act);
+  else atomicAdd((unsigned long long*)(acc + n), (unsigned long long)d2fix(y, pro.act));
   QSTAMP(5);
 #undef QSTAMP
 }
@@ -947,7 +1001,7 @@ __global__ __launch_bounds__(768) void k_gemv_q4g_slim(const uint4* __restrict__
     for (int j = 0; j < NJ; j++) {
       const float t[8] = {ha[j].x, ha[j].y, ha[j].z, ha[j].w, hb[j].x, hb[j].y, hb[j].z, hb[j].w};
 #pragma unroll
-      for (int e = 0; e < 8; e++) v[j][e] = hasprev ? round_t<ACT>(t[e] + round_t<ACT>(FIX ? fix2f((long long)pv[j][e]) : (float)pv[j][e])) : t[e];
+      for (int e = 0; e < 8; e++) v[j][e] = hasprev ? round_t<ACT>(t[e] + round_t<ACT>(FIX ? fix2f((long long)pv[j][e], ACT) : (float)pv[j][e])) : t[e];
 #pragma unroll
       for (int e = 0; e < 8; e += 2) ssd += (double)(v[j][e] * v[j][e]) + (double)(v[j][e + 1] * v[j][e + 1]);
       if (blockIdx.x == 0 && pro.h_out) {
@@ -980,13 +1034,14 @@ __global__ __launch_bounds__(768) void k_gemv_q4g_slim(const uint4* __restrict__
       xq_split8(x, am, w, sp, cs);
 #pragma unroll
       for (int p = 0; p < XQ_NP; p++) sp[p] = grp_reduce<16, OpAdd>(sp[p]);
+      const int4 g2w = xq_gpar_hi<16>(w, sp);
       if (mine) {
         unsigned* plw = (unsigned*)xpl + ((so >> 2) * XQ_NP) * 4 + (so & 3);
 #pragma unroll
         for (int p = 0; p < XQ_NP; p++) plw[p * 4] = w[p];
         if ((so & 15) == 0) {
           gpar[2 * (so >> 4)] = make_int4(__float_as_int(cs), sp[0], sp[1], sp[2]);
-          gpar[2 * (so >> 4) + 1] = make_int4(sp[3], sp[4], sp[5], 0);
+          gpar[2 * (so >> 4) + 1] = g2w;
         }
       }
       __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -1017,15 +1072,16 @@ __global__ __launch_bounds__(768) void k_gemv_q4g_slim(const uint4* __restrict__
     double y = 0.0;
 #pragma unroll
     for (int b = 0; b < 2; b++) {
-      int D[XQ_NP] = {0, 0, 0, 0, 0, 0};
+      int D[XQ_NP] = {0, 0, 0, 0, 0, 0, 0, 0};
+      const bool low = xq_low(gpar, 2 * b);
 #pragma unroll
-      for (int c = 0; c < 4; c++) q4_chunk(Q[b * 4 + c], xpl + (b * 4 + c) * XQ_NP, D);
+      for (int c = 0; c < 4; c++) q4_chunk(Q[b * 4 + c], xpl + (b * 4 + c) * XQ_NP, D, low);
       y += q4_term(D, gpar[2 * b], gpar[2 * b + 1], sq[b], zq[b]);
       if (b == 0) SSTAMP(5);
     }
     const int n = tq * 64 + lane;
     if (bias != nullptr && ksl == 0) y += (double)bias[n];
-    atomicAdd((unsigned long long*)(acc + n), (unsigned long long)d2fix(y));
+    atomicAdd((unsigned long long*)(acc + n), (unsigned long long)d2fix(y, ACT));
   }
   SSTAMP(6);
   if (DIAG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -1078,7 +1134,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_q4g_cols(const uint4* __restri
     float v[8] = {ha.x, ha.y, ha.z, ha.w, hb.x, hb.y, hb.z, hb.w};
     if (hasprev) {
 #pragma unroll
-      for (int e = 0; e < 8; e++) v[e] = round_t<ACT>(v[e] + round_t<ACT>(FIX ? fix2f((long long)pv[e]) : (float)pv[e]));
+      for (int e = 0; e < 8; e++) v[e] = round_t<ACT>(v[e] + round_t<ACT>(FIX ? fix2f((long long)pv[e], ACT) : (float)pv[e]));
     }
     if (blockIdx.x == 0 && pro.h_out) { *(float4*)(pro.h_out + i0) = make_float4(v[0], v[1], v[2], v[3]); *(float4*)(pro.h_out + i0 + 4) = make_float4(v[4], v[5], v[6], v[7]); }
     double ssd = 0.0;
@@ -1100,13 +1156,14 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_q4g_cols(const uint4* __restri
     xq_split8(x, am, w, sp, cs);
 #pragma unroll
     for (int p = 0; p < XQ_NP; p++) sp[p] = grp_reduce<16, OpAdd>(sp[p]);
+    const int4 g2w = xq_gpar_hi<16>(w, sp);
     const int oct = tid - NP * 64;
     unsigned* plw = (unsigned*)xpl + ((oct >> 2) * XQ_NP) * 4 + (oct & 3);
 #pragma unroll
     for (int p = 0; p < XQ_NP; p++) plw[p * 4] = w[p];
     if ((lane & 15) == 0) {
       gpar[2 * (oct >> 4)] = make_int4(__float_as_int(cs), sp[0], sp[1], sp[2]);
-      gpar[2 * (oct >> 4) + 1] = make_int4(sp[3], sp[4], sp[5], 0);
+      gpar[2 * (oct >> 4) + 1] = g2w;
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     if (lane == 0) atomicAdd((unsigned*)&cnt[1], 1u);
@@ -1126,9 +1183,10 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_q4g_cols(const uint4* __restri
   double y = 0.0;
 #pragma unroll
   for (int b = 0; b < 2; b++) {
-    int D[XQ_NP] = {0, 0, 0, 0, 0, 0};
+    int D[XQ_NP] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool low = xq_low(gpar, 2 * (wave * 2 + b));
 #pragma unroll
-    for (int c = 0; c < 4; c++) q4_chunk(Q[b * 4 + c], xpl + ((wave * 2 + b) * 4 + c) * XQ_NP, D);
+    for (int c = 0; c < 4; c++) q4_chunk(Q[b * 4 + c], xpl + ((wave * 2 + b) * 4 + c) * XQ_NP, D, low);
     y += q4_term(D, gpar[2 * (wave * 2 + b)], gpar[2 * (wave * 2 + b) + 1], sq[b], zq[b]);
   }
   part[wave * 64 + lane] = y;
@@ -1143,7 +1201,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_q4g_cols(const uint4* __restri
     out[n] = round_t<ACT>(f);
   }
 }
-static size_t q4g_cols_smem(int H) { return (size_t)H * 3 + (size_t)(H >> 7) * 32 + 16 * 64 * 8 + 16 * 8 + 64; }
+static size_t q4g_cols_smem(int H) { return (size_t)(H >> 5) * XQ_NP * 16 + (size_t)(H >> 7) * 32 + 16 * 64 * 8 + 16 * 8 + 64; }
 bool bzk_gemv_cols_ok(const LinearDev& L, const Pro& pro, int act) {
   static const bool off = getenv("BZ_COLS_QKV") == nullptr;   // opt-in: measured slower than the slim kernel (7.8 vs 6.8 us: a CU sustains ~27 GB/s, 96 CUs x 128 KiB take longer than 192 x 64 KiB)
   return !off && act == BZ_F16 && L.kind == LK_Q4G && !L.perm && pro.mode == PRO_NORM && pro.perm == nullptr && L.K == pro.H && (L.K == 2048 || L.K == 4096) && L.N % 64 == 0 &&
@@ -1217,21 +1275,21 @@ __global__ __launch_bounds__(512) void k_gemm_q4g_rows(const uint4* __restrict__
       double y = bv;
       q4g_consume(Q[0], r * 2, xpl, gpar, sq[0], zq[0], y);
       q4g_consume(Q[1], r * 2 + 1, xpl, gpar, sq[1], zq[1], y);
-      atomicAdd((unsigned long long*)(acc + (size_t)r * N + n), (unsigned long long)d2fix(y));
+      atomicAdd((unsigned long long*)(acc + (size_t)r * N + n), (unsigned long long)d2fix(y, XDT));
     }
   }
 }
 
 // out[i] = R(fix2f(acc[i])), acc[i] = 0  (the accumulator is ready for the next GEMM)
 __global__ void k_fix_rows_finish(long long* acc, size_t n, int act, float* out) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) { out[i] = round_act(fix2f(acc[i]), act); acc[i] = 0; }
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) { out[i] = round_act(fix2f(acc[i], act), act); acc[i] = 0; }
 }
 
 bool bzk_gemm_q4g_rows_ok(const LinearDev& L) { return L.kind == LK_Q4G && !L.perm && L.K % 256 == 0 && L.N % 64 == 0; }
 
 // Y[rows][N] (f32, rounded to act) = X16[rows][K] . W^T for any number of rows, 8 at a time; `acc` is scratch of 8 * N fixed-point values (zero on entry and on exit)
 int bzk_gemm_q4g_rows(hipStream_t s, const LinearDev& L, int xdt, const void* x16, int rows, int act, long long* acc, float* y) {
-  if (!bzk_gemm_q4g_rows_ok(L) || (xdt != BZ_F16 && xdt != BZ_BF16)) BZ_FAIL(BZ_E_UNSUPPORTED, "gemm_q4g_rows: unsupported weight / activation format");
+  if (!bzk_gemm_q4g_rows_ok(L) || (xdt != BZ_F16 && xdt != BZ_BF16) || xdt != act) BZ_FAIL(BZ_E_UNSUPPORTED, "gemm_q4g_rows: unsupported weight / activation format");
   const int nks = L.K / 256, ntg = (L.N / 64 + 7) / 8;
   for (int r0 = 0; r0 < rows; r0 += 8) {
     const int nr = std::min(8, rows - r0);
@@ -1528,7 +1586,7 @@ __global__ __launch_bounds__(256) void k_gemv_gq(const uint4* __restrict__ Wq, c
   }
   const int n = nt * 64 + lane;
   if (bias != nullptr && ks == 0) y += bias[n];
-  atomicAdd((unsigned long long*)(acc + n), (unsigned long long)f2fix(y));
+  atomicAdd((unsigned long long*)(acc + n), (unsigned long long)f2fix(y, pro.act));
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1714,7 +1772,7 @@ __global__ __launch_bounds__(512) void k_gemv_gq_slim(const uint4* __restrict__ 
   }
   const int n = tq * 64 + lane;
   if (bias != nullptr && ksl == 0) y += bias[n];
-  atomicAdd((unsigned long long*)(acc + n), (unsigned long long)f2fix(y));
+  atomicAdd((unsigned long long*)(acc + n), (unsigned long long)f2fix(y, pro.act));
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1925,7 +1983,7 @@ __global__ __launch_bounds__(NW * 64) void k_mlp_gq(const uint4* __restrict__ Wg
     }
     const int n = (wave * TPW + q) * 64 + lane;
     if (bd != nullptr && sl == 0) y += bd[n];
-    atomicAdd((unsigned long long*)(acc + n), (unsigned long long)f2fix(y));
+    atomicAdd((unsigned long long*)(acc + n), (unsigned long long)f2fix(y, pro.act));
   }
 }
 static size_t mlp_gq_smem(int H) { return (size_t)H * 3 + (size_t)(H >> 5) * 32 + 16 * 128 * 4 + 64 * 4 + 48 * 4 + 64 + 16 * 4 + 16 + 64; }
@@ -1984,7 +2042,7 @@ static size_t gq_smem(int SBW) { size_t KR = (size_t)SBW * 256; return KR * 4 + 
 
 static size_t q4g_smem(int GW) {
   size_t KR = (size_t)GW * 128;
-  return KR * 4 + KR / 4 * 4 * 3 + (size_t)GW * 32 + (size_t)4 * GW * 64 * 2 + (size_t)4 * GW * 64 + 16;
+  return KR * 4 + (KR >> 5) * XQ_NP * 16 + (size_t)GW * 32 + (size_t)4 * GW * 64 * 2 + (size_t)4 * GW * 64 + 16;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -2115,7 +2173,7 @@ __device__ __forceinline__ void rows_body(const void* __restrict__ W, const floa
         if (cr + rr < rend) {
           if (SPLIT) {
             if (bias && ks == 0) v += bias[cr + rr];
-            if (lane == 0) atomicAdd((unsigned long long*)(accbuf + cr + rr), (unsigned long long)f2fix(v));
+            if (lane == 0) atomicAdd((unsigned long long*)(accbuf + cr + rr), (unsigned long long)f2fix(v, pro.act));
           } else {
             if (bias) v += bias[cr + rr];
             v = round_act(v, act);
@@ -2233,7 +2291,7 @@ __global__ __launch_bounds__(ROUTE ? 832 : 768) void k_gemv_rows2(const void* __
   if (ROUTE && wave == 12) {
     // ---- the routing wave (13th): logits -> softmax + top-k -> expert ids for the tile waves' second range; nobody waits for it before that
     __builtin_amdgcn_s_setprio(3);
-    for (int j = lane; j < route.E; j += 64) lgs[j] = fix2f(route.lg[j]);
+    for (int j = lane; j < route.E; j += 64) lgs[j] = fix2f(route.lg[j], pro.act);
     __syncthreads();                               // (the rendezvous barrier: every wave passes it once)
     __builtin_amdgcn_s_waitcnt(0xc07f);
     moe_softmax_topk(lgs, route.E, route.top_k, route.n_shared, route.routed_scale, route.norm_topk, ssel, swgt, lane);
@@ -2415,7 +2473,7 @@ __global__ __launch_bounds__(ROUTE ? 832 : 768) void k_gemv_rows2(const void* __
           const int row = 4 * (u - (second ? ubr : ubr - NRG)) + jrow;
           if ((lane & 15) == 0 && row < N) {
             if (bias && (second ? kB : kA) == 0) v += bias[row];
-            atomicAdd((unsigned long long*)((second ? apB : apA) + row), (unsigned long long)f2fix(v));
+            atomicAdd((unsigned long long*)((second ? apB : apA) + row), (unsigned long long)f2fix(v, pro.act));
           }
         }
       }
@@ -2572,7 +2630,7 @@ __global__ __launch_bounds__(768) void k_mlp_dense(const void* __restrict__ Wgu,
       const int n = n0 + t * 16;
       if ((lane & 3) == 0) {
         if (bd != nullptr && slab == 0) d += bd[n];
-        atomicAdd((unsigned long long*)(acc + n), (unsigned long long)f2fix(d));
+        atomicAdd((unsigned long long*)(acc + n), (unsigned long long)f2fix(d, pro.act));
       }
     }
   }
@@ -3067,7 +3125,7 @@ int bzk_rope_row(hipStream_t s, const int* pos, const float* cos_t, const float*
 }
 
 __global__ void k_fix_to_f32(const long long* acc, int n, int act, float* out) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = round_act(fix2f(acc[i]), act);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = round_act(fix2f(acc[i], act), act);
 }
 int bzk_fix_to_f32(hipStream_t s, const long long* acc, int n, int act, float* out) {
   hipLaunchKernelGGL(k_fix_to_f32, dim3((n + 255) / 256), dim3(256), 0, s, acc, n, act, out);
@@ -3328,7 +3386,7 @@ __device__ __forceinline__ void vsrc_issue(const void* p, int fix, int i, unsign
   lo = u[e]; hi = u[e + fix];
 }
 __device__ __forceinline__ float vsrc_finish(int fix, unsigned lo, unsigned hi, int act) {
-  const float f = round_act(fix2f((long long)(((unsigned long long)hi << 32) | lo)), act);
+  const float f = round_act(fix2f((long long)(((unsigned long long)hi << 32) | lo), act), act);
   return fix ? f : __uint_as_float(lo);
 }
 template <int PAGED>
@@ -3599,7 +3657,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn2(AttnArgs a, const uint4* __re
       const int n = nd0 + t * RPL + rsub;
       if (piece == 0) {
         if (bias != nullptr && hq == 0) d += bias[n];
-        atomicAdd((unsigned long long*)(acc + n), (unsigned long long)f2fix(d));
+        atomicAdd((unsigned long long*)(acc + n), (unsigned long long)f2fix(d, a.act));
       }
     }
     return;
@@ -3625,7 +3683,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn2(AttnArgs a, const uint4* __re
     q4g_consume(Wb[t], 0, xpl, gpar, sc[t], zp[t], y);
     const int n = (t0 + t) * 64 + lane;
     if (bias != nullptr && hq == 0) y += (double)bias[n];
-    if (wave < OW) atomicAdd((unsigned long long*)(acc + n), (unsigned long long)d2fix(y));
+    if (wave < OW) atomicAdd((unsigned long long*)(acc + n), (unsigned long long)d2fix(y, a.act));
   }
   STAMP(8);
 #undef STAMP
@@ -3819,11 +3877,11 @@ __global__ __launch_bounds__(512) void k_attn2f(AttnArgs a, const uint4* __restr
     }
     const int n = t0 * 64 + lane;
     if (bias != nullptr && hq == 0) y += bias[n];
-    atomicAdd((unsigned long long*)(acc + n), (unsigned long long)f2fix(y));
+    atomicAdd((unsigned long long*)(acc + n), (unsigned long long)f2fix(y, a.act));
   }
 }
 
-static size_t attn2_smem(int nw) { return (size_t)(64 * 3 + 2 * nw + 128 + 96 + 8) * 4 + (size_t)(nw * 128 + nw) * 8; }
+static size_t attn2_smem(int nw) { return (size_t)(64 * 3 + 2 * nw + 128 + 4 * XQ_NP * 4 + 8) * 4 + (size_t)(nw * 128 + nw) * 8; }
 
 // picks the column-slice count so that nq * CS ~ 256 workgroups, and the wave count (8 waves halve the per-wave attention chain);
 // returns 0 when the fused form does not apply
@@ -4193,7 +4251,7 @@ __global__ __launch_bounds__(512) void k_attn_merge_oproj(AttnArgs a, const floa
     q4g_consume(Wb[t], 0, xpl, gpar, sc[t], zp[t], y);
     const int n = (t0 + t) * 64 + lane;
     if (bias != nullptr && hq == 0) y += (double)bias[n];
-    atomicAdd((unsigned long long*)(acc + n), (unsigned long long)d2fix(y));
+    atomicAdd((unsigned long long*)(acc + n), (unsigned long long)d2fix(y, a.act));
   }
 }
 
@@ -4539,6 +4597,12 @@ __global__ __launch_bounds__(64 * PARTS) void k_ssm_step(SsmArgs a) {
   const float dt = round_act(softplus_f(round_act(dtraw + dtb, a.act)), a.act);
   const float dA = bz_expf(dt * -bz_expf(alog));
   __syncthreads();
+  if (a.conv_out) {      // op-level entry points: the conv output as the forward path computed it (B / C by the first head of their group)
+    if (hd % hpg == 0)
+      for (int t = tid; t < NS; t += NTH) { a.conv_out[a.d_inner + g * NS + t] = sB[t]; a.conv_out[a.d_inner + a.n_groups * NS + g * NS + t] = sC[t]; }
+    for (int t = tid; t < HD; t += NTH) a.conv_out[hd * HD + t] = sX[t];
+    if (a.conv_only) return;
+  }
   float vsq = 0.f;
   for (int p0 = 0; p0 < HD; p0 += 64) {
     const int p = p0 + tid / PARTS;
@@ -4597,6 +4661,11 @@ __global__ __launch_bounds__(64 * PARTS) void k_ssm_step(SsmArgs a) {
       a.vss[hd] = t;
     }
   }
+}
+int bzk_conv_shift(hipStream_t s, const ConvShift& c, int act) {
+  if (c.n > 0) hipLaunchKernelGGL(k_conv_shift, dim3((c.n + 255) / 256), dim3(256), 0, s, c, act);
+  BZ_HIP(hipGetLastError());
+  return BZ_OK;
 }
 int bzk_ssm_step(hipStream_t s, const SsmArgs& a) {
   if (a.head_dim > 256 || a.conv_kernel < 2) BZ_FAIL(BZ_E_UNSUPPORTED, "ssm_step: head_dim %d / conv kernel %d unsupported", a.head_dim, a.conv_kernel);
@@ -5180,12 +5249,12 @@ __global__ void k_moe_combine(long long* acc, const float* wsel, int top_k, int 
   if (i >= H) return;
   float r = 0.f;
   for (int k = 0; k < top_k; k++) {
-    r += wsel[k] * round_act(fix2f(acc[(size_t)k * H + i]), act);
+    r += wsel[k] * round_act(fix2f(acc[(size_t)k * H + i], act), act);
     acc[(size_t)k * H + i] = 0;
   }
   r = round_act(r, act);
   if (has_shared) {
-    r = round_act(r + round_act(fix2f(acc[(size_t)top_k * H + i]), act), act);
+    r = round_act(r + round_act(fix2f(acc[(size_t)top_k * H + i], act), act), act);
     acc[(size_t)top_k * H + i] = 0;
   }
   out[i] = r;
@@ -5257,11 +5326,11 @@ __global__ __launch_bounds__(256) void k_moe_route_rows(const unsigned short* __
           const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
           const float4 xa = k < H ? *(const float4*)(xs + k) : z4, xb = k < H ? *(const float4*)(xs + k + 4) : z4;
           const float d = piece_dot<WDT>(w[j], xa, xb);
-          accf += f2fix(grp_reduce<16, OpAdd>(xrow16<OpAdd>(xrow32<OpAdd>(d))));
+          accf += f2fix(grp_reduce<16, OpAdd>(xrow16<OpAdd>(xrow32<OpAdd>(d))), DT);
         }
       }
     }
-    if (lane == 0) lg[e] = fix2f(accf);
+    if (lane == 0) lg[e] = fix2f(accf, DT);
   }
   __syncthreads();
   if (wave == 0) moe_softmax_topk(lg, E, top_k, 0, routed_scale, norm_topk, sel + (size_t)t * top_k, wsel + (size_t)t * top_k, lane);

@@ -490,6 +490,40 @@ class LoadedModel:
     def linear_shape(self, name):
         return self._shapes[name]
 
+    def conv1d_step(self, layer, state, zx):
+        """ConvOps: the conv1d step (+ SiLU) of Mamba2 layer `layer` on the in_proj row zx; returns xbc [conv_dim]; the layer's conv window advances"""
+        c = self.mamba_config()
+        zt = self.dev.tensor(np.ascontiguousarray(zx, dtype=np.float32))
+        out = self.dev.zeros((c["d_inner"] + 2 * c["n_groups"] * c["d_state"],), L.F32)
+        L.check(L.lib().bz_conv1d_step(self.h, layer, state.h, zt.h, out.h))
+        return out.to_numpy()
+
+    def ssm_step(self, layer, state, zx):
+        """the mixer's fused step (conv1d + SSM recurrence + gate) on the in_proj row zx; returns the gated y [d_inner]; conv window and SSM state advance"""
+        c = self.mamba_config()
+        zt = self.dev.tensor(np.ascontiguousarray(zx, dtype=np.float32))
+        out = self.dev.zeros((c["d_inner"],), L.F32)
+        L.check(L.lib().bz_ssm_step(self.h, layer, state.h, zt.h, out.h))
+        return out.to_numpy()
+
+    def moe_route(self, layer, hidden):
+        """router of DeepSeek MoE layer `layer` on the residual-stream row (norm inside): (sel int32 [top_k + n_shared], w float32 [...], xn float32 [H])"""
+        n = self.c.moe_top_k + self.c.moe_n_shared
+        ht = self.dev.tensor(np.ascontiguousarray(hidden, dtype=np.float32))
+        sel, w, xn = self.dev.zeros((n,), L.I32), self.dev.zeros((n,), L.F32), self.dev.zeros((self.c.hidden,), L.F32)
+        L.check(L.lib().bz_moe_route(self.h, layer, ht.h, sel.h, w.h, xn.h))
+        return sel.to_numpy(), w.to_numpy(), xn.to_numpy()
+
+    def moe_grouped_gemv(self, layer, which, sel, x):
+        """grouped expert GEMV: which 0 -> gate|up of experts sel[] on the shared row x [H]; which 1 -> down (SiLU*up prologue) on x [n_slots, 2 moe_inter]"""
+        sel = np.ascontiguousarray(sel, dtype=np.int32)
+        st = self.dev.tensor(sel, L.I32)
+        xt = self.dev.tensor(np.ascontiguousarray(x, dtype=np.float32))
+        N = 2 * self.c.moe_inter if which == 0 else self.c.hidden
+        y = self.dev.zeros((len(sel), N), L.F32)
+        L.check(L.lib().bz_moe_grouped_gemv(self.h, layer, which, st.h, len(sel), xt.h, y.h))
+        return y.to_numpy()
+
     def dequant(self, name):
         N, K = self._shapes[name]
         out = np.empty((N, K), dtype=np.float32)
@@ -596,6 +630,12 @@ class LayeredSsmState:
 
     def reset(self):
         L.check(L.lib().bz_ssm_state_reset(self.h))
+
+    def read(self, layer, which, n):
+        """one layer of the state as float32: which 0 = SSM state (n_heads * head_dim * d_state values), 1 = conv window (conv_dim * (k-1))"""
+        out = np.empty(n, dtype=np.float32)
+        L.check(L.lib().bz_ssm_state_read(self.h, layer, which, _ptr(out), n))
+        return out
 
 
 class LayeredPagedKvCache:

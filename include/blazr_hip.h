@@ -339,6 +339,25 @@ int bz_paged_attn_decode(bz_model* m, const bz_tensor* q, bz_paged_kv* kv, int l
                          bz_tensor* out);
 /* kv_insert kernel (cuda_graphs.rs:5): write k,v F32 [n_kv_heads, head_dim] at `position` (contiguous) */
 int bz_kv_insert(bz_model* m, bz_kv* kv, int layer, int position, const bz_tensor* k, const bz_tensor* v);
+/* ConvOps (engine/executor.rs:71) -- Mamba2 layer `layer`: depthwise causal conv1d STEP (+ bias, SiLU) over the raw in_proj row zx = [z | x B C | dt]
+ * (F32 device, 2 d_inner + 2 n_groups d_state + n_heads values): xbc_out [d_inner + 2 n_groups d_state] F32; the layer's conv window inside `state`
+ * (LayeredSsmState, docs/architecture.md:52-54: conv [conv_dim, k-1]) moves on by this token; the SSM state is not touched. */
+int bz_conv1d_step(bz_model* m, int layer, bz_ssm_state* state, const bz_tensor* zx, bz_tensor* xbc_out);
+/* The Mamba2 mixer's step as the decode path runs it (one launch: conv1d step + SiLU, h = exp(dt A) h + dt B x, y = C h + D x, gate y * silu(z)):
+ * y_out [d_inner] F32 (before the gated RMSNorm); `state` (conv window + SSM state [n_heads, head_dim, d_state]) advances by one token
+ * (forward_with_ssm_state, engine/executor_generate.rs:137,148). */
+int bz_ssm_step(bz_model* m, int layer, bz_ssm_state* state, const bz_tensor* zx, bz_tensor* y_out);
+/* One layer of a LayeredSsmState copied to the host as F32 (which = 0: SSM state [n_heads * head_dim * d_state], 1: conv window [conv_dim * (k-1)]);
+ * n = the expected element count.  Test / debugging aid for the two entry points above (the state layouts are docs/architecture.md:52-54). */
+int bz_ssm_state_read(const bz_ssm_state* state, int layer, int which, float* host, size_t n);
+/* MoE router of DeepSeek-V2 layer `layer` (docs/architecture.md:108-119: softmax -> greedy top-k -> weights): hidden = the residual stream row [H] F32,
+ * the layer's post-attention RMSNorm runs inside (as in the decode step).  sel_out I32 / w_out F32 [top_k + n_shared]: the routed experts in selection
+ * order (ties -> lowest index), then the shared experts' slots (index n_experts + j, weight 1); xn_out (optional) F32 [H] the normalised row. */
+int bz_moe_route(bz_model* m, int layer, const bz_tensor* hidden, bz_tensor* sel_out, bz_tensor* w_out, bz_tensor* xn_out);
+/* Grouped expert GEMV over the stacked expert weights (engine/executor_cache.rs:218-219,344-348): slot s uses expert sel[s] (I32 device, n_slots <= 128).
+ * which = 0: gate|up projections, x F32 [H] shared by all slots -> y F32 [n_slots][2 moe_inter];
+ * which = 1: down projection with the SiLU(gate) * up prologue, x F32 [n_slots][2 moe_inter] -> y F32 [n_slots][H]. */
+int bz_moe_grouped_gemv(bz_model* m, int layer, int which, const bz_tensor* sel, int n_slots, const bz_tensor* x, bz_tensor* y);
 /* The exponential every kernel of this library uses (SiLU, softmax weights, sampling): ONE specified sequence of IEEE operations (range reduction by ln2
  * in two fma steps, degree-5 polynomial, exact 2^n scaling; < 1 ulp), evaluated here on the HOST for n values -- the same function body the device code
  * compiles, so a CPU-only test can pin it bit for bit against an independent restatement.  boostr's own exp (ActivationOps / softmax behind

@@ -200,6 +200,9 @@ orc_ssm_state* orc_ssm_state_new(const orc_mamba2_cfg* cfg);
 void orc_ssm_state_free(orc_ssm_state* s);
 /* executor_generate.rs:137,148 forward_with_ssm_state */
 int orc_mamba2_forward(const orc_mamba2* m, const int64_t* tokens, int S, orc_ssm_state* st, float* logits, int all_logits);
+/* the mixer's two state-carrying ops on their own (zx = rounded in_proj row [z | x B C | dt]); conv_state / ssm = ONE layer's state */
+void orc_mamba2_conv1d_step(const orc_mamba2_cfg* c, const orc_mamba2_layer* L, const float* zx, float* conv_state, float* xbc);
+void orc_mamba2_ssm_step(const orc_mamba2_cfg* c, const orc_mamba2_layer* L, const float* zx, const float* xbc, float* ssm, float* y);
 int orc_mamba2_generate(const orc_mamba2* m, const int64_t* prompt, int n_prompt, int max_tokens, int64_t eos_id, int64_t* out_tokens,
                         float* logits_trace);
 

@@ -42,6 +42,49 @@ orc_ssm_state* orc_ssm_state_new(const orc_mamba2_cfg* c) {
 }
 void orc_ssm_state_free(orc_ssm_state* s) { if (!s) return; free(s->ssm); free(s->conv); free(s); }
 
+/* The two halves of the mixer between in_proj and the gated norm, as separate entry points (op-level parity tests call them; the forward below is built
+   from them).  zx = the rounded in_proj row [z (d_inner) | x B C (conv_dim) | dt (n_heads)].
+   conv1d step: depthwise causal convolution over the window [state (k-1 values) | this token's value], + bias, R, SiLU, R; the window moves on. */
+void orc_mamba2_conv1d_step(const orc_mamba2_cfg* c, const orc_mamba2_layer* L, const float* zx, float* conv_state, float* xbc) {
+  const int DI = c->d_inner, NS = c->d_state, G = c->n_groups, KC = c->conv_kernel, act = c->act_dtype;
+  const int conv_dim = DI + 2 * G * NS;
+  const float* xraw = zx + DI;
+  float* cs = conv_state;
+  for (int ch = 0; ch < conv_dim; ch++) {
+    float a = 0.0f;
+    for (int j = 0; j < KC - 1; j++) a += cs[(size_t)ch * (KC - 1) + j] * L->conv_w[(size_t)ch * KC + j];
+    a += xraw[ch] * L->conv_w[(size_t)ch * KC + KC - 1];
+    a = orc_round(a + L->conv_b[ch], act);
+    xbc[ch] = orc_round(orc_silu(a), act);
+    for (int j = 0; j + 1 < KC - 1; j++) cs[(size_t)ch * (KC - 1) + j] = cs[(size_t)ch * (KC - 1) + j + 1];
+    cs[(size_t)ch * (KC - 1) + KC - 2] = xraw[ch];
+  }
+}
+/* SSM step (HF Mamba2 single-token recurrence): h = R(h exp(dt A) + (dt x) B), y = R(C.h + D x), then the gate y = R(y R(silu z)); ssm = this layer's
+   [n_heads][head_dim][d_state] */
+void orc_mamba2_ssm_step(const orc_mamba2_cfg* c, const orc_mamba2_layer* L, const float* zx, const float* xbc, float* ssm, float* y) {
+  const int DI = c->d_inner, NH = c->n_heads, HD = c->head_dim, NS = c->d_state, G = c->n_groups, act = c->act_dtype;
+  const int conv_dim = DI + 2 * G * NS;
+  const float* z = zx; const float* dtr = zx + DI + conv_dim;
+  const float* x = xbc; const float* Bm = xbc + DI; const float* Cm = xbc + DI + G * NS;
+  for (int hd = 0; hd < NH; hd++) {
+    const int g = hd / (NH / G);
+    const float dt = orc_round(softplus_f(orc_round(dtr[hd] + L->dt_bias[hd], act)), act);
+    const float dA = orc_expf(dt * -orc_expf(L->A_log[hd]));
+    for (int p = 0; p < HD; p++) {
+      const float xv = x[hd * HD + p];
+      float* hs = ssm + ((size_t)hd * HD + p) * NS;
+      float acc = 0.0f;
+      for (int n = 0; n < NS; n++) {
+        hs[n] = orc_round(hs[n] * dA + (dt * xv) * Bm[g * NS + n], act);
+        acc += hs[n] * Cm[g * NS + n];
+      }
+      y[hd * HD + p] = orc_round(acc + L->D[hd] * xv, act);
+    }
+  }
+  for (int i = 0; i < DI; i++) y[i] = orc_round(y[i] * orc_round(orc_silu(z[i]), act), act);
+}
+
 int orc_mamba2_forward(const orc_mamba2* m, const int64_t* tokens, int S, orc_ssm_state* st, float* logits, int all_logits) {
   const orc_mamba2_cfg* c = &m->cfg;
   const int D = c->hidden, DI = c->d_inner, NH = c->n_heads, HD = c->head_dim, NS = c->d_state, G = c->n_groups, KC = c->conv_kernel;
@@ -60,36 +103,11 @@ int orc_mamba2_forward(const orc_mamba2* m, const int64_t* tokens, int S, orc_ss
       const orc_mamba2_layer* L = &m->layers[l];
       orc_rms_norm(h, L->norm, D, c->rms_eps, act, xn);
       orc_linear_forward(&L->in_proj, xn, 1, zx); orc_round_vec(zx, (size_t)d_in, act);
-      const float* z = zx; const float* xraw = zx + DI; const float* dtr = zx + DI + conv_dim;
       float* cs = st->conv + (size_t)l * conv_dim * (KC - 1);
-      for (int ch = 0; ch < conv_dim; ch++) {
-        float a = 0.0f;
-        for (int j = 0; j < KC - 1; j++) a += cs[(size_t)ch * (KC - 1) + j] * L->conv_w[(size_t)ch * KC + j];
-        a += xraw[ch] * L->conv_w[(size_t)ch * KC + KC - 1];
-        a = orc_round(a + L->conv_b[ch], act);
-        xbc[ch] = orc_round(orc_silu(a), act);
-        for (int j = 0; j + 1 < KC - 1; j++) cs[(size_t)ch * (KC - 1) + j] = cs[(size_t)ch * (KC - 1) + j + 1];
-        cs[(size_t)ch * (KC - 1) + KC - 2] = xraw[ch];
-      }
-      const float* x = xbc; const float* Bm = xbc + DI; const float* Cm = xbc + DI + G * NS;
       float* ss = st->ssm + (size_t)l * NH * HD * NS;
-      for (int hd = 0; hd < NH; hd++) {
-        const int g = hd / (NH / G);
-        const float dt = orc_round(softplus_f(orc_round(dtr[hd] + L->dt_bias[hd], act)), act);
-        const float dA = orc_expf(dt * -orc_expf(L->A_log[hd]));
-        for (int p = 0; p < HD; p++) {
-          const float xv = x[hd * HD + p];
-          float* hs = ss + ((size_t)hd * HD + p) * NS;
-          float acc = 0.0f;
-          for (int n = 0; n < NS; n++) {
-            hs[n] = orc_round(hs[n] * dA + (dt * xv) * Bm[g * NS + n], act);
-            acc += hs[n] * Cm[g * NS + n];
-          }
-          y[hd * HD + p] = orc_round(acc + L->D[hd] * xv, act);
-        }
-      }
+      orc_mamba2_conv1d_step(c, L, zx, cs, xbc);
+      orc_mamba2_ssm_step(c, L, zx, xbc, ss, y);
       const int gsz = DI / G;
-      for (int i = 0; i < DI; i++) y[i] = orc_round(y[i] * orc_round(orc_silu(z[i]), act), act);
       for (int g = 0; g < G; g++) {
         double ssd = 0.0;
         for (int i = 0; i < gsz; i++) ssd += (double)(y[g * gsz + i] * y[g * gsz + i]);

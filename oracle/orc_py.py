@@ -179,6 +179,8 @@ def lib():
         L.orc_ssm_state_free.argtypes = [C.POINTER(SsmState)]
         L.orc_mamba2_forward.restype = C.c_int
         L.orc_mamba2_forward.argtypes = [C.POINTER(Mamba2), C.c_void_p, C.c_int, C.POINTER(SsmState), C.c_void_p, C.c_int]
+        L.orc_mamba2_conv1d_step.argtypes = [C.POINTER(Mamba2Cfg), C.POINTER(Mamba2Layer), C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_mamba2_ssm_step.argtypes = [C.POINTER(Mamba2Cfg), C.POINTER(Mamba2Layer), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_mamba2_generate.restype = C.c_int
         L.orc_mamba2_generate.argtypes = [C.POINTER(Mamba2), C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]
         L.orc_dsv2_new.restype = C.POINTER(Dsv2)
@@ -444,6 +446,21 @@ class OrcMamba2:
         out = np.empty((len(t) if all_logits else 1, self.cfg.vocab), dtype=np.float32)
         lib().orc_mamba2_forward(self.h, _p(t), len(t), state, _p(out), int(all_logits))
         return out
+
+    def conv1d_step(self, layer, zx, conv_state):
+        """conv_state: float32 [conv_dim, k-1] of ONE layer, updated in place; returns xbc [conv_dim]"""
+        c = self.cfg
+        xbc = np.empty(c.d_inner + 2 * c.n_groups * c.d_state, dtype=np.float32)
+        lib().orc_mamba2_conv1d_step(C.byref(c), C.byref(self.h.contents.layers[layer]), _p(np.ascontiguousarray(zx, dtype=np.float32)), _p(conv_state), _p(xbc))
+        return xbc
+
+    def ssm_step(self, layer, zx, xbc, ssm):
+        """ssm: float32 [n_heads, head_dim, d_state] of ONE layer, updated in place; returns the gated y [d_inner]"""
+        c = self.cfg
+        y = np.empty(c.d_inner, dtype=np.float32)
+        lib().orc_mamba2_ssm_step(C.byref(c), C.byref(self.h.contents.layers[layer]), _p(np.ascontiguousarray(zx, dtype=np.float32)), _p(np.ascontiguousarray(xbc, dtype=np.float32)),
+                                  _p(ssm), _p(y))
+        return y
 
     def generate(self, prompt, max_tokens, eos_id=-1, trace=False):
         p = np.ascontiguousarray(prompt, dtype=np.int64)
