@@ -180,8 +180,8 @@ __device__ __forceinline__ void quant_x64(const float* a, uint4* pl, int4* gpar)
 }
 
 
-// one 32-k chunk: the lane's 16-byte weight piece against the six main planes (24 V_DOT8_I32_I4, 6 broadcast ds_read_b128), + the two low planes of a flagged group
-__device__ __forceinline__ void q4_chunk(const uint4& w, const uint4* pl8, int (&D)[XQ_NP], bool low) {
+// one 32-k chunk: the lane's 16-byte weight piece against the six main planes (24 V_DOT8_I32_I4, 6 broadcast ds_read_b128)
+__device__ __forceinline__ void q4_chunk(const uint4& w, const uint4* pl8, int (&D)[XQ_NM]) {
   const unsigned W[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
   for (int p = 0; p < XQ_NM; p++) {
@@ -190,18 +190,20 @@ __device__ __forceinline__ void q4_chunk(const uint4& w, const uint4* pl8, int (
 #pragma unroll
     for (int j = 0; j < 4; j++) D[p] = __builtin_amdgcn_sdot8((int)W[j], (int)X[j], D[p], false);
   }
-  if (low) {
+}
+// ... against the two LOW planes: a second, rare pass over a flagged group's chunks (its weights are still in registers)
+__device__ __forceinline__ void q4_chunk_low(const uint4& w, const uint4* pl8, int (&DL)[2]) {
+  const unsigned W[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
-    for (int p = XQ_NM; p < XQ_NP; p++) {
-      const uint4 P = pl8[p];
-      const unsigned X[4] = {P.x, P.y, P.z, P.w};
+  for (int p = 0; p < 2; p++) {
+    const uint4 P = pl8[XQ_NM + p];
+    const unsigned X[4] = {P.x, P.y, P.z, P.w};
 #pragma unroll
-      for (int j = 0; j < 4; j++) D[p] = __builtin_amdgcn_sdot8((int)W[j], (int)X[j], D[p], false);
-    }
+    for (int j = 0; j < 4; j++) DL[p] = __builtin_amdgcn_sdot8((int)W[j], (int)X[j], DL[p], false);
   }
 }
-// the same planes against two weight pieces (gate and up of the fused MLP): the planes are read from LDS once
-__device__ __forceinline__ void q4_chunk2(const uint4& wa, const uint4& wb, const uint4* pl8, int (&Da)[XQ_NP], int (&Db)[XQ_NP], bool low) {
+// the same main planes against two weight pieces (gate and up of the fused MLP): the planes are read from LDS once
+__device__ __forceinline__ void q4_chunk2(const uint4& wa, const uint4& wb, const uint4* pl8, int (&Da)[XQ_NM], int (&Db)[XQ_NM]) {
   const unsigned Wa[4] = {wa.x, wa.y, wa.z, wa.w}, Wb[4] = {wb.x, wb.y, wb.z, wb.w};
 #pragma unroll
   for (int p = 0; p < XQ_NM; p++) {
@@ -213,63 +215,60 @@ __device__ __forceinline__ void q4_chunk2(const uint4& wa, const uint4& wb, cons
       Db[p] = __builtin_amdgcn_sdot8((int)Wb[j], (int)X[j], Db[p], false);
     }
   }
-  if (low) {
-#pragma unroll
-    for (int p = XQ_NM; p < XQ_NP; p++) {
-      const uint4 P = pl8[p];
-      const unsigned X[4] = {P.x, P.y, P.z, P.w};
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        Da[p] = __builtin_amdgcn_sdot8((int)Wa[j], (int)X[j], Da[p], false);
-        Db[p] = __builtin_amdgcn_sdot8((int)Wb[j], (int)X[j], Db[p], false);
-      }
-    }
-  }
 }
-// group epilogue: s * c * [256 * sum_{p<6} 16^p (D_p + (8 - z) S_p) + low part], exact -- |V_p| <= 2^14, the two three-plane halves fit int32, their join
-// (< 2^36), its shift by 8 bits plus the low part (< 2^19) and the product with the f32 factor s c are exact in double.  An unflagged group has
-// D_6 = D_7 = S_6 = S_7 = 0: the low part vanishes without a branch.
-__device__ __forceinline__ double q4_term(const int (&D)[XQ_NP], const int4 g1, const int4 g2, float s, int z) {
+// low part of a flagged group for one column: (D_6 + (8 - z) S_6) + 16 (D_7 + (8 - z) S_7)
+__device__ __forceinline__ int q4_low(const int (&DL)[2], const int4 g2, int z) {
+  const int zz = 8 - z, s6 = (g2.w << 20) >> 20, s7 = (g2.w << 8) >> 20;
+  return (DL[0] + zz * s6) + ((DL[1] + zz * s7) << 4);
+}
+// group epilogue: s * c * [256 * sum_{p<6} 16^p (D_p + (8 - z) S_p) + lw], exact -- |V_p| <= 2^14, the two three-plane halves fit int32, their join
+// (< 2^36), its shift by 8 bits plus the low part lw (< 2^19; 0 for an unflagged group) and the product with the f32 factor s c are exact in double
+__device__ __forceinline__ double q4_term(const int (&D)[XQ_NM], int lw, const int4 g1, const int4 g2, float s, int z) {
   const int zz = 8 - z;
   const int V0 = D[0] + zz * g1.y, V1 = D[1] + zz * g1.z, V2 = D[2] + zz * g1.w, V3 = D[3] + zz * g2.x, V4 = D[4] + zz * g2.y, V5 = D[5] + zz * g2.z;
   const int lo = V0 + (V1 << 4) + (V2 << 8), hi = V3 + (V4 << 4) + (V5 << 8);
-  const int s6 = (g2.w << 20) >> 20, s7 = (g2.w << 8) >> 20;
-  const int lw = (D[6] + zz * s6) + ((D[7] + zz * s7) << 4);
   return (double)(s * __int_as_float(g1.x)) * fma(fma((double)hi, 4096.0, (double)lo), 256.0, (double)lw);
 }
 
+// NCH 32-k chunks of one tile whose planes start at chunk index co; group parameters at gpar[gp], gpar[gp + 1]
+template <int NCH>
+__device__ __forceinline__ void q4g_consume_n(const uint4* w, int co, int gp, const uint4* pl, const int4* gpar, float s, int z, double& y) {
+  int D[XQ_NM] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int c = 0; c < NCH; c++) q4_chunk(w[c], pl + (co + c) * XQ_NP, D);
+  int lw = 0;
+  if (xq_low(gpar, gp)) {
+    int DL[2] = {0, 0};
+#pragma unroll
+    for (int c = 0; c < NCH; c++) q4_chunk_low(w[c], pl + (co + c) * XQ_NP, DL);
+    lw = q4_low(DL, gpar[gp + 1], z);
+  }
+  y += q4_term(D, lw, gpar[gp], gpar[gp + 1], s, z);
+}
 // one 128-k group (four chunks) of one tile
 __device__ __forceinline__ void q4g_consume(const uint4 (&w)[4], int g, const uint4* pl, const int4* gpar, float s, int z, double& y) {
-  int D[XQ_NP] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const bool low = xq_low(gpar, 2 * g);
-#pragma unroll
-  for (int c = 0; c < 4; c++) q4_chunk(w[c], pl + (g * 4 + c) * XQ_NP, D, low);
-  y += q4_term(D, gpar[2 * g], gpar[2 * g + 1], s, z);
+  q4g_consume_n<4>(w, g * 4, 2 * g, pl, gpar, s, z, y);
 }
-// two weight tiles against the SAME activation group (gate and up of the fused MLP)
-__device__ __forceinline__ void q4g_consume2(const uint4 (&wa)[4], const uint4 (&wb)[4], int g, const uint4* pl, const int4* gpar, float sa, int za, float sb, int zb,
+// two weight tiles against the SAME activation group (gate and up of the fused MLP); wa / wb start at the group's first chunk
+__device__ __forceinline__ void q4g_consume2(const uint4* wa, const uint4* wb, int g, const uint4* pl, const int4* gpar, float sa, int za, float sb, int zb,
                                              double& ya, double& yb) {
-  int Da[XQ_NP] = {0, 0, 0, 0, 0, 0, 0, 0}, Db[XQ_NP] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const bool low = xq_low(gpar, 2 * g);
+  int Da[XQ_NM] = {0, 0, 0, 0, 0, 0}, Db[XQ_NM] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
-  for (int c = 0; c < 4; c++) q4_chunk2(wa[c], wb[c], pl + (g * 4 + c) * XQ_NP, Da, Db, low);
+  for (int c = 0; c < 4; c++) q4_chunk2(wa[c], wb[c], pl + (g * 4 + c) * XQ_NP, Da, Db);
   const int4 g1 = gpar[2 * g], g2 = gpar[2 * g + 1];
-  ya += q4_term(Da, g1, g2, sa, za);
-  yb += q4_term(Db, g1, g2, sb, zb);
-}
-// the same arithmetic over NCH 32-k chunks whose planes start at chunk index co; group parameters at gpar[gp], gpar[gp + 1]
-template <int NCH>
-__device__ __forceinline__ void q4g_consume_n(const uint4 (&w)[NCH], int co, int gp, const uint4* pl, const int4* gpar, float s, int z, double& y) {
-  int D[XQ_NP] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const bool low = xq_low(gpar, gp);
+  int lwa = 0, lwb = 0;
+  if (xq_low(gpar, 2 * g)) {
+    int La[2] = {0, 0}, Lb[2] = {0, 0};
 #pragma unroll
-  for (int c = 0; c < NCH; c++) q4_chunk(w[c], pl + (co + c) * XQ_NP, D, low);
-  y += q4_term(D, gpar[gp], gpar[gp + 1], s, z);
+    for (int c = 0; c < 4; c++) { q4_chunk_low(wa[c], pl + (g * 4 + c) * XQ_NP, La); q4_chunk_low(wb[c], pl + (g * 4 + c) * XQ_NP, Lb); }
+    lwa = q4_low(La, g2, za); lwb = q4_low(Lb, g2, zb);
+  }
+  ya += q4_term(Da, lwa, g1, g2, sa, za);
+  yb += q4_term(Db, lwb, g1, g2, sb, zb);
 }
 
 // fixed point from the double a lane accumulated over its groups
 __device__ __forceinline__ long long d2fix(double p, int act) { return __double2ll_rn(p * fix_scale(act)); }
-
 
 template <int ACT> __device__ __forceinline__ float round_t(float x) {
   if (ACT == BZ_F16) return __half2float(__float2half_rn(x));

@@ -463,13 +463,7 @@ __global__ __launch_bounds__(NW * 64) void k_mlp_q4g(const uint4* __restrict__ W
   for (int b = 0; b < 2; b++) {
     if (b == 0) MSTAMP(5);
     if (b == 1) MSTAMP(7);
-    int Da[XQ_NP] = {0, 0, 0, 0, 0, 0, 0, 0}, Db[XQ_NP] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const bool low = xq_low(gpar, 2 * (gbeg + b));
-#pragma unroll
-    for (int c = 0; c < 4; c++) q4_chunk2(Ag[b * 4 + c], Au[b * 4 + c], xpl + ((gbeg + b) * 4 + c) * XQ_NP, Da, Db, low);
-    const int4 g1 = gpar[2 * (gbeg + b)], g2 = gpar[2 * (gbeg + b) + 1];
-    yg += q4_term(Da, g1, g2, sg[b], zg[b]);
-    yu += q4_term(Db, g1, g2, su[b], zu[b]);
+    q4g_consume2(&Ag[b * 4], &Au[b * 4], gbeg + b, xpl, gpar, sg[b], zg[b], su[b], zu[b], yg, yu);
     if (b == 0) MSTAMP(6);
     if (b == 1) MSTAMP(8);
     if (b == 0) {
@@ -797,11 +791,7 @@ __global__ __launch_bounds__(768) void k_gemv_q4g_slim(const uint4* __restrict__
     double y = 0.0;
 #pragma unroll
     for (int b = 0; b < 2; b++) {
-      int D[XQ_NP] = {0, 0, 0, 0, 0, 0, 0, 0};
-      const bool low = xq_low(gpar, 2 * b);
-#pragma unroll
-      for (int c = 0; c < 4; c++) q4_chunk(Q[b * 4 + c], xpl + (b * 4 + c) * XQ_NP, D, low);
-      y += q4_term(D, gpar[2 * b], gpar[2 * b + 1], sq[b], zq[b]);
+      q4g_consume_n<4>(&Q[b * 4], b * 4, 2 * b, xpl, gpar, sq[b], zq[b], y);
       if (b == 0) SSTAMP(5);
     }
     const int n = tq * 64 + lane;
@@ -908,11 +898,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_q4g_cols(const uint4* __restri
   double y = 0.0;
 #pragma unroll
   for (int b = 0; b < 2; b++) {
-    int D[XQ_NP] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const bool low = xq_low(gpar, 2 * (wave * 2 + b));
-#pragma unroll
-    for (int c = 0; c < 4; c++) q4_chunk(Q[b * 4 + c], xpl + ((wave * 2 + b) * 4 + c) * XQ_NP, D, low);
-    y += q4_term(D, gpar[2 * (wave * 2 + b)], gpar[2 * (wave * 2 + b) + 1], sq[b], zq[b]);
+    q4g_consume_n<4>(&Q[b * 4], (wave * 2 + b) * 4, 2 * (wave * 2 + b), xpl, gpar, sq[b], zq[b], y);
   }
   part[wave * 64 + lane] = y;
   __syncthreads();
