@@ -230,41 +230,64 @@ __device__ __forceinline__ double q4_term(const int (&D)[XQ_NM], int lw, const i
   return (double)(s * __int_as_float(g1.x)) * fma(fma((double)hi, 4096.0, (double)lo), 256.0, (double)lw);
 }
 
-// NCH 32-k chunks of one tile whose planes start at chunk index co; group parameters at gpar[gp], gpar[gp + 1]
-template <int NCH>
-__device__ __forceinline__ void q4g_consume_n(const uint4* w, int co, int gp, const uint4* pl, const int4* gpar, float s, int z, double& y) {
+// NCH 32-k chunks w[OFF .. OFF + NCH) of one tile (a register array: indexed with compile-time constants only -- a pointer into it would send the array
+// to scratch memory) whose planes start at chunk index co; group parameters at gpar[gp], gpar[gp + 1].
+// A flagged group takes a SEPARATE straight-line path (main + low planes chunk by chunk): a conditional second pass over the weights after the main pass
+// keeps weights and accumulators alive across a branch, and the register allocator of the fused kernels answered that with 264 spilled registers.
+// SB: a scheduling barrier after every chunk -- without it the scheduler of a large kernel hoists the plane reads of ALL chunks (24 registers each) to the top
+template <int OFF, int NCH, int NTOT, bool SB = false>
+__device__ __forceinline__ void q4g_consume_at(const uint4 (&w)[NTOT], int co, int gp, const uint4* pl, const int4* gpar, float s, int z, double& y) {
   int D[XQ_NM] = {0, 0, 0, 0, 0, 0};
+  if (!xq_low(gpar, gp)) {
 #pragma unroll
-  for (int c = 0; c < NCH; c++) q4_chunk(w[c], pl + (co + c) * XQ_NP, D);
-  int lw = 0;
-  if (xq_low(gpar, gp)) {
+    for (int c = 0; c < NCH; c++) { q4_chunk(w[OFF + c], pl + (co + c) * XQ_NP, D); if (SB) __builtin_amdgcn_sched_barrier(0); }
+    y += q4_term(D, 0, gpar[gp], gpar[gp + 1], s, z);
+  } else {
     int DL[2] = {0, 0};
 #pragma unroll
-    for (int c = 0; c < NCH; c++) q4_chunk_low(w[c], pl + (co + c) * XQ_NP, DL);
-    lw = q4_low(DL, gpar[gp + 1], z);
+    for (int c = 0; c < NCH; c++) { q4_chunk(w[OFF + c], pl + (co + c) * XQ_NP, D); q4_chunk_low(w[OFF + c], pl + (co + c) * XQ_NP, DL); if (SB) __builtin_amdgcn_sched_barrier(0); }
+    y += q4_term(D, q4_low(DL, gpar[gp + 1], z), gpar[gp], gpar[gp + 1], s, z);
   }
-  y += q4_term(D, lw, gpar[gp], gpar[gp + 1], s, z);
+}
+template <int NCH>
+__device__ __forceinline__ void q4g_consume_n(const uint4 (&w)[NCH], int co, int gp, const uint4* pl, const int4* gpar, float s, int z, double& y) {
+  q4g_consume_at<0, NCH, NCH>(w, co, gp, pl, gpar, s, z, y);
 }
 // one 128-k group (four chunks) of one tile
 __device__ __forceinline__ void q4g_consume(const uint4 (&w)[4], int g, const uint4* pl, const int4* gpar, float s, int z, double& y) {
-  q4g_consume_n<4>(w, g * 4, 2 * g, pl, gpar, s, z, y);
+  q4g_consume_at<0, 4, 4>(w, g * 4, 2 * g, pl, gpar, s, z, y);
 }
-// two weight tiles against the SAME activation group (gate and up of the fused MLP); wa / wb start at the group's first chunk
-__device__ __forceinline__ void q4g_consume2(const uint4* wa, const uint4* wb, int g, const uint4* pl, const int4* gpar, float sa, int za, float sb, int zb,
-                                             double& ya, double& yb) {
+// two weight tiles against the SAME activation group (gate and up of the fused MLP): chunks wa[OA .. OA + 4), wb[OB .. OB + 4) (wa and wb may be one array)
+template <int OA, int OB, bool SB, int NA, int NB>
+__device__ __forceinline__ void q4g_consume2_x(const uint4 (&wa)[NA], const uint4 (&wb)[NB], int g, const uint4* pl, const int4* gpar, float sa, int za, float sb, int zb,
+                                               double& ya, double& yb) {
   int Da[XQ_NM] = {0, 0, 0, 0, 0, 0}, Db[XQ_NM] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-  for (int c = 0; c < 4; c++) q4_chunk2(wa[c], wb[c], pl + (g * 4 + c) * XQ_NP, Da, Db);
   const int4 g1 = gpar[2 * g], g2 = gpar[2 * g + 1];
-  int lwa = 0, lwb = 0;
-  if (xq_low(gpar, 2 * g)) {
+  if (!xq_low(gpar, 2 * g)) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) { q4_chunk2(wa[OA + c], wb[OB + c], pl + (g * 4 + c) * XQ_NP, Da, Db); if (SB) __builtin_amdgcn_sched_barrier(0); }
+    ya += q4_term(Da, 0, g1, g2, sa, za);
+    yb += q4_term(Db, 0, g1, g2, sb, zb);
+  } else {
     int La[2] = {0, 0}, Lb[2] = {0, 0};
 #pragma unroll
-    for (int c = 0; c < 4; c++) { q4_chunk_low(wa[c], pl + (g * 4 + c) * XQ_NP, La); q4_chunk_low(wb[c], pl + (g * 4 + c) * XQ_NP, Lb); }
-    lwa = q4_low(La, g2, za); lwb = q4_low(Lb, g2, zb);
+    for (int c = 0; c < 4; c++) {
+      q4_chunk2(wa[OA + c], wb[OB + c], pl + (g * 4 + c) * XQ_NP, Da, Db);
+      q4_chunk_low(wa[OA + c], pl + (g * 4 + c) * XQ_NP, La); q4_chunk_low(wb[OB + c], pl + (g * 4 + c) * XQ_NP, Lb);
+      if (SB) __builtin_amdgcn_sched_barrier(0);
+    }
+    ya += q4_term(Da, q4_low(La, g2, za), g1, g2, sa, za);
+    yb += q4_term(Db, q4_low(Lb, g2, zb), g1, g2, sb, zb);
   }
-  ya += q4_term(Da, lwa, g1, g2, sa, za);
-  yb += q4_term(Db, lwb, g1, g2, sb, zb);
+}
+template <int OFF, int NTOT>
+__device__ __forceinline__ void q4g_consume2_at(const uint4 (&wa)[NTOT], const uint4 (&wb)[NTOT], int g, const uint4* pl, const int4* gpar, float sa, int za, float sb, int zb,
+                                                double& ya, double& yb) {
+  q4g_consume2_x<OFF, OFF, false>(wa, wb, g, pl, gpar, sa, za, sb, zb, ya, yb);
+}
+template <int OA, int OB, int NTOT, bool SB = false>
+__device__ __forceinline__ void q4g_consume2_ab(const uint4 (&w)[NTOT], int g, const uint4* pl, const int4* gpar, float sa, int za, float sb, int zb, double& ya, double& yb) {
+  q4g_consume2_x<OA, OB, SB>(w, w, g, pl, gpar, sa, za, sb, zb, ya, yb);
 }
 
 // fixed point from the double a lane accumulated over its groups

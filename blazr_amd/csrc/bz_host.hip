@@ -59,6 +59,9 @@ extern "C" int bz_device_open(int id, bz_device** out) {
   d->pinned_bytes = 1 << 20;
   BZ_HIP(hipHostMalloc(&d->pinned, d->pinned_bytes, hipHostMallocDefault));
   BZ_HIP(hipMalloc((void**)&d->scratch, 4096));
+  BZ_HIP(hipMalloc((void**)&d->persist_bar, bzk_persist_bar_words() * 4));
+  BZ_HIP(hipMemset(d->persist_bar, 0, bzk_persist_bar_words() * 4));
+  { void* pe = nullptr; BZ_HIP(hipHostMalloc(&pe, 64, hipHostMallocMapped)); d->persist_err = (volatile unsigned*)pe; *d->persist_err = 0u; }
   *out = d;
   return BZ_OK;
   BZ_API_END
@@ -73,6 +76,8 @@ void bz_dev_release(bz_device* d) {
   for (auto ev : d->events) hipEventDestroy(ev);
   if (d->pinned) hipHostFree(d->pinned);
   if (d->scratch) hipFree(d->scratch);
+  if (d->persist_bar) hipFree(d->persist_bar);
+  if (d->persist_err) hipHostFree((void*)d->persist_err);
   bzk_sample_free(d->samp_ws);
   hipStreamDestroy(d->stream);
   hipStreamDestroy(d->copy_stream);
@@ -87,12 +92,19 @@ extern "C" int bz_device_close(bz_device* d) {
   return BZ_OK;
   BZ_API_END
 }
+// The persistent decode launch (bz_persist.hip) ends with this word set when one of its grid-barrier waits ran into its wall-clock limit (a lost arrival):
+// the results of that step are garbage.  Checked wherever the host has just synchronised with the device; the word is sticky until the device is reopened.
+static int persist_check(bz_device* d) {
+  if (d && d->persist_err && *d->persist_err != 0u)
+    BZ_FAIL(BZ_E_HIP, "persistent decode launch: a grid-barrier wait exceeded its limit (results invalid); set BZ_NO_PERSIST=1 to use the launch-per-phase path");
+  return BZ_OK;
+}
 extern "C" int bz_device_synchronize(bz_device* d) {
   BZ_API_BEGIN
   if (!d) BZ_FAIL(BZ_E_INVALID, "null device");
   BZ_HIP(hipStreamSynchronize(d->stream));
   BZ_HIP(hipStreamSynchronize(d->copy_stream));
-  return BZ_OK;
+  return persist_check(d);
   BZ_API_END
 }
 extern "C" int bz_device_memory_info(bz_device* d, size_t* f, size_t* t) {
@@ -304,6 +316,7 @@ struct bz_model {
   float* cos_t = nullptr; float* sin_t = nullptr;
   float* rope_cur = nullptr;   // [cos | sin] row of the current position (staged by the embed kernel)
   float* att_ws = nullptr;     // split-KV attention partials (bzk_attn_split_ws_bytes)
+  void* persist_tab = nullptr; // device table of per-layer weight pointers for the persistent decode launch (nullptr: the model does not qualify)
   // workspace
   float* hbuf[2] = {nullptr, nullptr};
   // batched-prefill workspace (bz_prefill.hip), allocated on first use for `pf_rows` prompt rows
@@ -886,6 +899,27 @@ extern "C" int bz_model_finalize(bz_model* m) {
   BZ_TRY(dev_alloc(m, &p, 64)); m->tok_tmp = (long long*)p;
   BZ_TRY(dev_alloc(m, &p, 64)); m->pos_tmp = (int*)p;
 
+  // the persistent decode launch (bz_persist.hip): every layer int4 without act-order / bias, the Llama-3-8B head geometry, f16 activations
+  if (bzk_persist_shape_ok(H, I, nq, nkv, hd, c.act_dtype, BZ_F16)) {
+    bool ok = true;
+    for (auto& Ld : m->layers)
+      for (const FusedLinear* F : {&Ld.qkv, &Ld.o, &Ld.gateup, &Ld.down})
+        ok = ok && F->parts.size() == 1 && F->parts[0].kind == LK_Q4G && !F->parts[0].perm && !F->parts[0].bias && F->fix_out;
+    if (ok) {
+      const size_t eb = bzk_persist_layer_bytes();
+      std::vector<char> tab(eb * c.n_layers);
+      for (int l = 0; l < c.n_layers && ok; l++) {
+        const LayerDev& Ld = m->layers[l];
+        ok = bzk_persist_fill_layer(tab.data() + eb * l, Ld.qkv.parts[0], Ld.o.parts[0], Ld.gateup.parts[0], Ld.down.parts[0], Ld.attn_norm, Ld.ffn_norm) == BZ_OK;
+      }
+      if (ok) {
+        BZ_TRY(dev_alloc(m, &p, tab.size()));
+        BZ_HIP(hipMemcpy(p, tab.data(), tab.size(), hipMemcpyHostToDevice));
+        m->persist_tab = p;
+      }
+    }
+  }
+
   // accounting
   size_t act_b = bz_dtype_size(c.act_dtype);
   m->per_token = (size_t)(2 * c.n_layers + 1) * H * act_b + (size_t)H * bz_dtype_size(m->embed_dt);
@@ -1408,7 +1442,33 @@ static int llama_step(bz_model* m, const StepIO& io) {
     BZ_HIP(hipMemcpyAsync(m->hbuf[cur], io.hidden_in, (size_t)H * 4, hipMemcpyDeviceToDevice, st));
     if (io.prev_in) { prev.p = io.prev_in; prev.fix = 0; }
   }
-  for (int l = io.layer_start; l < lend; l++) {
+  // The layers as ONE persistent launch (bz_persist.hip) when the model qualifies, the context fits the single-launch attention (no split-KV partner
+  // inside the persistent kernel) and the step starts without a deferred residual.  Bit-identical to the launch-per-phase path below (same arithmetic,
+  // integer accumulators); BZ_NO_PERSIST=1 keeps the three launches per layer.
+  static const bool no_persist = getenv("BZ_NO_PERSIST") != nullptr;
+  int l_first = io.layer_start;
+  if (!no_persist && m->persist_tab && prev.p == nullptr && lend > io.layer_start && io.att_positions == 0 && io.kv.dtype == BZ_F16 && io.kv.hd == c.head_dim && io.d_pos) {
+    BzPersistLaunch pl{};
+    pl.layers = (const char*)m->persist_tab + bzk_persist_layer_bytes() * io.layer_start; pl.n_layers = lend - io.layer_start;
+    pl.h_in = m->hbuf[cur]; pl.h_out = m->hbuf[cur ^ 1];
+    pl.ring_m = m->ring[0]; pl.ring_q = m->ring[1]; pl.ring_o = m->ring[2];
+    pl.rope_cur = m->rope_cur; pl.pos = io.d_pos; pl.kv = io.kv;
+    // the K / V bases of the table's first layer: the kernel indexes layers from 0
+    pl.kv.k = (char*)io.kv.k + (size_t)io.layer_start * io.kv.layer_stride * bz_dtype_size(io.kv.dtype);
+    pl.kv.v = (char*)io.kv.v + (size_t)io.layer_start * io.kv.layer_stride * bz_dtype_size(io.kv.dtype);
+    pl.bar = m->dev->persist_bar; pl.err_host = (unsigned*)m->dev->persist_err; pl.eps = c.rms_eps; pl.I = I;
+    double bytes = 0.0;
+    for (int l = io.layer_start; l < lend; l++)
+      for (const FusedLinear* F : {&m->layers[l].qkv, &m->layers[l].o, &m->layers[l].gateup, &m->layers[l].down}) bytes += (double)F->parts[0].algo_bytes;
+    pl.algo_bytes = bytes;
+    BZ_TRY(bzk_llama_persist(st, pl));
+    cur ^= 1;
+    // ring state after the launch: ring[0] = the last MLP's output (the deferred residual), ring[1] zeroed in its last phase, ring[2] read but not zeroed
+    prev = VSrc{m->ring[0], 1};
+    rs.ri = 1; rs.dirty[0] = H; rs.dirty[1] = 0; rs.dirty[2] = H;
+    l_first = lend;
+  }
+  for (int l = l_first; l < lend; l++) {
     const LayerDev& Ld = m->layers[l];
     Pro pn{}; pn.mode = PRO_NORM; pn.src = prev; pn.h_in = m->hbuf[cur]; pn.h_out = m->hbuf[cur ^ 1]; pn.norm_w = Ld.attn_norm;
     pn.eps = c.rms_eps; pn.H = H; pn.act = act;
@@ -2982,7 +3042,7 @@ extern "C" int bz_decode_graph_read_token(bz_decode_graph* g, int64_t step, int6
   else BZ_HIP(hipEventSynchronize(g->evs[step % g->evs.size()]));
   if (g->replays - step > bz_decode_graph::LOGCAP) BZ_FAIL(BZ_E_INVALID, "read_token: step %lld fell out of the token log", (long long)step);
   *out = ((volatile long long*)g->tok_log)[step % bz_decode_graph::LOGCAP];
-  return BZ_OK;
+  return persist_check(g->m->dev);
   BZ_API_END
 }
 extern "C" int bz_decode_graph_read_logits(bz_decode_graph* g, float* host, size_t n) {

@@ -87,6 +87,8 @@ struct bz_device {
   float* scratch = nullptr;   // 4 KiB device scratch (sampling partials)
   void* samp_ws = nullptr;    // non-greedy sampling workspace (bz_sample.hip), grown on demand
   std::mutex mu;              // guards the per-device scratch / sampling workspace / staging ring (concurrent generate() calls share a device)
+  unsigned* persist_bar = nullptr;             // grid-barrier words of the persistent decode launch (bz_persist.hip), one set per device
+  volatile unsigned* persist_err = nullptr;    // pinned host word the launch sets when a barrier wait ran into its limit (checked wherever the host synchronises)
   int refs = 1;               // the handle itself + every live child object (tensor/model/cache/graph)
 };
 void bz_dev_retain(bz_device* d);
@@ -243,6 +245,21 @@ int bzk_attn_merge_oproj_ok(const AttnArgs& a, const LinearDev& L);
 int bzk_attn_merge_oproj(hipStream_t s, const AttnArgs& a, const float* ws, int SPL, int nsplit, const LinearDev& L, long long* acc);
 int bzk_kv_insert(hipStream_t s, const KvView& kv, int layer, const float* k, const float* v, const int* pos, int nkv, int hd);
 int bzk_kv_read(hipStream_t s, const KvView& kv, int layer, int kvh, int which, int len, float* out);
+
+// the layers of a Llama decode step as one persistent launch (bz_persist.hip)
+struct BzPersistLaunch {
+  const void* layers; int n_layers;       // device table of per-layer weight pointers (bzk_persist_fill_layer entries)
+  const float* h_in; float* h_out;
+  long long* ring_m; long long* ring_q; long long* ring_o;
+  const float* rope_cur; const int* pos; KvView kv;
+  unsigned* bar; unsigned* err_host; float eps; int I; double algo_bytes;
+};
+size_t bzk_persist_smem();
+size_t bzk_persist_layer_bytes();
+size_t bzk_persist_bar_words();
+bool bzk_persist_shape_ok(int H, int I, int nq, int nkv, int hd, int act, int kv_dtype);
+int bzk_persist_fill_layer(void* host_entry, const LinearDev& qkv, const LinearDev& o, const LinearDev& gu, const LinearDev& dn, const float* attn_norm, const float* ffn_norm);
+int bzk_llama_persist(hipStream_t s, const BzPersistLaunch& pl);
 
 // final argmax over partials (or full logits) -> token; optionally advance position and publish token
 struct FinalArgs {

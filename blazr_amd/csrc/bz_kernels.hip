@@ -463,7 +463,8 @@ __global__ __launch_bounds__(NW * 64) void k_mlp_q4g(const uint4* __restrict__ W
   for (int b = 0; b < 2; b++) {
     if (b == 0) MSTAMP(5);
     if (b == 1) MSTAMP(7);
-    q4g_consume2(&Ag[b * 4], &Au[b * 4], gbeg + b, xpl, gpar, sg[b], zg[b], su[b], zu[b], yg, yu);
+    if (b == 0) q4g_consume2_at<0>(Ag, Au, gbeg, xpl, gpar, sg[0], zg[0], su[0], zu[0], yg, yu);
+    else q4g_consume2_at<4>(Ag, Au, gbeg + 1, xpl, gpar, sg[1], zg[1], su[1], zu[1], yg, yu);
     if (b == 0) MSTAMP(6);
     if (b == 1) MSTAMP(8);
     if (b == 0) {
@@ -791,7 +792,8 @@ __global__ __launch_bounds__(768) void k_gemv_q4g_slim(const uint4* __restrict__
     double y = 0.0;
 #pragma unroll
     for (int b = 0; b < 2; b++) {
-      q4g_consume_n<4>(&Q[b * 4], b * 4, 2 * b, xpl, gpar, sq[b], zq[b], y);
+      if (b == 0) q4g_consume_at<0, 4>(Q, 0, 0, xpl, gpar, sq[0], zq[0], y);
+      else q4g_consume_at<4, 4>(Q, 4, 2, xpl, gpar, sq[1], zq[1], y);
       if (b == 0) SSTAMP(5);
     }
     const int n = tq * 64 + lane;
@@ -898,7 +900,8 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_q4g_cols(const uint4* __restri
   double y = 0.0;
 #pragma unroll
   for (int b = 0; b < 2; b++) {
-    q4g_consume_n<4>(&Q[b * 4], (wave * 2 + b) * 4, 2 * (wave * 2 + b), xpl, gpar, sq[b], zq[b], y);
+    if (b == 0) q4g_consume_at<0, 4>(Q, (wave * 2) * 4, 2 * (wave * 2), xpl, gpar, sq[0], zq[0], y);
+    else q4g_consume_at<4, 4>(Q, (wave * 2 + 1) * 4, 2 * (wave * 2 + 1), xpl, gpar, sq[1], zq[1], y);
   }
   part[wave * 64 + lane] = y;
   __syncthreads();

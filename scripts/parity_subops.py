@@ -100,6 +100,14 @@ lpm = None if opm is None else dev.tensor(opm.astype(np.float32))
 kv = runtime.LayeredKvCache(dev, nl, 1, nkv, 8, cfg["max_seq_len"], hd, L.F16)
 gh, gpm = lm.forward_layers_range(lh, lpm, kv, layer, layer + 1, 0)
 oh2, opm2 = om.layers_range(oh, opm, okv, layer, layer + 1, 0)
+gk = np.concatenate([kv.read(layer, hh, 0, 1).reshape(-1) for hh in range(nkv)])
+gv = np.concatenate([kv.read(layer, hh, 1, 1).reshape(-1) for hh in range(nkv)])
+report("fused layer: K row (cache)", gk, k, orc_py.OrcLinear(lay["k"]).dequant().astype(np.float64) @ xn.astype(np.float64))
+report("fused layer: V row (cache)", gv, v, orc_py.OrcLinear(lay["v"]).dequant().astype(np.float64) @ xn.astype(np.float64))
+bad = np.nonzero(gv != v)[0]
+for i in bad[:6]:
+    ex = float(orc_py.OrcLinear(lay["v"]).dequant()[i].astype(np.float64) @ xn.astype(np.float64))
+    print("      v[%d]: gpu %.9g oracle %.9g exact %.12g (f16 neighbours %.9g / %.9g)" % (i, gv[i], v[i], ex, np.float16(ex), np.nextafter(np.float16(ex), np.float16(np.inf if ex > float(np.float16(ex)) else -np.inf))))
 report("fused layer: h'", gh.to_numpy(), oh2)
 report("fused layer: mlp out", gpm.to_numpy(), opm2)
 report("   (oracle h' vs sub-op h2)", h2, oh2)
