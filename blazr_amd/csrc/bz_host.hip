@@ -900,7 +900,7 @@ extern "C" int bz_model_finalize(bz_model* m) {
   BZ_TRY(dev_alloc(m, &p, 64)); m->pos_tmp = (int*)p;
 
   // the persistent decode launch (bz_persist.hip): every layer int4 without act-order / bias, the Llama-3-8B head geometry, f16 activations
-  if (bzk_persist_shape_ok(H, I, nq, nkv, hd, c.act_dtype, BZ_F16)) {
+  if (bzk_persist_shape_ok(H, I, nq, nkv, hd, c.act_dtype, BZ_F16) && !c.rope_interleaved) {
     bool ok = true;
     for (auto& Ld : m->layers)
       for (const FusedLinear* F : {&Ld.qkv, &Ld.o, &Ld.gateup, &Ld.down})
@@ -1461,7 +1461,22 @@ static int llama_step(bz_model* m, const StepIO& io) {
     for (int l = io.layer_start; l < lend; l++)
       for (const FusedLinear* F : {&m->layers[l].qkv, &m->layers[l].o, &m->layers[l].gateup, &m->layers[l].down}) bytes += (double)F->parts[0].algo_bytes;
     pl.algo_bytes = bytes;
+    // diagnostic: per-wave phase stamps of layer 1 (workgroups 0 and 131), printed after the launch (eager steps only)
+    static const bool pstamps_on = getenv("BZ_PERSIST_STAMPS") != nullptr;
+    static long long* pstamps = nullptr; static int pstamp_prints = 0;
+    if (pstamps_on && !tl_capture_stream && pstamp_prints < 3) { if (!pstamps) hipMalloc(&pstamps, 2 * 8 * 32 * 8); hipMemsetAsync(pstamps, 0, 2 * 8 * 32 * 8, st); pl.stamps = pstamps; }
     BZ_TRY(bzk_llama_persist(st, pl));
+    if (pl.stamps) {
+      std::vector<long long> hs(2 * 8 * 32);
+      hipStreamSynchronize(st); hipMemcpy(hs.data(), pstamps, hs.size() * 8, hipMemcpyDeviceToHost); pstamp_prints++;
+      const long long t0 = hs[0];
+      for (int g = 0; g < 2; g++)
+        for (int w = 0; w < 8; w++) {
+          fprintf(stderr, "[bz] persist stamps wg %3d wave %d (us since wg 0 wave 0 entered phase Q of layer 1):", g ? 131 : 0, w);
+          for (int i = 0; i < 18; i++) fprintf(stderr, " %d:%.2f", i, hs[(g * 8 + w) * 32 + i] ? (hs[(g * 8 + w) * 32 + i] - t0) / 100.0 : -1.0);
+          fprintf(stderr, "\n");
+        }
+    }
     cur ^= 1;
     // ring state after the launch: ring[0] = the last MLP's output (the deferred residual), ring[1] zeroed in its last phase, ring[2] read but not zeroed
     prev = VSrc{m->ring[0], 1};

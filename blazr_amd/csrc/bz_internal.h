@@ -252,7 +252,7 @@ struct BzPersistLaunch {
   const float* h_in; float* h_out;
   long long* ring_m; long long* ring_q; long long* ring_o;
   const float* rope_cur; const int* pos; KvView kv;
-  unsigned* bar; unsigned* err_host; float eps; int I; double algo_bytes;
+  unsigned* bar; unsigned* err_host; float eps; int I; double algo_bytes; long long* stamps;
 };
 size_t bzk_persist_smem();
 size_t bzk_persist_layer_bytes();

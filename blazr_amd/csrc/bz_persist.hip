@@ -89,6 +89,7 @@ struct PersistArgs {
   unsigned* bar;          // barrier words (persist across launches): 8 group counters, top counter, generation, error -- BAR_STRIDE words apart
   unsigned* err_host;     // host-pinned word: set (never cleared by the device) when a barrier wait ran into its limit
   float eps; int I;
+  long long* stamps;      // diagnostic (BZ_PERSIST_STAMPS): s_memrealtime of workgroup 0 / 131 at the phase boundaries of layer 1 (nullptr: off)
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -141,6 +142,7 @@ __global__ __launch_bounds__(512) void k_llama_persist(PersistArgs a_in) {
   const bool m_on = wg < NUNIT;                                    // M: unit (64 intermediate columns)
   const int m_sl = m_on ? wg : 0;
 
+#define PSTAMP(i) do { if (a.stamps && l == 1 && lane == 0 && (wg == 0 || wg == 131)) a.stamps[((wg ? 1 : 0) * 8 + wave) * 32 + (i)] = (long long)now100(); } while (0)
 #define GRID_BARRIER()                                                                                                               \
   do {                                                                                                                               \
     vm_drain();                                                                                                                      \
@@ -258,8 +260,10 @@ __global__ __launch_bounds__(512) void k_llama_persist(PersistArgs a_in) {
     // =====================================================================================================================
     // Phase Q: h' = R(h + R(mlp_prev)) -> hres; RMSNorm; the workgroup's 256-k slice of the normalised row -> planes; 6 tiles x 256 k of q/k/v
     // =====================================================================================================================
+    PSTAMP(0);
     {
       ROW_UPDATE(a.ring_m, l > 0, false)
+      PSTAMP(1);
       const int so = oct - q_osl;                                    // this thread's octet inside the slice (0..31) when it lies there
       if (so >= 0 && so < 32) {
         unsigned* plw = (unsigned*)S.xpl + ((so >> 2) * XQ_NP) * 4 + (so & 3);
@@ -278,9 +282,12 @@ __global__ __launch_bounds__(512) void k_llama_persist(PersistArgs a_in) {
       }
       if (wave == 6 && lane < 16) acc_zero(a.ring_o + wg * 16 + lane);     // zero duty: o_proj accumulator (read in the previous M phase)
     }
+    PSTAMP(2);
     vm_drain();
+    PSTAMP(3);
     PREFETCH_A(L, l);
     GRID_BARRIER();
+    PSTAMP(4);
 
     // =====================================================================================================================
     // Phase A: q/k/v finish (+ RoPE), KV append, attention of head a_hq over the cache (exact sums, two passes), o_proj slab -> ring_o
@@ -313,6 +320,7 @@ __global__ __launch_bounds__(512) void k_llama_persist(PersistArgs a_in) {
       }
       e_qkv += 3;
       if (!dead && !lds_wait(&cnt[C_QKV], e_qkv)) dead = true;
+      PSTAMP(5);
       if ((a_hq & 3) == 0 && a_cs == 0 && wave == 3) {   // KV append, once per kv head: 64 threads x 4-byte pairs
         size_t woff;
         if (PAGED) woff = kv_slot_off(kv, l, a_kvh, kv.slot ? kv.slot[0] : (kv.block_table[pos / kv.bs] * kv.bs + pos % kv.bs));
@@ -350,6 +358,7 @@ __global__ __launch_bounds__(512) void k_llama_persist(PersistArgs a_in) {
         for (int i = 0; i < 8; i++) Mw = fmaxf(Mw, sc_[i]);
       }
       Mw = wave_max(Mw);
+      PSTAMP(6);
       if (lane == 0) { S.u.at.wred[wave] = Mw; lds_signal(&cnt[C_MAX]); }
       e_max += NW;
       if (!dead && !lds_wait(&cnt[C_MAX], e_max)) dead = true;
@@ -390,6 +399,7 @@ __global__ __launch_bounds__(512) void k_llama_persist(PersistArgs a_in) {
         for (int q = 0; q < 8; q++) S.u.at.pout[wave * PHD + piece * 8 + q] = accv[q];
       }
       if (lane == 0) { S.u.at.lred[wave] = lsum; lds_signal(&cnt[C_PV]); }
+      PSTAMP(7);
       e_pv += NW;
       if (wave < 2) {
         if (!dead && !lds_wait(&cnt[C_PV], e_pv)) dead = true;
@@ -426,15 +436,19 @@ __global__ __launch_bounds__(512) void k_llama_persist(PersistArgs a_in) {
       e_qa += 1;
       {
         if (!dead && !lds_wait(&cnt[C_QA], e_qa)) dead = true;
+        PSTAMP(8);
         double y = 0.0;
         q4g_consume_at<0, 4, 16, true>(P, 0, 0, S.u.at.xpl, S.u.at.gpar, sA[0], zA[0], y);
         acc_add(a.ring_o + (a_cs * 8 + wave) * 64 + lane, d2fix(y, ACT));
       }
       if (wave == 6 && lane < 16 && l > 0) acc_zero(a.ring_m + wg * 16 + lane);   // zero duty: the previous MLP accumulator (read in phase Q)
     }
+    PSTAMP(9);
     vm_drain();
+    PSTAMP(10);
     PREFETCH_M(L);
     GRID_BARRIER();
+    PSTAMP(11);
 
     // =====================================================================================================================
     // Phase M: h'' = R(h' + R(o)) -> hres; RMSNorm; planes of the whole row; gate / up of 64 intermediate columns; SiLU * up; the 64-k slab of down
@@ -448,6 +462,7 @@ __global__ __launch_bounds__(512) void k_llama_persist(PersistArgs a_in) {
         if ((lane & 15) == 0) { S.gpar[2 * (oct >> 4)] = make_int4(__float_as_int(cs_), sp_[0], sp_[1], sp_[2]); S.gpar[2 * (oct >> 4) + 1] = g2w_; }
         if (lane == 0) lds_signal(&cnt[C_PL]);
       }
+      PSTAMP(12);
       e_pl += NW;
       if (m_on) {
         const int GD = I >> 7, gd = m_sl >> 1, tbeg = wave * 8;
@@ -491,6 +506,7 @@ __global__ __launch_bounds__(512) void k_llama_persist(PersistArgs a_in) {
         __builtin_amdgcn_sched_barrier(0);
         q4g_consume2_ab<0, 4, 8, true>(G3, wave * 4 + 3, S.xpl, S.gpar, sA[3], zA[3], sB[3], zB[3], yg, yu);
         __builtin_amdgcn_sched_barrier(0);
+        PSTAMP(13);
         S.u.m.part[wave * 128 + lane] = yg;
         S.u.m.part[wave * 128 + 64 + lane] = yu;
         if (lane == 0) lds_signal(&cnt[C_PART]);
@@ -531,6 +547,7 @@ __global__ __launch_bounds__(512) void k_llama_persist(PersistArgs a_in) {
         }
         e_tail += 1;
         if (!dead && !lds_wait(&cnt[C_TAIL], e_tail)) dead = true;
+        PSTAMP(14);
 #pragma unroll
         for (int q = 0; q < 8; q++) {
           double y = 0.0;
@@ -542,13 +559,17 @@ __global__ __launch_bounds__(512) void k_llama_persist(PersistArgs a_in) {
       }
       if (wave == 6 && lane < 24) acc_zero(a.ring_q + wg * 24 + lane);     // zero duty: q/k/v accumulator (read in phase A)
     }
+    PSTAMP(15);
     if (l + 1 < a.n_layers) {
       vm_drain();
+      PSTAMP(16);
       PREFETCH_Q(a.layers[l + 1]);
       GRID_BARRIER();
+      PSTAMP(17);
     }
   }
 #undef GRID_BARRIER
+#undef PSTAMP
 #undef PREFETCH_Q
 #undef PREFETCH_A
 #undef PREFETCH_M
@@ -582,7 +603,7 @@ int bzk_persist_fill_layer(void* host_entry, const LinearDev& qkv, const LinearD
 int bzk_llama_persist(hipStream_t s, const BzPersistLaunch& pl) {
   PersistArgs a{};
   a.layers = (const PLayer*)pl.layers; a.n_layers = pl.n_layers; a.h_in = pl.h_in; a.h_out = pl.h_out;
-  a.ring_m = pl.ring_m; a.ring_q = pl.ring_q; a.ring_o = pl.ring_o; a.rope_cur = pl.rope_cur; a.pos = pl.pos; a.kv = pl.kv; a.bar = pl.bar; a.err_host = pl.err_host; a.eps = pl.eps; a.I = pl.I;
+  a.ring_m = pl.ring_m; a.ring_q = pl.ring_q; a.ring_o = pl.ring_o; a.rope_cur = pl.rope_cur; a.pos = pl.pos; a.kv = pl.kv; a.bar = pl.bar; a.err_host = pl.err_host; a.eps = pl.eps; a.I = pl.I; a.stamps = pl.stamps;
   const size_t smem = sizeof(PersistLds);
   static bool attr_set = false;
   if (!attr_set) {
