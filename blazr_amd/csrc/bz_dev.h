@@ -51,7 +51,7 @@ __device__ __forceinline__ float vsrc_get(const VSrc& s, int i, int act) {
   if (s.fix) return round_act(fix2f(((const long long*)s.p)[i], act), act);
   return ((const float*)s.p)[i];
 }
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + bz_expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) { return div_rn(x, 1.0f + bz_expf(-x)); }
 
 
 // ---------------------------------------------------------------------------------------------------------

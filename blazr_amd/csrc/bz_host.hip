@@ -1504,6 +1504,15 @@ static int llama_step(bz_model* m, const StepIO& io) {
     VSrc qkv;
     BZ_TRY(run_fused(m, Ld.qkv, pn, rs, &qkv));
     cur ^= 1;
+    {   // diagnostic (scripts/qkv_dump.py): the raw q/k/v accumulator of one layer, written to a file (eager steps only)
+      static const char* dump = getenv("BZ_DUMP_QKV");
+      static const int dump_layer = getenv("BZ_DUMP_LAYER") ? atoi(getenv("BZ_DUMP_LAYER")) : 0;
+      if (dump && !tl_capture_stream && l == dump_layer && qkv.fix) {
+        std::vector<long long> hq(Ld.qkv.N);
+        hipStreamSynchronize(st); hipMemcpy(hq.data(), qkv.p, hq.size() * 8, hipMemcpyDeviceToHost);
+        FILE* f = fopen(dump, "wb"); if (f) { fwrite(hq.data(), 8, hq.size(), f); fclose(f); }
+      }
+    }
 
     AttnArgs aa{};
     aa.qkv = qkv; aa.cos_t = m->cos_t; aa.sin_t = m->sin_t; aa.interleaved = c.rope_interleaved; aa.pos = io.d_pos; aa.rope_cur = m->rope_cur;

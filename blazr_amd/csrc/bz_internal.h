@@ -486,6 +486,13 @@ __host__ __device__ __forceinline__ float bz_expf(float x) {
   __builtin_memcpy(&sc, &sb, 4);
   return y * sc;
 }
+// Correctly rounded f32 quotient / square root through double (53 >= 2 * 24 + 2 bits: the double result rounds to the correctly rounded float).  Written out
+// because hipcc does not always give `a / b` and `1.0f / sqrtf(x)` the IEEE sequence: measured in round 3 (scripts/qkv_dump.py), the slim q/k/v kernel's
+// 1 / rms came out ONE ULP LOW next to the generic kernel's (same source expression) -- five of 4096 normalised activations then round to the other f16
+// neighbour, and every q/k/v column of the layer is off by ~1e-4.  The oracle's C expressions (IEEE division and sqrtf) are these values.
+__host__ __device__ __forceinline__ float div_rn(float a, float b) { return (float)((double)a / (double)b); }
+__host__ __device__ __forceinline__ float sqrt_rn(float x) { return (float)sqrt((double)x); }
+__host__ __device__ __forceinline__ float rms_scale(float ss, float n, float eps) { return div_rn(1.0f, sqrt_rn(div_rn(ss, n) + eps)); }   // 1 / sqrt(ss / n + eps), each step rounded to f32
 // RoPE pair: the products are exact in double (x: <= 24 significant bits, table entry: 24), one rounding of their difference / sum in double and
 // one to f32 -- the same bits whatever gets contracted (oracle: orc_rope_apply)
 __device__ __forceinline__ float rope_lo(float x0, float x1, float c, float s) { return (float)((double)x0 * (double)c - (double)x1 * (double)s); }

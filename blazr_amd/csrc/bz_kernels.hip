@@ -143,7 +143,7 @@ __device__ void build_x_simple(const Pro& p, int k0, int KR, float* xs, float* r
     else if (p.src.fix) ssd = norm_pass1<SWZ, true, true>(p, k0, KR, xs, writer);
     else ssd = norm_pass1<SWZ, false, true>(p, k0, KR, xs, writer);
     const float ss = (float)block_sum_d<4>(ssd);   // the rounded exact sum (also orders the xs writes of pass 1 before the reads below)
-    const float rs = 1.0f / sqrtf(ss / (float)p.H + p.eps);
+    const float rs = rms_scale(ss, (float)p.H, p.eps);
     for (int base = 0; base < KR; base += 2048) {
       float ww[8];
 #pragma unroll
@@ -167,7 +167,7 @@ __device__ void build_x_simple(const Pro& p, int k0, int KR, float* xs, float* r
         ss += v * v;
       }
       ss = block_sum256(ss, red);
-      const float rs = 1.0f / sqrtf(ss / (float)gsz + p.eps);
+      const float rs = rms_scale(ss, (float)gsz, p.eps);
       for (int i = tid; i < gsz; i += 256) {
         const int kk = g * gsz + i;
         xs[xs_pos<SWZ>(kk)] = round_act(p.norm_w[kk] * round_act(xs[xs_pos<SWZ>(kk)] * rs, p.act), p.act);
@@ -179,7 +179,7 @@ __device__ void build_x_simple(const Pro& p, int k0, int KR, float* xs, float* r
     if (tid < G) {
       float ss = 0.f;
       for (int h = 0; h < hpg; h++) ss += p.h_in[tid * hpg + h];
-      red[4 + tid] = 1.0f / sqrtf(ss / (float)gsz + p.eps);
+      red[4 + tid] = rms_scale(ss, (float)gsz, p.eps);
     }
     __syncthreads();
     for (int base = 0; base < KR; base += 2048) {
@@ -295,7 +295,7 @@ __device__ __forceinline__ void xfinish(const Pro& p, int KR, const XRegs<MODE, 
       }
     }
     const float ss = (float)block_sum_d<4>(ssd);
-    const float rs = 1.0f / sqrtf(ss / (float)p.H + p.eps);
+    const float rs = rms_scale(ss, (float)p.H, p.eps);
 #pragma unroll
     for (int e = 0; e < E; e++) {
       const int i = e * 256 + tid;
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(NW * 64) void k_mlp_q4g(const uint4* __restrict__ W
     ssd = ((dred[0] + dred[1]) + (dred[2] + dred[3]));
     if (NP == 8) ssd += ((dred[4] + dred[5]) + (dred[6] + dred[7]));
     const float ss = (float)ssd;                  // the rounded exact sum of squares (oracle: orc_rms_norm)
-    const float rs = 1.0f / sqrtf(ss / (float)H + pro.eps);
+    const float rs = rms_scale(ss, (float)H, pro.eps);
     MSTAMP(2);
     // (3p) x = R(w R(h' rs)) in registers -> the octet's six plane words, the group's sums (16 threads)
     const float nwv[8] = {na.x, na.y, na.z, na.w, nb.x, nb.y, nb.z, nb.w};
@@ -736,7 +736,7 @@ __global__ __launch_bounds__(768) void k_gemv_q4g_slim(const uint4* __restrict__
       lds_wait_count(&cnt[0], 4);
       SSTAMP(3);
       const float ss = (float)((red[0] + red[1]) + (red[2] + red[3]));
-      const float rs = 1.0f / sqrtf(ss / (float)H + pro.eps);
+      const float rs = rms_scale(ss, (float)H, pro.eps);
       float sv[8];
 #pragma unroll
       for (int e = 0; e < 8; e++) {
@@ -862,7 +862,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_q4g_cols(const uint4* __restri
     lds_wait_count(&cnt[0], NP);
     ssd = ((dred[0] + dred[1]) + (dred[2] + dred[3]));
     if (NP == 8) ssd += ((dred[4] + dred[5]) + (dred[6] + dred[7]));
-    const float rs = 1.0f / sqrtf((float)ssd / (float)H + pro.eps);
+    const float rs = rms_scale((float)ssd, (float)H, pro.eps);
     const float nwv[8] = {na.x, na.y, na.z, na.w, nb.x, nb.y, nb.z, nb.w};
     float x[8];
     float am = 0.f;
@@ -1396,7 +1396,7 @@ __global__ __launch_bounds__(512) void k_gemv_gq_slim(const uint4* __restrict__ 
     if (lane == 0) red[wave] = ss;
     __syncthreads();
     ss = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
-    const float rs = 1.0f / sqrtf(ss / (float)pro.H + pro.eps);
+    const float rs = rms_scale(ss, (float)pro.H, pro.eps);
     if (tid < 64) {
       const float4 v = *(const float4*)(xs + tid * 4);
       *(float4*)(xs + tid * 4) = make_float4(round_act(nw.x * round_act(v.x * rs, pro.act), pro.act), round_act(nw.y * round_act(v.y * rs, pro.act), pro.act),
@@ -1613,7 +1613,7 @@ __global__ __launch_bounds__(NW * 64) void k_mlp_gq(const uint4* __restrict__ Wg
     lds_wait_count(&cnt[0], NP);
     float tot = (red[0] + red[1]) + (red[2] + red[3]);
     if (NP == 8) tot += (red[4] + red[5]) + (red[6] + red[7]);
-    const float rs = 1.0f / sqrtf(tot / (float)H + pro.eps);
+    const float rs = rms_scale(tot, (float)H, pro.eps);
     const float nwv[8] = {na.x, na.y, na.z, na.w, nb.x, nb.y, nb.z, nb.w};
     float x[8];
 #pragma unroll
@@ -2079,7 +2079,7 @@ __global__ __launch_bounds__(ROUTE ? 832 : 768) void k_gemv_rows2(const void* __
       if (lane == 0) atomicAdd(&cnt[0], 1u);
       lds_wait_count(&cnt[0], 4);
       const float ss = (float)((dred[0] + dred[1]) + (dred[2] + dred[3]));   // the rounded exact sum of squares (oracle: orc_rms_norm)
-      const float rs = 1.0f / sqrtf(ss / (float)H + pro.eps);
+      const float rs = rms_scale(ss, (float)H, pro.eps);
 #pragma unroll
       for (int r = 0; r < NR; r++) {
         float4 v = *(const float4*)(xs + r * 1024 + tid * 4);
@@ -2100,7 +2100,7 @@ __global__ __launch_bounds__(ROUTE ? 832 : 768) void k_gemv_rows2(const void* __
         double t = 0.0;
         for (int h = lane; h < hpg; h += 64) t += (double)pro.h_in[g * hpg + h];
         t = wave_sum_d(t);
-        if (lane == 0) grs[wave][g] = 1.0f / sqrtf((float)t / (float)gsz + pro.eps);
+        if (lane == 0) grs[wave][g] = rms_scale((float)t, (float)gsz, pro.eps);
       }
       __builtin_amdgcn_s_waitcnt(0xc07f);
       const float rs = grs[wave][min(skc[0] / gsz, 7)];
@@ -2266,7 +2266,7 @@ __global__ __launch_bounds__(768) void k_mlp_dense(const void* __restrict__ Wgu,
         if (lane == 0) atomicAdd(&cnt[0], 1u);
         lds_wait_count(&cnt[0], 4);
         const float ss = (float)((dred[0] + dred[1]) + (dred[2] + dred[3]));
-        const float rs = 1.0f / sqrtf(ss / (float)H + pro.eps);
+        const float rs = rms_scale(ss, (float)H, pro.eps);
         for (int b2 = 0; b2 < H; b2 += 2048) {     // every batch of this thread (H <= 2048: exactly the values above)
           const int j0 = b2 + tid * 8;
           if (j0 < H) {
@@ -2991,7 +2991,7 @@ __global__ __launch_bounds__(256) void k_attn_decode(AttnArgs a) {
     __syncthreads();
   }
 
-  const float scale = 1.0f / sqrtf((float)HD);
+  const float scale = div_rn(1.0f, sqrt_rn((float)HD));
   float m = -INFINITY, l = 0.f;
   float o[HD];
 #pragma unroll
@@ -3037,7 +3037,7 @@ __global__ __launch_bounds__(256) void k_attn_decode(AttnArgs a) {
     for (int i = 0; i < HD; i += 4) *(float4*)(ored + tid * LDR + i) = make_float4(o[i] * w, o[i + 1] * w, o[i + 2] * w, o[i + 3] * w);
   }
   __syncthreads();
-  const float inv = 1.0f / ((wred[4] + wred[5]) + (wred[6] + wred[7]));
+  const float inv = div_rn(1.0f, (wred[4] + wred[5]) + (wred[6] + wred[7]));
   // thread t: column t % HD, rows t / HD, t / HD + 256 / HD, ...   (256 / HD row-phases)
   constexpr int PH = 256 / HD;            // 2 for HD 128, 4 for HD 64
   const int col = tid % HD, ph = tid / HD;
@@ -3218,7 +3218,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn2(AttnArgs a, const uint4* __re
   // to ~1e-16, so the result does not depend on the chunk / wave / lane decomposition and equals the oracle's bits (round 2 merged 256-position chunks online
   // with f32 sums: ~1e-7 of order-dependent error, i.e. about one flipped f16 rounding per layer).  A context of up to 256 positions keeps its rows and scores in
   // registers between the passes; longer ones re-read K (L2 hits) in pass 2.
-  const float scale = 1.0f / sqrtf((float)HD);
+  const float scale = div_rn(1.0f, sqrt_rn((float)HD));
   const uint4 qq = ((const uint4*)q2)[piece];
   float qf[8];
   unpack2<KVDT>(qq.x, qf[0], qf[1]); unpack2<KVDT>(qq.y, qf[2], qf[3]); unpack2<KVDT>(qq.z, qf[4], qf[5]); unpack2<KVDT>(qq.w, qf[6], qf[7]);
@@ -3306,10 +3306,10 @@ __global__ __launch_bounds__(NW * 64) void k_attn2(AttnArgs a, const uint4* __re
     Orun = (float)oc; Lrun = (float)Lc;
   }
   if (!FUSE) {
-    if (tid < HD) a.out[(size_t)hq * HD + tid] = round_act(Orun / Lrun, a.act);
+    if (tid < HD) a.out[(size_t)hq * HD + tid] = round_act(div_rn(Orun, Lrun), a.act);
     return;
   }
-  if (tid < HD) outh[tid] = round_act(Orun / Lrun, a.act);
+  if (tid < HD) outh[tid] = round_act(div_rn(Orun, Lrun), a.act);
   if (FUSE == 2) {
     // dense o_proj: this lane's 8 weights of each output row against its 8 head outputs, reduced over the row's NPC lanes, one fixed-point atomic per (head, row)
     __syncthreads();
@@ -3451,7 +3451,7 @@ __global__ __launch_bounds__(512) void k_attn2f(AttnArgs a, const uint4* __restr
     if (tid < 64) { qf[2 * tid] = px0; qf[2 * tid + 1] = px1; }
     __syncthreads();
   }
-  const float scale = 1.0f / sqrtf((float)HD);
+  const float scale = div_rn(1.0f, sqrt_rn((float)HD));
   const float4 qa = *(const float4*)(qf + piece * 8), qb = *(const float4*)(qf + piece * 8 + 4);
   float Mrun = -INFINITY, Lrun = 0.f, Orun = 0.f;   // running state (threads < 128 own output d = tid)
   for (int c0 = 0; c0 < len; c0 += 256) {
@@ -3522,10 +3522,10 @@ __global__ __launch_bounds__(512) void k_attn2f(AttnArgs a, const uint4* __restr
     }
   }
   if (!FUSE) {
-    if (tid < 128) a.out[(size_t)hq * HD + tid] = round_act(Orun / Lrun, a.act);
+    if (tid < 128) a.out[(size_t)hq * HD + tid] = round_act(div_rn(Orun, Lrun), a.act);
     return;
   }
-  if (tid < 128) outh[tid] = round_act(Orun / Lrun, a.act);
+  if (tid < 128) outh[tid] = round_act(div_rn(Orun, Lrun), a.act);
   __syncthreads();
   quant_x32<GQ_Q4K>(outh, HD, xh, xm, xl, cpar);
   __syncthreads();
@@ -3709,7 +3709,7 @@ __global__ __launch_bounds__(REP == 8 ? 512 : 256) void k_attn_split(AttnArgs a,
   }
   const unsigned short* kb0 = (const unsigned short*)kv.k + (size_t)a.layer * kv.layer_stride;
   const unsigned short* vb0 = (const unsigned short*)kv.v + (size_t)a.layer * kv.layer_stride;
-  const float scale = 1.0f / sqrtf((float)HD);
+  const float scale = div_rn(1.0f, sqrt_rn((float)HD));
   uint4 qq[REP];
 #pragma unroll
   for (int h = 0; h < REP; h++) qq[h] = ((const uint4*)q2[h])[piece];
@@ -4167,7 +4167,7 @@ __global__ __launch_bounds__(256) void k_rms_norm(const float* x, const float* p
     ss += v * v;
   }
   ss = block_sum256(ss, red);
-  const float rs = 1.0f / sqrtf(ss / (float)n + eps);
+  const float rs = rms_scale(ss, (float)n, eps);
   for (int i = threadIdx.x; i < n; i += 256) {
     float v = xr[i];
     if (pr) v = round_act(v + pr[i], act);
@@ -4427,7 +4427,7 @@ __global__ __launch_bounds__(NW * 64) void k_mla_attn(MlaArgs a) {
     float ss = 0.f;
     for (int r = tid; r < R; r += NTH) { const float v = csrc(r); ccur[r] = v; ss += v * v; }
     ss = block_sum_nw<NW>(ss, red);
-    const float rs = 1.0f / sqrtf(ss / (float)R + a.eps);
+    const float rs = rms_scale(ss, (float)R, a.eps);
     for (int r = tid; r < R; r += NTH) ccur[r] = round_act(a.kv_norm[r] * round_act(ccur[r] * rs, a.act), a.act);
   }
   for (int j = tid; j < DR / 2; j += NTH) {
@@ -4544,7 +4544,7 @@ __global__ __launch_bounds__(NW * 64) void k_mla_attn(MlaArgs a) {
   float psum = 0.f;
   for (int t = tid; t < nloc; t += NTH) { const float p = bz_expf(sc[t] - mx); sc[t] = p; psum += p; }
   psum = block_sum_nw<NW>(psum, red);
-  const float inv = 1.0f / psum;
+  const float inv = div_rn(1.0f, psum);
   // ---- olat = R(sum_t p_t c_t * inv) ----
   {
     float acc[NCH][8];
@@ -4658,7 +4658,7 @@ __global__ __launch_bounds__(256) void k_mla_merge(MlaArgs a) {
     const float M = wave_max(on ? ms : -INFINITY);
     const float wv = on ? bz_expf(ms - M) : 0.f;
     const float L = wave_sum(wv * ls);
-    if (wave == 0) { wgt[lane] = wv; if (lane == 63) wgt[63] = 1.0f / L; }
+    if (wave == 0) { wgt[lane] = wv; if (lane == 63) wgt[63] = div_rn(1.0f, L); }
   }
   __syncthreads();
   const float inv = wgt[63];
@@ -4768,7 +4768,7 @@ __device__ __forceinline__ void moe_softmax_topk_n(const float* lg, int E, int t
         for (int l = 0; l < 64; l++) sum += __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v[j]), l));
       }
 #pragma unroll
-    for (int j = 0; j < NJM; j++) { const int ee = lane + 64 * j; v[j] = (j < NJ && ee < E) ? v[j] / sum : -1.f; }
+    for (int j = 0; j < NJM; j++) { const int ee = lane + 64 * j; v[j] = (j < NJ && ee < E) ? div_rn(v[j], sum) : -1.f; }
     float tsum = 0.f, myw = 0.f; int mysel = 0;
     for (int k = 0; k < top_k; k++) {
       float bv = -1.f; int bi = 0x7fffffff;
@@ -4800,7 +4800,7 @@ __device__ __forceinline__ void moe_softmax_topk_n(const float* lg, int E, int t
 #pragma unroll
       for (int j = 0; j < NJM; j++) if (j < NJ && lane + 64 * j == bi) v[j] = -1.f;
     }
-    if (lane < top_k) { sel[lane] = mysel; wsel[lane] = norm_topk ? myw / (tsum + 1e-20f) * routed_scale : myw * routed_scale; }
+    if (lane < top_k) { sel[lane] = mysel; wsel[lane] = norm_topk ? div_rn(myw, tsum + 1e-20f) * routed_scale : myw * routed_scale; }
     if (lane < n_shared) { sel[top_k + lane] = E + lane; wsel[top_k + lane] = 1.0f; }
 }
 __device__ void moe_softmax_topk(const float* lg, int E, int top_k, int n_shared, float routed_scale, int norm_topk, int* sel, float* wsel, int lane) {
@@ -4946,7 +4946,7 @@ __global__ __launch_bounds__(256) void k_mla_append_rows(const float* __restrict
   if ((tid & 63) == 0) red[tid >> 6] = ss;
   __syncthreads();
   ss = (red[0] + red[1]) + (red[2] + red[3]);
-  const float rs = 1.0f / sqrtf(ss / (float)R + eps);
+  const float rs = rms_scale(ss, (float)R, eps);
   const int Wd = R + DR;
   size_t wo = (size_t)layer * kv.layer_stride;
   if (kv.paged) wo += ((size_t)kv.block_table[pos / kv.bs] * kv.bs + (pos % kv.bs)) * Wd; else wo += (size_t)pos * Wd;

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(512) void k_llama_persist(PersistArgs a_in) {
     if (!dead && !lds_wait(&cnt[C_SS], e_ss)) dead = true;                                                                           \
     ssd = ((S.dred[0] + S.dred[1]) + (S.dred[2] + S.dred[3])) + ((S.dred[4] + S.dred[5]) + (S.dred[6] + S.dred[7]));                 \
     const float ss = (float)ssd;                                                                                                     \
-    const float rs = 1.0f / sqrtf(ss / (float)PH + a.eps);                                                                           \
+    const float rs = rms_scale(ss, (float)PH, a.eps);                                                                           \
     const float nwv[8] = {nwa.x, nwa.y, nwa.z, nwa.w, nwb.x, nwb.y, nwb.z, nwb.w};                                                   \
     float am = 0.f;                                                                                                                  \
     _Pragma("unroll") for (int e = 0; e < 8; e++) { x_[e] = round_t<ACT>(nwv[e] * round_t<ACT>(v[e] * rs)); am = fmaxf(am, fabsf(x_[e])); } \
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(512) void k_llama_persist(PersistArgs a_in) {
         ((unsigned*)((unsigned short*)kv.k + woff))[lane] = S.u.at.k2[lane];
         ((unsigned*)((unsigned short*)kv.v + woff))[lane] = S.u.at.v2[lane];
       }
-      const float scale = 1.0f / sqrtf((float)PHD);
+      const float scale = div_rn(1.0f, sqrt_rn((float)PHD));
       const uint4 qq = ((const uint4*)S.u.at.q2)[piece];
       float qf[8];
       unpack2<ACT>(qq.x, qf[0], qf[1]); unpack2<ACT>(qq.y, qf[2], qf[3]); unpack2<ACT>(qq.z, qf[4], qf[5]); unpack2<ACT>(qq.w, qf[6], qf[7]);
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(512) void k_llama_persist(PersistArgs a_in) {
         double oc = 0.0, Lc = 0.0;
 #pragma unroll
         for (int w = 0; w < NW; w++) { oc += S.u.at.pout[w * PHD + tid]; Lc += S.u.at.lred[w]; }
-        S.u.at.outh[tid] = round_t<ACT>((float)oc / (float)Lc);
+        S.u.at.outh[tid] = round_t<ACT>(div_rn((float)oc, (float)Lc));
         if (lane == 0) lds_signal(&cnt[C_OUT]);
       }
       e_out += 2;

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void k_pf_norm(float* hbuf, const float* prev,
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
   __syncthreads();
   ss = (red[0] + red[1]) + (red[2] + red[3]);
-  const float rs = 1.0f / sqrtf(ss / (float)H + eps);
+  const float rs = rms_scale(ss, (float)H, eps);
   for (int i = threadIdx.x; i < H; i += 256) x16[(size_t)blockIdx.x * H + i] = to16<DT>(pf_round(w[i] * pf_round(hr[i] * rs, act), act));
 }
 
@@ -577,7 +577,7 @@ __global__ __launch_bounds__(256) void k_pf_silu(const float* __restrict__ gu, i
   const float gv[4] = {g.x, g.y, g.z, g.w}, uv[4] = {u.x, u.y, u.z, u.w};
   unsigned short o[4];
 #pragma unroll
-  for (int e = 0; e < 4; e++) o[e] = to16<DT>(pf_round(pf_round(gv[e] / (1.0f + bz_expf(-gv[e])), act) * uv[e], act));
+  for (int e = 0; e < 4; e++) o[e] = to16<DT>(pf_round(pf_round(div_rn(gv[e], 1.0f + bz_expf(-gv[e])), act) * uv[e], act));
   uint2 w; w.x = o[0] | ((unsigned)o[1] << 16); w.y = o[2] | ((unsigned)o[3] << 16);
   *(uint2*)(a16 + (size_t)s * I + i) = w;
 }
@@ -860,7 +860,7 @@ __global__ void k_q4g_mfma_reduce(const float* __restrict__ part, int KS, size_t
 // registers and walks the tokens, so a prompt costs one pass over the state instead of a read-modify-write of it per token.
 // Arithmetic and rounding points are those of the decode-step kernels (k_ssm_step with its in-launch conv1d step, the GATED2 prologue).
 // ---------------------------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float pf_silu(float x) { return x / (1.0f + bz_expf(-x)); }
+__device__ __forceinline__ float pf_silu(float x) { return div_rn(x, 1.0f + bz_expf(-x)); }
 __device__ __forceinline__ float pf_softplus(float x) { return x > 20.0f ? x : log1pf(bz_expf(x)); }
 
 // out[t][ch] = R(silu(R(conv window + bias))): window = the kc-1 inputs before t (from the rows, or from the carried conv state) and in[t]
@@ -1050,7 +1050,7 @@ __global__ __launch_bounds__(256) void k_pf_gnorm(const float* __restrict__ v, c
     float ss = 0.f;
     for (int h = threadIdx.x & 63; h < hpg; h += 64) ss += vss[(size_t)t * NH + g * hpg + h];
     ss = wave_sum(ss);
-    if ((threadIdx.x & 63) == 0) rs[g] = 1.0f / sqrtf(ss / (float)gsz + eps);
+    if ((threadIdx.x & 63) == 0) rs[g] = rms_scale(ss, (float)gsz, eps);
   }
   __syncthreads();
   for (int i = threadIdx.x; i < DI; i += 256)
@@ -1273,7 +1273,7 @@ int bzk_pf_attn(hipStream_t s, int dt, const float* qkv, int S, int nq, int nkv,
   if (hd % 8 || hd > 256 || (256 % (hd / 8)) || (REP != 1 && REP != 2 && REP != 4 && REP != 8) || kv.dtype != dt)
     BZ_FAIL(BZ_E_UNSUPPORTED, "prefill attention: head_dim %d / group size %d / cache dtype unsupported", hd, REP);
   if (!row_pos && bzk_pf_attn_mfma_ok(hd, REP)) {
-    const float scale_m = 1.0f / sqrtf((float)hd);
+    const float scale_m = div_rn(1.0f, sqrt_rn((float)hd));
     const int HW = REP < 4 ? REP : 4, QT = 4 / HW;
     const dim3 grid((S + 32 * QT - 1) / (32 * QT), nkv, REP / HW);
     const double flops = 4.0 * nq * hd * ((double)S * pos0 + 0.5 * (double)S * S);
@@ -1291,7 +1291,7 @@ int bzk_pf_attn(hipStream_t s, int dt, const float* qkv, int S, int nq, int nkv,
   const int ctx = row_pos ? max_len : pos0 + S;
   const size_t smem = bzk_pf_attn_smem(nq, nkv, hd, ctx);
   if (smem > 160 * 1024) BZ_FAIL(BZ_E_UNSUPPORTED, "prefill attention: context %d too long for this kernel", ctx);
-  const float scale = 1.0f / sqrtf((float)hd);
+  const float scale = div_rn(1.0f, sqrt_rn((float)hd));
 #define LAUNCH_PFA(DT, R) do { \
     static bool attr_done = false; \
     if (!attr_done) { BZ_HIP(hipFuncSetAttribute((const void*)k_pf_attn<DT, DT, R>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_done = true; } \

@@ -32,8 +32,12 @@ for tok, pos in ((17, 0), (4242, 1), (99, 2)):
     print("token %d at position %d" % (tok, pos))
     for l in range(nl):
         # local: GPU layer l on the oracle's inputs (kv_l holds GPU-computed K/V of oracle-fed layers)
-        lh = dev.tensor(oh.astype(np.float32))
-        lpm = None if opm is None else dev.tensor(opm.astype(np.float32))
+        if os.environ.get("PRE_ADD"):      # the deferred residual added on the host: the layer starts without one (the persistent launch takes such steps)
+            lh = dev.tensor((oh if opm is None else (oh + opm).astype(np.float16)).astype(np.float32))
+            lpm = None
+        else:
+            lh = dev.tensor(oh.astype(np.float32))
+            lpm = None if opm is None else dev.tensor(opm.astype(np.float32))
         lh, lpm = lm.forward_layers_range(lh, lpm, kv_l, l, l + 1, pos)
         gh, gpm = lm.forward_layers_range(gh, gpm, kv_a, l, l + 1, pos)
         oh, opm = om.layers_range(oh, opm, okv, l, l + 1, pos)
