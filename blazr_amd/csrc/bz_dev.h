@@ -26,7 +26,7 @@ __device__ __forceinline__ float bf16_round(float x) {
   return __uint_as_float(u & 0xffff0000u);
 }
 __device__ __forceinline__ float round_act(float x, int act) {
-  if (act == BZ_F16) return __half2float(__float2half_rn(x));
+  if (act == BZ_F16) return f16_round(x);
   if (act == BZ_BF16) return bf16_round(x);
   return x;
 }
@@ -294,7 +294,7 @@ __device__ __forceinline__ void q4g_consume2_ab(const uint4 (&w)[NTOT], int g, c
 __device__ __forceinline__ long long d2fix(double p, int act) { return __double2ll_rn(p * fix_scale(act)); }
 
 template <int ACT> __device__ __forceinline__ float round_t(float x) {
-  if (ACT == BZ_F16) return __half2float(__float2half_rn(x));
+  if (ACT == BZ_F16) return f16_round(x);
   if (ACT == BZ_BF16) return bf16_round(x);
   return x;
 }
@@ -328,7 +328,7 @@ __device__ __forceinline__ float dot2acc(unsigned a, unsigned b, float c) {
 }
 template <int KVDT>
 __device__ __forceinline__ unsigned pack2(float x0, float x1) {
-  if (KVDT == BZ_F16) return (unsigned)__half_as_ushort(__float2half_rn(x0)) | ((unsigned)__half_as_ushort(__float2half_rn(x1)) << 16);
+  if (KVDT == BZ_F16) return (unsigned)__half_as_ushort(f16_cvt(x0)) | ((unsigned)__half_as_ushort(f16_cvt(x1)) << 16);
   return (__float_as_uint(bf16_round(x0)) >> 16) | (__float_as_uint(bf16_round(x1)) & 0xffff0000u);
 }
 template <int KVDT>

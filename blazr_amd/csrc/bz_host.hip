@@ -1476,6 +1476,10 @@ static int llama_step(bz_model* m, const StepIO& io) {
           for (int i = 0; i < 18; i++) fprintf(stderr, " %d:%.2f", i, hs[(g * 8 + w) * 32 + i] ? (hs[(g * 8 + w) * 32 + i] - t0) / 100.0 : -1.0);
           fprintf(stderr, "\n");
         }
+      { double d; float f1, f2; memcpy(&d, &hs[24], 8); int i1 = (int)hs[25], i2 = (int)hs[26]; memcpy(&f1, &i1, 4); memcpy(&f2, &i2, 4);
+        fprintf(stderr, "[bz] persist row update (last one of the launch, wg 0): ssd %.17g ss %.9g rs %.9g; wave sums:", d, f1, f2);
+        for (int w8 = 0; w8 < 8; w8++) { memcpy(&d, &hs[32 + w8], 8); fprintf(stderr, " %.17g", d); }
+        fprintf(stderr, "\n"); }
     }
     cur ^= 1;
     // ring state after the launch: ring[0] = the last MLP's output (the deferred residual), ring[1] zeroed in its last phase, ring[2] read but not zeroed

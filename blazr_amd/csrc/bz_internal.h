@@ -486,6 +486,19 @@ __host__ __device__ __forceinline__ float bz_expf(float x) {
   __builtin_memcpy(&sc, &sb, 4);
   return y * sc;
 }
+// f32 -> f16 with the f32 value MATERIALISED first.  Under hipcc's default -ffp-contract=fast the pair "f32 multiply, convert to f16" is fused into
+// v_fma_mixlo_f16, which rounds the EXACT product to f16 once; the oracle (and every kernel whose conversion sits behind a run-time dtype switch) rounds the
+// product to f32 and then to f16.  The two differ whenever the f32 rounding lands on or crosses an f16 midpoint: measured in round 3 on the slim q/k/v
+// kernel (scripts/qkv_dump.py), 5 of the 4096 normalised activations of one layer came out as the other f16 neighbour -- which moved every q/k/v column of
+// that layer by ~1e-4.  The empty asm makes the operand opaque, so the multiply keeps its own rounding.
+__device__ __forceinline__ float f16_round(float x) {
+  asm volatile("" : "+v"(x));
+  return __half2float(__float2half_rn(x));
+}
+__device__ __forceinline__ __half f16_cvt(float x) {
+  asm volatile("" : "+v"(x));
+  return __float2half_rn(x);
+}
 // Correctly rounded f32 quotient / square root through double (53 >= 2 * 24 + 2 bits: the double result rounds to the correctly rounded float).  Written out
 // because hipcc does not always give `a / b` and `1.0f / sqrtf(x)` the IEEE sequence: measured in round 3 (scripts/qkv_dump.py), the slim q/k/v kernel's
 // 1 / rms came out ONE ULP LOW next to the generic kernel's (same source expression) -- five of 4096 normalised activations then round to the other f16

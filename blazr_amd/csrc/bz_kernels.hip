@@ -2710,7 +2710,7 @@ __global__ void k_repack_awq(const uint32_t* qw, const float* sc, const float* z
     const int g = (int)(t % (size_t)G);
     const int nt = (int)(t / (size_t)G);
     const int n = nt * 64 + lane;
-    sout[idx] = __float2half_rn(sc[(size_t)g * N + n]);
+    sout[idx] = f16_cvt(sc[(size_t)g * N + n]);
     zout[idx] = (unsigned char)(int)zf[(size_t)g * N + n];
   }
 }
@@ -2747,7 +2747,7 @@ __global__ void k_repack_gptq(const uint32_t* qw, const float* sc, const uint32_
     const int n = nt * 64 + lane;
     // original group id of the sorted group: g_idx of its first member (all members share it)
     const int g = (perm && gidx) ? gidx[perm[gp * gs]] : gp;
-    sout[idx] = __float2half_rn(sc[(size_t)g * N + n]);
+    sout[idx] = f16_cvt(sc[(size_t)g * N + n]);
     zout[idx] = (unsigned char)(((qz[(size_t)g * (N >> 3) + (n >> 3)] >> (4 * (n & 7))) & 15u) + 1u);  // ASSUMPTION: AutoGPTQ v1 (+1)
   }
 }
@@ -2864,7 +2864,7 @@ __device__ __forceinline__ float kv_ld(const void* base, size_t off, int dt) {
   return ((const float*)base)[off];
 }
 __device__ __forceinline__ void kv_st(void* base, size_t off, int dt, float v) {
-  if (dt == BZ_F16) ((__half*)base)[off] = __float2half_rn(v);
+  if (dt == BZ_F16) ((__half*)base)[off] = f16_cvt(v);
   else if (dt == BZ_BF16) ((unsigned short*)base)[off] = (unsigned short)(__float_as_uint(bf16_round(v)) >> 16);
   else ((float*)base)[off] = v;
 }
@@ -2921,7 +2921,7 @@ struct KvRow {
 #pragma unroll
         for (int j = 0; j < 4; j++) {
           const float x0 = src[i * 8 + 2 * j], x1 = src[i * 8 + 2 * j + 1];
-          if (KVDT == BZ_F16) u[j] = (unsigned)__half_as_ushort(__float2half_rn(x0)) | ((unsigned)__half_as_ushort(__float2half_rn(x1)) << 16);
+          if (KVDT == BZ_F16) u[j] = (unsigned)__half_as_ushort(f16_cvt(x0)) | ((unsigned)__half_as_ushort(f16_cvt(x1)) << 16);
           else u[j] = (__float_as_uint(bf16_round(x0)) >> 16) | (__float_as_uint(bf16_round(x1)) & 0xffff0000u);
         }
         raw[i] = make_uint4(u[0], u[1], u[2], u[3]);
@@ -4304,7 +4304,7 @@ __global__ __launch_bounds__(64 * PARTS) void k_ssm_step(SsmArgs a) {
           const float hn = round_act(hcur * dA + dtx * sB[q * nq + n], a.act);
           acc += hn * sC[q * nq + n];
           if (SDT == BZ_F32) ((float*)a.state)[off + n] = hn;
-          else if (SDT == BZ_F16) ((__half*)a.state)[off + n] = __float2half_rn(hn);
+          else if (SDT == BZ_F16) ((__half*)a.state)[off + n] = f16_cvt(hn);
           else ((unsigned short*)a.state)[off + n] = (unsigned short)(__float_as_uint(bf16_round(hn)) >> 16);
         }
       }

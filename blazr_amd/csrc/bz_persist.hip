@@ -213,7 +213,7 @@ __global__ __launch_bounds__(512) void k_llama_persist(PersistArgs a_in) {
 
   // ---- row update: h <- R(h + R(acc)) in LDS, exact sum of squares over the workgroup, x = R(w R(h rs)) -> this thread's plane words ------------------
   //      (HASACC = false: the first layer's row has nothing to add).  Leaves x's eight plane words in w[], the group sums in sp[], the scale in cs.
-#define ROW_UPDATE(ACCPTR, HASACC, WRITE_OUT)                                                                                        \
+#define ROW_UPDATE(ACCPTR, HASACC, WRITE_OUT, DBG)                                                                                        \
   float x_[8]; unsigned w_[XQ_NP]; int sp_[XQ_NP]; float cs_; int4 g2w_;                                                             \
   {                                                                                                                                  \
     const float4 ha = *(const float4*)(S.hres + i0), hb = *(const float4*)(S.hres + i0 + 4);                                         \
@@ -235,6 +235,8 @@ __global__ __launch_bounds__(512) void k_llama_persist(PersistArgs a_in) {
     ssd = ((S.dred[0] + S.dred[1]) + (S.dred[2] + S.dred[3])) + ((S.dred[4] + S.dred[5]) + (S.dred[6] + S.dred[7]));                 \
     const float ss = (float)ssd;                                                                                                     \
     const float rs = rms_scale(ss, (float)PH, a.eps);                                                                           \
+    if (a.stamps && wg == 0 && tid == 0) { a.stamps[24 + 64 * (DBG)] = __double_as_longlong(ssd); a.stamps[25 + 64 * (DBG)] = __float_as_int(ss); a.stamps[26 + 64 * (DBG)] = __float_as_int(rs); \
+      for (int w8 = 0; w8 < 8; w8++) a.stamps[32 + 64 * (DBG) + w8] = __double_as_longlong(S.dred[w8]); }                                         \
     const float nwv[8] = {nwa.x, nwa.y, nwa.z, nwa.w, nwb.x, nwb.y, nwb.z, nwb.w};                                                   \
     float am = 0.f;                                                                                                                  \
     _Pragma("unroll") for (int e = 0; e < 8; e++) { x_[e] = round_t<ACT>(nwv[e] * round_t<ACT>(v[e] * rs)); am = fmaxf(am, fabsf(x_[e])); } \
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(512) void k_llama_persist(PersistArgs a_in) {
     // =====================================================================================================================
     PSTAMP(0);
     {
-      ROW_UPDATE(a.ring_m, l > 0, false)
+      ROW_UPDATE(a.ring_m, l > 0, false, 0)
       PSTAMP(1);
       const int so = oct - q_osl;                                    // this thread's octet inside the slice (0..31) when it lies there
       if (so >= 0 && so < 32) {
@@ -455,7 +457,7 @@ __global__ __launch_bounds__(512) void k_llama_persist(PersistArgs a_in) {
     // =====================================================================================================================
     {
       {
-        ROW_UPDATE(a.ring_o, true, (l == a.n_layers - 1 && wg == 0))
+        ROW_UPDATE(a.ring_o, true, (l == a.n_layers - 1 && wg == 0), 1)
         unsigned* plw = (unsigned*)S.xpl + ((oct >> 2) * XQ_NP) * 4 + (oct & 3);
 #pragma unroll
         for (int p = 0; p < XQ_NP; p++) plw[p * 4] = w_[p];

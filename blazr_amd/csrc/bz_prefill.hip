@@ -30,12 +30,12 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ float pf_round(float x, int act) {
-  if (act == BZ_F16) return __half2float(__float2half_rn(x));
+  if (act == BZ_F16) return f16_round(x);
   if (act == BZ_BF16) return (float)(__bf16)x;     // v_cvt_pk_bf16_f32 (round to nearest even) + shift
   return x;
 }
 template <int DT> __device__ __forceinline__ unsigned short to16(float x) {
-  if (DT == BZ_F16) return __half_as_ushort(__float2half_rn(x));
+  if (DT == BZ_F16) return __half_as_ushort(f16_cvt(x));
   const __bf16 b = (__bf16)x; return __builtin_bit_cast(unsigned short, b);
 }
 template <int DT> __device__ __forceinline__ float from16(unsigned short b) {
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(64) void k_pf_rope_kv(float* qkv, int nq, int nkv, 
     void* base = isv ? kv.v : kv.k;
     for (int i = threadIdx.x; i < hd; i += 64) {
       const float x = v[i];
-      if (kv.dtype == BZ_F16) ((__half*)base)[off + i] = __float2half_rn(x);
+      if (kv.dtype == BZ_F16) ((__half*)base)[off + i] = f16_cvt(x);
       else if (kv.dtype == BZ_BF16) ((unsigned short*)base)[off + i] = to16<BZ_BF16>(x);
       else ((float*)base)[off + i] = x;
     }
@@ -907,18 +907,18 @@ template <int SDT> __device__ __forceinline__ float st_load(const void* p, size_
 }
 template <int SDT> __device__ __forceinline__ void st_store(void* p, size_t i, float v) {
   if (SDT == BZ_F32) ((float*)p)[i] = v;
-  else if (SDT == BZ_F16) ((__half*)p)[i] = __float2half_rn(v);
+  else if (SDT == BZ_F16) ((__half*)p)[i] = f16_cvt(v);
   else ((unsigned short*)p)[i] = to16<BZ_BF16>(v);
 }
 template <int SDT> __device__ __forceinline__ float st_round(float v) {     // what a store + load of the state dtype does to a value
   if (SDT == BZ_F32) return v;
-  if (SDT == BZ_F16) return __half2float(__float2half_rn(v));
+  if (SDT == BZ_F16) return f16_round((v));
   return from16<BZ_BF16>(to16<BZ_BF16>(v));
 }
 
 // compile-time rounding to the activation dtype (bf16: v_cvt_pk_bf16_f32 + shift, two instructions on gfx950)
 template <int ACT> __device__ __forceinline__ float rnd(float x) {
-  if constexpr (ACT == BZ_F16) return __half2float(__float2half_rn(x));
+  if constexpr (ACT == BZ_F16) return f16_round(x);
   else if constexpr (ACT == BZ_BF16) return (float)(__bf16)x;
   else return x;
 }

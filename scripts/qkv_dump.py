@@ -27,6 +27,9 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     np.save(sys.argv[3] + ".h.npy", h)
     kv = runtime.LayeredKvCache(dev, layer + 1, 1, cfg["n_kv_heads"], 8, cfg["max_seq_len"], cfg["head_dim"], L.F16)
     lm.forward_layers_range(dev.tensor(h), None, kv, layer, layer + 1, 0)
+    dev.synchronize()
+    hd = h.astype(np.float64).reshape(-1)
+    print("exact sum of squares %.17g; per 512-element wave share: %s" % (float((hd ** 2).sum()), " ".join("%.17g" % float((hd[i * 512:(i + 1) * 512] ** 2).sum()) for i in range(8))), file=sys.stderr)
     dev.close()
     sys.exit(0)
 
