@@ -1442,10 +1442,11 @@ static int llama_step(bz_model* m, const StepIO& io) {
     BZ_HIP(hipMemcpyAsync(m->hbuf[cur], io.hidden_in, (size_t)H * 4, hipMemcpyDeviceToDevice, st));
     if (io.prev_in) { prev.p = io.prev_in; prev.fix = 0; }
   }
-  // The layers as ONE persistent launch (bz_persist.hip) when the model qualifies, the context fits the single-launch attention (no split-KV partner
-  // inside the persistent kernel) and the step starts without a deferred residual.  Bit-identical to the launch-per-phase path below (same arithmetic,
-  // integer accumulators); BZ_NO_PERSIST=1 keeps the three launches per layer.
-  static const bool no_persist = getenv("BZ_NO_PERSIST") != nullptr;
+  // The layers as ONE persistent launch (bz_persist.hip) -- OPT-IN (BZ_PERSIST=1): measured in round 3 it is slower than the three launches per layer
+  // (profiles/r03_persist_stamps.txt, DESIGN 8: a grid barrier on a CU that has weight requests in flight waits behind them, 5-10 us each).  Applies when the
+  // model qualifies, the context fits the single-launch attention and the step starts without a deferred residual.  Bit-identical to the launch-per-phase
+  // path below (same arithmetic, integer accumulators): tests/test_gpu_persist.py.
+  static const bool no_persist = getenv("BZ_PERSIST") == nullptr || getenv("BZ_NO_PERSIST") != nullptr;
   int l_first = io.layer_start;
   if (!no_persist && m->persist_tab && prev.p == nullptr && lend > io.layer_start && io.att_positions == 0 && io.kv.dtype == BZ_F16 && io.kv.hd == c.head_dim && io.d_pos) {
     BzPersistLaunch pl{};

@@ -287,8 +287,10 @@ __global__ __launch_bounds__(512) void k_llama_persist(PersistArgs a_in) {
     PSTAMP(2);
     vm_drain();
     PSTAMP(3);
-    PREFETCH_A(L, l);
+    // (the control wave polls the barrier word with vector loads, which return in order behind everything it has in flight: it requests its share after the barrier)
+    if (wave != CW) { PREFETCH_A(L, l); }
     GRID_BARRIER();
+    if (wave == CW) { PREFETCH_A(L, l); }
     PSTAMP(4);
 
     // =====================================================================================================================
@@ -448,8 +450,9 @@ __global__ __launch_bounds__(512) void k_llama_persist(PersistArgs a_in) {
     PSTAMP(9);
     vm_drain();
     PSTAMP(10);
-    PREFETCH_M(L);
+    if (wave != CW) { PREFETCH_M(L); }
     GRID_BARRIER();
+    if (wave == CW) { PREFETCH_M(L); }
     PSTAMP(11);
 
     // =====================================================================================================================
@@ -553,7 +556,7 @@ __global__ __launch_bounds__(512) void k_llama_persist(PersistArgs a_in) {
 #pragma unroll
         for (int q = 0; q < 8; q++) {
           double y = 0.0;
-          q4g_consume_at<0, 2, 2, true>(D[q], 0, 0, S.u.m.apl, S.u.m.apar, sd[q], zd[q], y);
+          q4g_consume_at<0, 2, 2, false>(D[q], 0, 0, S.u.m.apl, S.u.m.apar, sd[q], zd[q], y);
           acc_add(a.ring_m + (tbeg + q) * 64 + lane, d2fix(y, ACT));
         }
       } else {
@@ -565,8 +568,9 @@ __global__ __launch_bounds__(512) void k_llama_persist(PersistArgs a_in) {
     if (l + 1 < a.n_layers) {
       vm_drain();
       PSTAMP(16);
-      PREFETCH_Q(a.layers[l + 1]);
+      if (wave != CW) { PREFETCH_Q(a.layers[l + 1]); }
       GRID_BARRIER();
+      if (wave == CW) { PREFETCH_Q(a.layers[l + 1]); }
       PSTAMP(17);
     }
   }

@@ -1,6 +1,7 @@
 """The persistent decode launch (blazr_amd/csrc/bz_persist.hip: all layers of a step in ONE launch, weights of the next phase requested before every grid
 barrier) against the launch-per-phase path and the oracle.  Same arithmetic and integer accumulators on both GPU paths => logits, K/V cache rows and greedy ids
-must be IDENTICAL BITS; the launch-per-phase reference runs in a second process with BZ_NO_PERSIST=1 (the library reads its switches once).
+must be IDENTICAL BITS.  The persistent launch is opt-in (BZ_PERSIST=1: measured slower than the launches), so it runs in a second process with the
+switch set (the library reads its switches once).
 Reference anchors: /root/reference/src/engine/cuda_graphs.rs:97-170 (what one graph-mode step computes), executor_generate.rs:357,372."""
 import os
 import subprocess
@@ -67,16 +68,17 @@ def _run(tmp_path, name, env_extra):
 
 @pytest.mark.watchdog(1000)
 def test_persistent_step_is_bit_identical_to_the_launch_per_phase_step(tmp_path):
-    a = _run(tmp_path, "persist", {})
-    b = _run(tmp_path, "phases", {"BZ_NO_PERSIST": "1"})
+    a = _run(tmp_path, "persist", {"BZ_PERSIST": "1"})
+    b = _run(tmp_path, "phases", {})
     for k in ("rows0", "rows1", "k", "v", "ids_graph", "ids_eager", "ids_paged_graph"):
         assert np.array_equal(a[k], b[k]), (k, int((a[k] != b[k]).sum()))
     assert np.array_equal(a["rows0"], a["rows1"])                    # paged == contiguous, bit for bit
     assert a["ids_graph"].tolist() == a["ids_eager"].tolist() == a["ids_paged_graph"].tolist()
 
 
-def test_persistent_step_matches_the_oracle(device):
-    """the same path against the CPU oracle at the real layer widths (3 layers): logits at the north-star bar, every step"""
+def test_decode_step_matches_the_oracle_to_1e_4(device):
+    """the default decode path against the CPU oracle at the real layer widths (3 layers): every sub-op of the int4 path is bit-identical to the oracle's
+    (scripts/parity_depth.py: zero differing elements per layer), what remains is the dense lm_head's f32 summation order: 1e-4, every step"""
     model = synth.make_llama("llama3-8b-awq-2l", n_layers=3)
     cfg = model["config"]
     lm, om = runtime.LoadedModel.from_synth(device, model), orc_py.OrcLlama(model)
@@ -88,7 +90,7 @@ def test_persistent_step_matches_the_oracle(device):
         lg = lm.forward_with_kv_cache([tok], kv, i).to_numpy().reshape(-1)
         err = float(np.linalg.norm(lg.astype(np.float64) - lo) / np.linalg.norm(lo))
         worst = max(worst, err)
-        assert err <= 1e-3, (i, err)
+        assert err <= 1e-4, (i, err)
         tok = int(lo.argmax())
-    print("persistent step vs oracle, 3 layers at 8B widths, 24 steps: worst relative L2 %.3e" % worst)
+    print("decode step vs oracle, 3 layers at 8B widths, 24 steps: worst relative L2 %.3e" % worst)
     orc_py.lib().orc_kv_free(okv)
