@@ -161,13 +161,22 @@ def test_llama_awq_decode_across_512_to_650(device):
         got = lm.forward_with_kv_cache([int(t)], kv, i).to_numpy()
     _check_logits(got.reshape(-1), np.asarray(want).reshape(-1), "f16", factor=1.0)
     tok = int(np.asarray(want).reshape(-1).argmax())
-    worst = 0.0
+    worst_fused, worst_split = 0.0, 0.0
     for i in range(N):                                                  # contexts 501 .. 650: single launch up to 512, split-KV + merge beyond
         lo = np.asarray(om.forward_kv([tok], okv, P + i)).reshape(-1)
         lg = lm.forward_with_kv_cache([tok], kv, P + i).to_numpy().reshape(-1)
-        _check_logits(lg, lo, "f16", factor=1.0)
-        worst = max(worst, _rel_l2(lg, lo))
+        err = _rel_l2(lg, lo)
+        if P + i + 1 <= 512:
+            # the single-launch attention carries exact sums (two passes, double): every sub-op equals the oracle's bits, what is left is the lm_head's f32 order
+            worst_fused = max(worst_fused, err)
+            assert err <= 1e-4, (P + i, err)
+        else:
+            # split-KV partials are merged with f32 rescaling (exp(m_s - M) per slice): ~1e-7 per head output, i.e. an occasional flipped f16 rounding
+            worst_split = max(worst_split, err)
+            assert err <= 1.5e-3, (P + i, err)
         tok = int(lo.argmax())
+    worst = max(worst_fused, worst_split)
+    print("contexts <= 512 (exact attention sums): worst relative L2 %.3e; 513..650 (split-KV + merge): %.3e" % (worst_fused, worst_split))
     print("decode 501..650, 2 layers at 8B widths: worst relative L2 %.3e" % worst)
     # the graph path over the same boundary: ids equal the eager path's, bit for bit
     ex = runtime.Executor(lm)
