@@ -472,14 +472,18 @@ __global__ __launch_bounds__(NW * 64) void k_mlp_q4g(const uint4* __restrict__ W
       for (int q = 0; q < TPW; q++) {
         const uint4* wp = Wd + ((size_t)(tbeg + q) * (I >> 5) + 2 * sl) * 64 + lane;
         D[q][0] = ldnt(wp); D[q][1] = ldnt(wp + 64);
-        const size_t si = ((size_t)(tbeg + q) * GD + gd) * 64 + lane;
-        sd[q] = __half2float(Sd[si]); zd[q] = Zd[si];
       }
     }
   }
   MSTAMP(9);
   part[wave * 128 + lane] = yg;
   part[wave * 128 + 64 + lane] = yu;
+  // the slab's scales / zero points (L2-resident): requested here, under the partial-sum barrier and the tail -- eight registers less across the second group's dots
+#pragma unroll
+  for (int q = 0; q < TPW; q++) {
+    const size_t si = ((size_t)(tbeg + q) * GD + gd) * 64 + lane;
+    sd[q] = __half2float(Sd[si]); zd[q] = Zd[si];
+  }
   __syncthreads();
   MSTAMP(10);
   // (6) wave 0: sum of the waves' k-range partials (exact, fixed order), ONE rounding to f32 (the oracle's definition), + bias, R, SiLU * up,
