@@ -97,10 +97,12 @@ def main():
     ap.add_argument("--prompt-seed", type=int, default=26)
     ap.add_argument("--reps", type=int, default=3)           # timed runs of exactly --steps steps each; the median is reported
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true")     # skip the TTFT / ITL matrix of the reference's bench (prompt 32 / 128 / 512)
     ap.add_argument("--cpu-tokens", type=int, default=32)    # ~10 s of CPU work on the GPU box's host cores (bounded sample)
-    # OpenMP threads of the CPU baseline; 0 = min(logical CPUs, 64) -- the GEMVs are memory-bound on the host, more threads than memory channels
-    # buy nothing (SURVEY 8d planned OMP_NUM_THREADS = nproc; the count actually used is what `cpu_baseline.cores` reports)
-    ap.add_argument("--cpu-threads", type=int, default=0)
+    # OpenMP threads of the CPU baseline (SURVEY 8d planned OMP_NUM_THREADS = nproc; the count actually used is what `cpu_baseline.cores` reports).  Default 16:
+    # measured on the GPU box (256 logical CPUs, its share for one GPU is 16), 64 threads gave 2.6 tok/s against 3.4 with 16 -- the GEMVs are bound by
+    # the host's memory system, and oversubscribing the share only adds contention
+    ap.add_argument("--cpu-threads", type=int, default=16)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -211,7 +213,7 @@ def main():
     if want_cpu:
         # CPU baseline: the oracle (a port -- BASELINE.md 4), same weights, same prompt, bounded sample; and the parity gate
         from oracle import orc_py
-        orc_py.set_threads(args.cpu_threads if args.cpu_threads > 0 else min(os.cpu_count() or 1, 64))
+        orc_py.set_threads(max(1, min(args.cpu_threads, os.cpu_count() or 1)))
         model = dict(config=cfg, embed=emb, final_norm=fnorm, lm_head=lmh, layers=host_layers)
         om = orc_py.OrcLlama(model)
         n_cpu = max(2, args.cpu_tokens)
@@ -290,11 +292,37 @@ def main():
         out["prefill"] = {"tokens": pf_len, "ms": round(best, 3), "tokens_per_s": round(pf_len / (best / 1e3), 1), "gemm_tflops": round(2.0 * lin * pf_len / (best / 1e3) / 1e12, 2),
                           "mfma_peak_tflops": 2500.0, "frac_of_mfma_peak": round(2.0 * lin * pf_len / (best / 1e3) / 2.5e15, 4), "runs_ms": [round(v, 3) for v in pf_ms],
                           "note": "whole prompt phase of a 512-token prompt (norms, GEMMs on the matrix cores, RoPE / cache append, flash attention), not part of `value`"}
+    # the reference bench's own report (cli/bench.rs:24-33,142-160): prompt lengths 32 / 128 / 512, 1 warm-up + 3 measured generations of `--steps` tokens
+    # each through the whole generate loop (prefill, first token, graph capture, one replay per token, event-synchronised token reads); TTFT / total: median
+    # over the runs, inter-token latency: percentiles over all gaps of all runs, decode tok/s = (tokens - 1) / (total - TTFT), median.  Not part of `value`.
+    if rank == 0 and not args.no_latency:
+        out["latency"] = latency_matrix(runtime, synth, lm, cfg, max(args.steps, 16))
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def latency_matrix(runtime, synth, lm, cfg, n_decode, lengths=(32, 128, 512), warm=1, runs=3):
+    ex = runtime.Executor(lm)
+    rows = []
+    for pl in lengths:
+        if pl + n_decode + 8 > cfg["max_seq_len"]:
+            continue
+        prompt = synth.prompt_tokens(pl, cfg["vocab"], seed=100 + pl)
+        stats = []
+        for r in range(warm + runs):
+            ex.generate(prompt, n_decode, use_graph=True)
+            if r >= warm:
+                stats.append(dict(ex.last_stats))
+        med = lambda k: float(np.median([s[k] for s in stats]))   # noqa: E731
+        rows.append({"prompt_tokens": pl, "decode_tokens": n_decode, "runs": runs,
+                     "ttft_ms": {"median": round(med("ttft_ms"), 3), "samples": [round(s["ttft_ms"], 3) for s in stats]},
+                     "decode_tok_per_sec": {"median": round(med("decode_tok_per_s"), 2), "samples": [round(s["decode_tok_per_s"], 2) for s in stats]},
+                     "total_ms": {"median": round(med("total_ms"), 3)},
+                     "itl_ms": {"p50": round(med("itl_p50_ms"), 4), "p99": round(max(s["itl_p99_ms"] for s in stats), 4), "max": round(max(s["itl_max_ms"] for s in stats), 4)}})
+    return rows
 
 
 def bench_aux(args, rank, local_rank, world, dist):
@@ -373,6 +401,8 @@ def bench_aux(args, rank, local_rank, world, dist):
                       "tflops": round(pf_flops / (prefill_ms / 1e3) / 1e12, 2), "mfma_peak_tflops": 2500.0,
                       "frac_of_mfma_peak": round(pf_flops / (prefill_ms / 1e3) / 2.5e15, 4), "runs_ms": [round(v, 3) for v in pf_ms],
                       "note": "whole prompt phase (GEMMs on the matrix cores + attention / scan + routing), 2 x active weights x tokens FLOP"}
+    if rank == 0 and not args.no_latency:
+        out["latency"] = latency_matrix(runtime, synth, lm, cfg, max(args.steps, 16))
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

@@ -23,7 +23,7 @@ atexit.register(_at_exit)
 
 OK, E_INVALID, E_NODEVICE, E_HIP, E_UNSUPPORTED, E_NOTFOUND, E_OOM = 0, -1, -2, -3, -4, -5, -6
 F32, F16, BF16, I64, I32, U32, U8 = range(7)
-ABI_VERSION = 3
+ABI_VERSION = 4
 FWD_ALL_LOGITS = 1
 ROPE_NONE, ROPE_LINEAR, ROPE_LLAMA3, ROPE_YARN = 0, 1, 2, 3
 ARCH_LLAMA = 0
@@ -87,7 +87,8 @@ class KernelTime(C.Structure):
 
 class GenStats(C.Structure):
     _fields_ = [("prefill_ms", C.c_double), ("decode_ms", C.c_double), ("n_generated", C.c_int32),
-                ("finish_reason", C.c_int32)]
+                ("finish_reason", C.c_int32), ("ttft_ms", C.c_double), ("total_ms", C.c_double), ("itl_p50_ms", C.c_double),
+                ("itl_p99_ms", C.c_double), ("itl_max_ms", C.c_double), ("decode_tok_per_s", C.c_double)]
 
 
 # name -> (restype, argtypes); every symbol include/blazr_hip.h declares

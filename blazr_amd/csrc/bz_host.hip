@@ -3138,11 +3138,16 @@ extern "C" int bz_generate(bz_model* m, const int64_t* prompt, int n_prompt, con
   bz_tensor *t_prompt = nullptr, *t_logits = nullptr, *t_tok = nullptr, *t_ids = nullptr, *t_cnts = nullptr, *t_slot = nullptr, *t_bt = nullptr;
   bz_kv* kv = nullptr; bz_paged_kv* pkv = nullptr; bz_decode_graph* graph = nullptr; bz_ssm_state* ssm = nullptr; bz_mirostat* mstate = nullptr;
   const bool mamba = c.arch == BZ_ARCH_MAMBA2;   // executor_generate.rs:123-181
+  auto mamba_arch = [](const bz_model_config& cc) { return cc.arch == BZ_ARCH_MAMBA2; };
   std::vector<uint32_t> history(prompt, prompt + n_prompt);
   std::vector<int32_t> bt;
   int n_out = 0, finish = 0;
   auto T0 = std::chrono::steady_clock::now();
   auto T1 = T0;
+  std::vector<std::chrono::steady_clock::time_point> tok_t;   // host arrival time of every generated token (cli/bench.rs:285-292: TTFT, inter-token latency)
+  tok_t.reserve((size_t)std::max(max_tokens, 0));
+  const char* backend = mamba_arch(c) ? "mamba2" : (gc->paged ? "paged" : "contiguous");
+  BZ_TRACE("phase=\"prefill_start\" backend=\"%s\" prompt_tokens=%d", backend, n_prompt);   // executor_generate.rs:136,252,355
   int64_t sh1[1] = {1}, shp[1] = {n_prompt}, shv[2] = {1, c.vocab}, sh64[1] = {4096};
 #define GEN_TRY(x) do { rc = (x); if (rc != BZ_OK) goto done; } while (0)
   GEN_TRY(bz_tensor_from_host(dev, BZ_I64, shp, 1, prompt, &t_prompt));
@@ -3174,25 +3179,30 @@ extern "C" int bz_generate(bz_model* m, const int64_t* prompt, int n_prompt, con
   }
   GEN_TRY(bz_device_synchronize(dev));
   T1 = std::chrono::steady_clock::now();
-  BZ_TRACE("generate: prefill of %d tokens done (graph=%d paged=%d)", n_prompt, gc->use_graph, gc->paged);
+  BZ_TRACE("phase=\"prefill_end\" backend=\"%s\"", backend);                                   // :139,264,360
+  BZ_TRACE("phase=\"decode_start\" backend=\"%s\" max_tokens=%d graph=%d", backend, max_tokens, gc->use_graph);   // :140,265,361
 
   if (gc->use_graph) {
     // cuda_graphs.rs:149-189: first token from the prefill logits, then one graph launch per token
     int64_t tok;
     GEN_TRY(bz_argmax_to_buf(dev, t_logits, 1, c.vocab, t_tok));
     GEN_TRY(bz_tensor_to_host(t_tok, &tok, 8));
+    const auto t_first = std::chrono::steady_clock::now();   // the first token is on the host here; capturing the graph comes after it
     if (mamba) GEN_TRY(bz_decode_graph_capture_ssm(m, ssm, &graph));
     else if (gc->paged) { GEN_TRY(bz_decode_graph_capture_paged(m, pkv, (int)bt.size(), &graph)); GEN_TRY(bz_decode_graph_set_block_table(graph, bt.data(), (int)bt.size())); }
     else GEN_TRY(bz_decode_graph_capture(m, kv, &graph));
     GEN_TRY(bz_decode_graph_seed(graph, tok, n_prompt));
     BZ_TRACE("generate: graph captured and seeded with token %lld at position %d", (long long)tok, n_prompt);
     for (int i = 0; i < max_tokens; i++) {
-      out_tokens[n_out++] = tok; history.push_back((uint32_t)tok);
+      out_tokens[n_out++] = tok; history.push_back((uint32_t)tok); tok_t.push_back(i == 0 ? t_first : std::chrono::steady_clock::now());
       if (tok == gc->eos_id) { finish = 1; break; }
       if (i + 1 == max_tokens) break;
+      auto tl0 = std::chrono::steady_clock::now();
       GEN_TRY(bz_decode_graph_replay(graph));
+      auto tl1 = std::chrono::steady_clock::now();
       GEN_TRY(bz_decode_graph_read_token(graph, i, &tok));
-      BZ_TRACE("generate: replay %d -> token %lld", i, (long long)tok);
+      BZ_TRACE("step=%d token=%lld fwd_launch_us=%.1f sync_us=%.1f", i, (long long)tok, std::chrono::duration<double, std::micro>(tl1 - tl0).count(),
+               std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tl1).count());   // :313,394 fwd_launch / sync split
     }
   } else {
     std::vector<int64_t> ids; std::vector<int32_t> cnts;
@@ -3242,9 +3252,10 @@ extern "C" int bz_generate(bz_model* m, const int64_t* prompt, int n_prompt, con
         }
       }
       int64_t tok;
+      auto ts0 = std::chrono::steady_clock::now();
       GEN_TRY(bz_tensor_to_host_pipelined(t_tok, ev, &tok, 8));                      // :378 read_token_id
-      BZ_TRACE("generate: step %d -> token %lld", i, (long long)tok);
-      out_tokens[n_out++] = tok; history.push_back((uint32_t)tok);
+      BZ_TRACE("step=%d token=%lld sync_us=%.1f", i, (long long)tok, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - ts0).count());
+      out_tokens[n_out++] = tok; history.push_back((uint32_t)tok); tok_t.push_back(std::chrono::steady_clock::now());
       if (tok == gc->eos_id) { finish = 1; break; }
     }
   }
@@ -3252,10 +3263,25 @@ extern "C" int bz_generate(bz_model* m, const int64_t* prompt, int n_prompt, con
 done:
   {
     auto T2 = std::chrono::steady_clock::now();
+    BZ_TRACE("phase=\"decode_end\" backend=\"%s\" generated=%d", backend, n_out);                // :181,340,409
     if (stats) {
+      memset(stats, 0, sizeof(*stats));
       stats->prefill_ms = std::chrono::duration<double, std::milli>(T1 - T0).count();
       stats->decode_ms = std::chrono::duration<double, std::milli>(T2 - T1).count();
       stats->n_generated = n_out; stats->finish_reason = finish;
+      if (!tok_t.empty()) {   // cli/bench.rs:285-306
+        auto ms = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(t - T0).count(); };
+        stats->ttft_ms = ms(tok_t.front()); stats->total_ms = ms(tok_t.back());
+        std::vector<double> itl;
+        for (size_t i = 1; i < tok_t.size(); i++) itl.push_back(std::chrono::duration<double, std::milli>(tok_t[i] - tok_t[i - 1]).count());
+        if (!itl.empty()) {
+          std::sort(itl.begin(), itl.end());
+          auto pct = [&](double p) { size_t k = (size_t)std::ceil(p / 100.0 * (double)itl.size()); k = k ? k - 1 : 0; return itl[std::min(k, itl.size() - 1)]; };
+          stats->itl_p50_ms = pct(50.0); stats->itl_p99_ms = pct(99.0); stats->itl_max_ms = itl.back();
+          const double dec = stats->total_ms - stats->ttft_ms;
+          stats->decode_tok_per_s = dec > 0.0 ? (double)itl.size() / (dec / 1e3) : 0.0;
+        }
+      }
     }
   }
   bz_decode_graph_free(graph);

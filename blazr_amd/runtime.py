@@ -815,5 +815,7 @@ class Executor:
         out = np.zeros(max(max_tokens, 1), dtype=np.int64)
         st = L.GenStats()
         L.check(L.lib().bz_generate(self.model.h, _ptr(p), len(p), C.byref(g), _ptr(out), C.byref(st)))
-        self.last_stats = dict(prefill_ms=st.prefill_ms, decode_ms=st.decode_ms, n_generated=st.n_generated, finish_reason=st.finish_reason)
+        self.last_stats = dict(prefill_ms=st.prefill_ms, decode_ms=st.decode_ms, n_generated=st.n_generated, finish_reason=st.finish_reason,
+                               ttft_ms=st.ttft_ms, total_ms=st.total_ms, itl_p50_ms=st.itl_p50_ms, itl_p99_ms=st.itl_p99_ms, itl_max_ms=st.itl_max_ms,
+                               decode_tok_per_s=st.decode_tok_per_s)
         return out[:st.n_generated]

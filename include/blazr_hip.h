@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define BZ_ABI_VERSION 3
+#define BZ_ABI_VERSION 4
 
 enum {
   BZ_OK = 0,
@@ -275,7 +275,12 @@ typedef struct {
   int32_t n_logit_bias; const uint32_t* logit_bias_ids; const float* logit_bias_vals;
   int32_t reserved[4];
 } bz_gen_config;
-typedef struct { double prefill_ms, decode_ms; int32_t n_generated; int32_t finish_reason; /* 0 length, 1 eos */ } bz_gen_stats;
+/* prefill_ms / decode_ms: host wall time of the prompt phase and of everything after it.  The other timing fields are the reference bench's
+ * (/root/reference/src/cli/bench.rs:142-160,285-306), measured where its stream consumer measures them -- at the moment a token id has reached the host:
+ *   ttft_ms = start -> first token; itl_*: time between consecutive tokens (p50 / p99 / max over the n_generated - 1 gaps, nearest-rank percentiles);
+ *   total_ms = start -> last token; decode_tok_per_s = (n_generated - 1) / (total - ttft). */
+typedef struct { double prefill_ms, decode_ms; int32_t n_generated; int32_t finish_reason; /* 0 length, 1 eos */
+                 double ttft_ms, total_ms, itl_p50_ms, itl_p99_ms, itl_max_ms, decode_tok_per_s; } bz_gen_stats;
 /* ---- host-side sampler pieces, each a line-for-line restatement of the reference's Rust (they run on the CPU there too) ---------------- */
 float bz_compute_dynamic_temperature(const float* logits, int64_t vocab, float base, float range, float exponent);      /* sampling.rs:41-86 */
 int bz_apply_dry_penalty(float* logits, int64_t vocab, const uint32_t* recent, int64_t n_recent, float multiplier, int base, int allowed_length);   /* :270-320 */

@@ -739,3 +739,21 @@ def test_f32_cache_head_dim_128_attention(device, over):
     for mode in ("graph", "paged", "paged-graph"):
         got = ex.generate(q, 20, use_graph="graph" in mode, paged="paged" in mode)
         assert got.tolist() == base.tolist(), mode
+
+
+@pytest.mark.parametrize("mode", ["eager", "graph"])
+def test_generate_reports_the_reference_bench_timings(device, mode):
+    """bz_gen_stats carries what the reference's bench measures per generation (cli/bench.rs:142-160,285-306): TTFT, total, inter-token latency percentiles,
+    decode tok/s = (tokens - 1) / (total - TTFT) -- taken where the reference's stream consumer takes them, when a token id has reached the host"""
+    model = synth.make_llama("tiny-awq")
+    lm = runtime.LoadedModel.from_synth(device, model)
+    ex = runtime.Executor(lm)
+    p = synth.prompt_tokens(12, model["config"]["vocab"], seed=4)
+    toks = ex.generate(p, 40, use_graph=mode == "graph")
+    st = ex.last_stats
+    assert st["n_generated"] == len(toks) == 40
+    assert 0.0 < st["ttft_ms"] <= st["total_ms"]
+    assert st["prefill_ms"] <= st["ttft_ms"] + 1e-6          # the first token exists after the prompt phase
+    assert 0.0 < st["itl_p50_ms"] <= st["itl_p99_ms"] <= st["itl_max_ms"]
+    assert abs(st["decode_tok_per_s"] - 39 / ((st["total_ms"] - st["ttft_ms"]) / 1e3)) <= 1e-6 * st["decode_tok_per_s"]
+    assert st["itl_max_ms"] * 39 >= st["total_ms"] - st["ttft_ms"] - 1e-6
