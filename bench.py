@@ -61,18 +61,18 @@ def hip_events(stream):
 def kernels_sha16():
     """identity of the kernel sources this library was built from (the PMC pass is stamped with it)"""
     h = hashlib.sha256()
-    for f in ("bz_kernels.hip", "bz_internal.h"):
+    for f in ("bz_kernels.hip", "bz_internal.h", "bz_dev.h"):
         h.update(open(os.path.join(ROOT, "blazr_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
 
 def pmc_traffic(label):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/r02_pmc_traffic.json, made by
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/r03_pmc_traffic.json, made by
     scripts/pmc_traffic.py: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction (2*FETCH + WRITE) * 1024).  A process cannot collect
     PMC counters on itself, so the value is read back from the file -- and only when the file was made from THESE kernel sources
     (`kernels_sha16` stamp); a stale pass gives None and says so.  Returns (bytes or None, note)."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
     except (OSError, ValueError):
         return None, "no PMC pass committed for this round"
     if d.get("kernels_sha16") != kernels_sha16():
