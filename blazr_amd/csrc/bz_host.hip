@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <chrono>
 #include <numeric>
+#include <unordered_map>
 
 // ---------------------------------------------------------------------------------------------------------
 // errors
@@ -323,6 +324,13 @@ struct bz_model {
   int pf_rows = 0; float* pf_h = nullptr; float* pf_t = nullptr; float* pf_qkv = nullptr; float* pf_gu = nullptr; void* pf_x16 = nullptr;
   int* row_pos = nullptr; int row_pos_n = 0;   // device copy of a decode batch's per-row positions
   long long* pf_acc = nullptr;   // int4 multi-row GEMM scratch: 8 rows x widest N, fixed point, kept zero between launches
+  // block-format (GGUF) weights on the batched prompt path: per fused linear the power-of-two scale (device float) and, while the budget lasts, the matrix
+  // as three f16 pieces per weight [N][3 K] (6 bytes per weight: sized for 288 GB of HBM -- a 7B Q4_K_M model keeps 43 GB of them next to its 4.3 GB of blocks)
+  struct GqPf { float* wscale = nullptr; void* w3 = nullptr; };
+  std::unordered_map<const FusedLinear*, GqPf> gq_pf;
+  size_t gq_cache_bytes = 0;
+  unsigned* gq_amax = nullptr; void* gq_w3_scratch = nullptr; size_t gq_w3_scratch_bytes = 0;
+  void* pf_x3 = nullptr; float* pf_rscale = nullptr;   // split activation rows [rows][3 xw] f16 + their row scales
   float* pf_ws = nullptr; size_t pf_ws_bytes = 0;   // W4A16 MFMA GEMM: split-K partials for short prompts / decode batches
   long long* ring[3] = {nullptr, nullptr, nullptr};
   float* dring[3] = {nullptr, nullptr, nullptr};   // direct-output twins of the ring (ROWS kernels)
@@ -1847,12 +1855,22 @@ static int prefill_min_rows() {
 }
 static bool prefill_eligible(const bz_model* m, int S, int total_len) {
   const bz_model_config& c = m->cfg;
-  if (c.arch != BZ_ARCH_LLAMA || S < prefill_min_rows() || (c.act_dtype != BZ_F16 && c.act_dtype != BZ_BF16)) return false;
+  static const bool no_gq = getenv("BZ_NO_GGUF_PREFILL") != nullptr;
+  if (c.arch != BZ_ARCH_LLAMA || S < prefill_min_rows() || (c.act_dtype != BZ_F16 && c.act_dtype != BZ_BF16 && (c.act_dtype != BZ_F32 || no_gq))) return false;
   if (c.hidden % 64 || (c.n_heads * c.head_dim) % 64 || c.inter % 64 || c.head_dim % 8 || 256 % (c.head_dim / 8)) return false;
   const int rep = c.n_heads / c.n_kv_heads;
   if (rep != 1 && rep != 2 && rep != 4 && rep != 8) return false;
   if (!bzk_pf_attn_mfma_ok(c.head_dim, rep) && bzk_pf_attn_smem(c.n_heads, c.n_kv_heads, c.head_dim, total_len) > 160 * 1024) return false;   // (the scalar kernel keeps scores in LDS)
   // every projection either dense in the activation dtype (MFMA GEMM) or int4 without act-order (multi-row dot4 GEMM)
+  if (c.act_dtype == BZ_F32) {
+    // f32 activations (GGUF models): every projection in a block format, no bias, same K in all parts of a fused linear; the head stays the decode GEMV
+    for (const LayerDev& L : m->layers)
+      for (const FusedLinear* F : {&L.qkv, &L.o, &L.gateup, &L.down}) {
+        if (F->parts.empty()) return false;
+        for (const LinearDev& P : F->parts) if (!bzk_gq_split_ok(P) || P.bias || P.K != F->parts[0].K) return false;
+      }
+    return true;
+  }
   for (const LayerDev& L : m->layers)
     for (const FusedLinear* F : {&L.qkv, &L.o, &L.gateup, &L.down}) {
       if (F->parts.size() != 1) return false;
@@ -1881,7 +1899,11 @@ static int prefill_ws(bz_model* m, int rows) {
   BZ_TRY(dev_alloc(m, &p, (size_t)rows * c.hidden * 4)); m->pf_t = (float*)p;
   BZ_TRY(dev_alloc(m, &p, (size_t)rows * qn * 4)); m->pf_qkv = (float*)p;
   BZ_TRY(dev_alloc(m, &p, (size_t)rows * 2 * c.inter * 4)); m->pf_gu = (float*)p;
-  BZ_TRY(dev_alloc(m, &p, (size_t)rows * xw * 2)); m->pf_x16 = p;
+  BZ_TRY(dev_alloc(m, &p, (size_t)rows * xw * (c.act_dtype == BZ_F32 ? 4 : 2))); m->pf_x16 = p;
+  if (c.act_dtype == BZ_F32) {
+    BZ_TRY(dev_alloc(m, &p, (size_t)rows * 3 * xw * 2)); m->pf_x3 = p;
+    BZ_TRY(dev_alloc(m, &p, (size_t)rows * 4)); m->pf_rscale = (float*)p;
+  }
   if (!m->pf_acc) { const size_t an = 8 * std::max<size_t>(std::max<size_t>(qn, 2 * (size_t)c.inter), c.hidden); BZ_TRY(dev_alloc(m, &p, an * 8)); m->pf_acc = (long long*)p; BZ_HIP(hipMemset(p, 0, an * 8)); }
   BZ_TRY(ensure_pf_ws(m));
   m->pf_rows = rows;
@@ -1897,6 +1919,41 @@ static int pf_gemm(bz_model* m, const LinearDev& P, const void* x16, int n, floa
   //  R16((q - z) s) costs 1.4e-4 relative per GEMM and put awq 8B-width logits at 1.40e-3 against the 1e-3 bar -- removed)
   if (bzk_gemm_q4g_mfma_ok(P, act, n)) return bzk_gemm_q4g_mfma(st, P, x16, n, act, y, m->pf_ws, m->pf_ws_bytes);
   return bzk_gemm_q4g_rows(st, P, act, x16, n, act, m->pf_acc, y);
+}
+
+// Y[n][N] = X[n][K] . dequant(F)^T for a block-format fused linear, f32 rows in (m->pf_x16 as float), f32 rows out: both operands as three f16 pieces
+// (bz_prefill.hip: k_pf_split3 / k_gq_split3) through ONE 16-bit MFMA GEMM over 3 K.  The split weights are built on first use and kept while the budget
+// (BZ_GGUF_PREFILL_CACHE_GB, default 96) lasts; past it they are rebuilt into a scratch matrix per call.
+static int pf_gemm_gq(bz_model* m, const FusedLinear& F, const float* xf, int n, float* y) {
+  hipStream_t st = step_stream(m);
+  const int K = F.parts[0].K;
+  int N = 0;
+  for (const LinearDev& P : F.parts) N += P.N;
+  bz_model::GqPf& e = m->gq_pf[&F];
+  void* p;
+  if (!e.wscale) {
+    if (!m->gq_amax) { BZ_TRY(dev_alloc(m, &p, 16)); m->gq_amax = (unsigned*)p; }
+    BZ_TRY(dev_alloc(m, &p, 16)); e.wscale = (float*)p;
+    BZ_HIP(hipMemsetAsync(m->gq_amax, 0, 4, st));
+    for (const LinearDev& P : F.parts) BZ_TRY(bzk_gq_absmax(st, P, m->gq_amax));
+    BZ_TRY(bzk_gq_wscale(st, m->gq_amax, e.wscale));
+  }
+  const size_t bytes = (size_t)N * 3 * K * 2;
+  void* w3 = e.w3;
+  if (!w3) {
+    static const size_t budget = (size_t)(getenv("BZ_GGUF_PREFILL_CACHE_GB") ? atof(getenv("BZ_GGUF_PREFILL_CACHE_GB")) : 96.0) << 30;
+    size_t free_b = 0, total_b = 0;
+    const bool keep = m->gq_cache_bytes + bytes <= budget && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > bytes + ((size_t)8 << 30);
+    if (keep) { BZ_TRY(dev_alloc(m, &p, bytes)); e.w3 = w3 = p; m->gq_cache_bytes += bytes; }
+    else {
+      if (m->gq_w3_scratch_bytes < bytes) { BZ_HIP(hipStreamSynchronize(st)); BZ_TRY(dev_alloc(m, &p, bytes)); m->gq_w3_scratch = p; m->gq_w3_scratch_bytes = bytes; }
+      w3 = m->gq_w3_scratch;
+    }
+    int row0 = 0;
+    for (const LinearDev& P : F.parts) { BZ_TRY(bzk_gq_split3(st, P, e.wscale, w3, row0)); row0 += P.N; }
+  }
+  BZ_TRY(bzk_pf_split3(st, xf, n, K, m->pf_x3, m->pf_rscale, e.wscale));
+  return bzk_gemm_nt(st, BZ_F16, m->pf_x3, w3, nullptr, n, N, 3 * K, BZ_F32, y, m->pf_ws, m->pf_ws_bytes, m->pf_rscale);
 }
 
 // tokens [S] at positions pos0 .. pos0+S-1; `slots` (paged only): device i32 [S].  Logits of the last row (or all rows) -> logits_out.
@@ -1920,22 +1977,23 @@ static int prefill_dense(bz_model* m, const long long* d_tok, int S, const KvVie
     const float* prev = nullptr;
     for (int l = 0; l < c.n_layers; l++) {
       const LayerDev& L = m->layers[l];
+      const bool gq = act == BZ_F32;      // block-format projections: f32 rows, split operands
       BZ_TRY(bzk_pf_norm(st, dt, m->pf_h, prev, L.attn_norm, n, H, c.rms_eps, act, m->pf_x16));
-      BZ_TRY(pf_gemm(m, L.qkv.parts[0], m->pf_x16, n, m->pf_qkv));
+      BZ_TRY(gq ? pf_gemm_gq(m, L.qkv, (const float*)m->pf_x16, n, m->pf_qkv) : pf_gemm(m, L.qkv.parts[0], m->pf_x16, n, m->pf_qkv));
       BZ_TRY(bzk_pf_rope_kv(st, m->pf_qkv, n, nq, nkv, hd, m->cos_t, m->sin_t, c.rope_interleaved, p0, act, vw, l, slots ? slots + s0 : nullptr,
                             rc.row_pos ? rc.row_pos + s0 : nullptr));
       BZ_TRY(bzk_pf_attn(st, dt, m->pf_qkv, n, nq, nkv, hd, p0, act, vw, l, m->pf_x16, rc.row_pos ? rc.row_pos + s0 : nullptr, rc.table_stride, rc.max_len));
-      BZ_TRY(pf_gemm(m, L.o.parts[0], m->pf_x16, n, m->pf_t));
+      BZ_TRY(gq ? pf_gemm_gq(m, L.o, (const float*)m->pf_x16, n, m->pf_t) : pf_gemm(m, L.o.parts[0], m->pf_x16, n, m->pf_t));
       BZ_TRY(bzk_pf_norm(st, dt, m->pf_h, m->pf_t, L.ffn_norm, n, H, c.rms_eps, act, m->pf_x16));
-      BZ_TRY(pf_gemm(m, L.gateup.parts[0], m->pf_x16, n, m->pf_gu));
+      BZ_TRY(gq ? pf_gemm_gq(m, L.gateup, (const float*)m->pf_x16, n, m->pf_gu) : pf_gemm(m, L.gateup.parts[0], m->pf_x16, n, m->pf_gu));
       BZ_TRY(bzk_pf_silu(st, dt, m->pf_gu, n, I, act, m->pf_x16));
-      BZ_TRY(pf_gemm(m, L.down.parts[0], m->pf_x16, n, m->pf_t));
+      BZ_TRY(gq ? pf_gemm_gq(m, L.down, (const float*)m->pf_x16, n, m->pf_t) : pf_gemm(m, L.down.parts[0], m->pf_x16, n, m->pf_t));
       prev = m->pf_t;
     }
     // head.  Several rows wanted (all_logits, decode batch) and a dense lm_head in the activation dtype: final norm rows + one MFMA GEMM that
     // streams the lm_head once; otherwise the decode lm_head GEMV per row (final norm fused as its prologue)
     const LinearDev& LH = m->lm_head.parts[0];
-    if (all && n > 1 && LH.wdt == act && LH.K % 64 == 0 && logits_out->nbytes >= (size_t)(s0 + n) * c.vocab * 4) {
+    if (all && n > 1 && act != BZ_F32 && LH.wdt == act && LH.K % 64 == 0 && logits_out->nbytes >= (size_t)(s0 + n) * c.vocab * 4) {
       BZ_TRY(bzk_pf_norm(st, dt, m->pf_h, prev, m->final_norm, n, H, c.rms_eps, act, m->pf_x16));
       BZ_TRY(bzk_gemm_nt(st, act, m->pf_x16, LH.w, LH.bias, n, c.vocab, H, act, (float*)logits_out->ptr + (size_t)s0 * c.vocab, m->pf_ws, m->pf_ws_bytes));
       continue;
@@ -1943,6 +2001,14 @@ static int prefill_dense(bz_model* m, const long long* d_tok, int S, const KvVie
     for (int r = 0; r < n; r++) {
       const int srow = s0 + r;
       if (!all && srow != S - 1) continue;
+      if (m->lm_head.fix_out || m->lm_head.parts.size() != 1) {   // quantised lm_head (GGUF output.weight): the decode step's head on this row
+        StepIO hio{};
+        hio.do_embed = false; hio.do_head = true; hio.layer_start = 0; hio.layer_end = 0;
+        hio.hidden_in = m->pf_h + (size_t)r * H; hio.prev_in = prev + (size_t)r * H;
+        BZ_TRY(llama_step(m, hio));
+        BZ_TRY(emit_logits(m, logits_out, all ? srow : 0));
+        continue;
+      }
       Pro ph{}; ph.mode = PRO_NORM; ph.src = VSrc{prev + (size_t)r * H, 0}; ph.h_in = m->pf_h + (size_t)r * H; ph.h_out = nullptr; ph.norm_w = m->final_norm;
       ph.eps = c.rms_eps; ph.H = H; ph.act = act;
       GemvOut o{};

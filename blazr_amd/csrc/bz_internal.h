@@ -212,6 +212,12 @@ int bzk_dequant_q4g(hipStream_t s, const LinearDev& L, float* out /*[N][K] devic
 int bzk_dequant_rows(hipStream_t s, const LinearDev& L, float* out);
 int bzk_repack_gq(hipStream_t s, int kind, const void* raw, int N, int K, void* wq, void* wh, void* hd, void* dd);
 int bzk_dequant_gq(hipStream_t s, const LinearDev& L, float* out);
+// block formats on the batched prompt path: the matrix as three f16 pieces per weight (bz_prefill.hip, k_pf_split3)
+bool bzk_gq_split_ok(const LinearDev& L);
+int bzk_gq_absmax(hipStream_t s, const LinearDev& L, unsigned* amax);
+int bzk_gq_wscale(hipStream_t s, const unsigned* amax, float* wscale);
+int bzk_gq_split3(hipStream_t s, const LinearDev& L, const float* wscale, void* out, int row0);
+int bzk_pf_split3(hipStream_t s, const float* x, int S, int K, void* xs, float* rscale, const float* wscale);
 int bzk_argmax_partials(hipStream_t s, const float* v, long long n, float* pval, int* pidx, int nb);
 int bzk_embed(hipStream_t s, const void* table, int tdt, const long long* tok, int H, int act, float* h_out, const int* pos = nullptr,
               const float* cos_t = nullptr, const float* sin_t = nullptr, int half = 0, float* rope_cur = nullptr);   // rope_cur: stage [cos|sin] of *pos
@@ -322,7 +328,8 @@ int bzk_moe_combine(hipStream_t s, long long* acc, const float* wsel, int top_k,
 bool bzk_moe_rows2_ok(int wdt, int K);   // the balanced role kernel takes the grouped expert GEMVs (16-bit weights)
 
 // batched prefill for dense 16-bit models (bz_prefill.hip): MFMA GEMM + row-wise norm / RoPE + KV append / causal attention / SiLU*up
-int bzk_gemm_nt(hipStream_t s, int dt, const void* x16, const void* w, const float* bias, int S, int N, int K, int act, float* y, float* ws = nullptr, size_t ws_bytes = 0);   // ws: split-K partials (optional)
+int bzk_gemm_nt(hipStream_t s, int dt, const void* x16, const void* w, const float* bias, int S, int N, int K, int act, float* y, float* ws = nullptr, size_t ws_bytes = 0,
+                const float* rscale = nullptr);   // ws: split-K partials (optional); rscale: per-row multipliers of the accumulator (split f32 operands)
 int bzk_gemm_nt_grouped(hipStream_t s, int dt, const void* x16, const void* w, long long w_stride, int G, const int* g_off, const int* g_cnt, int max_rows, long long total_rows,
                         int N, int K, int act, float* y);
 int bzk_pf_cvt16(hipStream_t s, int dt, const float* x, size_t n, void* y);

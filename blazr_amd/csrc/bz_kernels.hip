@@ -2512,45 +2512,100 @@ int bzk_repack_gq(hipStream_t s, int kind, const void* raw, int N, int K, void* 
   return BZ_OK;
 }
 
+// one weight of the REPACKED layouts as the f32 value the decode kernels' arithmetic stands for (ggml's dequantisation formula per format)
+__device__ __forceinline__ float gq_elem(int fmt, const uint32_t* wq, const uint32_t* wh, const uint32_t* hd, const __half* dd, int K, int n, int k) {
+  const int nt = n >> 6, lane = n & 63;
+  if (fmt == GQ_Q80) {
+    const unsigned word = wq[(((size_t)nt * (K >> 4) + (k >> 4)) * 64 + lane) * 4 + ((k & 15) >> 2)];
+    const int q = (int)(signed char)((word >> (8 * (k & 3))) & 255u);
+    return __half2float(dd[((size_t)nt * (K >> 5) + (k >> 5)) * 64 + lane]) * (float)q;
+  }
+  const int kc = k >> 5, r = k & 31, j = r >> 3, rr = r & 7;
+  const unsigned word = wq[(((size_t)nt * (K >> 5) + kc) * 64 + lane) * 4 + j];
+  const unsigned byte = (word >> (8 * (rr & 3))) & 255u;
+  const size_t hi = (((size_t)nt * (K >> 8) + (k >> 8)) * 64 + lane) * 4;
+  const unsigned hw[4] = {hd[hi], hd[hi + 1], hd[hi + 2], hd[hi + 3]};
+  if (fmt == GQ_Q4K) {
+    const float q = rr < 4 ? (float)(byte & 15u) : (float)((byte >> 4) ^ 8u);
+    const float d = __half2float(__ushort_as_half((unsigned short)(hw[0] & 0xffffu))), dmin = __half2float(__ushort_as_half((unsigned short)(hw[0] >> 16)));
+    int sc, mn;
+    q4k_scale_min(hw, (k & 255) >> 5, sc, mn);
+    return (d * (float)sc) * q - (dmin * (float)mn);
+  }
+  const unsigned lo = rr < 4 ? (byte & 15u) : (byte >> 4);
+  const int F = r >> 2;   // k-order word
+  const unsigned hword = wh[(((size_t)nt * (K >> 5) + kc) * 64 + lane) * 2 + (F >> 2)];
+  const unsigned hi2 = (hword >> (8 * (r & 3) + 2 * (F & 3))) & 3u;
+  const int q = (int)(lo | (hi2 << 4)) - 32;
+  const int si = (k & 255) >> 4;
+  const int sc = (int)(signed char)((hw[si >> 2] >> (8 * (si & 3))) & 255u);
+  return __half2float(dd[((size_t)nt * (K >> 8) + (k >> 8)) * 64 + lane]) * (float)sc * (float)q;
+}
 // dequantise the REPACKED layouts to f32 [N][K] (validates the repack against the oracle's ggml dequant)
 __global__ void k_dequant_gq(int fmt, const uint32_t* wq, const uint32_t* wh, const uint32_t* hd, const __half* dd, int N, int K, float* out) {
   const size_t total = (size_t)N * K;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x)
+    out[idx] = gq_elem(fmt, wq, wh, hd, dd, K, (int)(idx / (size_t)K), (int)(idx % (size_t)K));
+}
+static int gq_fmt(const LinearDev& L) { return L.kind == LK_Q80 ? GQ_Q80 : (L.kind == LK_Q4K ? GQ_Q4K : GQ_Q6K); }
+int bzk_dequant_gq(hipStream_t s, const LinearDev& L, float* out) {
+  hipLaunchKernelGGL(k_dequant_gq, dim3(2048), dim3(256), 0, s, gq_fmt(L), (const uint32_t*)L.w, (const uint32_t*)L.zeros, (const uint32_t*)L.hdr,
+                     (const __half*)L.scales, L.N, L.K, out);
+  BZ_HIP(hipGetLastError());
+  return BZ_OK;
+}
+
+// ---- the batched prompt path of the block formats (bz_prefill.hip "f32-activation rows on the 16-bit matrix cores") -----------------------------------
+// largest |w| of a matrix (bits of a non-negative float order like unsigned integers): *amax must be zeroed first
+__global__ void k_gq_absmax(int fmt, const uint32_t* wq, const uint32_t* wh, const uint32_t* hd, const __half* dd, int N, int K, unsigned* amax) {
+  const size_t total = (size_t)N * K;
+  float am = 0.f;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x)
+    am = fmaxf(am, fabsf(gq_elem(fmt, wq, wh, hd, dd, K, (int)(idx / (size_t)K), (int)(idx % (size_t)K))));
+  am = wave_max(am);
+  if ((threadIdx.x & 63) == 0) atomicMax(amax, __float_as_uint(am));
+}
+// *amax (float bits) -> the power of two that brings it into [2^13, 2^14)
+__global__ void k_gq_wscale(const unsigned* amax, float* wscale) {
+  const unsigned eb = (*amax >> 23) & 255u;
+  *wscale = (eb == 0u || eb == 255u || eb > 240u || eb < 20u) ? 1.0f : __uint_as_float((127u + 13u + 127u - eb) << 23);
+}
+// W' rows [row0 + n][3 K] = [ wh | wh 2^-11 | wl 2^11 ] of w 2^e (f16 pieces; see k_pf_split3).  A thread takes 8 consecutive k of one column: three 16-byte stores.
+__global__ __launch_bounds__(256) void k_gq_split3(int fmt, const uint32_t* wq, const uint32_t* wh, const uint32_t* hd, const __half* dd, int N, int K, const float* wscale,
+                                                   unsigned short* out, int row0) {
+  const size_t total = (size_t)N * (K >> 3);
+  const float sc = *wscale;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-    const int k = (int)(idx % (size_t)K), n = (int)(idx / (size_t)K);
-    const int nt = n >> 6, lane = n & 63;
-    if (fmt == GQ_Q80) {
-      const unsigned word = wq[(((size_t)nt * (K >> 4) + (k >> 4)) * 64 + lane) * 4 + ((k & 15) >> 2)];
-      const int q = (int)(signed char)((word >> (8 * (k & 3))) & 255u);
-      out[idx] = __half2float(dd[((size_t)nt * (K >> 5) + (k >> 5)) * 64 + lane]) * (float)q;
-      continue;
+    const int n = (int)(idx / (size_t)(K >> 3)), k0 = (int)(idx % (size_t)(K >> 3)) * 8;
+    unsigned short a[8], b[8], c[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const float vs = gq_elem(fmt, wq, wh, hd, dd, K, n, k0 + e) * sc;
+      const __half h = f16_cvt(vs);
+      const float hf = __half2float(h), l = vs - hf;
+      a[e] = __half_as_ushort(h); b[e] = __half_as_ushort(f16_cvt(hf * (1.0f / 2048.0f))); c[e] = __half_as_ushort(f16_cvt(l * 2048.0f));
     }
-    const int kc = k >> 5, r = k & 31, j = r >> 3, rr = r & 7;
-    const unsigned word = wq[(((size_t)nt * (K >> 5) + kc) * 64 + lane) * 4 + j];
-    const unsigned byte = (word >> (8 * (rr & 3))) & 255u;
-    const size_t hi = (((size_t)nt * (K >> 8) + (k >> 8)) * 64 + lane) * 4;
-    const unsigned hw[4] = {hd[hi], hd[hi + 1], hd[hi + 2], hd[hi + 3]};
-    if (fmt == GQ_Q4K) {
-      const float q = rr < 4 ? (float)(byte & 15u) : (float)((byte >> 4) ^ 8u);
-      const float d = __half2float(__ushort_as_half((unsigned short)(hw[0] & 0xffffu))), dmin = __half2float(__ushort_as_half((unsigned short)(hw[0] >> 16)));
-      int sc, mn;
-      q4k_scale_min(hw, (k & 255) >> 5, sc, mn);
-      out[idx] = (d * (float)sc) * q - (dmin * (float)mn);
-    } else {
-      const unsigned lo = rr < 4 ? (byte & 15u) : (byte >> 4);
-      const int F = r >> 2;   // k-order word
-      const unsigned hword = wh[(((size_t)nt * (K >> 5) + kc) * 64 + lane) * 2 + (F >> 2)];
-      const unsigned hi2 = (hword >> (8 * (r & 3) + 2 * (F & 3))) & 3u;
-      const int q = (int)(lo | (hi2 << 4)) - 32;
-      const int si = (k & 255) >> 4;
-      const int sc = (int)(signed char)((hw[si >> 2] >> (8 * (si & 3))) & 255u);
-      out[idx] = __half2float(dd[((size_t)nt * (K >> 8) + (k >> 8)) * 64 + lane]) * (float)sc * (float)q;
-    }
+    unsigned short* o = out + (size_t)(row0 + n) * 3 * K + k0;
+    *(uint4*)o = make_uint4(a[0] | ((unsigned)a[1] << 16), a[2] | ((unsigned)a[3] << 16), a[4] | ((unsigned)a[5] << 16), a[6] | ((unsigned)a[7] << 16));
+    *(uint4*)(o + K) = make_uint4(b[0] | ((unsigned)b[1] << 16), b[2] | ((unsigned)b[3] << 16), b[4] | ((unsigned)b[5] << 16), b[6] | ((unsigned)b[7] << 16));
+    *(uint4*)(o + 2 * K) = make_uint4(c[0] | ((unsigned)c[1] << 16), c[2] | ((unsigned)c[3] << 16), c[4] | ((unsigned)c[5] << 16), c[6] | ((unsigned)c[7] << 16));
   }
 }
-int bzk_dequant_gq(hipStream_t s, const LinearDev& L, float* out) {
-  const int fmt = L.kind == LK_Q80 ? GQ_Q80 : (L.kind == LK_Q4K ? GQ_Q4K : GQ_Q6K);
-  hipLaunchKernelGGL(k_dequant_gq, dim3(2048), dim3(256), 0, s, fmt, (const uint32_t*)L.w, (const uint32_t*)L.zeros, (const uint32_t*)L.hdr,
-                     (const __half*)L.scales, L.N, L.K, out);
+bool bzk_gq_split_ok(const LinearDev& L) { return (L.kind == LK_Q80 || L.kind == LK_Q4K || L.kind == LK_Q6K) && L.K % 64 == 0 && L.N % 64 == 0; }
+// amax: device word holding the running maximum of the fused linear's parts (zeroed by the caller before the first part)
+int bzk_gq_absmax(hipStream_t s, const LinearDev& L, unsigned* amax) {
+  hipLaunchKernelGGL(k_gq_absmax, dim3(2048), dim3(256), 0, s, gq_fmt(L), (const uint32_t*)L.w, (const uint32_t*)L.zeros, (const uint32_t*)L.hdr, (const __half*)L.scales, L.N, L.K, amax);
+  BZ_HIP(hipGetLastError());
+  return BZ_OK;
+}
+int bzk_gq_wscale(hipStream_t s, const unsigned* amax, float* wscale) {
+  hipLaunchKernelGGL(k_gq_wscale, dim3(1), dim3(1), 0, s, amax, wscale);
+  BZ_HIP(hipGetLastError());
+  return BZ_OK;
+}
+int bzk_gq_split3(hipStream_t s, const LinearDev& L, const float* wscale, void* out, int row0) {
+  hipLaunchKernelGGL(k_gq_split3, dim3(4096), dim3(256), 0, s, gq_fmt(L), (const uint32_t*)L.w, (const uint32_t*)L.zeros, (const uint32_t*)L.hdr, (const __half*)L.scales, L.N, L.K, wscale,
+                     (unsigned short*)out, row0);
   BZ_HIP(hipGetLastError());
   return BZ_OK;
 }

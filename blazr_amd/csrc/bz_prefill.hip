@@ -38,6 +38,12 @@ template <int DT> __device__ __forceinline__ unsigned short to16(float x) {
   if (DT == BZ_F16) return __half_as_ushort(f16_cvt(x));
   const __bf16 b = (__bf16)x; return __builtin_bit_cast(unsigned short, b);
 }
+// one element of a GEMM-input row buffer: 16-bit for the 16-bit activation dtypes, plain f32 for f32-activation models (GGUF), whose rows are split into
+// 16-bit pieces by k_pf_split3 afterwards
+template <int DT> __device__ __forceinline__ void put_x(void* base, size_t i, float v) {
+  if constexpr (DT == BZ_F32) ((float*)base)[i] = v;
+  else ((unsigned short*)base)[i] = to16<DT>(v);
+}
 template <int DT> __device__ __forceinline__ float from16(unsigned short b) {
   if (DT == BZ_F16) return __half2float(__ushort_as_half(b));
   return __uint_as_float((unsigned)b << 16);
@@ -167,7 +173,7 @@ __device__ __forceinline__ void glds4(const void* gsrc, const unsigned char* lds
 template <int DT, int TM>
 __global__ __launch_bounds__(256) void k_gemm_nt2(const unsigned short* __restrict__ X, const unsigned short* __restrict__ W, const float* __restrict__ bias,
                                                   int S, int N, int K, int act, float* __restrict__ Y, float* __restrict__ part, int KS, int mtiles, int ntiles,
-                                                  const int* __restrict__ g_off, const int* __restrict__ g_cnt, long long w_stride) {
+                                                  const int* __restrict__ g_off, const int* __restrict__ g_cnt, long long w_stride, const float* __restrict__ rscale) {
   constexpr int BM = 64 * TM, TILE = (BM + 128) * 128;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem2[];   // the ONLY LDS object of this kernel (a second one makes hipcc drain vmcnt per k-step)
   const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
@@ -241,7 +247,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt2(const unsigned short* __restri
           const int m = m0 + wm * 32 * TM + 32 * t + (i & 3) + 8 * (i >> 2) + 4 * h;
           if (m < S) {
             if (part) part[((size_t)ks * S + m) * N + n] = acc[t][j][i];
-            else Y[(size_t)m * N + n] = pf_round(acc[t][j][i] + bv, act);
+            else Y[(size_t)m * N + n] = pf_round((rscale ? acc[t][j][i] * rscale[m] : acc[t][j][i]) + bv, act);     // rscale: a power of two per row (split f32 operands)
           }
         }
     }
@@ -250,7 +256,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt2(const unsigned short* __restri
 
 // row s: h <- R(h + prev) (prev optional) ; x16 <- to16(R(w * R(h * rs)))        grid = S
 template <int DT>
-__global__ __launch_bounds__(256) void k_pf_norm(float* hbuf, const float* prev, const float* w, int H, float eps, int act, unsigned short* x16) {
+__global__ __launch_bounds__(256) void k_pf_norm(float* hbuf, const float* prev, const float* w, int H, float eps, int act, void* x16) {
   __shared__ float red[4];
   float* hr = hbuf + (size_t)blockIdx.x * H;
   const float* pr = prev ? prev + (size_t)blockIdx.x * H : nullptr;
@@ -265,7 +271,7 @@ __global__ __launch_bounds__(256) void k_pf_norm(float* hbuf, const float* prev,
   __syncthreads();
   ss = (red[0] + red[1]) + (red[2] + red[3]);
   const float rs = rms_scale(ss, (float)H, eps);
-  for (int i = threadIdx.x; i < H; i += 256) x16[(size_t)blockIdx.x * H + i] = to16<DT>(pf_round(w[i] * pf_round(hr[i] * rs, act), act));
+  for (int i = threadIdx.x; i < H; i += 256) put_x<DT>(x16, (size_t)blockIdx.x * H + i, pf_round(w[i] * pf_round(hr[i] * rs, act), act));
 }
 
 // row s, head j of [q heads | k heads | v heads]: RoPE on q and k (rounded), k / v appended to the cache at position pos0 + s.   grid = (S, nq + 2 nkv)
@@ -330,7 +336,7 @@ __device__ __forceinline__ void ld_row8(const void* base, size_t off, float (&o)
   }
 }
 template <int DT, int KVDT, int REP>
-__global__ __launch_bounds__(256) void k_pf_attn(const float* qkv, int nq, int nkv, int hd, int pos0, int act, KvView kv, int layer, float scale, unsigned short* out16,
+__global__ __launch_bounds__(256) void k_pf_attn(const float* qkv, int nq, int nkv, int hd, int pos0, int act, KvView kv, int layer, float scale, void* out16,
                                                 const int* row_pos, int table_stride) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int s = blockIdx.x, kvh = blockIdx.y, len = (row_pos ? row_pos[s] : pos0 + s) + 1;
@@ -414,7 +420,7 @@ __global__ __launch_bounds__(256) void k_pf_attn(const float* qkv, int nq, int n
     float a = 0.f;
     for (int gg = 0; gg < RPP; gg++) a += part[(gg * REP + h) * hd + d];
     const float invh = 1.0f / ((red[4 * REP + h * 4] + red[4 * REP + h * 4 + 1]) + (red[4 * REP + h * 4 + 2] + red[4 * REP + h * 4 + 3]));
-    out16[(size_t)s * nq * hd + (size_t)(kvh * REP + h) * hd + d] = to16<DT>(pf_round(a * invh, act));
+    put_x<DT>(out16, (size_t)s * nq * hd + (size_t)(kvh * REP + h) * hd + d, pf_round(a * invh, act));
   }
 }
 
@@ -569,17 +575,63 @@ __global__ __launch_bounds__(256) void k_pf_attn_mfma(const float* __restrict__ 
 #undef PFA_GLOAD
 // a16[s][i] = to16(R(R(silu(g)) * u)),  gu rows = [gate (I) | up (I)]
 template <int DT>
-__global__ __launch_bounds__(256) void k_pf_silu(const float* __restrict__ gu, int S, int I, int act, unsigned short* __restrict__ a16) {   // grid = (ceil(I / 1024), S): 4 columns per thread
+__global__ __launch_bounds__(256) void k_pf_silu(const float* __restrict__ gu, int S, int I, int act, void* __restrict__ a16) {   // grid = (ceil(I / 1024), S): 4 columns per thread
   const int s = blockIdx.y, i = (blockIdx.x * 256 + threadIdx.x) * 4;
   if (i >= I) return;
   const float* row = gu + (size_t)s * 2 * I;
   const float4 g = *(const float4*)(row + i), u = *(const float4*)(row + I + i);
   const float gv[4] = {g.x, g.y, g.z, g.w}, uv[4] = {u.x, u.y, u.z, u.w};
-  unsigned short o[4];
+  float of[4];
 #pragma unroll
-  for (int e = 0; e < 4; e++) o[e] = to16<DT>(pf_round(pf_round(div_rn(gv[e], 1.0f + bz_expf(-gv[e])), act) * uv[e], act));
-  uint2 w; w.x = o[0] | ((unsigned)o[1] << 16); w.y = o[2] | ((unsigned)o[3] << 16);
-  *(uint2*)(a16 + (size_t)s * I + i) = w;
+  for (int e = 0; e < 4; e++) of[e] = pf_round(pf_round(div_rn(gv[e], 1.0f + bz_expf(-gv[e])), act) * uv[e], act);
+  if constexpr (DT == BZ_F32) *(float4*)((float*)a16 + (size_t)s * I + i) = make_float4(of[0], of[1], of[2], of[3]);
+  else {
+    unsigned short o[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) o[e] = to16<DT>(of[e]);
+    uint2 w; w.x = o[0] | ((unsigned)o[1] << 16); w.y = o[2] | ((unsigned)o[3] << 16);
+    *(uint2*)((unsigned short*)a16 + (size_t)s * I + i) = w;
+  }
+}
+
+// ---- f32-activation rows on the 16-bit matrix cores (GGUF-quantised models) ------------------------------------------------------------------------
+// A value v is carried as hi + lo, two f16 numbers: hi = f16(v'), lo = f16(v' - hi), v' = v 2^e with a power-of-two e that puts the row's (the matrix's)
+// largest magnitude at 2^13 -- every element down to 2^-16 of that maximum keeps 22 significant bits with both pieces NORMAL f16 numbers (nothing relies on
+// subnormal operands surviving the MFMA).  x . w = xh wh + xl wh + xh wl (+ xl wl, 2^-22 of the product: dropped) becomes ONE 16-bit GEMM over 3 K:
+//   X' row = [ xh | xl 2^11 | xh 2^-11 ],   W' row = [ wh | wh 2^-11 | wl 2^11 ]      (the 2^+-11 keep the small pieces in the normal range; exact)
+// and the f32 accumulator is scaled back by 2^-(e_row + e_w) in the GEMM's epilogue (rscale).  Products are exact, sums f32: an error of ~2^-22 per product
+// against the f32 arithmetic of the decode kernels (exact integer block sums, f32 scales).
+__device__ __forceinline__ void split3(float vs, unsigned short& hi, unsigned short& mid, unsigned short& lo, bool weight) {
+  const __half h = f16_cvt(vs);
+  const float hf = __half2float(h), l = vs - hf;              // exact (Sterbenz-like: hf is vs rounded to 11 bits)
+  hi = __half_as_ushort(h);
+  if (!weight) { mid = __half_as_ushort(f16_cvt(l * 2048.0f)); lo = __half_as_ushort(f16_cvt(hf * (1.0f / 2048.0f))); }      // [xh | xl 2^11 | xh 2^-11]
+  else { mid = __half_as_ushort(f16_cvt(hf * (1.0f / 2048.0f))); lo = __half_as_ushort(f16_cvt(l * 2048.0f)); }               // [wh | wh 2^-11 | wl 2^11]
+}
+// power of two that brings `am` into [2^13, 2^14) (1 for a zero / non-finite maximum)
+__device__ __forceinline__ float split_scale(float am) {
+  const unsigned eb = (__float_as_uint(am) >> 23) & 255u;
+  if (eb == 0u || eb == 255u || eb > 240u || eb < 20u) return 1.0f;
+  return __uint_as_float((127u + 13u + 127u - eb) << 23);     // 2^(13 - (eb - 127))
+}
+// x [S][K] f32 -> xs [S][3 K] f16 pieces; rscale[s] = 2^-e_s / wscale (wscale: device scalar, the weight matrix's 2^e_w; nullptr = 1)     grid = S
+__global__ __launch_bounds__(256) void k_pf_split3(const float* __restrict__ x, int K, unsigned short* __restrict__ xs, float* __restrict__ rscale, const float* __restrict__ wscale) {
+  __shared__ float red[4];
+  const float* xr = x + (size_t)blockIdx.x * K;
+  float am = 0.f;
+  for (int i = threadIdx.x; i < K; i += 256) am = fmaxf(am, fabsf(xr[i]));
+  am = wave_max(am);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = am;
+  __syncthreads();
+  am = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const float sc = split_scale(am);
+  unsigned short* o = xs + (size_t)blockIdx.x * 3 * K;
+  for (int i = threadIdx.x; i < K; i += 256) {
+    unsigned short a, b, c;
+    split3(xr[i] * sc, a, b, c, false);
+    o[i] = a; o[K + i] = b; o[2 * K + i] = c;
+  }
+  if (threadIdx.x == 0) rscale[blockIdx.x] = (1.0f / sc) / (wscale ? *wscale : 1.0f);
 }
 
 template <int DT>
@@ -845,10 +897,12 @@ __global__ __launch_bounds__(256) void k_gemm_q4g_lds(const uint4* __restrict__ 
   }
 }
 
-__global__ void k_q4g_mfma_reduce(const float* __restrict__ part, int KS, size_t SN, int N, const float* __restrict__ bias, int act, float* __restrict__ Y) {
+__global__ void k_q4g_mfma_reduce(const float* __restrict__ part, int KS, size_t SN, int N, const float* __restrict__ bias, int act, float* __restrict__ Y,
+                                  const float* __restrict__ rscale = nullptr) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < SN; i += (size_t)gridDim.x * 256) {
     float v = 0.f;
     for (int z = 0; z < KS; z++) v += part[(size_t)z * SN + i];      // fixed order: deterministic
+    if (rscale) v *= rscale[i / (size_t)N];
     Y[i] = pf_round(v + (bias ? bias[i % N] : 0.f), act);
   }
 }
@@ -1058,7 +1112,7 @@ __global__ __launch_bounds__(256) void k_pf_gnorm(const float* __restrict__ v, c
 }
 
 // ---- launchers ---------------------------------------------------------------------------------------------------------------------------
-int bzk_gemm_nt(hipStream_t s, int dt, const void* x16, const void* w, const float* bias, int S, int N, int K, int act, float* y, float* ws, size_t ws_bytes) {
+int bzk_gemm_nt(hipStream_t s, int dt, const void* x16, const void* w, const float* bias, int S, int N, int K, int act, float* y, float* ws, size_t ws_bytes, const float* rscale) {
   if (dt != BZ_F16 && dt != BZ_BF16) BZ_FAIL(BZ_E_UNSUPPORTED, "gemm_nt: 16-bit operands only");
   if (K % 64 || K < 64 || S <= 0 || N <= 0) BZ_FAIL(BZ_E_UNSUPPORTED, "gemm_nt: K=%d must be a positive multiple of 64", K);
   if ((unsigned long long)S * K >= (1ull << 32) || (unsigned long long)N * K >= (1ull << 32)) BZ_FAIL(BZ_E_UNSUPPORTED, "gemm_nt: operand of 2^32 elements or more");
@@ -1079,18 +1133,19 @@ int bzk_gemm_nt(hipStream_t s, int dt, const void* x16, const void* w, const flo
       static bool attr_done = false; \
       if (!attr_done) { BZ_HIP(hipFuncSetAttribute((const void*)k_gemm_nt2<DT, M>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536)); attr_done = true; } \
       BZ_LAUNCH("gemm_nt_mfma", flops, (k_gemm_nt2<DT, M>), dim3(grid), dim3(256), 2 * (64 * M + 128) * 128, s, (const unsigned short*)x16, (const unsigned short*)w, bias, S, N, K, act, y, part, KS, \
-                mtiles, ntiles, (const int*)nullptr, (const int*)nullptr, 0LL); } while (0)
+                mtiles, ntiles, (const int*)nullptr, (const int*)nullptr, 0LL, rscale); } while (0)
     if (dt == BZ_F16) { if (TM == 1) LAUNCH_G2(BZ_F16, 1); else LAUNCH_G2(BZ_F16, 2); }
     else { if (TM == 1) LAUNCH_G2(BZ_BF16, 1); else LAUNCH_G2(BZ_BF16, 2); }
 #undef LAUNCH_G2
     BZ_HIP(hipGetLastError());
     if (KS > 1) {
       const size_t SN = (size_t)S * N;
-      hipLaunchKernelGGL(k_q4g_mfma_reduce, dim3((unsigned)std::min<size_t>((SN + 255) / 256, 2048)), dim3(256), 0, s, (const float*)ws, KS, SN, N, bias, act, y);
+      hipLaunchKernelGGL(k_q4g_mfma_reduce, dim3((unsigned)std::min<size_t>((SN + 255) / 256, 2048)), dim3(256), 0, s, (const float*)ws, KS, SN, N, bias, act, y, rscale);
       BZ_HIP(hipGetLastError());
     }
     return BZ_OK;
   }
+  if (rscale) BZ_FAIL(BZ_E_UNSUPPORTED, "gemm_nt: row scales need the LDS-DMA kernel (unset BZ_GEMM_NT_WAVE_TILES)");
   // wave tile (32 MT) x (32 NT): as large as the problem allows while still giving the chip >= 512 waves
   int MT = S > 96 ? 4 : (S > 64 ? 3 : (S > 32 ? 2 : 1)), NT = 2;
   auto waves = [&](int mt, int nt) { return (long long)((S + 32 * mt - 1) / (32 * mt)) * ((N + 32 * nt - 1) / (32 * nt)); };
@@ -1125,7 +1180,7 @@ int bzk_gemm_nt_grouped(hipStream_t s, int dt, const void* x16, const void* w, l
       static bool attr_done = false; \
       if (!attr_done) { BZ_HIP(hipFuncSetAttribute((const void*)k_gemm_nt2<DT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536)); attr_done = true; } \
       BZ_LAUNCH("gemm_nt_mfma<grouped>", flops2, (k_gemm_nt2<DT, 1>), grid2, dim3(256), 2 * (64 + 128) * 128, s, (const unsigned short*)x16, (const unsigned short*)w, (const float*)nullptr, 0, N, K, act, y, \
-                (float*)nullptr, 1, mtiles, ntiles, g_off, g_cnt, w_stride); } while (0)
+                (float*)nullptr, 1, mtiles, ntiles, g_off, g_cnt, w_stride, (const float*)nullptr); } while (0)
     if (dt == BZ_F16) LAUNCH_GG2(BZ_F16); else LAUNCH_GG2(BZ_BF16);
 #undef LAUNCH_GG2
     BZ_HIP(hipGetLastError());
@@ -1248,8 +1303,9 @@ int bzk_pf_embed(hipStream_t s, const void* table, int tdt, const long long* tok
   return BZ_OK;
 }
 int bzk_pf_norm(hipStream_t s, int dt, float* hbuf, const float* prev, const float* w, int S, int H, float eps, int act, void* x16) {
-  if (dt == BZ_F16) hipLaunchKernelGGL(k_pf_norm<BZ_F16>, dim3(S), dim3(256), 0, s, hbuf, prev, w, H, eps, act, (unsigned short*)x16);
-  else hipLaunchKernelGGL(k_pf_norm<BZ_BF16>, dim3(S), dim3(256), 0, s, hbuf, prev, w, H, eps, act, (unsigned short*)x16);
+  if (dt == BZ_F16) hipLaunchKernelGGL(k_pf_norm<BZ_F16>, dim3(S), dim3(256), 0, s, hbuf, prev, w, H, eps, act, x16);
+  else if (dt == BZ_F32) hipLaunchKernelGGL(k_pf_norm<BZ_F32>, dim3(S), dim3(256), 0, s, hbuf, prev, w, H, eps, act, x16);
+  else hipLaunchKernelGGL(k_pf_norm<BZ_BF16>, dim3(S), dim3(256), 0, s, hbuf, prev, w, H, eps, act, x16);
   BZ_HIP(hipGetLastError());
   return BZ_OK;
 }
@@ -1272,7 +1328,7 @@ int bzk_pf_attn(hipStream_t s, int dt, const float* qkv, int S, int nq, int nkv,
   const int REP = nq / nkv;
   if (hd % 8 || hd > 256 || (256 % (hd / 8)) || (REP != 1 && REP != 2 && REP != 4 && REP != 8) || kv.dtype != dt)
     BZ_FAIL(BZ_E_UNSUPPORTED, "prefill attention: head_dim %d / group size %d / cache dtype unsupported", hd, REP);
-  if (!row_pos && bzk_pf_attn_mfma_ok(hd, REP)) {
+  if (!row_pos && dt != BZ_F32 && bzk_pf_attn_mfma_ok(hd, REP)) {
     const float scale_m = div_rn(1.0f, sqrt_rn((float)hd));
     const int HW = REP < 4 ? REP : 4, QT = 4 / HW;
     const dim3 grid((S + 32 * QT - 1) / (32 * QT), nkv, REP / HW);
@@ -1295,9 +1351,9 @@ int bzk_pf_attn(hipStream_t s, int dt, const float* qkv, int S, int nq, int nkv,
 #define LAUNCH_PFA(DT, R) do { \
     static bool attr_done = false; \
     if (!attr_done) { BZ_HIP(hipFuncSetAttribute((const void*)k_pf_attn<DT, DT, R>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_done = true; } \
-    hipLaunchKernelGGL((k_pf_attn<DT, DT, R>), dim3(S, nkv), dim3(256), smem, s, qkv, nq, nkv, hd, pos0, act, kv, layer, scale, (unsigned short*)out16, row_pos, table_stride); } while (0)
+    hipLaunchKernelGGL((k_pf_attn<DT, DT, R>), dim3(S, nkv), dim3(256), smem, s, qkv, nq, nkv, hd, pos0, act, kv, layer, scale, out16, row_pos, table_stride); } while (0)
 #define LAUNCH_PFA_R(DT) do { if (REP == 1) LAUNCH_PFA(DT, 1); else if (REP == 2) LAUNCH_PFA(DT, 2); else if (REP == 4) LAUNCH_PFA(DT, 4); else LAUNCH_PFA(DT, 8); } while (0)
-  if (dt == BZ_F16) LAUNCH_PFA_R(BZ_F16); else LAUNCH_PFA_R(BZ_BF16);
+  if (dt == BZ_F16) LAUNCH_PFA_R(BZ_F16); else if (dt == BZ_F32) LAUNCH_PFA_R(BZ_F32); else LAUNCH_PFA_R(BZ_BF16);
 #undef LAUNCH_PFA_R
 #undef LAUNCH_PFA
   BZ_HIP(hipGetLastError());
@@ -1306,8 +1362,14 @@ int bzk_pf_attn(hipStream_t s, int dt, const float* qkv, int S, int nq, int nkv,
 int bzk_pf_silu(hipStream_t s, int dt, const float* gu, int S, int I, int act, void* a16) {
   if (I % 4) BZ_FAIL(BZ_E_UNSUPPORTED, "pf_silu: intermediate size %d is not a multiple of 4", I);
   const dim3 grid((I + 1023) / 1024, S);
-  if (dt == BZ_F16) hipLaunchKernelGGL(k_pf_silu<BZ_F16>, grid, dim3(256), 0, s, gu, S, I, act, (unsigned short*)a16);
-  else hipLaunchKernelGGL(k_pf_silu<BZ_BF16>, grid, dim3(256), 0, s, gu, S, I, act, (unsigned short*)a16);
+  if (dt == BZ_F16) hipLaunchKernelGGL(k_pf_silu<BZ_F16>, grid, dim3(256), 0, s, gu, S, I, act, a16);
+  else if (dt == BZ_F32) hipLaunchKernelGGL(k_pf_silu<BZ_F32>, grid, dim3(256), 0, s, gu, S, I, act, a16);
+  else hipLaunchKernelGGL(k_pf_silu<BZ_BF16>, grid, dim3(256), 0, s, gu, S, I, act, a16);
+  BZ_HIP(hipGetLastError());
+  return BZ_OK;
+}
+int bzk_pf_split3(hipStream_t s, const float* x, int S, int K, void* xs, float* rscale, const float* wscale) {
+  hipLaunchKernelGGL(k_pf_split3, dim3(S), dim3(256), 0, s, x, K, (unsigned short*)xs, rscale, wscale);
   BZ_HIP(hipGetLastError());
   return BZ_OK;
 }
