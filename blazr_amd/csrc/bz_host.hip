@@ -1911,10 +1911,11 @@ static int prefill_ws(bz_model* m, int rows) {
 }
 
 // Y[n][N] = R(X16[n][K] . W^T): dense 16-bit weights on the matrix cores, int4 weights through the multi-row dot4 GEMM
-static int pf_gemm(bz_model* m, const LinearDev& P, const void* x16, int n, float* y) {
+static int pf_gemm(bz_model* m, const LinearDev& P, const void* x16, int n, float* y, bool exact = false) {
   hipStream_t st = step_stream(m);
   const int act = m->cfg.act_dtype;
   if (P.kind == LK_ROWS) return bzk_gemm_nt(st, act, x16, P.w, P.bias, n, P.N, P.K, act, y, m->pf_ws, m->pf_ws_bytes);
+  if (exact) return bzk_gemm_q4g_rows(st, P, act, x16, n, act, m->pf_acc, y);      // the decode kernels' arithmetic, 8 rows per pass over the weights
   // (dequantising an int4 linear to f16 once per chunk and running the f16 LDS-DMA GEMM was built and measured: 2048-token prompt 90 -> 65 ms, but
   //  R16((q - z) s) costs 1.4e-4 relative per GEMM and put awq 8B-width logits at 1.40e-3 against the 1e-3 bar -- removed)
   if (bzk_gemm_q4g_mfma_ok(P, act, n)) return bzk_gemm_q4g_mfma(st, P, x16, n, act, y, m->pf_ws, m->pf_ws_bytes);
@@ -1956,6 +1957,23 @@ static int pf_gemm_gq(bz_model* m, const FusedLinear& F, const float* xf, int n,
   return bzk_gemm_nt(st, BZ_F16, m->pf_x3, w3, nullptr, n, N, 3 * K, BZ_F32, y, m->pf_ws, m->pf_ws_bytes, m->pf_rscale);
 }
 
+// EXACT prompt rows (f16 int4 models): the multi-row form of the decode kernels' integer arithmetic for every projection, the exact scalar attention and
+// the decode lm_head -- a prompt row is then the same bits as the decode step would produce for it (and as the oracle's: tests/test_gpu_exact_prefill.py).
+// One pass over the weights serves 8 rows and costs ~3.9 ms at the 8B AWQ shape (13 launches per layer), the MFMA path has a floor of ~4.6 ms: up to
+// BZ_EXACT_PREFILL_MAX rows (default 16: two passes) exactness is nearly free (32 rows: 15.8 vs 4.8 ms); longer prompts take the matrix cores, whose f32 accumulation order differs from the exact sums: ~1e-6 per GEMM, which the f16 roundings
+// of a deep model amplify to the f16 noise floor (profiles/r03_prefill_parity_depth.txt).  BZ_EXACT_PREFILL=1 forces the exact rows for every prompt length.
+static bool prefill_exact(const bz_model* m, int n, bool decode_batch) {
+  static const bool force = getenv("BZ_EXACT_PREFILL") != nullptr && atoi(getenv("BZ_EXACT_PREFILL")) != 0;
+  static const bool never = getenv("BZ_EXACT_PREFILL") != nullptr && atoi(getenv("BZ_EXACT_PREFILL")) == 0;
+  static const int max_rows = getenv("BZ_EXACT_PREFILL_MAX") ? atoi(getenv("BZ_EXACT_PREFILL_MAX")) : 16;
+  if (never || decode_batch || m->cfg.act_dtype != BZ_F16) return false;
+  if (!force && n > max_rows) return false;
+  for (const LayerDev& L : m->layers)
+    for (const FusedLinear* F : {&L.qkv, &L.o, &L.gateup, &L.down})
+      if (F->parts.size() != 1 || !bzk_gemm_q4g_rows_ok(F->parts[0])) return false;
+  return true;
+}
+
 // tokens [S] at positions pos0 .. pos0+S-1; `slots` (paged only): device i32 [S].  Logits of the last row (or all rows) -> logits_out.
 // per-row context of a decode batch: row r is its own sequence (position row_pos[r], block-table row r); nullptr row_pos = one prompt
 struct RowsCtx { const int* row_pos = nullptr; int table_stride = 0; int max_len = 0; };
@@ -1967,6 +1985,8 @@ static int prefill_dense(bz_model* m, const long long* d_tok, int S, const KvVie
   const int H = c.hidden, I = c.inter, nq = c.n_heads, nkv = c.n_kv_heads, hd = c.head_dim, act = c.act_dtype, dt = c.act_dtype;
   const int CH = rc.row_pos ? 512 : 2048;      // prompts: 2048-row chunks (larger GEMMs: 8B AWQ 2048-token prompt 105 -> 90 ms)
   BZ_TRY(prefill_ws(m, std::min(S, CH)));
+  const bool exact = prefill_exact(m, S, rc.row_pos != nullptr);
+  const bool attn_exact = exact || act == BZ_F32;       // f32 models: the oracle's double-precision sums cost little next to the f32 cache reads
   for (int s0 = 0; s0 < S; s0 += CH) {
     const int n = std::min(CH, S - s0), p0 = pos0 + s0;
     // decode batch (row_pos set): one block-table row per sequence -- the kernels index rows by the row number INSIDE the chunk, so the chunk
@@ -1979,21 +1999,21 @@ static int prefill_dense(bz_model* m, const long long* d_tok, int S, const KvVie
       const LayerDev& L = m->layers[l];
       const bool gq = act == BZ_F32;      // block-format projections: f32 rows, split operands
       BZ_TRY(bzk_pf_norm(st, dt, m->pf_h, prev, L.attn_norm, n, H, c.rms_eps, act, m->pf_x16));
-      BZ_TRY(gq ? pf_gemm_gq(m, L.qkv, (const float*)m->pf_x16, n, m->pf_qkv) : pf_gemm(m, L.qkv.parts[0], m->pf_x16, n, m->pf_qkv));
+      BZ_TRY(gq ? pf_gemm_gq(m, L.qkv, (const float*)m->pf_x16, n, m->pf_qkv) : pf_gemm(m, L.qkv.parts[0], m->pf_x16, n, m->pf_qkv, exact));
       BZ_TRY(bzk_pf_rope_kv(st, m->pf_qkv, n, nq, nkv, hd, m->cos_t, m->sin_t, c.rope_interleaved, p0, act, vw, l, slots ? slots + s0 : nullptr,
                             rc.row_pos ? rc.row_pos + s0 : nullptr));
-      BZ_TRY(bzk_pf_attn(st, dt, m->pf_qkv, n, nq, nkv, hd, p0, act, vw, l, m->pf_x16, rc.row_pos ? rc.row_pos + s0 : nullptr, rc.table_stride, rc.max_len));
-      BZ_TRY(gq ? pf_gemm_gq(m, L.o, (const float*)m->pf_x16, n, m->pf_t) : pf_gemm(m, L.o.parts[0], m->pf_x16, n, m->pf_t));
+      BZ_TRY(bzk_pf_attn(st, dt, m->pf_qkv, n, nq, nkv, hd, p0, act, vw, l, m->pf_x16, rc.row_pos ? rc.row_pos + s0 : nullptr, rc.table_stride, rc.max_len, attn_exact));
+      BZ_TRY(gq ? pf_gemm_gq(m, L.o, (const float*)m->pf_x16, n, m->pf_t) : pf_gemm(m, L.o.parts[0], m->pf_x16, n, m->pf_t, exact));
       BZ_TRY(bzk_pf_norm(st, dt, m->pf_h, m->pf_t, L.ffn_norm, n, H, c.rms_eps, act, m->pf_x16));
-      BZ_TRY(gq ? pf_gemm_gq(m, L.gateup, (const float*)m->pf_x16, n, m->pf_gu) : pf_gemm(m, L.gateup.parts[0], m->pf_x16, n, m->pf_gu));
+      BZ_TRY(gq ? pf_gemm_gq(m, L.gateup, (const float*)m->pf_x16, n, m->pf_gu) : pf_gemm(m, L.gateup.parts[0], m->pf_x16, n, m->pf_gu, exact));
       BZ_TRY(bzk_pf_silu(st, dt, m->pf_gu, n, I, act, m->pf_x16));
-      BZ_TRY(gq ? pf_gemm_gq(m, L.down, (const float*)m->pf_x16, n, m->pf_t) : pf_gemm(m, L.down.parts[0], m->pf_x16, n, m->pf_t));
+      BZ_TRY(gq ? pf_gemm_gq(m, L.down, (const float*)m->pf_x16, n, m->pf_t) : pf_gemm(m, L.down.parts[0], m->pf_x16, n, m->pf_t, exact));
       prev = m->pf_t;
     }
     // head.  Several rows wanted (all_logits, decode batch) and a dense lm_head in the activation dtype: final norm rows + one MFMA GEMM that
     // streams the lm_head once; otherwise the decode lm_head GEMV per row (final norm fused as its prologue)
     const LinearDev& LH = m->lm_head.parts[0];
-    if (all && n > 1 && act != BZ_F32 && LH.wdt == act && LH.K % 64 == 0 && logits_out->nbytes >= (size_t)(s0 + n) * c.vocab * 4) {
+    if (all && n > 1 && !exact && act != BZ_F32 && LH.wdt == act && LH.K % 64 == 0 && logits_out->nbytes >= (size_t)(s0 + n) * c.vocab * 4) {
       BZ_TRY(bzk_pf_norm(st, dt, m->pf_h, prev, m->final_norm, n, H, c.rms_eps, act, m->pf_x16));
       BZ_TRY(bzk_gemm_nt(st, act, m->pf_x16, LH.w, LH.bias, n, c.vocab, H, act, (float*)logits_out->ptr + (size_t)s0 * c.vocab, m->pf_ws, m->pf_ws_bytes));
       continue;

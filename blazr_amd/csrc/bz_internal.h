@@ -338,7 +338,7 @@ int bzk_pf_norm(hipStream_t s, int dt, float* hbuf, const float* prev, const flo
 int bzk_pf_rope_kv(hipStream_t s, float* qkv, int S, int nq, int nkv, int hd, const float* cos_t, const float* sin_t, int interleaved, int pos0, int act,
                    const KvView& kv, int layer, const int* slots, const int* row_pos = nullptr);
 int bzk_pf_attn(hipStream_t s, int dt, const float* qkv, int S, int nq, int nkv, int hd, int pos0, int act, const KvView& kv, int layer, void* out16,
-                const int* row_pos = nullptr, int table_stride = 0, int max_len = 0);
+                const int* row_pos = nullptr, int table_stride = 0, int max_len = 0, bool exact = false);
 // Mamba2 batched prefill (bz_prefill.hip): conv over the prompt rows (+ carried conv state), in-kernel scan over the tokens, gated RMSNorm rows
 struct BzSsmScan {
   const float* xbc; int conv_dim; const float* zx; int ld; int dt_off; const float* dt_bias; const float* A_log; const float* D; void* state;
@@ -350,7 +350,7 @@ int bzk_pf_conv(hipStream_t s, const float* zx, int ld, int x_off, int conv_dim,
 int bzk_ssm_scan(hipStream_t s, const BzSsmScan& b, int state_dtype);
 int bzk_pf_gnorm(hipStream_t s, int dt, const float* v, const float* vss, const float* w, int S, int DI, int G, int NH, float eps, int act, void* x16);
 int bzk_pf_silu(hipStream_t s, int dt, const float* gu, int S, int I, int act, void* a16);
-size_t bzk_pf_attn_smem(int nq, int nkv, int hd, int len);
+size_t bzk_pf_attn_smem(int nq, int nkv, int hd, int len, bool exact = false);
 bool bzk_pf_attn_mfma_ok(int hd, int rep);
 
 // non-greedy sampling (bz_sample.hip)

@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include "bz_internal.h"
+#include <type_traits>
 
 namespace {
 
@@ -257,19 +258,21 @@ __global__ __launch_bounds__(256) void k_gemm_nt2(const unsigned short* __restri
 // row s: h <- R(h + prev) (prev optional) ; x16 <- to16(R(w * R(h * rs)))        grid = S
 template <int DT>
 __global__ __launch_bounds__(256) void k_pf_norm(float* hbuf, const float* prev, const float* w, int H, float eps, int act, void* x16) {
-  __shared__ float red[4];
+  __shared__ double red[4];
   float* hr = hbuf + (size_t)blockIdx.x * H;
   const float* pr = prev ? prev + (size_t)blockIdx.x * H : nullptr;
-  float ss = 0.f;
+  // the oracle's rule (orc_rms_norm): f32 squares summed in double, ONE rounding to f32 -- the decode kernels carry the sum the same way, so a row's 1 / rms is
+  // the same bits on both paths (a 1e-7 difference flips f16 roundings of the normalised row)
+  double ssd = 0.0;
   for (int i = threadIdx.x; i < H; i += 256) {
     float v = hr[i];
     if (pr) { v = pf_round(v + pr[i], act); hr[i] = v; }
-    ss += v * v;
+    ssd += (double)(v * v);
   }
-  ss = wave_sum(ss);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+  ssd = wave_sum_d(ssd);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ssd;
   __syncthreads();
-  ss = (red[0] + red[1]) + (red[2] + red[3]);
+  const float ss = (float)((red[0] + red[1]) + (red[2] + red[3]));
   const float rs = rms_scale(ss, (float)H, eps);
   for (int i = threadIdx.x; i < H; i += 256) put_x<DT>(x16, (size_t)blockIdx.x * H + i, pf_round(w[i] * pf_round(hr[i] * rs, act), act));
 }
@@ -335,18 +338,22 @@ __device__ __forceinline__ void ld_row8(const void* base, size_t off, float (&o)
     for (int i = 0; i < 4; i++) { o[2 * i] = from16<KVDT>((unsigned short)(u[i] & 0xffffu)); o[2 * i + 1] = from16<KVDT>((unsigned short)(u[i] >> 16)); }
   }
 }
-template <int DT, int KVDT, int REP>
+// EXACT: the oracle's arithmetic (orc_attn_decode), which is also the decode kernels' (k_attn2): score = f32(sum_double q k) * scale, p = exp(score - max),
+// l = f32(sum_double p), out = f32(sum_double p v) / l (IEEE division).  Products of 16-bit values (and of an f32 weight with one) are exact in double and the
+// sums are order-independent to ~1e-16, so a prompt row's attention output is the same bits as the decode step's.  (Non-exact form: f32 FMAs.)
+template <int DT, int KVDT, int REP, bool EXACT>
 __global__ __launch_bounds__(256) void k_pf_attn(const float* qkv, int nq, int nkv, int hd, int pos0, int act, KvView kv, int layer, float scale, void* out16,
                                                 const int* row_pos, int table_stride) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  typedef typename std::conditional<EXACT, double, float>::type acc_t;
   const int s = blockIdx.x, kvh = blockIdx.y, len = (row_pos ? row_pos[s] : pos0 + s) + 1;
   const int* btab = kv.block_table + (row_pos ? (size_t)s * table_stride : 0);   // decode batch: one block-table row per sequence
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int PR = hd >> 3, RPP = 256 / PR;              // lanes per row, rows per pass
   const int c = tid % PR, g = tid / PR;                // this thread's 8-dim piece and row slot
-  float* red = lds;                                    // [REP][4] + [REP][4]
-  float* part = red + 8 * REP;                         // [RPP][REP][hd]
-  float* sc = part + RPP * REP * hd;                   // [REP][len]
+  acc_t* red = (acc_t*)lds;                            // [REP][4] maxima (as acc_t) + [REP][4] sums
+  acc_t* part = red + 8 * REP;                         // [RPP][REP][hd]
+  float* sc = (float*)(part + RPP * REP * hd);         // [REP][len]
   float q[REP][8];
 #pragma unroll
   for (int h = 0; h < REP; h++)
@@ -364,13 +371,19 @@ __global__ __launch_bounds__(256) void k_pf_attn(const float* qkv, int nq, int n
     ld_row8<DT, KVDT>(kv.k, row_off(min(pb, len - 1)), k1);
 #pragma unroll
     for (int h = 0; h < REP; h++) {
-      float d0 = 0.f, d1 = 0.f;
+      acc_t d0 = 0, d1 = 0;
 #pragma unroll
-      for (int e = 0; e < 8; e++) { d0 += q[h][e] * k0[e]; d1 += q[h][e] * k1[e]; }
-      if (PR == 16) { d0 = grp_reduce<16, OpAdd>(d0); d1 = grp_reduce<16, OpAdd>(d1); }
-      else if (PR == 8) { d0 = grp_reduce<8, OpAdd>(d0); d1 = grp_reduce<8, OpAdd>(d1); }
-      else for (int m = 1; m < PR; m <<= 1) { d0 += __shfl_xor(d0, m, 64); d1 += __shfl_xor(d1, m, 64); }
-      if (c == 0) { if (pa < len) sc[h * len + pa] = d0 * scale; if (pb < len) sc[h * len + pb] = d1 * scale; }
+      for (int e = 0; e < 8; e++) { d0 += (acc_t)q[h][e] * (acc_t)k0[e]; d1 += (acc_t)q[h][e] * (acc_t)k1[e]; }
+      if constexpr (EXACT) {
+        if (PR == 16) { d0 = grp_sum_d<16>(d0); d1 = grp_sum_d<16>(d1); }
+        else if (PR == 8) { d0 = grp_sum_d<8>(d0); d1 = grp_sum_d<8>(d1); }
+        else for (int m = 1; m < PR; m <<= 1) { d0 += __shfl_xor(d0, m, 64); d1 += __shfl_xor(d1, m, 64); }
+      } else {
+        if (PR == 16) { d0 = grp_reduce<16, OpAdd>(d0); d1 = grp_reduce<16, OpAdd>(d1); }
+        else if (PR == 8) { d0 = grp_reduce<8, OpAdd>(d0); d1 = grp_reduce<8, OpAdd>(d1); }
+        else for (int m = 1; m < PR; m <<= 1) { d0 += __shfl_xor(d0, m, 64); d1 += __shfl_xor(d1, m, 64); }
+      }
+      if (c == 0) { if (pa < len) sc[h * len + pa] = (float)d0 * scale; if (pb < len) sc[h * len + pb] = (float)d1 * scale; }
     }
   }
   __syncthreads();
@@ -380,24 +393,24 @@ __global__ __launch_bounds__(256) void k_pf_attn(const float* qkv, int nq, int n
     float m = -INFINITY;
     for (int p = tid; p < len; p += 256) m = fmaxf(m, sc[h * len + p]);
     m = wave_max(m);
-    if (lane == 0) red[h * 4 + wave] = m;
+    if (lane == 0) red[h * 4 + wave] = (acc_t)m;
   }
   __syncthreads();
 #pragma unroll
   for (int h = 0; h < REP; h++) {
-    const float m = fmaxf(fmaxf(red[h * 4], red[h * 4 + 1]), fmaxf(red[h * 4 + 2], red[h * 4 + 3]));
-    float sum = 0.f;
-    for (int p = tid; p < len; p += 256) { const float e = bz_expf(sc[h * len + p] - m); sc[h * len + p] = e; sum += e; }
-    sum = wave_sum(sum);
+    const float m = fmaxf(fmaxf((float)red[h * 4], (float)red[h * 4 + 1]), fmaxf((float)red[h * 4 + 2], (float)red[h * 4 + 3]));
+    acc_t sum = 0;
+    for (int p = tid; p < len; p += 256) { const float e = bz_expf(sc[h * len + p] - m); sc[h * len + p] = e; sum += (acc_t)e; }
+    if constexpr (EXACT) sum = wave_sum_d(sum); else sum = wave_sum(sum);
     if (lane == 0) red[4 * REP + h * 4 + wave] = sum;
   }
   __syncthreads();
   // ---- PV: thread (c, g) accumulates its 8 dims over rows g, g + RPP, ... ----
-  float acc[REP][8];
+  acc_t acc[REP][8];
 #pragma unroll
   for (int h = 0; h < REP; h++)
 #pragma unroll
-    for (int e = 0; e < 8; e++) acc[h][e] = 0.f;
+    for (int e = 0; e < 8; e++) acc[h][e] = 0;
   for (int p0 = 0; p0 < len; p0 += 2 * RPP) {
     float v0[8], v1[8];
     const int pa = p0 + g, pb = p0 + RPP + g;
@@ -405,9 +418,9 @@ __global__ __launch_bounds__(256) void k_pf_attn(const float* qkv, int nq, int n
     ld_row8<DT, KVDT>(kv.v, row_off(min(pb, len - 1)), v1);
 #pragma unroll
     for (int h = 0; h < REP; h++) {
-      const float w0 = pa < len ? sc[h * len + pa] : 0.f, w1 = pb < len ? sc[h * len + pb] : 0.f;
+      const acc_t w0 = pa < len ? (acc_t)sc[h * len + pa] : (acc_t)0, w1 = pb < len ? (acc_t)sc[h * len + pb] : (acc_t)0;
 #pragma unroll
-      for (int e = 0; e < 8; e++) acc[h][e] += w0 * v0[e] + w1 * v1[e];
+      for (int e = 0; e < 8; e++) acc[h][e] += w0 * (acc_t)v0[e] + w1 * (acc_t)v1[e];
     }
   }
 #pragma unroll
@@ -417,10 +430,13 @@ __global__ __launch_bounds__(256) void k_pf_attn(const float* qkv, int nq, int n
   __syncthreads();
   for (int i = tid; i < REP * hd; i += 256) {
     const int h = i / hd, d = i % hd;
-    float a = 0.f;
+    acc_t a = 0;
     for (int gg = 0; gg < RPP; gg++) a += part[(gg * REP + h) * hd + d];
-    const float invh = 1.0f / ((red[4 * REP + h * 4] + red[4 * REP + h * 4 + 1]) + (red[4 * REP + h * 4 + 2] + red[4 * REP + h * 4 + 3]));
-    put_x<DT>(out16, (size_t)s * nq * hd + (size_t)(kvh * REP + h) * hd + d, pf_round(a * invh, act));
+    const acc_t lsum = (red[4 * REP + h * 4] + red[4 * REP + h * 4 + 1]) + (red[4 * REP + h * 4 + 2] + red[4 * REP + h * 4 + 3]);
+    float o;
+    if constexpr (EXACT) o = div_rn((float)a, (float)lsum);
+    else o = (float)a * (1.0f / (float)lsum);
+    put_x<DT>(out16, (size_t)s * nq * hd + (size_t)(kvh * REP + h) * hd + d, pf_round(o, act));
   }
 }
 
@@ -1319,16 +1335,16 @@ bool bzk_pf_attn_mfma_ok(int hd, int rep) {     // prompts: the MFMA flash kerne
   static const bool off = getenv("BZ_NO_PF_ATTN_MFMA") != nullptr;
   return !off && (hd == 64 || hd == 128) && (rep == 1 || rep == 2 || rep == 4 || rep == 8);
 }
-size_t bzk_pf_attn_smem(int nq, int nkv, int hd, int len) {
+size_t bzk_pf_attn_smem(int nq, int nkv, int hd, int len, bool exact) {
   const int REP = nq / nkv, RPP = 256 / (hd / 8);
-  return (size_t)(8 * REP + RPP * REP * hd + REP * len) * 4 + 64;
+  return (size_t)(8 * REP + RPP * REP * hd) * (exact ? 8 : 4) + (size_t)REP * len * 4 + 64;
 }
 int bzk_pf_attn(hipStream_t s, int dt, const float* qkv, int S, int nq, int nkv, int hd, int pos0, int act, const KvView& kv, int layer, void* out16,
-                const int* row_pos, int table_stride, int max_len) {
+                const int* row_pos, int table_stride, int max_len, bool exact) {
   const int REP = nq / nkv;
   if (hd % 8 || hd > 256 || (256 % (hd / 8)) || (REP != 1 && REP != 2 && REP != 4 && REP != 8) || kv.dtype != dt)
     BZ_FAIL(BZ_E_UNSUPPORTED, "prefill attention: head_dim %d / group size %d / cache dtype unsupported", hd, REP);
-  if (!row_pos && dt != BZ_F32 && bzk_pf_attn_mfma_ok(hd, REP)) {
+  if (!row_pos && dt != BZ_F32 && !exact && bzk_pf_attn_mfma_ok(hd, REP)) {
     const float scale_m = div_rn(1.0f, sqrt_rn((float)hd));
     const int HW = REP < 4 ? REP : 4, QT = 4 / HW;
     const dim3 grid((S + 32 * QT - 1) / (32 * QT), nkv, REP / HW);
@@ -1345,15 +1361,16 @@ int bzk_pf_attn(hipStream_t s, int dt, const float* qkv, int S, int nq, int nkv,
     return BZ_OK;
   }
   const int ctx = row_pos ? max_len : pos0 + S;
-  const size_t smem = bzk_pf_attn_smem(nq, nkv, hd, ctx);
+  const size_t smem = bzk_pf_attn_smem(nq, nkv, hd, ctx, exact);
   if (smem > 160 * 1024) BZ_FAIL(BZ_E_UNSUPPORTED, "prefill attention: context %d too long for this kernel", ctx);
   const float scale = div_rn(1.0f, sqrt_rn((float)hd));
-#define LAUNCH_PFA(DT, R) do { \
+#define LAUNCH_PFA(DT, R, EX) do { \
     static bool attr_done = false; \
-    if (!attr_done) { BZ_HIP(hipFuncSetAttribute((const void*)k_pf_attn<DT, DT, R>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_done = true; } \
-    hipLaunchKernelGGL((k_pf_attn<DT, DT, R>), dim3(S, nkv), dim3(256), smem, s, qkv, nq, nkv, hd, pos0, act, kv, layer, scale, out16, row_pos, table_stride); } while (0)
-#define LAUNCH_PFA_R(DT) do { if (REP == 1) LAUNCH_PFA(DT, 1); else if (REP == 2) LAUNCH_PFA(DT, 2); else if (REP == 4) LAUNCH_PFA(DT, 4); else LAUNCH_PFA(DT, 8); } while (0)
-  if (dt == BZ_F16) LAUNCH_PFA_R(BZ_F16); else if (dt == BZ_F32) LAUNCH_PFA_R(BZ_F32); else LAUNCH_PFA_R(BZ_BF16);
+    if (!attr_done) { BZ_HIP(hipFuncSetAttribute((const void*)k_pf_attn<DT, DT, R, EX>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_done = true; } \
+    hipLaunchKernelGGL((k_pf_attn<DT, DT, R, EX>), dim3(S, nkv), dim3(256), smem, s, qkv, nq, nkv, hd, pos0, act, kv, layer, scale, out16, row_pos, table_stride); } while (0)
+#define LAUNCH_PFA_R(DT, EX) do { if (REP == 1) LAUNCH_PFA(DT, 1, EX); else if (REP == 2) LAUNCH_PFA(DT, 2, EX); else if (REP == 4) LAUNCH_PFA(DT, 4, EX); else LAUNCH_PFA(DT, 8, EX); } while (0)
+  if (exact) { if (dt == BZ_F16) LAUNCH_PFA_R(BZ_F16, true); else if (dt == BZ_F32) LAUNCH_PFA_R(BZ_F32, true); else LAUNCH_PFA_R(BZ_BF16, true); }
+  else { if (dt == BZ_F16) LAUNCH_PFA_R(BZ_F16, false); else if (dt == BZ_F32) LAUNCH_PFA_R(BZ_F32, false); else LAUNCH_PFA_R(BZ_BF16, false); }
 #undef LAUNCH_PFA_R
 #undef LAUNCH_PFA
   BZ_HIP(hipGetLastError());

@@ -1,0 +1,86 @@
+"""GPU parity: the EXACT prompt rows of f16 int4 models (bz_host.hip `prefill_exact`).
+Prompts of up to BZ_EXACT_PREFILL_MAX (16) rows -- and every prompt under BZ_EXACT_PREFILL=1 -- run the multi-row form of the decode kernels' integer
+arithmetic (8 rows per pass over the weights), the exact scalar attention (double-precision sums, IEEE division) and the decode lm_head, so a prompt row is
+the SAME BITS as the decode step's row and sits where the decode rows sit against the oracle.  Longer prompts take the MFMA GEMMs, whose f32 accumulation
+order differs (at depth, the f16 roundings amplify any difference to the f16 noise floor).
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from blazr_amd import _lib as L
+from blazr_amd import runtime, synth
+from oracle import orc_py
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+CASES = [("tiny-awq", {}, 16), ("tiny-gptq", {}, 12), ("llama3-8b-awq-2l", dict(vocab=4096), 16), ("llama3-8b-awq-2l", dict(vocab=4096, n_layers=6), 13)]
+
+
+@pytest.mark.parametrize("preset,over,S", CASES, ids=["%s-%d" % (c[0], c[2]) for c in CASES])
+def test_short_prompt_rows_are_the_decode_rows_bit_for_bit(device, preset, over, S):
+    model = synth.make_llama(preset, **over)
+    cfg = model["config"]
+    lm, om = runtime.LoadedModel.from_synth(device, model), orc_py.OrcLlama(model)
+    nl, nkv = cfg["n_layers"], cfg["n_kv_heads"]
+    p = [int(t) for t in synth.prompt_tokens(S, cfg["vocab"], seed=31)]
+    mk = lambda: runtime.LayeredKvCache(device, nl, 1, nkv, S + 8, cfg["max_seq_len"], cfg["head_dim"], L.F16)
+    kv_a, kv_b = mk(), mk()
+    got = lm.forward_with_kv_cache(p, kv_a, 0, all_logits=True).to_numpy().reshape(S, -1)                        # one call: the batched (exact) rows
+    step = np.stack([lm.forward_with_kv_cache([t], kv_b, i).to_numpy().reshape(-1) for i, t in enumerate(p)])     # one call per token: the decode kernels
+    assert np.array_equal(got, step), "%d of %d logits differ" % (int((got != step).sum()), got.size)
+    for l in range(nl):
+        for which in (0, 1):
+            a = np.concatenate([kv_a.read(l, h, which, S).reshape(-1) for h in range(nkv)])
+            b = np.concatenate([kv_b.read(l, h, which, S).reshape(-1) for h in range(nkv)])
+            assert np.array_equal(a, b), (l, which, int((a != b).sum()))
+    okv = om.new_kv(S + 8)
+    want = om.forward_kv(p, okv, 0, all_logits=True).reshape(S, -1)
+    worst = max(_rel(got[i], want[i]) for i in range(S))
+    print("%s: %d prompt rows == decode rows; vs oracle worst row %.2e" % (preset, S, worst))
+    assert worst <= 1e-4          # what is left is the dense f16 lm_head's f32 summation order (and rare 2^-44-grid ties), as for the decode rows
+    orc_py.lib().orc_kv_free(okv)
+
+
+_CHILD = r"""
+import sys
+import numpy as np
+from blazr_amd import _lib as L, runtime, synth
+model = synth.make_llama("llama3-8b-awq-2l", vocab=2048)
+cfg = model["config"]
+dev = runtime.Device(0)
+lm = runtime.LoadedModel.from_synth(dev, model)
+S = 70
+p = [int(t) for t in synth.prompt_tokens(S, cfg["vocab"], seed=32)]
+mk = lambda: runtime.LayeredKvCache(dev, cfg["n_layers"], 1, cfg["n_kv_heads"], 80, cfg["max_seq_len"], cfg["head_dim"], L.F16)
+kv_a, kv_b = mk(), mk()
+a = lm.forward_with_kv_cache(p, kv_a, 0, all_logits=True).to_numpy().reshape(S, -1)
+b = np.stack([lm.forward_with_kv_cache([t], kv_b, i).to_numpy().reshape(-1) for i, t in enumerate(p)])
+print("DIFF", int((a != b).sum()), float(np.linalg.norm(a.astype(np.float64) - b) / np.linalg.norm(b)))
+"""
+
+
+def _child(env):
+    e = dict(os.environ)
+    e.update(env)
+    e["PYTHONPATH"] = os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + os.pathsep + e.get("PYTHONPATH", "")
+    r = subprocess.run([sys.executable, "-c", _CHILD], env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("DIFF")][0].split()
+    return int(line[1]), float(line[2])
+
+
+def test_forced_exact_rows_for_a_long_prompt_and_the_mfma_rows_beside_them():
+    n_forced, _ = _child({"BZ_EXACT_PREFILL": "1"})
+    assert n_forced == 0                                   # 70 rows, 9 passes: bit-identical to the decode rows
+    n_mfma, rel_mfma = _child({})
+    assert n_mfma > 0 and rel_mfma <= 2e-3                 # the matrix-core rows: same values to the f16 noise floor of a 2-layer model, not the same bits
