@@ -1151,7 +1151,17 @@ static int finalize_mamba2(bz_model* m) {
     BZ_TRY(take_vector_f32(m, p + "mixer.conv1d.weight", conv_dim * KC, &L.conv_w));
     BZ_TRY(take_vector_f32(m, p + "mixer.conv1d.bias", conv_dim, &L.conv_b));
     BZ_TRY(take_vector_f32(m, p + "mixer.dt_bias", NH, &L.dt_bias, false));   // kept as stored (f32 in HF checkpoints)
-    BZ_TRY(take_vector_f32(m, p + "mixer.A_log", NH, &L.A_log, false));   // kept as stored (f32 in HF checkpoints)
+    if (m->raw.count(p + "mixer.A_log")) BZ_TRY(take_vector_f32(m, p + "mixer.A_log", NH, &L.A_log, false));   // kept as stored (f32 in HF checkpoints)
+    else {   // GGUF (llama.cpp convention): ssm_a = A = -exp(A_log); the kernels take A_log
+      BZ_TRY(take_vector_f32(m, p + "mixer.A", NH, &L.A_log, false));
+      std::vector<float> a(NH);
+      BZ_HIP(hipMemcpy(a.data(), L.A_log, (size_t)NH * 4, hipMemcpyDeviceToHost));
+      for (int i = 0; i < NH; i++) {
+        if (!(a[i] < 0.f)) BZ_FAIL(BZ_E_INVALID, "layer %d: mixer.A[%d] = %g is not negative (A = -exp(A_log))", l, i, (double)a[i]);
+        a[i] = logf(-a[i]);
+      }
+      BZ_HIP(hipMemcpy(L.A_log, a.data(), (size_t)NH * 4, hipMemcpyHostToDevice));
+    }
     BZ_TRY(take_vector_f32(m, p + "mixer.D", NH, &L.D, false));   // kept as stored (f32 in HF checkpoints)
     BZ_TRY(take_vector_f32(m, p + "mixer.norm.weight", DI, &L.gnorm));
     BZ_TRY(build_fused(m, {p + "mixer.in_proj"}, &L.in_proj));

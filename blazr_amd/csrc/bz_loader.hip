@@ -668,6 +668,24 @@ std::string gguf_to_hf_name(const std::string& n) {
   return "";
 }
 
+// llama.cpp's mamba2 tensor names (the names the reference's loader maps live in the absent boostr crate; llama.cpp's converter is the convention GGUF files follow)
+// -> the HF Mamba2 names bz_model_finalize expects.  ssm_a holds A = -exp(A_log) (the converter folds the exponential): it arrives as "mixer.A" and finalize
+// turns it back into A_log = log(-A).
+std::string gguf_to_hf_name_mamba2(const std::string& n) {
+  if (n == "token_embd.weight") return "backbone.embeddings.weight";
+  if (n == "output_norm.weight") return "backbone.norm_f.weight";
+  if (n == "output.weight") return "lm_head.weight";
+  if (n.compare(0, 4, "blk.") != 0) return "";
+  const size_t dot = n.find('.', 4);
+  if (dot == std::string::npos) return "";
+  const std::string idx = n.substr(4, dot - 4), rest = n.substr(dot + 1);
+  static const std::pair<const char*, const char*> MAP[] = {
+      {"attn_norm.weight", "norm.weight"}, {"ssm_in.weight", "mixer.in_proj.weight"}, {"ssm_conv1d.weight", "mixer.conv1d.weight"}, {"ssm_conv1d.bias", "mixer.conv1d.bias"},
+      {"ssm_dt.bias", "mixer.dt_bias"}, {"ssm_a", "mixer.A"}, {"ssm_d", "mixer.D"}, {"ssm_norm.weight", "mixer.norm.weight"}, {"ssm_out.weight", "mixer.out_proj.weight"}};
+  for (auto& m : MAP) if (rest == m.first) return "backbone.layers." + idx + "." + m.second;
+  return "";
+}
+
 size_t ggml_row_bytes(int type, int64_t K) {
   switch (type) { case 0: return (size_t)K * 4; case 1: case 30: return (size_t)K * 2; case 8: return (size_t)(K / 32) * 34; case 12: return (size_t)(K / 256) * 144;
                   case 14: return (size_t)(K / 256) * 210; default: return 0; }
@@ -678,7 +696,9 @@ int load_gguf(bz_device* dev, const std::string& path, bz_model** out, bz_model_
   BZ_TRY(g.open(path));
   bz_model_config c; std::string arch;
   BZ_TRY(gguf_config(g, &c, &arch));
-  if (c.arch != BZ_ARCH_LLAMA) BZ_FAIL(BZ_E_UNSUPPORTED, "GGUF architecture '%s': only the llama-family tensor naming is mapped in this build", arch.c_str());
+  if (c.arch != BZ_ARCH_LLAMA && c.arch != BZ_ARCH_MAMBA2)
+    BZ_FAIL(BZ_E_UNSUPPORTED, "GGUF architecture '%s': the llama-family and mamba2 tensor namings are mapped in this build", arch.c_str());
+  const bool mamba = c.arch == BZ_ARCH_MAMBA2;
   bool has_output = false;
   for (auto& t : g.tensors) if (t.name == "output.weight") has_output = true;
   c.tie_embeddings = has_output ? 0 : 1;
@@ -688,7 +708,7 @@ int load_gguf(bz_device* dev, const std::string& path, bz_model** out, bz_model_
   for (auto& t : g.tensors) {
     if (rc != BZ_OK) break;
     if (t.name == "rope_freqs.weight") continue;
-    const std::string hf = gguf_to_hf_name(t.name);
+    const std::string hf = mamba ? gguf_to_hf_name_mamba2(t.name) : gguf_to_hf_name(t.name);
     if (hf.empty()) { rc = BZ_E_UNSUPPORTED; bz_set_error("GGUF tensor '%s' has no mapping", t.name.c_str()); break; }
     if (t.ne.empty() || t.ne.size() > 2) { rc = BZ_E_UNSUPPORTED; bz_set_error("GGUF tensor '%s': rank %zu", t.name.c_str(), t.ne.size()); break; }
     const int64_t K = t.ne[0], N = t.ne.size() == 2 ? t.ne[1] : 1;      // ne[0] is the contiguous dimension
@@ -704,7 +724,11 @@ int load_gguf(bz_device* dev, const std::string& path, bz_model** out, bz_model_
     if (t.type == 0 || t.type == 1 || t.type == 30) {
       const int dt = t.type == 0 ? BZ_F32 : (t.type == 1 ? BZ_F16 : BZ_BF16);
       int64_t shape[2] = {N, K};
-      rc = t.ne.size() == 2 ? bz_model_add_dense(m, hf.c_str(), dt, shape, 2, data) : bz_model_add_dense(m, hf.c_str(), dt, &K, 1, data);
+      // per-head / per-channel vectors that llama.cpp stores with a unit or group axis ([1, heads], [d_inner / groups, groups]) are vectors here
+      const bool as_vec = mamba && t.ne.size() == 2 && hf.find("in_proj") == std::string::npos && hf.find("out_proj") == std::string::npos &&
+                          hf.find("conv1d.weight") == std::string::npos && hf != "backbone.embeddings.weight" && hf != "lm_head.weight";
+      const int64_t flat = N * K;
+      rc = (t.ne.size() == 2 && !as_vec) ? bz_model_add_dense(m, hf.c_str(), dt, shape, 2, data) : bz_model_add_dense(m, hf.c_str(), dt, as_vec ? &flat : &K, 1, data);
     } else {
       rc = bz_model_add_gguf(m, hf.c_str(), t.type, N, K, data);
     }

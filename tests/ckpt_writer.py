@@ -228,3 +228,58 @@ def write_gguf(path, model, arch="llama", extra_kv=None, with_vocab_array=False)
             f.write(b)
         end = f.tell()
         f.write(b"\0" * ((32 - end % 32) % 32))
+
+
+def write_gguf_mamba2(path, model):
+    """A Mamba2 model in llama.cpp's GGUF conventions (arch "mamba2"): ssm_in / ssm_conv1d / ssm_dt.bias / ssm_a (= -exp(A_log)) / ssm_d / ssm_norm / ssm_out,
+    unquantised tensors (F32 / F16 / BF16 as the synth model stores them), the per-head vectors with llama.cpp's unit axis."""
+    cfg = model["config"]
+    arch = "mamba2"
+    kv = [("general.architecture", GG_STR, arch), ("general.alignment", GG_U32, 32), (arch + ".embedding_length", GG_U32, cfg["hidden"]),
+          (arch + ".block_count", GG_U32, cfg["n_layers"]), (arch + ".context_length", GG_U32, 1 << 20),
+          (arch + ".ssm.state_size", GG_U32, cfg["d_state"]), (arch + ".ssm.conv_kernel", GG_U32, cfg["conv_kernel"]), (arch + ".ssm.inner_size", GG_U32, cfg["d_inner"]),
+          (arch + ".ssm.head_dim", GG_U32, cfg["head_dim"]), (arch + ".ssm.group_count", GG_U32, cfg["n_groups"]),
+          (arch + ".attention.layer_norm_rms_epsilon", GG_F32, cfg["rms_eps"]), ("general.vocab_size", GG_U32, cfg["vocab"])]
+    tensors = []
+    ty_of = {np.dtype(np.float32): 0, np.dtype(np.float16): 1, np.dtype(np.uint16): 30}
+
+    def add(name, ne, arr):
+        a = np.ascontiguousarray(arr)
+        tensors.append((name, ne, ty_of[a.dtype], a.tobytes()))
+
+    D, DI, NH, G = cfg["hidden"], cfg["d_inner"], cfg["n_heads"], cfg["n_groups"]
+    add("token_embd.weight", [D, cfg["vocab"]], model["embed"])
+    add("output_norm.weight", [D], np.asarray(model["final_norm"], np.float32))
+    if not cfg.get("tie_embeddings"):
+        add("output.weight", [D, cfg["vocab"]], model["lm_head"]["weight"])
+    for i, lay in enumerate(model["layers"]):
+        p = "blk.%d." % i
+        conv_dim = lay["conv_w"].shape[0]
+        add(p + "attn_norm.weight", [D], np.asarray(lay["norm"], np.float32))
+        add(p + "ssm_in.weight", [lay["in_proj"]["K"], lay["in_proj"]["N"]], lay["in_proj"]["weight"])
+        add(p + "ssm_conv1d.weight", [cfg["conv_kernel"], conv_dim], np.asarray(lay["conv_w"], np.float32))
+        add(p + "ssm_conv1d.bias", [conv_dim], np.asarray(lay["conv_b"], np.float32))
+        add(p + "ssm_dt.bias", [NH], np.asarray(lay["dt_bias"], np.float32))
+        add(p + "ssm_a", [1, NH], (-np.exp(np.asarray(lay["A_log"], np.float64))).astype(np.float32))
+        add(p + "ssm_d", [1, NH], np.asarray(lay["D"], np.float32))
+        add(p + "ssm_norm.weight", [DI // G, G], np.asarray(lay["gnorm"], np.float32))
+        add(p + "ssm_out.weight", [lay["out_proj"]["K"], lay["out_proj"]["N"]], lay["out_proj"]["weight"])
+    with open(path, "wb") as f:
+        f.write(b"GGUF" + struct.pack("<IQQ", 3, len(tensors), len(kv)))
+        for k, ty, v in kv:
+            f.write(_gs(k) + struct.pack("<I", ty))
+            f.write(struct.pack("<I", v) if ty == GG_U32 else (struct.pack("<f", v) if ty == GG_F32 else _gs(v)))
+        off, offs = 0, []
+        for name, ne, ty, b in tensors:
+            offs.append(off)
+            off = (off + len(b) + 31) // 32 * 32
+        for (name, ne, ty, b), o in zip(tensors, offs):
+            f.write(_gs(name) + struct.pack("<I", len(ne)) + b"".join(struct.pack("<Q", d) for d in ne) + struct.pack("<IQ", ty, o))
+        pos = f.tell()
+        f.write(b"\0" * ((32 - pos % 32) % 32))
+        base = f.tell()
+        for (name, ne, ty, b), o in zip(tensors, offs):
+            f.seek(base + o)
+            f.write(b)
+        end = f.tell()
+        f.write(b"\0" * ((32 - end % 32) % 32))

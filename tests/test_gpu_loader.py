@@ -81,6 +81,30 @@ def test_gguf_checkpoint_equals_in_memory_model(device, tmp_path, preset):
     assert runtime.Executor(loaded).generate(p, 8).tolist() == runtime.Executor(direct).generate(p, 8).tolist()
 
 
+@pytest.mark.parametrize("preset", ["tiny-mamba2-g2", "tiny-mamba2"])
+def test_mamba2_gguf_checkpoint(device, tmp_path, preset):
+    """A Mamba2 GGUF file in llama.cpp's tensor naming (arch "mamba2"; the names the reference maps live in the absent boostr crate, so llama.cpp's converter is the
+    convention): metadata -> config (loader/gguf.rs:214-262), ssm_* tensors -> the mixer, ssm_a = -exp(A_log) turned back into A_log.  GGUF files run with f32
+    activations (gguf.rs:305), so the in-memory twin is the same weights under act_dtype f32; A_log goes through exp and log once (1 ulp), hence a bar, not bit equality."""
+    model = synth.make_mamba2(preset)
+    path = str(tmp_path / "mamba2.gguf")
+    W.write_gguf_mamba2(path, model)
+    cfg, info = runtime.config_from_gguf(path)
+    mc = model["config"]
+    assert cfg.arch == L.ARCH_MAMBA2 and (cfg.hidden, cfg.n_layers, cfg.ssm_d_inner, cfg.ssm_d_state, cfg.ssm_n_heads, cfg.ssm_head_dim, cfg.ssm_n_groups, cfg.ssm_conv_kernel) == (
+        mc["hidden"], mc["n_layers"], mc["d_inner"], mc["d_state"], mc["n_heads"], mc["head_dim"], mc["n_groups"], mc["conv_kernel"])
+    loaded = runtime.load_model(device, path)
+    assert loaded.c.act_dtype == L.F32 and loaded.c.tie_embeddings == (1 if mc.get("tie_embeddings") else 0)
+    twin = dict(model)
+    twin["config"] = dict(mc, act_dtype="f32")
+    direct = runtime.LoadedModel.from_synth(device, twin)
+    p = synth.prompt_tokens(9, mc["vocab"], seed=30)
+    a, b = _logits(loaded, p).astype(np.float64), _logits(direct, p).astype(np.float64)
+    rel = float(np.linalg.norm(a - b) / np.linalg.norm(b))
+    assert rel <= 1e-5, rel
+    assert runtime.Executor(loaded).generate(p, 8).tolist() == runtime.Executor(direct).generate(p, 8).tolist()
+
+
 def test_loader_errors(device, tmp_path):
     model = synth.make_llama("tiny-awq")
     t = W.hf_tensors(model)
