@@ -331,6 +331,7 @@ struct bz_model {
   size_t gq_cache_bytes = 0;
   unsigned* gq_amax = nullptr; void* gq_w3_scratch = nullptr; size_t gq_w3_scratch_bytes = 0;
   void* pf_x3 = nullptr; float* pf_rscale = nullptr;   // split activation rows [rows][3 xw] f16 + their row scales
+  void* pf_xq = nullptr; size_t pf_xq_bytes = 0;       // int8 digit planes + row parameters of the exact integer-MFMA GEMM (bzk_pf_quant_i8)
   float* pf_ws = nullptr; size_t pf_ws_bytes = 0;   // W4A16 MFMA GEMM: split-K partials for short prompts / decode batches
   long long* ring[3] = {nullptr, nullptr, nullptr};
   float* dring[3] = {nullptr, nullptr, nullptr};   // direct-output twins of the ring (ROWS kernels)
@@ -1921,11 +1922,18 @@ static int prefill_ws(bz_model* m, int rows) {
 }
 
 // Y[n][N] = R(X16[n][K] . W^T): dense 16-bit weights on the matrix cores, int4 weights through the multi-row dot4 GEMM
-static int pf_gemm(bz_model* m, const LinearDev& P, const void* x16, int n, float* y, bool exact = false) {
+// exact: 0 = the f16 MFMA GEMM, 1 = the multi-row form of the decode kernels (8 rows per pass over the weights), 2 = the integer-MFMA GEMM (exact group sums)
+static int pf_gemm(bz_model* m, const LinearDev& P, const void* x16, int n, float* y, int exact = 0) {
   hipStream_t st = step_stream(m);
   const int act = m->cfg.act_dtype;
   if (P.kind == LK_ROWS) return bzk_gemm_nt(st, act, x16, P.w, P.bias, n, P.N, P.K, act, y, m->pf_ws, m->pf_ws_bytes);
-  if (exact) return bzk_gemm_q4g_rows(st, P, act, x16, n, act, m->pf_acc, y);      // the decode kernels' arithmetic, 8 rows per pass over the weights
+  if (exact == 2 && bzk_gemm_q4g_i8_ok(P, act)) {
+    size_t po; const size_t need = bzk_pf_quant_i8_bytes(n, P.K, &po);
+    if (m->pf_xq_bytes < need) { BZ_HIP(hipStreamSynchronize(st)); void* p; BZ_TRY(dev_alloc(m, &p, need)); m->pf_xq = p; m->pf_xq_bytes = need; }
+    BZ_TRY(bzk_pf_quant_i8(st, x16, n, P.K, m->pf_xq));
+    return bzk_gemm_q4g_i8(st, P, m->pf_xq, n, act, y);
+  }
+  if (exact) return bzk_gemm_q4g_rows(st, P, act, x16, n, act, m->pf_acc, y);
   // (dequantising an int4 linear to f16 once per chunk and running the f16 LDS-DMA GEMM was built and measured: 2048-token prompt 90 -> 65 ms, but
   //  R16((q - z) s) costs 1.4e-4 relative per GEMM and put awq 8B-width logits at 1.40e-3 against the 1e-3 bar -- removed)
   if (bzk_gemm_q4g_mfma_ok(P, act, n)) return bzk_gemm_q4g_mfma(st, P, x16, n, act, y, m->pf_ws, m->pf_ws_bytes);
@@ -1972,16 +1980,22 @@ static int pf_gemm_gq(bz_model* m, const FusedLinear& F, const float* xf, int n,
 // One pass over the weights serves 8 rows and costs ~3.9 ms at the 8B AWQ shape (13 launches per layer), the MFMA path has a floor of ~4.6 ms: up to
 // BZ_EXACT_PREFILL_MAX rows (default 16: two passes) exactness is nearly free (32 rows: 15.8 vs 4.8 ms); longer prompts take the matrix cores, whose f32 accumulation order differs from the exact sums: ~1e-6 per GEMM, which the f16 roundings
 // of a deep model amplify to the f16 noise floor (profiles/r03_prefill_parity_depth.txt).  BZ_EXACT_PREFILL=1 forces the exact rows for every prompt length.
-static bool prefill_exact(const bz_model* m, int n, bool decode_batch) {
-  static const bool force = getenv("BZ_EXACT_PREFILL") != nullptr && atoi(getenv("BZ_EXACT_PREFILL")) != 0;
-  static const bool never = getenv("BZ_EXACT_PREFILL") != nullptr && atoi(getenv("BZ_EXACT_PREFILL")) == 0;
+// returns 0 (MFMA f16 path), 1 (exact rows) or 2 (exact integer-MFMA GEMMs: BZ_EXACT_PREFILL=2 for every prompt, or prompts of up to BZ_EXACT_I8_MAX rows)
+static int prefill_exact(const bz_model* m, int n, bool decode_batch) {
+  static const int env = getenv("BZ_EXACT_PREFILL") ? atoi(getenv("BZ_EXACT_PREFILL")) : -1;     // -1: by prompt length
   static const int max_rows = getenv("BZ_EXACT_PREFILL_MAX") ? atoi(getenv("BZ_EXACT_PREFILL_MAX")) : 16;
-  if (never || decode_batch || m->cfg.act_dtype != BZ_F16) return false;
-  if (!force && n > max_rows) return false;
+  static const int max_i8 = getenv("BZ_EXACT_I8_MAX") ? atoi(getenv("BZ_EXACT_I8_MAX")) : 0;
+  if (env == 0 || decode_batch || m->cfg.act_dtype != BZ_F16) return 0;
+  int mode = 0;
+  if (env == 1) mode = 1; else if (env >= 2) mode = n <= 16 ? 1 : 2;
+  else if (n <= max_rows) mode = 1; else if (n <= max_i8) mode = 2;
+  if (!mode) return 0;
   for (const LayerDev& L : m->layers)
-    for (const FusedLinear* F : {&L.qkv, &L.o, &L.gateup, &L.down})
-      if (F->parts.size() != 1 || !bzk_gemm_q4g_rows_ok(F->parts[0])) return false;
-  return true;
+    for (const FusedLinear* F : {&L.qkv, &L.o, &L.gateup, &L.down}) {
+      if (F->parts.size() != 1 || !bzk_gemm_q4g_rows_ok(F->parts[0])) return 0;
+      if (mode == 2 && !bzk_gemm_q4g_i8_ok(F->parts[0], BZ_F16)) mode = 1;
+    }
+  return mode;
 }
 
 // tokens [S] at positions pos0 .. pos0+S-1; `slots` (paged only): device i32 [S].  Logits of the last row (or all rows) -> logits_out.
@@ -1995,8 +2009,8 @@ static int prefill_dense(bz_model* m, const long long* d_tok, int S, const KvVie
   const int H = c.hidden, I = c.inter, nq = c.n_heads, nkv = c.n_kv_heads, hd = c.head_dim, act = c.act_dtype, dt = c.act_dtype;
   const int CH = rc.row_pos ? 512 : 2048;      // prompts: 2048-row chunks (larger GEMMs: 8B AWQ 2048-token prompt 105 -> 90 ms)
   BZ_TRY(prefill_ws(m, std::min(S, CH)));
-  const bool exact = prefill_exact(m, S, rc.row_pos != nullptr);
-  const bool attn_exact = exact || act == BZ_F32;       // f32 models: the oracle's double-precision sums cost little next to the f32 cache reads
+  const int exact = prefill_exact(m, S, rc.row_pos != nullptr);
+  const bool attn_exact = exact != 0 || act == BZ_F32;       // f32 models: the oracle's double-precision sums cost little next to the f32 cache reads
   for (int s0 = 0; s0 < S; s0 += CH) {
     const int n = std::min(CH, S - s0), p0 = pos0 + s0;
     // decode batch (row_pos set): one block-table row per sequence -- the kernels index rows by the row number INSIDE the chunk, so the chunk

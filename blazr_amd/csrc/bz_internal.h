@@ -217,6 +217,11 @@ bool bzk_gq_split_ok(const LinearDev& L);
 int bzk_gq_absmax(hipStream_t s, const LinearDev& L, unsigned* amax);
 int bzk_gq_wscale(hipStream_t s, const unsigned* amax, float* wscale);
 int bzk_gq_split3(hipStream_t s, const LinearDev& L, const float* wscale, void* out, int row0);
+// exact W4 GEMM on the integer matrix cores (bz_prefill.hip: k_gemm_q4g_i8)
+bool bzk_gemm_q4g_i8_ok(const LinearDev& L, int xdt);
+size_t bzk_pf_quant_i8_bytes(int S, int K, size_t* par_off);
+int bzk_pf_quant_i8(hipStream_t s, const void* x16, int S, int K, void* xq);
+int bzk_gemm_q4g_i8(hipStream_t s, const LinearDev& L, const void* xq, int S, int act, float* y);
 int bzk_pf_split3(hipStream_t s, const float* x, int S, int K, void* xs, float* rscale, const float* wscale);
 int bzk_argmax_partials(hipStream_t s, const float* v, long long n, float* pval, int* pidx, int nb);
 int bzk_embed(hipStream_t s, const void* table, int tdt, const long long* tok, int H, int act, float* h_out, const int* pos = nullptr,

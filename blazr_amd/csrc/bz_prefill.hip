@@ -913,6 +913,179 @@ __global__ __launch_bounds__(256) void k_gemm_q4g_lds(const uint4* __restrict__ 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// EXACT W4 GEMM on the integer matrix cores: the decode kernels' arithmetic (bz_dev.h: x = c * code exactly, c a power of two per 128-k group, code a 32-bit
+// integer; sum_k (q_k - z) code_k an exact integer) at prompt scale.  The 32-bit code is FOUR balanced int8 digits (code = sum_p 256^p b_p, b_p in [-128, 127]:
+// the bytes of (code + 0x80808080) ^ 0x80808080), the stored nibbles are (q - 8) in two's complement, so (w << 4) & 0xF0F0F0F0 / w & 0xF0F0F0F0 ARE the int8
+// values 16 (q - 8) of four k each -- six VALU per 32-k chunk and tile, no table, no subtract.  v_mfma_i32_32x32x32_i8 (operand map verified with exact integer
+// data: scripts/mfma_i8_probe.hip) sums one digit plane of a 32-k chunk per instruction: |plane sum of a group| <= 128 * 128 * 128 = 2^21, exact in int32.
+// Per 128-k group and output the four plane sums are joined (two shifted int32 adds, then one double FMA: < 2^47), the zero point comes in through the row's
+// code sum ((8 - z) * sum_k code_k), and the group's term s * c * Int is added into a double per output -- q4_term's value, in q4g_consume's order of groups.
+// A lane's column is fixed (C layout: col = lane & 31), so scale and zero point are per-lane scalars of a group; the row parameters (c, code sum) of the
+// workgroup's 32 rows sit in LDS for all groups.  A wave owns 32 rows x 64 columns and walks its two 32-column tiles one after the other over the SAME four weight
+// chunks (64 accumulator registers instead of 128: two waves per SIMD, one folding while the other multiplies); the activation digits come straight from
+// global memory / L1 (16 bytes per lane, plane and chunk; the WPB waves of a workgroup sit side by side on the same rows).
+//   Xq: [4 planes][S][K] int8        par: [S][K / 128] { double code sum ; float c ; pad }        grid = (ceil(N / 64 / WPB), ceil(S / 32))
+// ---------------------------------------------------------------------------------------------------------------------------------------
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+struct __attribute__((aligned(16))) RowPar { double rsum; float c; float pad; };
+
+template <int XDT>
+__global__ __launch_bounds__(256) void k_pf_quant_i8(const unsigned short* __restrict__ X, int K, signed char* __restrict__ Xq, size_t plane_stride, RowPar* __restrict__ par) {
+  const int s = blockIdx.x, G = K >> 7;
+  const unsigned short* xr = X + (size_t)s * K;
+  for (int e0 = threadIdx.x * 8; e0 < K; e0 += 256 * 8) {        // 16 lanes per 128-k group (K % 128 == 0, so a group never straddles the loop)
+    const uint4 raw = *(const uint4*)(xr + e0);
+    const unsigned u[4] = {raw.x, raw.y, raw.z, raw.w};
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { v[2 * i] = from16<XDT>((unsigned short)(u[i] & 0xffffu)); v[2 * i + 1] = from16<XDT>((unsigned short)(u[i] >> 16)); }
+    float am = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) am = fmaxf(am, fabsf(v[i]));
+    am = grp_reduce<16, OpMax>(am);
+    const unsigned eb = (__float_as_uint(am) >> 23) & 255u;               // as xq_split8: am * 2^e in [2^29, 2^30)
+    const bool live = eb >= 32u && eb < 255u;
+    const float inv = live ? __uint_as_float((283u - eb) << 23) : 0.f, cs = live ? __uint_as_float((eb - 29u) << 23) : 0.f;
+    unsigned cb[8]; double rs = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { const int code = (int)rintf(v[i] * inv); rs += (double)code; cb[i] = ((unsigned)code + 0x80808080u) ^ 0x80808080u; }
+    rs = grp_sum_d<16>(rs);
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+      const unsigned sel = 0x0c0c0000u | ((4u + p) << 8) | (unsigned)p;   // [lo.byte p, hi.byte p, 0, 0]
+      uint2 w;
+      w.x = __builtin_amdgcn_perm(cb[1], cb[0], sel) | (__builtin_amdgcn_perm(cb[3], cb[2], sel) << 16);
+      w.y = __builtin_amdgcn_perm(cb[5], cb[4], sel) | (__builtin_amdgcn_perm(cb[7], cb[6], sel) << 16);
+      *(uint2*)(Xq + (size_t)p * plane_stride + (size_t)s * K + e0) = w;
+    }
+    if ((threadIdx.x & 15) == 0) { RowPar rp; rp.rsum = rs; rp.c = cs; rp.pad = 0.f; par[(size_t)s * G + (e0 >> 7)] = rp; }
+  }
+}
+
+template <int WPB, int DBG = 0, bool SEQ = true>     // DBG (timing experiments, BZ_I8_DBG): 1 = no fold, 2 = no MFMAs, 3 = no LDS fragment reads, 4 = interleaved tiles
+__global__ __launch_bounds__(WPB * 64) void k_gemm_q4g_i8(const uint4* __restrict__ W, const __half* __restrict__ Sc, const unsigned char* __restrict__ Z, const float* __restrict__ bias,
+                                                           int N, int K, const signed char* __restrict__ Xq, size_t plane_stride, const RowPar* __restrict__ par, int S, int act,
+                                                           float* __restrict__ Y) {
+  // LDS, two buffers: [4 planes][32 rows][128 B] digits of one 128-k group (16-byte pieces XOR-swizzled by row & 7: conflict-free ds_read_b128 of a 32-row column
+  // of pieces) + the 32 rows' parameters.  The workgroup's waves share the rows, both column tiles of a wave share them again: one global read per group and workgroup.
+  constexpr int NT = WPB * 64, PL = 4 * 32 * 128, BUF = PL + 32 * (int)sizeof(RowPar), LPT = PL / 16 / NT;   // LPT: 16-byte pieces per thread and group (4 or 8)
+  __shared__ __attribute__((aligned(16))) unsigned char sm[2 * BUF];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
+  // XCD-aware order (1-D grid): consecutive workgroups of one XCD (blockIdx.x % 8) walk the ROW tiles of one column group, so a group's weights cross HBM -> L2 once
+  const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3, mt = (S + 31) / 32, cg = (jj / mt) * 8 + xcd;
+  if (cg * WPB * 64 >= N) return;                              // (whole workgroup: no barrier is skipped by part of it)
+  const int G = K >> 7, C32 = K >> 5, r0 = (jj % mt) * 32;
+  const int tile = min(cg * WPB + wave, N / 64 - 1);           // 64-column tile of this wave (past the edge: a masked duplicate -- every wave stays for the barriers)
+  const bool cols_on = (cg * WPB + wave) * 64 < N;
+  const uint4* wp = W + (size_t)tile * C32 * 64 + lane;
+  const __half* sp = Sc + (size_t)tile * G * 64 + c;
+  const unsigned char* zp = Z + (size_t)tile * G * 64 + c;
+  // staging map: piece i of this thread = (plane, row, 16-byte column) of the group's digit tile
+  const signed char* src[LPT]; int dst[LPT];
+#pragma unroll
+  for (int i = 0; i < LPT; i++) {
+    const int idx = tid + NT * i, p = idx >> 8, row = (idx >> 3) & 31, pc = idx & 7;
+    src[i] = Xq + (size_t)p * plane_stride + (size_t)min(r0 + row, S - 1) * K + pc * 16;
+    dst[i] = p * 4096 + row * 128 + ((pc ^ (row & 7)) << 4);
+  }
+  const RowPar* psrc = par + (size_t)min(r0 + (tid & 31), S - 1) * G;
+  uint4 st[LPT]; RowPar stp;
+#pragma unroll
+  for (int i = 0; i < LPT; i++) st[i] = *(const uint4*)(src[i]);
+  stp = psrc[0];
+  double tot[2][16];
+#pragma unroll
+  for (int T = 0; T < 2; T++)
+#pragma unroll
+    for (int i = 0; i < 16; i++) tot[T][i] = 0.0;
+  u32x4 wn[4], wn2[4];                                         // the weights of groups g + 1 and g + 2: a cold 16-byte load takes longer than one group's arithmetic
+#pragma unroll
+  for (int cc = 0; cc < 4; cc++) wn[cc] = __builtin_nontemporal_load((const u32x4*)(wp + (size_t)cc * 64));
+#pragma unroll
+  for (int cc = 0; cc < 4; cc++) wn2[cc] = __builtin_nontemporal_load((const u32x4*)(wp + (size_t)(min(1, G - 1) * 4 + cc) * 64));
+  const int aoff = c * 128, sw = c & 7;
+  for (int g = 0; g < G; g++) {
+    unsigned char* buf = sm + (g & 1) * BUF;
+#pragma unroll
+    for (int i = 0; i < LPT; i++) *(uint4*)(buf + dst[i]) = st[i];
+    if (tid < 32) ((RowPar*)(buf + PL))[tid] = stp;
+    u32x4 w[4];
+#pragma unroll
+    for (int cc = 0; cc < 4; cc++) { w[cc] = wn[cc]; wn[cc] = wn2[cc]; }
+    {
+      const int gn = min(g + 1, G - 1), gn2 = min(g + 2, G - 1);   // last groups: harmless re-loads
+#pragma unroll
+      for (int i = 0; i < LPT; i++) st[i] = *(const uint4*)(src[i] + (size_t)gn * 128);
+      stp = psrc[gn];
+#pragma unroll
+      for (int cc = 0; cc < 4; cc++) wn2[cc] = __builtin_nontemporal_load((const u32x4*)(wp + (size_t)(gn2 * 4 + cc) * 64));
+    }
+    const float sT[2] = {__half2float(sp[(size_t)g * 64]), __half2float(sp[(size_t)g * 64 + 32])};
+    const int zT[2] = {(int)zp[(size_t)g * 64], (int)zp[(size_t)g * 64 + 32]};
+    __syncthreads();                                          // the group's tile is in LDS; everyone is done with the buffer the next iteration overwrites
+    const RowPar* rp = (const RowPar*)(buf + PL);
+#pragma unroll
+    for (int T = 0; T < 2; T++) {
+      i32x16 acc[4];
+#pragma unroll
+      for (int p = 0; p < 4; p++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[p][i] = 0;
+      i32x4 an[4];                                                                           // the next chunk's digit fragments: read from LDS under this chunk's MFMAs
+#pragma unroll
+      for (int p = 0; p < 4; p++) an[p] = *(const i32x4*)(buf + p * 4096 + aoff + ((h ^ sw) << 4));
+#pragma unroll
+      for (int cc = 0; cc < 4; cc++) {
+        i32x4 a[4];
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+          if (DBG == 3) a[p] = i32x4{(int)w[cc].x, p, cc, lane};
+          else a[p] = an[p];                                                                 // row c, k 32 cc + 16 h .. + 15
+        }
+        if (cc < 3) {
+#pragma unroll
+          for (int p = 0; p < 4; p++) an[p] = *(const i32x4*)(buf + p * 4096 + aoff + (((2 * (cc + 1) + h) ^ sw) << 4));
+        }
+        // this tile's nibble words: lanes (c, h) need k 16 h .. 16 h + 15 of column 32 T + c
+        const u32x2 rxz = __builtin_amdgcn_permlane32_swap(w[cc].x, w[cc].z, false, false);   // .x: {cols 0-31: k 0-7 | k 16-23}   .y: the same for cols 32-63
+        const u32x2 ryw = __builtin_amdgcn_permlane32_swap(w[cc].y, w[cc].w, false, false);   // .x: {cols 0-31: k 8-15 | k 24-31}  .y: cols 32-63
+        const unsigned n0 = T == 0 ? rxz.x : rxz.y, n1 = T == 0 ? ryw.x : ryw.y;
+        i32x4 b;
+        b.x = (int)((n0 << 4) & 0xF0F0F0F0u); b.y = (int)(n0 & 0xF0F0F0F0u); b.z = (int)((n1 << 4) & 0xF0F0F0F0u); b.w = (int)(n1 & 0xF0F0F0F0u);
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+          if (DBG == 2) acc[p][cc] += a[p].x ^ b.x;
+          else acc[p] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[p], b, acc[p], 0, 0, 0);
+        }
+      }
+      const double zz = (double)(8 - zT[T]), sd = (double)sT[T];
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        if (DBG == 1) { tot[T][i] += (double)(acc[0][i] ^ acc[1][i] ^ acc[2][i] ^ acc[3][i]); continue; }
+        const RowPar q = rp[(i & 3) + 8 * (i >> 2) + 4 * h];
+        const int lo = acc[0][i] + acc[1][i] * 256, hi = acc[2][i] + acc[3][i] * 256;                 // 16 x the digit-weighted sums: < 2^21 + 2^29
+        const double in16 = fma((double)hi, 65536.0, (double)lo);                                    // 16 * sum_k (q_k - 8) code_k
+        const double in = fma(zz, q.rsum, in16 * 0.0625);                                            // sum_k (q_k - z) code_k, exact
+        tot[T][i] = fma(in * (double)q.c, sd, tot[T][i]);                                            // + s c Int (the product is exact in double)
+      }
+      if (SEQ) __builtin_amdgcn_sched_barrier(0);     // SEQ: the two tiles one after the other (64 accumulator registers, two waves per SIMD); else the compiler interleaves them (128, one wave per SIMD)
+    }
+  }
+  if (!cols_on) return;
+#pragma unroll
+  for (int T = 0; T < 2; T++) {
+    const int n = tile * 64 + 32 * T + c;
+    const double bv = bias ? (double)bias[n] : 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int m = r0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+      if (m < S) Y[(size_t)m * N + n] = pf_round((float)(tot[T][i] + bv), act);
+    }
+  }
+}
+
 __global__ void k_q4g_mfma_reduce(const float* __restrict__ part, int KS, size_t SN, int N, const float* __restrict__ bias, int act, float* __restrict__ Y,
                                   const float* __restrict__ rscale = nullptr) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < SN; i += (size_t)gridDim.x * 256) {
@@ -1373,6 +1546,40 @@ int bzk_pf_attn(hipStream_t s, int dt, const float* qkv, int S, int nq, int nkv,
   else { if (dt == BZ_F16) LAUNCH_PFA_R(BZ_F16, false); else if (dt == BZ_F32) LAUNCH_PFA_R(BZ_F32, false); else LAUNCH_PFA_R(BZ_BF16, false); }
 #undef LAUNCH_PFA_R
 #undef LAUNCH_PFA
+  BZ_HIP(hipGetLastError());
+  return BZ_OK;
+}
+bool bzk_gemm_q4g_i8_ok(const LinearDev& L, int xdt) {
+  return L.kind == LK_Q4G && !L.perm && L.K % 128 == 0 && L.N % 64 == 0 && xdt == BZ_F16;
+}
+size_t bzk_pf_quant_i8_bytes(int S, int K, size_t* par_off) { const size_t planes = (size_t)4 * S * K; *par_off = (planes + 255) / 256 * 256; return *par_off + (size_t)S * (K / 128) * sizeof(RowPar); }
+// x16 rows -> four int8 digit planes + row parameters in `xq` (bzk_pf_quant_i8_bytes(S, K) bytes)
+int bzk_pf_quant_i8(hipStream_t s, const void* x16, int S, int K, void* xq) {
+  if (K % 128) BZ_FAIL(BZ_E_UNSUPPORTED, "pf_quant_i8: K=%d is not a multiple of 128", K);
+  size_t po; bzk_pf_quant_i8_bytes(S, K, &po);
+  hipLaunchKernelGGL(k_pf_quant_i8<BZ_F16>, dim3(S), dim3(256), 0, s, (const unsigned short*)x16, K, (signed char*)xq, (size_t)S * K, (RowPar*)((char*)xq + po));
+  BZ_HIP(hipGetLastError());
+  return BZ_OK;
+}
+// Y[S][N] = R(X . dequant(W)^T), every group sum an exact integer (xq from bzk_pf_quant_i8 for the same S, K)
+int bzk_gemm_q4g_i8(hipStream_t s, const LinearDev& L, const void* xq, int S, int act, float* y) {
+  if (!bzk_gemm_q4g_i8_ok(L, BZ_F16)) BZ_FAIL(BZ_E_UNSUPPORTED, "gemm_q4g_i8: unsupported weight format");
+  size_t po; bzk_pf_quant_i8_bytes(S, L.K, &po);
+  const int ntile = L.N / 64, mt = (S + 31) / 32;
+  static const int wpb_env = getenv("BZ_I8_WPB") ? atoi(getenv("BZ_I8_WPB")) : 0;
+  int WPB = (long long)((ntile + 3) / 4) * mt >= 256 ? 4 : 2;      // a few hundred workgroups when the problem has them
+  if ((long long)((ntile + 7) / 8) * mt >= 512) WPB = 8;          // large problems: 32 x 512 tiles halve the activation re-reads from L2
+  if (wpb_env) WPB = wpb_env;
+  const double flops = 2.0 * S * (double)L.N * L.K;
+#define LAUNCH_I8X(W_) BZ_LAUNCH("gemm_q4g_i8_mfma", flops, (k_gemm_q4g_i8<W_, 0, false>), dim3(8u * (unsigned)(((ntile + W_ - 1) / W_ + 7) / 8) * (unsigned)mt), dim3(W_ * 64), 0, s, (const uint4*)L.w, (const __half*)L.scales, \
+              (const unsigned char*)L.zeros, L.bias, L.N, L.K, (const signed char*)xq, (size_t)S * L.K, (const RowPar*)((const char*)xq + po), S, act, y)
+#define LAUNCH_I8D(W_, D_) BZ_LAUNCH("gemm_q4g_i8_mfma", flops, (k_gemm_q4g_i8<W_, D_>), dim3(8u * (unsigned)(((ntile + W_ - 1) / W_ + 7) / 8) * (unsigned)mt), dim3(W_ * 64), 0, s, (const uint4*)L.w, (const __half*)L.scales, \
+              (const unsigned char*)L.zeros, L.bias, L.N, L.K, (const signed char*)xq, (size_t)S * L.K, (const RowPar*)((const char*)xq + po), S, act, y)
+#define LAUNCH_I8(W_) do { if (dbg == 1) LAUNCH_I8D(W_, 1); else if (dbg == 2) LAUNCH_I8D(W_, 2); else if (dbg == 3) LAUNCH_I8D(W_, 3); else if (dbg == 4) LAUNCH_I8X(W_); else LAUNCH_I8D(W_, 0); } while (0)
+  static const int dbg = getenv("BZ_I8_DBG") ? atoi(getenv("BZ_I8_DBG")) : 0;     // timing experiments only: the results are wrong
+  if (WPB == 8) LAUNCH_I8(8); else if (WPB == 4) LAUNCH_I8(4); else LAUNCH_I8(2);
+#undef LAUNCH_I8D
+#undef LAUNCH_I8
   BZ_HIP(hipGetLastError());
   return BZ_OK;
 }

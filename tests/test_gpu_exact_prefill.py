@@ -84,3 +84,15 @@ def test_forced_exact_rows_for_a_long_prompt_and_the_mfma_rows_beside_them():
     assert n_forced == 0                                   # 70 rows, 9 passes: bit-identical to the decode rows
     n_mfma, rel_mfma = _child({})
     assert n_mfma > 0 and rel_mfma <= 2e-3                 # the matrix-core rows: same values to the f16 noise floor of a 2-layer model, not the same bits
+
+
+@pytest.mark.parametrize("wpb", ["", "2", "4", "8"])
+def test_exact_gemm_on_the_integer_matrix_cores(wpb):
+    """BZ_EXACT_PREFILL=2: every projection of a 70-token prompt through k_gemm_q4g_i8 (four int8 digit planes of the 32-bit activation codes x sign-extended nibbles on
+    v_mfma_i32_32x32x32_i8, exact int32 plane sums, the decode kernels' per-group fold in double) + the exact attention: 0 of 70 x vocab logits differ from the decode
+    rows, for each workgroup shape (2 / 4 / 8 waves side by side on the same 32 rows)"""
+    env = {"BZ_EXACT_PREFILL": "2"}
+    if wpb:
+        env["BZ_I8_WPB"] = wpb
+    n, _ = _child(env)
+    assert n == 0
