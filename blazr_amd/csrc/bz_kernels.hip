@@ -3126,9 +3126,12 @@ __global__ __launch_bounds__(256) void k_attn_decode(AttnArgs a) {
 template <int KVDT, int FUSE, int TPW, int NW, int PAGED, int HD = 128>   // NW waves per block: each owns 256/NW positions of a chunk; HD = 128 or 64 (64: not fused)
 __global__ __launch_bounds__(NW * 64) void k_attn2(AttnArgs a, const uint4* __restrict__ W, const __half* __restrict__ S,
                                                const unsigned char* __restrict__ Z, const float* __restrict__ bias, int CS, long long* acc) {
-  // Mapping: a chunk is 256 positions, wave w owns positions c0 + PW w .. +PW-1 (PW = 256/NW).  One wave-wide 16-byte load fetches RPL = 512 / HD whole
-  // rows (1 KiB contiguous in the contiguous cache; 4 rows of 128 elements, 8 rows of 64): lane l holds piece (l % NPC) = elements 8 piece .. +7 of row
-  // RPL i + l / NPC for load i = 0..PW/RPL-1 (NPC = HD / 8 pieces per row).  A row's score is a 4-DOT2 partial per lane reduced over its 16 lanes -- and lands exactly in the
+  // Mapping: a chunk is 256 positions in row groups of RPL = 512 / HD whole rows (one wave-wide 16-byte load: 1 KiB contiguous in the contiguous cache; 4 rows of
+  // 128 elements, 8 rows of 64), dealt ROUND-ROBIN to the waves: load i of wave w is row group i NW + w, lane l holds piece (l % NPC) = elements 8 piece .. +7 of
+  // row RPL (i NW + w) + l / NPC (NPC = HD / 8 pieces per row).  A context of c positions is ceil(c / RPL) groups spread over all NW waves -- ceil(c / (RPL NW))
+  // iterations per wave, where contiguous blocks of 256 / NW positions per wave (rounds 1-3) gave the first wave all NL iterations of a short context and ran
+  // two live waves per SIMD from 129 positions on (attention + o_proj 8.6 us at 16 positions, 10.4 us averaged over a 128-token generation).  Dead iterations
+  // (wave-uniform) skip their loads, scores and P.V.  A row's score is a 4-DOT2 partial per lane reduced over its 16 lanes -- and lands exactly in the
   // lanes that hold that row's V pieces, so P.V accumulates in registers (8 outputs per lane) with no LDS image.
   //
   // Prologue discipline (measured with s_memrealtime stamps per wave):
@@ -3219,27 +3222,32 @@ __global__ __launch_bounds__(NW * 64) void k_attn2(AttnArgs a, const uint4* __re
   uint4 kr[NL], vr[NL];
 #pragma unroll
   for (int i = 0; i < NL; i++) { kr[i] = make_uint4(0, 0, 0, 0); vr[i] = make_uint4(0, 0, 0, 0); }
-  if (wave * PW < len) {
+#define ATT_ROW(i) (((i) * NW + wave) * RPL + rsub)                 /* row of load i inside a chunk */
+#define ATT_LIVE(c0_, i) ((c0_) + ((i) * NW + wave) * RPL < len)    /* wave-uniform: the row group has a position of the context */
+  if (wave * RPL < len) {
     if (!PAGED) {
       const unsigned short* kb = kb0 + (size_t)kvh * kv.cap * HD;
       const unsigned short* vb = vb0 + (size_t)kvh * kv.cap * HD;
-      const int r0 = wave * PW + rsub;
 #pragma unroll
       for (int i = 0; i < NL; i++) {
-        const unsigned off = (unsigned)min(r0 + RPL * i, pmax) * HD + piece * 8;
-        kr[i] = *(const uint4*)(kb + off);
-        vr[i] = *(const uint4*)(vb + off);
+        if (ATT_LIVE(0, i)) {
+          const unsigned off = (unsigned)min(ATT_ROW(i), pmax) * HD + piece * 8;
+          kr[i] = *(const uint4*)(kb + off);
+          vr[i] = *(const uint4*)(vb + off);
+        }
       }
     } else {
       int blk[NL];
 #pragma unroll
-      for (int i = 0; i < NL; i++) blk[i] = kv.block_table[min(wave * PW + RPL * i + rsub, pmax) / kv.bs];
+      for (int i = 0; i < NL; i++) blk[i] = ATT_LIVE(0, i) ? kv.block_table[min(ATT_ROW(i), pmax) / kv.bs] : 0;
 #pragma unroll
       for (int i = 0; i < NL; i++) {
-        const int pp = min(wave * PW + RPL * i + rsub, pmax);
-        const size_t off = (((size_t)blk[i] * kv.n_kv + kvh) * kv.bs + (pp % kv.bs)) * HD + piece * 8;
-        kr[i] = *(const uint4*)(kb0 + off);
-        vr[i] = *(const uint4*)(vb0 + off);
+        if (ATT_LIVE(0, i)) {
+          const int pp = min(ATT_ROW(i), pmax);
+          const size_t off = (((size_t)blk[i] * kv.n_kv + kvh) * kv.bs + (pp % kv.bs)) * HD + piece * 8;
+          kr[i] = *(const uint4*)(kb0 + off);
+          vr[i] = *(const uint4*)(vb0 + off);
+        }
       }
     }
   }
@@ -3286,7 +3294,8 @@ __global__ __launch_bounds__(NW * 64) void k_attn2(AttnArgs a, const uint4* __re
   float Mw = -INFINITY;
 #define ATT_SCORES(c0_)                                                                                                    \
   _Pragma("unroll") for (int i = 0; i < NL; i++) {                                                                         \
-    const int p = (c0_) + wave * PW + RPL * i + rsub;                                                                      \
+    if (!ATT_LIVE(c0_, i)) { sc_[i] = -INFINITY; continue; }                                                               \
+    const int p = (c0_) + ATT_ROW(i);                                                                                      \
     uint4 kk = kr[i];                                                                                                      \
     if (!a.q_only && p == pos) { kk = ((const uint4*)k2)[piece]; vr[i] = ((const uint4*)v2)[piece]; }                      \
     float kf[8];                                                                                                           \
@@ -3297,11 +3306,12 @@ __global__ __launch_bounds__(NW * 64) void k_attn2(AttnArgs a, const uint4* __re
     sc_[i] = (p < len) ? (float)d * scale : -INFINITY;                                                                     \
   }
   for (int c0 = 0; c0 < len; c0 += 256) {
-    const bool won = c0 + wave * PW < len;   // wave-uniform: this wave has live positions in the chunk
+    const bool won = c0 + wave * RPL < len;   // wave-uniform: this wave has live positions in the chunk
     if (!won) continue;
     if (c0 > 0) {
 #pragma unroll
-      for (int i = 0; i < NL; i++) kr[i] = *(const uint4*)(kb0 + kv_row_off_t<PAGED>(kv, 0, kvh, min(c0 + wave * PW + RPL * i + rsub, pmax)) + piece * 8);
+      for (int i = 0; i < NL; i++)
+        if (ATT_LIVE(c0, i)) kr[i] = *(const uint4*)(kb0 + kv_row_off_t<PAGED>(kv, 0, kvh, min(c0 + ATT_ROW(i), pmax)) + piece * 8);
     }
     ATT_SCORES(c0)
 #pragma unroll
@@ -3317,19 +3327,22 @@ __global__ __launch_bounds__(NW * 64) void k_attn2(AttnArgs a, const uint4* __re
   double accv[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   double lsum = 0.0;
   for (int c0 = 0; c0 < len; c0 += 256) {
-    const bool won = c0 + wave * PW < len;
+    const bool won = c0 + wave * RPL < len;
     if (!won) continue;
     if (!single) {
 #pragma unroll
       for (int i = 0; i < NL; i++) {
-        const size_t off = kv_row_off_t<PAGED>(kv, 0, kvh, min(c0 + wave * PW + RPL * i + rsub, pmax)) + piece * 8;
-        kr[i] = *(const uint4*)(kb0 + off);
-        vr[i] = *(const uint4*)(vb0 + off);
+        if (ATT_LIVE(c0, i)) {
+          const size_t off = kv_row_off_t<PAGED>(kv, 0, kvh, min(c0 + ATT_ROW(i), pmax)) + piece * 8;
+          kr[i] = *(const uint4*)(kb0 + off);
+          vr[i] = *(const uint4*)(vb0 + off);
+        }
       }
       ATT_SCORES(c0)
     }
 #pragma unroll
     for (int i = 0; i < NL; i++) {
+      if (!ATT_LIVE(c0, i)) continue;
       const float e = (sc_[i] == -INFINITY) ? 0.f : bz_expf(sc_[i] - Mall);
       const double ed = (double)e;
       lsum += ed;
@@ -3341,6 +3354,8 @@ __global__ __launch_bounds__(NW * 64) void k_attn2(AttnArgs a, const uint4* __re
     }
   }
 #undef ATT_SCORES
+#undef ATT_LIVE
+#undef ATT_ROW
   // rows of the wave: the RPL lane groups hold different rows -> reduce over xor (8,) 16, 32 (the lanes of a group are replicas for lsum)
   if (NPC == 8) lsum += dpp_get<DPP_ROR8>(lsum);
   lsum = xrow32_d(xrow16_d(lsum));
@@ -3479,12 +3494,17 @@ __global__ __launch_bounds__(512) void k_attn2f(AttnArgs a, const uint4* __restr
   float4 kr[NL][2], vr[NL][2];
 #pragma unroll
   for (int i = 0; i < NL; i++) { kr[i][0] = kr[i][1] = vr[i][0] = vr[i][1] = make_float4(0.f, 0.f, 0.f, 0.f); }
-  if (wave * PW < len) {
+  // row groups of 4 positions dealt round-robin to the waves (k_attn2's mapping: a short context spreads over all 8 waves, dead iterations are skipped)
+#define ATF_ROW(i) (((i) * NW + wave) * 4 + rsub)
+#define ATF_LIVE(c0_, i) ((c0_) + ((i) * NW + wave) * 4 < len)
+  if (wave * 4 < len) {
 #pragma unroll
     for (int i = 0; i < NL; i++) {
-      const size_t off = kv_row_off_t<PAGED>(kv, 0, kvh, min(wave * PW + 4 * i + rsub, pmax)) + piece * 8;
-      kr[i][0] = *(const float4*)(kb0 + off); kr[i][1] = *(const float4*)(kb0 + off + 4);
-      vr[i][0] = *(const float4*)(vb0 + off); vr[i][1] = *(const float4*)(vb0 + off + 4);
+      if (ATF_LIVE(0, i)) {
+        const size_t off = kv_row_off_t<PAGED>(kv, 0, kvh, min(ATF_ROW(i), pmax)) + piece * 8;
+        kr[i][0] = *(const float4*)(kb0 + off); kr[i][1] = *(const float4*)(kb0 + off + 4);
+        vr[i][0] = *(const float4*)(vb0 + off); vr[i][1] = *(const float4*)(vb0 + off + 4);
+      }
     }
   }
   const float px0 = vsrc_finish(fixq, r0l, r0h, a.act), px1 = vsrc_finish(fixq, r1l, r1h, a.act);
@@ -3514,15 +3534,17 @@ __global__ __launch_bounds__(512) void k_attn2f(AttnArgs a, const uint4* __restr
   const float4 qa = *(const float4*)(qf + piece * 8), qb = *(const float4*)(qf + piece * 8 + 4);
   float Mrun = -INFINITY, Lrun = 0.f, Orun = 0.f;   // running state (threads < 128 own output d = tid)
   for (int c0 = 0; c0 < len; c0 += 256) {
-    const bool won = c0 + wave * PW < len;
+    const bool won = c0 + wave * 4 < len;
     if (c0 > 0) {
       __syncthreads();
       if (won) {
 #pragma unroll
         for (int i = 0; i < NL; i++) {
-          const size_t off = kv_row_off_t<PAGED>(kv, 0, kvh, min(c0 + wave * PW + 4 * i + rsub, pmax)) + piece * 8;
-          kr[i][0] = *(const float4*)(kb0 + off); kr[i][1] = *(const float4*)(kb0 + off + 4);
-          vr[i][0] = *(const float4*)(vb0 + off); vr[i][1] = *(const float4*)(vb0 + off + 4);
+          if (ATF_LIVE(c0, i)) {
+            const size_t off = kv_row_off_t<PAGED>(kv, 0, kvh, min(c0 + ATF_ROW(i), pmax)) + piece * 8;
+            kr[i][0] = *(const float4*)(kb0 + off); kr[i][1] = *(const float4*)(kb0 + off + 4);
+            vr[i][0] = *(const float4*)(vb0 + off); vr[i][1] = *(const float4*)(vb0 + off + 4);
+          }
         }
       }
     }
@@ -3531,7 +3553,8 @@ __global__ __launch_bounds__(512) void k_attn2f(AttnArgs a, const uint4* __restr
     if (won) {
 #pragma unroll
       for (int i = 0; i < NL; i++) {
-        const int p = c0 + wave * PW + 4 * i + rsub;
+        if (!ATF_LIVE(c0, i)) { sc_[i] = -INFINITY; continue; }
+        const int p = c0 + ATF_ROW(i);
         float4 k0 = kr[i][0], k1 = kr[i][1];
         if (!a.q_only && p == pos) {
           k0 = *(const float4*)(kf + piece * 8); k1 = *(const float4*)(kf + piece * 8 + 4);
@@ -3554,6 +3577,7 @@ __global__ __launch_bounds__(512) void k_attn2f(AttnArgs a, const uint4* __restr
     if (won) {
 #pragma unroll
       for (int i = 0; i < NL; i++) {
+        if (!ATF_LIVE(c0, i)) continue;
         const float e = (sc_[i] == -INFINITY) ? 0.f : bz_expf(sc_[i] - Mc);
         lsum += e;
         accv[0] = fmaf(e, vr[i][0].x, accv[0]); accv[1] = fmaf(e, vr[i][0].y, accv[1]); accv[2] = fmaf(e, vr[i][0].z, accv[2]); accv[3] = fmaf(e, vr[i][0].w, accv[3]);
