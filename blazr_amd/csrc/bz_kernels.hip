@@ -4782,11 +4782,247 @@ __global__ __launch_bounds__(256) void k_mla_merge(MlaArgs a) {
   }
 }
 
+// Prompt rows, token-tiled (round 3).  The (head, token) workgroups of k_mla_attn<BATCH> each re-read the head's Wuk / Wuv (128 KB each at V2-Lite widths) and every
+// latent row of their context: 4.4 GB of L2 traffic per layer at 512 tokens -- 563 us, L2-bandwidth-bound.  Here a workgroup takes TT consecutive tokens of one head:
+// a weight row / a latent row is loaded ONCE and used for all TT tokens (TT x fewer bytes), and every token's sums run in exactly the order k_mla_attn<BATCH> uses
+// (wave w: nope rows / positions / v rows w-strided, the same FMA chains, the same wave_sum trees, the same pairing of the four waves' partials), so the output is
+// the same bits (tests: BZ_NO_MLA_TILE=1 against the default).    rank <= 512, nope % 16 == 0, v % 16 == 0;  grid = (n_heads, ceil(batch / TT)), 256 threads
+// LDS: qn[TT][DN] qp[TT][DR] qabs[TT][R] part[4][TT][R] red[2][TT][4] sc[TT][LS]   (LS = positions the tile's last token sees, rounded up to 4)
+template <int DT, int TT>
+__global__ __launch_bounds__(256) void k_mla_attn_tile(MlaArgs a, int LS) {
+  constexpr int NW = 4, NTH = 256, RIF = 4, TIF = 4;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int R = a.rank, DN = a.nope, DR = a.rope, DV = a.vdim;
+  float* qn = lds; float* qp = qn + TT * DN; float* qabs = qp + TT * DR; float* part = qabs + TT * R; float* red = part + NW * TT * R; float* sc = red + 2 * TT * NW;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hd = blockIdx.x;
+  const int tok0 = blockIdx.y * TT, ntok = min(TT, a.batch - tok0);
+  const int lmax = a.pos0 + tok0 + ntok;                 // the tile's last token attends over positions 0 .. lmax - 1 (its own row is in the cache)
+  const int QH = DN + DR, qoff = hd * QH;
+  const size_t rowbase = (size_t)a.layer * a.kv.layer_stride;
+  const int Wd = R + DR;
+  auto rowoff = [&](int p) -> size_t {
+    if (a.kv.paged) return rowbase + ((size_t)a.kv.block_table[p / a.kv.bs] * a.kv.bs + (p % a.kv.bs)) * Wd;
+    return rowbase + (size_t)p * Wd;
+  };
+  const size_t wrow0 = (size_t)hd * (DN + DV);
+  const int col = lane * 8;
+  const bool con = col < R;
+  const int colc = con ? col : 0;
+  // ---- q of the tile's tokens: q_nope as it is, q_pe roped and rounded ----
+  for (int i = tid; i < TT * DN; i += NTH) { const int t = i / DN, d = i % DN; qn[i] = t < ntok ? ((const float*)a.qkv.p)[(size_t)(tok0 + t) * a.q_stride + qoff + d] : 0.f; }
+  for (int i = tid; i < TT * (DR / 2); i += NTH) {
+    const int t = i / (DR / 2), j = i % (DR / 2);
+    if (t < ntok) {
+      const int pos = a.pos0 + tok0 + t;
+      const float c = a.cos_t[(size_t)pos * (DR / 2) + j], sn = a.sin_t[(size_t)pos * (DR / 2) + j];
+      const float* qrow = (const float*)a.qkv.p + (size_t)(tok0 + t) * a.q_stride;
+      const float x0 = qrow[qoff + DN + 2 * j], x1 = qrow[qoff + DN + 2 * j + 1];
+      qp[t * DR + 2 * j] = round_act(rope_lo(x0, x1, c, sn), a.act); qp[t * DR + 2 * j + 1] = round_act(rope_hi(x0, x1, c, sn), a.act);
+    } else { qp[t * DR + 2 * j] = 0.f; qp[t * DR + 2 * j + 1] = 0.f; }
+  }
+  __syncthreads();
+  // ---- qabs[t] = R(Wuk_h^T q_nope[t]): wave w takes nope rows [w DN/4, (w+1) DN/4) ----
+  {
+    const int d0 = wave * (DN / NW), d1 = d0 + DN / NW;
+    float acc[TT][8];
+#pragma unroll
+    for (int t = 0; t < TT; t++)
+#pragma unroll
+      for (int e = 0; e < 8; e++) acc[t][e] = 0.f;
+    float w0[RIF][8];
+#pragma unroll
+    for (int u = 0; u < RIF; u++) ld8t<DT>(a.wkvb, (wrow0 + (size_t)(d0 + u)) * R + colc, w0[u]);
+    for (int d = d0; d < d1; d += RIF) {
+      float wc[RIF][8];
+#pragma unroll
+      for (int u = 0; u < RIF; u++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) wc[u][e] = w0[u][e];
+      if (d + RIF < d1) {
+#pragma unroll
+        for (int u = 0; u < RIF; u++) ld8t<DT>(a.wkvb, (wrow0 + (size_t)(d + RIF + u)) * R + colc, w0[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < RIF; u++)
+#pragma unroll
+        for (int t = 0; t < TT; t++) {
+          const float qd = qn[t * DN + d + u];
+#pragma unroll
+          for (int e = 0; e < 8; e++) acc[t][e] += qd * wc[u][e];
+        }
+    }
+    if (con)
+#pragma unroll
+      for (int t = 0; t < TT; t++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) part[(wave * TT + t) * R + colc + e] = acc[t][e];
+  }
+  __syncthreads();
+  for (int i = tid; i < TT * R; i += NTH) {
+    const int t = i / R, r = i % R;
+    float s2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; w += 2) s2 += part[(w * TT + t) * R + r] + part[((w + 1) * TT + t) * R + r];
+    qabs[i] = round_act(s2, a.act);
+  }
+  __syncthreads();
+  // ---- scores: wave w takes positions w, w + 4, ...; a latent row is loaded once for the TT tokens ----
+  {
+    float qa[TT][8], qpl[TT];
+#pragma unroll
+    for (int t = 0; t < TT; t++) {
+      qpl[t] = (lane < DR) ? qp[t * DR + lane] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; e++) qa[t][e] = con ? qabs[t * R + colc + e] : 0.f;
+    }
+    for (int t0 = wave; t0 < lmax; t0 += NW * TIF) {
+      float cv[TIF][8], kp[TIF];
+#pragma unroll
+      for (int u = 0; u < TIF; u++) {
+        const size_t ro = rowoff(min(t0 + NW * u, lmax - 1));
+        ld8t<DT>(a.kv.k, ro + colc, cv[u]);
+        kp[u] = ld1t<DT>(a.kv.k, ro + R + min(lane, DR - 1));
+      }
+#pragma unroll
+      for (int u = 0; u < TIF; u++) {
+        const int pos = t0 + NW * u;
+        if (pos < lmax) {
+#pragma unroll
+          for (int t = 0; t < TT; t++) {
+            if (pos <= a.pos0 + tok0 + t && t < ntok) {                  // wave-uniform
+              float dsum = (lane < DR) ? qpl[t] * kp[u] : 0.f;
+#pragma unroll
+              for (int e = 0; e < 8; e++) dsum += qa[t][e] * cv[u][e];
+              dsum = wave_sum(dsum);
+              if (lane == 0) sc[t * LS + pos] = dsum * a.scale;
+            }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- softmax per token (thread-strided maxima / sums, then the four waves' values in block_sum_nw's order) ----
+  float mxv[TT], inv[TT];
+#pragma unroll
+  for (int t = 0; t < TT; t++) {
+    const int nloc = t < ntok ? a.pos0 + tok0 + t + 1 : 0;
+    float mx = -INFINITY;
+    for (int p = tid; p < nloc; p += NTH) mx = fmaxf(mx, sc[t * LS + p]);
+    mx = wave_max(mx);
+    if (lane == 0) red[t * NW + wave] = mx;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < TT; t++) {
+    float mx = red[t * NW];
+#pragma unroll
+    for (int w = 1; w < NW; w++) mx = fmaxf(mx, red[t * NW + w]);
+    mxv[t] = mx;
+  }
+#pragma unroll
+  for (int t = 0; t < TT; t++) {
+    const int nloc = t < ntok ? a.pos0 + tok0 + t + 1 : 0;
+    float psum = 0.f;
+    for (int p = tid; p < nloc; p += NTH) { const float pe = bz_expf(sc[t * LS + p] - mxv[t]); sc[t * LS + p] = pe; psum += pe; }
+    psum = wave_sum(psum);
+    if (lane == 0) red[(TT + t) * NW + wave] = psum;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < TT; t++) {
+    float ps = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; w += 2) ps += red[(TT + t) * NW + w] + red[(TT + t) * NW + w + 1];
+    inv[t] = t < ntok ? div_rn(1.0f, ps) : 0.f;
+  }
+  // ---- olat[t] = R(sum_p p_t c_p * inv_t) ----
+  {
+    float acc[TT][8];
+#pragma unroll
+    for (int t = 0; t < TT; t++)
+#pragma unroll
+      for (int e = 0; e < 8; e++) acc[t][e] = 0.f;
+    for (int t0 = wave; t0 < lmax; t0 += NW * TIF) {
+      float cv[TIF][8];
+#pragma unroll
+      for (int u = 0; u < TIF; u++) ld8t<DT>(a.kv.k, rowoff(min(t0 + NW * u, lmax - 1)) + colc, cv[u]);
+#pragma unroll
+      for (int u = 0; u < TIF; u++) {
+        const int pos = t0 + NW * u;
+#pragma unroll
+        for (int t = 0; t < TT; t++) {
+          const float pw = (pos < lmax && t < ntok && pos <= a.pos0 + tok0 + t) ? sc[t * LS + pos] : 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; e++) acc[t][e] += pw * cv[u][e];
+        }
+      }
+    }
+    if (con)
+#pragma unroll
+      for (int t = 0; t < TT; t++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) part[(wave * TT + t) * R + colc + e] = acc[t][e];
+  }
+  __syncthreads();
+  for (int i = tid; i < TT * R; i += NTH) {
+    const int t = i / R, r = i % R;
+    float s2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; w += 2) s2 += part[(w * TT + t) * R + r] + part[((w + 1) * TT + t) * R + r];
+    float iv = 0.f;
+#pragma unroll
+    for (int q = 0; q < TT; q++) iv = q == t ? inv[q] : iv;
+    qabs[i] = round_act(s2 * iv, a.act);
+  }
+  __syncthreads();
+  // ---- out[t] = R(Wuv_h olat[t]): wave w takes v rows [w DV/4, (w+1) DV/4) ----
+  {
+    float qa[TT][8];
+#pragma unroll
+    for (int t = 0; t < TT; t++)
+#pragma unroll
+      for (int e = 0; e < 8; e++) qa[t][e] = con ? qabs[t * R + colc + e] : 0.f;
+    const int v0 = wave * (DV / NW), v1 = v0 + DV / NW;
+    for (int d = v0; d < v1; d += RIF) {
+      float wc[RIF][8];
+#pragma unroll
+      for (int u = 0; u < RIF; u++) ld8t<DT>(a.wkvb, (wrow0 + DN + (size_t)(d + u)) * R + colc, wc[u]);
+#pragma unroll
+      for (int u = 0; u < RIF; u++)
+#pragma unroll
+        for (int t = 0; t < TT; t++) {
+          float s2 = 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; e++) s2 += wc[u][e] * qa[t][e];
+          s2 = wave_sum(s2);
+          if (lane == 0 && t < ntok) a.out[(size_t)(tok0 + t) * a.out_stride + hd * DV + d + u] = round_act(s2, a.act);
+        }
+    }
+  }
+}
+static size_t mla_tile_smem(const MlaArgs& a, int TT, int LS) { return (size_t)(TT * (a.nope + a.rope + a.rank) + 4 * TT * a.rank + 2 * TT * 4 + TT * LS) * 4 + 64; }
+static int mla_tile_tt(const MlaArgs& a, int max_len) {     // tokens per workgroup: 8, or 4 when the scores of 8 tokens do not fit; 0 = the (head, token) kernel
+  static const bool off = getenv("BZ_NO_MLA_TILE") != nullptr;
+  static const int env_tt = getenv("BZ_MLA_TILE") ? atoi(getenv("BZ_MLA_TILE")) : 0;
+  if (off || a.batch < 2 || a.rank > 512 || a.rank % 8 || a.nope % 16 || a.vdim % 16 || a.qkv.fix) return 0;
+  const int LS = (max_len + 3) & ~3;
+  if (env_tt == 4 || env_tt == 8) return mla_tile_smem(a, env_tt, LS) <= 160 * 1024 ? env_tt : 0;
+  if (mla_tile_smem(a, 4, LS) <= 64 * 1024) return 4;      // 4 tokens per workgroup and two or more workgroups per CU measured faster than 8 and one
+  if (mla_tile_smem(a, 8, LS) <= 160 * 1024) return 8;
+  if (mla_tile_smem(a, 4, LS) <= 160 * 1024) return 4;
+  return 0;
+}
+
 static bool mla_split_on(const MlaArgs& a) {
   static const bool off = getenv("BZ_NO_MLA_SPLIT") != nullptr;
   return !off && a.batch == 0 && a.ws != nullptr && a.nsplit > 1 && a.nsplit <= 62 && a.vdim % 16 == 0 && a.nope % 16 == 0;
 }
-int bzk_mla_nsplit(int n_heads) { return std::max(1, std::min(32, 256 / std::max(n_heads, 1))); }
+int bzk_mla_nsplit(int n_heads) {
+  static const int env = getenv("BZ_MLA_NSPLIT") ? atoi(getenv("BZ_MLA_NSPLIT")) : 0;     // tuning override (1..62)
+  if (env > 0) return std::min(env, 62);
+  return std::max(1, std::min(32, 256 / std::max(n_heads, 1)));
+}
 
 static int mla_waves(const MlaArgs& a) {
   // decode: one workgroup per head, 16 waves hide each other's dependent chains.  Prompt rows: thousands of (head, token) workgroups -- four waves
@@ -4801,10 +5037,25 @@ size_t bzk_mla_smem(const MlaArgs& a, int max_len) {
 int bzk_mla_attn(hipStream_t s, const MlaArgs& a, int max_len) {
   if (a.rank % 8 || a.rank > 1024 || a.rope > 64 || (a.rope & 1) || a.nope % 4 || a.vdim % 4 || a.kv.n_kv != 1 || a.kv.hd != a.rank + a.rope)
     BZ_FAIL(BZ_E_UNSUPPORTED, "mla_attn: rank %d / rope %d / nope %d / v %d unsupported", a.rank, a.rope, a.nope, a.vdim);
-  const size_t smem = bzk_mla_smem(a, max_len);
-  if (smem > 160 * 1024) BZ_FAIL(BZ_E_UNSUPPORTED, "mla_attn: context %d too long for the single-pass kernel", max_len);
   if (a.wdt != a.kv.dtype) BZ_FAIL(BZ_E_UNSUPPORTED, "mla_attn: kv_b_proj dtype %d must equal the cache dtype %d", a.wdt, a.kv.dtype);
   const double bytes = (double)a.n_heads * (a.nope + a.vdim) * a.rank * bz_dtype_size(a.wdt);
+  if (const int TT = a.batch > 0 ? mla_tile_tt(a, max_len) : 0) {     // prompt rows: token tiles
+    const int LS = (max_len + 3) & ~3;
+    const size_t sm = mla_tile_smem(a, TT, LS);
+    const dim3 grid(a.n_heads, (a.batch + TT - 1) / TT);
+#define LAUNCH_MT(DT, T_) do { \
+      static bool attr_done = false; \
+      if (!attr_done) { BZ_HIP(hipFuncSetAttribute((const void*)k_mla_attn_tile<DT, T_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_done = true; } \
+      BZ_LAUNCH("mla_attn<rows,tiled>", bytes, (k_mla_attn_tile<DT, T_>), grid, dim3(256), sm, s, a, LS); } while (0)
+#define LAUNCH_MT_T(DT) do { if (TT == 8) LAUNCH_MT(DT, 8); else LAUNCH_MT(DT, 4); } while (0)
+    if (a.wdt == BZ_F16) LAUNCH_MT_T(BZ_F16); else if (a.wdt == BZ_BF16) LAUNCH_MT_T(BZ_BF16); else LAUNCH_MT_T(BZ_F32);
+#undef LAUNCH_MT_T
+#undef LAUNCH_MT
+    BZ_HIP(hipGetLastError());
+    return BZ_OK;
+  }
+  const size_t smem = bzk_mla_smem(a, max_len);
+  if (smem > 160 * 1024) BZ_FAIL(BZ_E_UNSUPPORTED, "mla_attn: context %d too long for the single-pass kernel", max_len);
   const int NWV = mla_waves(a);
 #define LAUNCH_MLA_WB(NCH, DT, W_, B_) do { \
     static bool attr_done = false; \

@@ -142,3 +142,41 @@ def test_paged_latent_cache_forward_scattered_blocks(pair, device):
         y = lm.forward_with_paged_kv_cache([tok], pk, pk.compute_slot_mapping(n - 1, 1), pk.block_table_device_format(), n, n - 1).to_numpy()
         assert np.array_equal(x, y), i
         tok = int(x[0].argmax())
+
+
+_TILE_CHILD = r"""
+import sys
+import numpy as np
+from blazr_amd import _lib as L, runtime, synth
+preset, over, S = sys.argv[2], eval(sys.argv[3]), int(sys.argv[4])
+model = synth.make_dsv2(preset, **over)
+cfg = model["config"]
+dev = runtime.Device(0)
+lm = runtime.LoadedModel.from_synth(dev, model)
+p = synth.prompt_tokens(S, cfg["vocab"], seed=41)
+kv = lm.new_kv_cache(S + 40)
+a = lm.forward_with_kv_cache(p, kv, 0, all_logits=True).to_numpy()
+p2 = synth.prompt_tokens(21, cfg["vocab"], seed=42)          # a second chunk behind the first: keys before the chunk + the causal part
+b = lm.forward_with_kv_cache(p2, kv, S, all_logits=True).to_numpy()
+np.save(sys.argv[1], np.concatenate([a.reshape(S, -1), b.reshape(21, -1)]))
+"""
+
+
+@pytest.mark.parametrize("preset,over,S", [("tiny-dsv2", "{}", 37), ("deepseek-v2-lite", "dict(n_layers=2, vocab=2048)", 70)], ids=["tiny", "v2-lite-widths"])
+def test_token_tiled_mla_prompt_kernel_is_the_head_token_kernel_bit_for_bit(tmp_path, preset, over, S):
+    """k_mla_attn_tile (4 or 8 tokens of one head per workgroup: weight rows and latent rows loaded once per tile) against k_mla_attn<BATCH> (one workgroup per
+    (head, token)): the same sums in the same order, so every logit of every prompt row is the same bits -- first chunk and a second chunk at position S"""
+    import os
+    import subprocess
+    import sys
+    outs = {}
+    for name, env in (("tile4", {"BZ_MLA_TILE": "4"}), ("tile8", {"BZ_MLA_TILE": "8"}), ("default", {}), ("head_token", {"BZ_NO_MLA_TILE": "1"})):
+        f = str(tmp_path / (name + ".npy"))
+        e = dict(os.environ)
+        e.update(env)
+        e["PYTHONPATH"] = os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + os.pathsep + e.get("PYTHONPATH", "")
+        r = subprocess.run([sys.executable, "-c", _TILE_CHILD, f, preset, over, str(S)], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[name] = np.load(f)
+    for name in ("tile4", "tile8", "default"):
+        assert np.array_equal(outs[name], outs["head_token"]), (name, int((outs[name] != outs["head_token"]).sum()))
