@@ -1389,7 +1389,9 @@ int bzk_gemm_nt_grouped(hipStream_t s, int dt, const void* x16, const void* w, l
 
 bool bzk_gemm_q4g_mfma_ok(const LinearDev& L, int xdt, int rows) {
   static const bool off = getenv("BZ_NO_Q4G_MFMA") != nullptr;
-  return !off && L.kind == LK_Q4G && !L.perm && L.K % 128 == 0 && L.N % 64 == 0 && xdt == BZ_F16 && rows >= 9;   // 9+: the multi-row dot4 kernel would need a second pass over the weights
+  static const int min_rows = getenv("BZ_Q4G_MFMA_MIN") ? atoi(getenv("BZ_Q4G_MFMA_MIN")) : 5;   // measured on batched decode steps (8B AWQ, one graph per step): 5 / 6 / 8 sequences 4.46 / 4.77 / 5.41 ms
+                                                                                                  // through the multi-row dot8 kernel, 4.19 / 4.23 / 4.26 ms here; 3-4 sequences equal or better there
+  return !off && L.kind == LK_Q4G && !L.perm && L.K % 128 == 0 && L.N % 64 == 0 && xdt == BZ_F16 && rows >= min_rows;
 }
 // Y[S][N] (f32, rounded to act) = X16[S][K] . dequant(W)^T on the matrix cores (f16 activations)
 int bzk_gemm_q4g_mfma(hipStream_t s, const LinearDev& L, const void* x16, int S, int act, float* y, float* ws, size_t ws_bytes) {
