@@ -462,10 +462,11 @@ def test_generate_with_host_side_sampler_options(device):
         ex.generate(p, 4, use_graph=True, logit_bias={1: 1.0})
 
 
-@pytest.mark.parametrize("preset,nseq", [("tiny-awq", 3), ("tiny-awq", 10), ("tiny-bf16", 5), ("tiny-gptq", 4)])
+@pytest.mark.parametrize("preset,nseq", [("tiny-awq", 3), ("tiny-awq", 10), ("tiny-bf16", 5), ("tiny-gptq", 4), ("tiny-q4km", 3), ("tiny-q8_0", 9)])
 def test_batched_paged_decode_matches_per_sequence_oracle(device, preset, nseq):
     # batch_decode.rs:35-150: sequences of different lengths share one block pool (blocks interleaved), one new token each per step.
-    # int4 (no act-order) and dense 16-bit models take the weight-sharing multi-row path (10 sequences = two 8-row passes).
+    # int4 (no act-order), dense 16-bit and (since round 3) GGUF block-format models take the weight-sharing multi-row path (int4: 8-row passes up to 4 sequences, the
+    # W4A16 MFMA GEMM from 5; GGUF: the split-f16 MFMA GEMM over the rows, quantised lm_head row by row).
     model = synth.make_llama(preset)
     cfg = model["config"]
     lm, om = runtime.LoadedModel.from_synth(device, model), orc_py.OrcLlama(model)
