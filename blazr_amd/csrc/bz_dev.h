@@ -36,8 +36,10 @@ __device__ __forceinline__ float round_act(float x, int act) {
 // differences in its output.  Range at 2^-44: +-2^19 = 524288, enough where every value that is ever stored ends at 65504 (f16); bf16 / f32 activations have
 // no such bound (the synthetic Mistral Q4_K_M weights drive intermediate values past 5e5), so they keep 2^-32 (+-2^31).  Producer and consumer of an
 // accumulator belong to the same model and pass the same activation dtype.
-__device__ __forceinline__ double fix_scale(int act) { return act == BZ_F16 ? 17592186044416.0 : 4294967296.0; }            // 2^44 : 2^32
-__device__ __forceinline__ double fix_inv(int act) { return act == BZ_F16 ? 5.6843418860808015e-14 : 2.3283064365386963e-10; }
+// bf16 activations (round 3, with the exact dense sums): 2^-40, range +-2^23 -- a bf16 rounding interval is 2^3 wider than an f16 one, and at 2^-32 a sum over a few hundred
+// partials still flipped ~0.1 bf16 roundings per token of a 16-layer model (each one puts that token's logits back at the bf16 noise floor).
+__device__ __forceinline__ double fix_scale(int act) { return act == BZ_F16 ? 17592186044416.0 : (act == BZ_BF16 ? 1099511627776.0 : 4294967296.0); }            // 2^44 : 2^40 : 2^32
+__device__ __forceinline__ double fix_inv(int act) { return act == BZ_F16 ? 5.6843418860808015e-14 : (act == BZ_BF16 ? 9.094947017729282e-13 : 2.3283064365386963e-10); }
 __device__ __forceinline__ float fix2f(long long a, int act) {
   // ONE rounding of the exact fixed-point sum to f32 (the oracle rounds its double sum to f32 once): both 32-bit halves are exact in
   // double, so is their join below 2^53 (above, the join itself rounds to 53 bits first), and the cast rounds to nearest even

@@ -1864,7 +1864,7 @@ static int prefill_min_rows() {
   static const int v = getenv("BZ_NO_MFMA_PREFILL") ? (1 << 30) : (getenv("BZ_PREFILL_MIN") ? atoi(getenv("BZ_PREFILL_MIN")) : 8);
   return v;
 }
-static bool prefill_eligible(const bz_model* m, int S, int total_len) {
+static bool prefill_eligible(const bz_model* m, int S, int total_len, bool decode_batch = false) {
   const bz_model_config& c = m->cfg;
   static const bool no_gq = getenv("BZ_NO_GGUF_PREFILL") != nullptr;
   if (c.arch != BZ_ARCH_LLAMA || S < prefill_min_rows() || (c.act_dtype != BZ_F16 && c.act_dtype != BZ_BF16 && (c.act_dtype != BZ_F32 || no_gq))) return false;
@@ -1882,13 +1882,22 @@ static bool prefill_eligible(const bz_model* m, int S, int total_len) {
       }
     return true;
   }
+  bool any_dense = false;
   for (const LayerDev& L : m->layers)
     for (const FusedLinear* F : {&L.qkv, &L.o, &L.gateup, &L.down}) {
       if (F->parts.size() != 1) return false;
       const LinearDev& P = F->parts[0];
       const bool dense_ok = P.kind == LK_ROWS && P.wdt == c.act_dtype, q4_ok = bzk_gemm_q4g_rows_ok(P);
       if (!dense_ok && !q4_ok) return false;
+      any_dense = any_dense || dense_ok;
     }
+  // dense 16-bit models: the decode GEMVs carry exact sums (piece_dot_d), the MFMA GEMMs f32 ones -- prompts of up to BZ_EXACT_PREFILL_MAX (16) rows stay on the
+  // decode kernels, token by token, so that their rows are the oracle's bits like the int4 models' exact rows (bz_host.hip prefill_exact; BZ_EXACT_PREFILL=0: never)
+  if (any_dense && !decode_batch) {
+    static const int env = getenv("BZ_EXACT_PREFILL") ? atoi(getenv("BZ_EXACT_PREFILL")) : -1;
+    static const int max_rows = getenv("BZ_EXACT_PREFILL_MAX") ? atoi(getenv("BZ_EXACT_PREFILL_MAX")) : 16;
+    if (env != 0 && (env > 0 || S <= max_rows)) return false;
+  }
   return m->lm_head.parts.size() == 1 && m->lm_head.parts[0].kind == LK_ROWS && !m->lm_head.fix_out;
 }
 // split-K partials of the prefill GEMMs (bzk_gemm_nt / bzk_gemm_q4g_mfma)
@@ -2331,7 +2340,7 @@ extern "C" int bz_forward_paged_batch(bz_model* m, const bz_tensor* tokens, int 
     maxlen = std::max(maxlen, seq_lens[i]);
   }
   static const bool no_share = getenv("BZ_NO_BATCH_SHARING") != nullptr;
-  if (!no_share && N >= 2 && prefill_eligible(m, std::max(N, prefill_min_rows()), maxlen)) {
+  if (!no_share && N >= 2 && prefill_eligible(m, std::max(N, prefill_min_rows()), maxlen, true)) {
     // weight-sharing path: the N rows go through the multi-row pipeline (int4: one pass over the weights per 8 sequences; dense: MFMA GEMM),
     // each row with its own position, slot and block-table row
     std::vector<int> pos(N);
@@ -3016,7 +3025,7 @@ extern "C" int bz_decode_batch_graph_capture(bz_model* m, bz_paged_kv* kv, int N
   if (kv->layers != m->cfg.n_layers || kv->n_kv != m->cfg.n_kv_heads || kv->hd != m->cfg.head_dim) BZ_FAIL(BZ_E_INVALID, "batch graph capture: cache does not match the model");
   const int capacity = std::min(max_blocks * kv->block_size, m->cfg.max_seq_len);
   const LinearDev& LH = m->lm_head.parts[0];
-  if (!prefill_eligible(m, std::max(N, prefill_min_rows()), capacity) || LH.wdt != m->cfg.act_dtype || LH.K % 64)
+  if (!prefill_eligible(m, std::max(N, prefill_min_rows()), capacity, true) || LH.wdt != m->cfg.act_dtype || LH.K % 64)
     BZ_FAIL(BZ_E_UNSUPPORTED, "batch graph capture: the model does not take the weight-sharing multi-row step (int4 without act-order or dense 16-bit weights, 16-bit lm_head)");
   BZ_HIP(hipSetDevice(m->dev->id));
   BZ_TRY(prefill_ws(m, N));                      // workspace before the capture (allocation synchronises)

@@ -1821,6 +1821,37 @@ __device__ __forceinline__ float piece_dot(const RowPiece<WDT>& p, const float4&
   }
   return w[0] * xa.x + w[1] * xa.y + w[2] * xa.z + w[3] * xa.w + w[4] * xb.x + w[5] * xb.y + w[6] * xb.z + w[7] * xb.w;
 }
+// The same eight products added to `acc` in double.  The oracle DEFINES a linear layer's output as the exactly rounded dot product (oracle/orc_quant.c: products
+// exact in double, the sum carried in double, one rounding to f32, one to the activation dtype); a 16-bit weight times a 16-bit-valued activation is exact, the sum
+// over K in double is order-independent to ~1e-16, so a dense GEMV that accumulates like this produces the oracle's bits whatever its decomposition over lanes,
+// waves and workgroups -- which f32 FMA chains do not (round 2: two correct bf16 pipelines sat at the bf16 noise floor from each other, 2e-2 at 16 layers).
+// Cost: 8 converts + 8 double FMAs per eight weights against 8 f32 FMAs; the dense GEMVs are bound by their stream, not by this.
+template <int WDT>
+__device__ __forceinline__ double piece_dot_d(const RowPiece<WDT>& p, const double (&x)[8], double acc) {
+  float w[8];
+  if constexpr (WDT == BZ_F32) {
+    w[0] = __uint_as_float(p.a.x); w[1] = __uint_as_float(p.a.y); w[2] = __uint_as_float(p.a.z); w[3] = __uint_as_float(p.a.w);
+    w[4] = __uint_as_float(p.b.x); w[5] = __uint_as_float(p.b.y); w[6] = __uint_as_float(p.b.z); w[7] = __uint_as_float(p.b.w);
+  } else {
+    const unsigned u[4] = {p.a.x, p.a.y, p.a.z, p.a.w};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      if constexpr (WDT == BZ_F16) {
+        w[2 * i] = __half2float(__ushort_as_half((unsigned short)(u[i] & 0xffffu)));
+        w[2 * i + 1] = __half2float(__ushort_as_half((unsigned short)(u[i] >> 16)));
+      } else {
+        w[2 * i] = __uint_as_float(u[i] << 16);
+        w[2 * i + 1] = __uint_as_float(u[i] & 0xffff0000u);
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; e++) acc = fma((double)w[e], x[e], acc);
+  return acc;
+}
+__device__ __forceinline__ void x8_to_d(const float4& xa, const float4& xb, double (&x)[8]) {
+  x[0] = (double)xa.x; x[1] = (double)xa.y; x[2] = (double)xa.z; x[3] = (double)xa.w; x[4] = (double)xb.x; x[5] = (double)xb.y; x[6] = (double)xb.z; x[7] = (double)xb.w;
+}
 
 // A wave walks its rows four at a time, one 512-k chunk per step (row group, chunk).  Loads run two steps ahead of the
 // FMAs (three stage buffers), and the first two stages are issued before the prologue so that the weight stream is
@@ -1874,25 +1905,26 @@ __device__ __forceinline__ void rows_body(const void* __restrict__ W, const floa
     xs4 = (const float4*)xs;
   }
   float bestv = -INFINITY; int besti = 0x7fffffff;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};       // exact sums (piece_dot_d): a row's value does not depend on the lane / chunk decomposition
   int cr = rbeg, ckc = 0, cst = 0;
   auto consume = [&](const Stage& S) {
     if (cst >= nsteps) return;
     cst++;
-    const float4 xa = xs4[ckc * 128 + lane], xb = xs4[ckc * 128 + 64 + lane];
+    double xd[8];
+    x8_to_d(xs4[ckc * 128 + lane], xs4[ckc * 128 + 64 + lane], xd);
 #pragma unroll
-    for (int rr = 0; rr < 4; rr++) acc[rr] += piece_dot<WDT>(S.p[rr], xa, xb);
+    for (int rr = 0; rr < 4; rr++) acc[rr] = piece_dot_d<WDT>(S.p[rr], xd, acc[rr]);
     if (++ckc == KC) {
       ckc = 0;
 #pragma unroll
       for (int rr = 0; rr < 4; rr++) {
-        float v = wave_sum(acc[rr]);
-        acc[rr] = 0.f;
+        const double vd = wave_sum_d(acc[rr]);
+        acc[rr] = 0.0;
         if (cr + rr < rend) {
           if (SPLIT) {
-            if (bias && ks == 0) v += bias[cr + rr];
-            if (lane == 0) atomicAdd((unsigned long long*)(accbuf + cr + rr), (unsigned long long)f2fix(v, pro.act));
+            if (lane == 0) atomicAdd((unsigned long long*)(accbuf + cr + rr), (unsigned long long)d2fix(vd + ((bias && ks == 0) ? (double)bias[cr + rr] : 0.0), pro.act));
           } else {
+            float v = (float)vd;                 // one rounding of the exact sum, then the bias in f32 (the oracle's order)
             if (bias) v += bias[cr + rr];
             v = round_act(v, act);
             if (lane == 0) out[cr + rr] = v;
@@ -1946,6 +1978,24 @@ __device__ __forceinline__ float wave_sum4(float v0, float v1, float v2, float v
   const float s23 = __uint_as_float(r.x) + __uint_as_float(r.y);
   r = __builtin_amdgcn_permlane16_swap(__float_as_uint(s01), __float_as_uint(s23), false, false);
   return grp_reduce<16, OpAdd>(__uint_as_float(r.x) + __uint_as_float(r.y));
+}
+// the same transposed reduction of four doubles (both 32-bit halves through the same swaps)
+__device__ __forceinline__ void swap32_d(double a, double b, double& ra, double& rb) {
+  const long long ba = __double_as_longlong(a), bb = __double_as_longlong(b);
+  const bz_u2_t lo = __builtin_amdgcn_permlane32_swap((unsigned)ba, (unsigned)bb, false, false), hi = __builtin_amdgcn_permlane32_swap((unsigned)(ba >> 32), (unsigned)(bb >> 32), false, false);
+  ra = __longlong_as_double(((long long)hi.x << 32) | lo.x); rb = __longlong_as_double(((long long)hi.y << 32) | lo.y);
+}
+__device__ __forceinline__ void swap16_d(double a, double b, double& ra, double& rb) {
+  const long long ba = __double_as_longlong(a), bb = __double_as_longlong(b);
+  const bz_u2_t lo = __builtin_amdgcn_permlane16_swap((unsigned)ba, (unsigned)bb, false, false), hi = __builtin_amdgcn_permlane16_swap((unsigned)(ba >> 32), (unsigned)(bb >> 32), false, false);
+  ra = __longlong_as_double(((long long)hi.x << 32) | lo.x); rb = __longlong_as_double(((long long)hi.y << 32) | lo.y);
+}
+__device__ __forceinline__ double wave_sum4_d(double v0, double v1, double v2, double v3) {
+  double a, b;
+  swap32_d(v0, v1, a, b); const double s01 = a + b;
+  swap32_d(v2, v3, a, b); const double s23 = a + b;
+  swap16_d(s01, s23, a, b);
+  return grp_sum_d<16>(a + b);
 }
 
 // Mamba2: the B / C channels' conv state is shifted by the launch AFTER the SSM step (every head has read the old state by then): a side duty of
@@ -2173,8 +2223,9 @@ __global__ __launch_bounds__(ROUTE ? 832 : 768) void k_gemv_rows2(const void* __
       lds_wait_count(&cnt[1], 4);
     }
     const float* xr = xs + r * 1024;
-    const float4 xa0 = *(const float4*)(xr + lane * 8), xa1 = *(const float4*)(xr + lane * 8 + 4);
-    const float4 xb0 = *(const float4*)(xr + 512 + lane * 8), xb1 = *(const float4*)(xr + 512 + lane * 8 + 4);
+    double xdA[8], xdB[8];
+    x8_to_d(*(const float4*)(xr + lane * 8), *(const float4*)(xr + lane * 8 + 4), xdA);
+    x8_to_d(*(const float4*)(xr + 512 + lane * 8), *(const float4*)(xr + 512 + lane * 8 + 4), xdB);
     long long* apA = acc + (size_t)min(sbase[r] + slA[r], slots.acc_slots - 1) * (size_t)slots.acc_stride;
     long long* apB = acc + (size_t)min(sbase[r] + slB[r], slots.acc_slots - 1) * (size_t)slots.acc_stride;
     for (int uc = ua; uc < ue; uc += 4) {
@@ -2183,15 +2234,15 @@ __global__ __launch_bounds__(ROUTE ? 832 : 768) void k_gemv_rows2(const void* __
         const int u = uc + q;
         if (u < ue) {
           const bool second = u >= ubr;
-          const float4 xa = second ? xb0 : xa0, xb = second ? xb1 : xa1;
-          const float d0 = piece_dot<WDT>(st[q].p[0], xa, xb), d1 = piece_dot<WDT>(st[q].p[1], xa, xb);
-          const float d2 = piece_dot<WDT>(st[q].p[2], xa, xb), d3 = piece_dot<WDT>(st[q].p[3], xa, xb);
+          double d0, d1, d2, d3;       // exact sums (piece_dot_d): the unit's partial is the same number whatever the lane / wave decomposition
+          if (second) { d0 = piece_dot_d<WDT>(st[q].p[0], xdB, 0.0); d1 = piece_dot_d<WDT>(st[q].p[1], xdB, 0.0); d2 = piece_dot_d<WDT>(st[q].p[2], xdB, 0.0); d3 = piece_dot_d<WDT>(st[q].p[3], xdB, 0.0); }
+          else { d0 = piece_dot_d<WDT>(st[q].p[0], xdA, 0.0); d1 = piece_dot_d<WDT>(st[q].p[1], xdA, 0.0); d2 = piece_dot_d<WDT>(st[q].p[2], xdA, 0.0); d3 = piece_dot_d<WDT>(st[q].p[3], xdA, 0.0); }
           if (u + 4 < ue) issue(st[q], u + 4);
-          float v = wave_sum4(d0, d1, d2, d3);
+          double v = wave_sum4_d(d0, d1, d2, d3);
           const int row = 4 * (u - (second ? ubr : ubr - NRG)) + jrow;
           if ((lane & 15) == 0 && row < N) {
-            if (bias && (second ? kB : kA) == 0) v += bias[row];
-            atomicAdd((unsigned long long*)((second ? apB : apA) + row), (unsigned long long)f2fix(v, pro.act));
+            if (bias && (second ? kB : kA) == 0) v += (double)bias[row];
+            atomicAdd((unsigned long long*)((second ? apB : apA) + row), (unsigned long long)d2fix(v, pro.act));
           }
         }
       }
@@ -2307,14 +2358,15 @@ __global__ __launch_bounds__(768) void k_mlp_dense(const void* __restrict__ Wgu,
   if (zero_buf)
     for (int i = blockIdx.x * 512 + (tid - 256); i < zero_n; i += gridDim.x * 512) zero_buf[i] = 0;
   lds_wait_count(&cnt[1], 4);
-  float ag[4] = {0.f, 0.f, 0.f, 0.f}, au[4] = {0.f, 0.f, 0.f, 0.f};
+  double ag[4] = {0.0, 0.0, 0.0, 0.0}, au[4] = {0.0, 0.0, 0.0, 0.0};     // exact sums (piece_dot_d)
   for (int kc = 0; kc < KC; kc += 2) {
 #pragma unroll
     for (int q = 0; q < 2; q++) {
       if (kc + q < KC) {
-        const float4 xa = *(const float4*)(xs + (kc + q) * 512 + lane * 8), xb = *(const float4*)(xs + (kc + q) * 512 + lane * 8 + 4);
+        double xd[8];
+        x8_to_d(*(const float4*)(xs + (kc + q) * 512 + lane * 8), *(const float4*)(xs + (kc + q) * 512 + lane * 8 + 4), xd);
 #pragma unroll
-        for (int r = 0; r < 4; r++) { ag[r] += piece_dot<WDT>(st[q].g[r], xa, xb); au[r] += piece_dot<WDT>(st[q].u[r], xa, xb); }
+        for (int r = 0; r < 4; r++) { ag[r] = piece_dot_d<WDT>(st[q].g[r], xd, ag[r]); au[r] = piece_dot_d<WDT>(st[q].u[r], xd, au[r]); }
         if (kc + q + 2 < KC) issue(st[q], kc + q + 2);
       }
     }
@@ -2328,27 +2380,28 @@ __global__ __launch_bounds__(768) void k_mlp_dense(const void* __restrict__ Wgu,
 #pragma unroll
   for (int t = 0; t < 16; t++) if (t < NLD) D[t] = ldnt((const uint4*)(wd + (size_t)(n0 + t * 16) * 32 + ksub));
   {
-    const float sg = wave_sum4(ag[0], ag[1], ag[2], ag[3]), su = wave_sum4(au[0], au[1], au[2], au[3]);   // value j in 16-lane row [0, 2, 1, 3][j]
+    double sgd = wave_sum4_d(ag[0], ag[1], ag[2], ag[3]), sud = wave_sum4_d(au[0], au[1], au[2], au[3]);   // value j in 16-lane row [0, 2, 1, 3][j]
     const int j = ((lane >> 4) & 1) * 2 + (lane >> 5);
-    float g = sg, u = su;
-    if (bgu) { g += bgu[c0 + j]; u += bgu[I + c0 + j]; }
+    if (bgu) { sgd += (double)bgu[c0 + j]; sud += (double)bgu[I + c0 + j]; }
+    const float g = (float)sgd, u = (float)sud;       // ONE rounding of the exact sum to f32, as the oracle
     const float a = round_act(round_act(silu_f(round_act(g, act)), act) * round_act(u, act), act);
     if ((lane & 15) == 0) actl[tw * 4 + j] = a;
   }
   __builtin_amdgcn_s_waitcnt(0xc07f);
   if (lane == 0) atomicAdd(&cnt[2], 1u);
   lds_wait_count(&cnt[2], 8);
-  const float4 aa = *(const float4*)(actl + ksub), ab = *(const float4*)(actl + ksub + 4);
+  double ad[8];
+  x8_to_d(*(const float4*)(actl + ksub), *(const float4*)(actl + ksub + 4), ad);
 #pragma unroll
   for (int t = 0; t < 16; t++) {
     if (t < NLD) {
       RowPiece<WDT> pc; pc.a = D[t];
-      float d = piece_dot<WDT>(pc, aa, ab);
-      d = grp_reduce<4, OpAdd>(d);
+      double d = piece_dot_d<WDT>(pc, ad, 0.0);
+      d += dpp_get<DPP_XOR1>(d); d += dpp_get<DPP_XOR2>(d);      // the row's four lanes
       const int n = n0 + t * 16;
       if ((lane & 3) == 0) {
-        if (bd != nullptr && slab == 0) d += bd[n];
-        atomicAdd((unsigned long long*)(acc + n), (unsigned long long)f2fix(d, pro.act));
+        if (bd != nullptr && slab == 0) d += (double)bd[n];
+        atomicAdd((unsigned long long*)(acc + n), (unsigned long long)d2fix(d, pro.act));
       }
     }
   }
@@ -3387,17 +3440,20 @@ __global__ __launch_bounds__(NW * 64) void k_attn2(AttnArgs a, const uint4* __re
   if (FUSE == 2) {
     // dense o_proj: this lane's 8 weights of each output row against its 8 head outputs, reduced over the row's NPC lanes, one fixed-point atomic per (head, row)
     __syncthreads();
-    const float4 oa = *(const float4*)(outh + piece * 8), ob = *(const float4*)(outh + piece * 8 + 4);
+    double od[8];
+    x8_to_d(*(const float4*)(outh + piece * 8), *(const float4*)(outh + piece * 8 + 4), od);
 #pragma unroll
     for (int t = 0; t < DLD; t++) {
       float w8[8];
       unpack2<KVDT>(Wd[t].x, w8[0], w8[1]); unpack2<KVDT>(Wd[t].y, w8[2], w8[3]); unpack2<KVDT>(Wd[t].z, w8[4], w8[5]); unpack2<KVDT>(Wd[t].w, w8[6], w8[7]);
-      float d = w8[0] * oa.x + w8[1] * oa.y + w8[2] * oa.z + w8[3] * oa.w + w8[4] * ob.x + w8[5] * ob.y + w8[6] * ob.z + w8[7] * ob.w;
-      d = grp_reduce<NPC, OpAdd>(d);
+      double d = 0.0;                 // exact sums, as the other dense GEMVs (piece_dot_d)
+#pragma unroll
+      for (int e = 0; e < 8; e++) d = fma((double)w8[e], od[e], d);
+      d = grp_sum_d<NPC>(d);
       const int n = nd0 + t * RPL + rsub;
       if (piece == 0) {
-        if (bias != nullptr && hq == 0) d += bias[n];
-        atomicAdd((unsigned long long*)(acc + n), (unsigned long long)f2fix(d, a.act));
+        if (bias != nullptr && hq == 0) d += (double)bias[n];
+        atomicAdd((unsigned long long*)(acc + n), (unsigned long long)d2fix(d, a.act));
       }
     }
     return;
@@ -5314,7 +5370,7 @@ __global__ __launch_bounds__(256) void k_moe_route_rows(const unsigned short* __
   }
   __syncthreads();
   for (int e = wave; e < E; e += 4) {
-    long long accf = 0;                     // per 512-k chunk: the lane's 8-term dot, k_gemv_rows2's reduction tree, 2^-32 fixed point
+    long long accf = 0;                     // per 512-k chunk: the exact sum (double), rounded to the fixed-point grid as k_gemv_rows2 rounds its unit partials
     for (int k0 = 0; k0 < H; k0 += 4096) {
       RowPiece<WDT> w[8];
 #pragma unroll
@@ -5325,8 +5381,9 @@ __global__ __launch_bounds__(256) void k_moe_route_rows(const unsigned short* __
         if (k0 + j * 512 < H) {
           const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
           const float4 xa = k < H ? *(const float4*)(xs + k) : z4, xb = k < H ? *(const float4*)(xs + k + 4) : z4;
-          const float d = piece_dot<WDT>(w[j], xa, xb);
-          accf += f2fix(grp_reduce<16, OpAdd>(xrow16<OpAdd>(xrow32<OpAdd>(d))), DT);
+          double xd[8];
+          x8_to_d(xa, xb, xd);
+          accf += d2fix(wave_sum_d(piece_dot_d<WDT>(w[j], xd, 0.0)), DT);      // the chunk's exact sum on the fixed-point grid: k_gemv_rows2's value
         }
       }
     }

@@ -96,3 +96,28 @@ def test_exact_gemm_on_the_integer_matrix_cores(wpb):
         env["BZ_I8_WPB"] = wpb
     n, _ = _child(env)
     assert n == 0
+
+
+@pytest.mark.parametrize("preset,over", [("llama3.2-1b-bf16", dict(n_layers=4, vocab=4096)), ("tiny-bf16", {})], ids=["llama3.2-1b-widths", "tiny-bf16"])
+def test_dense_16bit_llama_is_the_oracle_bit_for_bit(device, preset, over):
+    """BASELINE config 0 (dense bf16 SafeTensors): the decode GEMVs carry their sums in double over exact products (bz_kernels.hip piece_dot_d: q/k/v, o_proj, gate / up, down,
+    lm_head), which is the oracle's definition of a linear layer; with the exact norm, RoPE, attention and SiLU of the int4 path every logit of a 12-token prompt (short prompts
+    stay on the decode kernels) and of 8 decode steps equals the oracle's.  Round 2 held this config to the bf16 noise floor (2e-2 at 16 layers)."""
+    model = synth.make_llama(preset, **over)
+    cfg = model["config"]
+    lm, om = runtime.LoadedModel.from_synth(device, model), orc_py.OrcLlama(model)
+    p = [int(t) for t in synth.prompt_tokens(12, cfg["vocab"], seed=51)]
+    kv = runtime.LayeredKvCache(device, cfg["n_layers"], 1, cfg["n_kv_heads"], 32, cfg["max_seq_len"], cfg["head_dim"], L.BF16)
+    okv = om.new_kv(32)
+    got = [lm.forward_with_kv_cache(p, kv, 0, all_logits=True).to_numpy().reshape(12, -1)]
+    want = [om.forward_kv(p, okv, 0, all_logits=True).reshape(12, -1)]
+    tok = int(want[0][-1].argmax())
+    for i in range(8):
+        got.append(lm.forward_with_kv_cache([tok], kv, 12 + i).to_numpy().reshape(1, -1))
+        want.append(om.forward_kv([tok], okv, 12 + i).reshape(1, -1))
+        tok = int(want[-1][0].argmax())
+    got, want = np.concatenate(got), np.concatenate(want)
+    ndiff = int((got != want).sum())
+    print("%s: %d of %d logits differ, rel L2 %.2e" % (preset, ndiff, got.size, _rel(got, want)))
+    assert ndiff <= got.size // 10000 and _rel(got, want) <= 1e-5      # (a sum within 1e-16 of a rounding boundary may still land on the other side)
+    orc_py.lib().orc_kv_free(okv)
