@@ -1199,7 +1199,7 @@ static int finalize_mamba2(bz_model* m) {
   }
   for (int i = 0; i < 2; i++) { BZ_TRY(dev_alloc(m, &p, (size_t)D * 4)); m->hbuf[i] = (float*)p; }
   BZ_TRY(dev_alloc(m, &p, (size_t)DI * 4)); m->ybuf = (float*)p;
-  BZ_TRY(dev_alloc(m, &p, (size_t)NH * 4)); m->vss = (float*)p;
+  BZ_TRY(dev_alloc(m, &p, (size_t)NH * 8)); m->vss = (float*)p;      // per head: the exact sum of squares as hi + lo floats
   BZ_TRY(dev_alloc(m, &p, (size_t)V * 4)); m->logits = (float*)p;
   m->nparts = bzk_gemv_rows_blocks(m->lm_head.parts[0]);
   BZ_TRY(dev_alloc(m, &p, (size_t)m->nparts * 4)); m->pval = (float*)p;
@@ -1730,7 +1730,7 @@ static int dsv2_step(bz_model* m, const StepIO& io) {
   BZ_TRY(bzk_embed(st, m->embed, m->embed_dt, io.d_tok, H, act, m->hbuf[cur]));
   for (int l = 0; l < c.n_layers; l++) {
     const DsLayerDev& L = m->dlayers[l];
-    Pro pn{}; pn.mode = PRO_NORM; pn.src = prev; pn.h_in = m->hbuf[cur]; pn.h_out = m->hbuf[cur ^ 1]; pn.norm_w = L.attn_norm; pn.eps = c.rms_eps; pn.H = H; pn.act = act;
+    Pro pn{}; pn.mode = PRO_NORM; pn.src = prev; pn.h_in = m->hbuf[cur]; pn.h_out = m->hbuf[cur ^ 1]; pn.norm_w = L.attn_norm; pn.eps = c.rms_eps; pn.H = H; pn.act = act; pn.f32_sums = 1;
     VSrc qkva;
     BZ_TRY(run_fused(m, L.qkva, pn, rs, &qkva));
     cur ^= 1;
@@ -1738,7 +1738,7 @@ static int dsv2_step(bz_model* m, const StepIO& io) {
     if (c.mla_q_lora_rank > 0) {
       // q = q_b_proj(q_a_layernorm(q_a)): a second GEMV whose prologue is the RMSNorm of the first one's leading q_lora_rank outputs (no residual);
       // the latent | k_pe part of the first GEMV's output reaches the attention kernel through `kva`
-      Pro pq{}; pq.mode = PRO_NORM; pq.src = VSrc{nullptr, 0}; pq.h_in = (const float*)qkva.p; pq.h_out = nullptr; pq.norm_w = L.q_norm; pq.eps = c.rms_eps; pq.H = c.mla_q_lora_rank; pq.act = act;
+      Pro pq{}; pq.mode = PRO_NORM; pq.src = VSrc{nullptr, 0}; pq.h_in = (const float*)qkva.p; pq.h_out = nullptr; pq.norm_w = L.q_norm; pq.eps = c.rms_eps; pq.H = c.mla_q_lora_rank; pq.act = act; pq.f32_sums = 1;
       VSrc qv;
       BZ_TRY(run_fused(m, L.q_b, pq, rs, &qv));
       ma.kva = (const float*)qkva.p + c.mla_q_lora_rank;
@@ -1749,15 +1749,15 @@ static int dsv2_step(bz_model* m, const StepIO& io) {
     ma.scale = mla_softmax_scale(c);
     ma.ws = m->mla_ws; ma.nsplit = m->mla_nsplit;
     BZ_TRY(bzk_mla_attn(st, ma, c.max_seq_len));
-    Pro pp{}; pp.mode = PRO_PLAIN; pp.src = VSrc{m->attn_out, 0}; pp.act = act; pp.H = 0;
+    Pro pp{}; pp.mode = PRO_PLAIN; pp.src = VSrc{m->attn_out, 0}; pp.act = act; pp.H = 0; pp.f32_sums = 1;
     VSrc ov;
     BZ_TRY(run_fused(m, L.o, pp, rs, &ov));
-    Pro pf{}; pf.mode = PRO_NORM; pf.src = ov; pf.h_in = m->hbuf[cur]; pf.h_out = m->hbuf[cur ^ 1]; pf.norm_w = L.ffn_norm; pf.eps = c.rms_eps; pf.H = H; pf.act = act;
+    Pro pf{}; pf.mode = PRO_NORM; pf.src = ov; pf.h_in = m->hbuf[cur]; pf.h_out = m->hbuf[cur ^ 1]; pf.norm_w = L.ffn_norm; pf.eps = c.rms_eps; pf.H = H; pf.act = act; pf.f32_sums = 1;
     if (!L.is_moe) {
       VSrc gu, dn;
       BZ_TRY(run_fused(m, L.gateup, pf, rs, &gu));
       cur ^= 1;
-      Pro ps{}; ps.mode = PRO_SILU; ps.src = gu; ps.H = c.inter; ps.act = act;
+      Pro ps{}; ps.mode = PRO_SILU; ps.src = gu; ps.H = c.inter; ps.act = act; ps.f32_sums = 1;
       BZ_TRY(run_fused(m, L.down, ps, rs, &dn));
       prev = dn;
     } else {
@@ -1770,7 +1770,8 @@ static int dsv2_step(bz_model* m, const StepIO& io) {
         LinearDev RL; RL.kind = LK_ROWS; RL.N = E; RL.K = H; RL.wdt = L.router_dt; RL.w = L.router; RL.sk = 2; RL.owned = false; RL.algo_bytes = (size_t)E * H * bz_dtype_size(L.router_dt);
         FusedLinear RF; RF.parts.push_back(RL); RF.n_off.push_back(0); RF.N = E; RF.K = H; RF.fix_out = true;
         VSrc lg;
-        BZ_TRY(run_fused(m, RF, pf, rs, &lg));
+        Pro pr = pf; pr.f32_sums = 0;      // the router's logits are exact sums on both paths (prompt rows: k_moe_route_rows), so a token routes the same way in a prompt and in a decode step
+        BZ_TRY(run_fused(m, RF, pr, rs, &lg));
         cur ^= 1;
         Pro pg = pf; pg.h_out = nullptr;
         MoeGemvArgs g1{};
@@ -2387,6 +2388,11 @@ static bool mamba_prefill_eligible(const bz_model* m, int S) {
   const bz_model_config& c = m->cfg;
   if (off || c.arch != BZ_ARCH_MAMBA2 || S < prefill_min_rows()) return false;
   if (c.act_dtype != BZ_F16 && c.act_dtype != BZ_BF16) return false;
+  {   // short prompts stay on the step kernels (exact sums: the oracle's bits), as for the dense Llama models (prefill_eligible)
+    static const int env = getenv("BZ_EXACT_PREFILL") ? atoi(getenv("BZ_EXACT_PREFILL")) : -1;
+    static const int max_rows = getenv("BZ_EXACT_PREFILL_MAX") ? atoi(getenv("BZ_EXACT_PREFILL_MAX")) : 16;
+    if (env != 0 && (env > 0 || S <= max_rows)) return false;
+  }
   if (!bzk_ssm_scan_ok(c.ssm_head_dim, c.ssm_d_state, c.ssm_n_groups, c.ssm_conv_kernel) || c.ssm_d_inner % c.ssm_n_groups || c.ssm_n_heads % c.ssm_n_groups) return false;
   for (const MambaLayerDev& L : m->mlayers)
     for (const FusedLinear* F : {&L.in_proj, &L.out_proj}) {

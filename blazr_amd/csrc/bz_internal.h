@@ -52,6 +52,7 @@ struct Pro {
   int aux2;            // GATED2: number of heads (h_in = per-head sums of v^2 from the SSM kernel, src = v = R(y * R(silu z)))
   long long* stamps;   // diagnostic only (BZ_MLP_STAMPS): s_memrealtime at phase boundaries of block 0
   int dbg;             // tuning only (bz_tune_gemv): 1 = store instead of atomics, 2 = skip the dot4 work, 4 = skip quantisation
+  int f32_sums;        // dense k_gemv_rows2: f32 FMA chains instead of the exact (double) sums -- the DeepSeek-V2 path sets it (k_gemv_rows2's EX)
 };
 
 enum { LK_NONE = 0, LK_Q4G = 1, LK_ROWS = 2, LK_Q4K = 3, LK_Q6K = 4, LK_Q80 = 5 };

@@ -177,9 +177,9 @@ __device__ void build_x_simple(const Pro& p, int k0, int KR, float* xs, float* r
     // gated RMSNorm with the gate and the per-head sums of squares already applied / reduced by the SSM kernel
     const int G = p.aux > 0 ? p.aux : 1, gsz = p.H / G, hpg = p.aux2 / G;
     if (tid < G) {
-      float ss = 0.f;
-      for (int h = 0; h < hpg; h++) ss += p.h_in[tid * hpg + h];
-      red[4 + tid] = rms_scale(ss, (float)gsz, p.eps);
+      double ss = 0.0;                                  // per-head exact sums arrive as hi + lo floats (k_ssm_step)
+      for (int h = 0; h < hpg; h++) ss += (double)p.h_in[2 * (tid * hpg + h)] + (double)p.h_in[2 * (tid * hpg + h) + 1];
+      red[4 + tid] = rms_scale((float)ss, (float)gsz, p.eps);
     }
     __syncthreads();
     for (int base = 0; base < KR; base += 2048) {
@@ -2020,7 +2020,9 @@ __global__ void k_conv_shift(ConvShift c, int act) {
 // publishes selection and weights for the down / combine launches.  One 5 us GEMV + ~3 us in front of this stream instead of a 14 us router launch
 // whose last workgroup ran the top-k behind a device-scope counter.
 __device__ void moe_softmax_topk(const float* lg, int E, int top_k, int n_shared, float routed_scale, int norm_topk, int* sel, float* wsel, int lane);
-template <int WDT, int MODE, bool FIX, int ROUTE = 0>
+// EX: exact sums (piece_dot_d / wave_sum4_d: Llama and Mamba2, whose every other op is exact too); DeepSeek-V2 (MLA sums, router softmax in f32) keeps the f32
+// chains -- there the exact GEMVs bought no bits and cost 35 % of the step (the 832-thread ROUTE form went 22 -> 62 us under the doubles' register pressure)
+template <int WDT, int MODE, bool FIX, int ROUTE = 0, bool EX = false>
 __global__ __launch_bounds__(ROUTE ? 832 : 768) void k_gemv_rows2(const void* __restrict__ W, const float* __restrict__ bias, int N, int K, Pro pro,
                                                     long long* __restrict__ acc, long long* zero_buf, int zero_n, ConvShift shift, MoeSlots slots, RouteArgs route) {
   // NR unit ranges per workgroup.  ROUTE: range 0 = the shared experts' slots [top_k, top_k + n_shared) (ids known: the stream starts at entry),
@@ -2151,8 +2153,8 @@ __global__ __launch_bounds__(ROUTE ? 832 : 768) void k_gemv_rows2(const void* __
       __builtin_amdgcn_sched_barrier(0);
       __syncthreads();
       for (int g = 0; g < G && g < 8; g++) {        // every row wave keeps its own copy of the (<= 8) group factors
-        double t = 0.0;
-        for (int h = lane; h < hpg; h += 64) t += (double)pro.h_in[g * hpg + h];
+        double t = 0.0;                                                     // per-head exact sums arrive as hi + lo floats (k_ssm_step)
+        for (int h = lane; h < hpg; h += 64) t += (double)pro.h_in[2 * (g * hpg + h)] + (double)pro.h_in[2 * (g * hpg + h) + 1];
         t = wave_sum_d(t);
         if (lane == 0) grs[wave][g] = rms_scale((float)t, (float)gsz, pro.eps);
       }
@@ -2223,9 +2225,10 @@ __global__ __launch_bounds__(ROUTE ? 832 : 768) void k_gemv_rows2(const void* __
       lds_wait_count(&cnt[1], 4);
     }
     const float* xr = xs + r * 1024;
-    double xdA[8], xdB[8];
-    x8_to_d(*(const float4*)(xr + lane * 8), *(const float4*)(xr + lane * 8 + 4), xdA);
-    x8_to_d(*(const float4*)(xr + 512 + lane * 8), *(const float4*)(xr + 512 + lane * 8 + 4), xdB);
+    const float4 xa0 = *(const float4*)(xr + lane * 8), xa1 = *(const float4*)(xr + lane * 8 + 4);
+    const float4 xb0 = *(const float4*)(xr + 512 + lane * 8), xb1 = *(const float4*)(xr + 512 + lane * 8 + 4);
+    double xdA[EX ? 8 : 1], xdB[EX ? 8 : 1];
+    if constexpr (EX) { x8_to_d(xa0, xa1, xdA); x8_to_d(xb0, xb1, xdB); }
     long long* apA = acc + (size_t)min(sbase[r] + slA[r], slots.acc_slots - 1) * (size_t)slots.acc_stride;
     long long* apB = acc + (size_t)min(sbase[r] + slB[r], slots.acc_slots - 1) * (size_t)slots.acc_stride;
     for (int uc = ua; uc < ue; uc += 4) {
@@ -2234,15 +2237,27 @@ __global__ __launch_bounds__(ROUTE ? 832 : 768) void k_gemv_rows2(const void* __
         const int u = uc + q;
         if (u < ue) {
           const bool second = u >= ubr;
-          double d0, d1, d2, d3;       // exact sums (piece_dot_d): the unit's partial is the same number whatever the lane / wave decomposition
-          if (second) { d0 = piece_dot_d<WDT>(st[q].p[0], xdB, 0.0); d1 = piece_dot_d<WDT>(st[q].p[1], xdB, 0.0); d2 = piece_dot_d<WDT>(st[q].p[2], xdB, 0.0); d3 = piece_dot_d<WDT>(st[q].p[3], xdB, 0.0); }
-          else { d0 = piece_dot_d<WDT>(st[q].p[0], xdA, 0.0); d1 = piece_dot_d<WDT>(st[q].p[1], xdA, 0.0); d2 = piece_dot_d<WDT>(st[q].p[2], xdA, 0.0); d3 = piece_dot_d<WDT>(st[q].p[3], xdA, 0.0); }
-          if (u + 4 < ue) issue(st[q], u + 4);
-          double v = wave_sum4_d(d0, d1, d2, d3);
           const int row = 4 * (u - (second ? ubr : ubr - NRG)) + jrow;
-          if ((lane & 15) == 0 && row < N) {
-            if (bias && (second ? kB : kA) == 0) v += (double)bias[row];
-            atomicAdd((unsigned long long*)((second ? apB : apA) + row), (unsigned long long)d2fix(v, pro.act));
+          if constexpr (EX) {
+            double d0, d1, d2, d3;       // exact sums (piece_dot_d): the unit's partial is the same number whatever the lane / wave decomposition
+            if (second) { d0 = piece_dot_d<WDT>(st[q].p[0], xdB, 0.0); d1 = piece_dot_d<WDT>(st[q].p[1], xdB, 0.0); d2 = piece_dot_d<WDT>(st[q].p[2], xdB, 0.0); d3 = piece_dot_d<WDT>(st[q].p[3], xdB, 0.0); }
+            else { d0 = piece_dot_d<WDT>(st[q].p[0], xdA, 0.0); d1 = piece_dot_d<WDT>(st[q].p[1], xdA, 0.0); d2 = piece_dot_d<WDT>(st[q].p[2], xdA, 0.0); d3 = piece_dot_d<WDT>(st[q].p[3], xdA, 0.0); }
+            if (u + 4 < ue) issue(st[q], u + 4);
+            double v = wave_sum4_d(d0, d1, d2, d3);
+            if ((lane & 15) == 0 && row < N) {
+              if (bias && (second ? kB : kA) == 0) v += (double)bias[row];
+              atomicAdd((unsigned long long*)((second ? apB : apA) + row), (unsigned long long)d2fix(v, pro.act));
+            }
+          } else {
+            const float4 xa = second ? xb0 : xa0, xb = second ? xb1 : xa1;
+            const float d0 = piece_dot<WDT>(st[q].p[0], xa, xb), d1 = piece_dot<WDT>(st[q].p[1], xa, xb);
+            const float d2 = piece_dot<WDT>(st[q].p[2], xa, xb), d3 = piece_dot<WDT>(st[q].p[3], xa, xb);
+            if (u + 4 < ue) issue(st[q], u + 4);
+            float v = wave_sum4(d0, d1, d2, d3);
+            if ((lane & 15) == 0 && row < N) {
+              if (bias && (second ? kB : kA) == 0) v += bias[row];
+              atomicAdd((unsigned long long*)((second ? apB : apA) + row), (unsigned long long)f2fix(v, pro.act));
+            }
           }
         }
       }
@@ -2712,7 +2727,8 @@ int bzk_gemv(hipStream_t s, const LinearDev& L, const Pro& pro, const GemvOut& o
     const int KC = (L.K + 511) / 512;
     const int nb = (int)std::max<long long>(std::min<long long>(256, U), KC);   // one workgroup per CU; a range lies in <= 2 chunks when nb >= K / 512
     const char* lbl = pro.mode == PRO_NORM ? "gemv_rows2<norm>" : pro.mode == PRO_GATED2 ? "gemv_rows2<gated>" : pro.mode == PRO_SILU ? "gemv_rows2<silu>" : "gemv_rows2";
-#define LAUNCH_R2(DT, MODE, FIX) BZ_LAUNCH(lbl, L.algo_bytes, (k_gemv_rows2<DT, MODE, FIX>), dim3(nb), dim3(768), 0, s, (const void*)L.w, L.bias, L.N, L.K, pro, \
+#define LAUNCH_R2(DT, MODE, FIX) do { if (pro.f32_sums) LAUNCH_R2X(DT, MODE, FIX, false); else LAUNCH_R2X(DT, MODE, FIX, true); } while (0)
+#define LAUNCH_R2X(DT, MODE, FIX, EX_) BZ_LAUNCH(lbl, L.algo_bytes, (k_gemv_rows2<DT, MODE, FIX, 0, EX_>), dim3(nb), dim3(768), 0, s, (const void*)L.w, L.bias, L.N, L.K, pro, \
     out.acc, out.zero_buf, out.zero_n, out.shift, MoeSlots{nullptr, 0, 1, 0, 0, 1}, RouteArgs{})
 #define LAUNCH_R2_F(DT, MODE) do { if (pro.src.fix) LAUNCH_R2(DT, MODE, true); else LAUNCH_R2(DT, MODE, false); } while (0)
 #define LAUNCH_R2_M(DT) do { if (pro.mode == PRO_NORM) LAUNCH_R2_F(DT, PRO_NORM); else if (pro.mode == PRO_SILU) LAUNCH_R2_F(DT, PRO_SILU); \
@@ -2721,6 +2737,7 @@ int bzk_gemv(hipStream_t s, const LinearDev& L, const Pro& pro, const GemvOut& o
 #undef LAUNCH_R2_M
 #undef LAUNCH_R2_F
 #undef LAUNCH_R2
+#undef LAUNCH_R2X
     BZ_HIP(hipGetLastError());
     return BZ_OK;
   }
@@ -4357,7 +4374,12 @@ int bzk_silu_mul(hipStream_t s, const float* g, const float* u, long long n, int
 // ---------------------------------------------------------------------------------------------------------
 // Mamba2 single-token kernels: causal conv1d step, SSM state update + readout
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float softplus_f(float x) { return x > 20.0f ? x : log1pf(bz_expf(x)); }
+// log1p in double, one rounding to f32 (the oracle's softplus: glibc's and ocml's f32 log1pf differ in the last bit often enough to matter; both are faithful in double)
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.0f ? x : (float)log1p((double)bz_expf(x)); }
+// Mamba2 arithmetic (round 3, the oracle's definitions -- orc_mamba2.c): the conv window's dot product and the readout C . h are exactly rounded sums (double over
+// exact products), the state update h dA + (dt x) B is two exact products summed in double and rounded once to f32, and y = f32(C . h) + D x with the D x product
+// rounded on its own (no fused multiply-add: __fmul_rn / __fadd_rn where a contraction would change the bits)
+__device__ __forceinline__ float ssm_h_update(float h, float dA, float dtx, float B) { return (float)fma((double)h, (double)dA, (double)dtx * (double)B); }
 
 // grid = n_heads; 256 threads = 64 rows (p) x 4 state quarters.  h = R(h * dA + (dt x) B); y = R(sum_n h C + D x)
 // The causal conv1d step (+ SiLU) runs in front, inside the same launch: a head's workgroup convolves its own head_dim x channels (and shifts
@@ -4367,7 +4389,8 @@ __device__ __forceinline__ float softplus_f(float x) { return x > 20.0f ? x : lo
 template <int SDT, int PARTS>   // PARTS threads share a state row: 4 (256-thread blocks) or 16 (1024 threads: 4 waves per SIMD, one 16-byte piece per thread)
 __global__ __launch_bounds__(64 * PARTS) void k_ssm_step(SsmArgs a) {
   constexpr int NTH = 64 * PARTS;
-  __shared__ float sB[256], sC[256], sX[256], sred[PARTS];
+  __shared__ float sB[256], sC[256], sX[256];
+  __shared__ double sredd[PARTS];
   const int hd = blockIdx.x, tid = threadIdx.x;
   const int NS = a.d_state, HD = a.head_dim, KC = a.conv_kernel;
   const int hpg = a.n_heads / a.n_groups;
@@ -4384,23 +4407,23 @@ __global__ __launch_bounds__(64 * PARTS) void k_ssm_step(SsmArgs a) {
     const int ch = t < NS ? a.d_inner + g * NS + t : (t < 2 * NS ? a.d_inner + a.n_groups * NS + g * NS + (t - NS) : hd * HD + (t - 2 * NS));
     float* cs = a.conv_state + (size_t)ch * (KC - 1);
     const float xr = vsrc_get(a.zx, a.x_off + ch, a.act);
-    float c = 0.f;
+    double cd = 0.0;
     if (KC == 4) {
       const float c0 = cs[0], c1 = cs[1], c2 = cs[2];
       const float4 w = *(const float4*)(a.conv_w + (size_t)ch * 4);
-      c += c0 * w.x; c += c1 * w.y; c += c2 * w.z; c += xr * w.w;
+      cd = fma((double)c0, (double)w.x, cd); cd = fma((double)c1, (double)w.y, cd); cd = fma((double)c2, (double)w.z, cd); cd = fma((double)xr, (double)w.w, cd);
       if (t >= 2 * NS) { cs[0] = c1; cs[1] = c2; cs[2] = xr; }
     } else {
-      for (int j = 0; j < KC - 1; j++) c += cs[j] * a.conv_w[(size_t)ch * KC + j];
-      c += xr * a.conv_w[(size_t)ch * KC + KC - 1];
+      for (int j = 0; j < KC - 1; j++) cd = fma((double)cs[j], (double)a.conv_w[(size_t)ch * KC + j], cd);
+      cd = fma((double)xr, (double)a.conv_w[(size_t)ch * KC + KC - 1], cd);
       if (t >= 2 * NS) { for (int j = 0; j + 1 < KC - 1; j++) cs[j] = cs[j + 1]; cs[KC - 2] = xr; }
     }
-    c = round_act(c + a.conv_b[ch], a.act);
+    float c = round_act(__fadd_rn((float)cd, a.conv_b[ch]), a.act);
     c = round_act(silu_f(c), a.act);
     if (t < NS) sB[t] = c; else if (t < 2 * NS) sC[t - NS] = c; else sX[t - 2 * NS] = c;
   }
   const float dt = round_act(softplus_f(round_act(dtraw + dtb, a.act)), a.act);
-  const float dA = bz_expf(dt * -bz_expf(alog));
+  const float dA = bz_expf(__fmul_rn(dt, -bz_expf(alog)));
   __syncthreads();
   if (a.conv_out) {      // op-level entry points: the conv output as the forward path computed it (B / C by the first head of their group)
     if (hd % hpg == 0)
@@ -4408,13 +4431,13 @@ __global__ __launch_bounds__(64 * PARTS) void k_ssm_step(SsmArgs a) {
     for (int t = tid; t < HD; t += NTH) a.conv_out[hd * HD + t] = sX[t];
     if (a.conv_only) return;
   }
-  float vsq = 0.f;
+  double vsq = 0.0;
   for (int p0 = 0; p0 < HD; p0 += 64) {
     const int p = p0 + tid / PARTS;
-    float acc = 0.f, xv = 0.f;
+    double acc = 0.0; float xv = 0.f;
     if (p < HD) {
       xv = sX[p];
-      const float dtx = dt * xv;
+      const float dtx = __fmul_rn(dt, xv);
       const size_t off = ((size_t)hd * HD + p) * NS + q * nq;
       if (vec) {
         // 16-bit state: 8 elements per 16-byte load / store
@@ -4426,10 +4449,10 @@ __global__ __launch_bounds__(64 * PARTS) void k_ssm_step(SsmArgs a) {
           for (int j = 0; j < 4; j++) {
             float h0, h1;
             unpack2<SDT>(u[j], h0, h1);
-            h0 = round_act(h0 * dA + dtx * sB[q * nq + n + 2 * j], a.act);
-            h1 = round_act(h1 * dA + dtx * sB[q * nq + n + 2 * j + 1], a.act);
-            acc += h0 * sC[q * nq + n + 2 * j];
-            acc += h1 * sC[q * nq + n + 2 * j + 1];
+            h0 = round_act(ssm_h_update(h0, dA, dtx, sB[q * nq + n + 2 * j]), a.act);
+            h1 = round_act(ssm_h_update(h1, dA, dtx, sB[q * nq + n + 2 * j + 1]), a.act);
+            acc = fma((double)h0, (double)sC[q * nq + n + 2 * j], acc);
+            acc = fma((double)h1, (double)sC[q * nq + n + 2 * j + 1], acc);
             u[j] = pack2<SDT>(h0, h1);
           }
           *sp = make_uint4(u[0], u[1], u[2], u[3]);
@@ -4440,30 +4463,34 @@ __global__ __launch_bounds__(64 * PARTS) void k_ssm_step(SsmArgs a) {
           if (SDT == BZ_F32) hcur = ((float*)a.state)[off + n];
           else if (SDT == BZ_F16) hcur = __half2float(((__half*)a.state)[off + n]);
           else hcur = __uint_as_float((unsigned)((unsigned short*)a.state)[off + n] << 16);
-          const float hn = round_act(hcur * dA + dtx * sB[q * nq + n], a.act);
-          acc += hn * sC[q * nq + n];
+          const float hn = round_act(ssm_h_update(hcur, dA, dtx, sB[q * nq + n]), a.act);
+          acc = fma((double)hn, (double)sC[q * nq + n], acc);
           if (SDT == BZ_F32) ((float*)a.state)[off + n] = hn;
           else if (SDT == BZ_F16) ((__half*)a.state)[off + n] = f16_cvt(hn);
           else ((unsigned short*)a.state)[off + n] = (unsigned short)(__float_as_uint(bf16_round(hn)) >> 16);
         }
       }
     }
-    acc = grp_reduce<PARTS, OpAdd>(acc);
+    acc += dpp_get<DPP_XOR1>(acc); acc += dpp_get<DPP_XOR2>(acc);                       // the PARTS lanes of a state row (4 or 16, aligned)
+    if (PARTS == 16) { acc += dpp_get<DPP_HMIRROR>(acc); acc += dpp_get<DPP_MIRROR>(acc); }
     if (p < HD && q == 0) {
-      float yv = round_act(acc + Dh * xv, a.act);
-      if (a.gate) { yv = round_act(yv * round_act(silu_f(vsrc_get(a.zx, a.z_off + hd * HD + p, a.act)), a.act), a.act); vsq += yv * yv; }
+      float yv = round_act(__fadd_rn((float)acc, __fmul_rn(Dh, xv)), a.act);
+      if (a.gate) { yv = round_act(__fmul_rn(yv, round_act(silu_f(vsrc_get(a.zx, a.z_off + hd * HD + p, a.act)), a.act)), a.act); vsq += (double)__fmul_rn(yv, yv); }
       a.y[hd * HD + p] = yv;
     }
   }
   if (a.gate) {
-    vsq = wave_sum(vsq);             // fixed tree: the per-head sum is deterministic
-    if ((tid & 63) == 0) sred[tid >> 6] = vsq;
+    // the head's sum of squares, exact (f32 squares summed in double); handed on as hi + lo floats: vss[2 head], vss[2 head + 1] (the group sum of the consumer
+    // is then the oracle's double sum of the group's squares, rounded once)
+    vsq = wave_sum_d(vsq);
+    if ((tid & 63) == 0) sredd[tid >> 6] = vsq;
     __syncthreads();
     if (tid == 0) {
-      float t = 0.f;
+      double t = 0.0;
 #pragma unroll
-      for (int w = 0; w < PARTS; w += 2) t += sred[w] + sred[w + 1];
-      a.vss[hd] = t;
+      for (int w = 0; w < PARTS; w++) t += sredd[w];
+      const float hi = (float)t;
+      a.vss[2 * hd] = hi; a.vss[2 * hd + 1] = (float)(t - (double)hi);
     }
   }
 }

@@ -1104,7 +1104,7 @@ __global__ void k_q4g_mfma_reduce(const float* __restrict__ part, int KS, size_t
 // Arithmetic and rounding points are those of the decode-step kernels (k_ssm_step with its in-launch conv1d step, the GATED2 prologue).
 // ---------------------------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float pf_silu(float x) { return div_rn(x, 1.0f + bz_expf(-x)); }
-__device__ __forceinline__ float pf_softplus(float x) { return x > 20.0f ? x : log1pf(bz_expf(x)); }
+__device__ __forceinline__ float pf_softplus(float x) { return x > 20.0f ? x : (float)log1p((double)bz_expf(x)); }   // as the step kernel (and the oracle): log1p in double
 
 // out[t][ch] = R(silu(R(conv window + bias))): window = the kc-1 inputs before t (from the rows, or from the carried conv state) and in[t]
 __global__ void k_pf_conv(const float* __restrict__ zx, int ld, int x_off, int conv_dim, int kc, const float* __restrict__ w, const float* __restrict__ b,

@@ -23,7 +23,9 @@
 #include <stdlib.h>
 #include <string.h>
 
-static float softplus_f(float x) { return x > 20.0f ? x : log1pf(orc_expf(x)); }
+/* log1p through double (glibc here, ocml on the GPU: both faithful in double, one rounding to f32 -- the same float unless the double result sits within 1e-16 of a
+   rounding boundary); the f32 log1pf of the two libraries differ in the last bit often enough to matter */
+static float softplus_f(float x) { return x > 20.0f ? x : (float)log1p((double)orc_expf(x)); }
 
 orc_mamba2* orc_mamba2_new(const orc_mamba2_cfg* cfg) {
   orc_mamba2* m = (orc_mamba2*)calloc(1, sizeof(orc_mamba2));
@@ -51,9 +53,12 @@ void orc_mamba2_conv1d_step(const orc_mamba2_cfg* c, const orc_mamba2_layer* L, 
   const float* xraw = zx + DI;
   float* cs = conv_state;
   for (int ch = 0; ch < conv_dim; ch++) {
-    float a = 0.0f;
-    for (int j = 0; j < KC - 1; j++) a += cs[(size_t)ch * (KC - 1) + j] * L->conv_w[(size_t)ch * KC + j];
-    a += xraw[ch] * L->conv_w[(size_t)ch * KC + KC - 1];
+    /* the window's dot product is the exactly rounded one (products exact in double, one rounding to f32), like every other sum of the oracle: an f32 chain would make
+       the result depend on whether an implementation fuses its multiply-adds */
+    double ad = 0.0;
+    for (int j = 0; j < KC - 1; j++) ad += (double)cs[(size_t)ch * (KC - 1) + j] * (double)L->conv_w[(size_t)ch * KC + j];
+    ad += (double)xraw[ch] * (double)L->conv_w[(size_t)ch * KC + KC - 1];
+    float a = (float)ad;
     a = orc_round(a + L->conv_b[ch], act);
     xbc[ch] = orc_round(orc_silu(a), act);
     for (int j = 0; j + 1 < KC - 1; j++) cs[(size_t)ch * (KC - 1) + j] = cs[(size_t)ch * (KC - 1) + j + 1];
@@ -74,12 +79,15 @@ void orc_mamba2_ssm_step(const orc_mamba2_cfg* c, const orc_mamba2_layer* L, con
     for (int p = 0; p < HD; p++) {
       const float xv = x[hd * HD + p];
       float* hs = ssm + ((size_t)hd * HD + p) * NS;
-      float acc = 0.0f;
+      /* state update: both products are exact in double, their sum is rounded once to double, once to f32, once to the state dtype; readout: the exactly rounded
+         dot product C . h (double), then + D x in f32 */
+      const float dtx = dt * xv;
+      double acc = 0.0;
       for (int n = 0; n < NS; n++) {
-        hs[n] = orc_round(hs[n] * dA + (dt * xv) * Bm[g * NS + n], act);
-        acc += hs[n] * Cm[g * NS + n];
+        hs[n] = orc_round((float)((double)hs[n] * (double)dA + (double)dtx * (double)Bm[g * NS + n]), act);
+        acc += (double)hs[n] * (double)Cm[g * NS + n];
       }
-      y[hd * HD + p] = orc_round(acc + L->D[hd] * xv, act);
+      y[hd * HD + p] = orc_round((float)acc + L->D[hd] * xv, act);
     }
   }
   for (int i = 0; i < DI; i++) y[i] = orc_round(y[i] * orc_round(orc_silu(z[i]), act), act);

@@ -121,3 +121,30 @@ def test_dense_16bit_llama_is_the_oracle_bit_for_bit(device, preset, over):
     print("%s: %d of %d logits differ, rel L2 %.2e" % (preset, ndiff, got.size, _rel(got, want)))
     assert ndiff <= got.size // 10000 and _rel(got, want) <= 1e-5      # (a sum within 1e-16 of a rounding boundary may still land on the other side)
     orc_py.lib().orc_kv_free(okv)
+
+
+@pytest.mark.parametrize("preset,over", [("tiny-mamba2", {}), ("tiny-mamba2-g2", {}), ("mamba2-2.7b", dict(n_layers=3, vocab=4096))], ids=["tiny-bf16", "tiny-f32-2groups", "2.7b-widths"])
+def test_mamba2_steps_are_the_oracle_bit_for_bit(device, preset, over):
+    """BASELINE config 3 (Mamba2): with the exact dense GEMVs (in_proj, out_proj, lm_head) and the step kernel's sums defined as the oracle defines them -- conv window and C . h
+    readout exactly rounded (double over exact products), h dA + (dt x) B summed in double, softplus through a double log1p, the gated norm's sum of squares exact (per-head
+    hi + lo partials) -- a 10-token prompt (short prompts stay on the step kernels) and 8 decode steps give the oracle's logits."""
+    model = synth.make_mamba2(preset, **over)
+    cfg = model["config"]
+    lm, om = runtime.LoadedModel.from_synth(device, model), orc_py.OrcMamba2(model)
+    p = [int(t) for t in synth.prompt_tokens(10, cfg["vocab"], seed=61)]
+    st, ost = runtime.LayeredSsmState(lm), om.new_state()
+    got = [lm.forward_with_ssm_state(p, st, all_logits=True).to_numpy().reshape(10, -1)]
+    want = [om.forward(p, ost, all_logits=True).reshape(10, -1)]
+    tok = int(want[0][-1].argmax())
+    for i in range(8):
+        got.append(lm.forward_with_ssm_state([tok], st).to_numpy().reshape(1, -1))
+        want.append(om.forward([tok], ost).reshape(1, -1))
+        tok = int(want[-1][0].argmax())
+    got, want = np.concatenate(got), np.concatenate(want)
+    ndiff = int((got != want).sum())
+    print("%s: %d of %d logits differ, rel L2 %.2e" % (preset, ndiff, got.size, _rel(got, want)))
+    if cfg["act_dtype"] == "f32":      # f32 activations keep the 2^-32 fixed-point grid between launches (range for GGUF-scale values): f32-rounding-level differences
+        assert _rel(got, want) <= 1e-6
+    else:
+        assert ndiff <= got.size // 1000 and _rel(got, want) <= 1e-4
+    orc_py.lib().orc_ssm_state_free(ost)
