@@ -401,6 +401,40 @@ def bench_aux(args, rank, local_rank, world, dist):
                       "tflops": round(pf_flops / (prefill_ms / 1e3) / 1e12, 2), "mfma_peak_tflops": 2500.0,
                       "frac_of_mfma_peak": round(pf_flops / (prefill_ms / 1e3) / 2.5e15, 4), "runs_ms": [round(v, 3) for v in pf_ms],
                       "note": "whole prompt phase (GEMMs on the matrix cores + attention / scan + routing), 2 x active weights x tokens FLOP"}
+    if mamba and rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # CPU baseline + parity gate for the Mamba2 workload: the oracle on the same synthetic weights (a second, host-resident copy of the model: 2 bytes per
+        # weight), the prompt token by token (the step kernels under test from the first position on) and `--cpu-tokens` teacher-forced steps
+        from oracle import orc_py
+        orc_py.set_threads(max(1, min(args.cpu_threads, os.cpu_count() or 1)))
+        model = synth.make_mamba2(cfg)
+        om = orc_py.OrcMamba2(model)
+        lm2 = runtime.LoadedModel.from_synth(dev, model)
+        n_cpu = max(2, min(args.cpu_tokens, 16))
+        ost, st2 = om.new_state(), runtime.LayeredSsmState(lm2)
+        tp0 = time.perf_counter()
+        cpu_rows = [np.asarray(om.forward(prompt, ost)).reshape(-1).copy()]
+        t_prefill = time.perf_counter() - tp0
+        cpu_tokens = [int(cpu_rows[0].argmax())]
+        td0 = time.perf_counter()
+        for i in range(n_cpu - 1):
+            cpu_rows.append(np.asarray(om.forward([cpu_tokens[-1]], ost)).reshape(-1).copy())
+            cpu_tokens.append(int(cpu_rows[-1].argmax()))
+        t_decode = time.perf_counter() - td0
+        orc_py.lib().orc_ssm_state_free(ost)
+        for t in prompt:
+            row = lm2.forward_with_ssm_state([int(t)], st2)
+        gpu_rows = [row.to_numpy().reshape(-1).copy()]
+        for i in range(n_cpu - 1):
+            gpu_rows.append(lm2.forward_with_ssm_state([cpu_tokens[i]], st2).to_numpy().reshape(-1).copy())
+        l2 = [float(np.linalg.norm(g.astype(np.float64) - c) / np.linalg.norm(c)) for g, c in zip(gpu_rows, cpu_rows)]
+        out["cpu_baseline"] = {"value": round((n_cpu - 1) / t_decode, 3), "unit": "tokens/s", "cores": orc_py.lib().orc_num_threads(), "kind": "port",
+                               "sample": "oracle/liborc.so (C + OpenMP), same synthetic weights and prompt: %d-token prompt (%.1f s) + %d greedy decode tokens (%.1f s); host has %d "
+                                         "logical CPUs" % (args.prompt_len, t_prefill, n_cpu - 1, t_decode, os.cpu_count())}
+        out["parity"] = {"greedy_ids_match": bool(all(int(g.argmax()) == t for g, t in zip(gpu_rows, cpu_tokens))), "n_tokens": n_cpu,
+                         "teacher_forced": {"rel_l2_max": round(max(l2), 9), "rel_l2_mean": round(float(np.mean(l2)), 9), "rel_l2_per_step": [round(v, 9) for v in l2],
+                                            "logits_differing": int(sum(int((g != c.astype(np.float32)).sum()) for g, c in zip(gpu_rows, cpu_rows))), "logits_compared": int(sum(g.size for g in gpu_rows))},
+                         "note": "prompt row + teacher-forced decode rows of the step kernels against the CPU oracle (exact sums on both sides: DESIGN 4)"}
+        del lm2
     if rank == 0 and not args.no_latency:
         out["latency"] = latency_matrix(runtime, synth, lm, cfg, max(args.steps, 16))
     if rank == 0:
