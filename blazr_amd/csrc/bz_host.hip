@@ -1879,7 +1879,10 @@ static bool prefill_eligible(const bz_model* m, int S, int total_len, bool decod
     for (const LayerDev& L : m->layers)
       for (const FusedLinear* F : {&L.qkv, &L.o, &L.gateup, &L.down}) {
         if (F->parts.empty()) return false;
-        for (const LinearDev& P : F->parts) if (!bzk_gq_split_ok(P) || P.bias || P.K != F->parts[0].K) return false;
+        unsigned long long ntot = 0;
+        for (const LinearDev& P : F->parts) { if (!bzk_gq_split_ok(P) || P.bias || P.K != F->parts[0].K) return false; ntot += (unsigned long long)P.N; }
+        // the split operands go through ONE 16-bit GEMM over 3 K whose element offsets are 32-bit (bzk_gemm_nt)
+        if (ntot * 3ull * (unsigned long long)F->parts[0].K >= (1ull << 32) || (unsigned long long)std::min(S, 2048) * 3ull * (unsigned long long)F->parts[0].K >= (1ull << 32)) return false;
       }
     return true;
   }
