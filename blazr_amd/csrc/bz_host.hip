@@ -295,6 +295,7 @@ struct bz_model {
   std::recursive_mutex mu;
   std::vector<DsLayerDev> dlayers;
   float* mla_ws = nullptr; int mla_nsplit = 1;   // MLA decode over context slices: partials [n_heads][nsplit][rank + 2]
+  double* mla_wsd = nullptr; unsigned* mla_sync = nullptr;   // exact decode MLA (k_mla_attn_x): double partials [n_heads][nsplit][rank + 1]; per-head {maximum, arrivals} words
   long long* moe_gu_acc = nullptr;   // fixed-point gate / up of the MoE slots (k_gemv_rows2's MoE form); zeroed by the combine launch
   float* moe_xn = nullptr; float* moe_gu = nullptr; float* moe_out = nullptr; long long* moe_acc = nullptr; int* moe_sel = nullptr; float* moe_w = nullptr; float* moe_lg = nullptr; unsigned* moe_cnt = nullptr;
   // DeepSeek-V2 batched-prefill rows (allocated on first use for dpf_rows prompt rows)
@@ -1110,6 +1111,8 @@ static int finalize_dsv2(bz_model* m) {
   BZ_TRY(dev_alloc(m, &p, (size_t)NH * DV * 4)); m->attn_out = (float*)p;
   m->mla_nsplit = bzk_mla_nsplit(NH);
   BZ_TRY(dev_alloc(m, &p, (size_t)NH * m->mla_nsplit * (R + 2) * 4)); m->mla_ws = (float*)p;
+  BZ_TRY(dev_alloc(m, &p, (size_t)NH * m->mla_nsplit * (R + 1) * 8)); m->mla_wsd = (double*)p;
+  BZ_TRY(dev_alloc(m, &p, (size_t)(2 * NH + 2) * 4)); m->mla_sync = (unsigned*)p; BZ_HIP(hipMemset(p, 0, (size_t)(2 * NH + 2) * 4));
   BZ_TRY(dev_alloc(m, &p, (size_t)V * 4)); m->logits = (float*)p;
   if (E > 0) {
     BZ_TRY(dev_alloc(m, &p, (size_t)H * 4)); m->moe_xn = (float*)p;
@@ -1730,7 +1733,7 @@ static int dsv2_step(bz_model* m, const StepIO& io) {
   BZ_TRY(bzk_embed(st, m->embed, m->embed_dt, io.d_tok, H, act, m->hbuf[cur]));
   for (int l = 0; l < c.n_layers; l++) {
     const DsLayerDev& L = m->dlayers[l];
-    Pro pn{}; pn.mode = PRO_NORM; pn.src = prev; pn.h_in = m->hbuf[cur]; pn.h_out = m->hbuf[cur ^ 1]; pn.norm_w = L.attn_norm; pn.eps = c.rms_eps; pn.H = H; pn.act = act; pn.f32_sums = 1;
+    Pro pn{}; pn.mode = PRO_NORM; pn.src = prev; pn.h_in = m->hbuf[cur]; pn.h_out = m->hbuf[cur ^ 1]; pn.norm_w = L.attn_norm; pn.eps = c.rms_eps; pn.H = H; pn.act = act; pn.f32_sums = 0;
     VSrc qkva;
     BZ_TRY(run_fused(m, L.qkva, pn, rs, &qkva));
     cur ^= 1;
@@ -1738,7 +1741,7 @@ static int dsv2_step(bz_model* m, const StepIO& io) {
     if (c.mla_q_lora_rank > 0) {
       // q = q_b_proj(q_a_layernorm(q_a)): a second GEMV whose prologue is the RMSNorm of the first one's leading q_lora_rank outputs (no residual);
       // the latent | k_pe part of the first GEMV's output reaches the attention kernel through `kva`
-      Pro pq{}; pq.mode = PRO_NORM; pq.src = VSrc{nullptr, 0}; pq.h_in = (const float*)qkva.p; pq.h_out = nullptr; pq.norm_w = L.q_norm; pq.eps = c.rms_eps; pq.H = c.mla_q_lora_rank; pq.act = act; pq.f32_sums = 1;
+      Pro pq{}; pq.mode = PRO_NORM; pq.src = VSrc{nullptr, 0}; pq.h_in = (const float*)qkva.p; pq.h_out = nullptr; pq.norm_w = L.q_norm; pq.eps = c.rms_eps; pq.H = c.mla_q_lora_rank; pq.act = act; pq.f32_sums = 0;
       VSrc qv;
       BZ_TRY(run_fused(m, L.q_b, pq, rs, &qv));
       ma.kva = (const float*)qkva.p + c.mla_q_lora_rank;
@@ -1748,16 +1751,19 @@ static int dsv2_step(bz_model* m, const StepIO& io) {
     ma.n_heads = NH; ma.rank = R; ma.nope = DN; ma.rope = DR; ma.vdim = DV; ma.act = act; ma.kv = io.kv; ma.layer = l; ma.out = m->attn_out;
     ma.scale = mla_softmax_scale(c);
     ma.ws = m->mla_ws; ma.nsplit = m->mla_nsplit;
-    BZ_TRY(bzk_mla_attn(st, ma, c.max_seq_len));
-    Pro pp{}; pp.mode = PRO_PLAIN; pp.src = VSrc{m->attn_out, 0}; pp.act = act; pp.H = 0; pp.f32_sums = 1;
+    // exact decode (16-bit models): every sum as the oracle defines it, one maximum over the whole context (BZ_DSV2_F32_SUMS=1: the f32 kernels)
+    static const bool f32_mla = getenv("BZ_DSV2_F32_SUMS") != nullptr;
+    if (!f32_mla && (act == BZ_F16 || act == BZ_BF16) && bzk_mla_x_ok(ma, c.max_seq_len)) BZ_TRY(bzk_mla_attn_x(st, ma, c.max_seq_len, m->mla_wsd, m->mla_sync, (unsigned*)m->dev->persist_err));
+    else BZ_TRY(bzk_mla_attn(st, ma, c.max_seq_len));
+    Pro pp{}; pp.mode = PRO_PLAIN; pp.src = VSrc{m->attn_out, 0}; pp.act = act; pp.H = 0; pp.f32_sums = 0;
     VSrc ov;
     BZ_TRY(run_fused(m, L.o, pp, rs, &ov));
-    Pro pf{}; pf.mode = PRO_NORM; pf.src = ov; pf.h_in = m->hbuf[cur]; pf.h_out = m->hbuf[cur ^ 1]; pf.norm_w = L.ffn_norm; pf.eps = c.rms_eps; pf.H = H; pf.act = act; pf.f32_sums = 1;
+    Pro pf{}; pf.mode = PRO_NORM; pf.src = ov; pf.h_in = m->hbuf[cur]; pf.h_out = m->hbuf[cur ^ 1]; pf.norm_w = L.ffn_norm; pf.eps = c.rms_eps; pf.H = H; pf.act = act; pf.f32_sums = 0;
     if (!L.is_moe) {
       VSrc gu, dn;
       BZ_TRY(run_fused(m, L.gateup, pf, rs, &gu));
       cur ^= 1;
-      Pro ps{}; ps.mode = PRO_SILU; ps.src = gu; ps.H = c.inter; ps.act = act; ps.f32_sums = 1;
+      Pro ps{}; ps.mode = PRO_SILU; ps.src = gu; ps.H = c.inter; ps.act = act; ps.f32_sums = 0;
       BZ_TRY(run_fused(m, L.down, ps, rs, &dn));
       prev = dn;
     } else {
@@ -2086,6 +2092,11 @@ static int prefill_dense(bz_model* m, const long long* d_tok, int S, const KvVie
 static bool dsv2_prefill_eligible(const bz_model* m, int S, int total_len, const KvView& view) {
   const bz_model_config& c = m->cfg;
   if (c.arch != BZ_ARCH_DEEPSEEK2 || S < prefill_min_rows() || (c.act_dtype != BZ_F16 && c.act_dtype != BZ_BF16) || c.mla_q_lora_rank > 0) return false;
+  {   // short prompts stay on the decode kernels (exact sums), as for the other families (prefill_eligible)
+    static const int env = getenv("BZ_EXACT_PREFILL") ? atoi(getenv("BZ_EXACT_PREFILL")) : -1;
+    static const int max_rows = getenv("BZ_EXACT_PREFILL_MAX") ? atoi(getenv("BZ_EXACT_PREFILL_MAX")) : 16;
+    if (env != 0 && (env > 0 || S <= max_rows)) return false;
+  }
   if (c.hidden % 64 || (c.n_heads * c.mla_v_dim) % 64 || (c.moe_n_experts > 0 && c.moe_inter % 64) || view.dtype != c.act_dtype) return false;
   for (const DsLayerDev& L : m->dlayers) {
     for (const FusedLinear* F : {&L.qkva, &L.o}) if (F->parts.size() != 1 || F->parts[0].kind != LK_ROWS || F->parts[0].wdt != c.act_dtype) return false;

@@ -1849,6 +1849,23 @@ __device__ __forceinline__ double piece_dot_d(const RowPiece<WDT>& p, const doub
   for (int e = 0; e < 8; e++) acc = fma((double)w[e], x[e], acc);
   return acc;
 }
+// 16-bit weights times 16-bit-valued activations: the f32 product is already exact (8 + 8 or 11 + 11 significant bits), so the double only has to carry the SUM --
+// one f32 multiply, one convert, one double add per element, and no double copy of x in registers (the 832-thread routing form of k_gemv_rows2 has 128 registers)
+template <int WDT>
+__device__ __forceinline__ double piece_dot_x(const RowPiece<WDT>& p, const float4& xa, const float4& xb, double acc) {
+  static_assert(WDT == BZ_F16 || WDT == BZ_BF16, "exact f32 products need 16-bit operands");
+  const unsigned u[4] = {p.a.x, p.a.y, p.a.z, p.a.w};
+  const float x[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    float w0, w1;
+    if constexpr (WDT == BZ_F16) { w0 = __half2float(__ushort_as_half((unsigned short)(u[i] & 0xffffu))); w1 = __half2float(__ushort_as_half((unsigned short)(u[i] >> 16))); }
+    else { w0 = __uint_as_float(u[i] << 16); w1 = __uint_as_float(u[i] & 0xffff0000u); }
+    acc += (double)__fmul_rn(w0, x[2 * i]);
+    acc += (double)__fmul_rn(w1, x[2 * i + 1]);
+  }
+  return acc;
+}
 __device__ __forceinline__ void x8_to_d(const float4& xa, const float4& xb, double (&x)[8]) {
   x[0] = (double)xa.x; x[1] = (double)xa.y; x[2] = (double)xa.z; x[3] = (double)xa.w; x[4] = (double)xb.x; x[5] = (double)xb.y; x[6] = (double)xb.z; x[7] = (double)xb.w;
 }
@@ -1910,10 +1927,16 @@ __device__ __forceinline__ void rows_body(const void* __restrict__ W, const floa
   auto consume = [&](const Stage& S) {
     if (cst >= nsteps) return;
     cst++;
-    double xd[8];
-    x8_to_d(xs4[ckc * 128 + lane], xs4[ckc * 128 + 64 + lane], xd);
+    const float4 xa = xs4[ckc * 128 + lane], xb = xs4[ckc * 128 + 64 + lane];
+    if constexpr (WDT == BZ_F32) {       // f32 weights: the products need the double too
+      double xd[8];
+      x8_to_d(xa, xb, xd);
 #pragma unroll
-    for (int rr = 0; rr < 4; rr++) acc[rr] = piece_dot_d<WDT>(S.p[rr], xd, acc[rr]);
+      for (int rr = 0; rr < 4; rr++) acc[rr] = piece_dot_d<WDT>(S.p[rr], xd, acc[rr]);
+    } else {
+#pragma unroll
+      for (int rr = 0; rr < 4; rr++) acc[rr] = piece_dot_x<WDT>(S.p[rr], xa, xb, acc[rr]);
+    }
     if (++ckc == KC) {
       ckc = 0;
 #pragma unroll
@@ -2227,8 +2250,7 @@ __global__ __launch_bounds__(ROUTE ? 832 : 768) void k_gemv_rows2(const void* __
     const float* xr = xs + r * 1024;
     const float4 xa0 = *(const float4*)(xr + lane * 8), xa1 = *(const float4*)(xr + lane * 8 + 4);
     const float4 xb0 = *(const float4*)(xr + 512 + lane * 8), xb1 = *(const float4*)(xr + 512 + lane * 8 + 4);
-    double xdA[EX ? 8 : 1], xdB[EX ? 8 : 1];
-    if constexpr (EX) { x8_to_d(xa0, xa1, xdA); x8_to_d(xb0, xb1, xdB); }
+
     long long* apA = acc + (size_t)min(sbase[r] + slA[r], slots.acc_slots - 1) * (size_t)slots.acc_stride;
     long long* apB = acc + (size_t)min(sbase[r] + slB[r], slots.acc_slots - 1) * (size_t)slots.acc_stride;
     for (int uc = ua; uc < ue; uc += 4) {
@@ -2239,9 +2261,10 @@ __global__ __launch_bounds__(ROUTE ? 832 : 768) void k_gemv_rows2(const void* __
           const bool second = u >= ubr;
           const int row = 4 * (u - (second ? ubr : ubr - NRG)) + jrow;
           if constexpr (EX) {
-            double d0, d1, d2, d3;       // exact sums (piece_dot_d): the unit's partial is the same number whatever the lane / wave decomposition
-            if (second) { d0 = piece_dot_d<WDT>(st[q].p[0], xdB, 0.0); d1 = piece_dot_d<WDT>(st[q].p[1], xdB, 0.0); d2 = piece_dot_d<WDT>(st[q].p[2], xdB, 0.0); d3 = piece_dot_d<WDT>(st[q].p[3], xdB, 0.0); }
-            else { d0 = piece_dot_d<WDT>(st[q].p[0], xdA, 0.0); d1 = piece_dot_d<WDT>(st[q].p[1], xdA, 0.0); d2 = piece_dot_d<WDT>(st[q].p[2], xdA, 0.0); d3 = piece_dot_d<WDT>(st[q].p[3], xdA, 0.0); }
+            const float4 xa = second ? xb0 : xa0, xb = second ? xb1 : xa1;
+            // exact sums (piece_dot_x): the unit's partial is the same number whatever the lane / wave decomposition
+            const double d0 = piece_dot_x<WDT>(st[q].p[0], xa, xb, 0.0), d1 = piece_dot_x<WDT>(st[q].p[1], xa, xb, 0.0);
+            const double d2 = piece_dot_x<WDT>(st[q].p[2], xa, xb, 0.0), d3 = piece_dot_x<WDT>(st[q].p[3], xa, xb, 0.0);
             if (u + 4 < ue) issue(st[q], u + 4);
             double v = wave_sum4_d(d0, d1, d2, d3);
             if ((lane & 15) == 0 && row < N) {
@@ -2378,10 +2401,9 @@ __global__ __launch_bounds__(768) void k_mlp_dense(const void* __restrict__ Wgu,
 #pragma unroll
     for (int q = 0; q < 2; q++) {
       if (kc + q < KC) {
-        double xd[8];
-        x8_to_d(*(const float4*)(xs + (kc + q) * 512 + lane * 8), *(const float4*)(xs + (kc + q) * 512 + lane * 8 + 4), xd);
+        const float4 xa = *(const float4*)(xs + (kc + q) * 512 + lane * 8), xb = *(const float4*)(xs + (kc + q) * 512 + lane * 8 + 4);
 #pragma unroll
-        for (int r = 0; r < 4; r++) { ag[r] = piece_dot_d<WDT>(st[q].g[r], xd, ag[r]); au[r] = piece_dot_d<WDT>(st[q].u[r], xd, au[r]); }
+        for (int r = 0; r < 4; r++) { ag[r] = piece_dot_x<WDT>(st[q].g[r], xa, xb, ag[r]); au[r] = piece_dot_x<WDT>(st[q].u[r], xa, xb, au[r]); }
         if (kc + q + 2 < KC) issue(st[q], kc + q + 2);
       }
     }
@@ -2405,13 +2427,12 @@ __global__ __launch_bounds__(768) void k_mlp_dense(const void* __restrict__ Wgu,
   __builtin_amdgcn_s_waitcnt(0xc07f);
   if (lane == 0) atomicAdd(&cnt[2], 1u);
   lds_wait_count(&cnt[2], 8);
-  double ad[8];
-  x8_to_d(*(const float4*)(actl + ksub), *(const float4*)(actl + ksub + 4), ad);
+  const float4 aa = *(const float4*)(actl + ksub), ab = *(const float4*)(actl + ksub + 4);
 #pragma unroll
   for (int t = 0; t < 16; t++) {
     if (t < NLD) {
       RowPiece<WDT> pc; pc.a = D[t];
-      double d = piece_dot_d<WDT>(pc, ad, 0.0);
+      double d = piece_dot_x<WDT>(pc, aa, ab, 0.0);
       d += dpp_get<DPP_XOR1>(d); d += dpp_get<DPP_XOR2>(d);      // the row's four lanes
       const int n = n0 + t * 16;
       if ((lane & 3) == 0) {
@@ -3457,15 +3478,15 @@ __global__ __launch_bounds__(NW * 64) void k_attn2(AttnArgs a, const uint4* __re
   if (FUSE == 2) {
     // dense o_proj: this lane's 8 weights of each output row against its 8 head outputs, reduced over the row's NPC lanes, one fixed-point atomic per (head, row)
     __syncthreads();
-    double od[8];
-    x8_to_d(*(const float4*)(outh + piece * 8), *(const float4*)(outh + piece * 8 + 4), od);
+    const float4 oa = *(const float4*)(outh + piece * 8), ob = *(const float4*)(outh + piece * 8 + 4);
+    const float of8[8] = {oa.x, oa.y, oa.z, oa.w, ob.x, ob.y, ob.z, ob.w};
 #pragma unroll
     for (int t = 0; t < DLD; t++) {
       float w8[8];
       unpack2<KVDT>(Wd[t].x, w8[0], w8[1]); unpack2<KVDT>(Wd[t].y, w8[2], w8[3]); unpack2<KVDT>(Wd[t].z, w8[4], w8[5]); unpack2<KVDT>(Wd[t].w, w8[6], w8[7]);
-      double d = 0.0;                 // exact sums, as the other dense GEMVs (piece_dot_d)
+      double d = 0.0;                 // exact sums, as the other dense GEMVs (piece_dot_x: 16-bit x 16-bit products are exact in f32)
 #pragma unroll
-      for (int e = 0; e < 8; e++) d = fma((double)w8[e], od[e], d);
+      for (int e = 0; e < 8; e++) d += (double)__fmul_rn(w8[e], of8[e]);
       d = grp_sum_d<NPC>(d);
       const int n = nd0 + t * RPL + rsub;
       if (piece == 0) {
@@ -4865,6 +4886,281 @@ __global__ __launch_bounds__(256) void k_mla_merge(MlaArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// EXACT decode MLA (round 3): k_mla_attn<SPLIT> / k_mla_merge with every sum as the oracle defines it (orc_dsv2.c: exactly rounded -- double over exact products, one
+// rounding to f32) and ONE maximum over the whole context: the context slices of a head exchange their local maxima through a device word and wait for each other
+// (all n_heads x nsplit workgroups are resident: one per CU), so that p_t = exp(s_t - M) is the oracle's weight and the slices' partial sums simply add up in double
+// -- the f32 form rescales slice partials by exp(m_slice - M), which is not the same number.  rank <= 512, 16 waves, 16-bit cache / kv_b.
+//   ws (double): [n_heads][nsplit][rank + 1] = partial latent sums | partial weight sum        sync (unsigned): [n_heads][2] = ordered-int maximum | arrivals (k_mla_merge_x resets both)
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned f2ord(float f) { const unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }     // order-preserving map
+__device__ __forceinline__ float ord2f(unsigned o) { return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o); }
+template <int NW> __device__ __forceinline__ double block_sum_nw_d(double v, double* redd) {   // deterministic; redd: LDS double[NW]
+  v = wave_sum_d(v);
+  if ((threadIdx.x & 63) == 0) redd[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double t = 0.0;
+#pragma unroll
+  for (int w = 0; w < NW; w++) t += redd[w];
+  __syncthreads();
+  return t;
+}
+template <int DT>
+__global__ __launch_bounds__(1024) void k_mla_attn_x(MlaArgs a, double* __restrict__ wsd, unsigned* __restrict__ sync, unsigned* __restrict__ err) {
+  constexpr int NW = 16, NTH = 1024, RIF = 8, TIF = 4;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int R = a.rank, DN = a.nope, DR = a.rope;
+  float* ccur = lds; float* kcur = ccur + R; float* qn = kcur + DR; float* qp = qn + DN; float* qabs = qp + DR;
+  double* partd = (double*)(qabs + R + ((2 * R + 2 * DR + DN) & 1));      // [NW][R], 8-byte aligned
+  double* redd = partd + NW * R;                                            // [NW]
+  float* red = (float*)(redd + NW); float* sc = red + 16;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hd = blockIdx.x;
+  const int pos = a.pos[0], nc = pos;               // cached positions 0 .. pos - 1; the current token comes from LDS
+  const int ts = (nc + a.nsplit - 1) / a.nsplit;
+  const int tlo = min((int)blockIdx.y * ts, nc), thi = min(tlo + ts, nc);
+  const bool own_cur = (int)blockIdx.y == a.nsplit - 1;
+  const int nloc = thi - tlo + (own_cur ? 1 : 0);
+  const int QH = DN + DR, qoff = hd * QH, coff = a.n_heads * QH;
+  auto qsrc = [&](int i) -> float { return vsrc_get(a.qkv, i, a.act); };
+  auto csrc = [&](int i) -> float { return a.kva ? a.kva[i] : vsrc_get(a.qkv, coff + i, a.act); };
+  const size_t rowbase = (size_t)a.layer * a.kv.layer_stride;
+  const int Wd = R + DR;
+  auto rowoff = [&](int p) -> size_t {
+    if (a.kv.paged) return rowbase + ((size_t)a.kv.block_table[p / a.kv.bs] * a.kv.bs + (p % a.kv.bs)) * Wd;
+    return rowbase + (size_t)p * Wd;
+  };
+  const size_t wrow0 = (size_t)hd * (DN + a.vdim);
+  const int col = lane * 8;
+  const bool con = col < R;
+  const int colc = con ? col : 0;
+  // ---- qabs partials first (weights only depend on the head): wave w takes nope rows [w DN/16, (w+1) DN/16) ----
+  const int d0 = wave * (DN / NW), d1 = d0 + DN / NW;
+  float w0[RIF][8];
+#pragma unroll
+  for (int u = 0; u < RIF; u++) ld8t<DT>(a.wkvb, (wrow0 + (size_t)min(d0 + u, d1 - 1)) * R + colc, w0[u]);
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- current token: latent norm (exact sum of squares), k_pe / q_pe rope, q_nope ----
+  const float* cr = a.cos_t + (size_t)pos * (DR / 2); const float* sr = a.sin_t + (size_t)pos * (DR / 2);
+  {
+    double ssd = 0.0;
+    for (int r = tid; r < R; r += NTH) { const float v = csrc(r); ccur[r] = v; ssd += (double)__fmul_rn(v, v); }
+    ssd = block_sum_nw_d<NW>(ssd, redd);
+    const float rs = rms_scale((float)ssd, (float)R, a.eps);
+    for (int r = tid; r < R; r += NTH) ccur[r] = round_act(__fmul_rn(a.kv_norm[r], round_act(__fmul_rn(ccur[r], rs), a.act)), a.act);
+  }
+  for (int j = tid; j < DR / 2; j += NTH) {
+    const float c = cr[j], s = sr[j];
+    const float k0 = csrc(R + 2 * j), k1 = csrc(R + 2 * j + 1);
+    kcur[2 * j] = round_act(rope_lo(k0, k1, c, s), a.act); kcur[2 * j + 1] = round_act(rope_hi(k0, k1, c, s), a.act);
+    const float x0 = qsrc(qoff + DN + 2 * j), x1 = qsrc(qoff + DN + 2 * j + 1);
+    qp[2 * j] = round_act(rope_lo(x0, x1, c, s), a.act); qp[2 * j + 1] = round_act(rope_hi(x0, x1, c, s), a.act);
+  }
+  for (int d = tid; d < DN; d += NTH) qn[d] = qsrc(qoff + d);
+  __syncthreads();
+  if (hd == 0 && blockIdx.y == 0) {
+    size_t wo;
+    if (a.kv.paged) { const int slot = a.kv.slot ? a.kv.slot[0] : (a.kv.block_table[pos / a.kv.bs] * a.kv.bs + pos % a.kv.bs); wo = rowbase + (size_t)slot * Wd; }
+    else wo = rowbase + (size_t)pos * Wd;
+    for (int i = tid; i < Wd; i += NTH) kv_st(a.kv.k, wo + i, a.kv.dtype, i < R ? ccur[i] : kcur[i - R]);
+  }
+  {
+    double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};      // 16-bit q x 16-bit weight: the f32 product is exact, the double carries the sum
+    for (int d = d0; d < d1; d += RIF) {
+      if (d > d0) {
+#pragma unroll
+        for (int u = 0; u < RIF; u++) ld8t<DT>(a.wkvb, (wrow0 + (size_t)min(d + u, d1 - 1)) * R + colc, w0[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < RIF; u++) {
+        const float qd = (d + u < d1) ? qn[d + u] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; e++) acc[e] += (double)__fmul_rn(qd, w0[u][e]);
+      }
+    }
+    if (con)
+#pragma unroll
+      for (int e = 0; e < 8; e++) partd[wave * R + colc + e] = acc[e];
+  }
+  __syncthreads();
+  for (int r = tid; r < R; r += NTH) {
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) t += partd[w * R + r];
+    qabs[r] = round_act((float)t, a.act);
+  }
+  __syncthreads();
+  // ---- scores: wave w takes cached tokens tlo + w, + 16, ...; exact sums (f32 products of 16-bit values are exact) ----
+  float qa[8];
+  const float qpl = (lane < DR) ? qp[lane] : 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; e++) qa[e] = con ? qabs[colc + e] : 0.f;
+  for (int t0 = tlo + wave; t0 < thi; t0 += NW * TIF) {
+    float cv[TIF][8], kp[TIF];
+#pragma unroll
+    for (int u = 0; u < TIF; u++) {
+      const size_t ro = rowoff(min(t0 + NW * u, thi - 1));
+      ld8t<DT>(a.kv.k, ro + colc, cv[u]);
+      kp[u] = ld1t<DT>(a.kv.k, ro + R + min(lane, DR - 1));
+    }
+#pragma unroll
+    for (int u = 0; u < TIF; u++) {
+      double dsum = (lane < DR) ? (double)__fmul_rn(qpl, kp[u]) : 0.0;
+#pragma unroll
+      for (int e = 0; e < 8; e++) dsum += (double)__fmul_rn(qa[e], cv[u][e]);
+      dsum = wave_sum_d(dsum);
+      if (lane == 0 && t0 + NW * u < thi) sc[t0 + NW * u - tlo] = __fmul_rn((float)dsum, a.scale);
+    }
+  }
+  if (own_cur && wave == 0) {
+    double dsum = (lane < DR) ? (double)__fmul_rn(qpl, kcur[lane]) : 0.0;
+    if (con)
+#pragma unroll
+      for (int e = 0; e < 8; e++) dsum += (double)__fmul_rn(qa[e], ccur[colc + e]);
+    dsum = wave_sum_d(dsum);
+    if (lane == 0) sc[thi - tlo] = __fmul_rn((float)dsum, a.scale);
+  }
+  __syncthreads();
+  // ---- the maximum over the WHOLE context: local maximum -> device word of the head -> wait for the other slices ----
+  float mx = -INFINITY;
+  for (int t = tid; t < nloc; t += NTH) mx = fmaxf(mx, sc[t]);
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  if (tid == 0) {
+    float m2 = red[0];
+#pragma unroll
+    for (int w = 1; w < NW; w++) m2 = fmaxf(m2, red[w]);
+    unsigned* sw = sync + 2 * hd;
+    if (nloc > 0) __hip_atomic_fetch_max(sw, f2ord(m2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(sw + 1, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);       // release: the maximum above is visible to whoever sees this arrival
+    const long long t_start = (long long)__builtin_amdgcn_s_memrealtime();
+    bool ok = true;
+    while (__hip_atomic_load(sw + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)a.nsplit) {
+      __builtin_amdgcn_s_sleep(1);
+      if ((long long)__builtin_amdgcn_s_memrealtime() - t_start > 2000000) { ok = false; break; }      // 20 ms at 100 MHz: a slice is missing -> flag, do not hang
+    }
+    if (!ok) atomicExch(err, 1u);
+    red[0] = ord2f(__hip_atomic_load(sw, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT));
+  }
+  __syncthreads();
+  const float M = red[0];
+  __syncthreads();
+  double psum = 0.0;
+  for (int t = tid; t < nloc; t += NTH) { const float pe = bz_expf(sc[t] - M); sc[t] = pe; psum += (double)pe; }
+  psum = block_sum_nw_d<NW>(psum, redd);
+  // ---- partial latent sum: sum_t p_t c_t in double (an f32 weight times a 16-bit value is exact in double) ----
+  {
+    double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int t0 = tlo + wave; t0 < thi; t0 += NW * TIF) {
+      float cv[TIF][8];
+#pragma unroll
+      for (int u = 0; u < TIF; u++) ld8t<DT>(a.kv.k, rowoff(min(t0 + NW * u, thi - 1)) + colc, cv[u]);
+#pragma unroll
+      for (int u = 0; u < TIF; u++) {
+        const double pw = (t0 + NW * u < thi) ? (double)sc[t0 + NW * u - tlo] : 0.0;
+#pragma unroll
+        for (int e = 0; e < 8; e++) acc[e] = fma(pw, (double)cv[u][e], acc[e]);
+      }
+    }
+    if (own_cur && wave == 0) {
+      const double pw = (double)sc[thi - tlo];
+      if (con)
+#pragma unroll
+        for (int e = 0; e < 8; e++) acc[e] = fma(pw, (double)ccur[colc + e], acc[e]);
+    }
+    if (con)
+#pragma unroll
+      for (int e = 0; e < 8; e++) partd[wave * R + colc + e] = acc[e];
+  }
+  __syncthreads();
+  double* wsp = wsd + ((size_t)hd * a.nsplit + blockIdx.y) * (R + 1);
+  for (int r = tid; r < R; r += NTH) {
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) t += partd[w * R + r];
+    wsp[r] = t;
+  }
+  if (tid == 0) wsp[R] = psum;
+}
+// merge of the exact partials + Wuv: grid = (n_heads, 4); olat_h = R(f32(sum_s part_s) / f32(sum_s l_s)), out_h = R(f32(Wuv_h . olat_h)); workgroup (h, 0) resets the head's sync words
+template <int DT>
+__global__ __launch_bounds__(256) void k_mla_merge_x(MlaArgs a, const double* __restrict__ wsd, unsigned* __restrict__ sync) {
+  __shared__ float olat[512];
+  __shared__ double lsh;
+  const int R = a.rank, DN = a.nope, DV = a.vdim, NSP = a.nsplit;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hd = blockIdx.x;
+  const int rows = DV / 4, v0 = blockIdx.y * rows + wave * (rows / 4), v1 = v0 + rows / 4;
+  const size_t wrow0 = (size_t)hd * (DN + DV);
+  const int col = lane * 8;
+  const bool con = col < R;
+  const int colc = con ? col : 0;
+  constexpr int RIF = 8;
+  float w0[RIF][8];
+#pragma unroll
+  for (int u = 0; u < RIF; u++) ld8t<DT>(a.wkvb, (wrow0 + DN + (size_t)min(v0 + u, v1 - 1)) * R + colc, w0[u]);
+  __builtin_amdgcn_sched_barrier(0);
+  const double* wsp = wsd + (size_t)hd * NSP * (R + 1);
+  if (wave == 0) {                                          // lane s holds slice s (NSP <= 62)
+    const double l = wave_sum_d(lane < NSP ? wsp[(size_t)min(lane, NSP - 1) * (R + 1) + R] : 0.0);
+    if (lane == 0) lsh = l;
+  }
+  __syncthreads();
+  const float inv = div_rn(1.0f, (float)lsh);              // the oracle: inv = 1 / f32(sum p), olat = R(f32(sum p c) * inv)
+  for (int r = tid; r < R; r += 256) {
+    double t = 0.0;
+    for (int s0 = 0; s0 < NSP; s0 += 8) {                   // eight slices' loads in flight (clamped index, nothing added beyond the last slice)
+      double pv[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) pv[j] = wsp[(size_t)min(s0 + j, NSP - 1) * (R + 1) + r];
+#pragma unroll
+      for (int j = 0; j < 8; j++) t += (s0 + j < NSP) ? pv[j] : 0.0;
+    }
+    olat[r] = round_act(__fmul_rn((float)t, inv), a.act);
+  }
+  if (blockIdx.y == 0 && tid == 0) { sync[2 * hd] = 0u; sync[2 * hd + 1] = 0u; }     // (0 = below every ordered float: the next step's atomicMax starts from it)
+  __syncthreads();
+  float qa[8];
+#pragma unroll
+  for (int e = 0; e < 8; e++) qa[e] = con ? olat[colc + e] : 0.f;
+  for (int d = v0; d < v1; d += RIF) {
+    if (d > v0) {
+#pragma unroll
+      for (int u = 0; u < RIF; u++) ld8t<DT>(a.wkvb, (wrow0 + DN + (size_t)min(d + u, v1 - 1)) * R + colc, w0[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < RIF; u++) {
+      double sacc = 0.0;
+#pragma unroll
+      for (int e = 0; e < 8; e++) sacc += (double)__fmul_rn(w0[u][e], qa[e]);
+      sacc = wave_sum_d(sacc);
+      if (lane == 0 && d + u < v1) a.out[hd * DV + d + u] = round_act((float)sacc, a.act);
+    }
+  }
+}
+size_t bzk_mla_x_smem(const MlaArgs& a, int max_len) {
+  const int nsc = (max_len + a.nsplit - 1) / a.nsplit + 1;
+  return (size_t)(2 * a.rank + 2 * a.rope + a.nope + 2 + 16 + nsc) * 4 + (size_t)(16 * a.rank + 16) * 8 + 64;
+}
+bool bzk_mla_x_ok(const MlaArgs& a, int max_len) {
+  return a.batch == 0 && a.rank <= 512 && a.rank % 8 == 0 && a.nsplit > 1 && a.nsplit <= 62 && a.nope % 16 == 0 && a.vdim % 16 == 0 &&
+         (a.wdt == BZ_F16 || a.wdt == BZ_BF16) && a.wdt == a.kv.dtype && bzk_mla_x_smem(a, max_len) <= 160 * 1024;
+}
+// exact decode MLA: wsd = n_heads * nsplit * (rank + 1) doubles, sync = 2 * n_heads zeroed words (+ err word)
+int bzk_mla_attn_x(hipStream_t s, const MlaArgs& a, int max_len, double* wsd, unsigned* sync, unsigned* err) {
+  if (!bzk_mla_x_ok(a, max_len)) BZ_FAIL(BZ_E_UNSUPPORTED, "mla_attn_x: shape not supported by the exact decode kernel");
+  const size_t smem = bzk_mla_x_smem(a, max_len);
+  const double bytes = (double)a.n_heads * (a.nope + a.vdim) * a.rank * bz_dtype_size(a.wdt);
+#define LAUNCH_MX(DT) do { \
+    static bool attr_done = false; \
+    if (!attr_done) { BZ_HIP(hipFuncSetAttribute((const void*)k_mla_attn_x<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_done = true; } \
+    BZ_LAUNCH("mla_attn<split,exact>", bytes, (k_mla_attn_x<DT>), dim3(a.n_heads, a.nsplit), dim3(1024), smem, s, a, wsd, sync, err); \
+    BZ_LAUNCH("mla_merge<exact>", bytes * a.vdim / (a.nope + a.vdim), (k_mla_merge_x<DT>), dim3(a.n_heads, 4), dim3(256), 0, s, a, (const double*)wsd, sync); } while (0)
+  if (a.wdt == BZ_F16) LAUNCH_MX(BZ_F16); else LAUNCH_MX(BZ_BF16);
+#undef LAUNCH_MX
+  BZ_HIP(hipGetLastError());
+  return BZ_OK;
+}
+
 // Prompt rows, token-tiled (round 3).  The (head, token) workgroups of k_mla_attn<BATCH> each re-read the head's Wuk / Wuv (128 KB each at V2-Lite widths) and every
 // latent row of their context: 4.4 GB of L2 traffic per layer at 512 tokens -- 563 us, L2-bandwidth-bound.  Here a workgroup takes TT consecutive tokens of one head:
 // a weight row / a latent row is loaded ONCE and used for all TT tokens (TT x fewer bytes), and every token's sums run in exactly the order k_mla_attn<BATCH> uses
@@ -5104,7 +5400,9 @@ static bool mla_split_on(const MlaArgs& a) {
 int bzk_mla_nsplit(int n_heads) {
   static const int env = getenv("BZ_MLA_NSPLIT") ? atoi(getenv("BZ_MLA_NSPLIT")) : 0;     // tuning override (1..62)
   if (env > 0) return std::min(env, 62);
-  return std::max(1, std::min(32, 256 / std::max(n_heads, 1)));
+  // 8 context slices per head: with the exact decode kernel (k_mla_attn_x: the slices wait for each other's maxima) 8 measured 377 tok/s against 365 with 16 on V2-Lite at
+  // context ~580; the f32 kernels, which do not wait, preferred 16 (450 vs 439)
+  return std::max(1, std::min(8, 256 / std::max(n_heads, 1)));
 }
 
 static int mla_waves(const MlaArgs& a) {
@@ -5301,7 +5599,7 @@ int bzk_moe_gemv(hipStream_t s, const MoeGemvArgs& g, int wdt, int n_slots, cons
     const MoeSlots ms{g.sel, g.expert_stride, n_slots, g.src_stride, g.acc_stride, g.acc_slots};
     if (pro.mode == PRO_NORM && (g.route.E > 1024 || g.route.top_k + g.route.n_shared > 128 || pro.H != g.K || g.src_stride != 0)) BZ_FAIL(BZ_E_UNSUPPORTED, "moe gate/up with in-launch routing: E %d unsupported", g.route.E);
     const char* lbl = pro.mode == PRO_SILU ? "moe_rows2<down>" : (pro.mode == PRO_NORM ? "moe_rows2<route+gate_up>" : "moe_rows2<gate_up>");
-#define LAUNCH_MR2(DT, MODE, FIX, RT) BZ_LAUNCH(lbl, bytes, (k_gemv_rows2<DT, MODE, FIX, RT>), dim3(nb), dim3(RT ? 832 : 768), 0, s, g.w, (const float*)nullptr, g.N, g.K, pro, g.acc, \
+#define LAUNCH_MR2(DT, MODE, FIX, RT) BZ_LAUNCH(lbl, bytes, (k_gemv_rows2<DT, MODE, FIX, RT, true>), dim3(nb), dim3(RT ? 832 : 768), 0, s, g.w, (const float*)nullptr, g.N, g.K, pro, g.acc, \
     (long long*)nullptr, 0, ConvShift{}, ms, g.route)
 #define LAUNCH_MR2_F(DT, MODE, RT) do { if (pro.src.fix) LAUNCH_MR2(DT, MODE, true, RT); else LAUNCH_MR2(DT, MODE, false, RT); } while (0)
 #define LAUNCH_MR2_M(DT) do { if (pro.mode == PRO_SILU) LAUNCH_MR2_F(DT, PRO_SILU, 0); else if (pro.mode == PRO_NORM) LAUNCH_MR2_F(DT, PRO_NORM, 1); else LAUNCH_MR2_F(DT, PRO_PLAIN, 0); } while (0)
@@ -5332,7 +5630,7 @@ __global__ void k_moe_combine(long long* acc, const float* wsel, int top_k, int 
   if (i >= H) return;
   float r = 0.f;
   for (int k = 0; k < top_k; k++) {
-    r += wsel[k] * round_act(fix2f(acc[(size_t)k * H + i], act), act);
+    r = __fadd_rn(r, __fmul_rn(wsel[k], round_act(fix2f(acc[(size_t)k * H + i], act), act)));     // the oracle's f32 chain: product rounded, then added (no contraction)
     acc[(size_t)k * H + i] = 0;
   }
   r = round_act(r, act);
@@ -5408,9 +5706,10 @@ __global__ __launch_bounds__(256) void k_moe_route_rows(const unsigned short* __
         if (k0 + j * 512 < H) {
           const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
           const float4 xa = k < H ? *(const float4*)(xs + k) : z4, xb = k < H ? *(const float4*)(xs + k + 4) : z4;
-          double xd[8];
-          x8_to_d(xa, xb, xd);
-          accf += d2fix(wave_sum_d(piece_dot_d<WDT>(w[j], xd, 0.0)), DT);      // the chunk's exact sum on the fixed-point grid: k_gemv_rows2's value
+          double dj;
+          if constexpr (WDT == BZ_F32) { double xd[8]; x8_to_d(xa, xb, xd); dj = piece_dot_d<WDT>(w[j], xd, 0.0); }
+          else dj = piece_dot_x<WDT>(w[j], xa, xb, 0.0);
+          accf += d2fix(wave_sum_d(dj), DT);      // the chunk's exact sum on the fixed-point grid: k_gemv_rows2's value
         }
       }
     }
@@ -5473,7 +5772,7 @@ __global__ void k_moe_combine_rows(const float* __restrict__ ye, const int* __re
   const int t = blockIdx.x;
   for (int i = threadIdx.x; i < H; i += blockDim.x) {
     float r = 0.f;
-    for (int k = 0; k < top_k; k++) r += wsel[(size_t)t * top_k + k] * ye[(size_t)row_of[(size_t)t * top_k + k] * H + i];
+    for (int k = 0; k < top_k; k++) r = __fadd_rn(r, __fmul_rn(wsel[(size_t)t * top_k + k], ye[(size_t)row_of[(size_t)t * top_k + k] * H + i]));
     r = round_act(r, act);
     if (ysh) r = round_act(r + round_act(ysh[(size_t)t * H + i], act), act);
     out[(size_t)t * H + i] = r;

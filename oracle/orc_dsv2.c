@@ -109,7 +109,7 @@ int orc_dsv2_forward(const orc_dsv2* m, const int64_t* tokens, int S, orc_mla_ca
   float* q = (float*)malloc(sizeof(float) * (size_t)NH * QH); float* kva = (float*)malloc(sizeof(float) * W);
   float* qa = (float*)malloc(sizeof(float) * (size_t)(c->q_lora_rank > 0 ? c->q_lora_rank : 1));
   float* att = (float*)malloc(sizeof(float) * (size_t)NH * DV);
-  float* qabs = (float*)malloc(sizeof(float) * R); float* olat = (float*)malloc(sizeof(float) * R);
+  float* qabs = (float*)malloc(sizeof(float) * R); float* olat = (float*)malloc(sizeof(float) * R); double* qabsd = (double*)malloc(sizeof(double) * R);
   float* sc = (float*)malloc(sizeof(float) * (size_t)(position + S));
   float* tg = (float*)malloc(sizeof(float) * (size_t)(imax > c->moe_inter ? imax : c->moe_inter)); float* tu = (float*)malloc(sizeof(float) * (size_t)(imax > c->moe_inter ? imax : c->moe_inter));
   float* ye = (float*)malloc(sizeof(float) * H); float* routed = (float*)malloc(sizeof(float) * H);
@@ -146,29 +146,31 @@ int orc_dsv2_forward(const orc_dsv2* m, const int64_t* tokens, int S, orc_mla_ca
         orc_rope_apply(qh + DN, DR, DR, cr, sr, 1); orc_round_vec(qh + DN, (size_t)DR, act);
         const float* Wuk = L->kv_b_f32 + (size_t)hd * (DN + DV) * R;
         const float* Wuv = Wuk + (size_t)DN * R;
-        for (int r = 0; r < R; r++) qabs[r] = 0.0f;
-        for (int d = 0; d < DN; d++) { const float qd = qh[d]; const float* wr = Wuk + (size_t)d * R; for (int r = 0; r < R; r++) qabs[r] += qd * wr[r]; }
-        orc_round_vec(qabs, (size_t)R, act);
+        /* every sum is the exactly rounded one (round 3, as in orc_ops.c / orc_quant.c: products of f32 values are exact in double, the sum is carried in double and
+           rounded to f32 once), so that an implementation's result does not depend on its order of summation */
+        for (int r = 0; r < R; r++) qabsd[r] = 0.0;
+        for (int d = 0; d < DN; d++) { const double qd = (double)qh[d]; const float* wr = Wuk + (size_t)d * R; for (int r = 0; r < R; r++) qabsd[r] += qd * (double)wr[r]; }
+        for (int r = 0; r < R; r++) qabs[r] = orc_round((float)qabsd[r], act);
         float mx = -INFINITY;
         for (int t = 0; t < len; t++) {
           const float* ct = lat + (size_t)t * W;
-          float d0 = 0.0f, d1 = 0.0f;
-          for (int r = 0; r < R; r++) d0 += qabs[r] * ct[r];
-          for (int j = 0; j < DR; j++) d1 += qh[DN + j] * ct[R + j];
-          sc[t] = (d0 + d1) * scale;
+          double d0 = 0.0;
+          for (int r = 0; r < R; r++) d0 += (double)qabs[r] * (double)ct[r];
+          for (int j = 0; j < DR; j++) d0 += (double)qh[DN + j] * (double)ct[R + j];
+          sc[t] = (float)d0 * scale;
           if (sc[t] > mx) mx = sc[t];
         }
-        float sum = 0.0f;
-        for (int t = 0; t < len; t++) { sc[t] = orc_expf(sc[t] - mx); sum += sc[t]; }
-        const float inv = 1.0f / sum;
-        for (int r = 0; r < R; r++) olat[r] = 0.0f;
-        for (int t = 0; t < len; t++) { const float* ct = lat + (size_t)t * W; const float p = sc[t]; for (int r = 0; r < R; r++) olat[r] += p * ct[r]; }
-        for (int r = 0; r < R; r++) olat[r] = orc_round(olat[r] * inv, act);
+        double sumd = 0.0;
+        for (int t = 0; t < len; t++) { sc[t] = orc_expf(sc[t] - mx); sumd += (double)sc[t]; }
+        const float inv = 1.0f / (float)sumd;
+        for (int r = 0; r < R; r++) qabsd[r] = 0.0;
+        for (int t = 0; t < len; t++) { const float* ct = lat + (size_t)t * W; const double p = (double)sc[t]; for (int r = 0; r < R; r++) qabsd[r] += p * (double)ct[r]; }
+        for (int r = 0; r < R; r++) olat[r] = orc_round((float)qabsd[r] * inv, act);
         for (int d = 0; d < DV; d++) {
           const float* wr = Wuv + (size_t)d * R;
-          float a = 0.0f;
-          for (int r = 0; r < R; r++) a += wr[r] * olat[r];
-          att[(size_t)hd * DV + d] = orc_round(a, act);
+          double a = 0.0;
+          for (int r = 0; r < R; r++) a += (double)wr[r] * (double)olat[r];
+          att[(size_t)hd * DV + d] = orc_round((float)a, act);
         }
       }
       orc_linear_forward(&L->o, att, 1, o); orc_round_vec(o, (size_t)H, act);
@@ -203,7 +205,7 @@ int orc_dsv2_forward(const orc_dsv2* m, const int64_t* tokens, int S, orc_mla_ca
     }
   }
   if (kc->seq_len < position + S) kc->seq_len = position + S;
-  free(h); free(xn); free(o); free(q); free(kva); free(qa); free(att); free(qabs); free(olat); free(sc); free(tg); free(tu); free(ye); free(routed);
+  free(h); free(xn); free(o); free(q); free(kva); free(qa); free(att); free(qabs); free(olat); free(qabsd); free(sc); free(tg); free(tu); free(ye); free(routed);
   free(rl); free(sel); free(sw);
   return 0;
 }

@@ -148,3 +148,26 @@ def test_mamba2_steps_are_the_oracle_bit_for_bit(device, preset, over):
     else:
         assert ndiff <= got.size // 1000 and _rel(got, want) <= 1e-4
     orc_py.lib().orc_ssm_state_free(ost)
+
+
+@pytest.mark.parametrize("preset,over", [("tiny-dsv2", {}), ("deepseek-v2-lite", dict(n_layers=3, vocab=4096))], ids=["tiny-bf16", "v2-lite-widths"])
+def test_deepseek_v2_steps_against_the_oracle(device, preset, over):
+    """BASELINE config 4 (DeepSeek-V2, MLA + MoE): exact GEMVs (router and experts included), the exact decode MLA (k_mla_attn_x: double sums, one maximum over the whole
+    context shared by the context slices) and the combine as the oracle's f32 chain -- a 10-token prompt (short prompts stay on the decode kernels) and 8 decode steps"""
+    model = synth.make_dsv2(preset, **over)
+    cfg = model["config"]
+    lm, om = runtime.LoadedModel.from_synth(device, model), orc_py.OrcDsv2(model)
+    p = [int(t) for t in synth.prompt_tokens(10, cfg["vocab"], seed=71)]
+    kv, okc = lm.new_kv_cache(32), om.new_cache(64)
+    got = [lm.forward_with_kv_cache(p, kv, 0, all_logits=True).to_numpy().reshape(10, -1)]
+    want = [om.forward(p, okc, 0, all_logits=True).reshape(10, -1)]
+    tok = int(want[0][-1].argmax())
+    for i in range(8):
+        got.append(lm.forward_with_kv_cache([tok], kv, 10 + i).to_numpy().reshape(1, -1))
+        want.append(om.forward([tok], okc, 10 + i).reshape(1, -1))
+        tok = int(want[-1][0].argmax())
+    got, want = np.concatenate(got), np.concatenate(want)
+    ndiff = int((got != want).sum())
+    print("%s: %d of %d logits differ, rel L2 %.2e" % (preset, ndiff, got.size, _rel(got, want)))
+    assert ndiff <= got.size // 1000 and _rel(got, want) <= 1e-4
+    orc_py.lib().orc_mla_cache_free(okc)
