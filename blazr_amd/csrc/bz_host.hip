@@ -295,6 +295,7 @@ struct bz_model {
   std::recursive_mutex mu;
   std::vector<DsLayerDev> dlayers;
   float* mla_ws = nullptr; int mla_nsplit = 1;   // MLA decode over context slices: partials [n_heads][nsplit][rank + 2]
+  float* mla_scw = nullptr; float* mla_mxw = nullptr;        // exact decode MLA, three-launch form: scores [n_heads][nsplit][ceil(max_seq_len / nsplit) + 1], slice maxima [n_heads][nsplit]
   double* mla_wsd = nullptr; unsigned* mla_sync = nullptr;   // exact decode MLA (k_mla_attn_x): double partials [n_heads][nsplit][rank + 1]; per-head {maximum, arrivals} words
   long long* moe_gu_acc = nullptr;   // fixed-point gate / up of the MoE slots (k_gemv_rows2's MoE form); zeroed by the combine launch
   float* moe_xn = nullptr; float* moe_gu = nullptr; float* moe_out = nullptr; long long* moe_acc = nullptr; int* moe_sel = nullptr; float* moe_w = nullptr; float* moe_lg = nullptr; unsigned* moe_cnt = nullptr;
@@ -1113,6 +1114,8 @@ static int finalize_dsv2(bz_model* m) {
   BZ_TRY(dev_alloc(m, &p, (size_t)NH * m->mla_nsplit * (R + 2) * 4)); m->mla_ws = (float*)p;
   BZ_TRY(dev_alloc(m, &p, (size_t)NH * m->mla_nsplit * (R + 1) * 8)); m->mla_wsd = (double*)p;
   BZ_TRY(dev_alloc(m, &p, (size_t)(2 * NH + 2) * 4)); m->mla_sync = (unsigned*)p; BZ_HIP(hipMemset(p, 0, (size_t)(2 * NH + 2) * 4));
+  BZ_TRY(dev_alloc(m, &p, (size_t)NH * m->mla_nsplit * ((c.max_seq_len + m->mla_nsplit - 1) / m->mla_nsplit + 1) * 4)); m->mla_scw = (float*)p;
+  BZ_TRY(dev_alloc(m, &p, (size_t)NH * m->mla_nsplit * 4)); m->mla_mxw = (float*)p;
   BZ_TRY(dev_alloc(m, &p, (size_t)V * 4)); m->logits = (float*)p;
   if (E > 0) {
     BZ_TRY(dev_alloc(m, &p, (size_t)H * 4)); m->moe_xn = (float*)p;
@@ -1753,7 +1756,7 @@ static int dsv2_step(bz_model* m, const StepIO& io) {
     ma.ws = m->mla_ws; ma.nsplit = m->mla_nsplit;
     // exact decode (16-bit models): every sum as the oracle defines it, one maximum over the whole context (BZ_DSV2_F32_SUMS=1: the f32 kernels)
     static const bool f32_mla = getenv("BZ_DSV2_F32_SUMS") != nullptr;
-    if (!f32_mla && (act == BZ_F16 || act == BZ_BF16) && bzk_mla_x_ok(ma, c.max_seq_len)) BZ_TRY(bzk_mla_attn_x(st, ma, c.max_seq_len, m->mla_wsd, m->mla_sync, (unsigned*)m->dev->persist_err));
+    if (!f32_mla && (act == BZ_F16 || act == BZ_BF16) && bzk_mla_x_ok(ma, c.max_seq_len)) BZ_TRY(bzk_mla_attn_x(st, ma, c.max_seq_len, m->mla_wsd, m->mla_sync, (unsigned*)m->dev->persist_err, m->mla_scw, m->mla_mxw));
     else BZ_TRY(bzk_mla_attn(st, ma, c.max_seq_len));
     Pro pp{}; pp.mode = PRO_PLAIN; pp.src = VSrc{m->attn_out, 0}; pp.act = act; pp.H = 0; pp.f32_sums = 0;
     VSrc ov;

@@ -311,7 +311,7 @@ struct MlaArgs {
 int bzk_mla_nsplit(int n_heads);
 // exact decode MLA (bz_kernels.hip k_mla_attn_x / k_mla_merge_x): wsd = n_heads * nsplit * (rank + 1) doubles, sync = 2 * n_heads words (zero), err = one word
 bool bzk_mla_x_ok(const MlaArgs& a, int max_len);
-int bzk_mla_attn_x(hipStream_t s, const MlaArgs& a, int max_len, double* wsd, unsigned* sync, unsigned* err);
+int bzk_mla_attn_x(hipStream_t s, const MlaArgs& a, int max_len, double* wsd, unsigned* sync, unsigned* err, float* scw = nullptr, float* mxw = nullptr);   // scw: n_heads * nsplit * (ceil(max_len / nsplit) + 1) floats, mxw: n_heads * nsplit (three-launch form)
 // prompt rows: latent RMSNorm + k_pe RoPE of rows s = 0 .. S-1 (source row s at kva + s * stride), appended to the cache at position pos0 + s
 int bzk_mla_append_rows(hipStream_t s, const float* kva, long long stride, int S, const float* kv_norm, float eps, int rank, int rope, const float* cos_t, const float* sin_t,
                         int pos0, int act, const KvView& kv, int layer);

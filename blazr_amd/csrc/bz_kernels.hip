@@ -5082,6 +5082,197 @@ __global__ __launch_bounds__(1024) void k_mla_attn_x(MlaArgs a, double* __restri
   }
   if (tid == 0) wsp[R] = psum;
 }
+template <int DT>
+__global__ __launch_bounds__(1024) void k_mla_scores_x(MlaArgs a, float* __restrict__ scw, float* __restrict__ mxw, int SCS) {
+  constexpr int NW = 16, NTH = 1024, RIF = 8, TIF = 4;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int R = a.rank, DN = a.nope, DR = a.rope;
+  float* ccur = lds; float* kcur = ccur + R; float* qn = kcur + DR; float* qp = qn + DN; float* qabs = qp + DR;
+  double* partd = (double*)(qabs + R + ((2 * R + 2 * DR + DN) & 1));      // [NW][R], 8-byte aligned
+  double* redd = partd + NW * R;                                            // [NW]
+  float* red = (float*)(redd + NW); float* sc = red + 16;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hd = blockIdx.x;
+  const int pos = a.pos[0], nc = pos;               // cached positions 0 .. pos - 1; the current token comes from LDS
+  const int ts = (nc + a.nsplit - 1) / a.nsplit;
+  const int tlo = min((int)blockIdx.y * ts, nc), thi = min(tlo + ts, nc);
+  const bool own_cur = (int)blockIdx.y == a.nsplit - 1;
+  const int nloc = thi - tlo + (own_cur ? 1 : 0);
+  const int QH = DN + DR, qoff = hd * QH, coff = a.n_heads * QH;
+  auto qsrc = [&](int i) -> float { return vsrc_get(a.qkv, i, a.act); };
+  auto csrc = [&](int i) -> float { return a.kva ? a.kva[i] : vsrc_get(a.qkv, coff + i, a.act); };
+  const size_t rowbase = (size_t)a.layer * a.kv.layer_stride;
+  const int Wd = R + DR;
+  auto rowoff = [&](int p) -> size_t {
+    if (a.kv.paged) return rowbase + ((size_t)a.kv.block_table[p / a.kv.bs] * a.kv.bs + (p % a.kv.bs)) * Wd;
+    return rowbase + (size_t)p * Wd;
+  };
+  const size_t wrow0 = (size_t)hd * (DN + a.vdim);
+  const int col = lane * 8;
+  const bool con = col < R;
+  const int colc = con ? col : 0;
+  // ---- qabs partials first (weights only depend on the head): wave w takes nope rows [w DN/16, (w+1) DN/16) ----
+  const int d0 = wave * (DN / NW), d1 = d0 + DN / NW;
+  float w0[RIF][8];
+#pragma unroll
+  for (int u = 0; u < RIF; u++) ld8t<DT>(a.wkvb, (wrow0 + (size_t)min(d0 + u, d1 - 1)) * R + colc, w0[u]);
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- current token: latent norm (exact sum of squares), k_pe / q_pe rope, q_nope ----
+  const float* cr = a.cos_t + (size_t)pos * (DR / 2); const float* sr = a.sin_t + (size_t)pos * (DR / 2);
+  {
+    double ssd = 0.0;
+    for (int r = tid; r < R; r += NTH) { const float v = csrc(r); ccur[r] = v; ssd += (double)__fmul_rn(v, v); }
+    ssd = block_sum_nw_d<NW>(ssd, redd);
+    const float rs = rms_scale((float)ssd, (float)R, a.eps);
+    for (int r = tid; r < R; r += NTH) ccur[r] = round_act(__fmul_rn(a.kv_norm[r], round_act(__fmul_rn(ccur[r], rs), a.act)), a.act);
+  }
+  for (int j = tid; j < DR / 2; j += NTH) {
+    const float c = cr[j], s = sr[j];
+    const float k0 = csrc(R + 2 * j), k1 = csrc(R + 2 * j + 1);
+    kcur[2 * j] = round_act(rope_lo(k0, k1, c, s), a.act); kcur[2 * j + 1] = round_act(rope_hi(k0, k1, c, s), a.act);
+    const float x0 = qsrc(qoff + DN + 2 * j), x1 = qsrc(qoff + DN + 2 * j + 1);
+    qp[2 * j] = round_act(rope_lo(x0, x1, c, s), a.act); qp[2 * j + 1] = round_act(rope_hi(x0, x1, c, s), a.act);
+  }
+  for (int d = tid; d < DN; d += NTH) qn[d] = qsrc(qoff + d);
+  __syncthreads();
+  if (hd == 0 && blockIdx.y == 0) {
+    size_t wo;
+    if (a.kv.paged) { const int slot = a.kv.slot ? a.kv.slot[0] : (a.kv.block_table[pos / a.kv.bs] * a.kv.bs + pos % a.kv.bs); wo = rowbase + (size_t)slot * Wd; }
+    else wo = rowbase + (size_t)pos * Wd;
+    for (int i = tid; i < Wd; i += NTH) kv_st(a.kv.k, wo + i, a.kv.dtype, i < R ? ccur[i] : kcur[i - R]);
+  }
+  {
+    double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};      // 16-bit q x 16-bit weight: the f32 product is exact, the double carries the sum
+    for (int d = d0; d < d1; d += RIF) {
+      if (d > d0) {
+#pragma unroll
+        for (int u = 0; u < RIF; u++) ld8t<DT>(a.wkvb, (wrow0 + (size_t)min(d + u, d1 - 1)) * R + colc, w0[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < RIF; u++) {
+        const float qd = (d + u < d1) ? qn[d + u] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; e++) acc[e] += (double)__fmul_rn(qd, w0[u][e]);
+      }
+    }
+    if (con)
+#pragma unroll
+      for (int e = 0; e < 8; e++) partd[wave * R + colc + e] = acc[e];
+  }
+  __syncthreads();
+  for (int r = tid; r < R; r += NTH) {
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) t += partd[w * R + r];
+    qabs[r] = round_act((float)t, a.act);
+  }
+  __syncthreads();
+  // ---- scores: wave w takes cached tokens tlo + w, + 16, ...; exact sums (f32 products of 16-bit values are exact) ----
+  float qa[8];
+  const float qpl = (lane < DR) ? qp[lane] : 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; e++) qa[e] = con ? qabs[colc + e] : 0.f;
+  for (int t0 = tlo + wave; t0 < thi; t0 += NW * TIF) {
+    float cv[TIF][8], kp[TIF];
+#pragma unroll
+    for (int u = 0; u < TIF; u++) {
+      const size_t ro = rowoff(min(t0 + NW * u, thi - 1));
+      ld8t<DT>(a.kv.k, ro + colc, cv[u]);
+      kp[u] = ld1t<DT>(a.kv.k, ro + R + min(lane, DR - 1));
+    }
+#pragma unroll
+    for (int u = 0; u < TIF; u++) {
+      double dsum = (lane < DR) ? (double)__fmul_rn(qpl, kp[u]) : 0.0;
+#pragma unroll
+      for (int e = 0; e < 8; e++) dsum += (double)__fmul_rn(qa[e], cv[u][e]);
+      dsum = wave_sum_d(dsum);
+      if (lane == 0 && t0 + NW * u < thi) sc[t0 + NW * u - tlo] = __fmul_rn((float)dsum, a.scale);
+    }
+  }
+  if (own_cur && wave == 0) {
+    double dsum = (lane < DR) ? (double)__fmul_rn(qpl, kcur[lane]) : 0.0;
+    if (con)
+#pragma unroll
+      for (int e = 0; e < 8; e++) dsum += (double)__fmul_rn(qa[e], ccur[colc + e]);
+    dsum = wave_sum_d(dsum);
+    if (lane == 0) sc[thi - tlo] = __fmul_rn((float)dsum, a.scale);
+  }
+  __syncthreads();
+  // ---- this slice's scores and their maximum go to the workspace: the weights need the maximum over ALL slices (k_mla_weights_x, after the kernel boundary) ----
+  float mx = -INFINITY;
+  for (int t = tid; t < nloc; t += NTH) { const float v = sc[t]; mx = fmaxf(mx, v); scw[((size_t)hd * a.nsplit + blockIdx.y) * SCS + t] = v; }
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  if (tid == 0) {
+    float m2 = red[0];
+#pragma unroll
+    for (int w = 1; w < NW; w++) m2 = fmaxf(m2, red[w]);
+    mxw[hd * a.nsplit + blockIdx.y] = m2;
+  }
+}
+// second launch of the three-launch exact form: p_t = exp(s_t - M) with M over all slices, partial weight sum and partial latent sum (double) of this slice
+template <int DT>
+__global__ __launch_bounds__(1024) void k_mla_weights_x(MlaArgs a, const float* __restrict__ scw, const float* __restrict__ mxw, int SCS, double* __restrict__ wsd) {
+  constexpr int NW = 16, NTH = 1024, TIF = 4;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int R = a.rank, DR = a.rope;
+  double* partd = (double*)lds;                 // [NW][R]
+  double* redd = partd + NW * R;                // [NW]
+  float* sc = (float*)(redd + NW);              // [nloc]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hd = blockIdx.x;
+  const int pos = a.pos[0], nc = pos;
+  const int ts = (nc + a.nsplit - 1) / a.nsplit;
+  const int tlo = min((int)blockIdx.y * ts, nc), thi = min(tlo + ts, nc);
+  const bool own_cur = (int)blockIdx.y == a.nsplit - 1;
+  const int nloc = thi - tlo + (own_cur ? 1 : 0);
+  const size_t rowbase = (size_t)a.layer * a.kv.layer_stride;
+  const int Wd = R + DR;
+  auto rowoff = [&](int p) -> size_t {
+    if (a.kv.paged) return rowbase + ((size_t)a.kv.block_table[p / a.kv.bs] * a.kv.bs + (p % a.kv.bs)) * Wd;
+    return rowbase + (size_t)p * Wd;
+  };
+  const int col = lane * 8;
+  const bool con = col < R;
+  const int colc = con ? col : 0;
+  float M = -INFINITY;
+  for (int s0 = 0; s0 < a.nsplit; s0++) M = fmaxf(M, mxw[hd * a.nsplit + s0]);      // (uniform loads: the same nsplit words for every lane)
+  double psum = 0.0;
+  for (int t = tid; t < nloc; t += NTH) { const float pe = bz_expf(scw[((size_t)hd * a.nsplit + blockIdx.y) * SCS + t] - M); sc[t] = pe; psum += (double)pe; }
+  psum = block_sum_nw_d<NW>(psum, redd);         // (its barriers also publish sc)
+  {
+    double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    const int tend = thi + (own_cur ? 1 : 0);     // the current token's row is in the cache (written by the scores launch)
+    for (int t0 = tlo + wave; t0 < tend; t0 += NW * TIF) {
+      float cv[TIF][8];
+#pragma unroll
+      for (int u = 0; u < TIF; u++) {
+        const int pp = min(t0 + NW * u, tend - 1);
+        size_t ro;
+        if (pp == pos && a.kv.paged) { const int slot = a.kv.slot ? a.kv.slot[0] : (a.kv.block_table[pos / a.kv.bs] * a.kv.bs + pos % a.kv.bs); ro = rowbase + (size_t)slot * Wd; }
+        else ro = rowoff(pp);
+        ld8t<DT>(a.kv.k, ro + colc, cv[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < TIF; u++) {
+        const double pw = (t0 + NW * u < tend) ? (double)sc[t0 + NW * u - tlo] : 0.0;
+#pragma unroll
+        for (int e = 0; e < 8; e++) acc[e] = fma(pw, (double)cv[u][e], acc[e]);
+      }
+    }
+    if (con)
+#pragma unroll
+      for (int e = 0; e < 8; e++) partd[wave * R + colc + e] = acc[e];
+  }
+  __syncthreads();
+  double* wsp = wsd + ((size_t)hd * a.nsplit + blockIdx.y) * (R + 1);
+  for (int r = tid; r < R; r += NTH) {
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) t += partd[w * R + r];
+    wsp[r] = t;
+  }
+  if (tid == 0) wsp[R] = psum;
+}
 // merge of the exact partials + Wuv: grid = (n_heads, 4); olat_h = R(f32(sum_s part_s) / f32(sum_s l_s)), out_h = R(f32(Wuv_h . olat_h)); workgroup (h, 0) resets the head's sync words
 template <int DT>
 __global__ __launch_bounds__(256) void k_mla_merge_x(MlaArgs a, const double* __restrict__ wsd, unsigned* __restrict__ sync) {
@@ -5146,14 +5337,23 @@ bool bzk_mla_x_ok(const MlaArgs& a, int max_len) {
          (a.wdt == BZ_F16 || a.wdt == BZ_BF16) && a.wdt == a.kv.dtype && bzk_mla_x_smem(a, max_len) <= 160 * 1024;
 }
 // exact decode MLA: wsd = n_heads * nsplit * (rank + 1) doubles, sync = 2 * n_heads zeroed words (+ err word)
-int bzk_mla_attn_x(hipStream_t s, const MlaArgs& a, int max_len, double* wsd, unsigned* sync, unsigned* err) {
+int bzk_mla_attn_x(hipStream_t s, const MlaArgs& a, int max_len, double* wsd, unsigned* sync, unsigned* err, float* scw, float* mxw) {
   if (!bzk_mla_x_ok(a, max_len)) BZ_FAIL(BZ_E_UNSUPPORTED, "mla_attn_x: shape not supported by the exact decode kernel");
   const size_t smem = bzk_mla_x_smem(a, max_len);
+  const int SCS = (max_len + a.nsplit - 1) / a.nsplit + 1;             // scores per (head, slice) in the workspace
+  const size_t smem_w = (size_t)(16 * a.rank + 16) * 8 + (size_t)SCS * 4 + 64;
   const double bytes = (double)a.n_heads * (a.nope + a.vdim) * a.rank * bz_dtype_size(a.wdt);
+  // one launch with the slices waiting for each other's maxima (BZ_MLA_X_WAIT=1), or three launches (scores + slice maxima | weights + partial sums | merge): the
+  // wait is a device word polled from a CU with loads in flight (13 us on V2-Lite), the extra kernel boundary costs less
+  static const bool wait_form = getenv("BZ_MLA_X_WAIT") != nullptr;
 #define LAUNCH_MX(DT) do { \
     static bool attr_done = false; \
-    if (!attr_done) { BZ_HIP(hipFuncSetAttribute((const void*)k_mla_attn_x<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_done = true; } \
-    BZ_LAUNCH("mla_attn<split,exact>", bytes, (k_mla_attn_x<DT>), dim3(a.n_heads, a.nsplit), dim3(1024), smem, s, a, wsd, sync, err); \
+    if (!attr_done) { BZ_HIP(hipFuncSetAttribute((const void*)k_mla_attn_x<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+                      BZ_HIP(hipFuncSetAttribute((const void*)k_mla_scores_x<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+                      BZ_HIP(hipFuncSetAttribute((const void*)k_mla_weights_x<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_done = true; } \
+    if (wait_form || !scw) BZ_LAUNCH("mla_attn<split,exact>", bytes, (k_mla_attn_x<DT>), dim3(a.n_heads, a.nsplit), dim3(1024), smem, s, a, wsd, sync, err); \
+    else { BZ_LAUNCH("mla_scores<exact>", bytes * a.nope / (a.nope + a.vdim), (k_mla_scores_x<DT>), dim3(a.n_heads, a.nsplit), dim3(1024), smem, s, a, scw, mxw, SCS); \
+           BZ_LAUNCH("mla_weights<exact>", 0.0, (k_mla_weights_x<DT>), dim3(a.n_heads, a.nsplit), dim3(1024), smem_w, s, a, (const float*)scw, (const float*)mxw, SCS, wsd); } \
     BZ_LAUNCH("mla_merge<exact>", bytes * a.vdim / (a.nope + a.vdim), (k_mla_merge_x<DT>), dim3(a.n_heads, 4), dim3(256), 0, s, a, (const double*)wsd, sync); } while (0)
   if (a.wdt == BZ_F16) LAUNCH_MX(BZ_F16); else LAUNCH_MX(BZ_BF16);
 #undef LAUNCH_MX
